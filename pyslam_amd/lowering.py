@@ -1,0 +1,346 @@
+"""Lower a ``Problem`` object graph into flat SoA tables for the HIP core.
+
+The reference keeps one Python object per residual block and per parameter
+(reference pyslam/problem.py:43-108) and walks them every iteration
+(problem.py:279-360).  Here the walk happens ONCE, at ``solve()`` time: blocks
+are dispatched on their ``KIND`` tag into typed tables that are uploaded to
+HBM and stay resident for the whole Gauss-Newton loop (SURVEY.md section 7,
+step 2).  ``LoweredProblem`` is also what the synthetic generators emit
+directly (pyslam_amd/synthetic.py), so the benchmark never builds 500 k Python
+objects.
+
+Table layout (all fp64 / int32, C-contiguous):
+
+* ``poses``      (P, 12) SE(3): R row-major (9) | t (3);  (P, 6) SE(2): R (4) | t (2)
+* ``pose_rid``   (P,)  index into the reduced (Schur) system, -1 = held constant
+* ``points``     (L, 3) landmarks;  ``point_vid`` (L,) variable index, -1 = constant
+* ``obs_*``      reprojection observations: pose idx, point idx, (u,v,d), group idx
+* ``obs_groups`` (G, 4) [camera idx, stiffness idx, loss id, loss k]
+* ``e_*``        binary pose-pose edges: i, j, T_obs^-1 (same packing as poses), group idx
+* ``u_*``        unary pose priors:      i,    T_obs^-1,                        group idx
+* ``edge_groups``(G, 3) [stiffness idx, loss id, loss k]
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from pyslam_amd.liegroups import SE2, SE3
+from pyslam_amd import losses as _losses
+
+F64 = np.float64
+I32 = np.int32
+
+
+def _f(a, shape):
+    return np.ascontiguousarray(np.asarray(a, dtype=F64).reshape(shape))
+
+
+def _i(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=I32).reshape(-1))
+
+
+@dataclass
+class LoweredProblem:
+    dof: int = 6
+    poses: np.ndarray = None
+    pose_rid: np.ndarray = None
+    points: np.ndarray = None
+    point_vid: np.ndarray = None
+    obs_pose: np.ndarray = None
+    obs_point: np.ndarray = None
+    obs_uvd: np.ndarray = None
+    obs_grp: np.ndarray = None
+    cams: np.ndarray = None
+    stiff3: np.ndarray = None
+    obs_groups: np.ndarray = None
+    e_i: np.ndarray = None
+    e_j: np.ndarray = None
+    e_Tobs_inv: np.ndarray = None
+    e_grp: np.ndarray = None
+    u_i: np.ndarray = None
+    u_Tobs_inv: np.ndarray = None
+    u_grp: np.ndarray = None
+    stiffd: np.ndarray = None
+    edge_groups: np.ndarray = None
+    pose_keys: list = field(default_factory=list)
+    point_keys: list = field(default_factory=list)
+
+    # ---- derived sizes -------------------------------------------------
+    @property
+    def pose_width(self):
+        return 12 if self.dof == 6 else 6
+
+    @property
+    def num_poses(self):
+        return 0 if self.poses is None else self.poses.shape[0]
+
+    @property
+    def num_points(self):
+        return 0 if self.points is None else self.points.shape[0]
+
+    @property
+    def num_obs(self):
+        return 0 if self.obs_pose is None else self.obs_pose.shape[0]
+
+    @property
+    def num_edges(self):
+        return 0 if self.e_i is None else self.e_i.shape[0]
+
+    @property
+    def num_priors(self):
+        return 0 if self.u_i is None else self.u_i.shape[0]
+
+    @property
+    def num_reduced(self):
+        return int((self.pose_rid >= 0).sum()) if self.num_poses else 0
+
+    @property
+    def num_var_points(self):
+        return int((self.point_vid >= 0).sum()) if self.num_points else 0
+
+    def finalize(self):
+        """Fill absent tables with empty arrays of the right width / dtype."""
+        d, pw = self.dof, self.pose_width
+        self.poses = _f(self.poses if self.poses is not None else [], (-1, pw))
+        self.pose_rid = _i(self.pose_rid if self.pose_rid is not None else [])
+        self.points = _f(self.points if self.points is not None else [], (-1, 3))
+        self.point_vid = _i(self.point_vid if self.point_vid is not None else [])
+        self.obs_pose = _i(self.obs_pose if self.obs_pose is not None else [])
+        self.obs_point = _i(self.obs_point if self.obs_point is not None else [])
+        self.obs_uvd = _f(self.obs_uvd if self.obs_uvd is not None else [], (-1, 3))
+        self.obs_grp = _i(self.obs_grp if self.obs_grp is not None else
+                          np.zeros(self.obs_pose.shape[0]))
+        self.cams = _f(self.cams if self.cams is not None else [], (-1, 5))
+        self.stiff3 = _f(self.stiff3 if self.stiff3 is not None else [], (-1, 9))
+        self.obs_groups = _f(self.obs_groups if self.obs_groups is not None else [], (-1, 4))
+        self.e_i = _i(self.e_i if self.e_i is not None else [])
+        self.e_j = _i(self.e_j if self.e_j is not None else [])
+        self.e_Tobs_inv = _f(self.e_Tobs_inv if self.e_Tobs_inv is not None else [], (-1, pw))
+        self.e_grp = _i(self.e_grp if self.e_grp is not None else np.zeros(self.e_i.shape[0]))
+        self.u_i = _i(self.u_i if self.u_i is not None else [])
+        self.u_Tobs_inv = _f(self.u_Tobs_inv if self.u_Tobs_inv is not None else [], (-1, pw))
+        self.u_grp = _i(self.u_grp if self.u_grp is not None else np.zeros(self.u_i.shape[0]))
+        self.stiffd = _f(self.stiffd if self.stiffd is not None else [], (-1, d * d))
+        self.edge_groups = _f(self.edge_groups if self.edge_groups is not None else [], (-1, 3))
+        self.validate()
+        return self
+
+    def validate(self):
+        P, L = self.num_poses, self.num_points
+        assert self.dof in (3, 6)
+        assert self.pose_rid.shape == (P,) and self.point_vid.shape == (L,)
+        for idx, hi in ((self.obs_pose, P), (self.e_i, P), (self.e_j, P), (self.u_i, P),
+                        (self.obs_point, L)):
+            if idx.size:
+                assert idx.min() >= 0 and idx.max() < hi, "index out of range"
+        if self.num_obs:
+            assert self.dof == 6, "reprojection residuals need SE(3) poses"
+            assert self.obs_grp.max() < self.obs_groups.shape[0]
+        if self.num_edges:
+            assert self.e_grp.max() < self.edge_groups.shape[0]
+        if self.num_priors:
+            assert self.u_grp.max() < self.edge_groups.shape[0]
+
+    def copy(self):
+        out = LoweredProblem()
+        for k, v in self.__dict__.items():
+            setattr(out, k, v.copy() if isinstance(v, np.ndarray) else
+                    (list(v) if isinstance(v, list) else v))
+        return out
+
+
+# ---------------------------------------------------------------------------
+# pose packing
+# ---------------------------------------------------------------------------
+def pack_pose(T):
+    """liegroups SE2/SE3 -> flat row [R row-major | t]."""
+    return np.concatenate([np.asarray(T.rot.mat, dtype=F64).ravel(),
+                           np.asarray(T.trans, dtype=F64).ravel()])
+
+
+def pack_pose_matrix(M):
+    """(d+1,d+1) homogeneous matrix -> flat row."""
+    n = M.shape[0] - 1
+    return np.concatenate([M[:n, :n].ravel(), M[:n, n]])
+
+
+def pack_pose_matrices(Ms):
+    Ms = np.asarray(Ms, dtype=F64)
+    n = Ms.shape[1] - 1
+    return np.concatenate([Ms[:, :n, :n].reshape(len(Ms), n * n), Ms[:, :n, n]], axis=1)
+
+
+def unpack_pose(row, dof):
+    """flat row -> (R, t) numpy views (copied)."""
+    n = 3 if dof == 6 else 2
+    return np.array(row[:n * n]).reshape(n, n), np.array(row[n * n:n * n + n])
+
+
+def pose_rows_to_matrices(rows, dof):
+    rows = np.asarray(rows, dtype=F64)
+    n = 3 if dof == 6 else 2
+    out = np.tile(np.identity(n + 1), (rows.shape[0], 1, 1))
+    out[:, :n, :n] = rows[:, :n * n].reshape(-1, n, n)
+    out[:, :n, n] = rows[:, n * n:]
+    return out
+
+
+# ---------------------------------------------------------------------------
+# object graph -> LoweredProblem
+# ---------------------------------------------------------------------------
+class NotLowerable(Exception):
+    """Raised when a problem contains blocks/parameters with no typed device
+    kernel; Problem then takes the host-evaluated generic path."""
+
+
+class _Interner:
+    """Small table of distinct rows keyed by the identity / bytes of the source."""
+
+    def __init__(self):
+        self.rows, self._by_key = [], {}
+
+    def add(self, row, key=None):
+        row = np.ascontiguousarray(np.asarray(row, dtype=F64).ravel())
+        key = row.tobytes() if key is None else key
+        idx = self._by_key.get(key)
+        if idx is None:
+            idx = len(self.rows)
+            self.rows.append(row)
+            self._by_key[key] = idx
+        return idx
+
+    def table(self, width):
+        return (np.stack(self.rows) if self.rows else np.zeros((0, width))).reshape(-1, width)
+
+
+def _loss_id_k(loss):
+    lid = getattr(loss, 'LOSS_ID', None)
+    if lid is None:
+        raise NotLowerable("loss {} has no device restatement".format(type(loss).__name__))
+    return float(lid), float(getattr(loss, 'k', 0.))
+
+
+def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
+          constant_param_keys):
+    """Build a LoweredProblem from the registries of a Problem."""
+    const = set(constant_param_keys)
+    pose_keys, point_keys, pose_ix, point_ix = [], [], {}, {}
+    dof = None
+    for key, val in param_dict.items():
+        if isinstance(val, (SE3, SE2)):
+            d = val.dof
+            if dof is None:
+                dof = d
+            elif dof != d:
+                raise NotLowerable("mixed SE(2)/SE(3) poses")
+            pose_ix[key] = len(pose_keys)
+            pose_keys.append(key)
+        elif isinstance(val, np.ndarray) and val.shape == (3,):
+            point_ix[key] = len(point_keys)
+            point_keys.append(key)
+        else:
+            raise NotLowerable("parameter {!r} is neither an SE2/SE3 pose nor a 3-vector".format(key))
+    if dof is None:
+        dof = 6
+
+    lp = LoweredProblem(dof=dof, pose_keys=pose_keys, point_keys=point_keys)
+    pw = lp.pose_width
+    poses = np.zeros((len(pose_keys), pw))
+    for k, i in pose_ix.items():
+        poses[i] = pack_pose(param_dict[k])
+    points = [np.asarray(param_dict[k], dtype=F64) for k in point_keys]
+    fixed_points = []          # motion-only points appended after the landmarks
+
+    rid, n = np.full(len(pose_keys), -1, dtype=I32), 0
+    for k in pose_keys:
+        if k not in const:
+            rid[pose_ix[k]] = n
+            n += 1
+    vid, n = [], 0
+    for k in point_keys:
+        if k in const:
+            vid.append(-1)
+        else:
+            vid.append(n)
+            n += 1
+
+    cams, st3, std = _Interner(), _Interner(), _Interner()
+    ogrp, egrp = _Interner(), _Interner()
+    o_pose, o_pt, o_uvd, o_g = [], [], [], []
+    e_i, e_j, e_T, e_g = [], [], [], []
+    u_i, u_T, u_g = [], [], []
+    L0 = len(point_keys)
+    ogrp_cache, egrp_cache = {}, {}   # keyed by object identity: O(1) per block
+
+    for block, keys, loss in zip(residual_blocks, block_param_keys, block_loss_functions):
+        kind = getattr(block, 'KIND', 'generic')
+        for k in keys:
+            if k not in param_dict:
+                raise KeyError(k)
+        lid, lk = _loss_id_k(loss)   # cheap attribute reads
+        if kind in ('reproj', 'reproj_motion_only', 'reproj_motion_only_batch'):
+            cam = block.camera
+            if getattr(cam, 'CAMERA_ID', None) != 0:
+                raise NotLowerable("camera {} has no device restatement".format(type(cam).__name__))
+            if dof != 6 or keys[0] not in pose_ix:
+                raise NotLowerable("reprojection block needs an SE(3) pose first")
+            gkey = (id(cam), id(block.stiffness), id(loss))
+            g = ogrp_cache.get(gkey)
+            if g is None:
+                if np.size(block.stiffness) != 9:
+                    raise NotLowerable("reprojection stiffness must be 3x3")
+                g = ogrp.add([cams.add(cam.intrinsics()), st3.add(block.stiffness), lid, lk])
+                ogrp_cache[gkey] = g
+            if kind == 'reproj':
+                if keys[1] not in point_ix:
+                    raise NotLowerable("reprojection block needs a 3-vector landmark second")
+                o_pose.append(pose_ix[keys[0]])
+                o_pt.append(point_ix[keys[1]])
+                o_uvd.append(np.asarray(block.obs, dtype=F64))
+                o_g.append(g)
+            else:
+                pts = np.atleast_2d(block.pt_1 if kind == 'reproj_motion_only' else block.pts_1)
+                obs2 = np.atleast_2d(np.asarray(block.obs_2, dtype=F64))
+                for p, o in zip(pts, obs2):
+                    o_pose.append(pose_ix[keys[0]])
+                    o_pt.append(L0 + len(fixed_points))
+                    fixed_points.append(np.asarray(p, dtype=F64))
+                    o_uvd.append(o)
+                    o_g.append(g)
+        elif kind in ('pose_pose', 'pose_prior'):
+            if any(k not in pose_ix for k in keys):
+                raise NotLowerable("pose block on a non-pose parameter")
+            if block.obstype.dof != dof:
+                raise NotLowerable("observation group differs from the pose group")
+            obs = block.T_2_1_obs if kind == 'pose_pose' else block.T_obs
+            gkey = (id(block.stiffness), id(loss))
+            g = egrp_cache.get(gkey)
+            if g is None:
+                if np.size(block.stiffness) != dof * dof:
+                    raise NotLowerable("pose stiffness must be dof x dof")
+                g = egrp.add([std.add(block.stiffness), lid, lk])
+                egrp_cache[gkey] = g
+            if kind == 'pose_pose':
+                e_i.append(pose_ix[keys[0]])
+                e_j.append(pose_ix[keys[1]])
+                e_T.append(pack_pose(obs.inv()))
+                e_g.append(g)
+            else:
+                u_i.append(pose_ix[keys[0]])
+                u_T.append(pack_pose(obs.inv()))
+                u_g.append(g)
+        else:
+            raise NotLowerable("block {} has no typed device kernel".format(type(block).__name__))
+
+    lp.poses, lp.pose_rid = poses, rid
+    lp.points = np.array(points + fixed_points).reshape(-1, 3)
+    lp.point_vid = np.array(vid + [-1] * len(fixed_points), dtype=I32)
+    lp.obs_pose, lp.obs_point, lp.obs_grp = o_pose, o_pt, o_g
+    lp.obs_uvd = np.array(o_uvd).reshape(-1, 3)
+    lp.cams, lp.stiff3, lp.obs_groups = cams.table(5), st3.table(9), ogrp.table(4)
+    lp.e_i, lp.e_j, lp.e_grp = e_i, e_j, e_g
+    lp.e_Tobs_inv = np.array(e_T).reshape(-1, pw)
+    lp.u_i, lp.u_grp = u_i, u_g
+    lp.u_Tobs_inv = np.array(u_T).reshape(-1, pw)
+    lp.stiffd, lp.edge_groups = std.table(dof * dof), egrp.table(3)
+    return lp.finalize()

@@ -1,0 +1,13 @@
+"""Residual blocks (explicit re-exports of every name the reference's
+pkgutil walk would surface, pyslam/residuals/__init__.py:1-14).
+PhotometricResidualSE3 is out of scope (dense image alignment)."""
+from .pose import PoseResidual, PoseToPoseResidual, PoseToPoseOrientationResidual
+from .reprojection import (ReprojectionResidual, ReprojectionMotionOnlyResidual,
+                           ReprojectionMotionOnlyBatchResidual,
+                           ReprojectionResidualFrameToFrame)
+from .quadratic import QuadraticResidual
+
+__all__ = ["PoseResidual", "PoseToPoseResidual", "PoseToPoseOrientationResidual",
+           "ReprojectionResidual", "ReprojectionMotionOnlyResidual",
+           "ReprojectionMotionOnlyBatchResidual", "ReprojectionResidualFrameToFrame",
+           "QuadraticResidual"]
