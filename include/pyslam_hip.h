@@ -1,0 +1,168 @@
+/*
+ * pyslam_hip.h -- C ABI of the MI355X-native Gauss-Newton / LM core.
+ *
+ * The reference (utiasSTARS/pyslam) has no native or FFI boundary: its hot
+ * path is pure Python.  This header defines the
+ * boundary a maintainer would bind instead; every entry point names the
+ * reference code it replaces (paths relative to the reference repository).
+ * The binding itself (ctypes) is shown in INTEGRATION.md and implemented in
+ * pyslam_amd/_native.py.
+ *
+ * Conventions
+ *   - plain C types only; all table pointers in ps_problem_desc are HOST
+ *     pointers, copied to HBM by ps_problem_create (the handle owns its device
+ *     memory; the caller keeps ownership of the host arrays);
+ *   - every function returns 0 on success, <0 on error (message through
+ *     ps_last_error()); nothing throws across the ABI;
+ *   - all launches go to ONE HIP stream per handle (the `stream` argument of
+ *     ps_problem_create, a hipStream_t; NULL = a stream the handle creates);
+ *     functions that return host scalars synchronise that stream, the
+ *     others only enqueue;
+ *   - arithmetic is fp64 throughout (the reference is float64 numpy).
+ *
+ * Table layout: see pyslam_amd/lowering.py (LoweredProblem).
+ */
+#ifndef PYSLAM_HIP_H
+#define PYSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ps_problem ps_problem;
+
+typedef struct ps_problem_desc {
+    int32_t dof;                 /* 6: SE(3) poses, 3: SE(2) poses                           */
+    int32_t num_poses;           /* rows of `poses` (12 doubles SE3 / 6 doubles SE2 each)     */
+    const double*  poses;        /* [R row-major | t]                                         */
+    const int32_t* pose_rid;     /* index in the reduced system, -1 = held constant           */
+    int32_t num_points;
+    const double*  points;       /* (num_points, 3)                                           */
+    const int32_t* point_vid;    /* variable-landmark index, -1 = held constant               */
+
+    /* stereo reprojection blocks (reference residuals/reprojection_residual.py:13-37,
+       reprojection_motion_only_residual.py:35-113 lowered onto constant points) */
+    int64_t num_obs;
+    const int32_t* obs_pose;
+    const int32_t* obs_point;
+    const double*  obs_uvd;      /* (num_obs, 3)                                              */
+    const int32_t* obs_grp;      /* row of obs_groups                                         */
+    int32_t num_cams;       const double* cams;        /* (num_cams, 5) cu cv fu fv b         */
+    int32_t num_stiff3;     const double* stiff3;      /* (num_stiff3, 9) 3x3 row-major       */
+    int32_t num_obs_groups; const double* obs_groups;  /* (n, 4) cam, stiff, loss id, loss k  */
+
+    /* pose-pose edges (reference residuals/pose_to_pose_residual.py:12-32) */
+    int64_t num_edges;
+    const int32_t* e_i;
+    const int32_t* e_j;
+    const double*  e_Tobs_inv;   /* T_2_1_obs^-1, packed like poses                           */
+    const int32_t* e_grp;        /* row of edge_groups                                        */
+    /* unary pose priors (reference residuals/pose_residual.py:12-27) */
+    int64_t num_priors;
+    const int32_t* u_i;
+    const double*  u_Tobs_inv;
+    const int32_t* u_grp;
+    int32_t num_stiffd;      const double* stiffd;       /* (n, dof*dof) row-major            */
+    int32_t num_edge_groups; const double* edge_groups;  /* (n, 3) stiff, loss id, loss k     */
+
+    /* multi-GPU: pose pairs (reduced indices, i<j) that other landmark shards
+       couple, so every rank builds the SAME block pattern for the all-reduce */
+    int64_t num_extra_pairs;
+    const int32_t* extra_pair_i;
+    const int32_t* extra_pair_j;
+} ps_problem_desc;
+
+/* sizes a binding needs to allocate result buffers */
+typedef struct ps_problem_info {
+    int32_t dof, num_poses, num_reduced, num_points, num_var_points;
+    int64_t num_obs, num_edges, num_priors;
+    int64_t reduced_nnzb;        /* blocks in the reduced (Schur) system, both triangles      */
+    int64_t num_pairs;           /* off-diagonal Schur contributions (upper triangle)         */
+    int64_t reduce_count;        /* doubles in the all-reduce payload [S | g | cost]          */
+    int64_t device_bytes;        /* HBM held by the handle                                    */
+} ps_problem_info;
+
+enum { PS_NUM_STAGES = 10 };
+/* stage ids for ps_get_stage_times */
+enum { PS_ST_LANDMARK = 0, PS_ST_POSE = 1, PS_ST_SCHUR = 2, PS_ST_EDGES = 3, PS_ST_PCG = 4,
+       PS_ST_BACKSUB = 5, PS_ST_UPDATE = 6, PS_ST_COST = 7, PS_ST_TOTAL = 8, PS_ST_SCHUR_KERNEL = 9 };
+
+const char* ps_last_error(void);
+int ps_device_count(void);
+
+/* Lower the tables to HBM and precompute the iteration-invariant structure
+   (landmark / pose segment lists, Schur pair lists, block pattern).
+   Replaces the per-iteration Python bookkeeping of pyslam/problem.py:294-329. */
+int ps_problem_create(const ps_problem_desc* desc, void* stream, ps_problem** out);
+int ps_problem_destroy(ps_problem* h);
+int ps_get_info(ps_problem* h, ps_problem_info* info);
+
+/* sum_blocks sum_i rho(r_i) at the current parameters -- pyslam/problem.py:110-128
+   (include_all_constant=1) or the cost term of problem.py:334,358
+   (include_all_constant=0: blocks whose parameters are all constant are skipped). */
+int ps_eval_cost(ps_problem* h, int include_all_constant, double* cost);
+
+/* Residuals + Jacobians + IRLS weights + J^T J assembly + landmark elimination:
+   builds the reduced system S dx_p = g in HBM.  Replaces pyslam/problem.py:279-360
+   (block.evaluate, loss.weight, sparse.bmat, HT.dot(HT.T), -HT.dot(e)).
+   lambda: Marquardt damping added as lambda*diag(J^T J); 0 = the reference's GN. */
+int ps_linearize(ps_problem* h, double lambda);
+
+/* Device pointer + length of the contiguous payload [S values | g | cost] a
+   multi-GPU caller all-reduces (sum) between ps_linearize and ps_solve_reduced. */
+int ps_reduce_buffer(ps_problem* h, void** dev_ptr, int64_t* count);
+
+/* Block-Jacobi PCG on the reduced system; replaces the splinalg.spsolve call of
+   pyslam/problem.py:186 together with ps_backsub.  Stops at ||r|| <= tol*||g||. */
+int ps_solve_reduced(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out);
+
+/* Landmark back-substitution dx_l = Hll^-1 (b_l - W^T dx_p). */
+int ps_backsub(ps_problem* h);
+
+/* dx in device order [reduced poses (dof each) | variable points (3 each)];
+   either pointer may be NULL.  ps_step_norm2 returns ||dx||^2. */
+int ps_get_dx(ps_problem* h, double* dx_pose, double* dx_point);
+int ps_step_norm2(ps_problem* h, double* norm2);
+
+/* T <- exp(step*xi) T, p <- p + step*dp -- pyslam/problem.py:155-156, 400-409. */
+int ps_apply_update(ps_problem* h, double step);
+
+/* best_params snapshot / restore of pyslam/problem.py:163-175. */
+int ps_snapshot_params(ps_problem* h);
+int ps_restore_params(ps_problem* h);
+
+int ps_get_params(ps_problem* h, double* poses, double* points);
+int ps_set_params(ps_problem* h, const double* poses, const double* points);
+
+/* One whole Gauss-Newton / LM iteration with a single host synchronisation:
+   linearize -> PCG -> back-substitution -> update -> post-step cost.
+   cost_out = cost after the step (linesearch != 0, pyslam/problem.py:362-398 with its
+   always-full step) or cost at the linearisation point (linesearch == 0, problem.py:192). */
+int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters,
+                    int linesearch, double* cost_out, double* dx_norm_out,
+                    int* pcg_iters_out, double* pcg_relres_out);
+
+/* Parity / debug taps (device -> host). */
+int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx,
+                          double* vals, double* g);       /* BSR, dof x dof blocks */
+int ps_get_landmark_factors(ps_problem* h, double* cinv /* (nv,6) */, double* c /* (nv,3) */);
+int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /* (N,18) */,
+                           double* jpoint /* (N,9) */);  /* IRLS-scaled, original obs order */
+
+/* hipEvent stage timers on the handle's stream (the reference has no tracing). */
+int ps_set_profiling(ps_problem* h, int enabled);
+int ps_get_stage_times(ps_problem* h, double* ms /* PS_NUM_STAGES */, int64_t* counts, int reset);
+
+/* Host-evaluated generic path (user-defined Python residual blocks): dense
+   J (m x n, row-major) and r are uploaded, the device forms J^T J, -J^T r and
+   solves by Cholesky; optionally returns the inverse (compute_covariance,
+   pyslam/problem.py:196-203). */
+int ps_dense_normal_solve(const double* J, const double* r, int32_t m, int32_t n,
+                          double* dx, double* covariance /* n*n or NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSLAM_HIP_H */

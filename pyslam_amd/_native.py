@@ -1,0 +1,117 @@
+"""ctypes binding of libpyslam_hip.so (C ABI: include/pyslam_hip.h).
+
+There is NO CPU fallback: ``load()`` raises if the library has not been built
+and ``DeviceProblem`` raises if no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpyslam_hip.so')
+
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+PS_NUM_STAGES = 10
+STAGE_NAMES = ['landmark_pass', 'pose_pass', 'schur_pairs', 'pose_factors', 'pcg',
+               'backsub', 'update', 'cost', 'iteration_total', 'reserved']
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ('dof', C.c_int32), ('num_poses', C.c_int32), ('poses', c_f64p), ('pose_rid', c_i32p),
+        ('num_points', C.c_int32), ('points', c_f64p), ('point_vid', c_i32p),
+        ('num_obs', C.c_int64), ('obs_pose', c_i32p), ('obs_point', c_i32p), ('obs_uvd', c_f64p),
+        ('obs_grp', c_i32p),
+        ('num_cams', C.c_int32), ('cams', c_f64p), ('num_stiff3', C.c_int32), ('stiff3', c_f64p),
+        ('num_obs_groups', C.c_int32), ('obs_groups', c_f64p),
+        ('num_edges', C.c_int64), ('e_i', c_i32p), ('e_j', c_i32p), ('e_Tobs_inv', c_f64p), ('e_grp', c_i32p),
+        ('num_priors', C.c_int64), ('u_i', c_i32p), ('u_Tobs_inv', c_f64p), ('u_grp', c_i32p),
+        ('num_stiffd', C.c_int32), ('stiffd', c_f64p), ('num_edge_groups', C.c_int32), ('edge_groups', c_f64p),
+        ('num_extra_pairs', C.c_int64), ('extra_pair_i', c_i32p), ('extra_pair_j', c_i32p),
+    ]
+
+
+class ProblemInfo(C.Structure):
+    _fields_ = [
+        ('dof', C.c_int32), ('num_poses', C.c_int32), ('num_reduced', C.c_int32),
+        ('num_points', C.c_int32), ('num_var_points', C.c_int32),
+        ('num_obs', C.c_int64), ('num_edges', C.c_int64), ('num_priors', C.c_int64),
+        ('reduced_nnzb', C.c_int64), ('num_pairs', C.c_int64), ('reduce_count', C.c_int64),
+        ('device_bytes', C.c_int64),
+    ]
+
+
+# every symbol include/pyslam_hip.h declares: name -> (restype, argtypes)
+H = C.c_void_p
+SIGNATURES = {
+    'ps_last_error': (C.c_char_p, []),
+    'ps_device_count': (C.c_int, []),
+    'ps_problem_create': (C.c_int, [C.POINTER(ProblemDesc), C.c_void_p, C.POINTER(H)]),
+    'ps_problem_destroy': (C.c_int, [H]),
+    'ps_get_info': (C.c_int, [H, C.POINTER(ProblemInfo)]),
+    'ps_eval_cost': (C.c_int, [H, C.c_int, c_f64p]),
+    'ps_linearize': (C.c_int, [H, C.c_double]),
+    'ps_reduce_buffer': (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'ps_solve_reduced': (C.c_int, [H, C.c_double, C.c_int, C.POINTER(C.c_int), c_f64p]),
+    'ps_backsub': (C.c_int, [H]),
+    'ps_get_dx': (C.c_int, [H, c_f64p, c_f64p]),
+    'ps_step_norm2': (C.c_int, [H, c_f64p]),
+    'ps_apply_update': (C.c_int, [H, C.c_double]),
+    'ps_snapshot_params': (C.c_int, [H]),
+    'ps_restore_params': (C.c_int, [H]),
+    'ps_get_params': (C.c_int, [H, c_f64p, c_f64p]),
+    'ps_set_params': (C.c_int, [H, c_f64p, c_f64p]),
+    'ps_gn_iteration': (C.c_int, [H, C.c_double, C.c_double, C.c_int, C.c_int, c_f64p, c_f64p,
+                                  C.POINTER(C.c_int), c_f64p]),
+    'ps_get_reduced_system': (C.c_int, [H, c_i32p, c_i32p, c_f64p, c_f64p]),
+    'ps_get_landmark_factors': (C.c_int, [H, c_f64p, c_f64p]),
+    'ps_debug_reproj_blocks': (C.c_int, [H, c_f64p, c_f64p, c_f64p]),
+    'ps_set_profiling': (C.c_int, [H, C.c_int]),
+    'ps_get_stage_times': (C.c_int, [H, c_f64p, C.POINTER(C.c_int64), C.c_int]),
+    'ps_dense_normal_solve': (C.c_int, [c_f64p, c_f64p, C.c_int32, C.c_int32, c_f64p, c_f64p]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP core; raise loudly if it is missing (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "{} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). pyslam_amd has no CPU solver path.".format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError(load().ps_last_error().decode('utf-8', 'replace'))
+
+
+def f64p(a):
+    return a.ctypes.data_as(c_f64p) if a is not None else None
+
+
+def i32p(a):
+    return a.ctypes.data_as(c_i32p) if a is not None else None
+
+
+def require_gpu():
+    lib = load()
+    if lib.ps_device_count() < 1:
+        raise NativeError("no HIP device visible: pyslam_amd solves only on an MI355X (no CPU fallback)")
+    return lib

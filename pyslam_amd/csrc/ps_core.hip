@@ -1,0 +1,827 @@
+// ps_core.hip -- host side of the C ABI declared in include/pyslam_hip.h:
+// table upload, iteration-invariant structure (segment / pair / block lists),
+// kernel sequencing on one HIP stream, hipEvent stage timers.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+//              -Iinclude pyslam_amd/csrc/ps_core.hip -o pyslam_amd/lib/libpyslam_hip.so
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pyslam_hip.h"
+#include "ps_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) { g_err = msg; return -1; }
+
+#define HIP_OK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+struct ps_problem {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int D = 6, PW = 12;
+    int P = 0, nr = 0, L = 0, nv = 0;
+    long N = 0, Nl = 0, Np = 0;     // observations: all / on variable points / on variable poses
+    long F = 0;                     // pose factors (edges + priors)
+    long npairs = 0;
+    int nnzb = 0;
+    size_t dev_bytes = 0;
+    std::vector<void*> allocs;
+
+    // parameter tables
+    double *poses = nullptr, *points = nullptr, *poses_snap = nullptr, *points_snap = nullptr;
+    int32_t *pose_rid = nullptr, *point_vid = nullptr;
+    // reprojection
+    ObsGroup* ogroups = nullptr;
+    LObs* lobs = nullptr;
+    int32_t *lorig = nullptr, *lm_ptr = nullptr, *lm_point = nullptr;
+    double *Z = nullptr, *Cinv = nullptr, *cvec = nullptr, *dxl = nullptr;
+    int32_t* pidx = nullptr;
+    PItem* pitems = nullptr;
+    int npitems = 0;
+    int32_t* pitem_ptr = nullptr;
+    double* ppartial = nullptr;
+    int2* pairs = nullptr;
+    PairItem* pair_items = nullptr;
+    int npair_items = 0;
+    // factors
+    FactorGroup* fgroups = nullptr;
+    int32_t *f_i = nullptr, *f_j = nullptr, *f_grp = nullptr;
+    double *f_Tinv = nullptr, *fscratch = nullptr;
+    int32_t *eslots = nullptr, *eptr = nullptr, *eslot_diag = nullptr, *gptr = nullptr, *gitems = nullptr;
+    int2* eitems = nullptr;
+    int nes = 0;
+    // reduced system
+    int32_t *row_ptr = nullptr, *col_idx = nullptr, *diag_slot = nullptr;
+    double* red = nullptr;          // [S (nnzb*D*D) | g (nr*D) | cost]
+    long red_count = 0;
+    double *S = nullptr, *g = nullptr, *red_cost = nullptr;
+    std::vector<int32_t> h_row_ptr, h_col_idx;
+    // pcg
+    double *x = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *q = nullptr, *Minv = nullptr;
+    double *rz_part = nullptr, *rr_part = nullptr, *pq_part = nullptr, *hist = nullptr;
+    int npartA = 0, npartB = 0, hist_cap = 0, last_pcg_iters = 0;
+    // scalars
+    double *cost_partials = nullptr, *scalars = nullptr, *h_scalars = nullptr;
+    int32_t *status = nullptr, *h_status = nullptr;
+    int ncost_obs = 0, ncost_fac = 0, nsq = 0;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[2 * PS_NUM_STAGES] = {};
+    std::vector<std::pair<int, int>> pending;   // (stage, event slot) recorded, not yet read
+    double stage_ms[PS_NUM_STAGES] = {};
+    int64_t stage_n[PS_NUM_STAGES] = {};
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+
+    template <typename T>
+    int alloc(T** out, size_t n) {
+        *out = nullptr;
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
+        allocs.push_back(p);
+        dev_bytes += bytes;
+        *out = (T*)p;
+        return 0;
+    }
+    template <typename T>
+    int upload(T** out, const std::vector<T>& v) {
+        if (alloc(out, v.size())) return -1;
+        if (!v.empty()) HIP_OK(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+    template <typename T>
+    int upload(T** out, const T* src, size_t n) {
+        if (alloc(out, n)) return -1;
+        if (n) HIP_OK(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+
+namespace {
+
+// ---- stage timers ---------------------------------------------------------
+struct StageTimer {
+    ps_problem* h;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    int slot = -1;
+    StageTimer(ps_problem* h_, int st) : h(h_), stage(st) {
+        if (!h->profiling) return;
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); h->ev_pool.push_back(e); }
+        }
+        slot = (int)h->ev_used;
+        a = h->ev_pool[h->ev_used++];
+        b = h->ev_pool[h->ev_used++];
+        hipEventRecord(a, h->stream);
+    }
+    ~StageTimer() {
+        if (!a) return;
+        hipEventRecord(b, h->stream);
+        h->pending.push_back({stage, slot});
+    }
+};
+
+void drain_timers(ps_problem* h) {      // call after a stream synchronisation
+    for (auto& pr : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[pr.second], h->ev_pool[pr.second + 1]) == hipSuccess) {
+            h->stage_ms[pr.first] += ms;
+            h->stage_n[pr.first] += 1;
+        }
+    }
+    h->pending.clear();
+    h->ev_used = 0;
+}
+
+int sync(ps_problem* h) {
+    HIP_OK(hipStreamSynchronize(h->stream));
+    drain_timers(h);
+    return 0;
+}
+
+int read_scalars(ps_problem* h) {
+    HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+// ---- structure building ---------------------------------------------------
+struct PairRec { uint64_t key; int32_t a, b; };
+
+template <int D>
+int launch_factor_pass(ps_problem* h, double lambda) {
+    if (h->F == 0) return 0;
+    hipLaunchKernelGGL(k_factor_pass<D>, dim3(cdiv(h->F, 4)), dim3(256), 0, h->stream, (int)h->F, h->f_i,
+                       h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->fscratch);
+    const long threads = (long)h->nes * D * D + (long)h->nr * D;
+    hipLaunchKernelGGL(k_factor_assemble<D>, dim3(cdiv(threads, 256)), dim3(256), 0, h->stream, h->nes,
+                       h->eslots, h->eptr, h->eitems, h->eslot_diag, h->nr, h->gptr, h->gitems,
+                       h->fscratch, lambda, h->S, h->g);
+    return 0;
+}
+
+template <int D>
+int pcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
+    const int nr = h->nr;
+    if (max_iters + 2 > h->hist_cap) return fail("pcg max_iters exceeds the history buffer (4096)");
+    hipLaunchKernelGGL(k_block_jacobi<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
+                       h->S, h->Minv, h->status);
+    hipLaunchKernelGGL(k_pcg_init<D>, dim3(h->npartB), dim3(256), 0, h->stream, nr, h->g, h->Minv, h->x,
+                       h->r, h->z, h->rz_part, h->rr_part, h->status);
+    const double tol2 = tol * tol;
+    int k = 0;
+    int chunk = std::max(4, h->last_pcg_iters + 1);
+    bool done = false;
+    while (!done) {
+        const int n = std::min(chunk, max_iters + 1 - k);   // +1: the launch that only detects convergence
+        for (int i = 0; i < n; ++i, ++k) {
+            double* pold = (k & 1) ? h->p1 : h->p0;
+            double* pnew = (k & 1) ? h->p0 : h->p1;
+            hipLaunchKernelGGL(k_pcg_spmv<D>, dim3(h->npartA), dim3(256), 0, h->stream, nr, h->row_ptr,
+                               h->col_idx, h->S, h->z, pold, pnew, h->q, h->rz_part, h->rr_part, h->npartB,
+                               h->pq_part, h->hist, k, tol2, h->status, h->scalars);
+            if (k < max_iters)
+                hipLaunchKernelGGL(k_pcg_update<D>, dim3(h->npartB), dim3(256), 0, h->stream, nr, h->Minv,
+                                   pnew, h->q, h->x, h->r, h->z, h->pq_part, h->npartA, h->hist, k,
+                                   h->rz_part, h->rr_part, h->status);
+        }
+        HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        done = h->h_status[ST_PCG_DONE] != 0 || k > max_iters;
+        chunk = 8;
+    }
+    h->last_pcg_iters = h->h_status[ST_PCG_ITERS];
+    if (iters_out) *iters_out = h->h_status[ST_PCG_ITERS];
+    const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
+    if (relres_out) *relres_out = rr0 > 0.0 ? std::sqrt(rrf / rr0) : 0.0;
+    if (h->h_status[ST_DIAG_FAIL])
+        return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+    return 0;
+}
+
+int linearize(ps_problem* h, double lambda) {
+    HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+    if (h->nv > 0) {
+        StageTimer t(h, PS_ST_LANDMARK);
+        hipLaunchKernelGGL(k_landmark_pass, dim3(cdiv(h->nv, 256)), dim3(256), 0, h->stream, h->nv, h->lm_ptr,
+                           h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,
+                           h->Cinv, h->cvec, h->status);
+    }
+    if (h->npitems > 0) {
+        StageTimer t(h, PS_ST_POSE);
+        hipLaunchKernelGGL(k_pose_pass, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pidx, h->lobs,
+                           h->poses, h->points, h->point_vid, h->ogroups, h->Z, h->cvec, h->ppartial);
+        hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
+                           h->ppartial, h->diag_slot, lambda, h->S, h->g);
+    }
+    if (h->npair_items > 0) {
+        StageTimer t(h, PS_ST_SCHUR);
+        hipLaunchKernelGGL(k_schur_pairs, dim3(cdiv((long)h->npair_items * 64, 256)), dim3(256), 0, h->stream,
+                           h->npair_items, h->pair_items, h->pairs, h->Z, h->S);
+    }
+    if (h->F > 0 && h->nr > 0) {
+        StageTimer t(h, PS_ST_EDGES);
+        if (h->D == 6) launch_factor_pass<6>(h, lambda); else launch_factor_pass<3>(h, lambda);
+    }
+    return 0;
+}
+
+int cost_pass(ps_problem* h, int include_all, int scalar_slot) {
+    StageTimer t(h, PS_ST_COST);
+    int n = 0;
+    if (h->N > 0) {
+        hipLaunchKernelGGL(k_cost_reproj, dim3(h->ncost_obs), dim3(256), 0, h->stream, h->N, h->lobs, h->poses,
+                           h->points, h->pose_rid, h->point_vid, h->ogroups, include_all, h->cost_partials);
+        n += h->ncost_obs;
+    }
+    if (h->F > 0) {
+        if (h->D == 6)
+            hipLaunchKernelGGL(k_cost_factors<6>, dim3(h->ncost_fac), dim3(256), 0, h->stream, (int)h->F, h->f_i,
+                               h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->pose_rid, include_all,
+                               h->cost_partials + n);
+        else
+            hipLaunchKernelGGL(k_cost_factors<3>, dim3(h->ncost_fac), dim3(256), 0, h->stream, (int)h->F, h->f_i,
+                               h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->pose_rid, include_all,
+                               h->cost_partials + n);
+        n += h->ncost_fac;
+    }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, n, h->cost_partials,
+                       h->scalars + scalar_slot);
+    return 0;
+}
+
+int backsub(ps_problem* h) {
+    if (h->nv == 0) return 0;
+    StageTimer t(h, PS_ST_BACKSUB);
+    hipLaunchKernelGGL(k_backsub, dim3(cdiv(h->nv, 256)), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
+                       h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl);
+    return 0;
+}
+
+int step_norm(ps_problem* h) {
+    // partial sums of squares of [x | dxl] then a single-workgroup reduce
+    double* part = h->cost_partials;      // reused: the cost pass of this iteration runs later
+    int n = 0;
+    if (h->nr > 0) {
+        const int b = std::min(256, cdiv((long)h->nr * h->D, 256));
+        hipLaunchKernelGGL(k_sumsq_partials, dim3(b), dim3(256), 0, h->stream, (long)h->nr * h->D, h->x, 1.0, part);
+        n += b;
+    }
+    if (h->nv > 0) {
+        const int b = std::min(256, cdiv((long)h->nv * 3, 256));
+        hipLaunchKernelGGL(k_sumsq_partials, dim3(b), dim3(256), 0, h->stream, (long)h->nv * 3, h->dxl, 1.0, part + n);
+        n += b;
+    }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, n, part, h->scalars + SC_DXNORM2);
+    return 0;
+}
+
+int apply_update(ps_problem* h, double step) {
+    StageTimer t(h, PS_ST_UPDATE);
+    if (h->nr > 0) {
+        if (h->D == 6)
+            hipLaunchKernelGGL(k_update_poses<6>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses);
+        else
+            hipLaunchKernelGGL(k_update_poses<3>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses);
+    }
+    if (h->nv > 0)
+        hipLaunchKernelGGL(k_update_points, dim3(cdiv((long)h->nv * 3, 256)), dim3(256), 0, h->stream, h->nv,
+                           h->lm_point, h->dxl, step, h->points);
+    return 0;
+}
+
+int solve_reduced(ps_problem* h, double tol, int max_iters, int* iters, double* relres) {
+    if (h->nr == 0) { if (iters) *iters = 0; if (relres) *relres = 0.0; return 0; }
+    StageTimer t(h, PS_ST_PCG);
+    return h->D == 6 ? pcg_run<6>(h, tol, max_iters, iters, relres) : pcg_run<3>(h, tol, max_iters, iters, relres);
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char* ps_last_error(void) { return g_err.c_str(); }
+
+int ps_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ps_problem_destroy(ps_problem* h) {
+    if (!h) return 0;
+    hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) hipFree(p);
+    if (h->h_scalars) hipHostFree(h->h_scalars);
+    if (h->h_status) hipHostFree(h->h_status);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) {
+    if (!d || !out) return fail("null argument");
+    *out = nullptr;
+    if (d->dof != 6 && d->dof != 3) return fail("dof must be 6 (SE3) or 3 (SE2)");
+    if (d->num_obs > 0 && d->dof != 6) return fail("reprojection blocks need SE(3) poses");
+    if (d->num_poses >= (1 << 24)) return fail("more than 2^24 poses");
+    if (d->num_obs_groups > 255) return fail("more than 255 observation groups");
+    if (d->num_obs >= (1L << 31) / 18) return fail("too many observations for 32-bit indexing");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible");
+
+    ps_problem* h = new ps_problem();
+    struct Guard { ps_problem* h; bool ok = false; ~Guard() { if (!ok) ps_problem_destroy(h); } } guard{h};
+    if (stream) h->stream = (hipStream_t)stream;
+    else { HIP_OK(hipStreamCreate(&h->stream)); h->own_stream = true; }
+    const int D = h->D = d->dof;
+    const int PW = h->PW = (D == 6 ? 12 : 6);
+    const int DD = D * D;
+    h->P = d->num_poses; h->L = d->num_points; h->N = d->num_obs;
+    const int P = h->P, L = h->L;
+    const long N = h->N;
+
+    // ---- parameter tables
+    if (h->upload(&h->poses, d->poses, (size_t)P * PW)) return -1;
+    if (h->upload(&h->points, d->points, (size_t)L * 3)) return -1;
+    if (h->upload(&h->pose_rid, d->pose_rid, (size_t)P)) return -1;
+    if (h->upload(&h->point_vid, d->point_vid, (size_t)L)) return -1;
+    if (h->alloc(&h->poses_snap, (size_t)P * PW) || h->alloc(&h->points_snap, (size_t)L * 3)) return -1;
+    int nr = 0, nv = 0;
+    for (int i = 0; i < P; ++i) if (d->pose_rid[i] >= 0) nr = std::max(nr, d->pose_rid[i] + 1);
+    for (int i = 0; i < L; ++i) if (d->point_vid[i] >= 0) nv = std::max(nv, d->point_vid[i] + 1);
+    h->nr = nr; h->nv = nv;
+    std::vector<int32_t> lm_point(nv, -1);
+    for (int i = 0; i < L; ++i) if (d->point_vid[i] >= 0) lm_point[d->point_vid[i]] = i;
+    for (int v = 0; v < nv; ++v) if (lm_point[v] < 0) return fail("point_vid is not a dense 0..nv-1 numbering");
+    {
+        std::vector<char> seen(nr, 0);
+        for (int i = 0; i < P; ++i) if (d->pose_rid[i] >= 0) {
+            if (seen[d->pose_rid[i]]) return fail("pose_rid has duplicates");
+            seen[d->pose_rid[i]] = 1;
+        }
+        for (int i = 0; i < nr; ++i) if (!seen[i]) return fail("pose_rid is not a dense 0..nr-1 numbering");
+    }
+
+    // ---- observation groups
+    std::vector<ObsGroup> og(std::max(1, d->num_obs_groups));
+    for (int gi = 0; gi < d->num_obs_groups; ++gi) {
+        const double* row = d->obs_groups + 4 * gi;
+        const int cam = (int)row[0], st = (int)row[1];
+        if (cam < 0 || cam >= d->num_cams || st < 0 || st >= d->num_stiff3) return fail("obs group index out of range");
+        const double* c = d->cams + 5 * cam;
+        ObsGroup& o = og[gi];
+        o.cu = c[0]; o.cv = c[1]; o.fu = c[2]; o.fv = c[3]; o.b = c[4];
+        for (int k = 0; k < 9; ++k) o.S[k] = d->stiff3[9 * st + k];
+        o.loss_id = (int)row[2]; o.loss_k = row[3];
+    }
+    if (h->upload(&h->ogroups, og)) return -1;
+
+    // ---- observations sorted by landmark: variable points (by vid) first, then constant points
+    std::vector<int64_t> order(N);
+    for (long i = 0; i < N; ++i) order[i] = i;
+    auto lm_key = [&](long i) -> int64_t {
+        const int v = d->point_vid[d->obs_point[i]];
+        return v >= 0 ? (int64_t)v : (int64_t)nv + d->obs_point[i];
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return lm_key(a) < lm_key(b); });
+    std::vector<LObs> lobs(N);
+    std::vector<int32_t> lorig(N), lm_ptr(nv + 1, 0);
+    long Nl = 0;
+    for (long k = 0; k < N; ++k) {
+        const long i = order[k];
+        const int pose = d->obs_pose[i], pt = d->obs_point[i], grp = d->obs_grp[i];
+        if (pose < 0 || pose >= P || pt < 0 || pt >= L || grp < 0 || grp >= d->num_obs_groups)
+            return fail("observation index out of range");
+        LObs& o = lobs[k];
+        o.u = d->obs_uvd[3 * i]; o.v = d->obs_uvd[3 * i + 1]; o.d = d->obs_uvd[3 * i + 2];
+        o.pose_grp = (int32_t)((uint32_t)pose | ((uint32_t)grp << 24));
+        o.point = pt;
+        lorig[k] = (int32_t)i;
+        const int v = d->point_vid[pt];
+        if (v >= 0) { lm_ptr[v + 1] += 1; ++Nl; }
+    }
+    for (int v = 0; v < nv; ++v) lm_ptr[v + 1] += lm_ptr[v];
+    h->Nl = Nl;
+    if (h->upload(&h->lobs, lobs) || h->upload(&h->lorig, lorig) || h->upload(&h->lm_ptr, lm_ptr) ||
+        h->upload(&h->lm_point, lm_point)) return -1;
+    if (h->alloc(&h->Z, (size_t)Nl * 18) || h->alloc(&h->Cinv, (size_t)nv * 6) ||
+        h->alloc(&h->cvec, (size_t)nv * 3) || h->alloc(&h->dxl, (size_t)nv * 3)) return -1;
+    HIP_OK(hipMemsetAsync(h->dxl, 0, std::max<size_t>(1, (size_t)nv * 3) * sizeof(double), h->stream));
+
+    // ---- pose segments (observations on variable poses), chunks of 256
+    std::vector<int32_t> pcount(nr + 1, 0);
+    for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pcount[r + 1]++; }
+    for (int r = 0; r < nr; ++r) pcount[r + 1] += pcount[r];
+    const long Np = h->Np = pcount[nr];
+    std::vector<int32_t> pidx(Np), fill(pcount.begin(), pcount.end() - 1);
+    for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pidx[fill[r]++] = (int32_t)k; }
+    std::vector<PItem> pitems;
+    std::vector<int32_t> pitem_ptr(nr + 1, 0);
+    for (int r = 0; r < nr; ++r) {
+        for (int s = pcount[r]; s < pcount[r + 1]; s += 256)
+            pitems.push_back({r, s, std::min(s + 256, pcount[r + 1]), 0});
+        pitem_ptr[r + 1] = (int32_t)pitems.size();
+    }
+    h->npitems = (int)pitems.size();
+    if (h->upload(&h->pidx, pidx) || h->upload(&h->pitems, pitems) || h->upload(&h->pitem_ptr, pitem_ptr) ||
+        h->alloc(&h->ppartial, (size_t)pitems.size() * PS_NPOSE_ACC)) return -1;
+
+    // ---- pose factors: edges then priors
+    const long E = d->num_edges, Q = d->num_priors, F = h->F = E + Q;
+    std::vector<FactorGroup> fg(std::max(1, d->num_edge_groups));
+    for (int gi = 0; gi < d->num_edge_groups; ++gi) {
+        const double* row = d->edge_groups + 3 * gi;
+        const int st = (int)row[0];
+        if (st < 0 || st >= d->num_stiffd) return fail("edge group stiffness index out of range");
+        std::memset(&fg[gi], 0, sizeof(FactorGroup));
+        for (int k = 0; k < DD; ++k) fg[gi].S[k] = d->stiffd[(size_t)DD * st + k];
+        fg[gi].loss_id = (int)row[1]; fg[gi].loss_k = row[2];
+    }
+    std::vector<int32_t> f_i(F), f_j(F), f_grp(F);
+    std::vector<double> f_T((size_t)F * PW);
+    for (long f = 0; f < E; ++f) {
+        f_i[f] = d->e_i[f]; f_j[f] = d->e_j[f]; f_grp[f] = d->e_grp[f];
+        std::memcpy(&f_T[(size_t)f * PW], d->e_Tobs_inv + (size_t)f * PW, PW * sizeof(double));
+    }
+    for (long u = 0; u < Q; ++u) {
+        f_i[E + u] = -1; f_j[E + u] = d->u_i[u]; f_grp[E + u] = d->u_grp[u];
+        std::memcpy(&f_T[(size_t)(E + u) * PW], d->u_Tobs_inv + (size_t)u * PW, PW * sizeof(double));
+    }
+    for (long f = 0; f < F; ++f)
+        if (f_j[f] < 0 || f_j[f] >= P || f_i[f] >= P || f_grp[f] < 0 || f_grp[f] >= d->num_edge_groups)
+            return fail("pose factor index out of range");
+    if (h->upload(&h->fgroups, fg) || h->upload(&h->f_i, f_i) || h->upload(&h->f_j, f_j) ||
+        h->upload(&h->f_grp, f_grp) || h->upload(&h->f_Tinv, f_T)) return -1;
+    const int FROW = 3 * DD + 2 * D;
+    if (h->alloc(&h->fscratch, (size_t)F * FROW)) return -1;
+
+    // ---- Schur pairs per landmark (upper-triangle block keys)
+    std::vector<PairRec> prs;
+    for (int v = 0; v < nv; ++v) {
+        for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) {
+            const int ra = d->pose_rid[PS_POSE_OF(lobs[a])];
+            if (ra < 0) continue;
+            for (int b = a + 1; b < lm_ptr[v + 1]; ++b) {
+                const int rb = d->pose_rid[PS_POSE_OF(lobs[b])];
+                if (rb < 0) continue;
+                if (ra <= rb) prs.push_back({((uint64_t)ra << 32) | (uint32_t)rb, a, b});
+                else prs.push_back({((uint64_t)rb << 32) | (uint32_t)ra, b, a});
+            }
+        }
+    }
+    std::stable_sort(prs.begin(), prs.end(), [](const PairRec& x, const PairRec& y) { return x.key < y.key; });
+    h->npairs = (long)prs.size();
+    if (prs.size() >= (1UL << 31)) return fail("too many Schur pairs for 32-bit indexing");
+
+    // ---- block pattern of the reduced system
+    std::vector<uint64_t> keys;                 // upper keys (ri <= rj)
+    keys.reserve(prs.size() / 8 + nr + F + d->num_extra_pairs);
+    for (int r = 0; r < nr; ++r) keys.push_back(((uint64_t)r << 32) | (uint32_t)r);
+    for (size_t k = 0; k < prs.size(); ++k) if (k == 0 || prs[k].key != prs[k - 1].key) keys.push_back(prs[k].key);
+    for (long f = 0; f < E; ++f) {
+        const int ra = d->pose_rid[f_i[f]], rb = d->pose_rid[f_j[f]];
+        if (ra >= 0 && rb >= 0 && ra != rb)
+            keys.push_back(((uint64_t)std::min(ra, rb) << 32) | (uint32_t)std::max(ra, rb));
+    }
+    for (long k = 0; k < d->num_extra_pairs; ++k) {
+        const int ra = d->extra_pair_i[k], rb = d->extra_pair_j[k];
+        if (ra < 0 || rb < 0 || ra >= nr || rb >= nr) return fail("extra pair index out of range");
+        keys.push_back(((uint64_t)std::min(ra, rb) << 32) | (uint32_t)std::max(ra, rb));
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<int32_t>& row_ptr = h->h_row_ptr;
+    std::vector<int32_t>& col_idx = h->h_col_idx;
+    row_ptr.assign(nr + 1, 0);
+    for (uint64_t k : keys) {
+        const int a = (int)(k >> 32), b = (int)(uint32_t)k;
+        row_ptr[a + 1]++;
+        if (a != b) row_ptr[b + 1]++;
+    }
+    for (int r = 0; r < nr; ++r) row_ptr[r + 1] += row_ptr[r];
+    const long nnzb_l = row_ptr[nr];
+    if (nnzb_l * DD >= (1L << 31)) return fail("reduced system too large for 32-bit block offsets");
+    const int nnzb = h->nnzb = (int)nnzb_l;
+    col_idx.assign(nnzb, 0);
+    {
+        std::vector<int32_t> f2(row_ptr.begin(), row_ptr.end() - 1);
+        // lower part first needs sorted columns per row: insert (b,a) pairs in key order gives
+        // ascending a for row b; then (a,b) gives ascending b >= a.  Do two passes.
+        for (uint64_t k : keys) { const int a = (int)(k >> 32), b = (int)(uint32_t)k; if (a != b) col_idx[f2[b]++] = a; }
+        for (uint64_t k : keys) { const int a = (int)(k >> 32), b = (int)(uint32_t)k; col_idx[f2[a]++] = b; }
+    }
+    auto slot_of = [&](int a, int b) -> int {
+        const int32_t* lo = col_idx.data() + row_ptr[a];
+        const int32_t* hi = col_idx.data() + row_ptr[a + 1];
+        const int32_t* it = std::lower_bound(lo, hi, b);
+        return (it != hi && *it == b) ? (int)(it - col_idx.data()) : -1;
+    };
+    std::vector<int32_t> diag_slot(nr);
+    for (int r = 0; r < nr; ++r) diag_slot[r] = slot_of(r, r);
+    if (h->upload(&h->row_ptr, row_ptr) || h->upload(&h->col_idx, col_idx) || h->upload(&h->diag_slot, diag_slot)) return -1;
+    h->red_count = (long)nnzb * DD + (long)nr * D + 2;
+    if (h->alloc(&h->red, (size_t)h->red_count)) return -1;
+    h->S = h->red; h->g = h->red + (size_t)nnzb * DD; h->red_cost = h->g + (size_t)nr * D;
+
+    // pair list + one work item per block that has pairs
+    std::vector<int2> pairs(prs.size());
+    std::vector<PairItem> pitm;
+    for (size_t k = 0; k < prs.size(); ++k) {
+        pairs[k] = make_int2(prs[k].a, prs[k].b);
+        if (k == 0 || prs[k].key != prs[k - 1].key) {
+            const int a = (int)(prs[k].key >> 32), b = (int)(uint32_t)prs[k].key;
+            if (!pitm.empty()) pitm.back().end = (int32_t)k;
+            pitm.push_back({slot_of(a, b), slot_of(b, a), (int32_t)k, 0});
+        }
+    }
+    if (!pitm.empty()) pitm.back().end = (int32_t)prs.size();
+    h->npair_items = (int)pitm.size();
+    if (h->upload(&h->pairs, pairs) || h->upload(&h->pair_items, pitm)) return -1;
+    prs.clear(); prs.shrink_to_fit();
+
+    // ---- factor contribution lists
+    {
+        struct C { int32_t slot, off, tr; };
+        std::vector<C> cs;
+        std::vector<std::vector<int32_t>> gl(nr);
+        for (long f = 0; f < F; ++f) {
+            const int ra = f_i[f] >= 0 ? d->pose_rid[f_i[f]] : -1, rb = d->pose_rid[f_j[f]];
+            const int32_t base = (int32_t)(f * FROW);
+            if ((size_t)f * FROW >= (1UL << 31)) return fail("too many pose factors for 32-bit scratch offsets");
+            if (ra >= 0) { cs.push_back({diag_slot[ra], base, 0}); gl[ra].push_back(base + 3 * DD); }
+            if (rb >= 0) { cs.push_back({diag_slot[rb], base + 2 * DD, 0}); gl[rb].push_back(base + 3 * DD + D); }
+            if (ra >= 0 && rb >= 0) {
+                if (ra == rb) return fail("pose-pose edge connects a pose with itself");
+                cs.push_back({slot_of(ra, rb), base + DD, 0});
+                cs.push_back({slot_of(rb, ra), base + DD, 1});
+            }
+        }
+        std::stable_sort(cs.begin(), cs.end(), [](const C& x, const C& y) { return x.slot < y.slot; });
+        std::vector<int32_t> eslots, eptr, ediag, gptr(nr + 1, 0), gitems;
+        std::vector<int2> eitems(cs.size());
+        for (size_t k = 0; k < cs.size(); ++k) {
+            eitems[k] = make_int2(cs[k].off, cs[k].tr);
+            if (k == 0 || cs[k].slot != cs[k - 1].slot) { eslots.push_back(cs[k].slot); eptr.push_back((int32_t)k); }
+        }
+        eptr.push_back((int32_t)cs.size());
+        for (int32_t s : eslots) {
+            // diagonal iff the slot is some row's diag slot: find its row by binary search on row_ptr
+            const int row = (int)(std::upper_bound(row_ptr.begin(), row_ptr.end(), s) - row_ptr.begin()) - 1;
+            ediag.push_back(col_idx[s] == row ? 1 : 0);
+        }
+        for (int r = 0; r < nr; ++r) { gptr[r + 1] = gptr[r] + (int32_t)gl[r].size(); gitems.insert(gitems.end(), gl[r].begin(), gl[r].end()); }
+        h->nes = (int)eslots.size();
+        if (h->upload(&h->eslots, eslots) || h->upload(&h->eptr, eptr) || h->upload(&h->eslot_diag, ediag) ||
+            h->upload(&h->eitems, eitems) || h->upload(&h->gptr, gptr) || h->upload(&h->gitems, gitems)) return -1;
+    }
+
+    // ---- PCG workspace
+    const size_t nvec = (size_t)nr * D;
+    h->npartA = std::max(1, cdiv(nr, 4));
+    h->npartB = std::max(1, cdiv(nr, D == 6 ? PS_PCG_BR(6) : PS_PCG_BR(3)));
+    h->hist_cap = 4098;
+    if (h->alloc(&h->x, nvec) || h->alloc(&h->r, nvec) || h->alloc(&h->z, nvec) || h->alloc(&h->p0, nvec) ||
+        h->alloc(&h->p1, nvec) || h->alloc(&h->q, nvec) || h->alloc(&h->Minv, (size_t)nr * DD) ||
+        h->alloc(&h->rz_part, h->npartB) || h->alloc(&h->rr_part, h->npartB) || h->alloc(&h->pq_part, h->npartA) ||
+        h->alloc(&h->hist, h->hist_cap)) return -1;
+    HIP_OK(hipMemsetAsync(h->x, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->p0, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->p1, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
+
+    // ---- scalars
+    h->ncost_obs = N > 0 ? std::min(2048, cdiv(N, 256)) : 0;
+    h->ncost_fac = F > 0 ? std::min(1024, cdiv(F, 256)) : 0;
+    if (h->alloc(&h->cost_partials, (size_t)std::max(h->ncost_obs + h->ncost_fac, 512) + 8) ||
+        h->alloc(&h->scalars, SC_NWORDS) || h->alloc(&h->status, ST_NWORDS)) return -1;
+    HIP_OK(hipMemsetAsync(h->scalars, 0, SC_NWORDS * sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+    HIP_OK(hipHostMalloc((void**)&h->h_scalars, SC_NWORDS * sizeof(double)));
+    HIP_OK(hipHostMalloc((void**)&h->h_status, ST_NWORDS * sizeof(int32_t)));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    guard.ok = true;
+    *out = h;
+    return 0;
+}
+
+int ps_get_info(ps_problem* h, ps_problem_info* info) {
+    if (!h || !info) return fail("null argument");
+    info->dof = h->D; info->num_poses = h->P; info->num_reduced = h->nr; info->num_points = h->L;
+    info->num_var_points = h->nv; info->num_obs = h->N; info->num_edges = h->F; info->num_priors = 0;
+    info->reduced_nnzb = h->nnzb; info->num_pairs = h->npairs; info->reduce_count = h->red_count;
+    info->device_bytes = (int64_t)h->dev_bytes;
+    return 0;
+}
+
+int ps_eval_cost(ps_problem* h, int include_all_constant, double* cost) {
+    if (!h || !cost) return fail("null argument");
+    if (cost_pass(h, include_all_constant, SC_COST)) return -1;
+    if (read_scalars(h)) return -1;
+    *cost = h->h_scalars[SC_COST];
+    return 0;
+}
+
+int ps_linearize(ps_problem* h, double lambda) {
+    if (!h) return fail("null argument");
+    return linearize(h, lambda);
+}
+
+int ps_reduce_buffer(ps_problem* h, void** dev_ptr, int64_t* count) {
+    if (!h || !dev_ptr || !count) return fail("null argument");
+    *dev_ptr = h->red; *count = h->red_count;
+    return 0;
+}
+
+int ps_solve_reduced(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
+    if (!h) return fail("null argument");
+    const int rc = solve_reduced(h, tol, max_iters, iters_out, relres_out);
+    if (rc == 0 && h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    return rc;
+}
+
+int ps_backsub(ps_problem* h) {
+    if (!h) return fail("null argument");
+    return backsub(h);
+}
+
+int ps_get_dx(ps_problem* h, double* dx_pose, double* dx_point) {
+    if (!h) return fail("null argument");
+    if (dx_pose && h->nr) HIP_OK(hipMemcpyAsync(dx_pose, h->x, (size_t)h->nr * h->D * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (dx_point && h->nv) HIP_OK(hipMemcpyAsync(dx_point, h->dxl, (size_t)h->nv * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int ps_step_norm2(ps_problem* h, double* norm2) {
+    if (!h || !norm2) return fail("null argument");
+    if (step_norm(h) || read_scalars(h)) return -1;
+    *norm2 = h->h_scalars[SC_DXNORM2];
+    return 0;
+}
+
+int ps_apply_update(ps_problem* h, double step) {
+    if (!h) return fail("null argument");
+    return apply_update(h, step);
+}
+
+int ps_snapshot_params(ps_problem* h) {
+    if (!h) return fail("null argument");
+    if (h->P) HIP_OK(hipMemcpyAsync(h->poses_snap, h->poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (h->L) HIP_OK(hipMemcpyAsync(h->points_snap, h->points, (size_t)h->L * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int ps_restore_params(ps_problem* h) {
+    if (!h) return fail("null argument");
+    if (h->P) HIP_OK(hipMemcpyAsync(h->poses, h->poses_snap, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (h->L) HIP_OK(hipMemcpyAsync(h->points, h->points_snap, (size_t)h->L * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int ps_get_params(ps_problem* h, double* poses, double* points) {
+    if (!h) return fail("null argument");
+    if (poses && h->P) HIP_OK(hipMemcpyAsync(poses, h->poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (points && h->L) HIP_OK(hipMemcpyAsync(points, h->points, (size_t)h->L * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int ps_set_params(ps_problem* h, const double* poses, const double* points) {
+    if (!h) return fail("null argument");
+    if (poses && h->P) HIP_OK(hipMemcpyAsync(h->poses, poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (points && h->L) HIP_OK(hipMemcpyAsync(h->points, points, (size_t)h->L * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return sync(h);
+}
+
+int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters, int linesearch,
+                    double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out) {
+    if (!h) return fail("null argument");
+    {
+        StageTimer total(h, PS_ST_TOTAL);     // closed before the synchronising read-back
+        if (linearize(h, lambda)) return -1;
+        if (solve_reduced(h, pcg_tol, pcg_max_iters, pcg_iters_out, pcg_relres_out)) return -1;
+        if (backsub(h)) return -1;
+        if (!linesearch && cost_pass(h, 0, SC_LINCOST)) return -1;
+        if (step_norm(h)) return -1;
+        if (apply_update(h, 1.0)) return -1;
+        if (linesearch && cost_pass(h, 1, SC_COST)) return -1;
+    }
+    if (read_scalars(h)) return -1;
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+    if (dx_norm_out) *dx_norm_out = std::sqrt(h->h_scalars[SC_DXNORM2]);
+    return 0;
+}
+
+int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx, double* vals, double* g) {
+    if (!h) return fail("null argument");
+    if (row_ptr) std::memcpy(row_ptr, h->h_row_ptr.data(), h->h_row_ptr.size() * sizeof(int32_t));
+    if (col_idx) std::memcpy(col_idx, h->h_col_idx.data(), h->h_col_idx.size() * sizeof(int32_t));
+    if (vals && h->nnzb) HIP_OK(hipMemcpyAsync(vals, h->S, (size_t)h->nnzb * h->D * h->D * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (g && h->nr) HIP_OK(hipMemcpyAsync(g, h->g, (size_t)h->nr * h->D * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int ps_get_landmark_factors(ps_problem* h, double* cinv, double* c) {
+    if (!h) return fail("null argument");
+    if (cinv && h->nv) HIP_OK(hipMemcpyAsync(cinv, h->Cinv, (size_t)h->nv * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (c && h->nv) HIP_OK(hipMemcpyAsync(c, h->cvec, (size_t)h->nv * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int ps_debug_reproj_blocks(ps_problem* h, double* r, double* jpose, double* jpoint) {
+    if (!h || !r || !jpose || !jpoint) return fail("null argument");
+    if (h->N == 0) return 0;
+    double *dr, *djp, *djl;
+    HIP_OK(hipMalloc((void**)&dr, (size_t)h->N * 3 * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&djp, (size_t)h->N * 18 * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&djl, (size_t)h->N * 9 * sizeof(double)));
+    hipLaunchKernelGGL(k_debug_reproj, dim3(cdiv(h->N, 256)), dim3(256), 0, h->stream, h->N, h->lobs, h->lorig,
+                       h->poses, h->points, h->ogroups, dr, djp, djl);
+    hipMemcpyAsync(r, dr, (size_t)h->N * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(jpose, djp, (size_t)h->N * 18 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(jpoint, djl, (size_t)h->N * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    const int rc = sync(h);
+    hipFree(dr); hipFree(djp); hipFree(djl);
+    return rc;
+}
+
+int ps_set_profiling(ps_problem* h, int enabled) {
+    if (!h) return fail("null argument");
+    h->profiling = enabled != 0;
+    return 0;
+}
+
+int ps_get_stage_times(ps_problem* h, double* ms, int64_t* counts, int reset) {
+    if (!h) return fail("null argument");
+    for (int i = 0; i < PS_NUM_STAGES; ++i) {
+        if (ms) ms[i] = h->stage_ms[i];
+        if (counts) counts[i] = h->stage_n[i];
+        if (reset) { h->stage_ms[i] = 0.0; h->stage_n[i] = 0; }
+    }
+    return 0;
+}
+
+int ps_dense_normal_solve(const double* J, const double* r, int32_t m, int32_t n, double* dx, double* covariance) {
+    if (!J || !r || !dx || m <= 0 || n <= 0) return fail("bad argument");
+    if (n > 2048) return fail("generic (host-evaluated) path supports at most 2048 unknowns");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible");
+    double *dJ = nullptr, *dr = nullptr, *dH = nullptr, *dB = nullptr;
+    int32_t* dst = nullptr;
+    const int nrhs = covariance ? n + 1 : 1;
+    HIP_OK(hipMalloc((void**)&dJ, (size_t)m * n * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&dr, (size_t)m * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&dH, (size_t)n * n * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&dB, (size_t)n * nrhs * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&dst, ST_NWORDS * sizeof(int32_t)));
+    HIP_OK(hipMemset(dst, 0, ST_NWORDS * sizeof(int32_t)));
+    HIP_OK(hipMemcpy(dJ, J, (size_t)m * n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dr, r, (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+    double* dg = nullptr;
+    HIP_OK(hipMalloc((void**)&dg, (size_t)n * sizeof(double)));
+    hipLaunchKernelGGL(k_dense_normal, dim3(cdiv((long)n * n, 256)), dim3(256), 0, 0, m, n, dJ, dr, dH, dg);
+    // B = [g | I]
+    std::vector<double> B((size_t)n * nrhs, 0.0), gh(n);
+    HIP_OK(hipMemcpy(gh.data(), dg, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { B[(size_t)i * nrhs] = gh[i]; if (covariance) B[(size_t)i * nrhs + 1 + i] = 1.0; }
+    HIP_OK(hipMemcpy(dB, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dense_chol_solve, dim3(1), dim3(256), 0, 0, n, nrhs, dH, dB, dst);
+    HIP_OK(hipMemcpy(B.data(), dB, B.size() * sizeof(double), hipMemcpyDeviceToHost));
+    int32_t st[ST_NWORDS];
+    HIP_OK(hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        dx[i] = B[(size_t)i * nrhs];
+        if (covariance) for (int j = 0; j < n; ++j) covariance[(size_t)i * n + j] = B[(size_t)i * nrhs + 1 + j];
+    }
+    hipFree(dJ); hipFree(dr); hipFree(dH); hipFree(dB); hipFree(dst); hipFree(dg);
+    if (st[ST_DIAG_FAIL]) return fail("normal matrix is not positive definite");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,772 @@
+// ps_kernels.h -- device kernels of the Gauss-Newton / LM iteration (gfx950, fp64).
+//
+// Pipeline per iteration:
+//   k_landmark_pass   thread / landmark : H_ll, b_l -> chol -> c_l, Z_i = W_i C^-T
+//   k_pose_pass       WG / pose chunk   : J_p^T J_p - Z Z^T, -J_p^T r - Z c  (tree reduce)
+//   k_pose_finalize   WG / pose         : chunk partials -> diagonal S block, g
+//   k_schur_pairs     wave / S block    : S_ij -= sum Z_i Z_j^T over shared landmarks
+//   k_factor_pass     wave / pose edge  : pose-pose & prior blocks via LDS-staged 6x6 Jacobians
+//   k_factor_assemble thread / S entry  : gather edge blocks into S, g
+//   k_pcg_*           block-Jacobi PCG, 2 launches / iteration
+//   k_backsub         thread / landmark : dx_l = C^-T (c_l - sum Z_i^T dx_p)
+//   k_update_*        retraction, k_cost_* robust cost
+// Every reduction has a fixed order: results are bitwise reproducible run to run.
+#pragma once
+#include "ps_math.h"
+
+struct __attribute__((aligned(32))) LObs {   // one reprojection observation, 32 B
+    double u, v, d;
+    int32_t pose_grp;      // pose index (low 24 bits) | group (high 8 bits)
+    int32_t point;
+};
+struct PItem { int32_t rid, start, end, pad; };
+struct PairItem { int32_t slot, slotT, start, end; };
+struct FactorGroup { double S[36]; int32_t loss_id; int32_t pad; double loss_k; };
+
+#define PS_POSE_OF(o) ((o).pose_grp & 0xFFFFFF)
+#define PS_GRP_OF(o) (((uint32_t)(o).pose_grp) >> 24)
+
+// status words
+enum { ST_LM_FAIL = 0, ST_DIAG_FAIL = 1, ST_PCG_DONE = 2, ST_PCG_ITERS = 3, ST_NWORDS = 8 };
+// scalar slots
+enum { SC_COST = 0, SC_DXNORM2 = 1, SC_LINCOST = 2, SC_RR0 = 3, SC_RRFINAL = 4, SC_THRESH = 5, SC_NWORDS = 8 };
+
+PS_DEV double wave_sum(double v) {          // xor butterfly: every lane gets the total
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// deterministic block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in every thread
+PS_DEV double block_sum(double v, double* lds /* >= 16 doubles */) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += lds[i];
+    return t;
+}
+
+// ---------------------------------------------------------------------------
+// landmark pass
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_landmark_pass(
+    int nv, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_point,
+    const LObs* __restrict__ lobs, const double* __restrict__ poses,
+    const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
+    const ObsGroup* __restrict__ groups, double lambda,
+    double* __restrict__ Z, double* __restrict__ Cinv, double* __restrict__ cvec,
+    int32_t* __restrict__ status)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    const int b = lm_ptr[v], e = lm_ptr[v + 1];
+    const int pt = lm_point[v];
+    const double pw[3] = {points[3 * pt], points[3 * pt + 1], points[3 * pt + 2]};
+
+    double H00 = 0, H10 = 0, H11 = 0, H20 = 0, H21 = 0, H22 = 0, b0 = 0, b1 = 0, b2 = 0;
+    for (int i = b; i < e; ++i) {
+        const LObs o = lobs[i];
+        const Se3 T = se3_load(poses + 12 * PS_POSE_OF(o));
+        ReprojEval ev;
+        reproj_eval<false, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        const double* J = ev.Jl;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            H00 += J[3 * k] * J[3 * k];
+            H10 += J[3 * k + 1] * J[3 * k];
+            H11 += J[3 * k + 1] * J[3 * k + 1];
+            H20 += J[3 * k + 2] * J[3 * k];
+            H21 += J[3 * k + 2] * J[3 * k + 1];
+            H22 += J[3 * k + 2] * J[3 * k + 2];
+            b0 -= J[3 * k] * ev.r[k];
+            b1 -= J[3 * k + 1] * ev.r[k];
+            b2 -= J[3 * k + 2] * ev.r[k];
+        }
+    }
+    const double damp = 1.0 + lambda;
+    H00 *= damp; H11 *= damp; H22 *= damp;
+    // H_ll = C C^T
+    const double l00 = sqrt(H00);
+    const double l10 = H10 / l00, l20 = H20 / l00;
+    const double d1 = H11 - l10 * l10;
+    const double l11 = sqrt(d1);
+    const double l21 = (H21 - l20 * l10) / l11;
+    const double d2 = H22 - l20 * l20 - l21 * l21;
+    const double l22 = sqrt(d2);
+    if (!(H00 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) atomicAdd(&status[ST_LM_FAIL], 1);
+    // M = C^-1 (lower)
+    const double M00 = 1.0 / l00, M11 = 1.0 / l11, M22 = 1.0 / l22;
+    const double M10 = -l10 * M00 * M11;
+    const double M21 = -l21 * M11 * M22;
+    const double M20 = -(l20 * M00 + l21 * M10) * M22;
+    double* ci = Cinv + 6 * (size_t)v;
+    ci[0] = M00; ci[1] = M10; ci[2] = M11; ci[3] = M20; ci[4] = M21; ci[5] = M22;
+    double* cv = cvec + 3 * (size_t)v;
+    cv[0] = M00 * b0;
+    cv[1] = M10 * b0 + M11 * b1;
+    cv[2] = M20 * b0 + M21 * b1 + M22 * b2;
+
+    for (int i = b; i < e; ++i) {
+        const LObs o = lobs[i];
+        const int pose = PS_POSE_OF(o);
+        if (pose_rid[pose] < 0) continue;
+        const Se3 T = se3_load(poses + 12 * pose);
+        ReprojEval ev;
+        reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        double* z = Z + 18 * (size_t)i;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double w0 = ev.Jp[a] * ev.Jl[0] + ev.Jp[6 + a] * ev.Jl[3] + ev.Jp[12 + a] * ev.Jl[6];
+            const double w1 = ev.Jp[a] * ev.Jl[1] + ev.Jp[6 + a] * ev.Jl[4] + ev.Jp[12 + a] * ev.Jl[7];
+            const double w2 = ev.Jp[a] * ev.Jl[2] + ev.Jp[6 + a] * ev.Jl[5] + ev.Jp[12 + a] * ev.Jl[8];
+            z[3 * a] = w0 * M00;
+            z[3 * a + 1] = w0 * M10 + w1 * M11;
+            z[3 * a + 2] = w0 * M20 + w1 * M21 + w2 * M22;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pose pass: 33 sums per chunk = 21 (upper J^T J - Z Z^T) + 6 (g) + 6 (diag J^T J, for damping)
+// ---------------------------------------------------------------------------
+#define PS_NPOSE_ACC 33
+__global__ __launch_bounds__(256) void k_pose_pass(
+    const PItem* __restrict__ items, const int32_t* __restrict__ pidx,
+    const LObs* __restrict__ lobs, const double* __restrict__ poses,
+    const double* __restrict__ points, const int32_t* __restrict__ point_vid,
+    const ObsGroup* __restrict__ groups, const double* __restrict__ Z,
+    const double* __restrict__ cvec, double* __restrict__ partial)
+{
+    __shared__ double red[4][PS_NPOSE_ACC];
+    const PItem it = items[blockIdx.x];
+    const int i = it.start + threadIdx.x;
+    double acc[PS_NPOSE_ACC];
+#pragma unroll
+    for (int k = 0; k < PS_NPOSE_ACC; ++k) acc[k] = 0.0;
+    if (i < it.end) {
+        const int li = pidx[i];
+        const LObs o = lobs[li];
+        const Se3 T = se3_load(poses + 12 * PS_POSE_OF(o));
+        const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
+        ReprojEval ev;
+        reproj_eval<true, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b)
+                acc[n++] = ev.Jp[a] * ev.Jp[b] + ev.Jp[6 + a] * ev.Jp[6 + b] + ev.Jp[12 + a] * ev.Jp[12 + b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            acc[21 + a] = -(ev.Jp[a] * ev.r[0] + ev.Jp[6 + a] * ev.r[1] + ev.Jp[12 + a] * ev.r[2]);
+            acc[27 + a] = ev.Jp[a] * ev.Jp[a] + ev.Jp[6 + a] * ev.Jp[6 + a] + ev.Jp[12 + a] * ev.Jp[12 + a];
+        }
+        const int v = point_vid[o.point];
+        if (v >= 0) {
+            double z[18];
+            const double* zp = Z + 18 * (size_t)li;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) z[k] = zp[k];
+            const double c0 = cvec[3 * (size_t)v], c1 = cvec[3 * (size_t)v + 1], c2 = cvec[3 * (size_t)v + 2];
+            n = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b)
+                    acc[n++] -= z[3 * a] * z[3 * b] + z[3 * a + 1] * z[3 * b + 1] + z[3 * a + 2] * z[3 * b + 2];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                acc[21 + a] -= z[3 * a] * c0 + z[3 * a + 1] * c1 + z[3 * a + 2] * c2;
+        }
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < PS_NPOSE_ACC; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) red[w][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < PS_NPOSE_ACC)
+        partial[(size_t)blockIdx.x * PS_NPOSE_ACC + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void k_pose_finalize(
+    int nr, const int32_t* __restrict__ pitem_ptr, const double* __restrict__ partial,
+    const int32_t* __restrict__ diag_slot, double lambda,
+    double* __restrict__ S, double* __restrict__ g)
+{
+    __shared__ double v[PS_NPOSE_ACC];
+    const int rid = blockIdx.x, t = threadIdx.x;
+    if (t < PS_NPOSE_ACC) {
+        double s = 0.0;
+        for (int it = pitem_ptr[rid]; it < pitem_ptr[rid + 1]; ++it) s += partial[(size_t)it * PS_NPOSE_ACC + t];
+        v[t] = s;
+    }
+    __syncthreads();
+    if (t < 36) {
+        const int r = t / 6, c = t % 6;
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        const int idx = a * 6 - (a * (a - 1)) / 2 + (b - a);   // upper-triangle packed index
+        double val = v[idx];
+        if (r == c) val += lambda * v[27 + r];
+        S[(size_t)diag_slot[rid] * 36 + t] += val;
+    }
+    if (t < 6) g[(size_t)rid * 6 + t] += v[21 + t];
+}
+
+// ---------------------------------------------------------------------------
+// Schur off-diagonal blocks: one wave per reduced-system block
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_schur_pairs(
+    int nitems, const PairItem* __restrict__ items, const int2* __restrict__ pairs,
+    const double* __restrict__ Z, double* __restrict__ S)
+{
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= nitems) return;
+    const PairItem it = items[w];
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    for (int i = it.start + lane; i < it.end; i += 64) {
+        const int2 p = pairs[i];
+        double za[18], zb[18];
+        const double* pa = Z + 18 * (size_t)p.x;
+        const double* pb = Z + 18 * (size_t)p.y;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) { za[k] = pa[k]; zb[k] = pb[k]; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                acc[6 * a + b] += za[3 * a] * zb[3 * b] + za[3 * a + 1] * zb[3 * b + 1] + za[3 * a + 2] * zb[3 * b + 2];
+    }
+    double mine = 0.0, mineT = 0.0;
+    const int r = lane / 6, c = lane % 6;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == k) mine = s;
+        if (lane < 36 && c * 6 + r == k) mineT = s;
+    }
+    if (lane < 36) {
+        if (it.slot == it.slotT) {
+            S[(size_t)it.slot * 36 + lane] -= mine + mineT;
+        } else {
+            S[(size_t)it.slot * 36 + lane] -= mine;
+            S[(size_t)it.slotT * 36 + c * 6 + r] -= mine;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pose-pose / prior factors: one wave per factor, Jacobians staged in LDS.
+// scratch row per factor: [H11 | H12 | H22 | g1 | g2]  (3 D^2 + 2 D doubles)
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_factor_pass(
+    int nf, const int32_t* __restrict__ f_i, const int32_t* __restrict__ f_j,
+    const double* __restrict__ f_Tinv, const int32_t* __restrict__ f_grp,
+    const FactorGroup* __restrict__ groups, const double* __restrict__ poses,
+    double* __restrict__ scratch)
+{
+    typedef PoseOps<D> G;
+    constexpr int DD = D * D, ROW = 3 * DD + 2 * D;
+    __shared__ double sJ1[4][36], sJ2[4][36], sr[4][6];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + w;
+    const bool live = f < nf;
+    const bool act = live && lane < DD;
+    const int r = lane / D, c = lane % D;
+    bool binary = false;
+    if (live) {
+        const int i = f_i[f], j = f_j[f];
+        binary = i >= 0;
+        const FactorGroup& grp = groups[f_grp[f]];
+        const typename G::T T2 = G::load(poses + G::W * (size_t)j);
+        const typename G::T To = G::load(f_Tinv + G::W * (size_t)f);
+        typename G::T E, T21 = T2;
+        if (binary) {
+            const typename G::T T1i = G::inv(G::load(poses + G::W * (size_t)i));
+            E = G::mul(T2, G::mul(T1i, To));            // T_2 (T_1^-1 T_obs^-1)
+            T21 = G::mul(T2, T1i);
+        } else {
+            E = G::mul(T2, To);
+        }
+        double xi[D], s[D];
+        G::log(E, xi);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double rk = 0.0;
+#pragma unroll
+            for (int m = 0; m < D; ++m) rk += grp.S[k * D + m] * xi[m];
+            s[k] = sqrt(ps_loss_weight(grp.loss_id, grp.loss_k, rk));
+            if (lane == 0) sr[w][k] = s[k] * rk;
+        }
+        if (act) {
+            // row r of J~ (scaled by s_r): J1 = -S Ad(T_2 T_1^-1), J2 = S
+            double sk = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) if (k == r) sk = s[k];
+            double j1 = 0.0;
+            if (binary) {
+#pragma unroll
+                for (int m = 0; m < D; ++m) j1 -= grp.S[r * D + m] * G::adj(T21, m, c);
+            }
+            sJ1[w][lane] = sk * j1;
+            sJ2[w][lane] = sk * grp.S[lane];
+        }
+    }
+    __syncthreads();
+    if (!act) return;
+    double h11 = 0.0, h12 = 0.0, h22 = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        h11 += sJ1[w][k * D + r] * sJ1[w][k * D + c];
+        h12 += sJ1[w][k * D + r] * sJ2[w][k * D + c];
+        h22 += sJ2[w][k * D + r] * sJ2[w][k * D + c];
+    }
+    double* out = scratch + (size_t)f * ROW;
+    out[lane] = h11; out[DD + lane] = h12; out[2 * DD + lane] = h22;
+    if (c == 0) {
+        double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { g1 -= sJ1[w][k * D + r] * sr[w][k]; g2 -= sJ2[w][k * D + r] * sr[w][k]; }
+        out[3 * DD + r] = g1; out[3 * DD + D + r] = g2;
+    }
+}
+
+// gather factor blocks into S (one thread per entry of every touched block) and g
+template <int D>
+__global__ __launch_bounds__(256) void k_factor_assemble(
+    int nslots, const int32_t* __restrict__ eslots, const int32_t* __restrict__ eptr,
+    const int2* __restrict__ eitems /* (scratch offset, transpose) */,
+    const int32_t* __restrict__ slot_is_diag,
+    int ng, const int32_t* __restrict__ gptr, const int32_t* __restrict__ gitems,
+    const double* __restrict__ scratch, double lambda, double* __restrict__ S, double* __restrict__ g)
+{
+    constexpr int DD = D * D;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nslots * DD) {
+        const int si = t / DD, e = t % DD, r = e / D, c = e % D;
+        double s = 0.0;
+        for (int k = eptr[si]; k < eptr[si + 1]; ++k) {
+            const int2 itx = eitems[k];
+            s += scratch[(size_t)itx.x + (itx.y ? c * D + r : e)];
+        }
+        const int slot = eslots[si];
+        if (r == c && slot_is_diag[si]) s *= (1.0 + lambda);
+        S[(size_t)slot * DD + e] += s;
+    }
+    const int u = t - nslots * DD;
+    if (u >= 0 && u < ng * D) {
+        const int rid = u / D, r = u % D;
+        double s = 0.0;
+        for (int k = gptr[rid]; k < gptr[rid + 1]; ++k) s += scratch[(size_t)gitems[k] + r];
+        g[(size_t)rid * D + r] += s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// block-Jacobi PCG on the reduced system (BSR, D x D blocks, both triangles)
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_block_jacobi(
+    int nr, const int32_t* __restrict__ diag_slot, const double* __restrict__ S,
+    double* __restrict__ Minv, int32_t* __restrict__ status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nr) return;
+    double A[D][D], L[D][D], Li[D][D];
+    const double* s = S + (size_t)diag_slot[i] * D * D;
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) { A[r][c] = s[r * D + c]; L[r][c] = 0.0; Li[r][c] = 0.0; }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        ok = ok && (d > 0.0);
+        const double l = sqrt(d);
+        L[j][j] = l;
+#pragma unroll
+        for (int i2 = j + 1; i2 < D; ++i2) {
+            double v = A[i2][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i2][k] * L[j][k];
+            L[i2][j] = v / l;
+        }
+    }
+    // Li = L^-1 (lower), column by column
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        Li[c][c] = 1.0 / L[c][c];
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = c; k < r; ++k) v -= L[r][k] * Li[k][c];
+            Li[r][c] = v / L[r][r];
+        }
+    }
+    if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
+    double* m = Minv + (size_t)i * D * D;     // A^-1 = Li^T Li
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = (r > c ? r : c); k < D; ++k) v += Li[k][r] * Li[k][c];
+            m[r * D + c] = v;
+        }
+}
+
+// vector-update kernels: each wave owns 64/D whole block rows (a block row never
+// straddles two waves, so its D lanes read r[] before any of them overwrites it)
+#define PS_PCG_BRW(D) (64 / (D))
+#define PS_PCG_BR(D) (4 * PS_PCG_BRW(D))
+
+// x = 0, r = g, z = M^-1 r, partial r.z and r.r
+template <int D>
+__global__ __launch_bounds__(256) void k_pcg_init(
+    int nr, const double* __restrict__ g, const double* __restrict__ Minv,
+    double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+    double* __restrict__ rz_part, double* __restrict__ rr_part, int32_t* __restrict__ status)
+{
+    __shared__ double lds[16];
+    const int t = threadIdx.x;
+    const int lane_ = t & 63;
+    const int brow = blockIdx.x * PS_PCG_BR(D) + (t >> 6) * PS_PCG_BRW(D) + lane_ / D, rr_ = lane_ % D;
+    double prz = 0.0, prr = 0.0;
+    if (lane_ < PS_PCG_BRW(D) * D && brow < nr) {
+        double rn[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) rn[c] = g[(size_t)brow * D + c];
+        double zi = 0.0, ri = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            zi += Minv[(size_t)brow * D * D + rr_ * D + c] * rn[c];
+            if (c == rr_) ri = rn[c];
+        }
+        const size_t i = (size_t)brow * D + rr_;
+        x[i] = 0.0; r[i] = ri; z[i] = zi;
+        prz = zi * ri; prr = ri * ri;
+    }
+    const double a = block_sum(prz, lds);
+    const double b = block_sum(prr, lds);
+    if (t == 0) { rz_part[blockIdx.x] = a; rr_part[blockIdx.x] = b; }
+    if (blockIdx.x == 0 && t == 0) { status[ST_PCG_DONE] = 0; status[ST_PCG_ITERS] = 0; }
+}
+
+// A: (beta from the partials) p = z + beta p_old on the fly; q = S p; partial p.q
+template <int D>
+__global__ __launch_bounds__(256) void k_pcg_spmv(
+    int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+    const double* __restrict__ S, const double* __restrict__ z,
+    const double* __restrict__ p_old, double* __restrict__ p_new, double* __restrict__ q,
+    const double* __restrict__ rz_part, const double* __restrict__ rr_part, int npartB,
+    double* __restrict__ pq_part, double* __restrict__ hist, int k, double tol2,
+    int32_t* __restrict__ status, double* __restrict__ scalars)
+{
+    if (status[ST_PCG_DONE]) return;
+    __shared__ double lds[4];
+    constexpr int DD = D * D;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double rz = 0.0, rr = 0.0;
+    for (int i = lane; i < npartB; i += 64) { rz += rz_part[i]; rr += rr_part[i]; }
+    rz = wave_sum(rz); rr = wave_sum(rr);
+    const double thresh = (k == 0) ? tol2 * rr : scalars[SC_THRESH];
+    const bool first_wave = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (!(rr > thresh)) {                      // converged (also catches rr == 0 and NaN)
+        if (first_wave) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = rr; if (k == 0) scalars[SC_RR0] = rr; }
+        return;
+    }
+    const double beta = (k == 0) ? 0.0 : rz / hist[k - 1];
+    if (first_wave) {
+        hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rr;
+        if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = rr; }
+    }
+    const int row = blockIdx.x * 4 + w;
+    const int r = lane / D, c = lane % D;
+    double acc = 0.0;
+    if (row < nr && lane < DD) {
+        for (int b = row_ptr[row]; b < row_ptr[row + 1]; ++b) {
+            const size_t j = (size_t)col_idx[b] * D + c;
+            acc += S[(size_t)b * DD + lane] * (z[j] + beta * p_old[j]);
+        }
+    }
+    // sum the D lanes of a row (c = 0..D-1 are adjacent lanes)
+    double t1 = acc + __shfl_down(acc, 1, 64);
+    double qr;
+    if (D == 6) { const double t2 = t1 + __shfl_down(t1, 2, 64); qr = t2 + __shfl_down(t1, 4, 64); }
+    else { qr = t1 + __shfl_down(acc, 2, 64); }
+    double pq = 0.0;
+    if (row < nr && lane < DD && c == 0) {
+        const size_t i = (size_t)row * D + r;
+        const double pn = z[i] + beta * p_old[i];
+        p_new[i] = pn; q[i] = qr;
+        pq = pn * qr;
+    }
+    pq = wave_sum(pq);
+    if (lane == 0) lds[w] = pq;
+    __syncthreads();
+    if (threadIdx.x == 0) pq_part[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+}
+
+// B: alpha = rz / p.q ; x += alpha p ; r -= alpha q ; z = M^-1 r ; partial r.z, r.r
+template <int D>
+__global__ __launch_bounds__(256) void k_pcg_update(
+    int nr, const double* __restrict__ Minv, const double* __restrict__ p,
+    const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r,
+    double* __restrict__ z, const double* __restrict__ pq_part, int npartA,
+    const double* __restrict__ hist, int k, double* __restrict__ rz_part,
+    double* __restrict__ rr_part, const int32_t* __restrict__ status)
+{
+    if (status[ST_PCG_DONE]) return;
+    __shared__ double lds[16];
+    const int t = threadIdx.x;
+    double pq = 0.0;
+    for (int i = t; i < npartA; i += 256) pq += pq_part[i];
+    pq = block_sum(pq, lds);
+    const double alpha = hist[k] / pq;
+    const int lane_ = t & 63;
+    const int brow = blockIdx.x * PS_PCG_BR(D) + (t >> 6) * PS_PCG_BRW(D) + lane_ / D, rr_ = lane_ % D;
+    double prz = 0.0, prr = 0.0;
+    if (lane_ < PS_PCG_BRW(D) * D && brow < nr) {
+        double rn[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) rn[c] = r[(size_t)brow * D + c] - alpha * q[(size_t)brow * D + c];
+        double zi = 0.0, ri = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            zi += Minv[(size_t)brow * D * D + rr_ * D + c] * rn[c];
+            if (c == rr_) ri = rn[c];
+        }
+        const size_t i = (size_t)brow * D + rr_;
+        x[i] += alpha * p[i];
+        prz = zi * ri; prr = ri * ri;
+        r[i] = ri; z[i] = zi;       // same-wave lanes have already loaded r[] (see PS_PCG_BRW)
+    }
+    const double a = block_sum(prz, lds);
+    const double b = block_sum(prr, lds);
+    if (t == 0) { rz_part[blockIdx.x] = a; rr_part[blockIdx.x] = b; }
+}
+
+// ---------------------------------------------------------------------------
+// back-substitution, retraction, cost, small reductions
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_backsub(
+    int nv, const int32_t* __restrict__ lm_ptr, const LObs* __restrict__ lobs,
+    const int32_t* __restrict__ pose_rid, const double* __restrict__ Z,
+    const double* __restrict__ Cinv, const double* __restrict__ cvec,
+    const double* __restrict__ xp, double* __restrict__ dxl)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nv) return;
+    double a0 = cvec[3 * (size_t)v], a1 = cvec[3 * (size_t)v + 1], a2 = cvec[3 * (size_t)v + 2];
+    for (int i = lm_ptr[v]; i < lm_ptr[v + 1]; ++i) {
+        const int rid = pose_rid[PS_POSE_OF(lobs[i])];
+        if (rid < 0) continue;
+        const double* z = Z + 18 * (size_t)i;
+        const double* x = xp + 6 * (size_t)rid;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double xa = x[a];
+            a0 -= z[3 * a] * xa; a1 -= z[3 * a + 1] * xa; a2 -= z[3 * a + 2] * xa;
+        }
+    }
+    const double* m = Cinv + 6 * (size_t)v;    // dx = M^T a
+    dxl[3 * (size_t)v] = m[0] * a0 + m[1] * a1 + m[3] * a2;
+    dxl[3 * (size_t)v + 1] = m[2] * a1 + m[4] * a2;
+    dxl[3 * (size_t)v + 2] = m[5] * a2;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_update_poses(
+    int P, const int32_t* __restrict__ pose_rid, const double* __restrict__ xp,
+    double step, double* __restrict__ poses)
+{
+    typedef PoseOps<D> G;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int rid = pose_rid[i];
+    if (rid < 0) return;
+    double xi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) xi[k] = step * xp[(size_t)rid * D + k];
+    G::store(poses + G::W * (size_t)i, G::mul(G::exp(xi), G::load(poses + G::W * (size_t)i)));
+}
+
+__global__ __launch_bounds__(256) void k_update_points(
+    int nv, const int32_t* __restrict__ lm_point, const double* __restrict__ dxl,
+    double step, double* __restrict__ points)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * nv) return;
+    points[3 * (size_t)lm_point[t / 3] + t % 3] += step * dxl[t];
+}
+
+// robust cost of the reprojection blocks: one partial per workgroup
+__global__ __launch_bounds__(256) void k_cost_reproj(
+    long n, const LObs* __restrict__ lobs, const double* __restrict__ poses,
+    const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
+    const int32_t* __restrict__ point_vid, const ObsGroup* __restrict__ groups,
+    int include_all, double* __restrict__ partials)
+{
+    __shared__ double lds[16];
+    double c = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const LObs o = lobs[i];
+        const int pose = PS_POSE_OF(o);
+        if (!include_all && pose_rid[pose] < 0 && point_vid[o.point] < 0) continue;
+        const Se3 T = se3_load(poses + 12 * pose);
+        const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
+        ReprojEval ev;
+        reproj_eval<false, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        c += ev.cost;
+    }
+    c = block_sum(c, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = c;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_cost_factors(
+    int nf, const int32_t* __restrict__ f_i, const int32_t* __restrict__ f_j,
+    const double* __restrict__ f_Tinv, const int32_t* __restrict__ f_grp,
+    const FactorGroup* __restrict__ groups, const double* __restrict__ poses,
+    const int32_t* __restrict__ pose_rid, int include_all, double* __restrict__ partials)
+{
+    typedef PoseOps<D> G;
+    __shared__ double lds[16];
+    double cst = 0.0;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
+        const int i = f_i[f], j = f_j[f];
+        if (!include_all && pose_rid[j] < 0 && (i < 0 || pose_rid[i] < 0)) continue;
+        const FactorGroup& grp = groups[f_grp[f]];
+        const typename G::T T2 = G::load(poses + G::W * (size_t)j);
+        const typename G::T To = G::load(f_Tinv + G::W * (size_t)f);
+        typename G::T E;
+        if (i >= 0) E = G::mul(T2, G::mul(G::inv(G::load(poses + G::W * (size_t)i)), To));
+        else E = G::mul(T2, To);
+        double xi[D];
+        G::log(E, xi);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double rk = 0.0;
+#pragma unroll
+            for (int m = 0; m < D; ++m) rk += grp.S[k * D + m] * xi[m];
+            cst += ps_loss_rho(grp.loss_id, grp.loss_k, rk);
+        }
+    }
+    cst = block_sum(cst, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = cst;
+}
+
+__global__ __launch_bounds__(256) void k_sumsq_partials(
+    long n, const double* __restrict__ v, double scale, double* __restrict__ partials)
+{
+    __shared__ double lds[16];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double a = scale * v[i];
+        s += a * a;
+    }
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// out[0] = sum(partials[0..n))  (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void k_reduce_partials(int n, const double* __restrict__ partials,
+                                                          double* __restrict__ out)
+{
+    __shared__ double lds[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// debug tap: IRLS-scaled residual / Jacobian blocks in ORIGINAL observation order
+__global__ __launch_bounds__(256) void k_debug_reproj(
+    long n, const LObs* __restrict__ lobs, const int32_t* __restrict__ lorig,
+    const double* __restrict__ poses, const double* __restrict__ points,
+    const ObsGroup* __restrict__ groups, double* __restrict__ r, double* __restrict__ jp,
+    double* __restrict__ jl)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const LObs o = lobs[i];
+    const Se3 T = se3_load(poses + 12 * PS_POSE_OF(o));
+    const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
+    ReprojEval ev;
+    reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+    const size_t k = (size_t)lorig[i];
+    for (int a = 0; a < 3; ++a) r[3 * k + a] = ev.r[a];
+    for (int a = 0; a < 18; ++a) jp[18 * k + a] = ev.Jp[a];
+    for (int a = 0; a < 9; ++a) jl[9 * k + a] = ev.Jl[a];
+}
+
+// ---------------------------------------------------------------------------
+// dense generic path: H = J^T J, g = -J^T r, in-place Cholesky solve (one workgroup)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_normal(int m, int n, const double* __restrict__ J,
+                                                       const double* __restrict__ r,
+                                                       double* __restrict__ H, double* __restrict__ g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n * n) {
+        const int a = t / n, b = t % n;
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += J[(size_t)k * n + a] * J[(size_t)k * n + b];
+        H[t] = s;
+    }
+    if (t < n) {
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s -= J[(size_t)k * n + t] * r[k];
+        g[t] = s;
+    }
+}
+
+// H (n x n, row-major, overwritten by its lower Cholesky factor); B (n x nrhs, row-major) <- H^-1 B
+__global__ __launch_bounds__(256) void k_dense_chol_solve(int n, int nrhs, double* __restrict__ H,
+                                                           double* __restrict__ B, int32_t* __restrict__ status)
+{
+    const int t = threadIdx.x;
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        if (t == 0) {
+            double d = H[(size_t)j * n + j];
+            for (int k = 0; k < j; ++k) d -= H[(size_t)j * n + k] * H[(size_t)j * n + k];
+            if (!(d > 0.0)) atomicAdd(&status[ST_DIAG_FAIL], 1);
+            H[(size_t)j * n + j] = sqrt(d);
+        }
+        __syncthreads();
+        const double l = H[(size_t)j * n + j];
+        for (int i = j + 1 + t; i < n; i += 256) {
+            double v = H[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) v -= H[(size_t)i * n + k] * H[(size_t)j * n + k];
+            H[(size_t)i * n + j] = v / l;
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < nrhs; c += 256) {            // one right-hand side per thread
+        for (int i = 0; i < n; ++i) {                // L y = b
+            double v = B[(size_t)i * nrhs + c];
+            for (int k = 0; k < i; ++k) v -= H[(size_t)i * n + k] * B[(size_t)k * nrhs + c];
+            B[(size_t)i * nrhs + c] = v / H[(size_t)i * n + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {           // L^T x = y
+            double v = B[(size_t)i * nrhs + c];
+            for (int k = i + 1; k < n; ++k) v -= H[(size_t)k * n + i] * B[(size_t)k * nrhs + c];
+            B[(size_t)i * nrhs + c] = v / H[(size_t)i * n + i];
+        }
+    }
+}

@@ -1,0 +1,179 @@
+"""DeviceProblem: a LoweredProblem resident in HBM behind the C ABI.
+
+Thin, stateless-on-the-host wrapper: every method maps to one ``ps_*`` entry
+point of include/pyslam_hip.h.  ``Problem.solve`` (pyslam_amd/problem.py) and
+bench.py drive it; multi-GPU sharding lives in pyslam_amd/distributed.py.
+"""
+import ctypes as C
+
+import numpy as np
+
+from pyslam_amd import _native as nat
+
+
+class DeviceProblem:
+    def __init__(self, lp, stream=None, extra_pairs=None):
+        lib = nat.require_gpu()
+        self._lib = lib
+        self.lp = lp
+        self.dof = lp.dof
+        d = nat.ProblemDesc()
+        keep = []       # host arrays must outlive the create call only
+
+        def F(a):
+            a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); return nat.f64p(a)
+
+        def I(a):
+            a = np.ascontiguousarray(a, dtype=np.int32); keep.append(a); return nat.i32p(a)
+
+        d.dof = lp.dof
+        d.num_poses, d.poses, d.pose_rid = lp.num_poses, F(lp.poses), I(lp.pose_rid)
+        d.num_points, d.points, d.point_vid = lp.num_points, F(lp.points), I(lp.point_vid)
+        d.num_obs = lp.num_obs
+        d.obs_pose, d.obs_point, d.obs_uvd, d.obs_grp = I(lp.obs_pose), I(lp.obs_point), F(lp.obs_uvd), I(lp.obs_grp)
+        d.num_cams, d.cams = lp.cams.shape[0], F(lp.cams)
+        d.num_stiff3, d.stiff3 = lp.stiff3.shape[0], F(lp.stiff3)
+        d.num_obs_groups, d.obs_groups = lp.obs_groups.shape[0], F(lp.obs_groups)
+        d.num_edges = lp.num_edges
+        d.e_i, d.e_j, d.e_Tobs_inv, d.e_grp = I(lp.e_i), I(lp.e_j), F(lp.e_Tobs_inv), I(lp.e_grp)
+        d.num_priors = lp.num_priors
+        d.u_i, d.u_Tobs_inv, d.u_grp = I(lp.u_i), F(lp.u_Tobs_inv), I(lp.u_grp)
+        d.num_stiffd, d.stiffd = lp.stiffd.shape[0], F(lp.stiffd)
+        d.num_edge_groups, d.edge_groups = lp.edge_groups.shape[0], F(lp.edge_groups)
+        if extra_pairs is not None and len(extra_pairs[0]):
+            d.num_extra_pairs = len(extra_pairs[0])
+            d.extra_pair_i, d.extra_pair_j = I(extra_pairs[0]), I(extra_pairs[1])
+        self._h = nat.H()
+        nat.check(lib.ps_problem_create(C.byref(d), C.c_void_p(stream or 0), C.byref(self._h)))
+        info = nat.ProblemInfo()
+        nat.check(lib.ps_get_info(self._h, C.byref(info)))
+        self.info = {k: getattr(info, k) for k, _ in nat.ProblemInfo._fields_}
+        self.nr, self.nv = info.num_reduced, info.num_var_points
+
+    # ---- lifetime ------------------------------------------------------
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.ps_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- hot path ------------------------------------------------------
+    def eval_cost(self, include_all_constant=True):
+        c = C.c_double()
+        nat.check(self._lib.ps_eval_cost(self._h, int(include_all_constant), C.byref(c)))
+        return c.value
+
+    def gn_iteration(self, lm_lambda=0., pcg_tol=1e-12, pcg_max_iters=1000, linesearch=True):
+        """-> (cost, ||dx||, pcg iterations, pcg relative residual); parameters are updated."""
+        cost, nrm, rel, it = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        nat.check(self._lib.ps_gn_iteration(self._h, lm_lambda, pcg_tol, pcg_max_iters, int(linesearch),
+                                            C.byref(cost), C.byref(nrm), C.byref(it), C.byref(rel)))
+        return cost.value, nrm.value, it.value, rel.value
+
+    def linearize(self, lm_lambda=0.):
+        nat.check(self._lib.ps_linearize(self._h, lm_lambda))
+
+    def solve_reduced(self, tol=1e-12, max_iters=1000):
+        rel, it = C.c_double(), C.c_int()
+        nat.check(self._lib.ps_solve_reduced(self._h, tol, max_iters, C.byref(it), C.byref(rel)))
+        return it.value, rel.value
+
+    def backsub(self):
+        nat.check(self._lib.ps_backsub(self._h))
+
+    def apply_update(self, step=1.0):
+        nat.check(self._lib.ps_apply_update(self._h, step))
+
+    def step_norm(self):
+        n2 = C.c_double()
+        nat.check(self._lib.ps_step_norm2(self._h, C.byref(n2)))
+        return float(np.sqrt(n2.value))
+
+    def snapshot(self):
+        nat.check(self._lib.ps_snapshot_params(self._h))
+
+    def restore(self):
+        nat.check(self._lib.ps_restore_params(self._h))
+
+    # ---- data movement -------------------------------------------------
+    def get_dx(self):
+        """(dx_pose (nr, dof), dx_point (nv, 3)) in device order."""
+        xp = np.zeros((self.nr, self.dof))
+        xl = np.zeros((self.nv, 3))
+        nat.check(self._lib.ps_get_dx(self._h, nat.f64p(xp), nat.f64p(xl)))
+        return xp, xl
+
+    def get_params(self):
+        poses = np.zeros((self.lp.num_poses, self.lp.pose_width))
+        points = np.zeros((self.lp.num_points, 3))
+        nat.check(self._lib.ps_get_params(self._h, nat.f64p(poses), nat.f64p(points)))
+        return poses, points
+
+    def set_params(self, poses=None, points=None):
+        p = None if poses is None else np.ascontiguousarray(poses, dtype=np.float64)
+        q = None if points is None else np.ascontiguousarray(points, dtype=np.float64)
+        nat.check(self._lib.ps_set_params(self._h, nat.f64p(p), nat.f64p(q)))
+
+    def reduce_buffer(self):
+        """(device pointer, number of doubles) of [S | g | cost] for the multi-GPU all-reduce."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        nat.check(self._lib.ps_reduce_buffer(self._h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    # ---- parity taps ---------------------------------------------------
+    def reduced_system(self):
+        """BSR (row_ptr, col_idx, vals (nnzb, d, d), g (nr*d,))."""
+        nnzb, d = self.info['reduced_nnzb'], self.dof
+        rp = np.zeros(self.nr + 1, dtype=np.int32)
+        ci = np.zeros(max(nnzb, 1), dtype=np.int32)
+        vals = np.zeros((max(nnzb, 1), d, d))
+        g = np.zeros(max(self.nr * d, 1))
+        nat.check(self._lib.ps_get_reduced_system(self._h, nat.i32p(rp), nat.i32p(ci), nat.f64p(vals), nat.f64p(g)))
+        return rp, ci[:nnzb], vals[:nnzb], g[:self.nr * d]
+
+    def reduced_dense(self):
+        rp, ci, vals, g = self.reduced_system()
+        d, n = self.dof, self.nr * self.dof
+        S = np.zeros((n, n))
+        for r in range(self.nr):
+            for k in range(rp[r], rp[r + 1]):
+                S[r * d:(r + 1) * d, ci[k] * d:(ci[k] + 1) * d] = vals[k]
+        return S, g
+
+    def landmark_factors(self):
+        cinv, c = np.zeros((self.nv, 6)), np.zeros((self.nv, 3))
+        nat.check(self._lib.ps_get_landmark_factors(self._h, nat.f64p(cinv), nat.f64p(c)))
+        return cinv, c
+
+    def debug_reproj_blocks(self):
+        n = self.lp.num_obs
+        r, jp, jl = np.zeros((n, 3)), np.zeros((n, 3, 6)), np.zeros((n, 3, 3))
+        nat.check(self._lib.ps_debug_reproj_blocks(self._h, nat.f64p(r), nat.f64p(jp), nat.f64p(jl)))
+        return r, jp, jl
+
+    # ---- tracing -------------------------------------------------------
+    def set_profiling(self, on=True):
+        nat.check(self._lib.ps_set_profiling(self._h, int(on)))
+
+    def stage_times(self, reset=False):
+        ms = (C.c_double * nat.PS_NUM_STAGES)()
+        cnt = (C.c_int64 * nat.PS_NUM_STAGES)()
+        nat.check(self._lib.ps_get_stage_times(self._h, ms, cnt, int(reset)))
+        return {n: (ms[i], cnt[i]) for i, n in enumerate(nat.STAGE_NAMES)}
+
+
+def dense_normal_solve(J, r, want_covariance=False):
+    """Host-evaluated generic path: dx = (J^T J)^-1 (-J^T r) on the device."""
+    lib = nat.require_gpu()
+    J = np.ascontiguousarray(J, dtype=np.float64)
+    r = np.ascontiguousarray(r, dtype=np.float64).reshape(-1)
+    m, n = J.shape
+    dx = np.zeros(n)
+    cov = np.zeros((n, n)) if want_covariance else None
+    nat.check(lib.ps_dense_normal_solve(nat.f64p(J), nat.f64p(r), m, n, nat.f64p(dx), nat.f64p(cov)))
+    return (dx, cov) if want_covariance else dx

@@ -1,0 +1,361 @@
+"""Problem / Options: the reference's user-facing API over the HIP core.
+
+Same public surface as reference pyslam/problem.py:11-409 (Options fields,
+``add_residual_block``, ``initialize_params``, ``set_parameters_constant`` /
+``_variable``, ``eval_cost``, ``solve``, ``solve_one_iter``,
+``compute_covariance``, ``get_covariance_block``, ``summary`` and the public
+attributes the reference's tests read).  What differs is where the work runs:
+
+* recognised blocks (reprojection, pose-pose, pose prior -- ``KIND`` tags) are
+  lowered ONCE into HBM tables (pyslam_amd/lowering.py) and the whole
+  Gauss-Newton iteration -- residuals, Jacobians, IRLS weights, J^T J, landmark
+  elimination, block-PCG, back-substitution, retraction, post-step cost -- runs
+  on the MI355X (include/pyslam_hip.h: ps_gn_iteration); the host sees two
+  scalars per iteration and runs the reference's termination logic on them;
+* problems with user-defined blocks / parameters are evaluated through the
+  block protocol on the host (that is user Python code) and only the normal
+  equations are formed and solved on the device (ps_dense_normal_solve).
+
+There is no CPU solver: without the HIP library or a GPU, solve() raises.
+"""
+import copy
+
+import numpy as np
+
+from pyslam_amd.losses import L2Loss
+from pyslam_amd import lowering
+from pyslam_amd.lowering import NotLowerable
+
+
+class Options:
+    """Optimisation options (reference pyslam/problem.py:11-37) plus the knobs
+    of the device solver, whose defaults reproduce the reference (lambda = 0)."""
+
+    def __init__(self):
+        self.max_iters = 100
+        self.min_update_norm = 1e-6
+        self.min_cost = 1e-12
+        self.min_cost_decrease = 0.9
+
+        self.linesearch_alpha = 0.8
+        self.linesearch_max_iters = 10
+        self.linesearch_min_cost_decrease = 0.9
+
+        self.allow_nondecreasing_steps = False
+        self.max_nondecreasing_steps = 3
+
+        self.num_threads = 1            # kept for API compatibility; the device path ignores it
+
+        # build-only
+        self.lm_lambda = 0.             # Marquardt damping lambda * diag(J^T J); 0 = Gauss-Newton
+        self.pcg_tol = 1e-12            # relative residual of the reduced (Schur) solve
+        self.pcg_max_iters = 2000
+
+
+class Problem:
+    def __init__(self, options=Options()):
+        self.options = options
+        self.param_dict = dict()
+        self.residual_blocks = []
+        self.block_param_keys = []
+        self.block_loss_functions = []
+        self.constant_param_keys = []
+
+        self._update_partition_dict = {}
+        self._covariance_matrix = None
+        self._cost_history = []
+
+        self._device = None
+        self._device_sig = None
+        self.solver_stats = []          # per iteration: (pcg iterations, pcg relative residual)
+
+    # ------------------------------------------------------------------
+    # registry (reference problem.py:72-108)
+    # ------------------------------------------------------------------
+    def add_residual_block(self, block, param_keys, loss=L2Loss()):
+        if isinstance(param_keys, str):
+            param_keys = [param_keys]
+        self.residual_blocks.append(block)
+        self.block_param_keys.append(param_keys)
+        self.block_loss_functions.append(loss)
+
+    def initialize_params(self, param_dict):
+        self.param_dict.update(copy.deepcopy(param_dict))
+
+    def set_parameters_constant(self, param_keys):
+        if isinstance(param_keys, str):
+            param_keys = [param_keys]
+        for key in param_keys:
+            if key not in self.constant_param_keys:
+                self.constant_param_keys.append(key)
+
+    def set_parameters_variable(self, param_keys):
+        if isinstance(param_keys, str):
+            param_keys = [param_keys]
+        for key in param_keys:
+            if key in self.constant_param_keys:
+                self.constant_param_keys.remove(key)
+
+    # ------------------------------------------------------------------
+    # lowering / device handle
+    # ------------------------------------------------------------------
+    def _lower(self, param_dict=None):
+        pd = self.param_dict if param_dict is None else param_dict
+        return lowering.lower(pd, self.residual_blocks, self.block_param_keys,
+                              self.block_loss_functions, self.constant_param_keys)
+
+    def _get_device(self, param_dict=None):
+        """DeviceProblem for the current structure; parameters refreshed from param_dict."""
+        from pyslam_amd.device import DeviceProblem
+        lp = self._lower(param_dict)
+        sig = (len(self.residual_blocks), tuple(self.param_dict.keys()), tuple(self.constant_param_keys),
+               lp.num_obs, lp.num_edges, lp.num_priors)
+        if self._device is not None and self._device_sig == sig:
+            self._device.set_params(lp.poses, lp.points)
+            self._device.lp = lp
+        else:
+            if self._device is not None:
+                self._device.close()
+            self._device = DeviceProblem(lp)
+            self._device_sig = sig
+        return self._device
+
+    def _write_back(self, dev):
+        """Copy the device parameter tables into the live param_dict objects."""
+        lp = dev.lp
+        poses, points = dev.get_params()
+        for key, row in zip(lp.pose_keys, poses):
+            R, t = lowering.unpack_pose(row, lp.dof)
+            T = self.param_dict[key]
+            T.rot.mat = R
+            T.trans = t
+        for key, p in zip(lp.point_keys, points):
+            val = self.param_dict[key]
+            if isinstance(val, np.ndarray):
+                val[...] = p
+            else:
+                self.param_dict[key] = p.copy()
+
+    def _dx_in_reference_order(self, dev):
+        xp, xl = dev.get_dx()
+        lp = dev.lp
+        n = max([r.stop for r in self._update_partition_dict.values()] + [0])
+        dx = np.zeros(n)
+        for key, rid in zip(lp.pose_keys, lp.pose_rid):
+            if rid >= 0:
+                dx[self._update_partition_dict[key]] = xp[rid]
+        for key, vid in zip(lp.point_keys, lp.point_vid):
+            if vid >= 0:
+                dx[self._update_partition_dict[key]] = xl[vid]
+        return dx
+
+    # ------------------------------------------------------------------
+    # cost (reference problem.py:110-128)
+    # ------------------------------------------------------------------
+    def eval_cost(self, param_dict=None):
+        try:
+            dev = self._get_device(param_dict)
+        except NotLowerable:
+            return self._eval_cost_host(param_dict)
+        return dev.eval_cost(include_all_constant=True)
+
+    def _eval_cost_host(self, param_dict=None):
+        pd = self.param_dict if param_dict is None else param_dict
+        cost = 0.
+        for block, keys, loss in zip(self.residual_blocks, self.block_param_keys,
+                                     self.block_loss_functions):
+            try:
+                params = [pd[key] for key in keys]
+            except KeyError as e:
+                print("Parameter {} has not been initialized".format(e.args[0]))
+            cost += np.sum(loss.loss(block.evaluate(params)))
+        return cost
+
+    # ------------------------------------------------------------------
+    # solve (reference problem.py:130-180)
+    # ------------------------------------------------------------------
+    def solve(self):
+        self._update_partition_dict = self._get_update_partition_dict()
+        try:
+            dev = self._get_device()
+        except NotLowerable:
+            dev = None
+        opt = self.options
+        self.solver_stats = []
+
+        cost = dev.eval_cost(True) if dev is not None else self._eval_cost_host()
+        dx_norm = 100.
+        optimization_iters = 0
+        nondecreasing_steps_taken = 0
+        self._cost_history = [cost]
+        best_params = None
+        done_optimization = False
+
+        while not done_optimization:
+            optimization_iters += 1
+            prev_cost = cost
+
+            if dev is not None:
+                # one device call: linearise, solve, update, post-step cost
+                cost, dx_norm, its, rel = dev.gn_iteration(
+                    opt.lm_lambda, opt.pcg_tol, opt.pcg_max_iters, opt.linesearch_max_iters > 0)
+                self.solver_stats.append((its, rel))
+            else:
+                dx, cost = self.solve_one_iter()
+                dx_norm = np.linalg.norm(dx)
+                for k, r in self._update_partition_dict.items():
+                    self._perturb_by_key(k, dx[r])
+            self._cost_history.append(cost)
+
+            done_optimization = optimization_iters > opt.max_iters or \
+                dx_norm < opt.min_update_norm or cost < opt.min_cost
+
+            if opt.allow_nondecreasing_steps:
+                if nondecreasing_steps_taken == 0:
+                    if dev is not None:
+                        dev.snapshot()
+                    else:
+                        best_params = copy.deepcopy(self.param_dict)
+                if cost >= opt.min_cost_decrease * prev_cost:
+                    nondecreasing_steps_taken += 1
+                else:
+                    nondecreasing_steps_taken = 0
+                if nondecreasing_steps_taken >= opt.max_nondecreasing_steps:
+                    done_optimization = True
+                    if dev is not None:
+                        dev.restore()
+                    else:
+                        self.param_dict.update(best_params)
+            else:
+                done_optimization = done_optimization or cost >= opt.min_cost_decrease * prev_cost
+
+        if dev is not None:
+            self._write_back(dev)
+        return self.param_dict
+
+    def solve_one_iter(self):
+        """One Gauss-Newton step: (step * dx, cost); parameters are NOT updated
+        (reference problem.py:182-194)."""
+        if not self._update_partition_dict:
+            self._update_partition_dict = self._get_update_partition_dict()
+        opt = self.options
+        try:
+            dev = self._get_device()
+        except NotLowerable:
+            return self._solve_one_iter_host()
+        saved = dev.get_params()
+        dev.linearize(opt.lm_lambda)
+        its, rel = dev.solve_reduced(opt.pcg_tol, opt.pcg_max_iters)
+        dev.backsub()
+        dx = self._dx_in_reference_order(dev)
+        if opt.linesearch_max_iters > 0:
+            dev.apply_update(1.0)                     # the reference's search always ends at step 1
+            cost = dev.eval_cost(True)
+            dev.set_params(*saved)
+        else:
+            cost = dev.eval_cost(False)
+        self.solver_stats.append((its, rel))
+        return dx, cost
+
+    # ---- generic (host-evaluated) path ---------------------------------
+    def _host_jacobian(self):
+        """Dense IRLS-scaled J~, e~ and cost by walking the blocks (reference
+        problem.py:338-360); used only for blocks without a device kernel."""
+        part = self._update_partition_dict
+        n = max([r.stop for r in part.values()] + [0])
+        rows, es, cost = [], [], 0.
+        for block, keys, loss in zip(self.residual_blocks, self.block_param_keys,
+                                     self.block_loss_functions):
+            params = [self.param_dict[key] for key in keys]
+            want = [key not in self.constant_param_keys for key in keys]
+            if not any(want):
+                continue
+            residual, jacobians = block.evaluate(params, want)
+            residual = np.atleast_1d(residual)
+            s = np.sqrt(loss.weight(residual))
+            Jrow = np.zeros((residual.size, n))
+            for key, jac in zip(keys, jacobians):
+                if jac is not None:
+                    jac = np.asarray(jac, dtype=float).reshape(residual.size, -1)
+                    Jrow[:, part[key].start:part[key].stop] += s[:, None] * jac
+            rows.append(Jrow)
+            es.append(s * residual)
+            cost += np.sum(loss.loss(residual))
+        return np.vstack(rows), np.concatenate(es), cost
+
+    def _solve_one_iter_host(self):
+        from pyslam_amd.device import dense_normal_solve
+        J, e, cost = self._host_jacobian()
+        dx = dense_normal_solve(J, e)
+        if self.options.linesearch_max_iters > 0:
+            test = copy.deepcopy(self.param_dict)
+            for k, r in self._update_partition_dict.items():
+                self._perturb_by_key(k, dx[r], test)
+            cost = self._eval_cost_host(test)
+        return dx, cost
+
+    # ------------------------------------------------------------------
+    # covariance (reference problem.py:196-216)
+    # ------------------------------------------------------------------
+    def compute_covariance(self):
+        try:
+            from pyslam_amd.device import dense_normal_solve
+            if not self._update_partition_dict:
+                self._update_partition_dict = self._get_update_partition_dict()
+            J, e, _ = self._host_jacobian()
+            _, self._covariance_matrix = dense_normal_solve(J, e, want_covariance=True)
+        except Exception as e:
+            print('Covariance computation failed!\n{}'.format(e))
+
+    def get_covariance_block(self, param0, param1):
+        try:
+            r0 = self._update_partition_dict[param0]
+            r1 = self._update_partition_dict[param1]
+            return np.squeeze(self._covariance_matrix[r0.start:r0.stop, r1.start:r1.stop])
+        except KeyError as e:
+            print('Cannot compute covariance for constant parameter {}'.format(e.args[0]))
+        return None
+
+    # ------------------------------------------------------------------
+    # reporting (reference problem.py:218-250; text format kept byte-identical)
+    # ------------------------------------------------------------------
+    def summary(self, format='brief'):
+        if not self._cost_history:
+            raise ValueError('solve has not yet been called')
+        if format == 'brief':
+            return 'Iterations: {:3} | Cost: {:12e} --> {:12e}'.format(
+                len(self._cost_history), self._cost_history[0], self._cost_history[-1])
+        if format == 'full':
+            header = '{:>5s} | {:>12s} --> {:>12s} | {:>10s}\n'.format(
+                'Iter', 'Initial cost', 'Final cost', 'Rel change')
+            lines = [header, '-' * len(header) + '\n']
+            for i, (ic, fc) in enumerate(zip(self._cost_history[:-1], self._cost_history[1:])):
+                lines.append('{:5} | {:12e} --> {:12e} | {:+10f}\n'.format(i, ic, fc, (fc - ic) / ic))
+            return ''.join(lines)
+        raise ValueError('Invalid summary format \'{}\'.'.format(format) +
+                         'Valid formats are \'brief\' and \'full\'')
+
+    # ------------------------------------------------------------------
+    # helpers (reference problem.py:252-277, 400-409)
+    # ------------------------------------------------------------------
+    def _get_update_partition_dict(self):
+        out, offset = {}, 0
+        for key, param in self.param_dict.items():
+            if key in self.constant_param_keys:
+                continue
+            if hasattr(param, 'dof'):
+                dof = param.dof
+            elif hasattr(param, '__len__'):
+                dof = len(param)
+            else:
+                dof = 1
+            out[key] = range(offset, offset + dof)
+            offset += dof
+        return out
+
+    def _perturb_by_key(self, key, dx, param_dict=None):
+        pd = self.param_dict if param_dict is None else param_dict
+        try:
+            pd[key].perturb(dx)
+        except AttributeError:
+            pd[key] += dx

@@ -1,0 +1,177 @@
+"""GPU parity: the HIP path (through the C ABI) against the numpy oracle and
+the reference-generated golden vectors.  Run with `-m gpu` on an MI355X."""
+import types
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, golden_lp, golden_options, SOLVE_CASES, rel_err
+from oracle import gn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_BLOCK = 1e-12      # r~, J~, reduced-system blocks
+TOL_COST = 1e-10
+TOL_DX = 1e-8          # dx vs scipy spsolve, PCG relative residual 1e-12
+
+
+def device(lp):
+    from pyslam_amd.device import DeviceProblem
+    return DeviceProblem(lp)
+
+
+def oracle_reduced(lp):
+    """Schur complement of the oracle's normal equations in DEVICE order
+    (poses by rid, landmarks by vid)."""
+    P, b, cost = orc.normal_equations(lp, points_first=False)
+    d, nr = lp.dof, lp.num_reduced
+    n_p = d * nr
+    P = P.toarray()
+    Hpp, Hpl, Hll = P[:n_p, :n_p], P[:n_p, n_p:], P[n_p:, n_p:]
+    if Hll.shape[0] == 0:
+        return Hpp, b[:n_p], cost
+    Hinv = np.linalg.inv(Hll)
+    return Hpp - Hpl @ Hinv @ Hpl.T, b[:n_p] - Hpl @ Hinv @ b[n_p:], cost
+
+
+def device_dx(dev, lp, points_first):
+    xp, xl = dev.get_dx()
+    pose_off, point_off, n = orc.unknown_offsets(lp, points_first)
+    dx = np.zeros(n)
+    for i in np.nonzero(pose_off >= 0)[0]:
+        dx[pose_off[i]:pose_off[i] + lp.dof] = xp[lp.pose_rid[i]]
+    for j in np.nonzero(point_off >= 0)[0]:
+        dx[point_off[j]:point_off[j] + 3] = xl[lp.point_vid[j]]
+    return dx
+
+
+@pytest.mark.parametrize('name', SOLVE_CASES)
+def test_cost_matches_oracle_and_golden(name):
+    g = load_golden(name)
+    lp = golden_lp(g)
+    dev = device(lp)
+    c = dev.eval_cost(True)
+    assert abs(c - orc.eval_cost(lp)) <= TOL_COST * abs(c)
+    assert abs(c - g['cost_history'][0]) <= TOL_COST * abs(c)
+    c2 = dev.eval_cost(False)
+    assert abs(c2 - float(g['lin_cost'])) <= TOL_COST * abs(c2)
+
+
+@pytest.mark.parametrize('name', [n for n in SOLVE_CASES if 'ba' in n or 'motion' in n])
+def test_reproj_blocks(name):
+    lp = golden_lp(load_golden(name))
+    dev = device(lp)
+    r, jp, jl = dev.debug_reproj_blocks()
+    ro, jpo, jlo = orc.eval_reproj(lp)
+    s = np.sqrt(orc._by_group(lp.obs_groups, lp.obs_grp, 2, 3, orc.loss_weight, ro))
+    assert rel_err(r, s * ro) < TOL_BLOCK
+    assert rel_err(jp, s[:, :, None] * jpo) < TOL_BLOCK
+    assert rel_err(jl, s[:, :, None] * jlo) < TOL_BLOCK
+
+
+@pytest.mark.parametrize('name', SOLVE_CASES)
+def test_reduced_system(name):
+    lp = golden_lp(load_golden(name))
+    dev = device(lp)
+    dev.linearize(0.)
+    S, g = dev.reduced_dense()
+    So, go, _ = oracle_reduced(lp)
+    assert rel_err(S, So) < 1e-11
+    assert rel_err(g, go) < 1e-11
+    assert np.abs(S - S.T).max() <= 1e-13 * np.abs(S).max()
+
+
+@pytest.mark.parametrize('name', SOLVE_CASES)
+def test_first_step_matches_reference_spsolve(name):
+    g = load_golden(name)
+    lp = golden_lp(g)
+    pf = bool(g.get('points_first', True))
+    dev = device(lp)
+    dev.linearize(0.)
+    its, rel = dev.solve_reduced(1e-12, 2000)
+    dev.backsub()
+    dx = device_dx(dev, lp, pf)
+    assert rel <= 1e-11
+    assert rel_err(dx, g['iter_dx'][0]) < TOL_DX, (its, rel)
+    assert abs(dev.step_norm() - np.linalg.norm(dx)) <= 1e-12 * np.linalg.norm(dx)
+
+
+@pytest.mark.parametrize('name', SOLVE_CASES)
+def test_solve_trace_matches_reference(name):
+    """Whole solve() through the Problem API on tables -> objects -> lowering."""
+    import pyslam_amd.synthetic as synthetic
+    from test_host_api import build_namespace
+    g = load_golden(name)
+    lp = golden_lp(g)
+    ns = build_namespace()
+    opt = ns.Options()
+    for k, v in golden_options(g).items():
+        setattr(opt, k, v)
+    problem = synthetic.to_objects(lp, ns, opt, points_first=bool(g.get('points_first', True)))
+    final = problem.solve()
+    ref = g['cost_history']
+    hist = np.array(problem._cost_history)
+    assert len(hist) == len(ref), (hist, ref)
+    big = ref > 1e-9 * ref[0]
+    assert np.allclose(hist[big], ref[big], rtol=1e-7)
+    if 'final_poses' in g:
+        from pyslam_amd.lowering import pack_pose
+        got = np.stack([pack_pose(final[k]) for k in lp.pose_keys])
+        assert np.abs(got - g['final_poses']).max() < 1e-8
+    if 'final_points' in g:
+        got = np.stack([final[k] for k in lp.point_keys])
+        assert np.abs(got - g['final_points']).max() < 1e-7
+
+
+def test_deterministic_bitwise():
+    lp = golden_lp(load_golden('ba_small'))
+    outs = []
+    for _ in range(2):
+        dev = device(lp)
+        dev.linearize(0.)
+        S, g = dev.reduced_dense()
+        dev.solve_reduced(1e-12, 500)
+        dev.backsub()
+        outs.append((S, g) + dev.get_dx())
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_generic_quadratic_and_cubic_goldens():
+    """Reference tests/test_problem.py:59-79 and the cubic notebook goldens."""
+    from pyslam.problem import Problem
+    from pyslam.residuals import QuadraticResidual
+    x = np.linspace(-5, 5, 10)
+    y = x * x - 2. * x + 3.
+    problem = Problem()
+    for xi, yi in zip(x, y):
+        problem.add_residual_block(QuadraticResidual(xi, yi, 1.), ['a', 'b', 'c'])
+    problem.initialize_params({'a': -20., 'b': 10., 'c': -30.})
+    out = problem.solve()
+    for k, v in {'a': 1., 'b': -2., 'c': 3.}.items():
+        assert np.allclose(out[k], v)
+
+    g = load_golden('cubic')
+
+    class CubicResidual:
+        def __init__(self, x, y):
+            self.x, self.y = np.atleast_1d(x), np.atleast_1d(y)
+
+        def evaluate(self, params, compute_jacobians=None):
+            a, b, c, d = params
+            r = a * self.x ** 3 + b * self.x ** 2 + c * self.x + d - self.y
+            if compute_jacobians:
+                return r, np.squeeze([self.x ** 3, self.x ** 2, self.x, np.atleast_1d(1.)])
+            return r
+
+    problem = Problem()
+    for xi, yi in zip(g['x'], g['y']):
+        problem.add_residual_block(CubicResidual(xi, yi), ['a', 'b', 'c', 'd'])
+    problem.initialize_params(dict(zip('abcd', g['init'])))
+    out = problem.solve()
+    assert len(problem._cost_history) == len(g['cost_history'])
+    assert abs(problem._cost_history[0] - g['cost_history'][0]) < 1e-9 * g['cost_history'][0]
+    assert np.allclose([np.squeeze(out[k]) for k in 'abcd'], g['final'], atol=1e-9)
+    problem.compute_covariance()
+    assert np.allclose(problem._covariance_matrix, g['covariance'], rtol=1e-9, atol=1e-15)
+    assert abs(problem.get_covariance_block('a', 'a') - 0.00017205419580419603) < 1e-12
