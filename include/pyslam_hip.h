@@ -115,7 +115,8 @@ int ps_linearize(ps_problem* h, double lambda);
 int ps_reduce_buffer(ps_problem* h, void** dev_ptr, int64_t* count);
 
 /* Block-Jacobi PCG on the reduced system; replaces the splinalg.spsolve call of
-   pyslam/problem.py:186 together with ps_backsub.  Stops at ||r|| <= tol*||g||. */
+   pyslam/problem.py:186 together with ps_backsub.  Stops when the preconditioned residual
+   norm sqrt(r^T M^-1 r) has dropped by `tol` (scale-invariant; relres_out reports it). */
 int ps_solve_reduced(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out);
 
 /* Landmark back-substitution dx_l = Hll^-1 (b_l - W^T dx_p). */

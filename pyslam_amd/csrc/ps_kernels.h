@@ -483,16 +483,19 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(
     double rz = 0.0, rr = 0.0;
     for (int i = lane; i < npartB; i += 64) { rz += rz_part[i]; rr += rr_part[i]; }
     rz = wave_sum(rz); rr = wave_sum(rr);
-    const double thresh = (k == 0) ? tol2 * rr : scalars[SC_THRESH];
+    // convergence in the PRECONDITIONED norm r^T M^-1 r: invariant to the block scaling of the
+    // system (a 1e12 prior next to unit-weight loop closures), unlike ||r||_2 / ||g||_2
+    (void)rr;
+    const double thresh = (k == 0) ? tol2 * rz : scalars[SC_THRESH];
     const bool first_wave = (blockIdx.x == 0 && threadIdx.x == 0);
-    if (!(rr > thresh)) {                      // converged (also catches rr == 0 and NaN)
-        if (first_wave) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = rr; if (k == 0) scalars[SC_RR0] = rr; }
+    if (!(rz > thresh)) {                      // converged (also catches rz == 0 and NaN)
+        if (first_wave) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = rz; if (k == 0) scalars[SC_RR0] = rz; }
         return;
     }
     const double beta = (k == 0) ? 0.0 : rz / hist[k - 1];
     if (first_wave) {
-        hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rr;
-        if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = rr; }
+        hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rz;
+        if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = rz; }
     }
     const int row = blockIdx.x * 4 + w;
     const int r = lane / D, c = lane % D;

@@ -34,6 +34,20 @@ def oracle_reduced(lp):
     return Hpp - Hpl @ Hinv @ Hpl.T, b[:n_p] - Hpl @ Hinv @ b[n_p:], cost
 
 
+def accurate_solve(P, b):
+    """Jacobi-scaled dense solve + iterative refinement with long-double residuals:
+    the arbiter when the normal matrix is too ill-conditioned for SuperLU itself
+    (posegraph examples: prior stiffness 1e6 vs loop 1 => cond(H) ~ 1e12)."""
+    P = np.asarray(P, dtype=float)
+    d = 1. / np.sqrt(np.diag(P))
+    Ps, bs = P * d[:, None] * d[None, :], b * d
+    x = np.linalg.solve(Ps, bs)
+    for _ in range(3):
+        res = bs.astype(np.longdouble) - Ps.astype(np.longdouble) @ x.astype(np.longdouble)
+        x = x + np.linalg.solve(Ps, res.astype(float))
+    return x * d
+
+
 def device_dx(dev, lp, points_first):
     xp, xl = dev.get_dx()
     pose_off, point_off, n = orc.unknown_offsets(lp, points_first)
@@ -88,11 +102,21 @@ def test_first_step_matches_reference_spsolve(name):
     pf = bool(g.get('points_first', True))
     dev = device(lp)
     dev.linearize(0.)
-    its, rel = dev.solve_reduced(1e-12, 2000)
+    # PCG tolerance (preconditioned relative residual).  1e-12 everywhere except the two
+    # reference pose-graph examples: stiffness 1e6 (prior) / 31.6 (odometry) / 1 (loop) leaves
+    # cond(M^-1 S) ~ 1e5 after block-Jacobi scaling, and error <= cond * relres.
+    tol = 1e-14 if name.startswith('posegraph') else 1e-12
+    its, rel = dev.solve_reduced(tol, 2000)
     dev.backsub()
     dx = device_dx(dev, lp, pf)
-    assert rel <= 1e-11
-    assert rel_err(dx, g['iter_dx'][0]) < TOL_DX, (its, rel)
+    assert rel <= 10 * tol
+    err_ref = rel_err(dx, g['iter_dx'][0])
+    if err_ref >= TOL_DX:
+        # only allowed when the reference's own spsolve is the inaccurate side
+        P, b, _ = orc.normal_equations(lp, pf)
+        exact = accurate_solve(P.toarray(), b)
+        assert rel_err(dx, exact) < TOL_DX, (its, rel, err_ref)
+        assert rel_err(g['iter_dx'][0], exact) > 10 * rel_err(dx, exact)
     assert abs(dev.step_norm() - np.linalg.norm(dx)) <= 1e-12 * np.linalg.norm(dx)
 
 
@@ -116,10 +140,10 @@ def test_solve_trace_matches_reference(name):
     assert np.allclose(hist[big], ref[big], rtol=1e-7)
     if 'final_poses' in g:
         from pyslam_amd.lowering import pack_pose
-        got = np.stack([pack_pose(final[k]) for k in lp.pose_keys])
+        got = np.stack([pack_pose(final[k]) for k in problem._device.lp.pose_keys])
         assert np.abs(got - g['final_poses']).max() < 1e-8
     if 'final_points' in g:
-        got = np.stack([final[k] for k in lp.point_keys])
+        got = np.stack([final[k] for k in problem._device.lp.point_keys])
         assert np.abs(got - g['final_points']).max() < 1e-7
 
 
