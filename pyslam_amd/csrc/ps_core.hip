@@ -605,7 +605,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
 
     // ---- PCG workspace
     const size_t nvec = (size_t)nr * D;
-    h->npartA = std::max(1, cdiv(nr, 4));
+    h->npartA = std::max(1, nr);      // k_pcg_spmv: one workgroup (and one p.q partial) per block row
     h->npartB = std::max(1, cdiv(nr, D == 6 ? PS_PCG_BR(6) : PS_PCG_BR(3)));
     h->hist_cap = 4098;
     if (h->alloc(&h->x, nvec) || h->alloc(&h->r, nvec) || h->alloc(&h->z, nvec) || h->alloc(&h->p0, nvec) ||

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(
     int32_t* __restrict__ status, double* __restrict__ scalars)
 {
     if (status[ST_PCG_DONE]) return;
-    __shared__ double lds[4];
+    __shared__ double lds[4][8];
     constexpr int DD = D * D;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double rz = 0.0, rr = 0.0;
@@ -497,31 +497,37 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(
         hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rz;
         if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = rz; }
     }
-    const int row = blockIdx.x * 4 + w;
-    const int r = lane / D, c = lane % D;
+    // one workgroup per block row; a wave pass covers 8 blocks x D rows (lane = 8*blk + row),
+    // so the row's blocks are fetched with 32-way memory parallelism instead of one at a time
+    const int row = blockIdx.x;
+    const int kk = lane >> 3, r = lane & 7;
     double acc = 0.0;
-    if (row < nr && lane < DD) {
-        for (int b = row_ptr[row]; b < row_ptr[row + 1]; ++b) {
-            const size_t j = (size_t)col_idx[b] * D + c;
-            acc += S[(size_t)b * DD + lane] * (z[j] + beta * p_old[j]);
+    if (r < D) {
+        const int end = row_ptr[row + 1];
+        for (int b = row_ptr[row] + w * 8 + kk; b < end; b += 32) {
+            const size_t j = (size_t)col_idx[b] * D;
+            const double* sb = S + (size_t)b * DD + r * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc += sb[c] * (z[j + c] + beta * p_old[j + c]);
         }
     }
-    // sum the D lanes of a row (c = 0..D-1 are adjacent lanes)
-    double t1 = acc + __shfl_down(acc, 1, 64);
-    double qr;
-    if (D == 6) { const double t2 = t1 + __shfl_down(t1, 2, 64); qr = t2 + __shfl_down(t1, 4, 64); }
-    else { qr = t1 + __shfl_down(acc, 2, 64); }
-    double pq = 0.0;
-    if (row < nr && lane < DD && c == 0) {
-        const size_t i = (size_t)row * D + r;
-        const double pn = z[i] + beta * p_old[i];
-        p_new[i] = pn; q[i] = qr;
-        pq = pn * qr;
-    }
-    pq = wave_sum(pq);
-    if (lane == 0) lds[w] = pq;
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < 8) lds[w][lane] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) pq_part[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+    if (w == 0) {
+        double pq = 0.0;
+        if (lane < D) {
+            const double qr = ((lds[0][lane] + lds[1][lane]) + lds[2][lane]) + lds[3][lane];
+            const size_t i = (size_t)row * D + lane;
+            const double pn = z[i] + beta * p_old[i];
+            p_new[i] = pn; q[i] = qr;
+            pq = pn * qr;
+        }
+        pq = wave_sum(pq);
+        if (lane == 0) pq_part[row] = pq;
+    }
 }
 
 // B: alpha = rz / p.q ; x += alpha p ; r -= alpha q ; z = M^-1 r ; partial r.z, r.r
