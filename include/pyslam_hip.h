@@ -152,6 +152,10 @@ int ps_get_landmark_factors(ps_problem* h, double* cinv /* (nv,6) */, double* c 
 int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /* (N,18) */,
                            double* jpoint /* (N,9) */);  /* IRLS-scaled, original obs order */
 
+/* Tuning knobs: "pcg_variant" (1 = fused single-launch-per-iteration CG on the block-Jacobi
+   scaled system [default], 0 = classic two-launch PCG), "pcg_chunk" (launches between polls). */
+int ps_set_option(ps_problem* h, const char* name, double value);
+
 /* hipEvent stage timers on the handle's stream (the reference has no tracing). */
 int ps_set_profiling(ps_problem* h, int enabled);
 int ps_get_stage_times(ps_problem* h, double* ms /* PS_NUM_STAGES */, int64_t* counts, int reset);

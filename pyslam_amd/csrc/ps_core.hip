@@ -78,6 +78,11 @@ struct ps_problem {
     double *x = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *q = nullptr, *Minv = nullptr;
     double *rz_part = nullptr, *rr_part = nullptr, *pq_part = nullptr, *hist = nullptr;
     int npartA = 0, npartB = 0, hist_cap = 0, last_pcg_iters = 0;
+    // fused CG (one launch per iteration) on the block-Jacobi-scaled system
+    int pcg_variant = 1;            // 1 = fused single-reduction CG, 0 = classic two-launch PCG
+    int pcg_chunk = 8;              // launches between host polls of the 'done' flag
+    double *Linv = nullptr, *cg_r[2] = {}, *cg_w[2] = {}, *cg_s[2] = {}, *cg_gd[2] = {}, *cg_xh = nullptr;
+    int32_t* brow_of = nullptr;
     // scalars
     double *cost_partials = nullptr, *scalars = nullptr, *h_scalars = nullptr;
     int32_t *status = nullptr, *h_status = nullptr;
@@ -221,6 +226,48 @@ int pcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* re
     return 0;
 }
 
+template <int D>
+int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
+    const int nr = h->nr, cap = h->hist_cap;
+    if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
+    hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
+                       h->S, h->Linv, h->status);
+    hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
+                       h->brow_of, h->Linv, h->S);
+    hipLaunchKernelGGL(k_cg_prepare<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->g, h->Linv,
+                       h->cg_r[0], h->cg_w[0], h->cg_s[0], h->p0, h->cg_xh, h->status);
+    const double tol2 = tol * tol;
+    int n = 0;                                     // launch counter: k = n - 1
+    int chunk = std::max(h->pcg_chunk, h->last_pcg_iters + 2);
+    bool done = false;
+    while (!done) {
+        const int m = std::min(chunk, max_iters + 2 - n);
+        for (int i = 0; i < m; ++i, ++n) {
+            const int o = n & 1, nw = o ^ 1;
+            hipLaunchKernelGGL(k_cg_fused<D>, dim3(nr), dim3(256), 0, h->stream, nr, h->row_ptr, h->col_idx, h->S,
+                               h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw], h->cg_s[nw],
+                               h->p0, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
+                               h->status, h->scalars);
+        }
+        HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        done = h->h_status[ST_PCG_DONE] != 0 || n >= max_iters + 2;
+        chunk = h->pcg_chunk;
+    }
+    hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->Linv,
+                       h->cg_xh, h->x);
+    h->last_pcg_iters = h->h_status[ST_PCG_ITERS];
+    if (iters_out) *iters_out = h->h_status[ST_PCG_ITERS];
+    const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
+    if (relres_out) *relres_out = rr0 > 0.0 ? std::sqrt(rrf / rr0) : 0.0;
+    if (h->h_status[ST_DIAG_FAIL])
+        return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+    if (h->h_status[ST_PCG_DONE] == 2)
+        return fail("CG breakdown: the reduced system is not positive definite");
+    return 0;
+}
+
 int linearize(ps_problem* h, double lambda) {
     HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
@@ -316,6 +363,8 @@ int apply_update(ps_problem* h, double step) {
 int solve_reduced(ps_problem* h, double tol, int max_iters, int* iters, double* relres) {
     if (h->nr == 0) { if (iters) *iters = 0; if (relres) *relres = 0.0; return 0; }
     StageTimer t(h, PS_ST_PCG);
+    if (h->pcg_variant == 1)
+        return h->D == 6 ? cg_fused_run<6>(h, tol, max_iters, iters, relres) : cg_fused_run<3>(h, tol, max_iters, iters, relres);
     return h->D == 6 ? pcg_run<6>(h, tol, max_iters, iters, relres) : pcg_run<3>(h, tol, max_iters, iters, relres);
 }
 
@@ -607,11 +656,20 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     const size_t nvec = (size_t)nr * D;
     h->npartA = std::max(1, nr);      // k_pcg_spmv: one workgroup (and one p.q partial) per block row
     h->npartB = std::max(1, cdiv(nr, D == 6 ? PS_PCG_BR(6) : PS_PCG_BR(3)));
-    h->hist_cap = 4098;
+    h->hist_cap = 4098;            // classic PCG uses [0,cap); the fused CG needs 2*cap (gamma | alpha)
     if (h->alloc(&h->x, nvec) || h->alloc(&h->r, nvec) || h->alloc(&h->z, nvec) || h->alloc(&h->p0, nvec) ||
         h->alloc(&h->p1, nvec) || h->alloc(&h->q, nvec) || h->alloc(&h->Minv, (size_t)nr * DD) ||
         h->alloc(&h->rz_part, h->npartB) || h->alloc(&h->rr_part, h->npartB) || h->alloc(&h->pq_part, h->npartA) ||
-        h->alloc(&h->hist, h->hist_cap)) return -1;
+        h->alloc(&h->hist, 2 * (size_t)h->hist_cap)) return -1;
+    {
+        std::vector<int32_t> brow_of(nnzb);
+        for (int r = 0; r < nr; ++r) for (int b = row_ptr[r]; b < row_ptr[r + 1]; ++b) brow_of[b] = r;
+        if (h->upload(&h->brow_of, brow_of)) return -1;
+        if (h->alloc(&h->Linv, (size_t)nr * DD) || h->alloc(&h->cg_xh, nvec)) return -1;
+        for (int k = 0; k < 2; ++k)
+            if (h->alloc(&h->cg_r[k], nvec) || h->alloc(&h->cg_w[k], nvec) || h->alloc(&h->cg_s[k], nvec) ||
+                h->alloc(&h->cg_gd[k], 2 * (size_t)std::max(nr, 1))) return -1;
+    }
     HIP_OK(hipMemsetAsync(h->x, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->p0, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->p1, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
@@ -769,6 +827,15 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r, double* jpose, double* jpoi
     const int rc = sync(h);
     hipFree(dr); hipFree(djp); hipFree(djl);
     return rc;
+}
+
+int ps_set_option(ps_problem* h, const char* name, double value) {
+    if (!h || !name) return fail("null argument");
+    const std::string n(name);
+    if (n == "pcg_variant") { if (value != 0 && value != 1) return fail("pcg_variant must be 0 or 1"); h->pcg_variant = (int)value; }
+    else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }
+    else return fail("unknown option: " + n);
+    return 0;
 }
 
 int ps_set_profiling(ps_problem* h, int enabled) {

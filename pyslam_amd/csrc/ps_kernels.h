@@ -476,36 +476,45 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(
     double* __restrict__ pq_part, double* __restrict__ hist, int k, double tol2,
     int32_t* __restrict__ status, double* __restrict__ scalars)
 {
-    if (status[ST_PCG_DONE]) return;
     __shared__ double lds[4][8];
     constexpr int DD = D * D;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // Every load below is independent: issue them all before the first branch so the
+    // kernel pays ONE memory latency here instead of a chain (these kernels are a few us
+    // long and latency-, not bandwidth-bound).
+    const int done = status[ST_PCG_DONE];
+    const int row = blockIdx.x;
+    const int rbeg = row_ptr[row], rend = row_ptr[row + 1];
+    const double rz_prev = hist[k > 0 ? k - 1 : 0];
+    const double thresh_in = scalars[SC_THRESH];
     double rz = 0.0, rr = 0.0;
     for (int i = lane; i < npartB; i += 64) { rz += rz_part[i]; rr += rr_part[i]; }
+    const int kk = lane >> 3, r = lane & 7;
+    const int b0 = rbeg + w * 8 + kk;
+    int cj = 0;
+    if (b0 < rend) cj = col_idx[b0];
+    if (done) return;
     rz = wave_sum(rz); rr = wave_sum(rr);
     // convergence in the PRECONDITIONED norm r^T M^-1 r: invariant to the block scaling of the
     // system (a 1e12 prior next to unit-weight loop closures), unlike ||r||_2 / ||g||_2
     (void)rr;
-    const double thresh = (k == 0) ? tol2 * rz : scalars[SC_THRESH];
+    const double thresh = (k == 0) ? tol2 * rz : thresh_in;
     const bool first_wave = (blockIdx.x == 0 && threadIdx.x == 0);
     if (!(rz > thresh)) {                      // converged (also catches rz == 0 and NaN)
         if (first_wave) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = rz; if (k == 0) scalars[SC_RR0] = rz; }
         return;
     }
-    const double beta = (k == 0) ? 0.0 : rz / hist[k - 1];
+    const double beta = (k == 0) ? 0.0 : rz / rz_prev;
     if (first_wave) {
         hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rz;
         if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = rz; }
     }
     // one workgroup per block row; a wave pass covers 8 blocks x D rows (lane = 8*blk + row),
     // so the row's blocks are fetched with 32-way memory parallelism instead of one at a time
-    const int row = blockIdx.x;
-    const int kk = lane >> 3, r = lane & 7;
     double acc = 0.0;
     if (r < D) {
-        const int end = row_ptr[row + 1];
-        for (int b = row_ptr[row] + w * 8 + kk; b < end; b += 32) {
-            const size_t j = (size_t)col_idx[b] * D;
+        for (int b = b0; b < rend; b += 32) {
+            const size_t j = (size_t)(b == b0 ? cj : col_idx[b]) * D;
             const double* sb = S + (size_t)b * DD + r * D;
 #pragma unroll
             for (int c = 0; c < D; ++c) acc += sb[c] * (z[j + c] + beta * p_old[j + c]);
@@ -539,34 +548,265 @@ __global__ __launch_bounds__(256) void k_pcg_update(
     const double* __restrict__ hist, int k, double* __restrict__ rz_part,
     double* __restrict__ rr_part, const int32_t* __restrict__ status)
 {
-    if (status[ST_PCG_DONE]) return;
     __shared__ double lds[16];
     const int t = threadIdx.x;
+    // all loads first (independent of alpha), then the reduction that yields alpha
+    const int done = status[ST_PCG_DONE];
+    const double rzk = hist[k];
     double pq = 0.0;
     for (int i = t; i < npartA; i += 256) pq += pq_part[i];
-    pq = block_sum(pq, lds);
-    const double alpha = hist[k] / pq;
     const int lane_ = t & 63;
     const int brow = blockIdx.x * PS_PCG_BR(D) + (t >> 6) * PS_PCG_BRW(D) + lane_ / D, rr_ = lane_ % D;
-    double prz = 0.0, prr = 0.0;
-    if (lane_ < PS_PCG_BRW(D) * D && brow < nr) {
-        double rn[D];
+    const bool act = lane_ < PS_PCG_BRW(D) * D && brow < nr;
+    double rv[D], qv[D], mv[D], pi = 0.0, xi_ = 0.0;
 #pragma unroll
-        for (int c = 0; c < D; ++c) rn[c] = r[(size_t)brow * D + c] - alpha * q[(size_t)brow * D + c];
+    for (int c = 0; c < D; ++c) { rv[c] = 0.0; qv[c] = 0.0; mv[c] = 0.0; }
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            rv[c] = r[(size_t)brow * D + c];
+            qv[c] = q[(size_t)brow * D + c];
+            mv[c] = Minv[(size_t)brow * D * D + rr_ * D + c];
+        }
+        pi = p[(size_t)brow * D + rr_];
+        xi_ = x[(size_t)brow * D + rr_];
+    }
+    if (done) return;
+    pq = block_sum(pq, lds);
+    const double alpha = rzk / pq;
+    double prz = 0.0, prr = 0.0;
+    if (act) {
         double zi = 0.0, ri = 0.0;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            zi += Minv[(size_t)brow * D * D + rr_ * D + c] * rn[c];
-            if (c == rr_) ri = rn[c];
+            const double rn = rv[c] - alpha * qv[c];
+            zi += mv[c] * rn;
+            if (c == rr_) ri = rn;
         }
         const size_t i = (size_t)brow * D + rr_;
-        x[i] += alpha * p[i];
-        prz = zi * ri; prr = ri * ri;
+        x[i] = xi_ + alpha * pi;
         r[i] = ri; z[i] = zi;       // same-wave lanes have already loaded r[] (see PS_PCG_BRW)
+        prz = zi * ri; prr = ri * ri;
     }
     const double a = block_sum(prz, lds);
     const double b = block_sum(prr, lds);
     if (t == 0) { rz_part[blockIdx.x] = a; rr_part[blockIdx.x] = b; }
+}
+
+// ---------------------------------------------------------------------------
+// Fused CG: ONE launch per iteration (Chronopoulos-Gear single-reduction form)
+// on the explicitly block-Jacobi-scaled system  S^ = L^-1 S L^-T,  g^ = L^-1 g,
+// x = L^-T x^   (M = L L^T = diag blocks of S).  Per iteration k:
+//   gamma_k = r.r, delta_k = w.r (reduced from the previous launch's partials)
+//   beta = gamma_k/gamma_{k-1},  alpha = gamma_k / (delta_k - beta gamma_k / alpha_{k-1})
+//   s = w + beta s ; p = r + beta p ; x += alpha p ; r -= alpha s ; w = S^ r
+// Every workgroup recomputes r_new at the columns it needs from (r, w, s) of the
+// previous launch, so the only global dependency is the launch boundary itself.
+// The k = -1 launch (alpha = beta = 0) initialises w = S^ g^ and the first partials.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_block_jacobi_factor(
+    int nr, const int32_t* __restrict__ diag_slot, const double* __restrict__ S,
+    double* __restrict__ Linv, int32_t* __restrict__ status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nr) return;
+    double A[D][D], L[D][D], Li[D][D];
+    const double* s = S + (size_t)diag_slot[i] * D * D;
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) { A[r][c] = s[r * D + c]; L[r][c] = 0.0; Li[r][c] = 0.0; }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        ok = ok && (d > 0.0);
+        const double l = sqrt(d);
+        L[j][j] = l;
+#pragma unroll
+        for (int i2 = j + 1; i2 < D; ++i2) {
+            double v = A[i2][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i2][k] * L[j][k];
+            L[i2][j] = v / l;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        Li[c][c] = 1.0 / L[c][c];
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = c; k < r; ++k) v -= L[r][k] * Li[k][c];
+            Li[r][c] = v / L[r][r];
+        }
+    }
+    if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
+    double* m = Linv + (size_t)i * D * D;
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) m[r * D + c] = Li[r][c];
+}
+
+// S_ij <- Linv_i S_ij Linv_j^T  (one 64-thread workgroup per block, in place)
+template <int D>
+__global__ __launch_bounds__(64) void k_scale_blocks(
+    int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+    const int32_t* __restrict__ brow_of, const double* __restrict__ Linv, double* __restrict__ S)
+{
+    constexpr int DD = D * D;
+    __shared__ double sS[36], sT[36], sLi[36], sLj[36];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int i = brow_of[b], j = col_idx[b];
+    if (t < DD) {
+        sS[t] = S[(size_t)b * DD + t];
+        sLi[t] = Linv[(size_t)i * DD + t];
+        sLj[t] = Linv[(size_t)j * DD + t];
+    }
+    __syncthreads();
+    const int r = t / D, c = t % D;
+    if (t < DD) {
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) v += sLi[r * D + a] * sS[a * D + c];
+        sT[t] = v;
+    }
+    __syncthreads();
+    if (t < DD) {
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) v += sT[r * D + a] * sLj[c * D + a];
+        S[(size_t)b * DD + t] = v;
+    }
+}
+
+// r0 = g^ = Linv g ; w = s = p = x^ = 0
+template <int D>
+__global__ __launch_bounds__(256) void k_cg_prepare(
+    int nr, const double* __restrict__ g, const double* __restrict__ Linv,
+    double* __restrict__ r, double* __restrict__ w, double* __restrict__ s,
+    double* __restrict__ p, double* __restrict__ x, int32_t* __restrict__ status)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { status[ST_PCG_DONE] = 0; status[ST_PCG_ITERS] = 0; }
+    if (t >= nr * D) return;
+    const int i = t / D, rr_ = t % D;
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) v += Linv[(size_t)i * D * D + rr_ * D + c] * g[(size_t)i * D + c];
+    r[t] = v; w[t] = 0.0; s[t] = 0.0; p[t] = 0.0; x[t] = 0.0;
+}
+
+PS_DEV double cg_rnew(double r, double w, double s, double alpha, double beta) {
+    return r - alpha * (w + beta * s);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_cg_fused(
+    int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+    const double* __restrict__ S,
+    const double* __restrict__ r_old, const double* __restrict__ w_old, const double* __restrict__ s_old,
+    double* __restrict__ r_new, double* __restrict__ w_new, double* __restrict__ s_new,
+    double* __restrict__ p, double* __restrict__ x,
+    const double* __restrict__ gd_in /* [2*nr] gamma | delta partials */, double* __restrict__ gd_out,
+    double* __restrict__ hist /* [0,cap): gamma, [cap,2cap): alpha */, int cap, int k, double tol2,
+    int32_t* __restrict__ status, double* __restrict__ scalars)
+{
+    __shared__ double lds[16];
+    __shared__ double part[4][8];
+    constexpr int DD = D * D;
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int row = blockIdx.x;
+    // ---- every independent load first (one memory latency, not a chain)
+    const int done = status[ST_PCG_DONE];
+    const int rbeg = row_ptr[row], rend = row_ptr[row + 1];
+    const double g_prev = hist[k > 0 ? k - 1 : 0];
+    const double a_prev = hist[cap + (k > 0 ? k - 1 : 0)];
+    const double thresh_in = scalars[SC_THRESH];
+    double gs = 0.0, ds = 0.0;
+    if (k >= 0)
+        for (int i = t; i < nr; i += 256) { gs += gd_in[i]; ds += gd_in[nr + i]; }
+    const int kk = lane >> 3, r = lane & 7;
+    const int b0 = rbeg + w * 8 + kk;
+    int cj = 0;
+    if (b0 < rend) cj = col_idx[b0];
+    double ri = 0.0, wi = 0.0, si = 0.0, pi = 0.0, xi_ = 0.0;
+    if (t < D) {
+        const size_t i = (size_t)row * D + t;
+        ri = r_old[i]; wi = w_old[i]; si = s_old[i]; pi = p[i]; xi_ = x[i];
+    }
+    if (done) return;
+    double alpha = 0.0, beta = 0.0;
+    if (k >= 0) {
+        const double gamma = block_sum(gs, lds);
+        const double delta = block_sum(ds, lds);
+        const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
+        const bool first = (blockIdx.x == 0 && t == 0);
+        if (!(gamma > thresh)) {                     // converged (or gamma == 0 / NaN)
+            if (first) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
+            return;
+        }
+        beta = (k == 0) ? 0.0 : gamma / g_prev;
+        const double denom = (k == 0) ? delta : delta - beta * gamma / a_prev;
+        alpha = gamma / denom;
+        if (!(denom > 0.0)) {                        // breakdown: stop, the host reports it
+            if (first) { status[ST_PCG_DONE] = 2; scalars[SC_RRFINAL] = gamma; }
+            return;
+        }
+        if (first) {
+            hist[k] = gamma; hist[cap + k] = alpha; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = gamma;
+            if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = gamma; }
+        }
+    }
+    // ---- w_new(row) = S^(row,:) r_new, with r_new recomputed per column block
+    double acc = 0.0;
+    if (r < D) {
+        for (int b = b0; b < rend; b += 32) {
+            const size_t j = (size_t)(b == b0 ? cj : col_idx[b]) * D;
+            const double* sb = S + (size_t)b * DD + r * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c)
+                acc += sb[c] * cg_rnew(r_old[j + c], w_old[j + c], s_old[j + c], alpha, beta);
+        }
+    }
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < 8) part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+        double gp = 0.0, dp = 0.0;
+        if (lane < D) {
+            const double wn = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+            const size_t i = (size_t)row * D + lane;
+            const double sn = wi + beta * si;
+            const double pn = ri + beta * pi;
+            const double rn = cg_rnew(ri, wi, si, alpha, beta);
+            s_new[i] = sn; p[i] = pn; x[i] = xi_ + alpha * pn; r_new[i] = rn; w_new[i] = wn;
+            gp = rn * rn; dp = wn * rn;
+        }
+        gp = wave_sum(gp); dp = wave_sum(dp);
+        if (lane == 0) { gd_out[row] = gp; gd_out[nr + row] = dp; }
+    }
+}
+
+// x = Linv^T x^
+template <int D>
+__global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __restrict__ Linv,
+                                                     const double* __restrict__ xh, double* __restrict__ x)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nr * D) return;
+    const int i = t / D, c = t % D;
+    double v = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) v += Linv[(size_t)i * D * D + a * D + c] * xh[(size_t)i * D + a];
+    x[t] = v;
 }
 
 // ---------------------------------------------------------------------------

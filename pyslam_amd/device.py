@@ -156,6 +156,9 @@ class DeviceProblem:
         nat.check(self._lib.ps_debug_reproj_blocks(self._h, nat.f64p(r), nat.f64p(jp), nat.f64p(jl)))
         return r, jp, jl
 
+    def set_option(self, name, value):
+        nat.check(self._lib.ps_set_option(self._h, name.encode(), float(value)))
+
     # ---- tracing -------------------------------------------------------
     def set_profiling(self, on=True):
         nat.check(self._lib.ps_set_profiling(self._h, int(on)))
