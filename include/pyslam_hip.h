@@ -145,6 +145,13 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
                     int linesearch, double* cost_out, double* dx_norm_out,
                     int* pcg_iters_out, double* pcg_relres_out);
 
+/* Second half of an iteration for a landmark-sharded (multi-GPU) caller, after
+   ps_linearize -> all-reduce -> ps_solve_reduced: back-substitution, update, cost, ONE
+   synchronisation.  Returns this shard's cost and ||dx_pose||^2, ||dx_point||^2 separately
+   (poses are replicated, landmarks are not). */
+int ps_gn_finish(ps_problem* h, int linesearch, double* cost_out, double* dx_pose_norm2,
+                 double* dx_point_norm2);
+
 /* Parity / debug taps (device -> host). */
 int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx,
                           double* vals, double* g);       /* BSR, dof x dof blocks */

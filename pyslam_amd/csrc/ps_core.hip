@@ -329,20 +329,21 @@ int backsub(ps_problem* h) {
 }
 
 int step_norm(ps_problem* h) {
-    // partial sums of squares of [x | dxl] then a single-workgroup reduce
+    // ||dx_pose||^2 and ||dx_point||^2 separately (a landmark-sharded caller sums the second
+    // across ranks); partial sums of squares, then a single-workgroup reduce each
     double* part = h->cost_partials;      // reused: the cost pass of this iteration runs later
-    int n = 0;
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
     if (h->nr > 0) {
         const int b = std::min(256, cdiv((long)h->nr * h->D, 256));
         hipLaunchKernelGGL(k_sumsq_partials, dim3(b), dim3(256), 0, h->stream, (long)h->nr * h->D, h->x, 1.0, part);
-        n += b;
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, b, part, h->scalars + SC_DXP2);
     }
     if (h->nv > 0) {
         const int b = std::min(256, cdiv((long)h->nv * 3, 256));
-        hipLaunchKernelGGL(k_sumsq_partials, dim3(b), dim3(256), 0, h->stream, (long)h->nv * 3, h->dxl, 1.0, part + n);
-        n += b;
+        hipLaunchKernelGGL(k_sumsq_partials, dim3(b), dim3(256), 0, h->stream, (long)h->nv * 3, h->dxl, 1.0, part + 256);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, b, part + 256, h->scalars + SC_DXL2);
     }
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, n, part, h->scalars + SC_DXNORM2);
     return 0;
 }
 
@@ -739,7 +740,7 @@ int ps_get_dx(ps_problem* h, double* dx_pose, double* dx_point) {
 int ps_step_norm2(ps_problem* h, double* norm2) {
     if (!h || !norm2) return fail("null argument");
     if (step_norm(h) || read_scalars(h)) return -1;
-    *norm2 = h->h_scalars[SC_DXNORM2];
+    *norm2 = h->h_scalars[SC_DXP2] + h->h_scalars[SC_DXL2];
     return 0;
 }
 
@@ -776,6 +777,28 @@ int ps_set_params(ps_problem* h, const double* poses, const double* points) {
     return sync(h);
 }
 
+namespace {
+int gn_finish(ps_problem* h, int linesearch) {
+    if (backsub(h)) return -1;
+    if (!linesearch && cost_pass(h, 0, SC_LINCOST)) return -1;
+    if (step_norm(h)) return -1;
+    if (apply_update(h, 1.0)) return -1;
+    if (linesearch && cost_pass(h, 1, SC_COST)) return -1;
+    return 0;
+}
+}  // namespace
+
+int ps_gn_finish(ps_problem* h, int linesearch, double* cost_out, double* dx_pose_norm2, double* dx_point_norm2) {
+    if (!h) return fail("null argument");
+    if (gn_finish(h, linesearch)) return -1;
+    if (read_scalars(h)) return -1;
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+    if (dx_pose_norm2) *dx_pose_norm2 = h->h_scalars[SC_DXP2];
+    if (dx_point_norm2) *dx_point_norm2 = h->h_scalars[SC_DXL2];
+    return 0;
+}
+
 int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters, int linesearch,
                     double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out) {
     if (!h) return fail("null argument");
@@ -783,16 +806,12 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
         StageTimer total(h, PS_ST_TOTAL);     // closed before the synchronising read-back
         if (linearize(h, lambda)) return -1;
         if (solve_reduced(h, pcg_tol, pcg_max_iters, pcg_iters_out, pcg_relres_out)) return -1;
-        if (backsub(h)) return -1;
-        if (!linesearch && cost_pass(h, 0, SC_LINCOST)) return -1;
-        if (step_norm(h)) return -1;
-        if (apply_update(h, 1.0)) return -1;
-        if (linesearch && cost_pass(h, 1, SC_COST)) return -1;
+        if (gn_finish(h, linesearch)) return -1;
     }
     if (read_scalars(h)) return -1;
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
-    if (dx_norm_out) *dx_norm_out = std::sqrt(h->h_scalars[SC_DXNORM2]);
+    if (dx_norm_out) *dx_norm_out = std::sqrt(h->h_scalars[SC_DXP2] + h->h_scalars[SC_DXL2]);
     return 0;
 }
 

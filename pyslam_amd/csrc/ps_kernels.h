@@ -29,7 +29,7 @@ struct FactorGroup { double S[36]; int32_t loss_id; int32_t pad; double loss_k; 
 // status words
 enum { ST_LM_FAIL = 0, ST_DIAG_FAIL = 1, ST_PCG_DONE = 2, ST_PCG_ITERS = 3, ST_NWORDS = 8 };
 // scalar slots
-enum { SC_COST = 0, SC_DXNORM2 = 1, SC_LINCOST = 2, SC_RR0 = 3, SC_RRFINAL = 4, SC_THRESH = 5, SC_NWORDS = 8 };
+enum { SC_COST = 0, SC_DXP2 = 1, SC_LINCOST = 2, SC_RR0 = 3, SC_RRFINAL = 4, SC_THRESH = 5, SC_DXL2 = 6, SC_NWORDS = 8 };
 
 PS_DEV double wave_sum(double v) {          // xor butterfly: every lane gets the total
 #pragma unroll
@@ -47,6 +47,23 @@ PS_DEV double block_sum(double v, double* lds /* >= 16 doubles */) {
     double t = 0.0;
     for (int i = 0; i < nw; ++i) t += lds[i];
     return t;
+}
+
+// two block-wide sums sharing one butterfly and one barrier pair (the shuffles of a and b
+// interleave, so the pair costs about one reduction's latency)
+PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ta = __shfl_xor(a, m, 64), tb = __shfl_xor(b, m, 64);
+        a += ta; b += tb;
+    }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { lds[w] = a; lds[16 + w] = b; }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < nw; ++i) { sa += lds[i]; sb += lds[16 + i]; }
+    a = sa; b = sb;
 }
 
 // ---------------------------------------------------------------------------
@@ -717,7 +734,7 @@ __global__ __launch_bounds__(256) void k_cg_fused(
     double* __restrict__ hist /* [0,cap): gamma, [cap,2cap): alpha */, int cap, int k, double tol2,
     int32_t* __restrict__ status, double* __restrict__ scalars)
 {
-    __shared__ double lds[16];
+    __shared__ double lds[32];
     __shared__ double part[4][8];
     constexpr int DD = D * D;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
@@ -743,8 +760,8 @@ __global__ __launch_bounds__(256) void k_cg_fused(
     if (done) return;
     double alpha = 0.0, beta = 0.0;
     if (k >= 0) {
-        const double gamma = block_sum(gs, lds);
-        const double delta = block_sum(ds, lds);
+        block_sum2(gs, ds, lds);
+        const double gamma = gs, delta = ds;
         const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
         const bool first = (blockIdx.x == 0 && t == 0);
         if (!(gamma > thresh)) {                     // converged (or gamma == 0 / NaN)

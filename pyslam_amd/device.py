@@ -75,6 +75,12 @@ class DeviceProblem:
                                             C.byref(cost), C.byref(nrm), C.byref(it), C.byref(rel)))
         return cost.value, nrm.value, it.value, rel.value
 
+    def gn_finish(self, linesearch=True):
+        """-> (shard cost, ||dx_pose||^2, ||dx_point||^2); parameters are updated."""
+        c, a, b = C.c_double(), C.c_double(), C.c_double()
+        nat.check(self._lib.ps_gn_finish(self._h, int(linesearch), C.byref(c), C.byref(a), C.byref(b)))
+        return c.value, a.value, b.value
+
     def linearize(self, lm_lambda=0.):
         nat.check(self._lib.ps_linearize(self._h, lm_lambda))
 

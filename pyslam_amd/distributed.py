@@ -1,0 +1,147 @@
+"""Landmark-sharded multi-GPU Gauss-Newton.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+Landmarks -- and therefore observations -- are partitioned across ranks; the
+pose table is replicated.  Per iteration:
+
+    ps_linearize            shard-local: residuals, Jacobians, H_ll, Z, partial S, g
+    ONE sum all-reduce      [S values | g | cost] on the device buffer the core exposes
+    ps_solve_reduced        replicated, deterministic -> identical dx_pose on every rank
+    ps_gn_finish            shard-local back-substitution, update, cost
+    scalar all-reduce       (cost, ||dx_point||^2)
+
+The reduced system's block pattern must be identical on every rank for the
+element-wise all-reduce, so ranks exchange their co-visibility pose pairs once
+at construction and pass the union to ps_problem_create as ``extra_pairs``.
+Pose factors (edges / priors) must live on exactly one rank (``shard_landmarks``
+gives them to rank 0): summing replicated factors would count them N times.
+"""
+import numpy as np
+
+from pyslam_amd.lowering import LoweredProblem
+
+
+def shard_landmarks(lp, rank, world):
+    """Contiguous landmark range balanced by observation count; factors on rank 0."""
+    if world == 1:
+        return lp
+    L = lp.num_points
+    counts = np.bincount(lp.obs_point, minlength=L).astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    total = cum[-1]
+    bounds = [int(np.searchsorted(cum, total * r / world, side='left')) for r in range(world)] + [L]
+    lo, hi = bounds[rank], bounds[rank + 1]
+    keep = (lp.obs_point >= lo) & (lp.obs_point < hi)
+    out = lp.copy()
+    out.points = lp.points[lo:hi]
+    vid = lp.point_vid[lo:hi].copy()
+    var = vid >= 0
+    vid[var] = np.arange(int(var.sum()))
+    out.point_vid = vid
+    out.point_keys = list(lp.point_keys[lo:hi])
+    out.obs_pose, out.obs_point = lp.obs_pose[keep], lp.obs_point[keep] - lo
+    out.obs_uvd, out.obs_grp = lp.obs_uvd[keep], lp.obs_grp[keep]
+    if rank != 0:
+        pw = lp.pose_width
+        out.e_i = out.e_j = out.e_grp = out.u_i = out.u_grp = np.zeros(0, np.int32)
+        out.e_Tobs_inv = out.u_Tobs_inv = np.zeros((0, pw))
+    return out.finalize()
+
+
+def pose_pair_keys(lp):
+    """Unique upper-triangle reduced pose pairs (ri < rj) this shard couples:
+    co-visibility through variable landmarks + pose-pose edges.  int64 ri<<32|rj."""
+    keys = []
+    if lp.num_obs:
+        rid = lp.pose_rid[lp.obs_pose]
+        sel = (rid >= 0) & (lp.point_vid[lp.obs_point] >= 0)
+        pt, rid = lp.obs_point[sel], rid[sel].astype(np.int64)
+        order = np.argsort(pt, kind='stable')
+        pt, rid = pt[order], rid[order]
+        shift = 1
+        while shift < pt.size:
+            same = pt[shift:] == pt[:-shift]
+            if not same.any():
+                break
+            a, b = rid[:-shift][same], rid[shift:][same]
+            ne = a != b
+            keys.append(np.unique((np.minimum(a, b)[ne] << 32) | np.maximum(a, b)[ne]))
+            shift += 1
+    if lp.num_edges:
+        a, b = lp.pose_rid[lp.e_i].astype(np.int64), lp.pose_rid[lp.e_j].astype(np.int64)
+        ok = (a >= 0) & (b >= 0) & (a != b)
+        keys.append(np.unique((np.minimum(a, b)[ok] << 32) | np.maximum(a, b)[ok]))
+    return np.unique(np.concatenate(keys)) if keys else np.zeros(0, np.int64)
+
+
+class _RawDeviceArray:
+    """Zero-copy view of a device pointer for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (n,), 'typestr': '<f8', 'data': (ptr, False),
+                                         'version': 2, 'strides': None}
+
+
+def _default_device_factory(lp, extra_pairs):
+    import torch
+    from pyslam_amd.device import DeviceProblem
+    dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream, extra_pairs=extra_pairs)
+    ptr, n = dev.reduce_buffer()
+    dev.reduce_tensor = torch.as_tensor(_RawDeviceArray(ptr, n), device='cuda')
+    return dev
+
+
+class ShardedDeviceProblem:
+    """Same surface as DeviceProblem for the pieces Problem.solve / bench.py use."""
+
+    def __init__(self, lp_shard, dist, device_factory=None):
+        import torch
+        self._torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        mine = pose_pair_keys(lp_shard)
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, mine)
+        union = np.unique(np.concatenate(gathered)) if gathered else mine
+        extra = np.setdiff1d(union, mine)
+        pairs = ((extra >> 32).astype(np.int32), (extra & 0xFFFFFFFF).astype(np.int32))
+        self.pattern_keys = union
+        self.dev = (device_factory or _default_device_factory)(lp_shard, pairs)
+        self.lp = lp_shard
+        self.info = dict(self.dev.info)
+        self._scal = torch.zeros(2, dtype=torch.float64, device=self.dev.reduce_tensor.device)
+
+    # ---- iteration -----------------------------------------------------
+    def eval_cost(self, include_all_constant=True):
+        self._scal[0] = self.dev.eval_cost(include_all_constant)
+        self._scal[1] = 0.
+        self.dist.all_reduce(self._scal)
+        return float(self._scal[0])
+
+    def gn_iteration(self, lm_lambda=0., pcg_tol=1e-12, pcg_max_iters=1000, linesearch=True):
+        self.dev.linearize(lm_lambda)
+        self.dist.all_reduce(self.dev.reduce_tensor)          # RCCL sum over xGMI, on the solver's stream
+        its, rel = self.dev.solve_reduced(pcg_tol, pcg_max_iters)
+        cost, dxp2, dxl2 = self.dev.gn_finish(linesearch)
+        self._scal[0], self._scal[1] = cost, dxl2
+        self.dist.all_reduce(self._scal)
+        s = self._scal.tolist()
+        return s[0], float(np.sqrt(dxp2 + s[1])), its, rel
+
+    # ---- passthrough ---------------------------------------------------
+    def snapshot(self):
+        self.dev.snapshot()
+
+    def restore(self):
+        self.dev.restore()
+
+    def get_params(self):
+        return self.dev.get_params()
+
+    def set_profiling(self, on=True):
+        self.dev.set_profiling(on)
+
+    def stage_times(self, reset=False):
+        return self.dev.stage_times(reset)
+
+    def close(self):
+        self.dev.close()

@@ -1,0 +1,136 @@
+"""world_size-2 gloo test of the landmark-sharded iteration (CPU).
+
+The HIP core cannot run here, so the per-shard device is replaced by a numpy
+stand-in built on the ORACLE (tests may use it): it produces the shard's partial
+reduced system exactly as the device does, and the test checks that sharding,
+pattern union, the [S|g|cost] all-reduce and the scalar reductions reproduce
+the single-process Gauss-Newton step of the oracle.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import gn_oracle as orc
+from pyslam_amd import synthetic
+from pyslam_amd.distributed import shard_landmarks, pose_pair_keys, ShardedDeviceProblem
+
+
+class OracleShardDevice:
+    """numpy stand-in for DeviceProblem: dense reduced system over ALL reduced poses."""
+
+    def __init__(self, lp, extra_pairs):
+        self.lp = lp
+        d, nr = lp.dof, lp.num_reduced
+        self.n = d * nr
+        self.reduce_tensor = torch.zeros(self.n * self.n + self.n + 1, dtype=torch.float64)
+        self.info = {'num_obs': lp.num_obs, 'num_reduced': nr}
+        self.extra_pairs = extra_pairs
+
+    def _split(self):
+        P, b, cost = orc.normal_equations(self.lp, points_first=False)
+        P = P.toarray()
+        n = self.n
+        return P[:n, :n], P[:n, n:], P[n:, n:], b[:n], b[n:], cost
+
+    def eval_cost(self, include_all=True):
+        return orc.eval_cost(self.lp, include_all)
+
+    def linearize(self, lam):
+        Hpp, Hpl, Hll, bp, bl, cost = self._split()
+        self.Hinv = np.linalg.inv(Hll) if Hll.size else Hll
+        self.Hpl, self.bl = Hpl, bl
+        S = Hpp - Hpl @ self.Hinv @ Hpl.T
+        g = bp - Hpl @ self.Hinv @ bl
+        self.reduce_tensor[:] = torch.from_numpy(np.concatenate([S.ravel(), g, [cost]]))
+
+    def solve_reduced(self, tol, max_iters):
+        buf = self.reduce_tensor.numpy()
+        n = self.n
+        self.dxp = np.linalg.solve(buf[:n * n].reshape(n, n), buf[n * n:n * n + n])
+        return 1, 0.0
+
+    def gn_finish(self, linesearch):
+        dxl = self.Hinv @ (self.bl - self.Hpl.T @ self.dxp)
+        dx = np.concatenate([self.dxp, dxl])
+        lin_cost = orc.eval_cost(self.lp, False)
+        self.lp = orc.apply_update(self.lp, dx, points_first=False)
+        cost = orc.eval_cost(self.lp, True) if linesearch else lin_cost
+        return cost, float(self.dxp @ self.dxp), float(dxl @ dxl)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=90, obs_per_lm=4, half_window=3, seed=11)
+    # an odometry edge + prior so factors exist (rank 0 only after sharding)
+    shard = shard_landmarks(lp, rank, world)
+    sp = ShardedDeviceProblem(shard, dist, device_factory=lambda l, e: OracleShardDevice(l, e))
+    c0 = sp.eval_cost(True)
+    cost, nrm, _, _ = sp.gn_iteration(0., 1e-12, 100, True)
+    poses, _ = sp.dev.lp.poses, None
+    if rank == 0:
+        out.put((c0, cost, nrm, sp.pattern_keys, sp.dev.lp.poses.copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_iteration_matches_single_process():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    c0, cost, nrm, keys, poses = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=90, obs_per_lm=4, half_window=3, seed=11)
+    assert abs(c0 - orc.eval_cost(lp)) <= 1e-12 * c0
+    dx, _ = orc.gauss_newton_step(lp, points_first=False)
+    new = orc.apply_update(lp, dx, points_first=False)
+    assert abs(cost - orc.eval_cost(new)) <= 1e-9 * cost
+    assert abs(nrm - np.linalg.norm(dx)) <= 1e-9 * nrm
+    assert np.abs(poses - new.poses).max() < 1e-9
+    assert np.array_equal(keys, pose_pair_keys(lp))          # union of shard patterns == global pattern
+
+
+def test_shards_partition_the_problem():
+    lp, _ = synthetic.stereo_ba(num_kf=10, num_lm=200, obs_per_lm=5, half_window=4, seed=3,
+                                const_point_fraction=0.1)
+    shards = [shard_landmarks(lp, r, 4) for r in range(4)]
+    assert sum(s.num_obs for s in shards) == lp.num_obs
+    assert sum(s.num_points for s in shards) == lp.num_points
+    assert sum(s.num_var_points for s in shards) == lp.num_var_points
+    counts = [s.num_obs for s in shards]
+    assert max(counts) - min(counts) <= 0.2 * lp.num_obs / 4 + 10     # balanced by observations
+    for s in shards:
+        assert np.array_equal(s.poses, lp.poses) and np.array_equal(s.pose_rid, lp.pose_rid)
+        assert set(s.point_vid[s.point_vid >= 0]) == set(range(s.num_var_points))
+    # cost is additive over shards
+    assert abs(sum(orc.eval_cost(s) for s in shards) - orc.eval_cost(lp)) <= 1e-10 * orc.eval_cost(lp)
+    # the union of the shards' block patterns is the global pattern
+    union = np.unique(np.concatenate([pose_pair_keys(s) for s in shards]))
+    assert np.array_equal(union, pose_pair_keys(lp))
+
+
+def test_pose_graph_factors_live_on_rank0_only():
+    lp, _ = synthetic.pose_graph(num_poses=30, num_loops=20, dof=6, seed=1)
+    s0, s1 = shard_landmarks(lp, 0, 2), shard_landmarks(lp, 1, 2)
+    assert s0.num_edges == lp.num_edges and s0.num_priors == lp.num_priors
+    assert s1.num_edges == 0 and s1.num_priors == 0
