@@ -60,7 +60,8 @@ struct ps_problem {
     double* ppartial = nullptr;
     int2* pairs = nullptr;
     PairItem* pair_items = nullptr;
-    int npair_items = 0;
+    int npair_items = 0, pair_per_xcd = 0;
+    int32_t* pair_order = nullptr;
     // factors
     FactorGroup* fgroups = nullptr;
     int32_t *f_i = nullptr, *f_j = nullptr, *f_grp = nullptr;
@@ -83,6 +84,17 @@ struct ps_problem {
     int pcg_chunk = 8;              // launches between host polls of the 'done' flag
     double *Linv = nullptr, *cg_r[2] = {}, *cg_w[2] = {}, *cg_s[2] = {}, *cg_gd[2] = {}, *cg_xh = nullptr;
     int32_t* brow_of = nullptr;
+    double* cg_p = nullptr;
+    double* Saug = nullptr;         // scaled (and, with a coarse level, augmented) matrix the CG runs on
+    int32_t* ident_slot = nullptr;
+    // two-level preconditioner (coarse level), built lazily by build_coarse()
+    int coarse_req = -1;            // requested number of groups: -1 = auto, 0 = off
+    int G = 0, ncb = 0, nc = 0, nr_aug = 0, nnzb_aug = 0;
+    size_t cg_cap = 0;              // CG vectors are allocated for this many block rows
+    int32_t *grp_of = nullptr, *grp_ptr = nullptr, *arow_ptr = nullptr, *acol_idx = nullptr,
+            *aug_slot = nullptr, *fine_nnz = nullptr, *run_ptr = nullptr;
+    double *tau = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr;
+    bool coarse_built = false;
     // scalars
     double *cost_partials = nullptr, *scalars = nullptr, *h_scalars = nullptr;
     int32_t *status = nullptr, *h_status = nullptr;
@@ -226,16 +238,111 @@ int pcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* re
     return 0;
 }
 
+int ensure_cg_buffers(ps_problem* h, int rows, int blocks) {
+    const int D = h->D;
+    if ((size_t)rows <= h->cg_cap && h->Saug) return 0;
+    const size_t nvec = (size_t)rows * D;
+    if (h->alloc(&h->cg_xh, nvec)) return -1;
+    for (int k = 0; k < 2; ++k)
+        if (h->alloc(&h->cg_r[k], nvec) || h->alloc(&h->cg_w[k], nvec) || h->alloc(&h->cg_s[k], nvec) ||
+            h->alloc(&h->cg_gd[k], 2 * (size_t)std::max(rows, 1))) return -1;
+    double* pv = nullptr;
+    if (h->alloc(&pv, nvec)) return -1;
+    h->cg_p = pv;                                  // the fused CG's search direction (own rows only)
+    if (h->alloc(&h->Saug, (size_t)std::max(blocks, 1) * D * D)) return -1;
+    h->cg_cap = rows;
+    return 0;
+}
+
+// Aggregates of consecutive reduced poses + the augmented BSR pattern [[S^, K], [K^T, I]].
+int build_coarse(ps_problem* h) {
+    const int nr = h->nr, D = h->D;
+    int G = h->coarse_req;
+    const int Gmax = (D == 6) ? 8 : 16;            // nc = 2 G D <= 96: L_c and L_c^-1 both LDS-resident
+    if (G < 0) G = (nr >= 48) ? std::min(Gmax, std::max(2, (nr + 14) / 28)) : 0;
+    G = std::min(G, Gmax);
+    if (G > 0 && nr < 2 * G) G = nr / 2;           // every group needs >= 2 poses (linear mode)
+    if (G < 2) G = 0;
+    h->G = G; h->coarse_built = true;
+    if (G == 0) {
+        h->ncb = h->nc = 0; h->nr_aug = nr; h->nnzb_aug = h->nnzb;
+        return ensure_cg_buffers(h, nr, h->nnzb);
+    }
+    const int ncb = 2 * G;
+    std::vector<int32_t> grp_of(nr), grp_ptr(G + 1);
+    std::vector<double> tau(nr);
+    for (int g = 0; g <= G; ++g) grp_ptr[g] = (int32_t)((long)nr * g / G);
+    for (int g = 0; g < G; ++g) {
+        const int n = grp_ptr[g + 1] - grp_ptr[g];
+        for (int i = grp_ptr[g]; i < grp_ptr[g + 1]; ++i) {
+            grp_of[i] = g;
+            tau[i] = ((i - grp_ptr[g]) - 0.5 * (n - 1)) / n;
+        }
+    }
+    const std::vector<int32_t>& rp = h->h_row_ptr;
+    const std::vector<int32_t>& ci = h->h_col_idx;
+    std::vector<int32_t> arp(nr + ncb + 1, 0), aci, slot(h->nnzb), fnz(nr);
+    aci.reserve((size_t)h->nnzb + 2 * (size_t)nr * ncb + ncb);
+    for (int i = 0; i < nr; ++i) {
+        fnz[i] = rp[i + 1] - rp[i];
+        for (int b = rp[i]; b < rp[i + 1]; ++b) { slot[b] = (int32_t)aci.size(); aci.push_back(ci[b]); }
+        for (int q = 0; q < ncb; ++q) aci.push_back(nr + q);
+        arp[i + 1] = (int32_t)aci.size();
+    }
+    for (int q = 0; q < ncb; ++q) {
+        for (int i = 0; i < nr; ++i) aci.push_back(i);
+        aci.push_back(nr + q);
+        arp[nr + q + 1] = (int32_t)aci.size();
+    }
+    // contiguous run of augmented-matrix blocks of fine row i whose column lies in group g
+    std::vector<int32_t> run((size_t)nr * (G + 1));
+    for (int i = 0; i < nr; ++i) {
+        int b = rp[i];
+        for (int g = 0; g <= G; ++g) {
+            while (b < rp[i + 1] && ci[b] < grp_ptr[g]) ++b;
+            run[(size_t)i * (G + 1) + g] = arp[i] + (b - rp[i]);
+        }
+    }
+    h->ncb = ncb; h->nc = ncb * D; h->nr_aug = nr + ncb; h->nnzb_aug = (int)aci.size();
+    if (h->upload(&h->run_ptr, run)) return -1;
+    if (h->upload(&h->grp_of, grp_of) || h->upload(&h->grp_ptr, grp_ptr) || h->upload(&h->tau, tau) ||
+        h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) || h->upload(&h->aug_slot, slot) ||
+        h->upload(&h->fine_nnz, fnz)) return -1;
+    if (h->alloc(&h->SZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
+        h->alloc(&h->Lci, (size_t)h->nc * h->nc) || h->alloc(&h->LciT, (size_t)h->nc * h->nc) ||
+        h->alloc(&h->tvec, (size_t)h->nc)) return -1;
+    return ensure_cg_buffers(h, h->nr_aug, h->nnzb_aug);
+}
+
 template <int D>
 int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
     const int nr = h->nr, cap = h->hist_cap;
     if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
+    if (!h->coarse_built && build_coarse(h)) return -1;
+    const int G = h->G, rows = h->nr_aug;
+    const int32_t* rp = G ? h->arow_ptr : h->row_ptr;
+    const int32_t* ci = G ? h->acol_idx : h->col_idx;
     hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
                        h->S, h->Linv, h->status);
     hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
-                       h->brow_of, h->Linv, h->S);
+                       h->brow_of, h->Linv, h->S, G ? h->aug_slot : h->ident_slot, h->Saug);
     hipLaunchKernelGGL(k_cg_prepare<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->g, h->Linv,
-                       h->cg_r[0], h->cg_w[0], h->cg_s[0], h->p0, h->cg_xh, h->status);
+                       h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh, h->status);
+    if (G) {
+        const int ncb = h->ncb, nc = h->nc;
+        hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), 0, h->stream,
+                           nr, G, h->run_ptr, h->acol_idx, h->tau, h->Saug, h->SZ);
+        hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
+                           nr, G, h->grp_ptr, h->tau, h->SZ, h->Ac);
+        HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(2 * (size_t)nc * nc * sizeof(double))));
+        hipLaunchKernelGGL(k_coarse_chol<D>, dim3(1), dim3(1024), 2 * (size_t)nc * nc * sizeof(double), h->stream,
+                           ncb, h->Ac, h->Lci, h->LciT, h->status);
+        hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr), dim3(256), (size_t)D * nc * sizeof(double), h->stream,
+                           nr, G, h->SZ, h->Lci, h->arow_ptr, h->fine_nnz, h->Saug);
+        hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, G, h->grp_ptr, h->tau, h->LciT,
+                           h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh);
+    }
     const double tol2 = tol * tol;
     int n = 0;                                     // launch counter: k = n - 1
     int chunk = std::max(h->pcg_chunk, h->last_pcg_iters + 2);
@@ -244,9 +351,9 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
         const int m = std::min(chunk, max_iters + 2 - n);
         for (int i = 0; i < m; ++i, ++n) {
             const int o = n & 1, nw = o ^ 1;
-            hipLaunchKernelGGL(k_cg_fused<D>, dim3(nr), dim3(256), 0, h->stream, nr, h->row_ptr, h->col_idx, h->S,
+            hipLaunchKernelGGL(k_cg_fused<D>, dim3(rows), dim3(PS_CG_THREADS), 0, h->stream, rows, rp, ci, h->Saug,
                                h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw], h->cg_s[nw],
-                               h->p0, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
+                               h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
                                h->status, h->scalars);
         }
         HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -255,8 +362,12 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
         done = h->h_status[ST_PCG_DONE] != 0 || n >= max_iters + 2;
         chunk = h->pcg_chunk;
     }
-    hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->Linv,
-                       h->cg_xh, h->x);
+    if (G)
+        hipLaunchKernelGGL(k_coarse_recover<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, G,
+                           h->grp_of, h->tau, h->Linv, h->Lci, h->cg_xh, h->x);
+    else
+        hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->Linv,
+                           h->cg_xh, h->x);
     h->last_pcg_iters = h->h_status[ST_PCG_ITERS];
     if (iters_out) *iters_out = h->h_status[ST_PCG_ITERS];
     const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
@@ -286,8 +397,8 @@ int linearize(ps_problem* h, double lambda) {
     }
     if (h->npair_items > 0) {
         StageTimer t(h, PS_ST_SCHUR);
-        hipLaunchKernelGGL(k_schur_pairs, dim3(cdiv((long)h->npair_items * 64, 256)), dim3(256), 0, h->stream,
-                           h->npair_items, h->pair_items, h->pairs, h->Z, h->S);
+        hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), 0, h->stream,
+                           h->pair_per_xcd, h->pair_order, h->pair_items, h->pairs, h->Z, h->S);
     }
     if (h->F > 0 && h->nr > 0) {
         StageTimer t(h, PS_ST_EDGES);
@@ -615,6 +726,22 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     if (!pitm.empty()) pitm.back().end = (int32_t)prs.size();
     h->npair_items = (int)pitm.size();
     if (h->upload(&h->pairs, pairs) || h->upload(&h->pair_items, pitm)) return -1;
+    {   // per-XCD work lists: items are sorted by block row, so equal contiguous shares of the PAIRS
+        // (not of the items) give each XCD a contiguous range of block rows with balanced work
+        std::vector<std::vector<int32_t>> lists(8);
+        const double total = (double)pairs.size();
+        for (size_t k = 0; k < pitm.size(); ++k) {
+            const int x = total > 0 ? std::min(7, (int)(8.0 * pitm[k].start / total)) : 0;
+            lists[x].push_back((int32_t)k);
+        }
+        size_t mx = 0;
+        for (auto& l : lists) mx = std::max(mx, l.size());
+        mx = (mx + 3) / 4 * 4;
+        std::vector<int32_t> order(8 * std::max<size_t>(mx, 4), -1);
+        for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), order.begin() + x * std::max<size_t>(mx, 4));
+        h->pair_per_xcd = (int)std::max<size_t>(mx, 4);
+        if (h->upload(&h->pair_order, order)) return -1;
+    }
     prs.clear(); prs.shrink_to_fit();
 
     // ---- factor contribution lists
@@ -663,13 +790,11 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         h->alloc(&h->rz_part, h->npartB) || h->alloc(&h->rr_part, h->npartB) || h->alloc(&h->pq_part, h->npartA) ||
         h->alloc(&h->hist, 2 * (size_t)h->hist_cap)) return -1;
     {
-        std::vector<int32_t> brow_of(nnzb);
+        std::vector<int32_t> brow_of(nnzb), ident(nnzb);
         for (int r = 0; r < nr; ++r) for (int b = row_ptr[r]; b < row_ptr[r + 1]; ++b) brow_of[b] = r;
-        if (h->upload(&h->brow_of, brow_of)) return -1;
-        if (h->alloc(&h->Linv, (size_t)nr * DD) || h->alloc(&h->cg_xh, nvec)) return -1;
-        for (int k = 0; k < 2; ++k)
-            if (h->alloc(&h->cg_r[k], nvec) || h->alloc(&h->cg_w[k], nvec) || h->alloc(&h->cg_s[k], nvec) ||
-                h->alloc(&h->cg_gd[k], 2 * (size_t)std::max(nr, 1))) return -1;
+        for (int b = 0; b < nnzb; ++b) ident[b] = b;
+        if (h->upload(&h->brow_of, brow_of) || h->upload(&h->ident_slot, ident)) return -1;
+        if (h->alloc(&h->Linv, (size_t)nr * DD)) return -1;
     }
     HIP_OK(hipMemsetAsync(h->x, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->p0, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
@@ -852,6 +977,10 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     if (!h || !name) return fail("null argument");
     const std::string n(name);
     if (n == "pcg_variant") { if (value != 0 && value != 1) return fail("pcg_variant must be 0 or 1"); h->pcg_variant = (int)value; }
+    else if (n == "coarse_groups") {
+        if (value < -1 || value > 64) return fail("coarse_groups out of range");
+        h->coarse_req = (int)value; h->coarse_built = false;
+    }
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }
     else return fail("unknown option: " + n);
     return 0;

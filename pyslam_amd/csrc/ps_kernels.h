@@ -238,13 +238,19 @@ __global__ __launch_bounds__(64) void k_pose_finalize(
 // ---------------------------------------------------------------------------
 // Schur off-diagonal blocks: one wave per reduced-system block
 // ---------------------------------------------------------------------------
+// XCD-aware work order: workgroup b runs on XCD b % 8 (observed dispatch rule; affects speed
+// only), and order[] lists, per XCD, the blocks of a CONTIGUOUS range of block rows.  All blocks
+// that share pose ri's Z rows (and, for neighbouring rows, pose rj's) then hit the same 4 MB L2
+// instead of being re-fetched by all eight.
 __global__ __launch_bounds__(256) void k_schur_pairs(
-    int nitems, const PairItem* __restrict__ items, const int2* __restrict__ pairs,
-    const double* __restrict__ Z, double* __restrict__ S)
+    int per_xcd, const int32_t* __restrict__ order, const PairItem* __restrict__ items,
+    const int2* __restrict__ pairs, const double* __restrict__ Z, double* __restrict__ S)
 {
-    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (w >= nitems) return;
+    const int local = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    if (local >= per_xcd) return;
+    const int w = order[(blockIdx.x & 7) * per_xcd + local];
+    if (w < 0) return;
     const PairItem it = items[w];
     double acc[36];
 #pragma unroll
@@ -670,11 +676,12 @@ __global__ __launch_bounds__(256) void k_block_jacobi_factor(
         for (int c = 0; c < D; ++c) m[r * D + c] = Li[r][c];
 }
 
-// S_ij <- Linv_i S_ij Linv_j^T  (one 64-thread workgroup per block, in place)
+// Sout[out_slot[b]] = Linv_i S_ij Linv_j^T  (one 64-thread workgroup per block; S itself is kept)
 template <int D>
 __global__ __launch_bounds__(64) void k_scale_blocks(
     int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
-    const int32_t* __restrict__ brow_of, const double* __restrict__ Linv, double* __restrict__ S)
+    const int32_t* __restrict__ brow_of, const double* __restrict__ Linv, const double* __restrict__ S,
+    const int32_t* __restrict__ out_slot, double* __restrict__ Sout)
 {
     constexpr int DD = D * D;
     __shared__ double sS[36], sT[36], sLi[36], sLj[36];
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(64) void k_scale_blocks(
         double v = 0.0;
 #pragma unroll
         for (int a = 0; a < D; ++a) v += sT[r * D + a] * sLj[c * D + a];
-        S[(size_t)b * DD + t] = v;
+        Sout[(size_t)out_slot[b] * DD + t] = v;
     }
 }
 
@@ -723,8 +730,10 @@ PS_DEV double cg_rnew(double r, double w, double s, double alpha, double beta) {
     return r - alpha * (w + beta * s);
 }
 
+#define PS_CG_WAVES 8
+#define PS_CG_THREADS (64 * PS_CG_WAVES)
 template <int D>
-__global__ __launch_bounds__(256) void k_cg_fused(
+__global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
     const double* __restrict__ S,
     const double* __restrict__ r_old, const double* __restrict__ w_old, const double* __restrict__ s_old,
@@ -735,7 +744,7 @@ __global__ __launch_bounds__(256) void k_cg_fused(
     int32_t* __restrict__ status, double* __restrict__ scalars)
 {
     __shared__ double lds[32];
-    __shared__ double part[4][8];
+    __shared__ double part[PS_CG_WAVES][8];
     constexpr int DD = D * D;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int row = blockIdx.x;
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(256) void k_cg_fused(
     const double thresh_in = scalars[SC_THRESH];
     double gs = 0.0, ds = 0.0;
     if (k >= 0)
-        for (int i = t; i < nr; i += 256) { gs += gd_in[i]; ds += gd_in[nr + i]; }
+        for (int i = t; i < nr; i += PS_CG_THREADS) { gs += gd_in[i]; ds += gd_in[nr + i]; }
     const int kk = lane >> 3, r = lane & 7;
     const int b0 = rbeg + w * 8 + kk;
     int cj = 0;
@@ -783,7 +792,7 @@ __global__ __launch_bounds__(256) void k_cg_fused(
     // ---- w_new(row) = S^(row,:) r_new, with r_new recomputed per column block
     double acc = 0.0;
     if (r < D) {
-        for (int b = b0; b < rend; b += 32) {
+        for (int b = b0; b < rend; b += 8 * PS_CG_WAVES) {
             const size_t j = (size_t)(b == b0 ? cj : col_idx[b]) * D;
             const double* sb = S + (size_t)b * DD + r * D;
 #pragma unroll
@@ -799,7 +808,9 @@ __global__ __launch_bounds__(256) void k_cg_fused(
     if (w == 0) {
         double gp = 0.0, dp = 0.0;
         if (lane < D) {
-            const double wn = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+            double wn = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < PS_CG_WAVES; ++ww) wn += part[ww][lane];
             const size_t i = (size_t)row * D + lane;
             const double sn = wi + beta * si;
             const double pn = ri + beta * pi;
@@ -823,6 +834,306 @@ __global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __rest
     double v = 0.0;
 #pragma unroll
     for (int a = 0; a < D; ++a) v += Linv[(size_t)i * D * D + a * D + c] * xh[(size_t)i * D + a];
+    x[t] = v;
+}
+
+// ---------------------------------------------------------------------------
+// Two-level (aggregation) preconditioning, folded into the matrix.
+//   coarse basis Z_c: per group of consecutive reduced poses, piecewise constant and
+//   piecewise linear (tau_i) per tangent dof  ->  ncb = 2 G coarse blocks, nc = ncb * D
+//   A_c = Z_c^T S Z_c = L_c L_c^T,  B = L^T Z_c (scaled coordinates)
+//   additive two-level M^-1 = I + B A_c^-1 B^T = V V^T,  V = [I, B L_c^-T]
+// CG on the augmented, consistent semi-definite system  V^T S^ V x~ = V^T g^,
+//        [[S^, K], [K^T, I]],   K = S^ B L_c^-T = L^-1 (S Z_c) L_c^-T
+// is exactly that PCG (Griebel 1994), so k_cg_fused runs unchanged on a larger BSR.
+// Low-frequency trajectory modes (lambda_min(M^-1 S) ~ 6e-4 on the C3 workload) are what
+// make block-Jacobi CG take ~100 iterations; the coarse space removes them (~25-30).
+// ---------------------------------------------------------------------------
+
+// The aggregates are piecewise constant / linear in the SCALED coordinates x^ = L^T x
+// (B = Z_c): A_c = Z_c^T S^ Z_c then inherits the unit block diagonal of S^ and stays well
+// conditioned even when block scales differ by 1e12 (priors), which keeps the augmented
+// matrix numerically positive semi-definite.
+
+// SZ[i][q] (D x D) = sum_j S^_ij * tau_j^a over the blocks of row i whose column lies in group g
+// (q = a*G + g; a = 0 constant, a = 1 linear).  Columns are sorted within a row and groups are
+// contiguous index ranges, so each (row, group) is a contiguous run of blocks: run_ptr[i*(G+1)+g].
+template <int D>
+__global__ __launch_bounds__(256) void k_coarse_rowsums(
+    int nr, int G, const int32_t* __restrict__ run_ptr, const int32_t* __restrict__ acol_idx,
+    const double* __restrict__ tau, const double* __restrict__ Saug, double* __restrict__ SZ)
+{
+    constexpr int DD = D * D;
+    const int ncb = 2 * G, i = blockIdx.x, nslot = ncb * DD;
+    for (int t = threadIdx.x; t < nslot; t += blockDim.x) {
+        const int q = t / DD, e = t % DD, a = q / G, g = q % G;
+        const int k0 = run_ptr[i * (G + 1) + g], k1 = run_ptr[i * (G + 1) + g + 1];
+        double acc = 0.0;
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) {
+            const double wgt = a ? tau[acol_idx[k]] : 1.0;
+            acc += Saug[(size_t)k * DD + e] * wgt;
+        }
+        SZ[(size_t)i * nslot + t] = acc;
+    }
+}
+
+// A_c[q][q'] (D x D block) = sum_{i in group(q)} tau_i^a SZ[i][q'] ; dense nc x nc, row-major
+template <int D>
+__global__ __launch_bounds__(256) void k_coarse_matrix(
+    int nr, int G, const int32_t* __restrict__ grp_ptr, const double* __restrict__ tau,
+    const double* __restrict__ SZ, double* __restrict__ Ac)
+{
+    constexpr int DD = D * D;
+    const int ncb = 2 * G, nc = ncb * D;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncb * ncb * DD) return;
+    const int e = t % DD, q2 = (t / DD) % ncb, q = t / (DD * ncb);
+    const int a = q / G, g = q % G;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int i = grp_ptr[g]; i < grp_ptr[g + 1]; ++i)
+        acc += (a ? tau[i] : 1.0) * SZ[((size_t)i * ncb + q2) * DD + e];
+    Ac[(size_t)(q * D + e / D) * nc + q2 * D + e % D] = acc;
+}
+
+// A_c = L_c L_c^T and Li = L_c^-1 by ONE workgroup, blocked by D x D (ncb block steps instead of
+// nc scalar steps), both matrices full row-major in LDS: 2 nc^2 doubles (nc <= 96).
+// Outputs Li and its transpose LiT (row-major, global) so later kernels read either coalesced.
+template <int D>
+__global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __restrict__ A,
+                                                       double* __restrict__ Li, double* __restrict__ LiT,
+                                                       int32_t* __restrict__ status)
+{
+    constexpr int DD = D * D;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int nc = ncb * D;
+    double* sL = sm;                    // nc x nc: A, overwritten by L (lower; upper part unused)
+    double* sX = sm + nc * nc;          // nc x nc: L^-1
+    __shared__ double sDi[32 * 36];     // inverse of every diagonal block of L
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int k = t; k < nc * nc; k += nt) { sL[k] = A[k]; sX[k] = 0.0; }
+    for (int J = 0; J < ncb; ++J) {
+        __syncthreads();
+        if (t == 0) {                   // D x D Cholesky of the diagonal block + its inverse
+            double L[D][D], Mi[D][D];
+            bool ok = true;
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < D; ++b2) { L[a][b2] = 0.0; Mi[a][b2] = 0.0; }
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double d = sL[(J * D + j) * nc + J * D + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+                ok = ok && (d > 0.0);
+                const double l = sqrt(d);
+                L[j][j] = l;
+#pragma unroll
+                for (int i = j + 1; i < D; ++i) {
+                    double v = sL[(J * D + i) * nc + J * D + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+                    L[i][j] = v / l;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                Mi[c][c] = 1.0 / L[c][c];
+#pragma unroll
+                for (int r = c + 1; r < D; ++r) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int k = c; k < r; ++k) v -= L[r][k] * Mi[k][c];
+                    Mi[r][c] = v / L[r][r];
+                }
+            }
+            if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < D; ++b2) {
+                    sL[(J * D + a) * nc + J * D + b2] = L[a][b2];
+                    sDi[J * DD + a * D + b2] = Mi[a][b2];
+                }
+        }
+        __syncthreads();
+        // panel: L_IJ = A_IJ L_JJ^-T   (entry (a,b) = sum_{k<=b} A_IJ[a][k] Mi[b][k])
+        const int m = ncb - J - 1;
+        double pv[4];
+        int np = 0;
+        for (int idx = t; idx < m * DD; idx += nt, ++np) {
+            const int I = J + 1 + idx / DD, e = idx % DD, a = e / D, b2 = e % D;
+            double v = 0.0;
+            for (int k = 0; k <= b2; ++k) v += sL[(I * D + a) * nc + J * D + k] * sDi[J * DD + b2 * D + k];
+            pv[np] = v;
+        }
+        __syncthreads();
+        np = 0;
+        for (int idx = t; idx < m * DD; idx += nt, ++np) {
+            const int I = J + 1 + idx / DD, e = idx % DD;
+            sL[(I * D + e / D) * nc + J * D + e % D] = pv[np];
+        }
+        __syncthreads();
+        // trailing update A_IK -= L_IJ L_KJ^T for J < K <= I
+        for (int idx = t; idx < m * m * DD; idx += nt) {
+            const int blk = idx / DD, e = idx % DD, a = e / D, b2 = e % D;
+            const int I = J + 1 + blk / m, K = J + 1 + blk % m;
+            if (K > I) continue;
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += sL[(I * D + a) * nc + J * D + k] * sL[(K * D + b2) * nc + J * D + k];
+            sL[(I * D + a) * nc + K * D + b2] -= v;
+        }
+    }
+    // X = L^-1 by block rows: X_RC = Mi_R (delta_RC I - sum_{K=C}^{R-1} L_RK X_KC), all C <= R in parallel
+    for (int R = 0; R < ncb; ++R) {
+        __syncthreads();
+        double tv[2];
+        int np = 0;
+        for (int idx = t; idx < (R + 1) * DD; idx += nt, ++np) {
+            const int C = idx / DD, e = idx % DD, a = e / D, b2 = e % D;
+            double v = (C == R && a == b2) ? 1.0 : 0.0;
+            for (int K = C; K < R; ++K)
+#pragma unroll
+                for (int k = 0; k < D; ++k) v -= sL[(R * D + a) * nc + K * D + k] * sX[(K * D + k) * nc + C * D + b2];
+            tv[np] = v;
+        }
+        __syncthreads();
+        np = 0;
+        for (int idx = t; idx < (R + 1) * DD; idx += nt, ++np) {          // stage T in the X_RC slots
+            const int C = idx / DD, e = idx % DD;
+            sX[(R * D + e / D) * nc + C * D + e % D] = tv[np];
+        }
+        __syncthreads();
+        np = 0;
+        for (int idx = t; idx < (R + 1) * DD; idx += nt, ++np) {
+            const int C = idx / DD, e = idx % DD, a = e / D, b2 = e % D;
+            double v = 0.0;
+            for (int k = 0; k <= a; ++k) v += sDi[R * DD + a * D + k] * sX[(R * D + k) * nc + C * D + b2];
+            tv[np] = v;
+        }
+        __syncthreads();
+        np = 0;
+        for (int idx = t; idx < (R + 1) * DD; idx += nt, ++np) {
+            const int C = idx / DD, e = idx % DD;
+            sX[(R * D + e / D) * nc + C * D + e % D] = tv[np];
+        }
+    }
+    __syncthreads();
+    for (int k = t; k < nc * nc; k += nt) {
+        const int r = k / nc, c = k % nc;
+        const double v = (c <= r) ? sX[k] : 0.0;
+        Li[k] = v;
+        LiT[(size_t)c * nc + r] = v;
+    }
+}
+
+// K_i = SZ_i Lci^T, written to both borders of the augmented BSR matrix.
+// One workgroup per fine block row i; thread per (r, c) of the D x nc strip.
+template <int D>
+__global__ __launch_bounds__(256) void k_coarse_border(
+    int nr, int G, const double* __restrict__ SZ, const double* __restrict__ Lci,
+    const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ fine_nnz, double* __restrict__ Saug)
+{
+    constexpr int DD = D * D;
+    extern __shared__ __attribute__((aligned(16))) double sT[];     // D x nc
+    const int ncb = 2 * G, nc = ncb * D;
+    const int i = blockIdx.x;
+    for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
+        const int r = t / nc, c = t % nc, q = c / D, cc = c % D;
+        sT[t] = SZ[((size_t)i * ncb + q) * DD + r * D + cc];
+    }
+    __syncthreads();
+    const int row_slot = arow_ptr[i] + fine_nnz[i];                 // first coarse column block of row i
+    for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
+        const int r = t / nc, c = t % nc, q = c / D, cc = c % D;
+        double v = 0.0;
+#pragma unroll 8
+        for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * Lci[(size_t)c * nc + k];
+        Saug[(size_t)(row_slot + q) * DD + r * D + cc] = v;                       // K   (row i, col nr+q)
+        Saug[(size_t)(arow_ptr[nr + q] + i) * DD + cc * D + r] = v;               // K^T (row nr+q, col i)
+    }
+}
+
+// coarse rows: diagonal block = I ; rhs b~_c = Lci * (Z_c^T g^) ; zero the CG vectors of the coarse rows
+template <int D>
+__global__ __launch_bounds__(1024) void k_coarse_rhs(
+    int nr, int G, const int32_t* __restrict__ grp_ptr, const double* __restrict__ tau,
+    const double* __restrict__ LciT, const int32_t* __restrict__ arow_ptr,
+    double* __restrict__ Saug, double* __restrict__ tvec /* nc scratch */,
+    double* __restrict__ r /* fine part holds g^ */, double* __restrict__ w, double* __restrict__ s,
+    double* __restrict__ p, double* __restrict__ x)
+{
+    constexpr int DD = D * D;
+    const int ncb = 2 * G, nc = ncb * D;
+    // t_q = sum_{i in g} tau_i^a g^_i : 8 lanes per output, then a 3-step butterfly
+    for (int base = 0; base < nc; base += blockDim.x / 8) {
+        const int t = base + threadIdx.x / 8, sub = threadIdx.x & 7;
+        double v = 0.0;
+        if (t < nc) {
+            const int q = t / D, c = t % D, a = q / G, gi = q % G;
+            for (int i = grp_ptr[gi] + sub; i < grp_ptr[gi + 1]; i += 8)
+                v += (a ? tau[i] : 1.0) * r[(size_t)i * D + c];
+        }
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        if (t < nc && sub == 0) tvec[t] = v;
+    }
+    for (int t = threadIdx.x; t < ncb * DD; t += blockDim.x) {
+        const int q = t / DD, e = t % DD;
+        Saug[(size_t)(arow_ptr[nr + q] + nr) * DD + e] = (e / D == e % D) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    __shared__ double stv[192];
+    for (int t = threadIdx.x; t < nc; t += blockDim.x) stv[t] = tvec[t];
+    __syncthreads();
+    for (int base = 0; base < nc; base += blockDim.x / 8) {         // b~_c[t] = sum_{k<=t} Lci[t][k] t_k
+        const int t = base + threadIdx.x / 8, sub = threadIdx.x & 7;
+        double v = 0.0;
+        if (t < nc) {
+#pragma unroll 4
+            for (int k = sub; k <= t; k += 8) v += LciT[(size_t)k * nc + t] * stv[k];
+        }
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        if (t < nc && sub == 0) {
+            const size_t o = (size_t)nr * D + t;
+            r[o] = v; w[o] = 0.0; s[o] = 0.0; p[o] = 0.0; x[o] = 0.0;
+        }
+    }
+}
+
+// x^_i = x~_f,i + y_const[g(i)] + tau_i y_lin[g(i)] with y = Lci^T x~_c ;  x_i = Linv_i^T x^_i
+// every workgroup first forms y (nc values) in LDS: y_k = sum_{m>=k} Lci[m][k] x~_c[m]
+template <int D>
+__global__ __launch_bounds__(256) void k_coarse_recover(
+    int nr, int G, const int32_t* __restrict__ grp_of, const double* __restrict__ tau,
+    const double* __restrict__ Linv, const double* __restrict__ Lci, const double* __restrict__ xh,
+    double* __restrict__ x)
+{
+    __shared__ double sy[192];
+    const int ncb = 2 * G, nc = ncb * D;
+    const double* xc = xh + (size_t)nr * D;
+    for (int base = 0; base < nc; base += blockDim.x / 8) {
+        const int k = base + threadIdx.x / 8, sub = threadIdx.x & 7;
+        double v = 0.0;
+        if (k < nc) {
+#pragma unroll 4
+            for (int m = k + sub; m < nc; m += 8) v += Lci[(size_t)m * nc + k] * xc[m];
+        }
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        if (k < nc && sub == 0) sy[k] = v;
+    }
+    __syncthreads();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nr * D) return;
+    const int i = t / D, c = t % D, gi = grp_of[i];
+    double v = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        const double xhat = xh[(size_t)i * D + a] + sy[gi * D + a] + tau[i] * sy[(G + gi) * D + a];
+        v += Linv[(size_t)i * D * D + a * D + c] * xhat;
+    }
     x[t] = v;
 }
 

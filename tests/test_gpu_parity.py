@@ -95,14 +95,20 @@ def test_reduced_system(name):
     assert np.abs(S - S.T).max() <= 1e-13 * np.abs(S).max()
 
 
-@pytest.mark.parametrize('variant', [1, 0], ids=['fused_cg', 'classic_pcg'])
+@pytest.mark.parametrize('variant', ['fused_cg', 'fused_cg_two_level', 'classic_pcg'])
 @pytest.mark.parametrize('name', SOLVE_CASES)
 def test_first_step_matches_reference_spsolve(name, variant):
     g = load_golden(name)
     lp = golden_lp(g)
     pf = bool(g.get('points_first', True))
     dev = device(lp)
-    dev.set_option('pcg_variant', variant)
+    dev.set_option('pcg_variant', 0 if variant == 'classic_pcg' else 1)
+    if variant == 'fused_cg':
+        dev.set_option('coarse_groups', 0)                 # block-Jacobi only
+    elif variant == 'fused_cg_two_level':
+        if lp.num_reduced < 4:
+            pytest.skip('too few poses for a coarse level')
+        dev.set_option('coarse_groups', max(2, min(7, lp.num_reduced // 3)))
     dev.linearize(0.)
     # PCG tolerance (preconditioned relative residual).  1e-12 everywhere except the
     # pose graphs: stiffness 1e6 (prior) / 31.6 (odometry) / 1 (loop), long chains => 
