@@ -77,6 +77,8 @@ def main():
     ap.add_argument('--kf', type=int, default=KF)
     ap.add_argument('--lm', type=int, default=LM_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-sharded', action='store_true',
+                    help='use the multi-GPU driver (RCCL all-reduce) even with one rank (testing)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -89,15 +91,17 @@ def main():
     from pyslam_amd import synthetic
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     lp, _ = synthetic.stereo_ba(num_kf=args.kf, num_lm=args.lm, obs_per_lm=OBS_PER_LM,
                                 half_window=HALF_WINDOW, seed=0,
                                 lm_offset=rank * args.lm, lm_total=world * args.lm)
 
-    if world > 1:
+    if dist is not None:
         from pyslam_amd.distributed import ShardedDeviceProblem
         dev = ShardedDeviceProblem(lp, dist)
     else:

@@ -91,9 +91,9 @@ struct ps_problem {
     int coarse_req = -1;            // requested number of groups: -1 = auto, 0 = off
     int G = 0, ncb = 0, nc = 0, nr_aug = 0, nnzb_aug = 0;
     size_t cg_cap = 0;              // CG vectors are allocated for this many block rows
-    int32_t *grp_of = nullptr, *grp_ptr = nullptr, *arow_ptr = nullptr, *acol_idx = nullptr,
-            *aug_slot = nullptr, *fine_nnz = nullptr, *run_ptr = nullptr;
-    double *tau = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr;
+    int32_t *pnode = nullptr, *slo = nullptr, *shi = nullptr, *run_lo = nullptr, *run_hi = nullptr,
+            *arow_ptr = nullptr, *acol_idx = nullptr, *aug_slot = nullptr, *fine_nnz = nullptr;
+    double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr;
     bool coarse_built = false;
     // scalars
     double *cost_partials = nullptr, *scalars = nullptr, *h_scalars = nullptr;
@@ -254,29 +254,32 @@ int ensure_cg_buffers(ps_problem* h, int rows, int blocks) {
     return 0;
 }
 
-// Aggregates of consecutive reduced poses + the augmented BSR pattern [[S^, K], [K^T, I]].
+// Coarse nodes (hat functions over the reduced-pose index) + the augmented BSR pattern
+// [[S^, K], [K^T, I]].  coarse_req = number of intervals G (ncb = G + 1 nodes).
 int build_coarse(ps_problem* h) {
     const int nr = h->nr, D = h->D;
     int G = h->coarse_req;
-    const int Gmax = (D == 6) ? 8 : 16;            // nc = 2 G D <= 96: L_c and L_c^-1 both LDS-resident
-    if (G < 0) G = (nr >= 48) ? std::min(Gmax, std::max(2, (nr + 14) / 28)) : 0;
+    const int Gmax = (D == 6) ? 15 : 31;           // nc = (G + 1) D <= 96: L_c and L_c^-1 both LDS-resident
+    if (G < 0) G = (nr >= 48) ? std::min(12, std::max(3, (nr + 9) / 18)) : 0;
     G = std::min(G, Gmax);
-    if (G > 0 && nr < 2 * G) G = nr / 2;           // every group needs >= 2 poses (linear mode)
-    if (G < 2) G = 0;
+    if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
+    if (G < 1) G = 0;
     h->G = G; h->coarse_built = true;
     if (G == 0) {
         h->ncb = h->nc = 0; h->nr_aug = nr; h->nnzb_aug = h->nnzb;
         return ensure_cg_buffers(h, nr, h->nnzb);
     }
-    const int ncb = 2 * G;
-    std::vector<int32_t> grp_of(nr), grp_ptr(G + 1);
-    std::vector<double> tau(nr);
-    for (int g = 0; g <= G; ++g) grp_ptr[g] = (int32_t)((long)nr * g / G);
-    for (int g = 0; g < G; ++g) {
-        const int n = grp_ptr[g + 1] - grp_ptr[g];
-        for (int i = grp_ptr[g]; i < grp_ptr[g + 1]; ++i) {
-            grp_of[i] = g;
-            tau[i] = ((i - grp_ptr[g]) - 0.5 * (n - 1)) / n;
+    const int ncb = G + 1;
+    std::vector<int32_t> pnode(nr), slo(ncb, nr), shi(ncb, 0);
+    std::vector<double> pw0(nr), pw1(nr);
+    for (int i = 0; i < nr; ++i) {
+        const double u = (double)i * G / (double)(nr - 1);
+        const int k = std::min(G - 1, (int)u);
+        const double th = u - k;
+        pnode[i] = k; pw0[i] = 1.0 - th; pw1[i] = th;
+        for (int q = k; q <= k + 1; ++q) {
+            if ((q == k ? pw0[i] : pw1[i]) == 0.0) continue;
+            slo[q] = std::min(slo[q], i); shi[q] = std::max(shi[q], i + 1);
         }
     }
     const std::vector<int32_t>& rp = h->h_row_ptr;
@@ -294,20 +297,20 @@ int build_coarse(ps_problem* h) {
         aci.push_back(nr + q);
         arp[nr + q + 1] = (int32_t)aci.size();
     }
-    // contiguous run of augmented-matrix blocks of fine row i whose column lies in group g
-    std::vector<int32_t> run((size_t)nr * (G + 1));
-    for (int i = 0; i < nr; ++i) {
-        int b = rp[i];
-        for (int g = 0; g <= G; ++g) {
-            while (b < rp[i + 1] && ci[b] < grp_ptr[g]) ++b;
-            run[(size_t)i * (G + 1) + g] = arp[i] + (b - rp[i]);
+    // contiguous run of augmented-matrix blocks of fine row i whose column lies in supp(q)
+    std::vector<int32_t> rlo((size_t)nr * ncb), rhi((size_t)nr * ncb);
+    for (int i = 0; i < nr; ++i)
+        for (int q = 0; q < ncb; ++q) {
+            const int32_t* lo = std::lower_bound(ci.data() + rp[i], ci.data() + rp[i + 1], slo[q]);
+            const int32_t* hi = std::lower_bound(ci.data() + rp[i], ci.data() + rp[i + 1], shi[q]);
+            rlo[(size_t)i * ncb + q] = arp[i] + (int32_t)(lo - (ci.data() + rp[i]));
+            rhi[(size_t)i * ncb + q] = arp[i] + (int32_t)(hi - (ci.data() + rp[i]));
         }
-    }
     h->ncb = ncb; h->nc = ncb * D; h->nr_aug = nr + ncb; h->nnzb_aug = (int)aci.size();
-    if (h->upload(&h->run_ptr, run)) return -1;
-    if (h->upload(&h->grp_of, grp_of) || h->upload(&h->grp_ptr, grp_ptr) || h->upload(&h->tau, tau) ||
-        h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) || h->upload(&h->aug_slot, slot) ||
-        h->upload(&h->fine_nnz, fnz)) return -1;
+    if (h->upload(&h->pnode, pnode) || h->upload(&h->slo, slo) || h->upload(&h->shi, shi) ||
+        h->upload(&h->pw0, pw0) || h->upload(&h->pw1, pw1) || h->upload(&h->run_lo, rlo) ||
+        h->upload(&h->run_hi, rhi) || h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) ||
+        h->upload(&h->aug_slot, slot) || h->upload(&h->fine_nnz, fnz)) return -1;
     if (h->alloc(&h->SZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci, (size_t)h->nc * h->nc) || h->alloc(&h->LciT, (size_t)h->nc * h->nc) ||
         h->alloc(&h->tvec, (size_t)h->nc)) return -1;
@@ -330,18 +333,19 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
                        h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh, h->status);
     if (G) {
         const int ncb = h->ncb, nc = h->nc;
-        hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), 0, h->stream,
-                           nr, G, h->run_ptr, h->acol_idx, h->tau, h->Saug, h->SZ);
+        hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), 0, h->stream, nr, ncb, h->run_lo, h->run_hi,
+                           h->acol_idx, h->pnode, h->pw0, h->pw1, h->Saug, h->SZ);
         hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
-                           nr, G, h->grp_ptr, h->tau, h->SZ, h->Ac);
+                           nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->SZ, h->Ac);
         HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(2 * (size_t)nc * nc * sizeof(double))));
         hipLaunchKernelGGL(k_coarse_chol<D>, dim3(1), dim3(1024), 2 * (size_t)nc * nc * sizeof(double), h->stream,
                            ncb, h->Ac, h->Lci, h->LciT, h->status);
         hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr), dim3(256), (size_t)D * nc * sizeof(double), h->stream,
-                           nr, G, h->SZ, h->Lci, h->arow_ptr, h->fine_nnz, h->Saug);
-        hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, G, h->grp_ptr, h->tau, h->LciT,
-                           h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh);
+                           nr, ncb, h->SZ, h->Lci, h->arow_ptr, h->fine_nnz, h->Saug);
+        hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
+                           h->pw0, h->pw1, h->LciT, h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
+                           h->cg_s[0], h->cg_p, h->cg_xh);
     }
     const double tol2 = tol * tol;
     int n = 0;                                     // launch counter: k = n - 1
@@ -363,8 +367,8 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
         chunk = h->pcg_chunk;
     }
     if (G)
-        hipLaunchKernelGGL(k_coarse_recover<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, G,
-                           h->grp_of, h->tau, h->Linv, h->Lci, h->cg_xh, h->x);
+        hipLaunchKernelGGL(k_coarse_recover<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->ncb,
+                           h->pnode, h->pw0, h->pw1, h->Linv, h->Lci, h->cg_xh, h->x);
     else
         hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->Linv,
                            h->cg_xh, h->x);
@@ -384,7 +388,7 @@ int linearize(ps_problem* h, double lambda) {
     HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
     if (h->nv > 0) {
         StageTimer t(h, PS_ST_LANDMARK);
-        hipLaunchKernelGGL(k_landmark_pass, dim3(cdiv(h->nv, 256)), dim3(256), 0, h->stream, h->nv, h->lm_ptr,
+        hipLaunchKernelGGL(k_landmark_pass, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr,
                            h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,
                            h->Cinv, h->cvec, h->status);
     }
@@ -397,7 +401,9 @@ int linearize(ps_problem* h, double lambda) {
     }
     if (h->npair_items > 0) {
         StageTimer t(h, PS_ST_SCHUR);
-        hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), 0, h->stream,
+        const size_t lds = 4 * (size_t)PS_SP_LDS_PER_WAVE * sizeof(double);
+        HIP_OK(hipFuncSetAttribute((const void*)k_schur_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), lds, h->stream,
                            h->pair_per_xcd, h->pair_order, h->pair_items, h->pairs, h->Z, h->S);
     }
     if (h->F > 0 && h->nr > 0) {
@@ -434,7 +440,7 @@ int cost_pass(ps_problem* h, int include_all, int scalar_slot) {
 int backsub(ps_problem* h) {
     if (h->nv == 0) return 0;
     StageTimer t(h, PS_ST_BACKSUB);
-    hipLaunchKernelGGL(k_backsub, dim3(cdiv(h->nv, 256)), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
+    hipLaunchKernelGGL(k_backsub, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
                        h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl);
     return 0;
 }
@@ -978,7 +984,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     const std::string n(name);
     if (n == "pcg_variant") { if (value != 0 && value != 1) return fail("pcg_variant must be 0 or 1"); h->pcg_variant = (int)value; }
     else if (n == "coarse_groups") {
-        if (value < -1 || value > 64) return fail("coarse_groups out of range");
+        if (value < -1 || value > 64) return fail("coarse_groups out of range (-1 auto, 0 off, else number of hat intervals)");
         h->coarse_req = (int)value; h->coarse_built = false;
     }
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }

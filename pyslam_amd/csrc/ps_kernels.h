@@ -67,8 +67,34 @@ PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
 }
 
 // ---------------------------------------------------------------------------
-// landmark pass
+// landmark pass: 16 lanes cooperate on one landmark (4 landmarks per wave), one observation
+// per lane: loads of the 32-byte records and stores of the 144-byte Z rows are contiguous
+// across lanes, residual + both Jacobians are evaluated ONCE, and H_ll / b_l are reduced with
+// a 4-step xor butterfly inside the 16-lane group (fixed order => deterministic).
+// Landmarks with more than 16 observations loop (lane j takes observations j, j+16, ...) and
+// re-evaluate in a second sweep to emit Z.
 // ---------------------------------------------------------------------------
+#define PS_LM_GROUP 16
+
+PS_DEV double group16_sum(double v) {
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+PS_DEV void lm_emit_z(const ReprojEval& ev, double M00, double M10, double M11, double M20, double M21,
+                      double M22, double* __restrict__ z) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const double w0 = ev.Jp[a] * ev.Jl[0] + ev.Jp[6 + a] * ev.Jl[3] + ev.Jp[12 + a] * ev.Jl[6];
+        const double w1 = ev.Jp[a] * ev.Jl[1] + ev.Jp[6 + a] * ev.Jl[4] + ev.Jp[12 + a] * ev.Jl[7];
+        const double w2 = ev.Jp[a] * ev.Jl[2] + ev.Jp[6 + a] * ev.Jl[5] + ev.Jp[12 + a] * ev.Jl[8];
+        z[3 * a] = w0 * M00;
+        z[3 * a + 1] = w0 * M10 + w1 * M11;
+        z[3 * a + 2] = w0 * M20 + w1 * M21 + w2 * M22;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_landmark_pass(
     int nv, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_point,
     const LObs* __restrict__ lobs, const double* __restrict__ poses,
@@ -77,18 +103,28 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
     double* __restrict__ Z, double* __restrict__ Cinv, double* __restrict__ cvec,
     int32_t* __restrict__ status)
 {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nv) return;
-    const int b = lm_ptr[v], e = lm_ptr[v + 1];
-    const int pt = lm_point[v];
-    const double pw[3] = {points[3 * pt], points[3 * pt + 1], points[3 * pt + 2]};
+    const int v = blockIdx.x * (blockDim.x / PS_LM_GROUP) + threadIdx.x / PS_LM_GROUP;
+    const int sub = threadIdx.x & (PS_LM_GROUP - 1);
+    const bool live = v < nv;                       // whole 16-lane groups are live or not
+    int b = 0, e = 0;
+    double pw[3] = {0.0, 0.0, 0.0};
+    if (live) {
+        b = lm_ptr[v]; e = lm_ptr[v + 1];
+        const int pt = lm_point[v];
+        pw[0] = points[3 * pt]; pw[1] = points[3 * pt + 1]; pw[2] = points[3 * pt + 2];
+    }
+    const bool single = (e - b) <= PS_LM_GROUP;     // the common case: one observation per lane
 
     double H00 = 0, H10 = 0, H11 = 0, H20 = 0, H21 = 0, H22 = 0, b0 = 0, b1 = 0, b2 = 0;
-    for (int i = b; i < e; ++i) {
+    ReprojEval ev;
+    bool have = false, variable_pose = false;
+    for (int i = b + sub; i < e; i += PS_LM_GROUP) {
         const LObs o = lobs[i];
-        const Se3 T = se3_load(poses + 12 * PS_POSE_OF(o));
-        ReprojEval ev;
-        reproj_eval<false, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        const int pose = PS_POSE_OF(o);
+        const Se3 T = se3_load(poses + 12 * pose);
+        variable_pose = pose_rid[pose] >= 0;
+        reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        have = true;
         const double* J = ev.Jl;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -103,6 +139,11 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
             b2 -= J[3 * k + 2] * ev.r[k];
         }
     }
+    H00 = group16_sum(H00); H10 = group16_sum(H10); H11 = group16_sum(H11);
+    H20 = group16_sum(H20); H21 = group16_sum(H21); H22 = group16_sum(H22);
+    b0 = group16_sum(b0); b1 = group16_sum(b1); b2 = group16_sum(b2);
+    if (!live) return;
+
     const double damp = 1.0 + lambda;
     H00 *= damp; H11 *= damp; H22 *= damp;
     // H_ll = C C^T
@@ -113,36 +154,31 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
     const double l21 = (H21 - l20 * l10) / l11;
     const double d2 = H22 - l20 * l20 - l21 * l21;
     const double l22 = sqrt(d2);
-    if (!(H00 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) atomicAdd(&status[ST_LM_FAIL], 1);
     // M = C^-1 (lower)
     const double M00 = 1.0 / l00, M11 = 1.0 / l11, M22 = 1.0 / l22;
     const double M10 = -l10 * M00 * M11;
     const double M21 = -l21 * M11 * M22;
     const double M20 = -(l20 * M00 + l21 * M10) * M22;
-    double* ci = Cinv + 6 * (size_t)v;
-    ci[0] = M00; ci[1] = M10; ci[2] = M11; ci[3] = M20; ci[4] = M21; ci[5] = M22;
-    double* cv = cvec + 3 * (size_t)v;
-    cv[0] = M00 * b0;
-    cv[1] = M10 * b0 + M11 * b1;
-    cv[2] = M20 * b0 + M21 * b1 + M22 * b2;
-
-    for (int i = b; i < e; ++i) {
+    if (sub == 0) {
+        if (!(H00 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) atomicAdd(&status[ST_LM_FAIL], 1);
+        double* ci = Cinv + 6 * (size_t)v;
+        ci[0] = M00; ci[1] = M10; ci[2] = M11; ci[3] = M20; ci[4] = M21; ci[5] = M22;
+        double* cv = cvec + 3 * (size_t)v;
+        cv[0] = M00 * b0;
+        cv[1] = M10 * b0 + M11 * b1;
+        cv[2] = M20 * b0 + M21 * b1 + M22 * b2;
+    }
+    if (single) {
+        if (have && variable_pose) lm_emit_z(ev, M00, M10, M11, M20, M21, M22, Z + 18 * (size_t)(b + sub));
+        return;
+    }
+    for (int i = b + sub; i < e; i += PS_LM_GROUP) {
         const LObs o = lobs[i];
         const int pose = PS_POSE_OF(o);
         if (pose_rid[pose] < 0) continue;
         const Se3 T = se3_load(poses + 12 * pose);
-        ReprojEval ev;
         reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
-        double* z = Z + 18 * (size_t)i;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const double w0 = ev.Jp[a] * ev.Jl[0] + ev.Jp[6 + a] * ev.Jl[3] + ev.Jp[12 + a] * ev.Jl[6];
-            const double w1 = ev.Jp[a] * ev.Jl[1] + ev.Jp[6 + a] * ev.Jl[4] + ev.Jp[12 + a] * ev.Jl[7];
-            const double w2 = ev.Jp[a] * ev.Jl[2] + ev.Jp[6 + a] * ev.Jl[5] + ev.Jp[12 + a] * ev.Jl[8];
-            z[3 * a] = w0 * M00;
-            z[3 * a + 1] = w0 * M10 + w1 * M11;
-            z[3 * a + 2] = w0 * M20 + w1 * M21 + w2 * M22;
-        }
+        lm_emit_z(ev, M00, M10, M11, M20, M21, M22, Z + 18 * (size_t)i);
     }
 }
 
@@ -242,12 +278,23 @@ __global__ __launch_bounds__(64) void k_pose_finalize(
 // only), and order[] lists, per XCD, the blocks of a CONTIGUOUS range of block rows.  All blocks
 // that share pose ri's Z rows (and, for neighbouring rows, pose rj's) then hit the same 4 MB L2
 // instead of being re-fetched by all eight.
+//
+// Z rows are 144 B and scattered, so a lane-per-pair gather issues 18 fully divergent 16-byte
+// loads per pair (41 M L1 accesses at C3, the measured bottleneck).  Instead each wave stages the
+// 128 rows of a 64-pair chunk through LDS: 9 consecutive lanes fetch the 9 x 16 B of ONE row, so
+// a load instruction touches ~14 cache lines instead of 64 (4.5x fewer L1 accesses); the rows sit
+// in LDS at their natural 144-byte stride, which is conflict-free for the ds_read_b128 of the
+// lane-per-pair compute phase that follows.  Waves never share LDS data: no workgroup barrier.
+#define PS_SP_ROWS 128                       // rows per chunk: 64 x (a, b)
+#define PS_SP_LDS_PER_WAVE 2400               // doubles: 128 rows x 18 = 2304, epilogue 36 x 65 + 36 = 2376
 __global__ __launch_bounds__(256) void k_schur_pairs(
     int per_xcd, const int32_t* __restrict__ order, const PairItem* __restrict__ items,
     const int2* __restrict__ pairs, const double* __restrict__ Z, double* __restrict__ S)
 {
-    const int lane = threadIdx.x & 63;
-    const int local = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* rows = smem + wv * PS_SP_LDS_PER_WAVE;
+    const int local = (blockIdx.x >> 3) * 4 + wv;
     if (local >= per_xcd) return;
     const int w = order[(blockIdx.x & 7) * per_xcd + local];
     if (w < 0) return;
@@ -255,33 +302,69 @@ __global__ __launch_bounds__(256) void k_schur_pairs(
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    for (int i = it.start + lane; i < it.end; i += 64) {
-        const int2 p = pairs[i];
-        double za[18], zb[18];
-        const double* pa = Z + 18 * (size_t)p.x;
-        const double* pb = Z + 18 * (size_t)p.y;
+    const int slot = lane / 9, piece = lane - 9 * slot;         // lane 63: slot 7 (idle)
+    for (int base = it.start; base < it.end; base += 64) {
+        const int n = min(64, it.end - base);                   // pairs in this chunk
+        int2 mine = make_int2(0, 0);
+        if (lane < n) mine = pairs[base + lane];
+        // ---- cooperative fetch: instruction k brings rows 7k .. 7k+6 (row r < 64: a_r, else b_{r-64})
+        double2 stage[19];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) { za[k] = pa[k]; zb[k] = pb[k]; }
+        for (int k = 0; k < 19; ++k) {
+            const int r = 7 * k + slot;
+            const int pr = r & 63;
+            const int ia = __shfl(mine.x, pr, 64), ib = __shfl(mine.y, pr, 64);
+            const bool ok = slot < 7 && r < PS_SP_ROWS && pr < n;
+            const size_t zrow = (size_t)((r < 64) ? ia : ib);
+            stage[k] = ok ? *reinterpret_cast<const double2*>(Z + 18 * zrow + 2 * piece) : make_double2(0.0, 0.0);
+        }
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+        for (int k = 0; k < 19; ++k) {
+            const int r = 7 * k + slot;
+            if (slot < 7 && r < PS_SP_ROWS) *reinterpret_cast<double2*>(rows + 18 * r + 2 * piece) = stage[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- lane-per-pair accumulate from LDS
+        if (lane < n) {
+            double za[18], zb[18];
+            const double2* pa = reinterpret_cast<const double2*>(rows + 18 * lane);
+            const double2* pb = reinterpret_cast<const double2*>(rows + 18 * (64 + lane));
 #pragma unroll
-            for (int b = 0; b < 6; ++b)
-                acc[6 * a + b] += za[3 * a] * zb[3 * b] + za[3 * a + 1] * zb[3 * b + 1] + za[3 * a + 2] * zb[3 * b + 2];
+            for (int k = 0; k < 9; ++k) {
+                const double2 u = pa[k], v = pb[k];
+                za[2 * k] = u.x; za[2 * k + 1] = u.y; zb[2 * k] = v.x; zb[2 * k + 1] = v.y;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b)
+                    acc[6 * a + b] += za[3 * a] * zb[3 * b] + za[3 * a + 1] * zb[3 * b + 1] + za[3 * a + 2] * zb[3 * b + 2];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    double mine = 0.0, mineT = 0.0;
+    // ---- reduce the 36 accumulators over the 64 lanes through LDS (the row buffer is free now):
+    // lane l stores acc[k] at [k][l] (row stride 65 doubles: 2-way conflicts at most), then lane k
+    // sums row k in lane order -- a fixed order, ~8x cheaper than 36 shuffle butterflies.
+    double* red = rows;                      // 36 * 65 + 36 = 2376 doubles <= PS_SP_LDS_PER_WAVE
+#pragma unroll
+    for (int k = 0; k < 36; ++k) red[k * 65 + lane] = acc[k];
+    __builtin_amdgcn_wave_barrier();
+    double mine_v = 0.0;
+    if (lane < 36) {
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) mine_v += red[lane * 65 + l];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double* sums = rows + 36 * 65;           // 36 block entries, for the mirrored / symmetrised write
+    if (lane < 36) sums[lane] = mine_v;
+    __builtin_amdgcn_wave_barrier();
     const int r = lane / 6, c = lane % 6;
-#pragma unroll
-    for (int k = 0; k < 36; ++k) {
-        const double s = wave_sum(acc[k]);
-        if (lane == k) mine = s;
-        if (lane < 36 && c * 6 + r == k) mineT = s;
-    }
     if (lane < 36) {
         if (it.slot == it.slotT) {
-            S[(size_t)it.slot * 36 + lane] -= mine + mineT;
+            S[(size_t)it.slot * 36 + lane] -= mine_v + sums[c * 6 + r];
         } else {
-            S[(size_t)it.slot * 36 + lane] -= mine;
-            S[(size_t)it.slotT * 36 + c * 6 + r] -= mine;
+            S[(size_t)it.slot * 36 + lane] -= mine_v;
+            S[(size_t)it.slotT * 36 + c * 6 + r] -= mine_v;
         }
     }
 }
@@ -839,61 +922,67 @@ __global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __rest
 
 // ---------------------------------------------------------------------------
 // Two-level (aggregation) preconditioning, folded into the matrix.
-//   coarse basis Z_c: per group of consecutive reduced poses, piecewise constant and
-//   piecewise linear (tau_i) per tangent dof  ->  ncb = 2 G coarse blocks, nc = ncb * D
-//   A_c = Z_c^T S Z_c = L_c L_c^T,  B = L^T Z_c (scaled coordinates)
+//   coarse basis P: hat functions over the reduced-pose index (ncb nodes), nc = ncb * D
+//   A_c = P^T S^ P = L_c L_c^T,  B = P (scaled coordinates)
 //   additive two-level M^-1 = I + B A_c^-1 B^T = V V^T,  V = [I, B L_c^-T]
 // CG on the augmented, consistent semi-definite system  V^T S^ V x~ = V^T g^,
-//        [[S^, K], [K^T, I]],   K = S^ B L_c^-T = L^-1 (S Z_c) L_c^-T
+//        [[S^, K], [K^T, I]],   K = S^ P L_c^-T
 // is exactly that PCG (Griebel 1994), so k_cg_fused runs unchanged on a larger BSR.
 // Low-frequency trajectory modes (lambda_min(M^-1 S) ~ 6e-4 on the C3 workload) are what
 // make block-Jacobi CG take ~100 iterations; the coarse space removes them (~25-30).
 // ---------------------------------------------------------------------------
 
-// The aggregates are piecewise constant / linear in the SCALED coordinates x^ = L^T x
-// (B = Z_c): A_c = Z_c^T S^ Z_c then inherits the unit block diagonal of S^ and stays well
-// conditioned even when block scales differ by 1e12 (priors), which keeps the augmented
-// matrix numerically positive semi-definite.
+// Coarse space: continuous piecewise-linear "hat" functions over the reduced-pose index, one
+// per coarse node and tangent dof, expressed in the SCALED coordinates x^ = L^T x (B = P, the
+// interpolation matrix with two weights per pose).  A_c = P^T S^ P inherits the unit block
+// diagonal of S^ and stays well conditioned even when block scales differ by 1e12 (priors),
+// which keeps the augmented matrix numerically positive semi-definite.  Hats need ~35 % fewer
+// coarse unknowns than discontinuous constant+linear aggregates for the same iteration count.
+//   pnode[i], pw0[i], pw1[i] : pose i interpolates nodes pnode[i] (weight pw0) and pnode[i]+1 (pw1)
+//   slo[q], shi[q]           : poses in the support of node q
+PS_DEV double coarse_weight(int j, int q, const int32_t* __restrict__ pnode,
+                            const double* __restrict__ pw0, const double* __restrict__ pw1) {
+    return (pnode[j] == q) ? pw0[j] : pw1[j];
+}
 
-// SZ[i][q] (D x D) = sum_j S^_ij * tau_j^a over the blocks of row i whose column lies in group g
-// (q = a*G + g; a = 0 constant, a = 1 linear).  Columns are sorted within a row and groups are
-// contiguous index ranges, so each (row, group) is a contiguous run of blocks: run_ptr[i*(G+1)+g].
+// SZ[i][q] (D x D) = sum_j S^_ij w(j,q) over the contiguous run of row i's blocks whose column
+// lies in the support of node q (run_lo / run_hi, precomputed).  One workgroup per fine row.
 template <int D>
 __global__ __launch_bounds__(256) void k_coarse_rowsums(
-    int nr, int G, const int32_t* __restrict__ run_ptr, const int32_t* __restrict__ acol_idx,
-    const double* __restrict__ tau, const double* __restrict__ Saug, double* __restrict__ SZ)
+    int nr, int ncb, const int32_t* __restrict__ run_lo, const int32_t* __restrict__ run_hi,
+    const int32_t* __restrict__ acol_idx, const int32_t* __restrict__ pnode,
+    const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ Saug, double* __restrict__ SZ)
 {
     constexpr int DD = D * D;
-    const int ncb = 2 * G, i = blockIdx.x, nslot = ncb * DD;
+    const int i = blockIdx.x, nslot = ncb * DD;
     for (int t = threadIdx.x; t < nslot; t += blockDim.x) {
-        const int q = t / DD, e = t % DD, a = q / G, g = q % G;
-        const int k0 = run_ptr[i * (G + 1) + g], k1 = run_ptr[i * (G + 1) + g + 1];
+        const int q = t / DD, e = t % DD;
+        const int k0 = run_lo[i * ncb + q], k1 = run_hi[i * ncb + q];
         double acc = 0.0;
 #pragma unroll 4
-        for (int k = k0; k < k1; ++k) {
-            const double wgt = a ? tau[acol_idx[k]] : 1.0;
-            acc += Saug[(size_t)k * DD + e] * wgt;
-        }
+        for (int k = k0; k < k1; ++k)
+            acc += Saug[(size_t)k * DD + e] * coarse_weight(acol_idx[k], q, pnode, pw0, pw1);
         SZ[(size_t)i * nslot + t] = acc;
     }
 }
 
-// A_c[q][q'] (D x D block) = sum_{i in group(q)} tau_i^a SZ[i][q'] ; dense nc x nc, row-major
+// A_c[q][q'] (D x D block) = sum_{i in supp(q)} w(i,q) SZ[i][q'] ; dense nc x nc, row-major
 template <int D>
 __global__ __launch_bounds__(256) void k_coarse_matrix(
-    int nr, int G, const int32_t* __restrict__ grp_ptr, const double* __restrict__ tau,
+    int nr, int ncb, const int32_t* __restrict__ slo, const int32_t* __restrict__ shi,
+    const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
     const double* __restrict__ SZ, double* __restrict__ Ac)
 {
     constexpr int DD = D * D;
-    const int ncb = 2 * G, nc = ncb * D;
+    const int nc = ncb * D;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ncb * ncb * DD) return;
     const int e = t % DD, q2 = (t / DD) % ncb, q = t / (DD * ncb);
-    const int a = q / G, g = q % G;
     double acc = 0.0;
 #pragma unroll 8
-    for (int i = grp_ptr[g]; i < grp_ptr[g + 1]; ++i)
-        acc += (a ? tau[i] : 1.0) * SZ[((size_t)i * ncb + q2) * DD + e];
+    for (int i = slo[q]; i < shi[q]; ++i)
+        acc += coarse_weight(i, q, pnode, pw0, pw1) * SZ[((size_t)i * ncb + q2) * DD + e];
     Ac[(size_t)(q * D + e / D) * nc + q2 * D + e % D] = acc;
 }
 
@@ -1034,12 +1123,12 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
 // One workgroup per fine block row i; thread per (r, c) of the D x nc strip.
 template <int D>
 __global__ __launch_bounds__(256) void k_coarse_border(
-    int nr, int G, const double* __restrict__ SZ, const double* __restrict__ Lci,
+    int nr, int ncb, const double* __restrict__ SZ, const double* __restrict__ Lci,
     const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ fine_nnz, double* __restrict__ Saug)
 {
     constexpr int DD = D * D;
     extern __shared__ __attribute__((aligned(16))) double sT[];     // D x nc
-    const int ncb = 2 * G, nc = ncb * D;
+    const int nc = ncb * D;
     const int i = blockIdx.x;
     for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
         const int r = t / nc, c = t % nc, q = c / D, cc = c % D;
@@ -1057,25 +1146,26 @@ __global__ __launch_bounds__(256) void k_coarse_border(
     }
 }
 
-// coarse rows: diagonal block = I ; rhs b~_c = Lci * (Z_c^T g^) ; zero the CG vectors of the coarse rows
+// coarse rows: diagonal block = I ; rhs b~_c = Lci * (P^T g^) ; zero the CG vectors of the coarse rows
 template <int D>
 __global__ __launch_bounds__(1024) void k_coarse_rhs(
-    int nr, int G, const int32_t* __restrict__ grp_ptr, const double* __restrict__ tau,
+    int nr, int ncb, const int32_t* __restrict__ slo, const int32_t* __restrict__ shi,
+    const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
     const double* __restrict__ LciT, const int32_t* __restrict__ arow_ptr,
     double* __restrict__ Saug, double* __restrict__ tvec /* nc scratch */,
     double* __restrict__ r /* fine part holds g^ */, double* __restrict__ w, double* __restrict__ s,
     double* __restrict__ p, double* __restrict__ x)
 {
     constexpr int DD = D * D;
-    const int ncb = 2 * G, nc = ncb * D;
-    // t_q = sum_{i in g} tau_i^a g^_i : 8 lanes per output, then a 3-step butterfly
+    const int nc = ncb * D;
+    // t_q = sum_{i in supp(q)} w(i,q) g^_i : 8 lanes per output, then a 3-step butterfly
     for (int base = 0; base < nc; base += blockDim.x / 8) {
         const int t = base + threadIdx.x / 8, sub = threadIdx.x & 7;
         double v = 0.0;
         if (t < nc) {
-            const int q = t / D, c = t % D, a = q / G, gi = q % G;
-            for (int i = grp_ptr[gi] + sub; i < grp_ptr[gi + 1]; i += 8)
-                v += (a ? tau[i] : 1.0) * r[(size_t)i * D + c];
+            const int q = t / D, c = t % D;
+            for (int i = slo[q] + sub; i < shi[q]; i += 8)
+                v += coarse_weight(i, q, pnode, pw0, pw1) * r[(size_t)i * D + c];
         }
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
         if (t < nc && sub == 0) tvec[t] = v;
@@ -1103,16 +1193,16 @@ __global__ __launch_bounds__(1024) void k_coarse_rhs(
     }
 }
 
-// x^_i = x~_f,i + y_const[g(i)] + tau_i y_lin[g(i)] with y = Lci^T x~_c ;  x_i = Linv_i^T x^_i
+// x^_i = x~_f,i + pw0_i y[node_i] + pw1_i y[node_i + 1] with y = Lci^T x~_c ;  x_i = Linv_i^T x^_i
 // every workgroup first forms y (nc values) in LDS: y_k = sum_{m>=k} Lci[m][k] x~_c[m]
 template <int D>
 __global__ __launch_bounds__(256) void k_coarse_recover(
-    int nr, int G, const int32_t* __restrict__ grp_of, const double* __restrict__ tau,
-    const double* __restrict__ Linv, const double* __restrict__ Lci, const double* __restrict__ xh,
-    double* __restrict__ x)
+    int nr, int ncb, const int32_t* __restrict__ pnode, const double* __restrict__ pw0,
+    const double* __restrict__ pw1, const double* __restrict__ Linv, const double* __restrict__ Lci,
+    const double* __restrict__ xh, double* __restrict__ x)
 {
     __shared__ double sy[192];
-    const int ncb = 2 * G, nc = ncb * D;
+    const int nc = ncb * D;
     const double* xc = xh + (size_t)nr * D;
     for (int base = 0; base < nc; base += blockDim.x / 8) {
         const int k = base + threadIdx.x / 8, sub = threadIdx.x & 7;
@@ -1127,11 +1217,13 @@ __global__ __launch_bounds__(256) void k_coarse_recover(
     __syncthreads();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nr * D) return;
-    const int i = t / D, c = t % D, gi = grp_of[i];
+    const int i = t / D, c = t % D, q = pnode[i];
+    const double w0 = pw0[i], w1 = pw1[i];
     double v = 0.0;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-        const double xhat = xh[(size_t)i * D + a] + sy[gi * D + a] + tau[i] * sy[(G + gi) * D + a];
+        const double y1 = (q + 1 < ncb) ? sy[(q + 1) * D + a] : 0.0;
+        const double xhat = xh[(size_t)i * D + a] + w0 * sy[q * D + a] + w1 * y1;
         v += Linv[(size_t)i * D * D + a * D + c] * xhat;
     }
     x[t] = v;
@@ -1146,20 +1238,27 @@ __global__ __launch_bounds__(256) void k_backsub(
     const double* __restrict__ Cinv, const double* __restrict__ cvec,
     const double* __restrict__ xp, double* __restrict__ dxl)
 {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nv) return;
-    double a0 = cvec[3 * (size_t)v], a1 = cvec[3 * (size_t)v + 1], a2 = cvec[3 * (size_t)v + 2];
-    for (int i = lm_ptr[v]; i < lm_ptr[v + 1]; ++i) {
-        const int rid = pose_rid[PS_POSE_OF(lobs[i])];
-        if (rid < 0) continue;
-        const double* z = Z + 18 * (size_t)i;
-        const double* x = xp + 6 * (size_t)rid;
+    // 16 lanes per landmark, one observation per lane (same mapping as k_landmark_pass)
+    const int v = blockIdx.x * (blockDim.x / PS_LM_GROUP) + threadIdx.x / PS_LM_GROUP;
+    const int sub = threadIdx.x & (PS_LM_GROUP - 1);
+    const bool live = v < nv;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (live) {
+        for (int i = lm_ptr[v] + sub; i < lm_ptr[v + 1]; i += PS_LM_GROUP) {
+            const int rid = pose_rid[PS_POSE_OF(lobs[i])];
+            if (rid < 0) continue;
+            const double* z = Z + 18 * (size_t)i;
+            const double* x = xp + 6 * (size_t)rid;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const double xa = x[a];
-            a0 -= z[3 * a] * xa; a1 -= z[3 * a + 1] * xa; a2 -= z[3 * a + 2] * xa;
+            for (int a = 0; a < 6; ++a) {
+                const double xa = x[a];
+                a0 -= z[3 * a] * xa; a1 -= z[3 * a + 1] * xa; a2 -= z[3 * a + 2] * xa;
+            }
         }
     }
+    a0 = group16_sum(a0); a1 = group16_sum(a1); a2 = group16_sum(a2);
+    if (!live || sub != 0) return;
+    a0 += cvec[3 * (size_t)v]; a1 += cvec[3 * (size_t)v + 1]; a2 += cvec[3 * (size_t)v + 2];
     const double* m = Cinv + 6 * (size_t)v;    // dx = M^T a
     dxl[3 * (size_t)v] = m[0] * a0 + m[1] * a1 + m[3] * a2;
     dxl[3 * (size_t)v + 1] = m[2] * a1 + m[4] * a2;
