@@ -90,11 +90,12 @@ struct ps_problem {
     // two-level preconditioner (coarse level), built lazily by build_coarse()
     int coarse_req = -1;            // requested number of groups: -1 = auto, 0 = off
     int G = 0, ncb = 0, nc = 0, nr_aug = 0, nnzb_aug = 0;
-    size_t cg_cap = 0;              // CG vectors are allocated for this many block rows
+    size_t cg_cap = 0, saug_cap = 0; // CG vectors / matrix are allocated for this many block rows / blocks
     int32_t *pnode = nullptr, *slo = nullptr, *shi = nullptr, *run_lo = nullptr, *run_hi = nullptr,
             *arow_ptr = nullptr, *acol_idx = nullptr, *aug_slot = nullptr, *fine_nnz = nullptr;
     double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr;
     bool coarse_built = false;
+    int ell_wf = 0, ell_wc = 0;     // two-class ELL widths of the CG matrix (0 = CSR)
     // scalars
     double *cost_partials = nullptr, *scalars = nullptr, *h_scalars = nullptr;
     int32_t *status = nullptr, *h_status = nullptr;
@@ -240,7 +241,7 @@ int pcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* re
 
 int ensure_cg_buffers(ps_problem* h, int rows, int blocks) {
     const int D = h->D;
-    if ((size_t)rows <= h->cg_cap && h->Saug) return 0;
+    if ((size_t)rows <= h->cg_cap && h->Saug && (size_t)blocks <= h->saug_cap) return 0;
     const size_t nvec = (size_t)rows * D;
     if (h->alloc(&h->cg_xh, nvec)) return -1;
     for (int k = 0; k < 2; ++k)
@@ -250,7 +251,8 @@ int ensure_cg_buffers(ps_problem* h, int rows, int blocks) {
     if (h->alloc(&pv, nvec)) return -1;
     h->cg_p = pv;                                  // the fused CG's search direction (own rows only)
     if (h->alloc(&h->Saug, (size_t)std::max(blocks, 1) * D * D)) return -1;
-    h->cg_cap = rows;
+    HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)std::max(blocks, 1) * D * D * sizeof(double), h->stream));
+    h->cg_cap = rows; h->saug_cap = (size_t)std::max(blocks, 1);
     return 0;
 }
 
@@ -265,9 +267,31 @@ int build_coarse(ps_problem* h) {
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
     if (G < 1) G = 0;
     h->G = G; h->coarse_built = true;
+    const std::vector<int32_t>& rp = h->h_row_ptr;
+    const std::vector<int32_t>& ci = h->h_col_idx;
+    int maxlen = 0;
+    for (int i = 0; i < nr; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
+    const int ncb_pre = G ? G + 1 : 0;
+    // pad rows to a common width unless that wastes more than 50 % (hub-like graphs): then CSR
+    const bool ell = nr > 0 && (long)(maxlen + ncb_pre) * nr <= (long)(1.5 * (h->nnzb + (long)ncb_pre * nr)) + 64;
+    const int wf = ell ? maxlen + ncb_pre : 0;
+    const int wc = ell ? nr + 1 : 0;
+    h->ell_wf = wf; h->ell_wc = wc;
     if (G == 0) {
-        h->ncb = h->nc = 0; h->nr_aug = nr; h->nnzb_aug = h->nnzb;
-        return ensure_cg_buffers(h, nr, h->nnzb);
+        h->ncb = h->nc = 0; h->nr_aug = nr;
+        if (!ell) { h->nnzb_aug = h->nnzb; h->arow_ptr = h->row_ptr; h->acol_idx = h->col_idx; h->aug_slot = h->ident_slot;
+                    return ensure_cg_buffers(h, nr, h->nnzb); }
+        std::vector<int32_t> arp(nr + 1), aci((size_t)nr * wf, 0), slot(h->nnzb);
+        for (int i = 0; i < nr; ++i) {
+            arp[i] = i * wf;
+            for (int b = rp[i]; b < rp[i + 1]; ++b) { slot[b] = i * wf + (b - rp[i]); aci[slot[b]] = ci[b]; }
+        }
+        arp[nr] = nr * wf;
+        h->nnzb_aug = nr * wf;
+        if (h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) || h->upload(&h->aug_slot, slot)) return -1;
+        if (ensure_cg_buffers(h, nr, h->nnzb_aug)) return -1;
+        HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)h->nnzb_aug * D * D * sizeof(double), h->stream));
+        return 0;
     }
     const int ncb = G + 1;
     std::vector<int32_t> pnode(nr), slo(ncb, nr), shi(ncb, 0);
@@ -282,14 +306,13 @@ int build_coarse(ps_problem* h) {
             slo[q] = std::min(slo[q], i); shi[q] = std::max(shi[q], i + 1);
         }
     }
-    const std::vector<int32_t>& rp = h->h_row_ptr;
-    const std::vector<int32_t>& ci = h->h_col_idx;
     std::vector<int32_t> arp(nr + ncb + 1, 0), aci, slot(h->nnzb), fnz(nr);
     aci.reserve((size_t)h->nnzb + 2 * (size_t)nr * ncb + ncb);
     for (int i = 0; i < nr; ++i) {
         fnz[i] = rp[i + 1] - rp[i];
         for (int b = rp[i]; b < rp[i + 1]; ++b) { slot[b] = (int32_t)aci.size(); aci.push_back(ci[b]); }
         for (int q = 0; q < ncb; ++q) aci.push_back(nr + q);
+        if (ell) while ((int)aci.size() < (i + 1) * wf) aci.push_back(0);     // zero-valued padding blocks
         arp[i + 1] = (int32_t)aci.size();
     }
     for (int q = 0; q < ncb; ++q) {
@@ -314,7 +337,9 @@ int build_coarse(ps_problem* h) {
     if (h->alloc(&h->SZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci, (size_t)h->nc * h->nc) || h->alloc(&h->LciT, (size_t)h->nc * h->nc) ||
         h->alloc(&h->tvec, (size_t)h->nc)) return -1;
-    return ensure_cg_buffers(h, h->nr_aug, h->nnzb_aug);
+    if (ensure_cg_buffers(h, h->nr_aug, h->nnzb_aug)) return -1;
+    HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)h->nnzb_aug * D * D * sizeof(double), h->stream));
+    return 0;
 }
 
 template <int D>
@@ -323,12 +348,12 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
     if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
     if (!h->coarse_built && build_coarse(h)) return -1;
     const int G = h->G, rows = h->nr_aug;
-    const int32_t* rp = G ? h->arow_ptr : h->row_ptr;
-    const int32_t* ci = G ? h->acol_idx : h->col_idx;
+    const int32_t* rp = h->arow_ptr;
+    const int32_t* ci = h->acol_idx;
     hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
                        h->S, h->Linv, h->status);
     hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
-                       h->brow_of, h->Linv, h->S, G ? h->aug_slot : h->ident_slot, h->Saug);
+                       h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug);
     hipLaunchKernelGGL(k_cg_prepare<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->g, h->Linv,
                        h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh, h->status);
     if (G) {
@@ -358,7 +383,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
             hipLaunchKernelGGL(k_cg_fused<D>, dim3(rows), dim3(PS_CG_THREADS), 0, h->stream, rows, rp, ci, h->Saug,
                                h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw], h->cg_s[nw],
                                h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
-                               h->status, h->scalars);
+                               h->status, h->scalars, nr, h->ell_wf, h->ell_wc);
         }
         HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));

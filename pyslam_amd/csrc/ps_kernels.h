@@ -31,10 +31,31 @@ enum { ST_LM_FAIL = 0, ST_DIAG_FAIL = 1, ST_PCG_DONE = 2, ST_PCG_ITERS = 3, ST_N
 // scalar slots
 enum { SC_COST = 0, SC_DXP2 = 1, SC_LINCOST = 2, SC_RR0 = 3, SC_RRFINAL = 4, SC_THRESH = 5, SC_DXL2 = 6, SC_NWORDS = 8 };
 
-PS_DEV double wave_sum(double v) {          // xor butterfly: every lane gets the total
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+// Wave-wide sum with DPP row operations instead of ds_bpermute shuffles (each __shfl_xor of a
+// double is two LDS-crossbar permutes, ~100+ cycles of latency; a DPP add is a plain VALU op).
+// Classic GCN/CDNA reduction: row_shr 1,2,4(masked),8(masked) -> 16-lane row totals in the
+// row's last lane, row_bcast15 / row_bcast31 carry them across rows; lane 63 holds the total,
+// which is broadcast with readlane.  Fixed association order => deterministic.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+PS_DEV double dpp_shift_add(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+    const unsigned long long m = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    return v + __builtin_bit_cast(double, m);      // lanes masked off by ROW/BANK_MASK add +0.0
+}
+
+PS_DEV double wave_sum(double v) {          // every lane gets the total
+    v = dpp_shift_add<0x111, 0xf, 0xf>(v);  // row_shr:1
+    v = dpp_shift_add<0x112, 0xf, 0xf>(v);  // row_shr:2
+    v = dpp_shift_add<0x114, 0xf, 0xe>(v);  // row_shr:4, banks 1-3
+    v = dpp_shift_add<0x118, 0xf, 0xc>(v);  // row_shr:8, banks 2-3
+    v = dpp_shift_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_shift_add<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, 63);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 // deterministic block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in every thread
@@ -52,11 +73,7 @@ PS_DEV double block_sum(double v, double* lds /* >= 16 doubles */) {
 // two block-wide sums sharing one butterfly and one barrier pair (the shuffles of a and b
 // interleave, so the pair costs about one reduction's latency)
 PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ta = __shfl_xor(a, m, 64), tb = __shfl_xor(b, m, 64);
-        a += ta; b += tb;
-    }
+    a = wave_sum(a); b = wave_sum(b);
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { lds[w] = a; lds[16 + w] = b; }
@@ -76,10 +93,12 @@ PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
 // ---------------------------------------------------------------------------
 #define PS_LM_GROUP 16
 
-PS_DEV double group16_sum(double v) {
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+PS_DEV double group16_sum(double v) {          // a 16-lane group is exactly one DPP row
+    v = dpp_shift_add<0x111, 0xf, 0xf>(v);
+    v = dpp_shift_add<0x112, 0xf, 0xf>(v);
+    v = dpp_shift_add<0x114, 0xf, 0xe>(v);
+    v = dpp_shift_add<0x118, 0xf, 0xc>(v);      // lane 15 of the row holds the group total
+    return __shfl(v, (int)(threadIdx.x & 63) | 15, 64);
 }
 
 PS_DEV void lm_emit_z(const ReprojEval& ev, double M00, double M10, double M11, double M20, double M21,
@@ -824,7 +843,8 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     double* __restrict__ p, double* __restrict__ x,
     const double* __restrict__ gd_in /* [2*nr] gamma | delta partials */, double* __restrict__ gd_out,
     double* __restrict__ hist /* [0,cap): gamma, [cap,2cap): alpha */, int cap, int k, double tol2,
-    int32_t* __restrict__ status, double* __restrict__ scalars)
+    int32_t* __restrict__ status, double* __restrict__ scalars,
+    int nfine, int wf, int wc /* two-class ELL: fine rows wf blocks wide, the rest wc; wf = 0 => CSR */)
 {
     __shared__ double lds[32];
     __shared__ double part[PS_CG_WAVES][8];
@@ -833,7 +853,15 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     const int row = blockIdx.x;
     // ---- every independent load first (one memory latency, not a chain)
     const int done = status[ST_PCG_DONE];
-    const int rbeg = row_ptr[row], rend = row_ptr[row + 1];
+    // padded (ELL) rows start at an address computed from the row index, so the column
+    // indices load in the same memory round trip as everything else (CSR needs row_ptr first)
+    int rbeg, rend;
+    if (wf > 0) {
+        rbeg = row < nfine ? row * wf : nfine * wf + (row - nfine) * wc;
+        rend = rbeg + (row < nfine ? wf : wc);
+    } else {
+        rbeg = row_ptr[row]; rend = row_ptr[row + 1];
+    }
     const double g_prev = hist[k > 0 ? k - 1 : 0];
     const double a_prev = hist[cap + (k > 0 ? k - 1 : 0)];
     const double thresh_in = scalars[SC_THRESH];
@@ -1011,6 +1039,7 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
             for (int a = 0; a < D; ++a)
 #pragma unroll
                 for (int b2 = 0; b2 < D; ++b2) { L[a][b2] = 0.0; Mi[a][b2] = 0.0; }
+            double il[D];                       // 1 / L[j][j]: one division per pivot, the rest are multiplies
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 double d = sL[(J * D + j) * nc + J * D + j];
@@ -1019,23 +1048,24 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
                 ok = ok && (d > 0.0);
                 const double l = sqrt(d);
                 L[j][j] = l;
+                il[j] = 1.0 / l;
 #pragma unroll
                 for (int i = j + 1; i < D; ++i) {
                     double v = sL[(J * D + i) * nc + J * D + j];
 #pragma unroll
                     for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
-                    L[i][j] = v / l;
+                    L[i][j] = v * il[j];
                 }
             }
 #pragma unroll
             for (int c = 0; c < D; ++c) {
-                Mi[c][c] = 1.0 / L[c][c];
+                Mi[c][c] = il[c];
 #pragma unroll
                 for (int r = c + 1; r < D; ++r) {
                     double v = 0.0;
 #pragma unroll
                     for (int k = c; k < r; ++k) v -= L[r][k] * Mi[k][c];
-                    Mi[r][c] = v / L[r][r];
+                    Mi[r][c] = v * il[r];
                 }
             }
             if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
