@@ -382,11 +382,16 @@ def linearize(lp, points_first=True):
     return J, np.concatenate(es), float(cost)
 
 
-def normal_equations(lp, points_first=True):
-    """precision = J~^T J~, information = -J~^T e~ (reference problem.py:332-333)."""
+def normal_equations(lp, points_first=True, lm_lambda=0.):
+    """precision = J~^T J~, information = -J~^T e~ (reference problem.py:332-333).
+    lm_lambda > 0 adds Marquardt damping lambda * diag(J~^T J~) (a build-only option; the
+    reference is lambda = 0)."""
     J, e, cost = linearize(lp, points_first)
     JT = J.T.tocsr()
-    return JT.dot(J).tocsr(), -JT.dot(e), cost
+    P = JT.dot(J).tocsr()
+    if lm_lambda:
+        P = (P + lm_lambda * sp.diags(P.diagonal())).tocsr()
+    return P, -JT.dot(e), cost
 
 
 def apply_update(lp, dx, points_first=True):

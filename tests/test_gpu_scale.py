@@ -1,0 +1,179 @@
+"""GPU checks at (or near) the BASELINE sizes through size-independent properties:
+the device step must satisfy the ORACLE's normal equations, costs must agree, landmark
+shards must sum to the unsharded reduced system, results must be bitwise reproducible."""
+import numpy as np
+import pytest
+
+from oracle import gn_oracle as orc
+from pyslam_amd import synthetic
+from pyslam_amd.distributed import shard_landmarks, pose_pair_keys
+
+pytestmark = pytest.mark.gpu
+
+
+def device(lp, **kw):
+    from pyslam_amd.device import DeviceProblem
+    return DeviceProblem(lp, **kw)
+
+
+def device_dx_posefirst(dev):
+    xp, xl = dev.get_dx()
+    return np.concatenate([xp.ravel(), xl.ravel()])
+
+
+@pytest.fixture(scope='module')
+def c3():
+    """BASELINE config C3: 200 keyframes, 50 000 landmarks, 500 000 reprojection blocks."""
+    lp, _ = synthetic.stereo_ba(200, 50000, 10, 20, seed=0)
+    return lp
+
+
+def test_c3_step_solves_the_reference_normal_equations(c3):
+    dev = device(c3)
+    c0 = dev.eval_cost(True)
+    assert abs(c0 - orc.eval_cost(c3)) <= 1e-11 * c0
+    dev.linearize(0.)
+    its, rel = dev.solve_reduced(1e-12, 2000)
+    dev.backsub()
+    dx = device_dx_posefirst(dev)
+    P, b, lin_cost = orc.normal_equations(c3, points_first=False)        # reference algebra (oracle)
+    res = P.dot(dx) - b
+    assert np.linalg.norm(res) <= 1e-9 * np.linalg.norm(b), (its, rel)
+    # block-wise too: the landmark part is an exact (direct) solve, the pose part is PCG
+    n = 6 * c3.num_reduced
+    assert np.linalg.norm(res[n:]) <= 1e-11 * np.linalg.norm(b[n:])
+    assert abs(dev.eval_cost(False) - lin_cost) <= 1e-11 * lin_cost
+    # applying the step reproduces the oracle's post-step cost
+    dev.apply_update(1.0)
+    c1 = dev.eval_cost(True)
+    assert abs(c1 - orc.eval_cost(orc.apply_update(c3, dx, points_first=False))) <= 1e-9 * c1
+    assert c1 < 0.05 * c0
+
+
+def test_c3_gn_iteration_matches_staged_calls_bitwise(c3):
+    a, b = device(c3), device(c3)
+    cost, nrm, its, rel = a.gn_iteration(0., 1e-12, 2000, True)
+    b.linearize(0.); b.solve_reduced(1e-12, 2000)
+    cost2, p2, l2 = b.gn_finish(True)
+    assert cost == cost2 and nrm == np.sqrt(p2 + l2)
+    pa, la = a.get_params()
+    pb, lb = b.get_params()
+    assert np.array_equal(pa, pb) and np.array_equal(la, lb)
+
+
+def test_c3_all_solver_variants_agree(c3):
+    ref = None
+    for variant, groups in ((1, -1), (1, 0), (0, 0)):
+        dev = device(c3)
+        dev.set_option('pcg_variant', variant)
+        dev.set_option('coarse_groups', groups)
+        dev.linearize(0.)
+        its, rel = dev.solve_reduced(1e-13, 3000)
+        dev.backsub()
+        dx = device_dx_posefirst(dev)
+        if ref is None:
+            ref = dx
+        else:
+            assert np.linalg.norm(dx - ref) <= 1e-9 * np.linalg.norm(ref), (variant, groups, its, rel)
+
+
+def test_landmark_shards_sum_to_the_unsharded_reduced_system():
+    """What the multi-GPU all-reduce relies on, checked on ONE GPU: every shard built with the
+    union block pattern, S and g summed on the host, compared with the unsharded system."""
+    lp, _ = synthetic.stereo_ba(60, 6000, 8, 10, seed=4)
+    full = device(lp)
+    full.linearize(0.)
+    rp, ci, vals, g = full.reduced_system()
+    union = pose_pair_keys(lp)
+    acc_v, acc_g, cost = np.zeros_like(vals), np.zeros_like(g), 0.
+    world = 4
+    for r in range(world):
+        sh = shard_landmarks(lp, r, world)
+        extra = np.setdiff1d(union, pose_pair_keys(sh))
+        dev = device(sh, extra_pairs=((extra >> 32).astype(np.int32), (extra & 0xFFFFFFFF).astype(np.int32)))
+        dev.linearize(0.)
+        rp2, ci2, v2, g2 = dev.reduced_system()
+        assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)       # identical pattern on every rank
+        acc_v += v2; acc_g += g2
+        cost += dev.eval_cost(True)
+    assert np.abs(acc_v - vals).max() <= 1e-11 * np.abs(vals).max()
+    assert np.abs(acc_g - g).max() <= 1e-11 * np.abs(g).max()
+    assert abs(cost - full.eval_cost(True)) <= 1e-12 * cost
+
+
+def test_marquardt_damping_matches_oracle():
+    lp, _ = synthetic.stereo_ba(12, 300, 5, 4, seed=9)
+    lam = 0.37
+    dev = device(lp)
+    dev.linearize(lam)
+    dev.solve_reduced(1e-13, 500)
+    dev.backsub()
+    P, b, _ = orc.normal_equations(lp, points_first=False, lm_lambda=lam)
+    dx = np.linalg.solve(P.toarray(), b)
+    assert np.linalg.norm(device_dx_posefirst(dev) - dx) <= 1e-9 * np.linalg.norm(dx)
+
+
+def test_medium_pose_graph_solve_matches_oracle_solve():
+    """C2 shape at 1/5 scale: 2 000 SE(3) poses, 10 000 edges, Huber loss, prior on pose 0."""
+    lp, _ = synthetic.pose_graph(num_poses=2000, num_loops=8001, dof=6, seed=2)
+    opts = dict(allow_nondecreasing_steps=True, max_nondecreasing_steps=3)
+    final, trace = orc.solve(lp, opts, points_first=True)
+    dev = device(lp)
+    hist = [dev.eval_cost(True)]
+    non = 0
+    for _ in range(30):                      # the reference's termination rules (problem.py:159-178)
+        prev = hist[-1]
+        cost, nrm, its, rel = dev.gn_iteration(0., 1e-13, 4000, True)
+        hist.append(cost)
+        if non == 0:
+            dev.snapshot()
+        non = non + 1 if cost >= 0.9 * prev else 0
+        if nrm < 1e-6 or cost < 1e-12 or non >= 3:
+            if non >= 3:
+                dev.restore()
+            break
+    ref = trace['cost_history']
+    assert len(hist) == len(ref)
+    assert np.allclose(hist, ref, rtol=1e-6)
+    poses, _ = dev.get_params()
+    assert np.abs(poses - final.poses).max() < 1e-6
+
+
+def test_reference_covariance_identity_se3():
+    """Reference tests/test_problem.py:294-321: Sigma_T1 = Sigma_odom + Ad(odom) Sigma_T0 Ad(odom)^T."""
+    from liegroups import SE3
+    from pyslam.problem import Options, Problem
+    from pyslam.residuals import PoseResidual, PoseToPoseResidual
+    from pyslam.utils import invsqrt
+    options = Options()
+    options.allow_nondecreasing_steps = True
+    options.max_nondecreasing_steps = 3
+    problem = Problem(options)
+    odom = SE3.exp(0.1 * np.ones(6))
+    odom_stiffness = invsqrt(1e-3 * np.eye(6))
+    T0_stiffness = invsqrt(1e-6 * np.eye(6))
+    odom_covar = np.linalg.inv(np.dot(odom_stiffness, odom_stiffness))
+    T0_covar = np.linalg.inv(np.dot(T0_stiffness, T0_stiffness))
+    problem.add_residual_block(PoseResidual(SE3.identity(), T0_stiffness), 'T0')
+    problem.add_residual_block(PoseToPoseResidual(odom, odom_stiffness), ['T0', 'T1'])
+    problem.initialize_params({'T0': SE3.identity(), 'T1': SE3.identity()})
+    problem.solve()
+    problem.compute_covariance()
+    expected = odom_covar + odom.adjoint().dot(T0_covar.dot(odom.adjoint().T))
+    assert np.allclose(problem.get_covariance_block('T1', 'T1'), expected)
+    assert problem.get_covariance_block('T1', 'nope') is None
+
+
+def test_solve_one_iter_api_does_not_move_parameters():
+    from conftest import load_golden, golden_lp
+    from test_host_api import build_namespace
+    g = load_golden('stereo_ba_example')
+    problem = synthetic.to_objects(golden_lp(g), build_namespace())
+    before = {k: np.array(v) if isinstance(v, np.ndarray) else v.as_matrix().copy()
+              for k, v in problem.param_dict.items()}
+    dx, cost = problem.solve_one_iter()
+    assert np.linalg.norm(dx - g['iter_dx'][0]) <= 1e-8 * np.linalg.norm(dx)
+    assert abs(cost - g['iter_cost'][0]) <= 1e-9 * cost
+    for k, v in problem.param_dict.items():
+        now = v if isinstance(v, np.ndarray) else v.as_matrix()
+        assert np.array_equal(now, before[k])
