@@ -51,6 +51,18 @@ def algorithmic_bytes(info, n_pcg, dof=6):
     return b_iter, b_schur, b_spmv
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, read
+    traffic corrected x2 as MI355X_MICROARCH.md prescribes for gfx950).  None if not collected."""
+    try:
+        with open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')) as f:
+            table = json.load(f)
+        return table[kernel]['hbm_bytes_corrected']
+    except Exception:
+        return None
+
+
 def cpu_baseline(lp):
     """The numpy/scipy oracle (a port of the reference's algebra) on the host cores."""
     from oracle import gn_oracle as orc
@@ -148,7 +160,7 @@ def main():
         if sch >= pcg_per_iter * 1.0 and sch > 0:
             kern, dur_ms, nbytes = 'k_schur_pairs', sch, b_schur
         else:
-            kern, dur_ms, nbytes = 'k_pcg_spmv+k_pcg_update (one PCG iteration)', pcg_per_iter, b_spmv
+            kern, dur_ms, nbytes = 'void k_cg_fused<6>', pcg_per_iter, b_spmv
         achieved = nbytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         line = {
             'metric': 'ms/LM-iter (Jac build + J^T J + Schur solve), stereo BA @ 500k residuals',
@@ -168,7 +180,8 @@ def main():
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'iteration_algorithmic_GBps': round(b_iter / (ms_per_step * 1e-3) / 1e9, 2),
             'roofline': {'bound': 'hbm', 'kernel': kern, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': pmc_traffic(kern),
                          'algorithmic_bytes_per_launch': int(nbytes), 'avg_launch_ms': round(dur_ms, 5)},
         }
         if not args.no_cpu_baseline and world == 1:
