@@ -207,3 +207,50 @@ def test_generic_quadratic_and_cubic_goldens():
     problem.compute_covariance()
     assert np.allclose(problem._covariance_matrix, g['covariance'], rtol=1e-9, atol=1e-15)
     assert abs(problem.get_covariance_block('a', 'a') - 0.00017205419580419603) < 1e-12
+
+
+@pytest.mark.parametrize('loss_id,k', [(0, 0.), (1, 0.), (2, 2.5), (3, 1.2), (4, 6.0), (5, 4.0)],
+                         ids=['L2', 'L1', 'Cauchy', 'Huber', 'Tukey', 'TDist'])
+def test_every_loss_on_device_matches_oracle(loss_id, k):
+    """IRLS weights / rho of all six reference losses (pyslam/losses.py) inside the BA and the
+    pose-graph kernels, against the oracle's element-wise restatement."""
+    import types
+    import pyslam_amd.synthetic as synthetic
+    loss = types.SimpleNamespace(LOSS_ID=loss_id, k=k)
+    lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=80, obs_per_lm=4, half_window=3, seed=21, loss=loss)
+    pg, _ = synthetic.pose_graph(num_poses=40, num_loops=30, dof=6, seed=22, loss=loss)
+    for prob in (lp, pg):
+        dev = device(prob)
+        c = dev.eval_cost(True)
+        assert abs(c - orc.eval_cost(prob)) <= TOL_COST * abs(c)
+        dev.linearize(0.)
+        S, g = dev.reduced_dense()
+        So, go, _ = oracle_reduced(prob)
+        assert rel_err(S, So) < 1e-11 and rel_err(g, go) < 1e-11
+
+
+def test_motion_only_batch_block_through_the_problem_api():
+    """C5: one ReprojectionMotionOnlyBatchResidual block + CauchyLoss, pipeline options
+    (reference pipelines/sparse.py:34-39,153-161); trace vs the reference-run golden."""
+    from liegroups import SE3
+    from pyslam.problem import Options, Problem
+    from pyslam.sensors import StereoCamera
+    from pyslam.residuals import ReprojectionMotionOnlyBatchResidual
+    from pyslam.losses import CauchyLoss
+    from pyslam_amd.lowering import pack_pose
+    g = load_golden('motion_only_cauchy')
+    opt = Options()
+    for k_, v in golden_options(g).items():
+        setattr(opt, k_, v)
+    problem = Problem(opt)
+    cam = StereoCamera(640., 480., 1000., 1000., 0.25, 1280, 960)
+    problem.add_residual_block(
+        ReprojectionMotionOnlyBatchResidual(cam, g['obs_1'], g['obs_2'], g['lp_stiff3'].reshape(3, 3)),
+        ['T_2_1'], CauchyLoss(3.0))
+    problem.initialize_params({'T_2_1': SE3.identity()})
+    out = problem.solve()
+    ref = g['cost_history']
+    assert len(problem._cost_history) == len(ref)
+    assert np.allclose(problem._cost_history, ref, rtol=1e-7)
+    assert np.abs(pack_pose(out['T_2_1']) - g['final_poses'][0]).max() < 1e-8
+    assert problem.summary() == str(g['summary_brief'])
