@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -75,6 +76,7 @@ struct ps_problem {
     long red_count = 0;
     double *S = nullptr, *g = nullptr, *red_cost = nullptr;
     std::vector<int32_t> h_row_ptr, h_col_idx;
+    std::vector<int32_t> h_vid_of_slot;   // landmarks are stored in locality order; external order is vid
     // pcg
     double *x = nullptr, *r = nullptr, *z = nullptr, *p0 = nullptr, *p1 = nullptr, *q = nullptr, *Minv = nullptr;
     double *rz_part = nullptr, *rr_part = nullptr, *pq_part = nullptr, *hist = nullptr;
@@ -95,13 +97,16 @@ struct ps_problem {
             *arow_ptr = nullptr, *acol_idx = nullptr, *aug_slot = nullptr, *fine_nnz = nullptr;
     double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr;
     bool coarse_built = false;
+    int cg_launched = 0;            // CG launches enqueued since the last setup
     int ell_wf = 0, ell_wc = 0;     // two-class ELL widths of the CG matrix (0 = CSR)
     // scalars
     double *cost_partials = nullptr, *scalars = nullptr, *h_scalars = nullptr;
     int32_t *status = nullptr, *h_status = nullptr;
     int ncost_obs = 0, ncost_fac = 0, nsq = 0;
+    double *sq_part_l = nullptr, *sq_part_p = nullptr;   // per-workgroup partials of ||dx_point||^2, ||dx_pose||^2
+    int nsq_l = 0, nsq_p = 0;
     // profiling
-    bool profiling = false;
+    int profiling = 0;              // 0 off, 1 = iteration total + Schur kernel only, 2 = every stage
     hipEvent_t ev[2 * PS_NUM_STAGES] = {};
     std::vector<std::pair<int, int>> pending;   // (stage, event slot) recorded, not yet read
     double stage_ms[PS_NUM_STAGES] = {};
@@ -143,8 +148,8 @@ struct StageTimer {
     int stage;
     hipEvent_t a = nullptr, b = nullptr;
     int slot = -1;
-    StageTimer(ps_problem* h_, int st) : h(h_), stage(st) {
-        if (!h->profiling) return;
+    StageTimer(ps_problem* h_, int st, int level = 2) : h(h_), stage(st) {
+        if (h->profiling < level) return;
         if (h->ev_used + 2 > h->ev_pool.size()) {
             for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); h->ev_pool.push_back(e); }
         }
@@ -153,11 +158,13 @@ struct StageTimer {
         b = h->ev_pool[h->ev_used++];
         hipEventRecord(a, h->stream);
     }
-    ~StageTimer() {
+    void stop() {                        // idempotent; the destructor calls it too
         if (!a) return;
         hipEventRecord(b, h->stream);
         h->pending.push_back({stage, slot});
+        a = nullptr;
     }
+    ~StageTimer() { stop(); }
 };
 
 void drain_timers(ps_problem* h) {      // call after a stream synchronisation
@@ -343,7 +350,7 @@ int build_coarse(ps_problem* h) {
 }
 
 template <int D>
-int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
+int cg_fused_setup(ps_problem* h, int max_iters) {
     const int nr = h->nr, cap = h->hist_cap;
     if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
     if (!h->coarse_built && build_coarse(h)) return -1;
@@ -372,31 +379,37 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
                            h->pw0, h->pw1, h->LciT, h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
                            h->cg_s[0], h->cg_p, h->cg_xh);
     }
+    h->cg_launched = 0;
+    return 0;
+}
+
+// enqueue `count` more CG launches (launch n runs iteration k = n - 1; converged launches exit at once)
+template <int D>
+void cg_fused_launch(ps_problem* h, double tol, int count) {
+    const int rows = h->nr_aug, cap = h->hist_cap;
     const double tol2 = tol * tol;
-    int n = 0;                                     // launch counter: k = n - 1
-    int chunk = std::max(h->pcg_chunk, h->last_pcg_iters + 2);
-    bool done = false;
-    while (!done) {
-        const int m = std::min(chunk, max_iters + 2 - n);
-        for (int i = 0; i < m; ++i, ++n) {
-            const int o = n & 1, nw = o ^ 1;
-            hipLaunchKernelGGL(k_cg_fused<D>, dim3(rows), dim3(PS_CG_THREADS), 0, h->stream, rows, rp, ci, h->Saug,
-                               h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw], h->cg_s[nw],
-                               h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
-                               h->status, h->scalars, nr, h->ell_wf, h->ell_wc);
-        }
-        HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipStreamSynchronize(h->stream));
-        done = h->h_status[ST_PCG_DONE] != 0 || n >= max_iters + 2;
-        chunk = h->pcg_chunk;
+    for (int i = 0; i < count; ++i, ++h->cg_launched) {
+        const int n = h->cg_launched, o = n & 1, nw = o ^ 1;
+        hipLaunchKernelGGL(k_cg_fused<D>, dim3(rows), dim3(PS_CG_THREADS), 0, h->stream, rows, h->arow_ptr,
+                           h->acol_idx, h->Saug, h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw],
+                           h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
+                           h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc);
     }
-    if (G)
+}
+
+// x = L^-T (x^_f + P y): gated on the CG's convergence flag when `gate` is given
+template <int D>
+void cg_fused_recover(ps_problem* h, const int32_t* gate) {
+    const int nr = h->nr;
+    if (h->G)
         hipLaunchKernelGGL(k_coarse_recover<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->ncb,
-                           h->pnode, h->pw0, h->pw1, h->Linv, h->Lci, h->cg_xh, h->x);
+                           h->pnode, h->pw0, h->pw1, h->Linv, h->Lci, h->cg_xh, h->x, gate);
     else
         hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->Linv,
-                           h->cg_xh, h->x);
+                           h->cg_xh, h->x, gate);
+}
+
+int cg_report(ps_problem* h, int* iters_out, double* relres_out) {
     h->last_pcg_iters = h->h_status[ST_PCG_ITERS];
     if (iters_out) *iters_out = h->h_status[ST_PCG_ITERS];
     const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
@@ -406,6 +419,25 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
     if (h->h_status[ST_PCG_DONE] == 2)
         return fail("CG breakdown: the reduced system is not positive definite");
     return 0;
+}
+
+// synchronous solve (staged API): poll the convergence flag every chunk
+template <int D>
+int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
+    if (cg_fused_setup<D>(h, max_iters)) return -1;
+    int chunk = std::max(h->pcg_chunk, h->last_pcg_iters + 2);
+    bool done = false;
+    while (!done) {
+        const int m = std::min(chunk, max_iters + 2 - h->cg_launched);
+        cg_fused_launch<D>(h, tol, m);
+        HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 2;
+        chunk = h->pcg_chunk;
+    }
+    cg_fused_recover<D>(h, nullptr);
+    return cg_report(h, iters_out, relres_out);
 }
 
 int linearize(ps_problem* h, double lambda) {
@@ -425,7 +457,7 @@ int linearize(ps_problem* h, double lambda) {
                            h->ppartial, h->diag_slot, lambda, h->S, h->g);
     }
     if (h->npair_items > 0) {
-        StageTimer t(h, PS_ST_SCHUR);
+        StageTimer t(h, PS_ST_SCHUR, 1);
         const size_t lds = 4 * (size_t)PS_SP_LDS_PER_WAVE * sizeof(double);
         HIP_OK(hipFuncSetAttribute((const void*)k_schur_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), lds, h->stream,
@@ -438,42 +470,47 @@ int linearize(ps_problem* h, double lambda) {
     return 0;
 }
 
-int cost_pass(ps_problem* h, int include_all, int scalar_slot) {
-    StageTimer t(h, PS_ST_COST);
+// cost partials into cost_partials[0..n); returns n.  The caller reduces them.
+int cost_partials_pass(ps_problem* h, int include_all, const int32_t* gate) {
     int n = 0;
     if (h->N > 0) {
         hipLaunchKernelGGL(k_cost_reproj, dim3(h->ncost_obs), dim3(256), 0, h->stream, h->N, h->lobs, h->poses,
-                           h->points, h->pose_rid, h->point_vid, h->ogroups, include_all, h->cost_partials);
+                           h->points, h->pose_rid, h->point_vid, h->ogroups, include_all, h->cost_partials, gate);
         n += h->ncost_obs;
     }
     if (h->F > 0) {
         if (h->D == 6)
             hipLaunchKernelGGL(k_cost_factors<6>, dim3(h->ncost_fac), dim3(256), 0, h->stream, (int)h->F, h->f_i,
                                h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->pose_rid, include_all,
-                               h->cost_partials + n);
+                               h->cost_partials + n, gate);
         else
             hipLaunchKernelGGL(k_cost_factors<3>, dim3(h->ncost_fac), dim3(256), 0, h->stream, (int)h->F, h->f_i,
                                h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->pose_rid, include_all,
-                               h->cost_partials + n);
+                               h->cost_partials + n, gate);
         n += h->ncost_fac;
     }
+    return n;
+}
+
+int cost_pass(ps_problem* h, int include_all, int scalar_slot) {
+    StageTimer t(h, PS_ST_COST);
+    const int n = cost_partials_pass(h, include_all, nullptr);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, n, h->cost_partials,
                        h->scalars + scalar_slot);
     return 0;
 }
 
-int backsub(ps_problem* h) {
+int backsub(ps_problem* h, const int32_t* gate = nullptr) {
     if (h->nv == 0) return 0;
     StageTimer t(h, PS_ST_BACKSUB);
-    hipLaunchKernelGGL(k_backsub, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
-                       h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl);
+    hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
+                       h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate);
     return 0;
 }
 
 int step_norm(ps_problem* h) {
-    // ||dx_pose||^2 and ||dx_point||^2 separately (a landmark-sharded caller sums the second
-    // across ranks); partial sums of squares, then a single-workgroup reduce each
-    double* part = h->cost_partials;      // reused: the cost pass of this iteration runs later
+    // standalone ||dx||^2 (ps_step_norm2): partial sums of squares of x and dxl, then two small reduces
+    double* part = h->cost_partials;
     HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
     if (h->nr > 0) {
@@ -489,17 +526,33 @@ int step_norm(ps_problem* h) {
     return 0;
 }
 
-int apply_update(ps_problem* h, double step) {
+int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool with_norm = false) {
     StageTimer t(h, PS_ST_UPDATE);
     if (h->nr > 0) {
+        double* sq = with_norm ? h->sq_part_p : nullptr;
         if (h->D == 6)
-            hipLaunchKernelGGL(k_update_poses<6>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses);
+            hipLaunchKernelGGL(k_update_poses<6>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses, sq, gate);
         else
-            hipLaunchKernelGGL(k_update_poses<3>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses);
+            hipLaunchKernelGGL(k_update_poses<3>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses, sq, gate);
     }
     if (h->nv > 0)
         hipLaunchKernelGGL(k_update_points, dim3(cdiv((long)h->nv * 3, 256)), dim3(256), 0, h->stream, h->nv,
-                           h->lm_point, h->dxl, step, h->points);
+                           h->lm_point, h->dxl, step, h->points, gate);
+    return 0;
+}
+
+// back-substitution, update, cost and ||dx||^2 with ONE final reduction launch.  `gate` (device
+// status words) makes every kernel a no-op until the CG has flagged convergence.
+int gn_tail(ps_problem* h, int linesearch, const int32_t* gate) {
+    if (backsub(h, gate)) return -1;
+    int ncost = 0;
+    if (!linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 0, gate); }
+    if (apply_update(h, 1.0, gate, true)) return -1;
+    if (linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 1, gate); }
+    hipLaunchKernelGGL(k_reduce3, dim3(3), dim3(256), 0, h->stream,
+                       ncost, h->cost_partials, h->scalars + (linesearch ? SC_COST : SC_LINCOST),
+                       h->nsq_p, h->sq_part_p, h->nr > 0 ? h->scalars + SC_DXP2 : nullptr,
+                       h->nsq_l, h->sq_part_l, h->nv > 0 ? h->scalars + SC_DXL2 : nullptr, gate);
     return 0;
 }
 
@@ -511,6 +564,37 @@ int solve_reduced(ps_problem* h, double tol, int max_iters, int* iters, double* 
     return h->D == 6 ? pcg_run<6>(h, tol, max_iters, iters, relres) : pcg_run<3>(h, tol, max_iters, iters, relres);
 }
 
+}  // namespace
+
+namespace {
+// ONE-synchronisation iteration for the fused CG: the CG launches (as many as the previous solve
+// needed, plus a margin), the recovery of x and the whole tail are enqueued back to back; the tail
+// kernels are gated on the device-side convergence flag, so if the CG needed more launches than
+// predicted the host simply enqueues more and repeats the (until then no-op) tail.
+template <int D>
+int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int linesearch,
+                              int* iters_out, double* relres_out, StageTimer* total) {
+    StageTimer tp(h, PS_ST_PCG);
+    if (cg_fused_setup<D>(h, max_iters)) return -1;
+    int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + 4 : 16;
+    for (;;) {
+        count = std::min(count, max_iters + 2 - h->cg_launched);
+        cg_fused_launch<D>(h, tol, count);
+        cg_fused_recover<D>(h, h->status);
+        tp.stop();
+        if (gn_tail(h, linesearch, h->status)) return -1;
+        if (total) total->stop();                       // close the iteration timer before the sync
+        if (read_scalars(h)) return -1;
+        if (h->h_status[ST_PCG_DONE] != 0) break;
+        if (h->cg_launched >= max_iters + 2) {          // not converged within max_iters: take the step anyway
+            cg_fused_recover<D>(h, nullptr);
+            if (gn_tail(h, linesearch, nullptr) || read_scalars(h)) return -1;
+            break;
+        }
+        count = std::max(8, h->cg_launched / 2);
+    }
+    return cg_report(h, iters_out, relres_out);
+}
 }  // namespace
 
 // ===========================================================================
@@ -564,15 +648,29 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     if (h->upload(&h->poses, d->poses, (size_t)P * PW)) return -1;
     if (h->upload(&h->points, d->points, (size_t)L * 3)) return -1;
     if (h->upload(&h->pose_rid, d->pose_rid, (size_t)P)) return -1;
-    if (h->upload(&h->point_vid, d->point_vid, (size_t)L)) return -1;
     if (h->alloc(&h->poses_snap, (size_t)P * PW) || h->alloc(&h->points_snap, (size_t)L * 3)) return -1;
     int nr = 0, nv = 0;
     for (int i = 0; i < P; ++i) if (d->pose_rid[i] >= 0) nr = std::max(nr, d->pose_rid[i] + 1);
     for (int i = 0; i < L; ++i) if (d->point_vid[i] >= 0) nv = std::max(nv, d->point_vid[i] + 1);
     h->nr = nr; h->nv = nv;
-    std::vector<int32_t> lm_point(nv, -1);
-    for (int i = 0; i < L; ++i) if (d->point_vid[i] >= 0) lm_point[d->point_vid[i]] = i;
-    for (int v = 0; v < nv; ++v) if (lm_point[v] < 0) return fail("point_vid is not a dense 0..nv-1 numbering");
+    std::vector<int32_t> point_of_vid(nv, -1);
+    for (int i = 0; i < L; ++i) if (d->point_vid[i] >= 0) point_of_vid[d->point_vid[i]] = i;
+    for (int v = 0; v < nv; ++v) if (point_of_vid[v] < 0) return fail("point_vid is not a dense 0..nv-1 numbering");
+    // Internal landmark order ("slots"): by the lowest pose index that observes the landmark, so the
+    // Z rows a pose (and a reduced-system block row) touches come from a compact address range and
+    // stay in the 4 MB per-XCD L2, whatever order the caller numbered the landmarks in.
+    std::vector<int32_t> first_pose(L, INT32_MAX);
+    for (long i = 0; i < N; ++i) {
+        const int pt = d->obs_point[i];
+        if (pt >= 0 && pt < L) first_pose[pt] = std::min(first_pose[pt], d->obs_pose[i]);
+    }
+    std::vector<int32_t>& vid_of_slot = h->h_vid_of_slot;
+    vid_of_slot.resize(nv);
+    for (int v = 0; v < nv; ++v) vid_of_slot[v] = v;
+    std::stable_sort(vid_of_slot.begin(), vid_of_slot.end(), [&](int32_t a, int32_t b) {
+        return first_pose[point_of_vid[a]] < first_pose[point_of_vid[b]]; });
+    std::vector<int32_t> lm_point(nv), point_slot(L, -1);
+    for (int s2 = 0; s2 < nv; ++s2) { lm_point[s2] = point_of_vid[vid_of_slot[s2]]; point_slot[lm_point[s2]] = s2; }
     {
         std::vector<char> seen(nr, 0);
         for (int i = 0; i < P; ++i) if (d->pose_rid[i] >= 0) {
@@ -581,6 +679,8 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         }
         for (int i = 0; i < nr; ++i) if (!seen[i]) return fail("pose_rid is not a dense 0..nr-1 numbering");
     }
+
+    if (h->upload(&h->point_vid, point_slot)) return -1;     // device-side 'vid' = internal slot
 
     // ---- observation groups
     std::vector<ObsGroup> og(std::max(1, d->num_obs_groups));
@@ -600,7 +700,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     std::vector<int64_t> order(N);
     for (long i = 0; i < N; ++i) order[i] = i;
     auto lm_key = [&](long i) -> int64_t {
-        const int v = d->point_vid[d->obs_point[i]];
+        const int v = point_slot[d->obs_point[i]];
         return v >= 0 ? (int64_t)v : (int64_t)nv + d->obs_point[i];
     };
     std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return lm_key(a) < lm_key(b); });
@@ -617,7 +717,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         o.pose_grp = (int32_t)((uint32_t)pose | ((uint32_t)grp << 24));
         o.point = pt;
         lorig[k] = (int32_t)i;
-        const int v = d->point_vid[pt];
+        const int v = point_slot[pt];
         if (v >= 0) { lm_ptr[v + 1] += 1; ++Nl; }
     }
     for (int v = 0; v < nv; ++v) lm_ptr[v + 1] += lm_ptr[v];
@@ -838,6 +938,9 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         h->alloc(&h->scalars, SC_NWORDS) || h->alloc(&h->status, ST_NWORDS)) return -1;
     HIP_OK(hipMemsetAsync(h->scalars, 0, SC_NWORDS * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+    h->nsq_l = nv > 0 ? cdiv(nv, 256 / PS_LM_GROUP) : 0;
+    h->nsq_p = nr > 0 ? cdiv(P, 256) : 0;
+    if (h->alloc(&h->sq_part_l, (size_t)h->nsq_l) || h->alloc(&h->sq_part_p, (size_t)h->nsq_p)) return -1;
     HIP_OK(hipHostMalloc((void**)&h->h_scalars, SC_NWORDS * sizeof(double)));
     HIP_OK(hipHostMalloc((void**)&h->h_status, ST_NWORDS * sizeof(int32_t)));
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -888,9 +991,16 @@ int ps_backsub(ps_problem* h) {
 
 int ps_get_dx(ps_problem* h, double* dx_pose, double* dx_point) {
     if (!h) return fail("null argument");
+    std::vector<double> tmp;
     if (dx_pose && h->nr) HIP_OK(hipMemcpyAsync(dx_pose, h->x, (size_t)h->nr * h->D * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (dx_point && h->nv) HIP_OK(hipMemcpyAsync(dx_point, h->dxl, (size_t)h->nv * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    return sync(h);
+    if (dx_point && h->nv) {
+        tmp.resize((size_t)h->nv * 3);
+        HIP_OK(hipMemcpyAsync(tmp.data(), h->dxl, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (sync(h)) return -1;
+    for (int s2 = 0; dx_point && s2 < h->nv; ++s2)       // internal slot order -> the caller's vid order
+        std::memcpy(dx_point + 3 * (size_t)h->h_vid_of_slot[s2], &tmp[3 * (size_t)s2], 3 * sizeof(double));
+    return 0;
 }
 
 int ps_step_norm2(ps_problem* h, double* norm2) {
@@ -933,20 +1043,11 @@ int ps_set_params(ps_problem* h, const double* poses, const double* points) {
     return sync(h);
 }
 
-namespace {
-int gn_finish(ps_problem* h, int linesearch) {
-    if (backsub(h)) return -1;
-    if (!linesearch && cost_pass(h, 0, SC_LINCOST)) return -1;
-    if (step_norm(h)) return -1;
-    if (apply_update(h, 1.0)) return -1;
-    if (linesearch && cost_pass(h, 1, SC_COST)) return -1;
-    return 0;
-}
-}  // namespace
-
 int ps_gn_finish(ps_problem* h, int linesearch, double* cost_out, double* dx_pose_norm2, double* dx_point_norm2) {
     if (!h) return fail("null argument");
-    if (gn_finish(h, linesearch)) return -1;
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
+    if (gn_tail(h, linesearch, nullptr)) return -1;
     if (read_scalars(h)) return -1;
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
@@ -959,12 +1060,22 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
                     double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out) {
     if (!h) return fail("null argument");
     {
-        StageTimer total(h, PS_ST_TOTAL);     // closed before the synchronising read-back
+        StageTimer total(h, PS_ST_TOTAL, 1);  // closed before the last synchronising read-back
         if (linearize(h, lambda)) return -1;
-        if (solve_reduced(h, pcg_tol, pcg_max_iters, pcg_iters_out, pcg_relres_out)) return -1;
-        if (gn_finish(h, linesearch)) return -1;
+        HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
+        HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
+        if (h->nr > 0 && h->pcg_variant == 1) {
+            const int rc = h->D == 6
+                ? gn_solve_and_finish_async<6>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, &total)
+                : gn_solve_and_finish_async<3>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, &total);
+            if (rc) return -1;
+        } else {
+            if (solve_reduced(h, pcg_tol, pcg_max_iters, pcg_iters_out, pcg_relres_out)) return -1;
+            if (gn_tail(h, linesearch, nullptr)) return -1;
+            total.stop();
+            if (read_scalars(h)) return -1;
+        }
     }
-    if (read_scalars(h)) return -1;
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
     if (dx_norm_out) *dx_norm_out = std::sqrt(h->h_scalars[SC_DXP2] + h->h_scalars[SC_DXL2]);
@@ -982,9 +1093,18 @@ int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx, dou
 
 int ps_get_landmark_factors(ps_problem* h, double* cinv, double* c) {
     if (!h) return fail("null argument");
-    if (cinv && h->nv) HIP_OK(hipMemcpyAsync(cinv, h->Cinv, (size_t)h->nv * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (c && h->nv) HIP_OK(hipMemcpyAsync(c, h->cvec, (size_t)h->nv * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    return sync(h);
+    std::vector<double> t6((size_t)h->nv * 6), t3((size_t)h->nv * 3);
+    if (h->nv) {
+        HIP_OK(hipMemcpyAsync(t6.data(), h->Cinv, t6.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(t3.data(), h->cvec, t3.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (sync(h)) return -1;
+    for (int s2 = 0; s2 < h->nv; ++s2) {
+        const size_t v = (size_t)h->h_vid_of_slot[s2];
+        if (cinv) std::memcpy(cinv + 6 * v, &t6[6 * (size_t)s2], 6 * sizeof(double));
+        if (c) std::memcpy(c + 3 * v, &t3[3 * (size_t)s2], 3 * sizeof(double));
+    }
+    return 0;
 }
 
 int ps_debug_reproj_blocks(ps_problem* h, double* r, double* jpose, double* jpoint) {
@@ -1019,7 +1139,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
 
 int ps_set_profiling(ps_problem* h, int enabled) {
     if (!h) return fail("null argument");
-    h->profiling = enabled != 0;
+    h->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
     return 0;
 }
 

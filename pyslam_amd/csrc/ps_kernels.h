@@ -937,8 +937,10 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
 // x = Linv^T x^
 template <int D>
 __global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __restrict__ Linv,
-                                                     const double* __restrict__ xh, double* __restrict__ x)
+                                                     const double* __restrict__ xh, double* __restrict__ x,
+                                                     const int32_t* __restrict__ gate)
 {
+    if (gate && !gate[ST_PCG_DONE]) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nr * D) return;
     const int i = t / D, c = t % D;
@@ -1229,9 +1231,10 @@ template <int D>
 __global__ __launch_bounds__(256) void k_coarse_recover(
     int nr, int ncb, const int32_t* __restrict__ pnode, const double* __restrict__ pw0,
     const double* __restrict__ pw1, const double* __restrict__ Linv, const double* __restrict__ Lci,
-    const double* __restrict__ xh, double* __restrict__ x)
+    const double* __restrict__ xh, double* __restrict__ x, const int32_t* __restrict__ gate)
 {
     __shared__ double sy[192];
+    if (gate && !gate[ST_PCG_DONE]) return;
     const int nc = ncb * D;
     const double* xc = xh + (size_t)nr * D;
     for (int base = 0; base < nc; base += blockDim.x / 8) {
@@ -1260,14 +1263,21 @@ __global__ __launch_bounds__(256) void k_coarse_recover(
 }
 
 // ---------------------------------------------------------------------------
-// back-substitution, retraction, cost, small reductions
+// back-substitution, retraction, cost, small reductions.
+// `gate`: when non-null the kernel returns unless the CG has flagged convergence
+// (status[ST_PCG_DONE]); ps_gn_iteration enqueues this tail right behind the CG launches
+// without a host synchronisation and re-runs it in the rare case the CG needed more launches.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_backsub(
     int nv, const int32_t* __restrict__ lm_ptr, const LObs* __restrict__ lobs,
     const int32_t* __restrict__ pose_rid, const double* __restrict__ Z,
     const double* __restrict__ Cinv, const double* __restrict__ cvec,
-    const double* __restrict__ xp, double* __restrict__ dxl)
+    const double* __restrict__ xp, double* __restrict__ dxl,
+    double* __restrict__ sq_part /* one partial of ||dx_l||^2 per workgroup */,
+    const int32_t* __restrict__ gate)
 {
+    __shared__ double lds[16];
+    if (gate && !gate[ST_PCG_DONE]) return;
     // 16 lanes per landmark, one observation per lane (same mapping as k_landmark_pass)
     const int v = blockIdx.x * (blockDim.x / PS_LM_GROUP) + threadIdx.x / PS_LM_GROUP;
     const int sub = threadIdx.x & (PS_LM_GROUP - 1);
@@ -1287,34 +1297,53 @@ __global__ __launch_bounds__(256) void k_backsub(
         }
     }
     a0 = group16_sum(a0); a1 = group16_sum(a1); a2 = group16_sum(a2);
-    if (!live || sub != 0) return;
-    a0 += cvec[3 * (size_t)v]; a1 += cvec[3 * (size_t)v + 1]; a2 += cvec[3 * (size_t)v + 2];
-    const double* m = Cinv + 6 * (size_t)v;    // dx = M^T a
-    dxl[3 * (size_t)v] = m[0] * a0 + m[1] * a1 + m[3] * a2;
-    dxl[3 * (size_t)v + 1] = m[2] * a1 + m[4] * a2;
-    dxl[3 * (size_t)v + 2] = m[5] * a2;
+    double sq = 0.0;
+    if (live && sub == 0) {
+        a0 += cvec[3 * (size_t)v]; a1 += cvec[3 * (size_t)v + 1]; a2 += cvec[3 * (size_t)v + 2];
+        const double* m = Cinv + 6 * (size_t)v;    // dx = M^T a
+        const double d0 = m[0] * a0 + m[1] * a1 + m[3] * a2;
+        const double d1 = m[2] * a1 + m[4] * a2;
+        const double d2 = m[5] * a2;
+        dxl[3 * (size_t)v] = d0; dxl[3 * (size_t)v + 1] = d1; dxl[3 * (size_t)v + 2] = d2;
+        sq = d0 * d0 + d1 * d1 + d2 * d2;
+    }
+    sq = block_sum(sq, lds);
+    if (threadIdx.x == 0) sq_part[blockIdx.x] = sq;
 }
 
 template <int D>
 __global__ __launch_bounds__(256) void k_update_poses(
     int P, const int32_t* __restrict__ pose_rid, const double* __restrict__ xp,
-    double step, double* __restrict__ poses)
+    double step, double* __restrict__ poses, double* __restrict__ sq_part /* per workgroup, or null */,
+    const int32_t* __restrict__ gate)
 {
     typedef PoseOps<D> G;
+    __shared__ double lds[16];
+    if (gate && !gate[ST_PCG_DONE]) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const int rid = pose_rid[i];
-    if (rid < 0) return;
-    double xi[D];
+    double sq = 0.0;
+    const int rid = (i < P) ? pose_rid[i] : -1;
+    if (rid >= 0) {
+        double xi[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) xi[k] = step * xp[(size_t)rid * D + k];
-    G::store(poses + G::W * (size_t)i, G::mul(G::exp(xi), G::load(poses + G::W * (size_t)i)));
+        for (int k = 0; k < D; ++k) {
+            const double v = xp[(size_t)rid * D + k];
+            sq += v * v;
+            xi[k] = step * v;
+        }
+        G::store(poses + G::W * (size_t)i, G::mul(G::exp(xi), G::load(poses + G::W * (size_t)i)));
+    }
+    if (sq_part) {
+        sq = block_sum(sq, lds);
+        if (threadIdx.x == 0) sq_part[blockIdx.x] = sq;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_update_points(
     int nv, const int32_t* __restrict__ lm_point, const double* __restrict__ dxl,
-    double step, double* __restrict__ points)
+    double step, double* __restrict__ points, const int32_t* __restrict__ gate)
 {
+    if (gate && !gate[ST_PCG_DONE]) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 3 * nv) return;
     points[3 * (size_t)lm_point[t / 3] + t % 3] += step * dxl[t];
@@ -1325,9 +1354,10 @@ __global__ __launch_bounds__(256) void k_cost_reproj(
     long n, const LObs* __restrict__ lobs, const double* __restrict__ poses,
     const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
     const int32_t* __restrict__ point_vid, const ObsGroup* __restrict__ groups,
-    int include_all, double* __restrict__ partials)
+    int include_all, double* __restrict__ partials, const int32_t* __restrict__ gate)
 {
     __shared__ double lds[16];
+    if (gate && !gate[ST_PCG_DONE]) return;
     double c = 0.0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const LObs o = lobs[i];
@@ -1348,10 +1378,12 @@ __global__ __launch_bounds__(256) void k_cost_factors(
     int nf, const int32_t* __restrict__ f_i, const int32_t* __restrict__ f_j,
     const double* __restrict__ f_Tinv, const int32_t* __restrict__ f_grp,
     const FactorGroup* __restrict__ groups, const double* __restrict__ poses,
-    const int32_t* __restrict__ pose_rid, int include_all, double* __restrict__ partials)
+    const int32_t* __restrict__ pose_rid, int include_all, double* __restrict__ partials,
+    const int32_t* __restrict__ gate)
 {
     typedef PoseOps<D> G;
     __shared__ double lds[16];
+    if (gate && !gate[ST_PCG_DONE]) return;
     double cst = 0.0;
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
         const int i = f_i[f], j = f_j[f];
@@ -1387,6 +1419,25 @@ __global__ __launch_bounds__(256) void k_sumsq_partials(
     }
     s = block_sum(s, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// up to three independent sums in ONE launch: workgroup b reduces partials_b[0..n_b) into out_b
+// (fixed order).  Used for {cost, ||dx_pose||^2, ||dx_point||^2} at the end of an iteration.
+__global__ __launch_bounds__(256) void k_reduce3(
+    int n0, const double* __restrict__ p0, double* __restrict__ o0,
+    int n1, const double* __restrict__ p1, double* __restrict__ o1,
+    int n2, const double* __restrict__ p2, double* __restrict__ o2, const int32_t* __restrict__ gate)
+{
+    __shared__ double lds[16];
+    if (gate && !gate[ST_PCG_DONE]) return;
+    const int n = blockIdx.x == 0 ? n0 : (blockIdx.x == 1 ? n1 : n2);
+    const double* p = blockIdx.x == 0 ? p0 : (blockIdx.x == 1 ? p1 : p2);
+    double* o = blockIdx.x == 0 ? o0 : (blockIdx.x == 1 ? o1 : o2);
+    if (!o) return;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) o[0] = s;
 }
 
 // out[0] = sum(partials[0..n))  (single workgroup, fixed order)

@@ -166,8 +166,10 @@ class DeviceProblem:
         nat.check(self._lib.ps_set_option(self._h, name.encode(), float(value)))
 
     # ---- tracing -------------------------------------------------------
-    def set_profiling(self, on=True):
-        nat.check(self._lib.ps_set_profiling(self._h, int(on)))
+    def set_profiling(self, level=2):
+        """0 off; 1 = hipEvents around the whole iteration and the Schur kernel only (cheap);
+        2 = around every stage (adds ~10 event records per iteration)."""
+        nat.check(self._lib.ps_set_profiling(self._h, int(level)))
 
     def stage_times(self, reset=False):
         ms = (C.c_double * nat.PS_NUM_STAGES)()

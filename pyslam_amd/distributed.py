@@ -137,8 +137,8 @@ class ShardedDeviceProblem:
     def get_params(self):
         return self.dev.get_params()
 
-    def set_profiling(self, on=True):
-        self.dev.set_profiling(on)
+    def set_profiling(self, level=2):
+        self.dev.set_profiling(level)
 
     def stage_times(self, reset=False):
         return self.dev.stage_times(reset)
