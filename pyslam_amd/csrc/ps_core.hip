@@ -97,6 +97,7 @@ struct ps_problem {
             *arow_ptr = nullptr, *acol_idx = nullptr, *aug_slot = nullptr, *fine_nnz = nullptr;
     double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr;
     bool coarse_built = false;
+    int cg_ablate = 0;
     int cg_launched = 0;            // CG launches enqueued since the last setup
     int ell_wf = 0, ell_wc = 0;     // two-class ELL widths of the CG matrix (0 = CSR)
     // scalars
@@ -393,7 +394,7 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
         hipLaunchKernelGGL(k_cg_fused<D>, dim3(rows), dim3(PS_CG_THREADS), 0, h->stream, rows, h->arow_ptr,
                            h->acol_idx, h->Saug, h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw],
                            h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
-                           h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc);
+                           h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc, h->cg_ablate);
     }
 }
 
@@ -1132,6 +1133,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
         if (value < -1 || value > 64) return fail("coarse_groups out of range (-1 auto, 0 off, else number of hat intervals)");
         h->coarse_req = (int)value; h->coarse_built = false;
     }
+    else if (n == "cg_ablate") h->cg_ablate = (int)value;
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }
     else return fail("unknown option: " + n);
     return 0;

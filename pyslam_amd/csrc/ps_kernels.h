@@ -844,7 +844,8 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     const double* __restrict__ gd_in /* [2*nr] gamma | delta partials */, double* __restrict__ gd_out,
     double* __restrict__ hist /* [0,cap): gamma, [cap,2cap): alpha */, int cap, int k, double tol2,
     int32_t* __restrict__ status, double* __restrict__ scalars,
-    int nfine, int wf, int wc /* two-class ELL: fine rows wf blocks wide, the rest wc; wf = 0 => CSR */)
+    int nfine, int wf, int wc /* two-class ELL: fine rows wf blocks wide, the rest wc; wf = 0 => CSR */,
+    int ablate /* timing experiments only: 1 skips the SpMV, 2 skips the partial-sum reduction */)
 {
     __shared__ double lds[32];
     __shared__ double part[PS_CG_WAVES][8];
@@ -866,12 +867,19 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     const double a_prev = hist[cap + (k > 0 ? k - 1 : 0)];
     const double thresh_in = scalars[SC_THRESH];
     double gs = 0.0, ds = 0.0;
-    if (k >= 0)
+    if (k >= 0 && ablate != 2)
         for (int i = t; i < nr; i += PS_CG_THREADS) { gs += gd_in[i]; ds += gd_in[nr + i]; }
     const int kk = lane >> 3, r = lane & 7;
     const int b0 = rbeg + w * 8 + kk;
-    int cj = 0;
-    if (b0 < rend) cj = col_idx[b0];
+    constexpr int STRIDE = 8 * PS_CG_WAVES;
+    // rows of the dense border K^T (row >= nfine in the ELL layout) have columns 0,1,2,... : their
+    // column index is arithmetic, so their vector loads do not wait for a col_idx load.
+    const bool dense_row = wf > 0 && row >= nfine;
+    int cj0 = 0, cj1 = 0;                        // column blocks of this lane's first two passes
+    if (!dense_row) {
+        if (b0 < rend) cj0 = col_idx[b0];
+        if (b0 + STRIDE < rend) cj1 = col_idx[b0 + STRIDE];
+    }
     double ri = 0.0, wi = 0.0, si = 0.0, pi = 0.0, xi_ = 0.0;
     if (t < D) {
         const size_t i = (size_t)row * D + t;
@@ -879,7 +887,8 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     }
     if (done) return;
     double alpha = 0.0, beta = 0.0;
-    if (k >= 0) {
+    if (k >= 0 && ablate == 2) { alpha = 1e-3; beta = 0.5; }
+    if (k >= 0 && ablate != 2) {
         block_sum2(gs, ds, lds);
         const double gamma = gs, delta = ds;
         const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
@@ -902,9 +911,13 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     }
     // ---- w_new(row) = S^(row,:) r_new, with r_new recomputed per column block
     double acc = 0.0;
-    if (r < D) {
-        for (int b = b0; b < rend; b += 8 * PS_CG_WAVES) {
-            const size_t j = (size_t)(b == b0 ? cj : col_idx[b]) * D;
+    if (r < D && ablate != 1) {
+#pragma unroll 2
+        for (int b = b0; b < rend; b += STRIDE) {
+            int jc;
+            if (dense_row) jc = (b == rend - 1) ? row : b - rbeg;
+            else jc = (b == b0) ? cj0 : ((b == b0 + STRIDE) ? cj1 : col_idx[b]);
+            const size_t j = (size_t)jc * D;
             const double* sb = S + (size_t)b * DD + r * D;
 #pragma unroll
             for (int c = 0; c < D; ++c)
