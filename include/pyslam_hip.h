@@ -152,6 +152,12 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
 int ps_gn_finish(ps_problem* h, int linesearch, double* cost_out, double* dx_pose_norm2,
                  double* dx_point_norm2);
 
+/* ps_solve_reduced + ps_gn_finish with ONE synchronisation (the tail is enqueued behind the CG
+   launches and gated on the device-side convergence flag): the sharded caller's second half. */
+int ps_gn_solve_finish(ps_problem* h, double pcg_tol, int pcg_max_iters, int linesearch, double* cost_out,
+                       double* dx_pose_norm2, double* dx_point_norm2, int* pcg_iters_out,
+                       double* pcg_relres_out);
+
 /* Parity / debug taps (device -> host). */
 int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx,
                           double* vals, double* g);       /* BSR, dof x dof blocks */

@@ -66,6 +66,8 @@ SIGNATURES = {
     'ps_gn_iteration': (C.c_int, [H, C.c_double, C.c_double, C.c_int, C.c_int, c_f64p, c_f64p,
                                   C.POINTER(C.c_int), c_f64p]),
     'ps_gn_finish': (C.c_int, [H, C.c_int, c_f64p, c_f64p, c_f64p]),
+    'ps_gn_solve_finish': (C.c_int, [H, C.c_double, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p,
+                                     C.POINTER(C.c_int), c_f64p]),
     'ps_get_reduced_system': (C.c_int, [H, c_i32p, c_i32p, c_f64p, c_f64p]),
     'ps_get_landmark_factors': (C.c_int, [H, c_f64p, c_f64p]),
     'ps_debug_reproj_blocks': (C.c_int, [H, c_f64p, c_f64p, c_f64p]),

@@ -1057,6 +1057,28 @@ int ps_gn_finish(ps_problem* h, int linesearch, double* cost_out, double* dx_pos
     return 0;
 }
 
+int ps_gn_solve_finish(ps_problem* h, double pcg_tol, int pcg_max_iters, int linesearch, double* cost_out,
+                       double* dx_pose_norm2, double* dx_point_norm2, int* pcg_iters_out, double* pcg_relres_out) {
+    if (!h) return fail("null argument");
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
+    if (h->nr > 0 && h->pcg_variant == 1) {
+        const int rc = h->D == 6
+            ? gn_solve_and_finish_async<6>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, nullptr)
+            : gn_solve_and_finish_async<3>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, nullptr);
+        if (rc) return -1;
+    } else {
+        if (solve_reduced(h, pcg_tol, pcg_max_iters, pcg_iters_out, pcg_relres_out)) return -1;
+        if (gn_tail(h, linesearch, nullptr)) return -1;
+        if (read_scalars(h)) return -1;
+    }
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+    if (dx_pose_norm2) *dx_pose_norm2 = h->h_scalars[SC_DXP2];
+    if (dx_point_norm2) *dx_point_norm2 = h->h_scalars[SC_DXL2];
+    return 0;
+}
+
 int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters, int linesearch,
                     double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out) {
     if (!h) return fail("null argument");

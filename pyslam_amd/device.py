@@ -81,6 +81,14 @@ class DeviceProblem:
         nat.check(self._lib.ps_gn_finish(self._h, int(linesearch), C.byref(c), C.byref(a), C.byref(b)))
         return c.value, a.value, b.value
 
+    def gn_solve_finish(self, pcg_tol=1e-12, pcg_max_iters=1000, linesearch=True):
+        """Reduced solve + back-substitution + update + cost with one sync.
+        -> (shard cost, ||dx_pose||^2, ||dx_point||^2, pcg iterations, relative residual)."""
+        c, a, b, rel, it = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        nat.check(self._lib.ps_gn_solve_finish(self._h, pcg_tol, pcg_max_iters, int(linesearch), C.byref(c),
+                                               C.byref(a), C.byref(b), C.byref(it), C.byref(rel)))
+        return c.value, a.value, b.value, it.value, rel.value
+
     def linearize(self, lm_lambda=0.):
         nat.check(self._lib.ps_linearize(self._h, lm_lambda))
 

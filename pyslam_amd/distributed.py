@@ -6,8 +6,8 @@ pose table is replicated.  Per iteration:
 
     ps_linearize            shard-local: residuals, Jacobians, H_ll, Z, partial S, g
     ONE sum all-reduce      [S values | g | cost] on the device buffer the core exposes
-    ps_solve_reduced        replicated, deterministic -> identical dx_pose on every rank
-    ps_gn_finish            shard-local back-substitution, update, cost
+    ps_gn_solve_finish      replicated, deterministic reduced solve (identical dx_pose on every
+                            rank) + shard-local back-substitution, update, cost; one host sync
     scalar all-reduce       (cost, ||dx_point||^2)
 
 The reduced system's block pattern must be identical on every rank for the
@@ -120,9 +120,8 @@ class ShardedDeviceProblem:
     def gn_iteration(self, lm_lambda=0., pcg_tol=1e-12, pcg_max_iters=1000, linesearch=True):
         self.dev.linearize(lm_lambda)
         self.dist.all_reduce(self.dev.reduce_tensor)          # RCCL sum over xGMI, on the solver's stream
-        its, rel = self.dev.solve_reduced(pcg_tol, pcg_max_iters)
-        cost, dxp2, dxl2 = self.dev.gn_finish(linesearch)
-        self._scal[0], self._scal[1] = cost, dxl2
+        cost, dxp2, dxl2, its, rel = self.dev.gn_solve_finish(pcg_tol, pcg_max_iters, linesearch)
+        self._scal.copy_(self._torch.tensor([cost, dxl2], dtype=self._torch.float64), non_blocking=True)
         self.dist.all_reduce(self._scal)
         s = self._scal.tolist()
         return s[0], float(np.sqrt(dxp2 + s[1])), its, rel

@@ -54,6 +54,10 @@ class OracleShardDevice:
         self.dxp = np.linalg.solve(buf[:n * n].reshape(n, n), buf[n * n:n * n + n])
         return 1, 0.0
 
+    def gn_solve_finish(self, tol, max_iters, linesearch):
+        its, rel = self.solve_reduced(tol, max_iters)
+        return self.gn_finish(linesearch) + (its, rel)
+
     def gn_finish(self, linesearch):
         dxl = self.Hinv @ (self.bl - self.Hpl.T @ self.dxp)
         dx = np.concatenate([self.dxp, dxl])
