@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
         __syncthreads();
         // panel: L_IJ = A_IJ L_JJ^-T   (entry (a,b) = sum_{k<=b} A_IJ[a][k] Mi[b][k])
         const int m = ncb - J - 1;
-        double pv[4];
+        double pv[4];                         // <= 15*36 (D=6) or 31*9 (D=3) entries over 256 threads
         int np = 0;
         for (int idx = t; idx < m * DD; idx += nt, ++np) {
             const int I = J + 1 + idx / DD, e = idx % DD, a = e / D, b2 = e % D;
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
     // X = L^-1 by block rows: X_RC = Mi_R (delta_RC I - sum_{K=C}^{R-1} L_RK X_KC), all C <= R in parallel
     for (int R = 0; R < ncb; ++R) {
         __syncthreads();
-        double tv[2];
+        double tv[4];                         // <= 16*36 entries over 256 threads
         int np = 0;
         for (int idx = t; idx < (R + 1) * DD; idx += nt, ++np) {
             const int C = idx / DD, e = idx % DD, a = e / D, b2 = e % D;
