@@ -98,6 +98,8 @@ struct ps_problem {
     double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr;
     bool coarse_built = false;
     int cg_ablate = 0;
+    bool cg_two_level_reduce = false, cg_short_rows = false;
+    double* cg_tot = nullptr;
     int cg_launched = 0;            // CG launches enqueued since the last setup
     int ell_wf = 0, ell_wc = 0;     // two-class ELL widths of the CG matrix (0 = CSR)
     // scalars
@@ -261,6 +263,7 @@ int ensure_cg_buffers(ps_problem* h, int rows, int blocks) {
     if (h->alloc(&h->Saug, (size_t)std::max(blocks, 1) * D * D)) return -1;
     HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)std::max(blocks, 1) * D * D * sizeof(double), h->stream));
     h->cg_cap = rows; h->saug_cap = (size_t)std::max(blocks, 1);
+    if (!h->cg_tot && h->alloc(&h->cg_tot, 2)) return -1;
     return 0;
 }
 
@@ -270,7 +273,9 @@ int build_coarse(ps_problem* h) {
     const int nr = h->nr, D = h->D;
     int G = h->coarse_req;
     const int Gmax = (D == 6) ? 15 : 31;           // nc = (G + 1) D <= 96: L_c and L_c^-1 both LDS-resident
-    if (G < 0) G = (nr >= 48) ? std::min(12, std::max(3, (nr + 9) / 18)) : 0;
+    // auto: on from 48 reduced poses; off beyond 4096 (the dense border rows K^T are handled by one
+    // workgroup each and would dominate the iteration -- a scalable coarse level is future work)
+    if (G < 0) G = (nr >= 48 && nr <= 4096) ? std::min(12, std::max(3, (nr + 9) / 18)) : 0;
     G = std::min(G, Gmax);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
     if (G < 1) G = 0;
@@ -355,6 +360,8 @@ int cg_fused_setup(ps_problem* h, int max_iters) {
     const int nr = h->nr, cap = h->hist_cap;
     if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
     if (!h->coarse_built && build_coarse(h)) return -1;
+    h->cg_two_level_reduce = h->nr_aug > 2048;
+    h->cg_short_rows = (long)h->nnzb_aug <= 24L * h->nr_aug;       // pose-graph-like rows: one wave per row
     const int G = h->G, rows = h->nr_aug;
     const int32_t* rp = h->arow_ptr;
     const int32_t* ci = h->acol_idx;
@@ -391,10 +398,17 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
     const double tol2 = tol * tol;
     for (int i = 0; i < count; ++i, ++h->cg_launched) {
         const int n = h->cg_launched, o = n & 1, nw = o ^ 1;
-        hipLaunchKernelGGL(k_cg_fused<D>, dim3(rows), dim3(PS_CG_THREADS), 0, h->stream, rows, h->arow_ptr,
-                           h->acol_idx, h->Saug, h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw],
-                           h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
-                           h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc, h->cg_ablate);
+        // large systems: totals of the previous launch's partials come from k_cg_reduce
+        const double* tot = h->cg_two_level_reduce ? h->cg_tot : nullptr;
+        if (tot && n > 0)
+            hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(1024), 0, h->stream, rows, h->cg_gd[o], h->cg_tot, h->status);
+#define PS_CG_LAUNCH(NWV)                                                                                          \
+        hipLaunchKernelGGL((k_cg_fused<D, NWV>), dim3(rows), dim3(64 * NWV), 0, h->stream, rows, h->arow_ptr,           \
+                           h->acol_idx, h->Saug, h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw],        \
+                           h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,      \
+                           h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc, h->cg_ablate, tot)
+        if (h->cg_short_rows) { PS_CG_LAUNCH(1); } else { PS_CG_LAUNCH(8); }
+#undef PS_CG_LAUNCH
     }
 }
 

@@ -832,10 +832,22 @@ PS_DEV double cg_rnew(double r, double w, double s, double alpha, double beta) {
     return r - alpha * (w + beta * s);
 }
 
-#define PS_CG_WAVES 8
-#define PS_CG_THREADS (64 * PS_CG_WAVES)
-template <int D>
-__global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
+// gamma / delta totals for large systems: with thousands of rows every workgroup re-reducing all
+// per-row partials would cost O(rows^2) traffic, so one extra single-workgroup launch per iteration
+// reduces them once (fixed order) and k_cg_fused reads two scalars (pre_reduced = 1).
+__global__ __launch_bounds__(1024) void k_cg_reduce(int nr, const double* __restrict__ gd, double* __restrict__ tot,
+                                                     const int32_t* __restrict__ status)
+{
+    __shared__ double lds[32];
+    if (status[ST_PCG_DONE]) return;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nr; i += 1024) { a += gd[i]; b += gd[nr + i]; }
+    block_sum2(a, b, lds);
+    if (threadIdx.x == 0) { tot[0] = a; tot[1] = b; }
+}
+
+template <int D, int NW /* waves per workgroup: 8 for long rows, 1 for short (pose-graph) rows */>
+__global__ __launch_bounds__(64 * NW) void k_cg_fused(
     int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
     const double* __restrict__ S,
     const double* __restrict__ r_old, const double* __restrict__ w_old, const double* __restrict__ s_old,
@@ -845,10 +857,11 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     double* __restrict__ hist /* [0,cap): gamma, [cap,2cap): alpha */, int cap, int k, double tol2,
     int32_t* __restrict__ status, double* __restrict__ scalars,
     int nfine, int wf, int wc /* two-class ELL: fine rows wf blocks wide, the rest wc; wf = 0 => CSR */,
-    int ablate /* timing experiments only: 1 skips the SpMV, 2 skips the partial-sum reduction */)
+    int ablate /* timing experiments only: 1 skips the SpMV, 2 skips the partial-sum reduction */,
+    const double* __restrict__ gd_tot /* non-null: totals already reduced by k_cg_reduce */)
 {
     __shared__ double lds[32];
-    __shared__ double part[PS_CG_WAVES][8];
+    __shared__ double part[NW][8];
     constexpr int DD = D * D;
     const int t = threadIdx.x, w = t >> 6, lane = t & 63;
     const int row = blockIdx.x;
@@ -867,11 +880,13 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     const double a_prev = hist[cap + (k > 0 ? k - 1 : 0)];
     const double thresh_in = scalars[SC_THRESH];
     double gs = 0.0, ds = 0.0;
-    if (k >= 0 && ablate != 2)
-        for (int i = t; i < nr; i += PS_CG_THREADS) { gs += gd_in[i]; ds += gd_in[nr + i]; }
+    if (k >= 0 && ablate != 2) {
+        if (gd_tot) { gs = gd_tot[0]; ds = gd_tot[1]; }
+        else for (int i = t; i < nr; i += 64 * NW) { gs += gd_in[i]; ds += gd_in[nr + i]; }
+    }
     const int kk = lane >> 3, r = lane & 7;
     const int b0 = rbeg + w * 8 + kk;
-    constexpr int STRIDE = 8 * PS_CG_WAVES;
+    constexpr int STRIDE = 8 * NW;
     // rows of the dense border K^T (row >= nfine in the ELL layout) have columns 0,1,2,... : their
     // column index is arithmetic, so their vector loads do not wait for a col_idx load.
     const bool dense_row = wf > 0 && row >= nfine;
@@ -889,7 +904,7 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
     double alpha = 0.0, beta = 0.0;
     if (k >= 0 && ablate == 2) { alpha = 1e-3; beta = 0.5; }
     if (k >= 0 && ablate != 2) {
-        block_sum2(gs, ds, lds);
+        if (!gd_tot) block_sum2(gs, ds, lds);
         const double gamma = gs, delta = ds;
         const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
         const bool first = (blockIdx.x == 0 && t == 0);
@@ -934,7 +949,7 @@ __global__ __launch_bounds__(PS_CG_THREADS) void k_cg_fused(
         if (lane < D) {
             double wn = 0.0;
 #pragma unroll
-            for (int ww = 0; ww < PS_CG_WAVES; ++ww) wn += part[ww][lane];
+            for (int ww = 0; ww < NW; ++ww) wn += part[ww][lane];
             const size_t i = (size_t)row * D + lane;
             const double sn = wi + beta * si;
             const double pn = ri + beta * pi;
