@@ -49,7 +49,7 @@ typedef struct ps_problem_desc {
     const int32_t* obs_point;
     const double*  obs_uvd;      /* (num_obs, 3)                                              */
     const int32_t* obs_grp;      /* row of obs_groups                                         */
-    int32_t num_cams;       const double* cams;        /* (num_cams, 5) cu cv fu fv b         */
+    int32_t num_cams;       const double* cams;        /* (num_cams, 5) cu cv fu fv b  (b = -1: RGB-D camera, third coordinate is z) */
     int32_t num_stiff3;     const double* stiff3;      /* (num_stiff3, 9) 3x3 row-major       */
     int32_t num_obs_groups; const double* obs_groups;  /* (n, 4) cam, stiff, loss id, loss k  */
 

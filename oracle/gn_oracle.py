@@ -235,8 +235,10 @@ def eval_reproj(lp, jac=True):
     cam = lp.cams[g[:, 0].astype(int)]
     S = lp.stiff3[g[:, 1].astype(int)].reshape(-1, 3, 3)
     cu, cv, fu, fv, b = cam.T
+    rgbd = b < 0                       # RGB-D rows (reference sensors/rgbd_camera.py:96-135): third coordinate is z
     iz = 1. / pc[:, 2]
-    uvd = np.stack([fu * pc[:, 0] * iz + cu, fv * pc[:, 1] * iz + cv, fu * b * iz], axis=1)
+    uvd = np.stack([fu * pc[:, 0] * iz + cu, fv * pc[:, 1] * iz + cv,
+                    np.where(rgbd, pc[:, 2], fu * b * iz)], axis=1)
     r = np.einsum('nij,nj->ni', S, uvd - lp.obs_uvd)
     if not jac:
         return r
@@ -246,7 +248,7 @@ def eval_reproj(lp, jac=True):
     Jc[:, 0, 2] = -fu * pc[:, 0] * iz2
     Jc[:, 1, 1] = fv * iz
     Jc[:, 1, 2] = -fv * pc[:, 1] * iz2
-    Jc[:, 2, 2] = -fu * b * iz2
+    Jc[:, 2, 2] = np.where(rgbd, 1., -fu * b * iz2)
     odot = np.zeros((pc.shape[0], 3, 6))
     odot[:, :, :3] = np.identity(3)
     odot[:, :, 3:] = wedge3(-pc)

@@ -705,7 +705,9 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         if (cam < 0 || cam >= d->num_cams || st < 0 || st >= d->num_stiff3) return fail("obs group index out of range");
         const double* c = d->cams + 5 * cam;
         ObsGroup& o = og[gi];
-        o.cu = c[0]; o.cv = c[1]; o.fu = c[2]; o.fv = c[3]; o.b = c[4];
+        o.cu = c[0]; o.cv = c[1]; o.fu = c[2]; o.fv = c[3];
+        o.cam_type = c[4] < 0.0 ? 1 : 0;            // cams row: baseline b >= 0 = stereo, b = -1 = RGB-D
+        o.b = o.cam_type ? 0.0 : c[4];
         for (int k = 0; k < 9; ++k) o.S[k] = d->stiff3[9 * st + k];
         o.loss_id = (int)row[2]; o.loss_k = row[3];
     }

@@ -271,7 +271,9 @@ template <> struct PoseOps<3> {
 //   J_pose = S Jc [I | -pc^]  (3x6),  J_point = S Jc R  (3x3)
 // followed by element-wise IRLS scaling (pyslam/problem.py:351-360).
 // ---------------------------------------------------------------------------
-struct ObsGroup { double cu, cv, fu, fv, b; double S[9]; int loss_id; double loss_k; };
+// cam_type: 0 = stereo (u, v, d = fu b / z), 1 = RGB-D (u, v, z)  -- reference
+// pyslam/sensors/stereo_camera.py:100-134 and rgbd_camera.py:96-135
+struct ObsGroup { double cu, cv, fu, fv, b; double S[9]; int loss_id; int cam_type; double loss_k; };
 
 struct ReprojEval {
     double r[3];        // sqrt(w) * r
@@ -288,7 +290,8 @@ PS_DEV void reproj_eval(const Se3& T, const double* __restrict__ pw, const doubl
     const double iz = 1.0 / pc[2];
     const double e0 = g.fu * pc[0] * iz + g.cu - uvd[0];
     const double e1 = g.fv * pc[1] * iz + g.cv - uvd[1];
-    const double e2 = g.fu * g.b * iz - uvd[2];
+    const bool rgbd = g.cam_type == 1;
+    const double e2 = (rgbd ? pc[2] : g.fu * g.b * iz) - uvd[2];
     double s[3];
     o.cost = 0.0;
 #pragma unroll
@@ -302,7 +305,7 @@ PS_DEV void reproj_eval(const Se3& T, const double* __restrict__ pw, const doubl
     const double iz2 = iz * iz;
     const double j00 = g.fu * iz, j02 = -g.fu * pc[0] * iz2;
     const double j11 = g.fv * iz, j12 = -g.fv * pc[1] * iz2;
-    const double j22 = -g.fu * g.b * iz2;
+    const double j22 = rgbd ? 1.0 : -g.fu * g.b * iz2;
     double SJ[9];                       // diag(s) * S * Jc
 #pragma unroll
     for (int i = 0; i < 3; ++i) {

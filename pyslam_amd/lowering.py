@@ -280,7 +280,7 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
         lid, lk = _loss_id_k(loss)   # cheap attribute reads
         if kind in ('reproj', 'reproj_motion_only', 'reproj_motion_only_batch'):
             cam = block.camera
-            if getattr(cam, 'CAMERA_ID', None) != 0:
+            if getattr(cam, 'CAMERA_ID', None) not in (0, 1):
                 raise NotLowerable("camera {} has no device restatement".format(type(cam).__name__))
             if dof != 6 or keys[0] not in pose_ix:
                 raise NotLowerable("reprojection block needs an SE(3) pose first")

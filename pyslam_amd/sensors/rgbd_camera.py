@@ -1,7 +1,8 @@
 """Pinhole RGB-D camera: (x,y,z) <-> (u,v,z).
 
 Public surface of reference pyslam/sensors/rgbd_camera.py:7-86 (SURVEY.md
-section 8f rank 2, "next"); host-side only in this round.
+section 8f rank 2); the device restatement shares the stereo reprojection
+kernels (csrc/ps_math.h, cam_type = 1).
 """
 import numpy as np
 
@@ -18,6 +19,10 @@ class RGBDCamera:
         self.fv = float(fv)
         self.w = int(w)
         self.h = int(h)
+
+    def intrinsics(self):
+        """(cu, cv, fu, fv, -1): the device camera table marks RGB-D rows with b = -1."""
+        return np.array([self.cu, self.cv, self.fu, self.fv, -1.0])
 
     def clone(self):
         return self.__class__(self.cu, self.cv, self.fu, self.fv, self.w, self.h)

@@ -254,3 +254,50 @@ def test_motion_only_batch_block_through_the_problem_api():
     assert np.allclose(problem._cost_history, ref, rtol=1e-7)
     assert np.abs(pack_pose(out['T_2_1']) - g['final_poses'][0]).max() < 1e-8
     assert problem.summary() == str(g['summary_brief'])
+
+
+def test_rgbd_camera_reprojection_blocks():
+    """RGBDCamera (u, v, z) through the same reprojection kernels.
+    Host evaluate() vs the oracle vs the device, then a full solve to the ground truth."""
+    from liegroups import SE3
+    from pyslam.problem import Options, Problem
+    from pyslam.sensors import RGBDCamera
+    from pyslam.residuals import ReprojectionResidual
+    rng = np.random.default_rng(3)
+    cam = RGBDCamera(320., 240., 500., 480., 640, 480)
+    pts = np.stack([rng.uniform(-2, 2, 30), rng.uniform(-1.5, 1.5, 30), rng.uniform(3, 9, 30)], 1)
+    Ts = [SE3.exp(s * np.array([0.3, -0.1, 0.2, 0.02, 0.05, -0.03])) for s in range(4)]
+    S = np.diag([1., 1., 20.])
+    opt = Options()
+    opt.allow_nondecreasing_steps, opt.max_nondecreasing_steps = True, 3
+    problem = Problem(opt)
+    for i, T in enumerate(Ts):
+        for j, p in enumerate(pts):
+            problem.add_residual_block(ReprojectionResidual(cam, cam.project(T.dot(p)), S),
+                                       ['T{}'.format(i), 'p{}'.format(j)])
+    init = {'p{}'.format(j): p + 0.05 * rng.standard_normal(3) for j, p in enumerate(pts)}
+    init.update({'T{}'.format(i): SE3.exp(0.02 * rng.standard_normal(6)).dot(T) for i, T in enumerate(Ts)})
+    init['T0'] = Ts[0]
+    problem.initialize_params(init)
+    problem.set_parameters_constant('T0')
+    lp = problem._lower()
+    assert lp.cams[0, 4] == -1.0
+    # host blocks == oracle blocks
+    r_o, Jp_o, Jl_o = orc.eval_reproj(lp)
+    r_h, J_h = problem.residual_blocks[37].evaluate(
+        [problem.param_dict[k] for k in problem.block_param_keys[37]], [True, True])
+    assert np.allclose(r_h, r_o[37], rtol=1e-12, atol=1e-12) and np.allclose(J_h[0], Jp_o[37], rtol=1e-12)
+    assert np.allclose(J_h[1], Jl_o[37], rtol=1e-12)
+    # device blocks == oracle blocks
+    dev = device(lp)
+    r, jp, jl = dev.debug_reproj_blocks()
+    assert rel_err(r, r_o) < TOL_BLOCK and rel_err(jp, Jp_o) < TOL_BLOCK and rel_err(jl, Jl_o) < TOL_BLOCK
+    dev.linearize(0.)
+    S_d, g_d = dev.reduced_dense()
+    So, go, _ = oracle_reduced(lp)
+    assert rel_err(S_d, So) < 1e-11 and rel_err(g_d, go) < 1e-11
+    out = problem.solve()
+    for i, T in enumerate(Ts):
+        assert np.linalg.norm(SE3.log(out['T{}'.format(i)].inv().dot(T))) < 1e-6
+    for j, p in enumerate(pts):
+        assert np.linalg.norm(out['p{}'.format(j)] - p) < 1e-6
