@@ -16,7 +16,9 @@ the initial parameters), so all K steps do identical work.
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling --
 every rank owns its own 50 000 landmarks / 500 000 observations over the SAME
 200 keyframes; the reduced pose system [S | g | cost] is summed with one RCCL
-all-reduce per iteration and then solved redundantly on every rank.
+all-reduce per iteration (issued by the HIP core itself on the solver's stream)
+and then solved redundantly on every rank; a second 2-double all-reduce sums
+the shards' cost and landmark step norm.
 
 Prints ONE JSON line (rank 0).
 """
@@ -200,6 +202,7 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
+        dev.close()
         dist.destroy_process_group()
 
 

@@ -158,6 +158,21 @@ int ps_gn_solve_finish(ps_problem* h, double pcg_tol, int pcg_max_iters, int lin
                        double* dx_pose_norm2, double* dx_point_norm2, int* pcg_iters_out,
                        double* pcg_relres_out);
 
+/* Fully asynchronous variant for the multi-GPU driver: ps_gn_solve_finish_enqueue enqueues the
+   reduced solve and the (convergence-gated) tail and leaves this shard's {cost, ||dx_point||^2}
+   in the 2-double device buffer of ps_shard_buffer; the caller all-reduces that buffer on the
+   same stream and calls ps_gn_result (the only synchronisation).  If *done == 0 the CG needed
+   more launches: call enqueue again with first = 0 (it returns 1 on the final, ungated pass). */
+int ps_shard_buffer(ps_problem* h, void** dev_ptr);
+
+/* Native collective: hand the core RCCL's ncclAllReduce entry point and an ncclComm_t (created by
+   the binding, one rank per GPU).  ps_gn_iteration then runs the whole landmark-sharded iteration
+   -- both all-reduces included -- on the handle's stream with a single host synchronisation. */
+int ps_set_collective(ps_problem* h, void* nccl_all_reduce_fn, void* nccl_comm);
+int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters, int linesearch, int first);
+int ps_gn_result(ps_problem* h, int* done, double* shard2, double* dx_pose_norm2,
+                 int* pcg_iters_out, double* pcg_relres_out);
+
 /* Parity / debug taps (device -> host). */
 int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx,
                           double* vals, double* g);       /* BSR, dof x dof blocks */

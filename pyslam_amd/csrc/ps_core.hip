@@ -106,6 +106,12 @@ struct ps_problem {
     double *cost_partials = nullptr, *scalars = nullptr, *h_scalars = nullptr;
     int32_t *status = nullptr, *h_status = nullptr;
     int ncost_obs = 0, ncost_fac = 0, nsq = 0;
+    // native RCCL: function pointer + communicator handed over by the binding (ps_set_collective)
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    allreduce_fn nccl_allreduce = nullptr;
+    void* nccl_comm = nullptr;
+    double* shard_buf = nullptr;    // {cost, ||dx_point||^2} of this landmark shard, for the caller's all-reduce
+    bool shard_out = false;         // k_reduce3 writes cost / ||dx_point||^2 there instead of into scalars
     double *sq_part_l = nullptr, *sq_part_p = nullptr;   // per-workgroup partials of ||dx_point||^2, ||dx_pose||^2
     int nsq_l = 0, nsq_p = 0;
     // profiling
@@ -564,10 +570,12 @@ int gn_tail(ps_problem* h, int linesearch, const int32_t* gate) {
     if (!linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 0, gate); }
     if (apply_update(h, 1.0, gate, true)) return -1;
     if (linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 1, gate); }
+    double* o_cost = h->shard_out ? h->shard_buf : h->scalars + (linesearch ? SC_COST : SC_LINCOST);
+    double* o_dxl = h->shard_out ? h->shard_buf + 1 : h->scalars + SC_DXL2;
     hipLaunchKernelGGL(k_reduce3, dim3(3), dim3(256), 0, h->stream,
-                       ncost, h->cost_partials, h->scalars + (linesearch ? SC_COST : SC_LINCOST),
+                       ncost, h->cost_partials, o_cost,
                        h->nsq_p, h->sq_part_p, h->nr > 0 ? h->scalars + SC_DXP2 : nullptr,
-                       h->nsq_l, h->sq_part_l, h->nv > 0 ? h->scalars + SC_DXL2 : nullptr, gate);
+                       h->nsq_l, h->sq_part_l, (h->nv > 0 || h->shard_out) ? o_dxl : nullptr, gate);
     return 0;
 }
 
@@ -957,7 +965,9 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
     h->nsq_l = nv > 0 ? cdiv(nv, 256 / PS_LM_GROUP) : 0;
     h->nsq_p = nr > 0 ? cdiv(P, 256) : 0;
-    if (h->alloc(&h->sq_part_l, (size_t)h->nsq_l) || h->alloc(&h->sq_part_p, (size_t)h->nsq_p)) return -1;
+    if (h->alloc(&h->sq_part_l, (size_t)h->nsq_l) || h->alloc(&h->sq_part_p, (size_t)h->nsq_p) ||
+        h->alloc(&h->shard_buf, 2)) return -1;
+    HIP_OK(hipMemsetAsync(h->shard_buf, 0, 2 * sizeof(double), h->stream));
     HIP_OK(hipHostMalloc((void**)&h->h_scalars, SC_NWORDS * sizeof(double)));
     HIP_OK(hipHostMalloc((void**)&h->h_status, ST_NWORDS * sizeof(int32_t)));
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -1095,9 +1105,83 @@ int ps_gn_solve_finish(ps_problem* h, double pcg_tol, int pcg_max_iters, int lin
     return 0;
 }
 
+int ps_set_collective(ps_problem* h, void* nccl_all_reduce_fn, void* nccl_comm) {
+    if (!h) return fail("null argument");
+    h->nccl_allreduce = (ps_problem::allreduce_fn)nccl_all_reduce_fn;
+    h->nccl_comm = nccl_comm;
+    return 0;
+}
+
+int ps_shard_buffer(ps_problem* h, void** dev_ptr) {
+    if (!h || !dev_ptr) return fail("null argument");
+    *dev_ptr = h->shard_buf;
+    return 0;
+}
+
+// Sharded second half WITHOUT a host synchronisation: (first != 0: CG setup,) CG launches, gated
+// tail; cost and ||dx_point||^2 of this shard land in ps_shard_buffer for the caller's all-reduce.
+// Returns 1 when this was the last, ungated pass (max_iters exhausted), else 0.
+int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters, int linesearch, int first) {
+    if (!h) return fail("null argument");
+    if (h->nr == 0 || h->pcg_variant != 1) return fail("ps_gn_solve_finish_enqueue needs the fused CG and a reduced system");
+    h->shard_out = true;
+    struct Reset { ps_problem* h; ~Reset() { h->shard_out = false; } } reset{h};
+    if (first) {
+        HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
+        if (h->D == 6 ? cg_fused_setup<6>(h, pcg_max_iters) : cg_fused_setup<3>(h, pcg_max_iters)) return -1;
+    }
+    int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + 4 : 16) : std::max(8, h->cg_launched / 2);
+    count = std::min(count, pcg_max_iters + 2 - h->cg_launched);
+    const bool last = count <= 0;
+    if (h->D == 6) { if (!last) cg_fused_launch<6>(h, pcg_tol, count); cg_fused_recover<6>(h, last ? nullptr : h->status); }
+    else { if (!last) cg_fused_launch<3>(h, pcg_tol, count); cg_fused_recover<3>(h, last ? nullptr : h->status); }
+    if (gn_tail(h, linesearch, last ? nullptr : h->status)) return -1;
+    return last ? 1 : 0;
+}
+
+// Synchronise and read back: done flag, the (all-reduced) shard buffer, ||dx_pose||^2, CG statistics.
+int ps_gn_result(ps_problem* h, int* done, double* shard2 /* [2] */, double* dx_pose_norm2,
+                 int* pcg_iters_out, double* pcg_relres_out) {
+    if (!h) return fail("null argument");
+    double sb[2] = {0.0, 0.0};
+    HIP_OK(hipMemcpyAsync(sb, h->shard_buf, sizeof(sb), hipMemcpyDeviceToHost, h->stream));
+    if (read_scalars(h)) return -1;
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (done) *done = h->h_status[ST_PCG_DONE];
+    if (shard2) { shard2[0] = sb[0]; shard2[1] = sb[1]; }
+    if (dx_pose_norm2) *dx_pose_norm2 = h->h_scalars[SC_DXP2];
+    return cg_report(h, pcg_iters_out, pcg_relres_out);
+}
+
 int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters, int linesearch,
                     double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out) {
     if (!h) return fail("null argument");
+    if (h->nccl_allreduce && h->nccl_comm) {
+        // landmark-sharded iteration, everything on the solver's stream in ONE call:
+        // linearize -> RCCL sum of [S | g | cost] -> replicated CG + gated shard-local tail ->
+        // RCCL sum of {cost, ||dx_point||^2} -> one synchronisation
+        if (h->nr == 0 || h->pcg_variant != 1) return fail("the sharded iteration needs the fused CG and a reduced system");
+        enum { NCCL_F64 = 8, NCCL_SUM = 0 };
+        StageTimer total(h, PS_ST_TOTAL, 1);
+        if (linearize(h, lambda)) return -1;
+        if (h->nccl_allreduce(h->red, h->red, (size_t)h->red_count, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
+            return fail("ncclAllReduce of the reduced system failed");
+        int first = 1, done = 0;
+        double sb[2] = {0.0, 0.0}, dxp2 = 0.0;
+        for (;;) {
+            const int last = ps_gn_solve_finish_enqueue(h, pcg_tol, pcg_max_iters, linesearch, first);
+            if (last < 0) return -1;
+            if (h->nccl_allreduce(h->shard_buf, h->shard_buf, 2, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
+                return fail("ncclAllReduce of the shard scalars failed");
+            total.stop();
+            if (ps_gn_result(h, &done, sb, &dxp2, pcg_iters_out, pcg_relres_out)) return -1;
+            if (done || last) break;
+            first = 0;
+        }
+        if (cost_out) *cost_out = sb[0];
+        if (dx_norm_out) *dx_norm_out = std::sqrt(dxp2 + sb[1]);
+        return 0;
+    }
     {
         StageTimer total(h, PS_ST_TOTAL, 1);  // closed before the last synchronising read-back
         if (linearize(h, lambda)) return -1;

@@ -89,6 +89,29 @@ class DeviceProblem:
                                                C.byref(a), C.byref(b), C.byref(it), C.byref(rel)))
         return c.value, a.value, b.value, it.value, rel.value
 
+    def set_collective(self, allreduce_fn_ptr, comm_ptr):
+        """Native RCCL: ps_gn_iteration then performs the sharded iteration incl. both all-reduces."""
+        nat.check(self._lib.ps_set_collective(self._h, C.c_void_p(allreduce_fn_ptr), C.c_void_p(comm_ptr)))
+
+    def shard_buffer(self):
+        ptr = C.c_void_p()
+        nat.check(self._lib.ps_shard_buffer(self._h, C.byref(ptr)))
+        return ptr.value
+
+    def gn_solve_finish_enqueue(self, pcg_tol, pcg_max_iters, linesearch, first):
+        """No host sync.  Returns True on the final (ungated) pass."""
+        rc = self._lib.ps_gn_solve_finish_enqueue(self._h, pcg_tol, pcg_max_iters, int(linesearch), int(first))
+        if rc < 0:
+            nat.check(rc)
+        return rc == 1
+
+    def gn_result(self):
+        """Sync. -> (done, shard cost sum, shard ||dx_point||^2 sum, ||dx_pose||^2, iterations, relres)."""
+        done, it, rel, dxp2 = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        sb = (C.c_double * 2)()
+        nat.check(self._lib.ps_gn_result(self._h, C.byref(done), sb, C.byref(dxp2), C.byref(it), C.byref(rel)))
+        return done.value != 0, sb[0], sb[1], dxp2.value, it.value, rel.value
+
     def linearize(self, lm_lambda=0.):
         nat.check(self._lib.ps_linearize(self._h, lm_lambda))
 

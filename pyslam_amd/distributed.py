@@ -74,6 +74,42 @@ def pose_pair_keys(lp):
     return np.unique(np.concatenate(keys)) if keys else np.zeros(0, np.int64)
 
 
+class NativeRccl:
+    """An ncclComm_t of our own (one rank per process) created through ctypes on the RCCL that
+    PyTorch already loaded; the unique id travels over the existing torch.distributed group.
+    The HIP core calls ncclAllReduce itself, on the solver's stream (ps_set_collective)."""
+
+    class _UniqueId(__import__('ctypes').Structure):
+        _fields_ = [('internal', __import__('ctypes').c_ubyte * 128)]   # c_char would truncate at NUL
+
+    def __init__(self, dist):
+        import ctypes as C
+        import os
+        import torch
+        path = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        self.lib = C.CDLL(path)
+        uid = self._UniqueId()
+        if dist.get_rank() == 0:
+            rc = self.lib.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise RuntimeError('ncclGetUniqueId failed: {}'.format(rc))
+        box = [bytes(bytearray(uid.internal)) if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        C.memmove(C.byref(uid), box[0], 128)
+        self.comm = C.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, self._UniqueId, C.c_int]
+        rc = self.lib.ncclCommInitRank(C.byref(self.comm), dist.get_world_size(), uid, dist.get_rank())
+        if rc != 0:
+            raise RuntimeError('ncclCommInitRank failed: {}'.format(rc))
+        self.allreduce_ptr = C.cast(self.lib.ncclAllReduce, C.c_void_p).value
+
+    def close(self):
+        if getattr(self, 'comm', None):
+            self.lib.ncclCommDestroy.argtypes = [__import__('ctypes').c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
 class _RawDeviceArray:
     """Zero-copy view of a device pointer for torch.as_tensor (CUDA array interface)."""
 
@@ -88,13 +124,14 @@ def _default_device_factory(lp, extra_pairs):
     dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream, extra_pairs=extra_pairs)
     ptr, n = dev.reduce_buffer()
     dev.reduce_tensor = torch.as_tensor(_RawDeviceArray(ptr, n), device='cuda')
+    dev.shard_tensor = torch.as_tensor(_RawDeviceArray(dev.shard_buffer(), 2), device='cuda')
     return dev
 
 
 class ShardedDeviceProblem:
     """Same surface as DeviceProblem for the pieces Problem.solve / bench.py use."""
 
-    def __init__(self, lp_shard, dist, device_factory=None):
+    def __init__(self, lp_shard, dist, device_factory=None, native_rccl=True):
         import torch
         self._torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -108,6 +145,15 @@ class ShardedDeviceProblem:
         self.dev = (device_factory or _default_device_factory)(lp_shard, pairs)
         self.lp = lp_shard
         self.info = dict(self.dev.info)
+        # GPU: let the HIP core drive RCCL itself (one ABI call + one sync per iteration)
+        self.native = None
+        if device_factory is None and native_rccl:
+            try:
+                self.native = NativeRccl(dist)
+                self.dev.set_collective(self.native.allreduce_ptr, self.native.comm.value)
+            except Exception as e:                       # fall back to torch.distributed collectives
+                print('pyslam_amd: native RCCL unavailable ({}); using torch.distributed'.format(e))
+                self.native = None
         self._scal = torch.zeros(2, dtype=torch.float64, device=self.dev.reduce_tensor.device)
 
     # ---- iteration -----------------------------------------------------
@@ -118,8 +164,21 @@ class ShardedDeviceProblem:
         return float(self._scal[0])
 
     def gn_iteration(self, lm_lambda=0., pcg_tol=1e-12, pcg_max_iters=1000, linesearch=True):
+        if self.native is not None:
+            return self.dev.gn_iteration(lm_lambda, pcg_tol, pcg_max_iters, linesearch)
         self.dev.linearize(lm_lambda)
         self.dist.all_reduce(self.dev.reduce_tensor)          # RCCL sum over xGMI, on the solver's stream
+        if hasattr(self.dev, 'shard_tensor'):
+            # fully asynchronous second half: the shard's {cost, ||dx_l||^2} are all-reduced on the
+            # device; ONE synchronisation per iteration (gn_result)
+            first = True
+            while True:
+                last = self.dev.gn_solve_finish_enqueue(pcg_tol, pcg_max_iters, linesearch, first)
+                self.dist.all_reduce(self.dev.shard_tensor)
+                done, cost, dxl2, dxp2, its, rel = self.dev.gn_result()
+                if done or last:
+                    return cost, float(np.sqrt(dxp2 + dxl2)), its, rel
+                first = False
         cost, dxp2, dxl2, its, rel = self.dev.gn_solve_finish(pcg_tol, pcg_max_iters, linesearch)
         self._scal.copy_(self._torch.tensor([cost, dxl2], dtype=self._torch.float64), non_blocking=True)
         self.dist.all_reduce(self._scal)
@@ -144,3 +203,5 @@ class ShardedDeviceProblem:
 
     def close(self):
         self.dev.close()
+        if self.native is not None:
+            self.native.close()
