@@ -95,11 +95,15 @@ struct ps_problem {
     size_t cg_cap = 0, saug_cap = 0; // CG vectors / matrix are allocated for this many block rows / blocks
     int32_t *pnode = nullptr, *slo = nullptr, *shi = nullptr, *run_lo = nullptr, *run_hi = nullptr,
             *arow_ptr = nullptr, *acol_idx = nullptr, *aug_slot = nullptr, *fine_nnz = nullptr;
-    double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr;
+    double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr, *chol_scratch = nullptr;
     bool coarse_built = false;
     int cg_ablate = 0;
     bool cg_two_level_reduce = false, cg_short_rows = false;
     double* cg_tot = nullptr;
+    // split mode (large systems): coarse rows are owned by k_cg_reduce_split
+    bool cg_split = false;
+    int cg_split_min_rows = 1024;
+    double *cg_U = nullptr, *cg_cgd[2] = {}, *cg_ab = nullptr;
     int cg_launched = 0;            // CG launches enqueued since the last setup
     int ell_wf = 0, ell_wc = 0;     // two-class ELL widths of the CG matrix (0 = CSR)
     // scalars
@@ -278,14 +282,18 @@ int ensure_cg_buffers(ps_problem* h, int rows, int blocks) {
 int build_coarse(ps_problem* h) {
     const int nr = h->nr, D = h->D;
     int G = h->coarse_req;
-    const int Gmax = (D == 6) ? 15 : 31;           // nc = (G + 1) D <= 96: L_c and L_c^-1 both LDS-resident
-    // auto: on from 48 reduced poses; off beyond 4096 (the dense border rows K^T are handled by one
-    // workgroup each and would dominate the iteration -- a scalable coarse level is future work)
-    if (G < 0) G = (nr >= 48 && nr <= 4096) ? std::min(12, std::max(3, (nr + 9) / 18)) : 0;
+    const int Gmax = 63;                           // nc = (G + 1) D <= 384; LDS-resident factorisation up to nc = 96
+    // auto: on from 48 reduced poses, ~18 poses per hat interval, at most 12 intervals while the
+    // coarse factorisation is LDS-resident; large systems (split mode, no dense border rows) take 24
+    if (G < 0) {
+        if (nr < 48) G = 0;
+        else if (nr > h->cg_split_min_rows) G = ((long)h->nnzb > 24L * nr) ? 24 : 0;   // not for long, sparse chains
+        else G = std::min(12, std::max(3, (nr + 9) / 18));
+    }
     G = std::min(G, Gmax);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
     if (G < 1) G = 0;
-    h->G = G; h->coarse_built = true;
+    h->G = G; h->coarse_built = true; h->cg_split = false;
     const std::vector<int32_t>& rp = h->h_row_ptr;
     const std::vector<int32_t>& ci = h->h_col_idx;
     int maxlen = 0;
@@ -334,10 +342,17 @@ int build_coarse(ps_problem* h) {
         if (ell) while ((int)aci.size() < (i + 1) * wf) aci.push_back(0);     // zero-valued padding blocks
         arp[i + 1] = (int32_t)aci.size();
     }
-    for (int q = 0; q < ncb; ++q) {
+    const bool split = nr > h->cg_split_min_rows;      // big systems: no dense K^T rows in the matrix
+    h->cg_split = split;
+    for (int q = 0; q < ncb && !split; ++q) {
         for (int i = 0; i < nr; ++i) aci.push_back(i);
         aci.push_back(nr + q);
         arp[nr + q + 1] = (int32_t)aci.size();
+    }
+    if (split) {
+        arp.resize(nr + 1);
+        if (h->alloc(&h->cg_U, (size_t)ncb * nr * D) || h->alloc(&h->cg_cgd[0], 2 * (size_t)ncb) ||
+            h->alloc(&h->cg_cgd[1], 2 * (size_t)ncb) || h->alloc(&h->cg_ab, 2)) return -1;
     }
     // contiguous run of augmented-matrix blocks of fine row i whose column lies in supp(q)
     std::vector<int32_t> rlo((size_t)nr * ncb), rhi((size_t)nr * ncb);
@@ -355,7 +370,7 @@ int build_coarse(ps_problem* h) {
         h->upload(&h->aug_slot, slot) || h->upload(&h->fine_nnz, fnz)) return -1;
     if (h->alloc(&h->SZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci, (size_t)h->nc * h->nc) || h->alloc(&h->LciT, (size_t)h->nc * h->nc) ||
-        h->alloc(&h->tvec, (size_t)h->nc)) return -1;
+        h->alloc(&h->tvec, (size_t)h->nc) || h->alloc(&h->chol_scratch, 2 * (size_t)h->nc * h->nc)) return -1;
     if (ensure_cg_buffers(h, h->nr_aug, h->nnzb_aug)) return -1;
     HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)h->nnzb_aug * D * D * sizeof(double), h->stream));
     return 0;
@@ -366,7 +381,7 @@ int cg_fused_setup(ps_problem* h, int max_iters) {
     const int nr = h->nr, cap = h->hist_cap;
     if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
     if (!h->coarse_built && build_coarse(h)) return -1;
-    h->cg_two_level_reduce = h->nr_aug > 2048;
+    h->cg_two_level_reduce = h->nr_aug > 2048 || h->cg_split;
     h->cg_short_rows = (long)h->nnzb_aug <= 24L * h->nr_aug;       // pose-graph-like rows: one wave per row
     const int G = h->G, rows = h->nr_aug;
     const int32_t* rp = h->arow_ptr;
@@ -383,15 +398,21 @@ int cg_fused_setup(ps_problem* h, int max_iters) {
                            h->acol_idx, h->pnode, h->pw0, h->pw1, h->Saug, h->SZ);
         hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
                            nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->SZ, h->Ac);
-        HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(2 * (size_t)nc * nc * sizeof(double))));
-        hipLaunchKernelGGL(k_coarse_chol<D>, dim3(1), dim3(1024), 2 * (size_t)nc * nc * sizeof(double), h->stream,
-                           ncb, h->Ac, h->Lci, h->LciT, h->status);
+        if (nc <= 96) {
+            const size_t chol_lds = 2 * (size_t)nc * nc * sizeof(double);
+            HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)chol_lds));
+            hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, h->stream, ncb, h->Ac, h->Lci,
+                               h->LciT, h->status, nullptr);
+        } else {
+            hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, h->stream, ncb, h->Ac, h->Lci,
+                               h->LciT, h->status, h->chol_scratch);
+        }
         hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr), dim3(256), (size_t)D * nc * sizeof(double), h->stream,
-                           nr, ncb, h->SZ, h->Lci, h->arow_ptr, h->fine_nnz, h->Saug);
+                           nr, ncb, h->SZ, h->Lci, h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1);
         hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
                            h->pw0, h->pw1, h->LciT, h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
-                           h->cg_s[0], h->cg_p, h->cg_xh);
+                           h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1);
     }
     h->cg_launched = 0;
     return 0;
@@ -400,21 +421,30 @@ int cg_fused_setup(ps_problem* h, int max_iters) {
 // enqueue `count` more CG launches (launch n runs iteration k = n - 1; converged launches exit at once)
 template <int D>
 void cg_fused_launch(ps_problem* h, double tol, int count) {
-    const int rows = h->nr_aug, cap = h->hist_cap;
+    const int cap = h->hist_cap;
+    const int rows = h->cg_split ? h->nr : h->nr_aug;      // matrix rows handled by k_cg_fused
+    const int ncbs = h->cg_split ? h->ncb : 0;
     const double tol2 = tol * tol;
     for (int i = 0; i < count; ++i, ++h->cg_launched) {
         const int n = h->cg_launched, o = n & 1, nw = o ^ 1;
-        // large systems: totals of the previous launch's partials come from k_cg_reduce
+        // large systems: totals of the previous launch's partials come from a reduce launch
         const double* tot = h->cg_two_level_reduce ? h->cg_tot : nullptr;
-        if (tot && n > 0)
+        if (tot && !h->cg_split && n > 0)
             hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(1024), 0, h->stream, rows, h->cg_gd[o], h->cg_tot, h->status);
 #define PS_CG_LAUNCH(NWV)                                                                                          \
         hipLaunchKernelGGL((k_cg_fused<D, NWV>), dim3(rows), dim3(64 * NWV), 0, h->stream, rows, h->arow_ptr,           \
                            h->acol_idx, h->Saug, h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw],        \
                            h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,      \
-                           h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc, h->cg_ablate, tot)
-        if (h->cg_short_rows) { PS_CG_LAUNCH(1); } else { PS_CG_LAUNCH(8); }
+                           h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc, h->cg_ablate, tot, ncbs,              \
+                           h->fine_nnz, h->cg_cgd[o], h->cg_U, h->cg_ab)
+        if (h->cg_short_rows) { PS_CG_LAUNCH(1); }
+        else if (rows > 1024) { PS_CG_LAUNCH(4); }      // many rows: smaller workgroups, more of them in flight
+        else { PS_CG_LAUNCH(8); }
 #undef PS_CG_LAUNCH
+        if (h->cg_split)      // fine totals + the coarse rows of this iteration
+            hipLaunchKernelGGL(k_cg_reduce_split<D>, dim3(1 + h->ncb), dim3(1024), 0, h->stream, rows, h->ncb,
+                               h->cg_gd[nw], h->cg_tot, h->cg_U, h->cg_ab, h->cg_r[o], h->cg_w[o], h->cg_s[o],
+                               h->cg_r[nw], h->cg_w[nw], h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_cgd[nw], h->status);
     }
 }
 
@@ -1256,6 +1286,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
         h->coarse_req = (int)value; h->coarse_built = false;
     }
     else if (n == "cg_ablate") h->cg_ablate = (int)value;
+    else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }
     else return fail("unknown option: " + n);
     return 0;

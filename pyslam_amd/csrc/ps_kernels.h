@@ -846,6 +846,76 @@ __global__ __launch_bounds__(1024) void k_cg_reduce(int nr, const double* __rest
     if (threadIdx.x == 0) { tot[0] = a; tot[1] = b; }
 }
 
+// Split mode: workgroup 0 reduces the fine rows' gamma / delta partials; workgroup 1 + q owns coarse
+// block row q of the augmented system [[S^, K], [K^T, I]]:
+//   w_new_c[q] = sum_i U[q][i] + r_new_c[q],  then the same vector recurrences as a fine row.
+template <int D>
+__global__ __launch_bounds__(1024) void k_cg_reduce_split(
+    int nr, int ncb, const double* __restrict__ gd, double* __restrict__ tot,
+    const double* __restrict__ U, const double* __restrict__ ab,
+    const double* __restrict__ r_old, const double* __restrict__ w_old, const double* __restrict__ s_old,
+    double* __restrict__ r_new, double* __restrict__ w_new, double* __restrict__ s_new,
+    double* __restrict__ p, double* __restrict__ x, double* __restrict__ cgd_out /* [2 ncb] */,
+    const int32_t* __restrict__ status)
+{
+    __shared__ double lds[32];
+    __shared__ double wpart[16][8];
+    const int t = threadIdx.x;
+    // independent loads first (this kernel is latency-bound: ~26-64 workgroups on 256 CUs)
+    const int done = status[ST_PCG_DONE];
+    if (blockIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+#pragma unroll 4
+        for (int i = t; i < nr; i += 1024) { a += gd[i]; b += gd[nr + i]; }
+        if (done) return;
+        block_sum2(a, b, lds);
+        if (t == 0) { tot[0] = a; tot[1] = b; }
+        return;
+    }
+    const int q = blockIdx.x - 1;
+    const double alpha = ab[0], beta = ab[1];
+    // sum over i of U[q][i][0..D): flat index e = i*D + c, thread t takes e = t, t + 1024*? ... keep c fixed
+    // per thread: with 1024 = 6*170 + 4 not a multiple of D, use the row mapping: rows t, t+1024, ...
+    double acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0;
+    const double* u = U + (size_t)q * nr * D;
+#pragma unroll 2
+    for (int i = t; i < nr; i += 1024)
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] += u[(size_t)i * D + c];
+    double ri = 0.0, wi = 0.0, si = 0.0, pi = 0.0, xi_ = 0.0;
+    if (t < D) {
+        const size_t i = (size_t)(nr + q) * D + t;
+        ri = r_old[i]; wi = w_old[i]; si = s_old[i]; pi = p[i]; xi_ = x[i];
+    }
+    if (done) return;
+    const int wv = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const double v = wave_sum(acc[c]);
+        if (lane == 0) wpart[wv][c] = v;
+    }
+    __syncthreads();
+    double gp = 0.0, dp = 0.0;
+    if (t < D) {
+        double ws = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ws += wpart[k][t];
+        const size_t i = (size_t)(nr + q) * D + t;
+        const double rn = cg_rnew(ri, wi, si, alpha, beta);
+        const double wn = ws + rn;                         // identity diagonal block
+        const double sn = wi + beta * si;
+        const double pn = ri + beta * pi;
+        s_new[i] = sn; p[i] = pn; x[i] = xi_ + alpha * pn; r_new[i] = rn; w_new[i] = wn;
+        gp = rn * rn; dp = wn * rn;
+    }
+    if (t < 64) {
+        gp = wave_sum(gp); dp = wave_sum(dp);
+        if (t == 0) { cgd_out[q] = gp; cgd_out[ncb + q] = dp; }
+    }
+}
+
 template <int D, int NW /* waves per workgroup: 8 for long rows, 1 for short (pose-graph) rows */>
 __global__ __launch_bounds__(64 * NW) void k_cg_fused(
     int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
@@ -858,7 +928,11 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused(
     int32_t* __restrict__ status, double* __restrict__ scalars,
     int nfine, int wf, int wc /* two-class ELL: fine rows wf blocks wide, the rest wc; wf = 0 => CSR */,
     int ablate /* timing experiments only: 1 skips the SpMV, 2 skips the partial-sum reduction */,
-    const double* __restrict__ gd_tot /* non-null: totals already reduced by k_cg_reduce */)
+    const double* __restrict__ gd_tot /* non-null: totals already reduced by k_cg_reduce */,
+    // split mode (large systems): the matrix holds fine rows only; this kernel also emits
+    // U[q][i] = K_iq^T r_new_i, and k_cg_reduce_split owns the ncb coarse rows
+    int ncb_split, const int32_t* __restrict__ fine_nnz, const double* __restrict__ cgd_in /* [2 ncb] */,
+    double* __restrict__ U, double* __restrict__ ab /* alpha, beta of this launch */)
 {
     __shared__ double lds[32];
     __shared__ double part[NW][8];
@@ -881,9 +955,14 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused(
     const double thresh_in = scalars[SC_THRESH];
     double gs = 0.0, ds = 0.0;
     if (k >= 0 && ablate != 2) {
-        if (gd_tot) { gs = gd_tot[0]; ds = gd_tot[1]; }
+        if (gd_tot) {
+            gs = gd_tot[0]; ds = gd_tot[1];
+            if (ncb_split)                       // + the coarse rows' shares (fixed order, every lane the same)
+                for (int q = 0; q < ncb_split; ++q) { gs += cgd_in[q]; ds += cgd_in[ncb_split + q]; }
+        }
         else for (int i = t; i < nr; i += 64 * NW) { gs += gd_in[i]; ds += gd_in[nr + i]; }
     }
+    const int fnz = ncb_split ? fine_nnz[row] : 0;
     const int kk = lane >> 3, r = lane & 7;
     const int b0 = rbeg + w * 8 + kk;
     constexpr int STRIDE = 8 * NW;
@@ -924,6 +1003,7 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused(
             if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = gamma; }
         }
     }
+    if (ncb_split && blockIdx.x == 0 && t == 0) { ab[0] = alpha; ab[1] = beta; }
     // ---- w_new(row) = S^(row,:) r_new, with r_new recomputed per column block
     double acc = 0.0;
     if (r < D && ablate != 1) {
@@ -937,6 +1017,37 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused(
 #pragma unroll
             for (int c = 0; c < D; ++c)
                 acc += sb[c] * cg_rnew(r_old[j + c], w_old[j + c], s_old[j + c], alpha, beta);
+        }
+    }
+    if (ncb_split) {
+        // transposed border for the coarse rows: U[q][row] = K_iq^T r_new_i.  Lane (group, r) holds
+        // row r of K_iq; the 8-lane group is summed with DPP row shifts (total lands in lane r == 7).
+        double rown = 0.0;
+        if (r < D) {
+            const size_t i = (size_t)row * D + r;
+            rown = cg_rnew(r_old[i], w_old[i], s_old[i], alpha, beta);
+        }
+        for (int q0 = 0; q0 < ncb_split; q0 += STRIDE) {
+            const int q = q0 + w * 8 + kk;
+            double tq[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) tq[c] = 0.0;
+            if (q < ncb_split && r < D) {
+                const double* sb = S + (size_t)(rbeg + fnz + q) * DD + r * D;
+#pragma unroll
+                for (int c = 0; c < D; ++c) tq[c] = sb[c] * rown;
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                tq[c] = dpp_shift_add<0x111, 0xf, 0xf>(tq[c]);
+                tq[c] = dpp_shift_add<0x112, 0xf, 0xf>(tq[c]);
+                tq[c] = dpp_shift_add<0x114, 0xf, 0xf>(tq[c]);
+            }
+            if (q < ncb_split && r == 7) {
+                double* u = U + ((size_t)q * nr + row) * D;
+#pragma unroll
+                for (int c = 0; c < D; ++c) u[c] = tq[c];
+            }
         }
     }
     acc += __shfl_xor(acc, 8, 64);
@@ -1047,17 +1158,21 @@ __global__ __launch_bounds__(256) void k_coarse_matrix(
 // A_c = L_c L_c^T and Li = L_c^-1 by ONE workgroup, blocked by D x D (ncb block steps instead of
 // nc scalar steps), both matrices full row-major in LDS: 2 nc^2 doubles (nc <= 96).
 // Outputs Li and its transpose LiT (row-major, global) so later kernels read either coalesced.
-template <int D>
+template <int D, bool IN_LDS>
 __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __restrict__ A,
                                                        double* __restrict__ Li, double* __restrict__ LiT,
-                                                       int32_t* __restrict__ status)
+                                                       int32_t* __restrict__ status, double* gscratch)
 {
     constexpr int DD = D * D;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int nc = ncb * D;
-    double* sL = sm;                    // nc x nc: A, overwritten by L (lower; upper part unused)
-    double* sX = sm + nc * nc;          // nc x nc: L^-1
-    __shared__ double sDi[32 * 36];     // inverse of every diagonal block of L
+    // both matrices live in LDS when they fit (nc <= 96); larger coarse levels fall back to a
+    // global (L2-resident) scratch -- same code, ~10x slower per step, used for big problems only
+    // (compile-time choice: with a run-time pointer select the compiler falls back to flat
+    // addressing for every access and the LDS path loses ~40 %)
+    double* sL = IN_LDS ? sm : gscratch;                    // nc x nc: A, overwritten by L (lower)
+    double* sX = sL + nc * nc;                              // nc x nc: L^-1
+    __shared__ double sDi[64 * 36];     // inverse of every diagonal block of L
     const int t = threadIdx.x, nt = blockDim.x;
     for (int k = t; k < nc * nc; k += nt) { sL[k] = A[k]; sX[k] = 0.0; }
     for (int J = 0; J < ncb; ++J) {
@@ -1184,7 +1299,8 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
 template <int D>
 __global__ __launch_bounds__(256) void k_coarse_border(
     int nr, int ncb, const double* __restrict__ SZ, const double* __restrict__ Lci,
-    const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ fine_nnz, double* __restrict__ Saug)
+    const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ fine_nnz, double* __restrict__ Saug,
+    int with_coarse_rows)
 {
     constexpr int DD = D * D;
     extern __shared__ __attribute__((aligned(16))) double sT[];     // D x nc
@@ -1202,7 +1318,8 @@ __global__ __launch_bounds__(256) void k_coarse_border(
 #pragma unroll 8
         for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * Lci[(size_t)c * nc + k];
         Saug[(size_t)(row_slot + q) * DD + r * D + cc] = v;                       // K   (row i, col nr+q)
-        Saug[(size_t)(arow_ptr[nr + q] + i) * DD + cc * D + r] = v;               // K^T (row nr+q, col i)
+        if (with_coarse_rows)
+            Saug[(size_t)(arow_ptr[nr + q] + i) * DD + cc * D + r] = v;           // K^T (row nr+q, col i)
     }
 }
 
@@ -1214,7 +1331,7 @@ __global__ __launch_bounds__(1024) void k_coarse_rhs(
     const double* __restrict__ LciT, const int32_t* __restrict__ arow_ptr,
     double* __restrict__ Saug, double* __restrict__ tvec /* nc scratch */,
     double* __restrict__ r /* fine part holds g^ */, double* __restrict__ w, double* __restrict__ s,
-    double* __restrict__ p, double* __restrict__ x)
+    double* __restrict__ p, double* __restrict__ x, int with_coarse_rows)
 {
     constexpr int DD = D * D;
     const int nc = ncb * D;
@@ -1230,12 +1347,13 @@ __global__ __launch_bounds__(1024) void k_coarse_rhs(
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
         if (t < nc && sub == 0) tvec[t] = v;
     }
-    for (int t = threadIdx.x; t < ncb * DD; t += blockDim.x) {
-        const int q = t / DD, e = t % DD;
-        Saug[(size_t)(arow_ptr[nr + q] + nr) * DD + e] = (e / D == e % D) ? 1.0 : 0.0;
-    }
+    if (with_coarse_rows)
+        for (int t = threadIdx.x; t < ncb * DD; t += blockDim.x) {
+            const int q = t / DD, e = t % DD;
+            Saug[(size_t)(arow_ptr[nr + q] + nr) * DD + e] = (e / D == e % D) ? 1.0 : 0.0;
+        }
     __syncthreads();
-    __shared__ double stv[192];
+    __shared__ double stv[400];
     for (int t = threadIdx.x; t < nc; t += blockDim.x) stv[t] = tvec[t];
     __syncthreads();
     for (int base = 0; base < nc; base += blockDim.x / 8) {         // b~_c[t] = sum_{k<=t} Lci[t][k] t_k

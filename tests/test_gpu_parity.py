@@ -95,7 +95,7 @@ def test_reduced_system(name):
     assert np.abs(S - S.T).max() <= 1e-13 * np.abs(S).max()
 
 
-@pytest.mark.parametrize('variant', ['fused_cg', 'fused_cg_two_level', 'classic_pcg'])
+@pytest.mark.parametrize('variant', ['fused_cg', 'fused_cg_two_level', 'fused_cg_two_level_split', 'classic_pcg'])
 @pytest.mark.parametrize('name', SOLVE_CASES)
 def test_first_step_matches_reference_spsolve(name, variant):
     g = load_golden(name)
@@ -105,10 +105,12 @@ def test_first_step_matches_reference_spsolve(name, variant):
     dev.set_option('pcg_variant', 0 if variant == 'classic_pcg' else 1)
     if variant == 'fused_cg':
         dev.set_option('coarse_groups', 0)                 # block-Jacobi only
-    elif variant == 'fused_cg_two_level':
+    elif variant.startswith('fused_cg_two_level'):
         if lp.num_reduced < 4:
             pytest.skip('too few poses for a coarse level')
         dev.set_option('coarse_groups', max(2, min(7, lp.num_reduced // 3)))
+        if variant.endswith('split'):                      # the large-system mode, forced on small problems
+            dev.set_option('cg_split_min_rows', 0)
     dev.linearize(0.)
     # PCG tolerance (preconditioned relative residual).  1e-12 everywhere except the
     # pose graphs: stiffness 1e6 (prior) / 31.6 (odometry) / 1 (loop), long chains => 

@@ -63,10 +63,12 @@ def test_c3_gn_iteration_matches_staged_calls_bitwise(c3):
 
 def test_c3_all_solver_variants_agree(c3):
     ref = None
-    for variant, groups in ((1, -1), (1, 0), (0, 0)):
+    for variant, groups, split in ((1, -1, False), (1, 0, False), (0, 0, False), (1, 24, True)):
         dev = device(c3)
         dev.set_option('pcg_variant', variant)
         dev.set_option('coarse_groups', groups)
+        if split:
+            dev.set_option('cg_split_min_rows', 0)
         dev.linearize(0.)
         its, rel = dev.solve_reduced(1e-13, 3000)
         dev.backsub()
@@ -74,7 +76,7 @@ def test_c3_all_solver_variants_agree(c3):
         if ref is None:
             ref = dx
         else:
-            assert np.linalg.norm(dx - ref) <= 1e-9 * np.linalg.norm(ref), (variant, groups, its, rel)
+            assert np.linalg.norm(dx - ref) <= 1e-9 * np.linalg.norm(ref), (variant, groups, split, its, rel)
 
 
 def test_landmark_shards_sum_to_the_unsharded_reduced_system():

@@ -9,10 +9,11 @@ t = time.time(); lp, _ = synthetic.stereo_ba(kf, lm, 10, 20, seed=1); print('gen
 t = time.time(); dev = DeviceProblem(lp); print('create %.1fs' % (time.time() - t), dev.info)
 for G in ([int(a) for a in sys.argv[3:]] or [-1]):
     dev.set_option('coarse_groups', G)
+    dev.set_params(lp.poses, lp.points)
     dev.snapshot()
     c0 = dev.eval_cost(True)
     for it in range(3):
-        dev.restore(); dev.set_profiling(True); dev.stage_times(reset=True)
+        dev.restore(); dev.set_profiling(2); dev.stage_times(reset=True)
         t = time.time(); out = dev.gn_iteration(0., 1e-12, 3000, True); dt = time.time() - t
         st = {k: round(v[0], 3) for k, v in dev.stage_times(reset=True).items() if v[1]}
     print('G', G, 'cost %.6e -> %.6e' % (c0, out[0]), 'iter %.3f ms' % (dt * 1e3), 'pcg', out[2], 'relres %.1e' % out[3], st)
