@@ -60,9 +60,13 @@ struct ps_problem {
     int32_t* pitem_ptr = nullptr;
     double* ppartial = nullptr;
     int2* pairs = nullptr;
-    PairItem* pair_items = nullptr;
     int npair_items = 0, pair_per_xcd = 0;
-    int32_t* pair_order = nullptr;
+    PairItem* pair_xitems = nullptr;   // work items in per-XCD dispatch order
+    // tiled Schur (Z larger than the L2s): per-task partial blocks + per-block task lists
+    int schur_tiles = 1, ncomb = 0;
+    double* Spart = nullptr;
+    PairItem* comb_items = nullptr;     // slot, slotT, [start, end) into comb_tasks
+    int32_t* comb_tasks = nullptr;
     // factors
     FactorGroup* fgroups = nullptr;
     int32_t *f_i = nullptr, *f_j = nullptr, *f_grp = nullptr;
@@ -97,7 +101,8 @@ struct ps_problem {
             *arow_ptr = nullptr, *acol_idx = nullptr, *aug_slot = nullptr, *fine_nnz = nullptr;
     double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr, *chol_scratch = nullptr;
     bool coarse_built = false;
-    int cg_ablate = 0;
+    int cg_ablate = 0, schur_ablate = 0;
+    int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;
     double* cg_tot = nullptr;
     // split mode (large systems): coarse rows are owned by k_cg_reduce_split
@@ -109,6 +114,8 @@ struct ps_problem {
     // scalars
     double *cost_partials = nullptr, *scalars = nullptr, *h_scalars = nullptr;
     int32_t *status = nullptr, *h_status = nullptr;
+    double* h_scalars_dev = nullptr;     // device-side aliases of the pinned, host-mapped result words
+    int32_t* h_status_dev = nullptr;
     int ncost_obs = 0, ncost_fac = 0, nsq = 0;
     // native RCCL: function pointer + communicator handed over by the binding (ps_set_collective)
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
@@ -205,7 +212,7 @@ int read_scalars(ps_problem* h) {
 }
 
 // ---- structure building ---------------------------------------------------
-struct PairRec { uint64_t key; int32_t a, b; };
+struct PairRec { uint64_t key; int32_t a, b, tile; };
 
 template <int D>
 int launch_factor_pass(ps_problem* h, double lambda) {
@@ -492,8 +499,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
 }
 
 int linearize(ps_problem* h, double lambda) {
-    HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double), h->stream));
-    HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+    HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double) + ST_NWORDS * sizeof(int32_t), h->stream));   // [S | g | cost | status]
     if (h->nv > 0) {
         StageTimer t(h, PS_ST_LANDMARK);
         hipLaunchKernelGGL(k_landmark_pass, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr,
@@ -509,10 +515,11 @@ int linearize(ps_problem* h, double lambda) {
     }
     if (h->npair_items > 0) {
         StageTimer t(h, PS_ST_SCHUR, 1);
-        const size_t lds = 4 * (size_t)PS_SP_LDS_PER_WAVE * sizeof(double);
-        HIP_OK(hipFuncSetAttribute((const void*)k_schur_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), lds, h->stream,
-                           h->pair_per_xcd, h->pair_order, h->pair_items, h->pairs, h->Z, h->S);
+        hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), 0, h->stream,
+                           h->pair_per_xcd, h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, h->schur_ablate);
+        if (h->Spart)
+            hipLaunchKernelGGL(k_schur_combine, dim3(cdiv(h->ncomb, 4)), dim3(256), 0, h->stream, h->ncomb,
+                               h->comb_items, h->comb_tasks, h->Spart, h->S);
     }
     if (h->F > 0 && h->nr > 0) {
         StageTimer t(h, PS_ST_EDGES);
@@ -551,11 +558,17 @@ int cost_pass(ps_problem* h, int include_all, int scalar_slot) {
     return 0;
 }
 
-int backsub(ps_problem* h, const int32_t* gate = nullptr) {
+int backsub(ps_problem* h, const int32_t* gate = nullptr, bool fuse_update = false) {
     if (h->nv == 0) return 0;
     StageTimer t(h, PS_ST_BACKSUB);
-    hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
-                       h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate);
+    if (fuse_update)       // + full-step landmark update + SE(3) retraction of the poses in the same launch
+        hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l + h->nsq_p), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
+                           h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate,
+                           h->nsq_l, h->lm_point, h->points, h->P, h->poses, h->sq_part_p);
+    else
+        hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
+                           h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate,
+                           h->nsq_l, (const int32_t*)nullptr, (double*)nullptr, 0, (double*)nullptr, (double*)nullptr);
     return 0;
 }
 
@@ -594,18 +607,22 @@ int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool
 
 // back-substitution, update, cost and ||dx||^2 with ONE final reduction launch.  `gate` (device
 // status words) makes every kernel a no-op until the CG has flagged convergence.
-int gn_tail(ps_problem* h, int linesearch, const int32_t* gate) {
-    if (backsub(h, gate)) return -1;
+int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = false) {
+    // line-search order (cost AFTER the step): back-substitution, landmark update and pose retraction
+    // are one launch when the problem has landmarks (then D == 6)
+    const bool fused = linesearch && h->nv > 0 && h->nr > 0 && h->D == 6;
+    if (backsub(h, gate, fused)) return -1;
     int ncost = 0;
     if (!linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 0, gate); }
-    if (apply_update(h, 1.0, gate, true)) return -1;
+    if (!fused && apply_update(h, 1.0, gate, true)) return -1;
     if (linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 1, gate); }
     double* o_cost = h->shard_out ? h->shard_buf : h->scalars + (linesearch ? SC_COST : SC_LINCOST);
     double* o_dxl = h->shard_out ? h->shard_buf + 1 : h->scalars + SC_DXL2;
     hipLaunchKernelGGL(k_reduce3, dim3(3), dim3(256), 0, h->stream,
                        ncost, h->cost_partials, o_cost,
                        h->nsq_p, h->sq_part_p, h->nr > 0 ? h->scalars + SC_DXP2 : nullptr,
-                       h->nsq_l, h->sq_part_l, (h->nv > 0 || h->shard_out) ? o_dxl : nullptr, gate);
+                       h->nsq_l, h->sq_part_l, (h->nv > 0 || h->shard_out) ? o_dxl : nullptr, gate,
+                       h->status, h->scalars, publish ? h->h_status_dev : nullptr, publish ? h->h_scalars_dev : nullptr);
     return 0;
 }
 
@@ -629,19 +646,19 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
                               int* iters_out, double* relres_out, StageTimer* total) {
     StageTimer tp(h, PS_ST_PCG);
     if (cg_fused_setup<D>(h, max_iters)) return -1;
-    int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + 4 : 16;
+    int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + h->cg_margin : 16;
     for (;;) {
         count = std::min(count, max_iters + 2 - h->cg_launched);
         cg_fused_launch<D>(h, tol, count);
         cg_fused_recover<D>(h, h->status);
         tp.stop();
-        if (gn_tail(h, linesearch, h->status)) return -1;
+        if (gn_tail(h, linesearch, h->status, true)) return -1;
         if (total) total->stop();                       // close the iteration timer before the sync
-        if (read_scalars(h)) return -1;
+        if (sync(h)) return -1;                         // k_reduce3 has published status + scalars to host memory
         if (h->h_status[ST_PCG_DONE] != 0) break;
         if (h->cg_launched >= max_iters + 2) {          // not converged within max_iters: take the step anyway
             cg_fused_recover<D>(h, nullptr);
-            if (gn_tail(h, linesearch, nullptr) || read_scalars(h)) return -1;
+            if (gn_tail(h, linesearch, nullptr, true) || sync(h)) return -1;
             break;
         }
         count = std::max(8, h->cg_launched / 2);
@@ -831,20 +848,47 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     if (h->alloc(&h->fscratch, (size_t)F * FROW)) return -1;
 
     // ---- Schur pairs per landmark (upper-triangle block keys)
+    // Landmark tiles: when Z (144 B per row) is much larger than the eight 4 MB L2s, the pair list is
+    // cut into tiles of consecutive landmarks (consecutive Z rows) and ONE XCD works through a whole
+    // tile: a Z row is then only ever requested by one L2 instead of by up to eight.  A block that
+    // receives pairs from several tiles gets one partial per (tile, block) task, summed in tile order
+    // by k_schur_combine (fixed order => deterministic).  Measured at C3 (72 MB of Z): 8 tiles of 9 MB
+    // beat both no tiling (71 -> 65 us) and L2-sized 2-4 MB tiles (71-82 us: five times more tasks,
+    // and the per-task prologue/epilogue costs more than the extra L2 hits save).
     std::vector<PairRec> prs;
+    int ntiles = 1;
+    {
+        const double zbytes = 144.0 * (double)lm_ptr[nv];
+        double tile_kb = 9216.0, min_mb = 16.0;
+        if (const char* e = getenv("PS_SCHUR_TILE_KB")) tile_kb = atof(e);
+        if (const char* e = getenv("PS_SCHUR_TILE_MIN_MB")) min_mb = atof(e);
+        if (tile_kb > 0 && zbytes > min_mb * 1048576.0)
+            ntiles = 8 * (int)std::ceil(zbytes / (8.0 * tile_kb * 1024.0));
+    }
+    std::vector<long> lm_pairs_before(nv + 1, 0);
     for (int v = 0; v < nv; ++v) {
+        long nvar = 0;
+        for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) nvar += d->pose_rid[PS_POSE_OF(lobs[a])] >= 0;
+        lm_pairs_before[v + 1] = lm_pairs_before[v] + nvar * (nvar - 1) / 2;
+    }
+    const long total_pairs = lm_pairs_before[nv];
+    for (int v = 0; v < nv; ++v) {
+        const int tile = (ntiles > 1 && total_pairs > 0)
+            ? (int)std::min<long>(ntiles - 1, (long)((double)ntiles * (double)lm_pairs_before[v] / (double)total_pairs)) : 0;
         for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) {
             const int ra = d->pose_rid[PS_POSE_OF(lobs[a])];
             if (ra < 0) continue;
             for (int b = a + 1; b < lm_ptr[v + 1]; ++b) {
                 const int rb = d->pose_rid[PS_POSE_OF(lobs[b])];
                 if (rb < 0) continue;
-                if (ra <= rb) prs.push_back({((uint64_t)ra << 32) | (uint32_t)rb, a, b});
-                else prs.push_back({((uint64_t)rb << 32) | (uint32_t)ra, b, a});
+                if (ra <= rb) prs.push_back({((uint64_t)ra << 32) | (uint32_t)rb, a, b, tile});
+                else prs.push_back({((uint64_t)rb << 32) | (uint32_t)ra, b, a, tile});
             }
         }
     }
-    std::stable_sort(prs.begin(), prs.end(), [](const PairRec& x, const PairRec& y) { return x.key < y.key; });
+    h->schur_tiles = ntiles;
+    std::stable_sort(prs.begin(), prs.end(), [](const PairRec& x, const PairRec& y) {
+        return x.tile != y.tile ? x.tile < y.tile : x.key < y.key; });
     h->npairs = (long)prs.size();
     if (prs.size() >= (1UL << 31)) return fail("too many Schur pairs for 32-bit indexing");
 
@@ -895,38 +939,75 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     for (int r = 0; r < nr; ++r) diag_slot[r] = slot_of(r, r);
     if (h->upload(&h->row_ptr, row_ptr) || h->upload(&h->col_idx, col_idx) || h->upload(&h->diag_slot, diag_slot)) return -1;
     h->red_count = (long)nnzb * DD + (long)nr * D + 2;
-    if (h->alloc(&h->red, (size_t)h->red_count)) return -1;
+    if (h->alloc(&h->red, (size_t)h->red_count + ST_NWORDS / 2)) return -1;       // + the status words: one memset clears both
+    h->status = reinterpret_cast<int32_t*>(h->red + h->red_count);
     h->S = h->red; h->g = h->red + (size_t)nnzb * DD; h->red_cost = h->g + (size_t)nr * D;
 
-    // pair list + one work item per block that has pairs
+    // pair list + one work item (task) per (tile, block) that has pairs
     std::vector<int2> pairs(prs.size());
     std::vector<PairItem> pitm;
+    std::vector<int32_t> task_tile;
     for (size_t k = 0; k < prs.size(); ++k) {
         pairs[k] = make_int2(prs[k].a, prs[k].b);
-        if (k == 0 || prs[k].key != prs[k - 1].key) {
+        if (k == 0 || prs[k].key != prs[k - 1].key || prs[k].tile != prs[k - 1].tile) {
             const int a = (int)(prs[k].key >> 32), b = (int)(uint32_t)prs[k].key;
             if (!pitm.empty()) pitm.back().end = (int32_t)k;
             pitm.push_back({slot_of(a, b), slot_of(b, a), (int32_t)k, 0});
+            task_tile.push_back(prs[k].tile);
         }
     }
     if (!pitm.empty()) pitm.back().end = (int32_t)prs.size();
     h->npair_items = (int)pitm.size();
-    if (h->upload(&h->pairs, pairs) || h->upload(&h->pair_items, pitm)) return -1;
-    {   // per-XCD work lists: items are sorted by block row, so equal contiguous shares of the PAIRS
-        // (not of the items) give each XCD a contiguous range of block rows with balanced work
+    if (h->upload(&h->pairs, pairs)) return -1;
+    {   // per-XCD work lists.  Untiled: items are sorted by block row, so equal contiguous shares of
+        // the PAIRS (not of the items) give each XCD a contiguous range of block rows with balanced
+        // work.  Tiled: XCD x takes tiles x, x + 8, ... (tiles hold equal pair counts).
         std::vector<std::vector<int32_t>> lists(8);
         const double total = (double)pairs.size();
         for (size_t k = 0; k < pitm.size(); ++k) {
-            const int x = total > 0 ? std::min(7, (int)(8.0 * pitm[k].start / total)) : 0;
+            const int x = ntiles > 1 ? (task_tile[k] & 7)
+                                     : (total > 0 ? std::min(7, (int)(8.0 * pitm[k].start / total)) : 0);
             lists[x].push_back((int32_t)k);
         }
+        // longest tasks first (within each tile): the short ones fill the tail of the XCD's schedule
+        if (!getenv("PS_SCHUR_NO_LPT"))
+            for (auto& l : lists)
+                std::stable_sort(l.begin(), l.end(), [&](int32_t x, int32_t y) {
+                    if (task_tile[x] != task_tile[y]) return task_tile[x] < task_tile[y];
+                    return pitm[x].end - pitm[x].start > pitm[y].end - pitm[y].start; });
         size_t mx = 0;
         for (auto& l : lists) mx = std::max(mx, l.size());
-        mx = (mx + 3) / 4 * 4;
-        std::vector<int32_t> order(8 * std::max<size_t>(mx, 4), -1);
-        for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), order.begin() + x * std::max<size_t>(mx, 4));
-        h->pair_per_xcd = (int)std::max<size_t>(mx, 4);
-        if (h->upload(&h->pair_order, order)) return -1;
+        mx = std::max<size_t>((mx + 3) / 4 * 4, 4);
+        std::vector<PairItem> xit(8 * mx, PairItem{-1, -1, 0, 0});
+        std::vector<int32_t> pos_of_task(pitm.size(), -1);
+        for (int x = 0; x < 8; ++x)
+            for (size_t q = 0; q < lists[x].size(); ++q) {
+                xit[x * mx + q] = pitm[lists[x][q]];
+                pos_of_task[lists[x][q]] = (int32_t)(x * mx + q);
+            }
+        h->pair_per_xcd = (int)mx;
+        if (h->upload(&h->pair_xitems, xit)) return -1;
+        if (ntiles > 1 && !pitm.empty()) {
+            // per-block task lists in tile order (tasks are numbered tile-major); partials are
+            // addressed by dispatch position
+            std::vector<std::pair<int32_t, int32_t>> bt(pitm.size());      // (slot, task)
+            for (size_t k = 0; k < pitm.size(); ++k) bt[k] = {pitm[k].slot, (int32_t)k};
+            std::stable_sort(bt.begin(), bt.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) {
+                return x.first < y.first; });
+            std::vector<PairItem> citm;
+            std::vector<int32_t> ctasks(bt.size());
+            for (size_t k = 0; k < bt.size(); ++k) {
+                ctasks[k] = pos_of_task[bt[k].second];
+                if (k == 0 || bt[k].first != bt[k - 1].first) {
+                    if (!citm.empty()) citm.back().end = (int32_t)k;
+                    citm.push_back({pitm[bt[k].second].slot, pitm[bt[k].second].slotT, (int32_t)k, 0});
+                }
+            }
+            citm.back().end = (int32_t)bt.size();
+            h->ncomb = (int)citm.size();
+            if (h->upload(&h->comb_items, citm) || h->upload(&h->comb_tasks, ctasks)) return -1;
+            if (h->alloc(&h->Spart, xit.size() * 36)) return -1;
+        }
     }
     prs.clear(); prs.shrink_to_fit();
 
@@ -990,7 +1071,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     h->ncost_obs = N > 0 ? std::min(2048, cdiv(N, 256)) : 0;
     h->ncost_fac = F > 0 ? std::min(1024, cdiv(F, 256)) : 0;
     if (h->alloc(&h->cost_partials, (size_t)std::max(h->ncost_obs + h->ncost_fac, 512) + 8) ||
-        h->alloc(&h->scalars, SC_NWORDS) || h->alloc(&h->status, ST_NWORDS)) return -1;
+        h->alloc(&h->scalars, SC_NWORDS)) return -1;
     HIP_OK(hipMemsetAsync(h->scalars, 0, SC_NWORDS * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
     h->nsq_l = nv > 0 ? cdiv(nv, 256 / PS_LM_GROUP) : 0;
@@ -998,8 +1079,10 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     if (h->alloc(&h->sq_part_l, (size_t)h->nsq_l) || h->alloc(&h->sq_part_p, (size_t)h->nsq_p) ||
         h->alloc(&h->shard_buf, 2)) return -1;
     HIP_OK(hipMemsetAsync(h->shard_buf, 0, 2 * sizeof(double), h->stream));
-    HIP_OK(hipHostMalloc((void**)&h->h_scalars, SC_NWORDS * sizeof(double)));
-    HIP_OK(hipHostMalloc((void**)&h->h_status, ST_NWORDS * sizeof(int32_t)));
+    HIP_OK(hipHostMalloc((void**)&h->h_scalars, SC_NWORDS * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostMalloc((void**)&h->h_status, ST_NWORDS * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostGetDevicePointer((void**)&h->h_scalars_dev, h->h_scalars, 0));
+    HIP_OK(hipHostGetDevicePointer((void**)&h->h_status_dev, h->h_status, 0));
     HIP_OK(hipStreamSynchronize(h->stream));
     guard.ok = true;
     *out = h;
@@ -1160,7 +1243,7 @@ int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters,
         HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
         if (h->D == 6 ? cg_fused_setup<6>(h, pcg_max_iters) : cg_fused_setup<3>(h, pcg_max_iters)) return -1;
     }
-    int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + 4 : 16) : std::max(8, h->cg_launched / 2);
+    int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + h->cg_margin : 16) : std::max(8, h->cg_launched / 2);
     count = std::min(count, pcg_max_iters + 2 - h->cg_launched);
     const bool last = count <= 0;
     if (h->D == 6) { if (!last) cg_fused_launch<6>(h, pcg_tol, count); cg_fused_recover<6>(h, last ? nullptr : h->status); }
@@ -1215,8 +1298,6 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
     {
         StageTimer total(h, PS_ST_TOTAL, 1);  // closed before the last synchronising read-back
         if (linearize(h, lambda)) return -1;
-        HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
-        HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
         if (h->nr > 0 && h->pcg_variant == 1) {
             const int rc = h->D == 6
                 ? gn_solve_and_finish_async<6>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, &total)
@@ -1231,7 +1312,8 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
     }
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
-    if (dx_norm_out) *dx_norm_out = std::sqrt(h->h_scalars[SC_DXP2] + h->h_scalars[SC_DXL2]);
+    // a slot whose reduction did not run (no reduced poses / no variable landmarks) is stale: count it as 0
+    if (dx_norm_out) *dx_norm_out = std::sqrt((h->nr > 0 ? h->h_scalars[SC_DXP2] : 0.0) + (h->nv > 0 ? h->h_scalars[SC_DXL2] : 0.0));
     return 0;
 }
 
@@ -1286,6 +1368,8 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
         h->coarse_req = (int)value; h->coarse_built = false;
     }
     else if (n == "cg_ablate") h->cg_ablate = (int)value;
+    else if (n == "schur_ablate") h->schur_ablate = (int)value;
+    else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }
     else return fail("unknown option: " + n);
@@ -1300,6 +1384,7 @@ int ps_set_profiling(ps_problem* h, int enabled) {
 
 int ps_get_stage_times(ps_problem* h, double* ms, int64_t* counts, int reset) {
     if (!h) return fail("null argument");
+    if (!h->pending.empty() && sync(h)) return -1;       // staged calls only enqueue: collect their events
     for (int i = 0; i < PS_NUM_STAGES; ++i) {
         if (ms) ms[i] = h->stage_ms[i];
         if (counts) counts[i] = h->stage_n[i];

@@ -299,92 +299,140 @@ __global__ __launch_bounds__(64) void k_pose_finalize(
 // instead of being re-fetched by all eight.
 //
 // Z rows are 144 B and scattered, so a lane-per-pair gather issues 18 fully divergent 16-byte
-// loads per pair (41 M L1 accesses at C3, the measured bottleneck).  Instead each wave stages the
-// 128 rows of a 64-pair chunk through LDS: 9 consecutive lanes fetch the 9 x 16 B of ONE row, so
-// a load instruction touches ~14 cache lines instead of 64 (4.5x fewer L1 accesses); the rows sit
-// in LDS at their natural 144-byte stride, which is conflict-free for the ds_read_b128 of the
-// lane-per-pair compute phase that follows.  Waves never share LDS data: no workgroup barrier.
-#define PS_SP_ROWS 128                       // rows per chunk: 64 x (a, b)
-#define PS_SP_LDS_PER_WAVE 2400               // doubles: 128 rows x 18 = 2304, epilogue 36 x 65 + 36 = 2376
-__global__ __launch_bounds__(256) void k_schur_pairs(
-    int per_xcd, const int32_t* __restrict__ order, const PairItem* __restrict__ items,
-    const int2* __restrict__ pairs, const double* __restrict__ Z, double* __restrict__ S)
+// loads per pair (41 M L1 accesses at C3).  Instead each wave moves the 64 rows of a 32-pair
+// chunk straight into LDS with global_load_lds_dwordx4 (no staging registers, no ds_write pass):
+// 9 consecutive lanes fetch the 9 x 16 B of ONE row, 7 rows per instruction, and because the
+// LDS destination of lane l is base + 16 l the rows land at their natural 144-byte stride, which
+// is conflict-free for the ds_read_b128 of the compute phase.  Two lanes share a pair (lane
+// p + 32 h accumulates block rows 3h .. 3h+2), so a lane carries 18 accumulators instead of 36:
+// ~9 KB of LDS and < 128 VGPRs per wave => 4 waves per SIMD, twice the loads in flight of the
+// register-staged 64-pair version.  Waves never share LDS data: no workgroup barrier.
+#define PS_SP_PAIRS 32                        // pairs per chunk: rows a_0..a_31, b_0..b_31
+#define PS_SP_LDS_PER_WAVE 1152               // doubles: 64 rows x 18
+
+typedef const __attribute__((address_space(1))) void* ps_gptr_t;
+typedef __attribute__((address_space(3))) void* ps_lptr_t;
+
+// sum over the 32 lanes of each wave half with DPP row operations (fixed order): lane 31 / 63
+// end up with the total of lanes 0-31 / 32-63
+PS_DEV double half_sum_dpp(double v) {
+    v = dpp_shift_add<0x111, 0xf, 0xf>(v);  // row_shr:1
+    v = dpp_shift_add<0x112, 0xf, 0xf>(v);  // row_shr:2
+    v = dpp_shift_add<0x114, 0xf, 0xe>(v);  // row_shr:4
+    v = dpp_shift_add<0x118, 0xf, 0xc>(v);  // row_shr:8
+    v = dpp_shift_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_schur_pairs(
+    int per_xcd, const PairItem* __restrict__ xitems /* [8][per_xcd], slot < 0: padding */,
+    const int2* __restrict__ pairs, const double* __restrict__ Z, double* __restrict__ S,
+    double* __restrict__ Spart /* tiled mode: one partial block per task position, else NULL */, int ablate)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ __attribute__((aligned(16))) double smem[4 * PS_SP_LDS_PER_WAVE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double* rows = smem + wv * PS_SP_LDS_PER_WAVE;
     const int local = (blockIdx.x >> 3) * 4 + wv;
     if (local >= per_xcd) return;
-    const int w = order[(blockIdx.x & 7) * per_xcd + local];
-    if (w < 0) return;
-    const PairItem it = items[w];
-    double acc[36];
+    const size_t pos = (size_t)(blockIdx.x & 7) * per_xcd + local;
+    const PairItem it = xitems[pos];
+    if (it.slot < 0) return;
+    const int p = lane & 31, hf = lane >> 5;                    // pair in the chunk, half of the block
+    const int slot = lane / 9, piece = lane - 9 * slot;         // fetch role; lane 63: slot 7 (idle)
+    const int32_t* flat = reinterpret_cast<const int32_t*>(pairs) + hf;
+    double acc[18];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    const int slot = lane / 9, piece = lane - 9 * slot;         // lane 63: slot 7 (idle)
-    for (int base = it.start; base < it.end; base += 64) {
-        const int n = min(64, it.end - base);                   // pairs in this chunk
-        int2 mine = make_int2(0, 0);
-        if (lane < n) mine = pairs[base + lane];
-        // ---- cooperative fetch: instruction k brings rows 7k .. 7k+6 (row r < 64: a_r, else b_{r-64})
-        double2 stage[19];
+    for (int k = 0; k < 18; ++k) acc[k] = 0.0;
+    // lane l holds the Z row index of LDS row l of a chunk (a_p for l < 32, b_p above); the index
+    // loads run two chunks ahead of the row fetches so that no chunk waits on them
+    int mine = (it.start + p < it.end) ? flat[2 * (size_t)(it.start + p)] : -1;
+    int mine1 = (it.start + PS_SP_PAIRS + p < it.end) ? flat[2 * (size_t)(it.start + PS_SP_PAIRS + p)] : -1;
+    for (int base = it.start; base < it.end; base += PS_SP_PAIRS) {
+        const int n = min(PS_SP_PAIRS, it.end - base);
+        // ---- cooperative fetch: instruction k brings rows 7k .. 7k+6 into LDS.  All ten index
+        // shuffles are issued first (one wait), the next-but-one chunk's indices are requested
+        // BEFORE the rows so that the single vmcnt(0) below never waits on a younger load.
+        int zrow[10];
 #pragma unroll
-        for (int k = 0; k < 19; ++k) {
+        for (int k = 0; k < 10; ++k) zrow[k] = __shfl(mine, (7 * k + slot) & 63, 64);
+        const int nb = base + 2 * PS_SP_PAIRS;
+        const int mine2 = (nb + p < it.end) ? flat[2 * (size_t)(nb + p)] : -1;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
             const int r = 7 * k + slot;
-            const int pr = r & 63;
-            const int ia = __shfl(mine.x, pr, 64), ib = __shfl(mine.y, pr, 64);
-            const bool ok = slot < 7 && r < PS_SP_ROWS && pr < n;
-            const size_t zrow = (size_t)((r < 64) ? ia : ib);
-            stage[k] = ok ? *reinterpret_cast<const double2*>(Z + 18 * zrow + 2 * piece) : make_double2(0.0, 0.0);
+            if (slot < 7 && r < 2 * PS_SP_PAIRS && zrow[k] >= 0 && !(ablate & 2))
+                __builtin_amdgcn_global_load_lds((ps_gptr_t)(Z + 18 * (size_t)zrow[k] + 2 * piece),
+                                                 (ps_lptr_t)(rows + 126 * k), 16, 0, 0);
         }
-#pragma unroll
-        for (int k = 0; k < 19; ++k) {
-            const int r = 7 * k + slot;
-            if (slot < 7 && r < PS_SP_ROWS) *reinterpret_cast<double2*>(rows + 18 * r + 2 * piece) = stage[k];
-        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): rows have landed in LDS
         __builtin_amdgcn_wave_barrier();
-        // ---- lane-per-pair accumulate from LDS
-        if (lane < n) {
-            double za[18], zb[18];
-            const double2* pa = reinterpret_cast<const double2*>(rows + 18 * lane);
-            const double2* pb = reinterpret_cast<const double2*>(rows + 18 * (64 + lane));
+        if (p < n && !(ablate & 1)) {
+            double za[9];
+            const double* pa = rows + 18 * p + 9 * hf;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const double2 u = pa[k], v = pb[k];
-                za[2 * k] = u.x; za[2 * k + 1] = u.y; zb[2 * k] = v.x; zb[2 * k + 1] = v.y;
+            for (int k = 0; k < 9; ++k) za[k] = pa[k];
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh) {
+                double zb[10];
+                // columns 3bh .. 3bh+2 need b-row entries 9bh .. 9bh+8; read 16-byte aligned
+                const double2* pb = reinterpret_cast<const double2*>(rows + 18 * (PS_SP_PAIRS + p) + 8 * bh);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { const double2 v = pb[k]; zb[2 * k] = v.x; zb[2 * k + 1] = v.y; }
+                const double* q = zb + bh;                      // q[0..8] = entries 9bh .. 9bh+8
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        acc[6 * a + 3 * bh + b] += za[3 * a] * q[3 * b] + za[3 * a + 1] * q[3 * b + 1] + za[3 * a + 2] * q[3 * b + 2];
             }
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = 0; b < 6; ++b)
-                    acc[6 * a + b] += za[3 * a] * zb[3 * b] + za[3 * a + 1] * zb[3 * b + 1] + za[3 * a + 2] * zb[3 * b + 2];
         }
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();                        // LDS reads done before the next fetch lands
+        mine = mine1; mine1 = mine2;
     }
-    // ---- reduce the 36 accumulators over the 64 lanes through LDS (the row buffer is free now):
-    // lane l stores acc[k] at [k][l] (row stride 65 doubles: 2-way conflicts at most), then lane k
-    // sums row k in lane order -- a fixed order, ~8x cheaper than 36 shuffle butterflies.
-    double* red = rows;                      // 36 * 65 + 36 = 2376 doubles <= PS_SP_LDS_PER_WAVE
+    // ---- reduce the 18 accumulators over the 32 lanes of each half (DPP, fixed order); lanes 31
+    // and 63 publish the 36 block entries through LDS for the coalesced, mirrored write
+    double* sums = rows;
 #pragma unroll
-    for (int k = 0; k < 36; ++k) red[k * 65 + lane] = acc[k];
-    __builtin_amdgcn_wave_barrier();
-    double mine_v = 0.0;
-    if (lane < 36) {
-#pragma unroll 8
-        for (int l = 0; l < 64; ++l) mine_v += red[lane * 65 + l];
+    for (int k = 0; k < 18; ++k) {
+        const double t = half_sum_dpp(acc[k]);
+        if (p == 31) sums[18 * hf + k] = t;                     // entry (3 hf + k / 6, k % 6) = 18 hf + k
     }
     __builtin_amdgcn_wave_barrier();
-    double* sums = rows + 36 * 65;           // 36 block entries, for the mirrored / symmetrised write
-    if (lane < 36) sums[lane] = mine_v;
-    __builtin_amdgcn_wave_barrier();
-    const int r = lane / 6, c = lane % 6;
     if (lane < 36) {
-        if (it.slot == it.slotT) {
+        const int r = lane / 6, c = lane % 6;
+        const double mine_v = sums[lane];
+        if (Spart) {
+            Spart[pos * 36 + lane] = mine_v;
+        } else if (it.slot == it.slotT) {                       // duplicate observation: a diagonal block
             S[(size_t)it.slot * 36 + lane] -= mine_v + sums[c * 6 + r];
-        } else {
-            S[(size_t)it.slot * 36 + lane] -= mine_v;
-            S[(size_t)it.slotT * 36 + c * 6 + r] -= mine_v;
+        } else {                                                // off-diagonal blocks are still zero here
+            S[(size_t)it.slot * 36 + lane] = -mine_v;
+            S[(size_t)it.slotT * 36 + c * 6 + r] = -mine_v;
         }
+    }
+}
+
+// tiled mode: sum the (tile, block) partials of every block in tile order and apply them to S and
+// to the mirrored block; one wave per block
+__global__ __launch_bounds__(256) void k_schur_combine(
+    int nblocks, const PairItem* __restrict__ items, const int32_t* __restrict__ tasks,
+    const double* __restrict__ Spart, double* __restrict__ S)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= nblocks || lane >= 36) return;
+    const PairItem it = items[b];
+    const int r = lane / 6, c = lane % 6;
+    double v = 0.0, vt = 0.0;
+    for (int k = it.start; k < it.end; ++k) {
+        const double* q = Spart + (size_t)tasks[k] * 36;
+        v += q[lane];
+        vt += q[c * 6 + r];
+    }
+    if (it.slot == it.slotT) {
+        S[(size_t)it.slot * 36 + lane] -= v + vt;
+    } else {
+        S[(size_t)it.slot * 36 + lane] -= v;
+        S[(size_t)it.slotT * 36 + lane] -= vt;
     }
 }
 
@@ -1420,10 +1468,29 @@ __global__ __launch_bounds__(256) void k_backsub(
     const double* __restrict__ Cinv, const double* __restrict__ cvec,
     const double* __restrict__ xp, double* __restrict__ dxl,
     double* __restrict__ sq_part /* one partial of ||dx_l||^2 per workgroup */,
-    const int32_t* __restrict__ gate)
+    const int32_t* __restrict__ gate,
+    // fused full-step update (NULL points: back-substitution only).  Workgroups >= nblk_l retract the
+    // SE(3) poses instead (nothing in the back-substitution reads `poses` or `points`).
+    int nblk_l, const int32_t* __restrict__ lm_point, double* __restrict__ points,
+    int P, double* __restrict__ poses, double* __restrict__ sq_part_p)
 {
     __shared__ double lds[16];
     if (gate && !gate[ST_PCG_DONE]) return;
+    if ((int)blockIdx.x >= nblk_l) {
+        typedef PoseOps<6> G;
+        const int i = (blockIdx.x - nblk_l) * blockDim.x + threadIdx.x;
+        double sq = 0.0;
+        const int rid = (i < P) ? pose_rid[i] : -1;
+        if (rid >= 0) {
+            double xi[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { xi[k] = xp[(size_t)rid * 6 + k]; sq += xi[k] * xi[k]; }
+            G::store(poses + G::W * (size_t)i, G::mul(G::exp(xi), G::load(poses + G::W * (size_t)i)));
+        }
+        sq = block_sum(sq, lds);
+        if (threadIdx.x == 0) sq_part_p[blockIdx.x - nblk_l] = sq;
+        return;
+    }
     // 16 lanes per landmark, one observation per lane (same mapping as k_landmark_pass)
     const int v = blockIdx.x * (blockDim.x / PS_LM_GROUP) + threadIdx.x / PS_LM_GROUP;
     const int sub = threadIdx.x & (PS_LM_GROUP - 1);
@@ -1452,6 +1519,10 @@ __global__ __launch_bounds__(256) void k_backsub(
         const double d2 = m[5] * a2;
         dxl[3 * (size_t)v] = d0; dxl[3 * (size_t)v + 1] = d1; dxl[3 * (size_t)v + 2] = d2;
         sq = d0 * d0 + d1 * d1 + d2 * d2;
+        if (points) {
+            double* pt = points + 3 * (size_t)lm_point[v];
+            pt[0] += d0; pt[1] += d1; pt[2] += d2;
+        }
     }
     sq = block_sum(sq, lds);
     if (threadIdx.x == 0) sq_part[blockIdx.x] = sq;
@@ -1572,9 +1643,21 @@ __global__ __launch_bounds__(256) void k_sumsq_partials(
 __global__ __launch_bounds__(256) void k_reduce3(
     int n0, const double* __restrict__ p0, double* __restrict__ o0,
     int n1, const double* __restrict__ p1, double* __restrict__ o1,
-    int n2, const double* __restrict__ p2, double* __restrict__ o2, const int32_t* __restrict__ gate)
+    int n2, const double* __restrict__ p2, double* __restrict__ o2, const int32_t* __restrict__ gate,
+    // publish (hst != NULL): the status words and the scalar slots go straight to pinned host memory, so
+    // the iteration ends with a stream synchronisation instead of two device-to-host copy launches
+    const int32_t* __restrict__ status, const double* __restrict__ scalars,
+    int32_t* __restrict__ hst, double* __restrict__ hsc)
 {
     __shared__ double lds[16];
+    if (hst && blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t < ST_NWORDS) hst[t] = status[t];
+        else if (t < ST_NWORDS + SC_NWORDS) {
+            const int k = t - ST_NWORDS;                 // slots owned by a reduction below are written there
+            if (o0 != scalars + k && o1 != scalars + k && o2 != scalars + k) hsc[k] = scalars[k];
+        }
+    }
     if (gate && !gate[ST_PCG_DONE]) return;
     const int n = blockIdx.x == 0 ? n0 : (blockIdx.x == 1 ? n1 : n2);
     const double* p = blockIdx.x == 0 ? p0 : (blockIdx.x == 1 ? p1 : p2);
@@ -1583,10 +1666,12 @@ __global__ __launch_bounds__(256) void k_reduce3(
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += p[i];
     s = block_sum(s, lds);
-    if (threadIdx.x == 0) o[0] = s;
+    if (threadIdx.x == 0) {
+        o[0] = s;
+        if (hsc && o >= scalars && o < scalars + SC_NWORDS) hsc[o - scalars] = s;
+    }
 }
 
-// out[0] = sum(partials[0..n))  (single workgroup, fixed order)
 __global__ __launch_bounds__(256) void k_reduce_partials(int n, const double* __restrict__ partials,
                                                           double* __restrict__ out)
 {

@@ -1,0 +1,21 @@
+"""Ablation timing of k_schur_pairs at C3 (bits: 1 = no LDS reads / FMAs, 2 = no Z fetch, 4 = all
+rows from the first 64 Z rows).  Results are wrong under ablation; timing only."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pyslam_amd import synthetic
+from pyslam_amd.device import DeviceProblem
+lp, _ = synthetic.stereo_ba(num_kf=200, num_lm=50000, obs_per_lm=10, half_window=20, seed=0)
+dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
+dev.snapshot()
+for ab in [0, 1, 2, 3]:
+    dev.set_option('schur_ablate', ab)
+    for _ in range(3):
+        dev.restore(); dev.linearize(0.0)
+    dev.set_profiling(1); dev.stage_times(reset=True)
+    for _ in range(20):
+        dev.restore(); dev.linearize(0.0)
+    torch.cuda.synchronize()
+    st = dev.stage_times(reset=True)
+    dev.set_profiling(0)
+    print('ablate', ab, {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if v[1] > 0})
