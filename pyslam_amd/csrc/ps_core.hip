@@ -99,7 +99,17 @@ struct ps_problem {
     size_t cg_cap = 0, saug_cap = 0; // CG vectors / matrix are allocated for this many block rows / blocks
     int32_t *pnode = nullptr, *slo = nullptr, *shi = nullptr, *run_lo = nullptr, *run_hi = nullptr,
             *arow_ptr = nullptr, *acol_idx = nullptr, *aug_slot = nullptr, *fine_nnz = nullptr;
-    double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *Lci = nullptr, *LciT = nullptr, *tvec = nullptr, *chol_scratch = nullptr;
+    double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *tvec = nullptr, *chol_scratch = nullptr;
+    // coarse factor L_c^-1 (and transpose), double-buffered: with "coarse_lag" the factorisation of THIS
+    // iteration's A_c runs on a side stream while the CG iterates with the previous iteration's factor
+    double *Lci2[2] = {}, *LciT2[2] = {};
+    int lci_cur = 0;                // buffer the current augmented system was built with
+    int lci_next = -1;              // buffer holding (or receiving, see side_pending) the newest factor; -1: none
+    bool side_pending = false;      // a side-stream factorisation is in flight: wait for ev_chol before reuse
+    int coarse_lag = 1;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ac = nullptr, ev_chol = nullptr;
+    int32_t* lag_status = nullptr;  // ST_DIAG_FAIL of the side-stream factorisation
     bool coarse_built = false;
     int cg_ablate = 0, schur_ablate = 0;
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
@@ -309,7 +319,7 @@ int build_coarse(ps_problem* h) {
     // pad rows to a common width unless that wastes more than 50 % (hub-like graphs): then CSR
     const bool ell = nr > 0 && (long)(maxlen + ncb_pre) * nr <= (long)(1.5 * (h->nnzb + (long)ncb_pre * nr)) + 64;
     const int wf = ell ? maxlen + ncb_pre : 0;
-    const int wc = ell ? nr + 1 : 0;
+    const int wc = ell ? nr + ncb_pre : 0;       // coarse rows: K^T (nr blocks) + the coarse-coarse row (ncb blocks)
     h->ell_wf = wf; h->ell_wc = wc;
     if (G == 0) {
         h->ncb = h->nc = 0; h->nr_aug = nr;
@@ -353,7 +363,7 @@ int build_coarse(ps_problem* h) {
     h->cg_split = split;
     for (int q = 0; q < ncb && !split; ++q) {
         for (int i = 0; i < nr; ++i) aci.push_back(i);
-        aci.push_back(nr + q);
+        for (int q2 = 0; q2 < ncb; ++q2) aci.push_back(nr + q2);
         arp[nr + q + 1] = (int32_t)aci.size();
     }
     if (split) {
@@ -376,15 +386,27 @@ int build_coarse(ps_problem* h) {
         h->upload(&h->run_hi, rhi) || h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) ||
         h->upload(&h->aug_slot, slot) || h->upload(&h->fine_nnz, fnz)) return -1;
     if (h->alloc(&h->SZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
-        h->alloc(&h->Lci, (size_t)h->nc * h->nc) || h->alloc(&h->LciT, (size_t)h->nc * h->nc) ||
+        h->alloc(&h->Lci2[0], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[0], (size_t)h->nc * h->nc) ||
+        h->alloc(&h->Lci2[1], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[1], (size_t)h->nc * h->nc) ||
         h->alloc(&h->tvec, (size_t)h->nc) || h->alloc(&h->chol_scratch, 2 * (size_t)h->nc * h->nc)) return -1;
+    if (!h->lag_status) {
+        if (h->alloc(&h->lag_status, ST_NWORDS)) return -1;
+        HIP_OK(hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+    }
+    if (!h->side) {
+        HIP_OK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_ac, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_chol, hipEventDisableTiming));
+    }
+    if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
+    h->lci_next = -1; h->lci_cur = 0;
     if (ensure_cg_buffers(h, h->nr_aug, h->nnzb_aug)) return -1;
     HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)h->nnzb_aug * D * D * sizeof(double), h->stream));
     return 0;
 }
 
 template <int D>
-int cg_fused_setup(ps_problem* h, int max_iters) {
+int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false) {
     const int nr = h->nr, cap = h->hist_cap;
     if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
     if (!h->coarse_built && build_coarse(h)) return -1;
@@ -401,25 +423,58 @@ int cg_fused_setup(ps_problem* h, int max_iters) {
                        h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh, h->status);
     if (G) {
         const int ncb = h->ncb, nc = h->nc;
+        if (h->side_pending) {                  // the side-stream factorisation still reads A_c / writes its buffer
+            HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0));
+            h->side_pending = false;
+        }
         hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), 0, h->stream, nr, ncb, h->run_lo, h->run_hi,
                            h->acol_idx, h->pnode, h->pw0, h->pw1, h->Saug, h->SZ);
         hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
                            nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->SZ, h->Ac);
-        if (nc <= 96) {
-            const size_t chol_lds = 2 * (size_t)nc * nc * sizeof(double);
-            HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)chol_lds));
-            hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, h->stream, ncb, h->Ac, h->Lci,
-                               h->LciT, h->status, nullptr);
+        // Exact: factor this iteration's A_c on the solver stream (51 us at C3, serial).  Lagged
+        // ("coarse_lag", whole-iteration calls only): build the augmented system with the factor of the
+        // PREVIOUS iteration's A_c -- any nonsingular L~ gives a consistent system V^T S^ V with
+        // V = [I, P L~^-T]; only the coarse-coarse block changes from I to L~^-1 A_c L~^-T -- and factor
+        // the current A_c on a side stream while the CG iterates.
+        auto launch_chol = [&](hipStream_t st, int buf, int32_t* stat) -> int {
+            if (nc <= 90) {                                        // 2 nc^2 doubles of dynamic LDS (<= 130 KB)
+                const size_t chol_lds = 2 * (size_t)nc * nc * sizeof(double);
+                HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)chol_lds));
+                hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, st, ncb, h->Ac, h->Lci2[buf],
+                                   h->LciT2[buf], stat, nullptr);
+            } else {
+                hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, st, ncb, h->Ac, h->Lci2[buf],
+                                   h->LciT2[buf], stat, h->chol_scratch);
+            }
+            return 0;
+        };
+        const bool lag = allow_lag && h->coarse_lag && !h->cg_split && h->lci_next >= 0;
+        const int border_lds = (int)((size_t)D * nc * sizeof(double));
+        if (lag) {
+            const int use = h->lci_next;
+            h->lci_cur = use;
+            hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr + ncb), dim3(256), border_lds, h->stream,
+                               nr, ncb, h->SZ, h->Lci2[use], h->arow_ptr, h->fine_nnz, h->Saug, 1, h->Ac);
+            hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
+                               h->pw0, h->pw1, h->LciT2[use], h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
+                               h->cg_s[0], h->cg_p, h->cg_xh, 2, h->lag_status, h->status);
+            HIP_OK(hipEventRecord(h->ev_ac, h->stream));           // A_c complete, buffer use^1 no longer read
+            HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
+            if (launch_chol(h->side, use ^ 1, h->lag_status)) return -1;
+            HIP_OK(hipEventRecord(h->ev_chol, h->side));
+            h->lci_next = use ^ 1; h->side_pending = true;
         } else {
-            hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, h->stream, ncb, h->Ac, h->Lci,
-                               h->LciT, h->status, h->chol_scratch);
+            const int buf = h->lci_cur;
+            if (launch_chol(h->stream, buf, h->status)) return -1;
+            hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr), dim3(256), border_lds, h->stream,
+                               nr, ncb, h->SZ, h->Lci2[buf], h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1,
+                               (const double*)nullptr);
+            hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
+                               h->pw0, h->pw1, h->LciT2[buf], h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
+                               h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, (const int32_t*)nullptr, h->status);
+            h->lci_next = buf;
         }
-        hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr), dim3(256), (size_t)D * nc * sizeof(double), h->stream,
-                           nr, ncb, h->SZ, h->Lci, h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1);
-        hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
-                           h->pw0, h->pw1, h->LciT, h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
-                           h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1);
     }
     h->cg_launched = 0;
     return 0;
@@ -461,7 +516,7 @@ void cg_fused_recover(ps_problem* h, const int32_t* gate) {
     const int nr = h->nr;
     if (h->G)
         hipLaunchKernelGGL(k_coarse_recover<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->ncb,
-                           h->pnode, h->pw0, h->pw1, h->Linv, h->Lci, h->cg_xh, h->x, gate);
+                           h->pnode, h->pw0, h->pw1, h->Linv, h->Lci2[h->lci_cur], h->cg_xh, h->x, gate);
     else
         hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->Linv,
                            h->cg_xh, h->x, gate);
@@ -472,8 +527,11 @@ int cg_report(ps_problem* h, int* iters_out, double* relres_out) {
     if (iters_out) *iters_out = h->h_status[ST_PCG_ITERS];
     const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
     if (relres_out) *relres_out = rr0 > 0.0 ? std::sqrt(rrf / rr0) : 0.0;
-    if (h->h_status[ST_DIAG_FAIL])
+    if (h->h_status[ST_DIAG_FAIL]) {
+        if (h->lag_status) hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream);
+        h->lci_next = -1;                               // never reuse a factor from a failed solve
         return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+    }
     if (h->h_status[ST_PCG_DONE] == 2)
         return fail("CG breakdown: the reduced system is not positive definite");
     return 0;
@@ -645,7 +703,7 @@ template <int D>
 int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int linesearch,
                               int* iters_out, double* relres_out, StageTimer* total) {
     StageTimer tp(h, PS_ST_PCG);
-    if (cg_fused_setup<D>(h, max_iters)) return -1;
+    if (cg_fused_setup<D>(h, max_iters, true)) return -1;
     int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + h->cg_margin : 16;
     for (;;) {
         count = std::min(count, max_iters + 2 - h->cg_launched);
@@ -683,10 +741,12 @@ int ps_device_count(void) {
 int ps_problem_destroy(ps_problem* h) {
     if (!h) return 0;
     hipStreamSynchronize(h->stream);
+    if (h->side) hipStreamSynchronize(h->side);
     for (void* p : h->allocs) hipFree(p);
     if (h->h_scalars) hipHostFree(h->h_scalars);
     if (h->h_status) hipHostFree(h->h_status);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1241,7 +1301,7 @@ int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters,
     struct Reset { ps_problem* h; ~Reset() { h->shard_out = false; } } reset{h};
     if (first) {
         HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
-        if (h->D == 6 ? cg_fused_setup<6>(h, pcg_max_iters) : cg_fused_setup<3>(h, pcg_max_iters)) return -1;
+        if (h->D == 6 ? cg_fused_setup<6>(h, pcg_max_iters, true) : cg_fused_setup<3>(h, pcg_max_iters, true)) return -1;
     }
     int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + h->cg_margin : 16) : std::max(8, h->cg_launched / 2);
     count = std::min(count, pcg_max_iters + 2 - h->cg_launched);
@@ -1369,6 +1429,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     }
     else if (n == "cg_ablate") h->cg_ablate = (int)value;
     else if (n == "schur_ablate") h->schur_ablate = (int)value;
+    else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }

@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused(
     const int kk = lane >> 3, r = lane & 7;
     const int b0 = rbeg + w * 8 + kk;
     constexpr int STRIDE = 8 * NW;
-    // rows of the dense border K^T (row >= nfine in the ELL layout) have columns 0,1,2,... : their
-    // column index is arithmetic, so their vector loads do not wait for a col_idx load.
+    // rows of the dense border K^T (row >= nfine in the ELL layout) have columns 0,1,2,...,nr+ncb-1:
+    // their column index is arithmetic, so their vector loads do not wait for a col_idx load.
     const bool dense_row = wf > 0 && row >= nfine;
     int cj0 = 0, cj1 = 0;                        // column blocks of this lane's first two passes
     if (!dense_row) {
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused(
 #pragma unroll 2
         for (int b = b0; b < rend; b += STRIDE) {
             int jc;
-            if (dense_row) jc = (b == rend - 1) ? row : b - rbeg;
+            if (dense_row) jc = b - rbeg;                  // K^T over the fine columns, then the coarse-coarse row
             else jc = (b == b0) ? cj0 : ((b == b0 + STRIDE) ? cj1 : col_idx[b]);
             const size_t j = (size_t)jc * D;
             const double* sb = S + (size_t)b * DD + r * D;
@@ -1344,16 +1344,38 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
 
 // K_i = SZ_i Lci^T, written to both borders of the augmented BSR matrix.
 // One workgroup per fine block row i; thread per (r, c) of the D x nc strip.
+// Lagged mode (Ac != NULL): Lci is the inverse factor of the PREVIOUS iteration's A_c, so the
+// coarse-coarse block of V^T S^ V is M = Lci A_c Lci^T (close to, but not exactly, I); workgroups
+// nr .. nr+ncb-1 compute block row q of M the same way: strip = (Lci A_c)_q, then strip * Lci^T.
 template <int D>
 __global__ __launch_bounds__(256) void k_coarse_border(
     int nr, int ncb, const double* __restrict__ SZ, const double* __restrict__ Lci,
     const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ fine_nnz, double* __restrict__ Saug,
-    int with_coarse_rows)
+    int with_coarse_rows, const double* __restrict__ Ac)
 {
     constexpr int DD = D * D;
     extern __shared__ __attribute__((aligned(16))) double sT[];     // D x nc
     const int nc = ncb * D;
     const int i = blockIdx.x;
+    if (i >= nr) {                                                  // lagged mode: row q of M
+        const int q = i - nr;
+        for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
+            const int r = t / nc, c = t % nc, rr = q * D + r;
+            double v = 0.0;
+#pragma unroll 4
+            for (int k = 0; k <= rr; ++k) v += Lci[(size_t)rr * nc + k] * Ac[(size_t)k * nc + c];
+            sT[t] = v;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
+            const int r = t / nc, c = t % nc, q2 = c / D, cc = c % D;
+            double v = 0.0;
+#pragma unroll 8
+            for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * Lci[(size_t)c * nc + k];
+            Saug[(size_t)(arow_ptr[nr + q] + nr + q2) * DD + r * D + cc] = v;
+        }
+        return;
+    }
     for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
         const int r = t / nc, c = t % nc, q = c / D, cc = c % D;
         sT[t] = SZ[((size_t)i * ncb + q) * DD + r * D + cc];
@@ -1379,10 +1401,14 @@ __global__ __launch_bounds__(1024) void k_coarse_rhs(
     const double* __restrict__ LciT, const int32_t* __restrict__ arow_ptr,
     double* __restrict__ Saug, double* __restrict__ tvec /* nc scratch */,
     double* __restrict__ r /* fine part holds g^ */, double* __restrict__ w, double* __restrict__ s,
-    double* __restrict__ p, double* __restrict__ x, int with_coarse_rows)
+    double* __restrict__ p, double* __restrict__ x,
+    int with_coarse_rows /* 1: write the coarse-coarse rows as identity (exact factor); 2: leave them (lagged) */,
+    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status)
 {
     constexpr int DD = D * D;
     const int nc = ncb * D;
+    // a lagged factor whose (side-stream) factorisation failed poisons this solve: report it
+    if (lag_status && threadIdx.x == 0 && lag_status[ST_DIAG_FAIL]) atomicAdd(&status[ST_DIAG_FAIL], 1);
     // t_q = sum_{i in supp(q)} w(i,q) g^_i : 8 lanes per output, then a 3-step butterfly
     for (int base = 0; base < nc; base += blockDim.x / 8) {
         const int t = base + threadIdx.x / 8, sub = threadIdx.x & 7;
@@ -1395,10 +1421,10 @@ __global__ __launch_bounds__(1024) void k_coarse_rhs(
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
         if (t < nc && sub == 0) tvec[t] = v;
     }
-    if (with_coarse_rows)
-        for (int t = threadIdx.x; t < ncb * DD; t += blockDim.x) {
-            const int q = t / DD, e = t % DD;
-            Saug[(size_t)(arow_ptr[nr + q] + nr) * DD + e] = (e / D == e % D) ? 1.0 : 0.0;
+    if (with_coarse_rows == 1)
+        for (int t = threadIdx.x; t < ncb * ncb * DD; t += blockDim.x) {
+            const int q = t / (ncb * DD), q2 = (t / DD) % ncb, e = t % DD;
+            Saug[(size_t)(arow_ptr[nr + q] + nr + q2) * DD + e] = (q == q2 && e / D == e % D) ? 1.0 : 0.0;
         }
     __syncthreads();
     __shared__ double stv[400];

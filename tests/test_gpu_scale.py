@@ -79,6 +79,23 @@ def test_c3_all_solver_variants_agree(c3):
             assert np.linalg.norm(dx - ref) <= 1e-9 * np.linalg.norm(ref), (variant, groups, split, its, rel)
 
 
+def test_lagged_coarse_factor_gives_the_same_trajectory(c3):
+    """From the second whole-iteration call on, the two-level CG is built with the coarse factor of
+    the PREVIOUS iteration (the current one is factored on a side stream).  The reduced solve must
+    still reach the same solution: three Gauss-Newton iterations with and without the lag agree."""
+    out = {}
+    for lag in (1, 0):
+        dev = device(c3)
+        dev.set_option('coarse_lag', lag)
+        trace = [dev.gn_iteration(0., 1e-12, 2000, True) for _ in range(3)]
+        out[lag] = (trace, dev.get_params())
+    for (c1, n1, i1, r1), (c0, n0, i0, r0) in zip(out[1][0], out[0][0]):
+        assert abs(c1 - c0) <= 1e-9 * abs(c0) and abs(n1 - n0) <= 1e-8 * n0
+        assert r1 <= 1e-12 and i1 <= i0 + 8            # a stale factor may cost a few CG iterations, not more
+    for a, b in zip(out[1][1], out[0][1]):
+        assert np.max(np.abs(a - b)) <= 1e-8
+
+
 def test_landmark_shards_sum_to_the_unsharded_reduced_system():
     """What the multi-GPU all-reduce relies on, checked on ONE GPU: every shard built with the
     union block pattern, S and g summed on the host, compared with the unsharded system."""
