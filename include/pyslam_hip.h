@@ -173,6 +173,17 @@ int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters,
 int ps_gn_result(ps_problem* h, int* done, double* shard2, double* dx_pose_norm2,
                  int* pcg_iters_out, double* pcg_relres_out);
 
+/* Covariance by columns -- pyslam/problem.py:196-216 (compute_covariance inverts the whole sparse
+   precision matrix; get_covariance_block slices it).  ps_covariance_begin linearises at the current
+   parameters (lambda = 0) and prepares the reduced solver.  ps_covariance_column then solves
+   H x = e_k, e_k the unit vector of component `comp` of reduced pose `index` (kind 0) or of variable
+   landmark `index` (kind 1), by the hot path's own Schur elimination, CG and back-substitution:
+   x = column k of the covariance, left in the dx buffers (read it with ps_get_dx).  Scales to any
+   problem the iteration handles; no dense n x n matrix is ever formed. */
+int ps_covariance_begin(ps_problem* h);
+int ps_covariance_column(ps_problem* h, int kind, int index, int comp, double tol, int max_iters,
+                         int* iters_out, double* relres_out);
+
 /* Parity / debug taps (device -> host). */
 int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx,
                           double* vals, double* g);       /* BSR, dof x dof blocks */

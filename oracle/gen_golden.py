@@ -200,7 +200,7 @@ def case_stereo_ba_example():
         obs_groups=[[0., 0., 0., 0.]],
         pose_keys=['T_cam{}_w'.format(i) for i in range(4)],
         point_keys=['pt{}_w'.format(i) for i in range(3)]).finalize()
-    solve_case('stereo_ba_example', lp, example_options())
+    solve_case('stereo_ba_example', lp, example_options(), covariance_key=True)
     np.savez_compressed(os.path.join(OUT, 'stereo_ba_example_truth.npz'), points=pts,
                         poses=np.stack([T.as_matrix() for T in Ts]))
 
@@ -345,7 +345,7 @@ def main():
 
     lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=60, obs_per_lm=4, half_window=3, seed=5,
                                 loss=ref_losses_huber(1.5), const_point_fraction=0.1)
-    solve_case('ba_tiny_huber', lp, example_options())
+    solve_case('ba_tiny_huber', lp, example_options(), covariance_key=True)
     lp, _ = synthetic.stereo_ba(num_kf=6, num_lm=40, obs_per_lm=4, half_window=3, seed=6)
     solve_case('ba_tiny_nolinesearch', lp,
                example_options(linesearch_max_iters=0, max_nondecreasing_steps=5,

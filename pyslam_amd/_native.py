@@ -72,6 +72,8 @@ SIGNATURES = {
     'ps_shard_buffer': (C.c_int, [H, C.POINTER(C.c_void_p)]),
     'ps_gn_solve_finish_enqueue': (C.c_int, [H, C.c_double, C.c_int, C.c_int, C.c_int]),
     'ps_gn_result': (C.c_int, [H, C.POINTER(C.c_int), c_f64p, c_f64p, C.POINTER(C.c_int), c_f64p]),
+    'ps_covariance_begin': (C.c_int, [H]),
+    'ps_covariance_column': (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int), c_f64p]),
     'ps_get_reduced_system': (C.c_int, [H, c_i32p, c_i32p, c_f64p, c_f64p]),
     'ps_get_landmark_factors': (C.c_int, [H, c_f64p, c_f64p]),
     'ps_debug_reproj_blocks': (C.c_int, [H, c_f64p, c_f64p, c_f64p]),

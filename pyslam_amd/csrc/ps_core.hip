@@ -120,6 +120,8 @@ struct ps_problem {
     int cg_split_min_rows = 1024;
     double *cg_U = nullptr, *cg_cgd[2] = {}, *cg_ab = nullptr;
     int cg_launched = 0;            // CG launches enqueued since the last setup
+    bool cov_ready = false;         // ps_covariance_begin has linearised and set the reduced solver up; cleared by linearize()
+    std::vector<int32_t> h_slot_of_vid;
     int ell_wf = 0, ell_wc = 0;     // two-class ELL widths of the CG matrix (0 = CSR)
     // scalars
     double *cost_partials = nullptr, *scalars = nullptr, *h_scalars = nullptr;
@@ -406,7 +408,7 @@ int build_coarse(ps_problem* h) {
 }
 
 template <int D>
-int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false) {
+int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rhs_only = false) {
     const int nr = h->nr, cap = h->hist_cap;
     if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
     if (!h->coarse_built && build_coarse(h)) return -1;
@@ -415,6 +417,17 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false) {
     const int G = h->G, rows = h->nr_aug;
     const int32_t* rp = h->arow_ptr;
     const int32_t* ci = h->acol_idx;
+    if (rhs_only) {
+        // same matrix (and coarse factor) as the last full setup, new right-hand side h->g
+        hipLaunchKernelGGL(k_cg_prepare<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->g, h->Linv,
+                           h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh, h->status);
+        if (G)
+            hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, h->ncb, h->slo, h->shi, h->pnode,
+                               h->pw0, h->pw1, h->LciT2[h->lci_cur], h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
+                               h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 2, (const int32_t*)nullptr, h->status);
+        h->cg_launched = 0;
+        return 0;
+    }
     hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
                        h->S, h->Linv, h->status);
     hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
@@ -539,8 +552,8 @@ int cg_report(ps_problem* h, int* iters_out, double* relres_out) {
 
 // synchronous solve (staged API): poll the convergence flag every chunk
 template <int D>
-int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
-    if (cg_fused_setup<D>(h, max_iters)) return -1;
+int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out, bool rhs_only = false) {
+    if (cg_fused_setup<D>(h, max_iters, false, rhs_only)) return -1;
     int chunk = std::max(h->pcg_chunk, h->last_pcg_iters + 2);
     bool done = false;
     while (!done) {
@@ -557,6 +570,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
 }
 
 int linearize(ps_problem* h, double lambda) {
+    h->cov_ready = false;
     HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double) + ST_NWORDS * sizeof(int32_t), h->stream));   // [S | g | cost | status]
     if (h->nv > 0) {
         StageTimer t(h, PS_ST_LANDMARK);
@@ -1374,6 +1388,52 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
     // a slot whose reduction did not run (no reduced poses / no variable landmarks) is stale: count it as 0
     if (dx_norm_out) *dx_norm_out = std::sqrt((h->nr > 0 ? h->h_scalars[SC_DXP2] : 0.0) + (h->nv > 0 ? h->h_scalars[SC_DXL2] : 0.0));
+    return 0;
+}
+
+int ps_covariance_begin(ps_problem* h) {
+    if (!h) return fail("null argument");
+    if (linearize(h, 0.0)) return -1;
+    if (h->nr > 0 && h->pcg_variant == 1) {
+        const int rc = h->D == 6 ? cg_fused_setup<6>(h, 16) : cg_fused_setup<3>(h, 16);
+        if (rc) return -1;
+    }
+    if (read_scalars(h)) return -1;
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (h->h_status[ST_DIAG_FAIL]) return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+    if (h->h_slot_of_vid.size() != h->h_vid_of_slot.size()) {
+        h->h_slot_of_vid.assign(h->h_vid_of_slot.size(), 0);
+        for (size_t s2 = 0; s2 < h->h_vid_of_slot.size(); ++s2) h->h_slot_of_vid[h->h_vid_of_slot[s2]] = (int32_t)s2;
+    }
+    h->cov_ready = true;
+    return 0;
+}
+
+int ps_covariance_column(ps_problem* h, int kind, int index, int comp, double tol, int max_iters,
+                         int* iters_out, double* relres_out) {
+    if (!h) return fail("null argument");
+    if (!h->cov_ready) return fail("ps_covariance_column: call ps_covariance_begin first (any linearisation invalidates it)");
+    if (kind == 0 ? (index < 0 || index >= h->nr || comp < 0 || comp >= h->D)
+                  : (kind != 1 || index < 0 || index >= h->nv || comp < 0 || comp >= 3))
+        return fail("ps_covariance_column: parameter index / component out of range");
+    // right-hand side of H x = e in Schur form: c_l = C_l^-1 r_l, g = r_p - sum_l Z_l c_l
+    if (h->nr) HIP_OK(hipMemsetAsync(h->g, 0, (size_t)h->nr * h->D * sizeof(double), h->stream));
+    if (h->nv) HIP_OK(hipMemsetAsync(h->cvec, 0, (size_t)h->nv * 3 * sizeof(double), h->stream));
+    const int slot = kind == 1 ? h->h_slot_of_vid[index] : index;
+    hipLaunchKernelGGL(k_cov_rhs, dim3(1), dim3(64), 0, h->stream, kind, slot, comp, h->D, h->lm_ptr, h->lobs,
+                       h->pose_rid, h->Z, h->Cinv, h->g, h->cvec);
+    int its = 0; double rel = 0.0;
+    if (h->nr > 0) {
+        int rc;
+        if (h->pcg_variant == 1)
+            rc = h->D == 6 ? cg_fused_run<6>(h, tol, max_iters, &its, &rel, true) : cg_fused_run<3>(h, tol, max_iters, &its, &rel, true);
+        else
+            rc = h->D == 6 ? pcg_run<6>(h, tol, max_iters, &its, &rel) : pcg_run<3>(h, tol, max_iters, &its, &rel);
+        if (rc) return -1;
+    }
+    if (backsub(h)) return -1;
+    if (iters_out) *iters_out = its;
+    if (relres_out) *relres_out = rel;
     return 0;
 }
 

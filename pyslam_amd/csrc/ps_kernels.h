@@ -1488,6 +1488,31 @@ __global__ __launch_bounds__(256) void k_coarse_recover(
 // (status[ST_PCG_DONE]); ps_gn_iteration enqueues this tail right behind the CG launches
 // without a host synchronisation and re-runs it in the rare case the CG needed more launches.
 // ---------------------------------------------------------------------------
+// covariance column (ps_covariance_column): right-hand side of H x = e_k in Schur form.  g and cvec
+// are zero on entry.  kind 0: g[index*D + comp] = 1.  kind 1 (landmark slot `index`): c = column
+// comp of M = C^-1, and g_j -= Z_j c for every observation of the landmark on a variable pose
+// (one thread walks them: duplicates of a pose accumulate in a fixed order).
+__global__ __launch_bounds__(64) void k_cov_rhs(
+    int kind, int index, int comp, int D, const int32_t* __restrict__ lm_ptr, const LObs* __restrict__ lobs,
+    const int32_t* __restrict__ pose_rid, const double* __restrict__ Z, const double* __restrict__ Cinv,
+    double* __restrict__ g, double* __restrict__ cvec)
+{
+    if (threadIdx.x != 0) return;
+    if (kind == 0) { g[(size_t)index * D + comp] = 1.0; return; }
+    const double* m = Cinv + 6 * (size_t)index;          // M00 M10 M11 M20 M21 M22
+    double c[3] = {0.0, 0.0, 0.0};
+    if (comp == 0) { c[0] = m[0]; c[1] = m[1]; c[2] = m[3]; }
+    else if (comp == 1) { c[1] = m[2]; c[2] = m[4]; }
+    else c[2] = m[5];
+    cvec[3 * (size_t)index] = c[0]; cvec[3 * (size_t)index + 1] = c[1]; cvec[3 * (size_t)index + 2] = c[2];
+    for (int i = lm_ptr[index]; i < lm_ptr[index + 1]; ++i) {
+        const int rid = pose_rid[PS_POSE_OF(lobs[i])];
+        if (rid < 0) continue;
+        const double* z = Z + 18 * (size_t)i;
+        for (int a = 0; a < 6; ++a) g[(size_t)rid * 6 + a] -= z[3 * a] * c[0] + z[3 * a + 1] * c[1] + z[3 * a + 2] * c[2];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_backsub(
     int nv, const int32_t* __restrict__ lm_ptr, const LObs* __restrict__ lobs,
     const int32_t* __restrict__ pose_rid, const double* __restrict__ Z,

@@ -137,6 +137,19 @@ class DeviceProblem:
     def restore(self):
         nat.check(self._lib.ps_restore_params(self._h))
 
+    # ---- covariance by columns (reference problem.py:196-216) ------------
+    def covariance_begin(self):
+        """Linearise at the current parameters and prepare the reduced solver."""
+        nat.check(self._lib.ps_covariance_begin(self._h))
+
+    def covariance_column(self, kind, index, comp, tol=1e-13, max_iters=4000):
+        """Column of the covariance (J^T W J)^-1 for component `comp` of reduced pose `index`
+        (kind 0) or variable landmark `index` (kind 1): (pose part (nr, dof), point part (nv, 3))."""
+        rel, it = C.c_double(), C.c_int()
+        nat.check(self._lib.ps_covariance_column(self._h, int(kind), int(index), int(comp), tol, max_iters,
+                                                 C.byref(it), C.byref(rel)))
+        return self.get_dx()
+
     # ---- data movement -------------------------------------------------
     def get_dx(self):
         """(dx_pose (nr, dof), dx_point (nv, 3)) in device order."""

@@ -297,20 +297,78 @@ class Problem:
     # ------------------------------------------------------------------
     # covariance (reference problem.py:196-216)
     # ------------------------------------------------------------------
+    #
+    # Typed problems: column k of the covariance is the solution of (J^T W J) x = e_k, computed on the
+    # device by the iteration's own Schur elimination + CG + back-substitution (one call per scalar
+    # unknown of the requested parameter), so blocks are available at any problem size.  The full
+    # dense ``_covariance_matrix`` the reference exposes is materialised only while it is small
+    # (<= DENSE_COVARIANCE_LIMIT unknowns); beyond that ``get_covariance_block`` computes columns on demand.
+    DENSE_COVARIANCE_LIMIT = 1500
+
     def compute_covariance(self):
         try:
-            from pyslam_amd.device import dense_normal_solve
             if not self._update_partition_dict:
                 self._update_partition_dict = self._get_update_partition_dict()
-            J, e, _ = self._host_jacobian()
-            _, self._covariance_matrix = dense_normal_solve(J, e, want_covariance=True)
+            self._covariance_matrix = None
+            self._cov_columns = {}
+            try:
+                dev = self._get_device()
+            except NotLowerable:
+                dev = None
+            if dev is None:
+                from pyslam_amd.device import dense_normal_solve
+                J, e, _ = self._host_jacobian()
+                _, self._covariance_matrix = dense_normal_solve(J, e, want_covariance=True)
+                return
+            dev.covariance_begin()
+            self._cov_device = dev
+            # scatter maps device order -> reference ordering (vectorised: C3 has 50 000 landmarks)
+            lp, part = dev.lp, self._update_partition_dict
+            self._cov_where = {}
+            sel = [(k, int(rid)) for k, rid in zip(lp.pose_keys, lp.pose_rid) if rid >= 0]
+            for k, rid in sel:
+                self._cov_where[k] = (0, rid, lp.dof)
+            self._cov_pose_src = np.array([rid for _, rid in sel], dtype=np.int64)
+            self._cov_pose_dst = (np.array([part[k].start for k, _ in sel], dtype=np.int64)[:, None]
+                                  + np.arange(lp.dof)[None, :]).reshape(-1)
+            sel = [(k, int(vid)) for k, vid in zip(lp.point_keys, lp.point_vid) if vid >= 0]
+            for k, vid in sel:
+                self._cov_where[k] = (1, vid, 3)
+            self._cov_point_src = np.array([vid for _, vid in sel], dtype=np.int64)
+            self._cov_point_dst = (np.array([part[k].start for k, _ in sel], dtype=np.int64)[:, None]
+                                   + np.arange(3)[None, :]).reshape(-1)
+            n = max([r.stop for r in part.values()] + [0])
+            if n <= self.DENSE_COVARIANCE_LIMIT:
+                cov = np.zeros((n, n))
+                for key, r in part.items():
+                    cov[:, r] = self._covariance_columns(key)
+                self._covariance_matrix = 0.5 * (cov + cov.T)
         except Exception as e:
             print('Covariance computation failed!\n{}'.format(e))
+
+    def _covariance_columns(self, key):
+        """(n, dof_key) column block of the covariance for parameter `key`, reference ordering."""
+        if key in self._cov_columns:
+            return self._cov_columns[key]
+        kind, index, width = self._cov_where[key]          # KeyError: constant / unknown parameter
+        n = max([r.stop for r in self._update_partition_dict.values()] + [0])
+        cols = np.zeros((n, width))
+        for c in range(width):
+            xp, xl = self._cov_device.covariance_column(kind, index, c)
+            if self._cov_pose_src.size:
+                cols[self._cov_pose_dst, c] = xp[self._cov_pose_src].reshape(-1)
+            if self._cov_point_src.size:
+                cols[self._cov_point_dst, c] = xl[self._cov_point_src].reshape(-1)
+        if len(self._cov_columns) < 64:
+            self._cov_columns[key] = cols
+        return cols
 
     def get_covariance_block(self, param0, param1):
         try:
             r0 = self._update_partition_dict[param0]
             r1 = self._update_partition_dict[param1]
+            if self._covariance_matrix is None and getattr(self, '_cov_device', None) is not None:
+                return np.squeeze(self._covariance_columns(param1)[r0.start:r0.stop, :])
             return np.squeeze(self._covariance_matrix[r0.start:r0.stop, r1.start:r1.stop])
         except KeyError as e:
             print('Cannot compute covariance for constant parameter {}'.format(e.args[0]))

@@ -303,3 +303,35 @@ def test_rgbd_camera_reprojection_blocks():
         assert np.linalg.norm(SE3.log(out['T{}'.format(i)].inv().dot(T))) < 1e-6
     for j, p in enumerate(pts):
         assert np.linalg.norm(out['p{}'.format(j)] - p) < 1e-6
+
+@pytest.mark.parametrize('name', ['stereo_ba_example', 'ba_tiny_huber', 'posegraph_2d_example', 'posegraph_3d_example'])
+def test_covariance_matches_reference(name):
+    """compute_covariance / get_covariance_block (reference problem.py:196-216) on typed problems:
+    the device computes covariance columns with the iteration's own Schur + CG + back-substitution;
+    the golden matrices are the reference's splinalg.inv(precision) after its own solve."""
+    import pyslam_amd.synthetic as synthetic
+    from test_host_api import build_namespace
+    g = load_golden(name)
+    lp = golden_lp(g)
+    ns = build_namespace()
+    opt = ns.Options()
+    for k, v in golden_options(g).items():
+        setattr(opt, k, v)
+    problem = synthetic.to_objects(lp, ns, opt, points_first=bool(g.get('points_first', True)))
+    problem.solve()
+    problem.compute_covariance()
+    ref = g['covariance']
+    cov = problem._covariance_matrix
+    assert cov.shape == ref.shape
+    assert np.linalg.norm(cov - ref) <= 1e-9 * np.linalg.norm(ref)
+    part = problem._update_partition_dict
+    keys = list(part.keys())
+    # on-demand blocks (the large-problem path: no dense matrix is kept)
+    problem.DENSE_COVARIANCE_LIMIT = 0
+    problem.compute_covariance()
+    assert problem._covariance_matrix is None
+    for k0, k1 in ((keys[0], keys[-1]), (keys[-1], keys[-1]), (keys[-1], keys[0]), (keys[len(keys) // 2], keys[1])):
+        blk = problem.get_covariance_block(k0, k1)
+        want = np.squeeze(ref[part[k0].start:part[k0].stop, part[k1].start:part[k1].stop])
+        assert np.abs(blk - want).max() <= 1e-9 * np.abs(ref).max(), (k0, k1)
+    assert problem.get_covariance_block(keys[0], 'not a parameter') is None

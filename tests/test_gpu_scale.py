@@ -196,3 +196,22 @@ def test_solve_one_iter_api_does_not_move_parameters():
     for k, v in problem.param_dict.items():
         now = v if isinstance(v, np.ndarray) else v.as_matrix()
         assert np.array_equal(now, before[k])
+
+def test_c3_covariance_columns_solve_the_reference_precision(c3):
+    """Covariance columns at BASELINE size (151 194 unknowns): H x = e_k must hold for the oracle's
+    (reference algebra) precision matrix H, for a pose and a landmark column."""
+    dev = device(c3)
+    dev.covariance_begin()
+    P, _, _ = orc.normal_equations(c3, points_first=False)
+    d, nr = c3.dof, c3.num_reduced
+    for kind, index, comp in ((0, 57, 4), (1, 31337, 1)):
+        xp, xl = dev.covariance_column(kind, index, comp)
+        x = np.concatenate([xp.ravel(), xl.ravel()])
+        e = np.zeros_like(x)
+        e[(index * d + comp) if kind == 0 else (nr * d + index * 3 + comp)] = 1.
+        res = P.dot(x) - e
+        # scale-free check: the residual measured in the norm of the diagonal of H
+        dg = np.sqrt(P.diagonal())
+        assert np.linalg.norm(res / dg) <= 1e-8 * np.linalg.norm(x * dg), (kind, index)
+        k = (index * d + comp) if kind == 0 else (nr * d + index * 3 + comp)
+        assert x[k] > 0.                                       # a variance
