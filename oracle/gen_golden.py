@@ -50,6 +50,7 @@ NS = types.SimpleNamespace(
     StereoCamera=ref_sensors.StereoCamera,
     PoseResidual=ref_residuals.PoseResidual,
     PoseToPoseResidual=ref_residuals.PoseToPoseResidual,
+    PoseToPoseOrientationResidual=ref_residuals.PoseToPoseOrientationResidual,
     ReprojectionResidual=ref_residuals.ReprojectionResidual,
     L2Loss=ref_losses.L2Loss, L1Loss=ref_losses.L1Loss, CauchyLoss=ref_losses.CauchyLoss,
     HuberLoss=ref_losses.HuberLoss, TukeyLoss=ref_losses.TukeyLoss,
@@ -356,6 +357,9 @@ def main():
     solve_case('pg_small_huber', lp, example_options())
     lp, _ = synthetic.pose_graph(num_poses=100, num_loops=150, dof=3, seed=4)
     solve_case('pg2d_small_huber', lp, example_options())
+    # rotation-only loop closures (reference residuals/pose_to_pose_orientation_residual.py)
+    lp, _ = synthetic.pose_graph(num_poses=30, num_loops=60, dof=6, seed=7, orientation_loops=True)
+    solve_case('pg_orientation_huber', lp, example_options(), covariance_key=True)
 
 
 def ref_losses_huber(k):

@@ -475,9 +475,10 @@ __global__ __launch_bounds__(256) void k_factor_pass(
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             double rk = 0.0;
-#pragma unroll
-            for (int m = 0; m < D; ++m) rk += grp.S[k * D + m] * xi[m];
-            s[k] = sqrt(ps_loss_weight(grp.loss_id, grp.loss_k, rk));
+            bool present = false;               // an all-zero stiffness row is an absent residual row
+#pragma unroll                                  // (rotation-only edges, lowering.py): no weight, no 0 * inf
+            for (int m = 0; m < D; ++m) { rk += grp.S[k * D + m] * xi[m]; present = present || grp.S[k * D + m] != 0.0; }
+            s[k] = present ? sqrt(ps_loss_weight(grp.loss_id, grp.loss_k, rk)) : 0.0;
             if (lane == 0) sr[w][k] = s[k] * rk;
         }
         if (act) {

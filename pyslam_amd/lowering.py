@@ -329,6 +329,29 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
                 u_i.append(pose_ix[keys[0]])
                 u_T.append(pack_pose(obs.inv()))
                 u_g.append(g)
+        elif kind == 'pose_pose_orientation':
+            # Rotation-only relative measurement (reference pose_to_pose_orientation_residual.py:4-38)
+            # as a pose-pose edge: T_obs = (C_obs, 0) and the 3x3 stiffness embedded in the rotational
+            # corner of a 6x6 one.  Then S6 log(T_2 T_1^-1 T_obs^-1) = [0; S3 log(C_2 C_1^T C_obs^T)],
+            # -S6 Ad(T_2 T_1^-1) = [0 0; 0 -S3 C_21] and S6 = [0 0; 0 S3]: exactly the reference's
+            # residual and 3x6 Jacobians, padded with three absent (all-zero) rows the kernels skip.
+            if dof != 6 or any(k not in pose_ix for k in keys):
+                raise NotLowerable("orientation block needs two SE(3) poses")
+            if getattr(block.obstype, 'dof', None) != 3 or np.size(block.stiffness) != 9:
+                raise NotLowerable("orientation block needs an SO(3) observation and a 3x3 stiffness")
+            gkey = (id(block.stiffness), id(loss), 'orientation')
+            g = egrp_cache.get(gkey)
+            if g is None:
+                S6 = np.zeros((6, 6))
+                S6[3:, 3:] = np.asarray(block.stiffness, dtype=F64).reshape(3, 3)
+                g = egrp.add([std.add(S6), lid, lk])
+                egrp_cache[gkey] = g
+            Tinv = np.zeros(12)
+            Tinv[:9] = np.asarray(block.C_2_1_obs.inv().as_matrix(), dtype=F64).reshape(-1)
+            e_i.append(pose_ix[keys[0]])
+            e_j.append(pose_ix[keys[1]])
+            e_T.append(Tinv)
+            e_g.append(g)
         else:
             raise NotLowerable("block {} has no typed device kernel".format(type(block).__name__))
 

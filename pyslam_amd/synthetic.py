@@ -136,8 +136,11 @@ def stereo_ba(num_kf=200, num_lm=50000, obs_per_lm=10, half_window=20, seed=0,
 # C2: SE(3) pose graph;  C1-style: SE(2) pose graph
 # ---------------------------------------------------------------------------
 def pose_graph(num_poses=10000, num_loops=40001, dof=6, seed=2, loss=None,
-               prior_first=True, const_first=False, init_noise=0.02, meas_noise=0.01):
-    """Noisy helix (SE3) / arc (SE2) with odometry + short-range loop closures."""
+               prior_first=True, const_first=False, init_noise=0.02, meas_noise=0.01,
+               orientation_loops=False):
+    """Noisy helix (SE3) / arc (SE2) with odometry + short-range loop closures.
+    orientation_loops (SE3): the loop closures measure the relative ROTATION only
+    (reference residuals/pose_to_pose_orientation_residual.py), lowered as lowering.py does."""
     loss = loss if loss is not None else losses.HuberLoss(1.0)
     group = SE3 if dof == 6 else SE2
     rng = np.random.default_rng(seed)
@@ -167,12 +170,23 @@ def pose_graph(num_poses=10000, num_loops=40001, dof=6, seed=2, loss=None,
     if const_first:
         rid = rid - 1
         T_init[0] = T_true[0]
+    e_grp = np.zeros(ei.size)
+    stiffd = [odom.ravel(), prior.ravel()]
+    edge_groups = [[0., *_loss_row(loss)], [1., *_loss_row(losses.L2Loss())]]
+    if orientation_loops:
+        assert dof == 6
+        meas[num_poses - 1:, :3, 3] = 0.           # T_obs = (C_obs, 0)
+        S6 = np.zeros((6, 6))
+        S6[3:, 3:] = invsqrt(1e-3 * np.identity(3))
+        stiffd.append(S6.ravel())
+        edge_groups.append([2., *_loss_row(loss)])
+        e_grp[num_poses - 1:] = 2
     lp = LoweredProblem(
         dof=dof, poses=pack_pose_matrices(T_init), pose_rid=rid,
         e_i=ei, e_j=ej, e_Tobs_inv=pack_pose_matrices(_inv_many(meas)),
-        e_grp=np.zeros(ei.size),
-        stiffd=np.stack([odom.ravel(), prior.ravel()]),
-        edge_groups=np.array([[0., *_loss_row(loss)], [1., *_loss_row(losses.L2Loss())]]),
+        e_grp=e_grp,
+        stiffd=np.stack(stiffd),
+        edge_groups=np.array(edge_groups),
         pose_keys=['T_{}_0'.format(i) for i in range(num_poses)])
     if prior_first and not const_first:
         lp.u_i = [0]
@@ -249,8 +263,13 @@ def to_objects(lp, ns, options=None, points_first=True):
     for i, Tinv, g in zip(lp.u_i, pose_objects(lp.u_Tobs_inv, lp.dof, ns), lp.u_grp):
         problem.add_residual_block(ns.PoseResidual(Tinv.inv(), eg[g][0]), [pkeys[i]], eg[g][1])
     for i, j, Tinv, g in zip(lp.e_i, lp.e_j, pose_objects(lp.e_Tobs_inv, lp.dof, ns), lp.e_grp):
-        problem.add_residual_block(ns.PoseToPoseResidual(Tinv.inv(), eg[g][0]),
-                                   [pkeys[i], pkeys[j]], eg[g][1])
+        S = eg[g][0]
+        if lp.dof == 6 and not S[:3, :].any() and not S[:, :3].any():
+            # rotation-only edge (lowering.py: 3x3 stiffness embedded in the rotational corner)
+            block = ns.PoseToPoseOrientationResidual(Tinv.inv().rot, S[3:, 3:].copy())
+        else:
+            block = ns.PoseToPoseResidual(Tinv.inv(), S)
+        problem.add_residual_block(block, [pkeys[i], pkeys[j]], eg[g][1])
     for i, j, uvd, g in zip(lp.obs_pose, lp.obs_point, lp.obs_uvd, lp.obs_grp):
         cam, S, loss = og[g]
         problem.add_residual_block(ns.ReprojectionResidual(cam, uvd.copy(), S),

@@ -304,7 +304,8 @@ def test_rgbd_camera_reprojection_blocks():
     for j, p in enumerate(pts):
         assert np.linalg.norm(out['p{}'.format(j)] - p) < 1e-6
 
-@pytest.mark.parametrize('name', ['stereo_ba_example', 'ba_tiny_huber', 'posegraph_2d_example', 'posegraph_3d_example'])
+@pytest.mark.parametrize('name', ['stereo_ba_example', 'ba_tiny_huber', 'posegraph_2d_example', 'posegraph_3d_example',
+                                  'pg_orientation_huber'])
 def test_covariance_matches_reference(name):
     """compute_covariance / get_covariance_block (reference problem.py:196-216) on typed problems:
     the device computes covariance columns with the iteration's own Schur + CG + back-substitution;

@@ -19,6 +19,7 @@ def build_namespace():
     return types.SimpleNamespace(
         Problem=P.Problem, Options=P.Options, StereoCamera=S.StereoCamera,
         PoseResidual=R.PoseResidual, PoseToPoseResidual=R.PoseToPoseResidual,
+        PoseToPoseOrientationResidual=R.PoseToPoseOrientationResidual,
         ReprojectionResidual=R.ReprojectionResidual,
         L2Loss=Ls.L2Loss, L1Loss=Ls.L1Loss, CauchyLoss=Ls.CauchyLoss, HuberLoss=Ls.HuberLoss,
         TukeyLoss=Ls.TukeyLoss, TDistributionLoss=Ls.TDistributionLoss,
@@ -285,3 +286,28 @@ def test_solver_fails_loudly_without_gpu():
     from pyslam_amd.device import DeviceProblem
     with pytest.raises(_native.NativeError):
         DeviceProblem(lp)
+
+
+def test_orientation_residual_lowers_to_a_rotation_only_edge():
+    """PoseToPoseOrientationResidual (reference pose_to_pose_orientation_residual.py:4-38) becomes a
+    pose-pose edge with T_obs = (C_obs, 0) and the 3x3 stiffness in the rotational corner of a 6x6 one;
+    the lowered tables reproduce the class's own residual and Jacobians through the numpy oracle."""
+    from liegroups import SE3, SO3
+    from pyslam.residuals import PoseToPoseOrientationResidual
+    from pyslam.losses import L2Loss
+    from pyslam_amd import lowering
+    from oracle import gn_oracle as orc
+    rng = np.random.default_rng(3)
+    T1, T2 = SE3.exp(rng.standard_normal(6) * 0.3), SE3.exp(rng.standard_normal(6) * 0.3)
+    C_obs = SO3.exp(rng.standard_normal(3) * 0.3)
+    S3 = np.diag([2., 3., 5.]) + 0.1 * rng.standard_normal((3, 3))
+    block = PoseToPoseOrientationResidual(C_obs, S3)
+    lp = lowering.lower({'a': T1, 'b': T2}, [block], [['a', 'b']], [L2Loss()], [])
+    assert lp.num_edges == 1 and lp.dof == 6
+    S6 = lp.stiffd[int(lp.edge_groups[lp.e_grp[0], 0])].reshape(6, 6)
+    assert not S6[:3].any() and not S6[:, :3].any() and np.array_equal(S6[3:, 3:], S3)
+    r, J1, J2 = orc.eval_edges(lp)
+    r_ref, (j1_ref, j2_ref) = block.evaluate([T1, T2], [True, True])
+    assert np.allclose(r[0, :3], 0.) and np.allclose(r[0, 3:], r_ref, atol=1e-14)
+    assert np.allclose(J1[0, 3:], j1_ref, atol=1e-14) and np.allclose(J2[0, 3:], j2_ref, atol=1e-14)
+    assert not J1[0, :3].any() and not J2[0, :3].any()
