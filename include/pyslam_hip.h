@@ -206,6 +206,23 @@ int ps_get_stage_times(ps_problem* h, double* ms /* PS_NUM_STAGES */, int64_t* c
 int ps_dense_normal_solve(const double* J, const double* r, int32_t m, int32_t n,
                           double* dx, double* covariance /* n*n or NULL */);
 
+/* Frame-to-frame RANSAC, the step before the motion-only solve in the reference's sparse VO pipeline
+   (pyslam/pipelines/sparse.py:148-150).  Stateless; host pointers in, host pointers out.
+   ps_ransac_transforms   -- compute_transform_fast (pyslam/pipelines/ransac.py:13-67): `batch` rigid
+                             alignments p_2 ~ C p_1 + r of n-point sets (pts: batch x n x 3), 4x4 out.
+   ps_ransac_cost         -- FrameToFrameRANSAC.compute_ransac_cost (:153-165): inlier masks
+                             (num_hyp x num_pts bytes) and counts of given 4x4 transforms; cam5 = cu cv fu fv b.
+   ps_ransac_frame_to_frame -- perform_ransac (:113-151) without the random draw: hypotheses from the
+                             caller's sample indices (num_hyp x set_size), scoring of all points, first
+                             hypothesis with the most inliers, its transform and inlier mask. */
+int ps_ransac_transforms(const double* pts_1, const double* pts_2, int32_t batch, int32_t n, double* T_out);
+int ps_ransac_cost(const double* T, int32_t num_hyp, const double* pts_1, const double* obs_2, int32_t num_pts,
+                   const double* cam5, double thresh, uint8_t* masks, int32_t* counts);
+int ps_ransac_frame_to_frame(const double* pts_1, const double* pts_2, const double* obs_2, int32_t num_pts,
+                             const int32_t* sample_idx, int32_t num_hyp, int32_t set_size, const double* cam5,
+                             double thresh, double* T_all, int32_t* counts, int32_t* best_index,
+                             int32_t* best_count, double* T_best, uint8_t* best_mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -334,6 +334,40 @@ def case_losses_sensors():
     save('losses_sensors', **out)
 
 
+def case_ransac():
+    """Frame-to-frame RANSAC (reference pipelines/ransac.py:97-165) on a seeded two-frame scene with
+    25 % gross outliers; the reference draws its minimal sets with np.random.randint, so the draw is
+    replayed under the same seed to record the sample indices."""
+    # the package __init__ imports every pipeline (cv2, viso2): load the one module by path instead
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_ransac', os.path.join(REF, 'pyslam', 'pipelines', 'ransac.py'))
+    ref_ransac = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_ransac)
+    rng = np.random.default_rng(11)
+    cam = ref_sensors.StereoCamera(*synthetic.STEREO_BA_CAMERA)
+    N = 300
+    T_21 = liegroups.SE3.exp(np.array([0.3, -0.05, 0.1, 0.02, -0.04, 0.03]))
+    pts_1 = np.stack([rng.uniform(-6, 6, N), rng.uniform(-3, 3, N), rng.uniform(5, 30, N)], axis=1)
+    obs_1 = cam.project(pts_1) + 0.2 * rng.standard_normal((N, 3))
+    obs_2 = cam.project(T_21.dot(pts_1)) + 0.2 * rng.standard_normal((N, 3))
+    bad = rng.choice(N, N // 4, replace=False)
+    obs_2[bad, :2] += rng.uniform(20, 60, (bad.size, 2)) * rng.choice([-1., 1.], (bad.size, 2))
+    r = ref_ransac.FrameToFrameRANSAC(cam)
+    r.set_obs(obs_1, obs_2)
+    np.random.seed(1234)
+    rand_idx = np.random.randint(r.num_pts, size=(r.ransac_iters, r.num_min_set_pts))
+    T_stacked = ref_ransac.compute_transform_fast(r.pts_1[rand_idx], r.pts_2[rand_idx], ref_ransac.SE3_SHAPE)
+    masks = r.compute_ransac_cost(T_stacked, r.pts_1, r.obs_2, cam, r.ransac_thresh)
+    np.random.seed(1234)
+    T_best, o1, o2, inl = r.perform_ransac()
+    assert np.array_equal(inl, np.where(masks[np.argmax(masks.sum(axis=1))])[0])
+    save('ransac', cam=np.array(synthetic.STEREO_BA_CAMERA, dtype=float), obs_1=obs_1, obs_2=obs_2,
+         pts_1=r.pts_1, pts_2=r.pts_2, seed=np.array(1234), rand_idx=rand_idx, thresh=np.array(float(r.ransac_thresh)),
+         T_stacked=T_stacked, inlier_counts=masks.sum(axis=1), T_best=T_best.as_matrix(), inlier_indices=inl,
+         obs_1_inliers=o1, obs_2_inliers=o2, T_true=T_21.as_matrix(), outliers=np.sort(bad))
+    print('  ransac: best hypothesis has {} / {} inliers ({} true outliers)'.format(len(inl), N, bad.size))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     case_losses_sensors()
@@ -343,6 +377,7 @@ def main():
     _posegraph_example(3)
     _posegraph_example(6)
     case_motion_only()
+    case_ransac()
 
     lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=60, obs_per_lm=4, half_window=3, seed=5,
                                 loss=ref_losses_huber(1.5), const_point_fraction=0.1)

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libpyslam_hip.so')
 
 c_i32p = C.POINTER(C.c_int32)
 c_f64p = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
 PS_NUM_STAGES = 10
 STAGE_NAMES = ['landmark_pass', 'pose_pass', 'schur_pairs', 'pose_factors', 'pcg',
                'backsub', 'update', 'cost', 'iteration_total', 'reserved']
@@ -80,6 +81,10 @@ SIGNATURES = {
     'ps_set_option': (C.c_int, [H, C.c_char_p, C.c_double]),
     'ps_set_profiling': (C.c_int, [H, C.c_int]),
     'ps_get_stage_times': (C.c_int, [H, c_f64p, C.POINTER(C.c_int64), C.c_int]),
+    'ps_ransac_transforms': (C.c_int, [c_f64p, c_f64p, C.c_int32, C.c_int32, c_f64p]),
+    'ps_ransac_cost': (C.c_int, [c_f64p, C.c_int32, c_f64p, c_f64p, C.c_int32, c_f64p, C.c_double, c_u8p, c_i32p]),
+    'ps_ransac_frame_to_frame': (C.c_int, [c_f64p, c_f64p, c_f64p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f64p,
+                                           C.c_double, c_f64p, c_i32p, c_i32p, c_i32p, c_f64p, c_u8p]),
     'ps_dense_normal_solve': (C.c_int, [c_f64p, c_f64p, C.c_int32, C.c_int32, c_f64p, c_f64p]),
 }
 

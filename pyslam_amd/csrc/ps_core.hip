@@ -16,6 +16,7 @@
 
 #include "pyslam_hip.h"
 #include "ps_kernels.h"
+#include "ps_ransac.h"
 
 namespace {
 
@@ -736,6 +737,20 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         count = std::max(8, h->cg_launched / 2);
     }
     return cg_report(h, iters_out, relres_out);
+}
+}  // namespace
+
+namespace {
+struct DevBuf {                      // scoped device allocation for the stateless entry points
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : fail("hipMalloc failed"); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+int need_device() {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible");
+    return 0;
 }
 }  // namespace
 
@@ -1548,6 +1563,80 @@ int ps_dense_normal_solve(const double* J, const double* r, int32_t m, int32_t n
     }
     hipFree(dJ); hipFree(dr); hipFree(dH); hipFree(dB); hipFree(dst); hipFree(dg);
     if (st[ST_DIAG_FAIL]) return fail("normal matrix is not positive definite");
+    return 0;
+}
+
+// ---- frame-to-frame RANSAC (reference pyslam/pipelines/ransac.py) -------------------------------
+int ps_ransac_transforms(const double* pts_1, const double* pts_2, int32_t batch, int32_t n, double* T_out) {
+    if (!pts_1 || !pts_2 || !T_out || batch < 0 || n <= 0) return fail("bad argument");
+    if (batch == 0) return 0;
+    if (need_device()) return -1;
+    const size_t nb = (size_t)batch * n * 3 * sizeof(double);
+    DevBuf a, b, t;
+    if (a.get(nb) || b.get(nb) || t.get((size_t)batch * 16 * sizeof(double))) return -1;
+    HIP_OK(hipMemcpy(a.p, pts_1, nb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(b.p, pts_2, nb, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ransac_transforms, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, a.as<double>(), b.as<double>(),
+                       t.as<double>());
+    HIP_OK(hipMemcpy(T_out, t.p, (size_t)batch * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ps_ransac_cost(const double* T, int32_t num_hyp, const double* pts_1, const double* obs_2, int32_t num_pts,
+                   const double* cam5, double thresh, uint8_t* masks, int32_t* counts) {
+    if (!T || !pts_1 || !obs_2 || !cam5 || num_hyp < 0 || num_pts < 0) return fail("bad argument");
+    if (num_hyp == 0) return 0;
+    if (need_device()) return -1;
+    DevBuf dT, dp, dobs, dcam, dcnt, dmask;
+    const size_t pb = (size_t)num_pts * 3 * sizeof(double);
+    if (dT.get((size_t)num_hyp * 16 * sizeof(double)) || dp.get(pb) || dobs.get(pb) || dcam.get(5 * sizeof(double)) ||
+        dcnt.get((size_t)num_hyp * sizeof(int32_t)) || dmask.get((size_t)num_hyp * num_pts)) return -1;
+    HIP_OK(hipMemcpy(dT.p, T, (size_t)num_hyp * 16 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dp.p, pts_1, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dobs.p, obs_2, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dcam.p, cam5, 5 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ransac_hypotheses, dim3(num_hyp), dim3(256), 0, 0, num_pts, 0, (const int32_t*)nullptr,
+                       dp.as<double>(), (const double*)nullptr, dobs.as<double>(), dcam.as<double>(), thresh,
+                       dT.as<double>(), dcnt.as<int32_t>(), dmask.as<uint8_t>());
+    if (masks) HIP_OK(hipMemcpy(masks, dmask.p, (size_t)num_hyp * num_pts, hipMemcpyDeviceToHost));
+    if (counts) HIP_OK(hipMemcpy(counts, dcnt.p, (size_t)num_hyp * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_OK(hipDeviceSynchronize());
+    return 0;
+}
+
+int ps_ransac_frame_to_frame(const double* pts_1, const double* pts_2, const double* obs_2, int32_t num_pts,
+                             const int32_t* sample_idx, int32_t num_hyp, int32_t set_size, const double* cam5,
+                             double thresh, double* T_all, int32_t* counts, int32_t* best_index,
+                             int32_t* best_count, double* T_best, uint8_t* best_mask) {
+    if (!pts_1 || !pts_2 || !obs_2 || !sample_idx || !cam5 || num_pts <= 0 || num_hyp <= 0 || set_size <= 0)
+        return fail("bad argument");
+    for (size_t k = 0; k < (size_t)num_hyp * set_size; ++k)
+        if (sample_idx[k] < 0 || sample_idx[k] >= num_pts) return fail("sample index out of range");
+    if (need_device()) return -1;
+    DevBuf dp1, dp2, dobs, dcam, didx, dT, dcnt, dmask, dbest, dTb, dbm;
+    const size_t pb = (size_t)num_pts * 3 * sizeof(double);
+    if (dp1.get(pb) || dp2.get(pb) || dobs.get(pb) || dcam.get(5 * sizeof(double)) ||
+        didx.get((size_t)num_hyp * set_size * sizeof(int32_t)) || dT.get((size_t)num_hyp * 16 * sizeof(double)) ||
+        dcnt.get((size_t)num_hyp * sizeof(int32_t)) || dmask.get((size_t)num_hyp * num_pts) ||
+        dbest.get(2 * sizeof(int32_t)) || dTb.get(16 * sizeof(double)) || dbm.get((size_t)num_pts)) return -1;
+    HIP_OK(hipMemcpy(dp1.p, pts_1, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dp2.p, pts_2, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dobs.p, obs_2, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dcam.p, cam5, 5 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(didx.p, sample_idx, (size_t)num_hyp * set_size * sizeof(int32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ransac_hypotheses, dim3(num_hyp), dim3(256), 0, 0, num_pts, set_size, didx.as<int32_t>(),
+                       dp1.as<double>(), dp2.as<double>(), dobs.as<double>(), dcam.as<double>(), thresh,
+                       dT.as<double>(), dcnt.as<int32_t>(), dmask.as<uint8_t>());
+    hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(256), 0, 0, num_hyp, num_pts, dcnt.as<int32_t>(), dT.as<double>(),
+                       dmask.as<uint8_t>(), dbest.as<int32_t>(), dTb.as<double>(), dbm.as<uint8_t>());
+    int32_t bi[2];
+    HIP_OK(hipMemcpy(bi, dbest.p, sizeof(bi), hipMemcpyDeviceToHost));
+    if (best_index) *best_index = bi[0];
+    if (best_count) *best_count = bi[1];
+    if (T_best) HIP_OK(hipMemcpy(T_best, dTb.p, 16 * sizeof(double), hipMemcpyDeviceToHost));
+    if (best_mask) HIP_OK(hipMemcpy(best_mask, dbm.p, (size_t)num_pts, hipMemcpyDeviceToHost));
+    if (T_all) HIP_OK(hipMemcpy(T_all, dT.p, (size_t)num_hyp * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    if (counts) HIP_OK(hipMemcpy(counts, dcnt.p, (size_t)num_hyp * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 0;
 }
 
