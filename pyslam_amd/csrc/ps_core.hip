@@ -55,7 +55,7 @@ struct ps_problem {
     LObs* lobs = nullptr;
     int32_t *lorig = nullptr, *lm_ptr = nullptr, *lm_point = nullptr;
     double *Z = nullptr, *Cinv = nullptr, *cvec = nullptr, *dxl = nullptr;
-    int32_t* pidx = nullptr;
+    LObs* pobs = nullptr;           // observation records in pose-sorted order (landmark slot + 1 in the pose bits)
     PItem* pitems = nullptr;
     int npitems = 0;
     int32_t* pitem_ptr = nullptr;
@@ -581,8 +581,8 @@ int linearize(ps_problem* h, double lambda) {
     }
     if (h->npitems > 0) {
         StageTimer t(h, PS_ST_POSE);
-        hipLaunchKernelGGL(k_pose_pass, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pidx, h->lobs,
-                           h->poses, h->points, h->point_vid, h->ogroups, h->Z, h->cvec, h->ppartial);
+        hipLaunchKernelGGL(k_pose_pass, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
+                           h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial);
         hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
                            h->ppartial, h->diag_slot, lambda, h->S, h->g);
     }
@@ -898,14 +898,26 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pidx[fill[r]++] = (int32_t)k; }
     std::vector<PItem> pitems;
     std::vector<int32_t> pitem_ptr(nr + 1, 0);
+    std::vector<int32_t> pose_of_rid(std::max(nr, 1), 0);
+    for (int p = 0; p < P; ++p) if (d->pose_rid[p] >= 0) pose_of_rid[d->pose_rid[p]] = p;
+    // chunk of observations per workgroup: 1024 (four per thread) once that still fills the chip
+    const int pchunk = Np >= 1024L * 512 ? 1024 : 256;
     for (int r = 0; r < nr; ++r) {
-        for (int s = pcount[r]; s < pcount[r + 1]; s += 256)
-            pitems.push_back({r, s, std::min(s + 256, pcount[r + 1]), 0});
+        for (int s = pcount[r]; s < pcount[r + 1]; s += pchunk)
+            pitems.push_back({r, s, std::min(s + pchunk, pcount[r + 1]), pose_of_rid[r]});
         pitem_ptr[r + 1] = (int32_t)pitems.size();
     }
+    // pose-sorted copy of the observation records; the pose bits (uniform per chunk) carry the landmark slot + 1
+    if (nv >= (1 << 24) - 1) return fail("too many variable landmarks for the 24-bit slot field");
+    std::vector<LObs> pobs((size_t)Np);
+    for (long k = 0; k < Np; ++k) {
+        pobs[k] = lobs[pidx[k]];
+        const int slot = point_slot[pobs[k].point];              // -1: constant point
+        pobs[k].pose_grp = (int32_t)(((uint32_t)PS_GRP_OF(pobs[k]) << 24) | (uint32_t)(slot + 1));
+    }
     h->npitems = (int)pitems.size();
-    if (h->upload(&h->pidx, pidx) || h->upload(&h->pitems, pitems) || h->upload(&h->pitem_ptr, pitem_ptr) ||
-        h->alloc(&h->ppartial, (size_t)pitems.size() * PS_NPOSE_ACC)) return -1;
+    if (h->upload(&h->pitems, pitems) || h->upload(&h->pitem_ptr, pitem_ptr) ||
+        h->upload(&h->pobs, pobs) || h->alloc(&h->ppartial, (size_t)pitems.size() * PS_NPOSE_ACC)) return -1;
 
     // ---- pose factors: edges then priors
     const long E = d->num_edges, Q = d->num_priors, F = h->F = E + Q;

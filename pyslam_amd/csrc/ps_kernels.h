@@ -204,45 +204,58 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
 // ---------------------------------------------------------------------------
 // pose pass: 33 sums per chunk = 21 (upper J^T J - Z Z^T) + 6 (g) + 6 (diag J^T J, for damping)
 // ---------------------------------------------------------------------------
+// One workgroup per chunk of one pose's observations (256, or 1024 = four per thread on big
+// problems so that the 33 wave reductions are paid once per four observations).  Observation
+// records come from a pose-sorted copy (contiguous) that carries the landmark slot, and the pose
+// is uniform per workgroup.  The Z row of an observation is NOT read back from HBM (144 B each,
+// scattered: that read alone cost 15 of this kernel's 37 us): it is recomputed in registers from
+// the Jacobians this kernel evaluates anyway and the landmark's 48-byte factor C^-1 (an L2-resident
+// table) -- lm_emit_z on the same inputs, so the values are those the landmark pass stored.
 #define PS_NPOSE_ACC 33
+typedef const __attribute__((address_space(1))) void* ps_gptr_t;
+typedef __attribute__((address_space(3))) void* ps_lptr_t;
+
 __global__ __launch_bounds__(256) void k_pose_pass(
-    const PItem* __restrict__ items, const int32_t* __restrict__ pidx,
-    const LObs* __restrict__ lobs, const double* __restrict__ poses,
-    const double* __restrict__ points, const int32_t* __restrict__ point_vid,
-    const ObsGroup* __restrict__ groups, const double* __restrict__ Z,
+    const PItem* __restrict__ items,
+    const LObs* __restrict__ pobs /* observation records in pose order, landmark slot + 1 in the pose bits */,
+    const double* __restrict__ poses, const double* __restrict__ points,
+    const ObsGroup* __restrict__ groups, const double* __restrict__ Cinv,
     const double* __restrict__ cvec, double* __restrict__ partial)
 {
     __shared__ double red[4][PS_NPOSE_ACC];
     const PItem it = items[blockIdx.x];
-    const int i = it.start + threadIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Se3 T = se3_load(poses + 12 * (size_t)it.pad);          // pad = pose table index of this chunk
     double acc[PS_NPOSE_ACC];
 #pragma unroll
     for (int k = 0; k < PS_NPOSE_ACC; ++k) acc[k] = 0.0;
-    if (i < it.end) {
-        const int li = pidx[i];
-        const LObs o = lobs[li];
-        const Se3 T = se3_load(poses + 12 * PS_POSE_OF(o));
-        const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
+    for (int i = it.start + threadIdx.x; i < it.end; i += 256) {
+        const LObs o = pobs[i];
+        const int v = PS_POSE_OF(o) - 1;                           // -1: constant landmark, no Schur term
+        const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
+        double m[6] = {0, 0, 0, 0, 0, 0}, c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if (v >= 0) {
+            const double* ci = Cinv + 6 * (size_t)v;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[k] = ci[k];
+            c0 = cvec[3 * (size_t)v]; c1 = cvec[3 * (size_t)v + 1]; c2 = cvec[3 * (size_t)v + 2];
+        }
         ReprojEval ev;
-        reproj_eval<true, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
         int n = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = a; b < 6; ++b)
-                acc[n++] = ev.Jp[a] * ev.Jp[b] + ev.Jp[6 + a] * ev.Jp[6 + b] + ev.Jp[12 + a] * ev.Jp[12 + b];
+                acc[n++] += ev.Jp[a] * ev.Jp[b] + ev.Jp[6 + a] * ev.Jp[6 + b] + ev.Jp[12 + a] * ev.Jp[12 + b];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            acc[21 + a] = -(ev.Jp[a] * ev.r[0] + ev.Jp[6 + a] * ev.r[1] + ev.Jp[12 + a] * ev.r[2]);
-            acc[27 + a] = ev.Jp[a] * ev.Jp[a] + ev.Jp[6 + a] * ev.Jp[6 + a] + ev.Jp[12 + a] * ev.Jp[12 + a];
+            acc[21 + a] -= ev.Jp[a] * ev.r[0] + ev.Jp[6 + a] * ev.r[1] + ev.Jp[12 + a] * ev.r[2];
+            acc[27 + a] += ev.Jp[a] * ev.Jp[a] + ev.Jp[6 + a] * ev.Jp[6 + a] + ev.Jp[12 + a] * ev.Jp[12 + a];
         }
-        const int v = point_vid[o.point];
         if (v >= 0) {
             double z[18];
-            const double* zp = Z + 18 * (size_t)li;
-#pragma unroll
-            for (int k = 0; k < 18; ++k) z[k] = zp[k];
-            const double c0 = cvec[3 * (size_t)v], c1 = cvec[3 * (size_t)v + 1], c2 = cvec[3 * (size_t)v + 2];
+            lm_emit_z(ev, m[0], m[1], m[2], m[3], m[4], m[5], z);
             n = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
@@ -254,7 +267,6 @@ __global__ __launch_bounds__(256) void k_pose_pass(
                 acc[21 + a] -= z[3 * a] * c0 + z[3 * a + 1] * c1 + z[3 * a + 2] * c2;
         }
     }
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < PS_NPOSE_ACC; ++k) {
         const double s = wave_sum(acc[k]);
@@ -309,9 +321,6 @@ __global__ __launch_bounds__(64) void k_pose_finalize(
 // register-staged 64-pair version.  Waves never share LDS data: no workgroup barrier.
 #define PS_SP_PAIRS 32                        // pairs per chunk: rows a_0..a_31, b_0..b_31
 #define PS_SP_LDS_PER_WAVE 1152               // doubles: 64 rows x 18
-
-typedef const __attribute__((address_space(1))) void* ps_gptr_t;
-typedef __attribute__((address_space(3))) void* ps_lptr_t;
 
 // sum over the 32 lanes of each wave half with DPP row operations (fixed order): lane 31 / 63
 // end up with the total of lanes 0-31 / 32-63
