@@ -129,6 +129,9 @@ struct ps_problem {
     int32_t *status = nullptr, *h_status = nullptr;
     double* h_scalars_dev = nullptr;     // device-side aliases of the pinned, host-mapped result words
     int32_t* h_status_dev = nullptr;
+    long long *h_seq = nullptr, *h_seq_dev = nullptr;   // sequence number stamped by the last k_reduce3 workgroup
+    long long seq = 0;
+    int32_t* arrivals = nullptr;
     int ncost_obs = 0, ncost_fac = 0, nsq = 0;
     // native RCCL: function pointer + communicator handed over by the binding (ps_set_collective)
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
@@ -216,6 +219,25 @@ int sync(ps_problem* h) {
     HIP_OK(hipStreamSynchronize(h->stream));
     drain_timers(h);
     return 0;
+}
+
+// End of a published iteration: watch the sequence word k_reduce3's last workgroup writes to pinned host
+// memory (a few microseconds cheaper than a stream synchronisation); falls back to the synchronisation
+// when stage timers need their events or the word does not show up in ~1 s.
+int wait_published(ps_problem* h) {
+    volatile long long* w = h->h_seq;
+    for (long spins = 0; spins < 400000000L; ++spins) {
+        if (*w == h->seq) {
+            if (h->pending.empty()) return 0;
+            // stage timers: everything up to k_reduce3 has completed; an event recorded behind it may
+            // need a moment more
+            HIP_OK(hipEventSynchronize(h->ev_pool[h->pending.back().second + 1]));
+            drain_timers(h);
+            return 0;
+        }
+        __builtin_ia32_pause();
+    }
+    return sync(h);
 }
 
 int read_scalars(ps_problem* h) {
@@ -695,7 +717,8 @@ int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = f
                        ncost, h->cost_partials, o_cost,
                        h->nsq_p, h->sq_part_p, h->nr > 0 ? h->scalars + SC_DXP2 : nullptr,
                        h->nsq_l, h->sq_part_l, (h->nv > 0 || h->shard_out) ? o_dxl : nullptr, gate,
-                       h->status, h->scalars, publish ? h->h_status_dev : nullptr, publish ? h->h_scalars_dev : nullptr);
+                       h->status, h->scalars, publish ? h->h_status_dev : nullptr, publish ? h->h_scalars_dev : nullptr,
+                       h->arrivals, publish ? h->h_seq_dev : nullptr, publish ? ++h->seq : 0LL);
     return 0;
 }
 
@@ -727,11 +750,11 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         tp.stop();
         if (gn_tail(h, linesearch, h->status, true)) return -1;
         if (total) total->stop();                       // close the iteration timer before the sync
-        if (sync(h)) return -1;                         // k_reduce3 has published status + scalars to host memory
+        if (wait_published(h)) return -1;               // k_reduce3 has published status + scalars to host memory
         if (h->h_status[ST_PCG_DONE] != 0) break;
         if (h->cg_launched >= max_iters + 2) {          // not converged within max_iters: take the step anyway
             cg_fused_recover<D>(h, nullptr);
-            if (gn_tail(h, linesearch, nullptr, true) || sync(h)) return -1;
+            if (gn_tail(h, linesearch, nullptr, true) || wait_published(h)) return -1;
             break;
         }
         count = std::max(8, h->cg_launched / 2);
@@ -774,6 +797,7 @@ int ps_problem_destroy(ps_problem* h) {
     for (void* p : h->allocs) hipFree(p);
     if (h->h_scalars) hipHostFree(h->h_scalars);
     if (h->h_status) hipHostFree(h->h_status);
+    if (h->h_seq) hipHostFree(h->h_seq);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); }
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -1184,6 +1208,11 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     HIP_OK(hipHostMalloc((void**)&h->h_status, ST_NWORDS * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_OK(hipHostGetDevicePointer((void**)&h->h_scalars_dev, h->h_scalars, 0));
     HIP_OK(hipHostGetDevicePointer((void**)&h->h_status_dev, h->h_status, 0));
+    HIP_OK(hipHostMalloc((void**)&h->h_seq, sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostGetDevicePointer((void**)&h->h_seq_dev, h->h_seq, 0));
+    *h->h_seq = 0;
+    if (h->alloc(&h->arrivals, 2)) return -1;
+    HIP_OK(hipMemsetAsync(h->arrivals, 0, 2 * sizeof(int32_t), h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     guard.ok = true;
     *out = h;
@@ -1376,7 +1405,7 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
         // RCCL sum of {cost, ||dx_point||^2} -> one synchronisation
         if (h->nr == 0 || h->pcg_variant != 1) return fail("the sharded iteration needs the fused CG and a reduced system");
         enum { NCCL_F64 = 8, NCCL_SUM = 0 };
-        StageTimer total(h, PS_ST_TOTAL, 1);
+        StageTimer total(h, PS_ST_TOTAL, 2);
         if (linearize(h, lambda)) return -1;
         if (h->nccl_allreduce(h->red, h->red, (size_t)h->red_count, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
             return fail("ncclAllReduce of the reduced system failed");
@@ -1397,7 +1426,7 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
         return 0;
     }
     {
-        StageTimer total(h, PS_ST_TOTAL, 1);  // closed before the last synchronising read-back
+        StageTimer total(h, PS_ST_TOTAL, 2);  // closed before the last synchronising read-back
         if (linearize(h, lambda)) return -1;
         if (h->nr > 0 && h->pcg_variant == 1) {
             const int rc = h->D == 6

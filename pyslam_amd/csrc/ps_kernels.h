@@ -1705,31 +1705,45 @@ __global__ __launch_bounds__(256) void k_reduce3(
     int n0, const double* __restrict__ p0, double* __restrict__ o0,
     int n1, const double* __restrict__ p1, double* __restrict__ o1,
     int n2, const double* __restrict__ p2, double* __restrict__ o2, const int32_t* __restrict__ gate,
-    // publish (hst != NULL): the status words and the scalar slots go straight to pinned host memory, so
-    // the iteration ends with a stream synchronisation instead of two device-to-host copy launches
+    // publish (hst != NULL): the status words and the scalar slots go straight to pinned host memory, and
+    // the last workgroup to finish stamps a sequence number behind them, so the host ends the iteration
+    // by watching that word instead of paying two device-to-host copies and a stream synchronisation
     const int32_t* __restrict__ status, const double* __restrict__ scalars,
-    int32_t* __restrict__ hst, double* __restrict__ hsc)
+    int32_t* __restrict__ hst, double* __restrict__ hsc,
+    int32_t* __restrict__ arrivals /* device word, 0 between launches */, long long* __restrict__ hseq, long long seq)
 {
     __shared__ double lds[16];
+    const bool open = !(gate && !gate[ST_PCG_DONE]);
     if (hst && blockIdx.x == 0) {
         const int t = threadIdx.x;
         if (t < ST_NWORDS) hst[t] = status[t];
         else if (t < ST_NWORDS + SC_NWORDS) {
             const int k = t - ST_NWORDS;                 // slots owned by a reduction below are written there
-            if (o0 != scalars + k && o1 != scalars + k && o2 != scalars + k) hsc[k] = scalars[k];
+            if (!open || (o0 != scalars + k && o1 != scalars + k && o2 != scalars + k)) hsc[k] = scalars[k];
         }
     }
-    if (gate && !gate[ST_PCG_DONE]) return;
     const int n = blockIdx.x == 0 ? n0 : (blockIdx.x == 1 ? n1 : n2);
     const double* p = blockIdx.x == 0 ? p0 : (blockIdx.x == 1 ? p1 : p2);
     double* o = blockIdx.x == 0 ? o0 : (blockIdx.x == 1 ? o1 : o2);
-    if (!o) return;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
-    s = block_sum(s, lds);
-    if (threadIdx.x == 0) {
-        o[0] = s;
-        if (hsc && o >= scalars && o < scalars + SC_NWORDS) hsc[o - scalars] = s;
+    if (open && o) {                                     // block-uniform condition
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+        s = block_sum(s, lds);
+        if (threadIdx.x == 0) {
+            o[0] = s;
+            if (hsc && o >= scalars && o < scalars + SC_NWORDS) hsc[o - scalars] = s;
+        }
+    }
+    if (hseq) {
+        __syncthreads();                                 // every host-bound store of this workgroup is issued
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            if (atomicAdd(arrivals, 1) == (int)gridDim.x - 1) {
+                *arrivals = 0;
+                __threadfence_system();
+                *reinterpret_cast<volatile long long*>(hseq) = seq;
+            }
+        }
     }
 }
 
