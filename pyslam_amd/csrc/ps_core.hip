@@ -129,6 +129,7 @@ struct ps_problem {
     int32_t *status = nullptr, *h_status = nullptr;
     double* h_scalars_dev = nullptr;     // device-side aliases of the pinned, host-mapped result words
     int32_t* h_status_dev = nullptr;
+    double *h_shard = nullptr, *h_shard_dev = nullptr;   // host-mapped copy of shard_buf (sharded iteration)
     long long *h_seq = nullptr, *h_seq_dev = nullptr;   // sequence number stamped by the last k_reduce3 workgroup
     long long seq = 0;
     int32_t* arrivals = nullptr;
@@ -798,6 +799,7 @@ int ps_problem_destroy(ps_problem* h) {
     if (h->h_scalars) hipHostFree(h->h_scalars);
     if (h->h_status) hipHostFree(h->h_status);
     if (h->h_seq) hipHostFree(h->h_seq);
+    if (h->h_shard) hipHostFree(h->h_shard);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); }
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -1209,6 +1211,8 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     HIP_OK(hipHostGetDevicePointer((void**)&h->h_scalars_dev, h->h_scalars, 0));
     HIP_OK(hipHostGetDevicePointer((void**)&h->h_status_dev, h->h_status, 0));
     HIP_OK(hipHostMalloc((void**)&h->h_seq, sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostMalloc((void**)&h->h_shard, 2 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostGetDevicePointer((void**)&h->h_shard_dev, h->h_shard, 0));
     HIP_OK(hipHostGetDevicePointer((void**)&h->h_seq_dev, h->h_seq, 0));
     *h->h_seq = 0;
     if (h->alloc(&h->arrivals, 2)) return -1;
@@ -1416,8 +1420,15 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
             if (last < 0) return -1;
             if (h->nccl_allreduce(h->shard_buf, h->shard_buf, 2, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
                 return fail("ncclAllReduce of the shard scalars failed");
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, h->stream, h->status, h->scalars, h->shard_buf,
+                               h->h_status_dev, h->h_scalars_dev, h->h_shard_dev, h->h_seq_dev, ++h->seq);
             total.stop();
-            if (ps_gn_result(h, &done, sb, &dxp2, pcg_iters_out, pcg_relres_out)) return -1;
+            if (wait_published(h)) return -1;
+            if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+            done = h->h_status[ST_PCG_DONE];
+            sb[0] = h->h_shard[0]; sb[1] = h->h_shard[1];
+            dxp2 = h->h_scalars[SC_DXP2];
+            if (cg_report(h, pcg_iters_out, pcg_relres_out)) return -1;
             if (done || last) break;
             first = 0;
         }

@@ -1747,6 +1747,24 @@ __global__ __launch_bounds__(256) void k_reduce3(
     }
 }
 
+// sharded iteration: status, scalars and the all-reduced {cost, ||dx_point||^2} to pinned host memory,
+// then the sequence word the host is watching (single workgroup)
+__global__ __launch_bounds__(64) void k_publish(
+    const int32_t* __restrict__ status, const double* __restrict__ scalars, const double* __restrict__ shard,
+    int32_t* __restrict__ hst, double* __restrict__ hsc, double* __restrict__ hshard,
+    long long* __restrict__ hseq, long long seq)
+{
+    const int t = threadIdx.x;
+    if (t < ST_NWORDS) hst[t] = status[t];
+    else if (t < ST_NWORDS + SC_NWORDS) hsc[t - ST_NWORDS] = scalars[t - ST_NWORDS];
+    else if (t < ST_NWORDS + SC_NWORDS + 2) hshard[t - ST_NWORDS - SC_NWORDS] = shard[t - ST_NWORDS - SC_NWORDS];
+    __syncthreads();
+    if (t == 0) {
+        __threadfence_system();
+        *reinterpret_cast<volatile long long*>(hseq) = seq;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_reduce_partials(int n, const double* __restrict__ partials,
                                                           double* __restrict__ out)
 {
