@@ -112,7 +112,7 @@ struct ps_problem {
     hipEvent_t ev_ac = nullptr, ev_chol = nullptr;
     int32_t* lag_status = nullptr;  // ST_DIAG_FAIL of the side-stream factorisation
     bool coarse_built = false;
-    int cg_ablate = 0, schur_ablate = 0;
+    int cg_ablate = 0, schur_ablate = 0, lm_ablate = 0;
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;
     double* cg_tot = nullptr;
@@ -600,7 +600,7 @@ int linearize(ps_problem* h, double lambda) {
         StageTimer t(h, PS_ST_LANDMARK);
         hipLaunchKernelGGL(k_landmark_pass, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr,
                            h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,
-                           h->Cinv, h->cvec, h->status);
+                           h->Cinv, h->cvec, h->status, h->lm_ablate);
     }
     if (h->npitems > 0) {
         StageTimer t(h, PS_ST_POSE);
@@ -1556,6 +1556,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     }
     else if (n == "cg_ablate") h->cg_ablate = (int)value;
     else if (n == "schur_ablate") h->schur_ablate = (int)value;
+    else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
     const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
     const ObsGroup* __restrict__ groups, double lambda,
     double* __restrict__ Z, double* __restrict__ Cinv, double* __restrict__ cvec,
-    int32_t* __restrict__ status)
+    int32_t* __restrict__ status, int ablate)
 {
     const int v = blockIdx.x * (blockDim.x / PS_LM_GROUP) + threadIdx.x / PS_LM_GROUP;
     const int sub = threadIdx.x & (PS_LM_GROUP - 1);
@@ -161,7 +161,6 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
     H00 = group16_sum(H00); H10 = group16_sum(H10); H11 = group16_sum(H11);
     H20 = group16_sum(H20); H21 = group16_sum(H21); H22 = group16_sum(H22);
     b0 = group16_sum(b0); b1 = group16_sum(b1); b2 = group16_sum(b2);
-    if (!live) return;
 
     const double damp = 1.0 + lambda;
     H00 *= damp; H11 *= damp; H22 *= damp;
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
     const double M10 = -l10 * M00 * M11;
     const double M21 = -l21 * M11 * M22;
     const double M20 = -(l20 * M00 + l21 * M10) * M22;
-    if (sub == 0) {
+    if (live && sub == 0) {
         if (!(H00 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) atomicAdd(&status[ST_LM_FAIL], 1);
         double* ci = Cinv + 6 * (size_t)v;
         ci[0] = M00; ci[1] = M10; ci[2] = M11; ci[3] = M20; ci[4] = M21; ci[5] = M22;
@@ -187,8 +186,37 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
         cv[1] = M10 * b0 + M11 * b1;
         cv[2] = M20 * b0 + M21 * b1 + M22 * b2;
     }
+    // ---- Z rows.  Common case (every landmark of the wave has <= 16 observations): the wave's rows are
+    // one contiguous range of Z, so they are transposed through LDS and stored as whole 16-byte pieces by
+    // consecutive lanes (1 KB per store instruction) instead of 18 stride-144 8-byte stores per lane.
+    __shared__ __attribute__((aligned(16))) double zst[4][64 * 18];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (__ballot(single || !live) == ~0ull && !(ablate & 2)) {
+        const int row0 = __shfl(b, 0, 64);                       // dead groups carry b = e = 0
+        const int eend = max(max(__shfl(e, 0, 64), __shfl(e, 16, 64)), max(__shfl(e, 32, 64), __shfl(e, 48, 64)));
+        const int nrows = eend - row0;
+        if (have) {
+            double z[18];
+            if (variable_pose) lm_emit_z(ev, M00, M10, M11, M20, M21, M22, z);
+            else {
+#pragma unroll
+                for (int k = 0; k < 18; ++k) z[k] = 0.0;         // rows of constant poses are never read
+            }
+            double2* dst = reinterpret_cast<double2*>(&zst[wv][18 * (b + sub - row0)]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dst[k] = make_double2(z[2 * k], z[2 * k + 1]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!(ablate & 1)) {
+            const double2* src = reinterpret_cast<const double2*>(zst[wv]);
+            double2* out = reinterpret_cast<double2*>(Z + 18 * (size_t)row0);
+            for (int k = lane; k < nrows * 9; k += 64) out[k] = src[k];
+        }
+        return;
+    }
+    if (!live) return;
     if (single) {
-        if (have && variable_pose) lm_emit_z(ev, M00, M10, M11, M20, M21, M22, Z + 18 * (size_t)(b + sub));
+        if (have && variable_pose && !(ablate & 1)) lm_emit_z(ev, M00, M10, M11, M20, M21, M22, Z + 18 * (size_t)(b + sub));
         return;
     }
     for (int i = b + sub; i < e; i += PS_LM_GROUP) {
