@@ -113,6 +113,7 @@ struct ps_problem {
     int32_t* lag_status = nullptr;  // ST_DIAG_FAIL of the side-stream factorisation
     bool coarse_built = false;
     int cg_ablate = 0, schur_ablate = 0, lm_ablate = 0;
+    int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;
     double* cg_tot = nullptr;
@@ -536,7 +537,15 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
                            h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,      \
                            h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc, h->cg_ablate, tot, ncbs,              \
                            h->fine_nnz, h->cg_cgd[o], h->cg_U, h->cg_ab)
-        if (h->cg_short_rows) { PS_CG_LAUNCH(1); }
+        if (h->cg_lds && !h->cg_short_rows && !h->cg_split && !tot && !h->cg_ablate && rows <= 1024 &&
+            (long)rows * D <= PS_CGV_MAX) {
+            // small systems: the whole CG vector goes through LDS, one global round trip per launch
+            hipLaunchKernelGGL((k_cg_fused_lds<D, 8>), dim3(rows), dim3(512), 0, h->stream, rows, h->arow_ptr,
+                               h->acol_idx, h->Saug, h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw],
+                               h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
+                               h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc);
+        }
+        else if (h->cg_short_rows) { PS_CG_LAUNCH(1); }
         else if (rows > 1024) { PS_CG_LAUNCH(4); }      // many rows: smaller workgroups, more of them in flight
         else { PS_CG_LAUNCH(8); }
 #undef PS_CG_LAUNCH
@@ -1558,6 +1567,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "schur_ablate") h->schur_ablate = (int)value;
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
+    else if (n == "cg_lds") h->cg_lds = value != 0.0;
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }

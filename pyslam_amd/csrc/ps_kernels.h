@@ -1159,6 +1159,148 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused(
     }
 }
 
+// Small systems (the whole CG vector fits in LDS: rows * D <= PS_CGV_MAX): ONE global round trip per
+// iteration.  k_cg_fused's SpMV needs r_new of the neighbouring block rows, i.e. r/w/s gathered
+// through the column indices -- a second, dependent round trip (~1.5 us of a ~6.5 us launch at C3).
+// Here every workgroup instead loads the WHOLE r, w, s vectors (coalesced, addresses known at
+// launch: ~30 KB at C3, L2-resident) together with its matrix blocks and the column indices, forms
+// r_new for every row in LDS once alpha / beta are known, and the SpMV gathers from LDS.
+#define PS_CGV_MAX 4096
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void k_cg_fused_lds(
+    int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+    const double* __restrict__ S,
+    const double* __restrict__ r_old, const double* __restrict__ w_old, const double* __restrict__ s_old,
+    double* __restrict__ r_new, double* __restrict__ w_new, double* __restrict__ s_new,
+    double* __restrict__ p, double* __restrict__ x,
+    const double* __restrict__ gd_in, double* __restrict__ gd_out,
+    double* __restrict__ hist, int cap, int k, double tol2,
+    int32_t* __restrict__ status, double* __restrict__ scalars,
+    int nfine, int wf, int wc)
+{
+    __shared__ double lds[32];
+    __shared__ double part[NW][8];
+    __shared__ double rn[PS_CGV_MAX];
+    constexpr int DD = D * D, NT = 64 * NW, NV = (PS_CGV_MAX + NT - 1) / NT, NPRE = 4;
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int row = blockIdx.x, nvec = nr * D;
+    // ---- every load of the launch is issued here: one memory latency
+    const int done = status[ST_PCG_DONE];
+    int rbeg, rend;
+    if (wf > 0) {
+        rbeg = row < nfine ? row * wf : nfine * wf + (row - nfine) * wc;
+        rend = rbeg + (row < nfine ? wf : wc);
+    } else {
+        rbeg = row_ptr[row]; rend = row_ptr[row + 1];
+    }
+    const double g_prev = hist[k > 0 ? k - 1 : 0];
+    const double a_prev = hist[cap + (k > 0 ? k - 1 : 0)];
+    const double thresh_in = scalars[SC_THRESH];
+    double gs = 0.0, ds = 0.0;
+    if (k >= 0) for (int i = t; i < nr; i += NT) { gs += gd_in[i]; ds += gd_in[nr + i]; }
+    double vr[NV], vw[NV], vs[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int i = t + q * NT;
+        vr[q] = vw[q] = vs[q] = 0.0;
+        if (i < nvec) { vr[q] = r_old[i]; vw[q] = w_old[i]; vs[q] = s_old[i]; }
+    }
+    const int kk = lane >> 3, r = lane & 7;
+    const int b0 = rbeg + w * 8 + kk;
+    constexpr int STRIDE = 8 * NW;
+    const bool dense_row = wf > 0 && row >= nfine;
+    int cj[NPRE];
+    double sv[NPRE][D];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        const int b = b0 + q * STRIDE;
+        cj[q] = 0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) sv[q][c] = 0.0;
+        if (b < rend && r < D) {
+            cj[q] = dense_row ? b - rbeg : col_idx[b];
+            const double* sb = S + (size_t)b * DD + r * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c) sv[q][c] = sb[c];
+        }
+    }
+    double ri = 0.0, wi = 0.0, si = 0.0, pi = 0.0, xi_ = 0.0;
+    if (t < D) {
+        const size_t i = (size_t)row * D + t;
+        ri = r_old[i]; wi = w_old[i]; si = s_old[i]; pi = p[i]; xi_ = x[i];
+    }
+    if (done) return;
+    double alpha = 0.0, beta = 0.0;
+    if (k >= 0) {
+        block_sum2(gs, ds, lds);
+        const double gamma = gs, delta = ds;
+        const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
+        const bool first = (blockIdx.x == 0 && t == 0);
+        if (!(gamma > thresh)) {                     // converged (or gamma == 0 / NaN)
+            if (first) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
+            return;
+        }
+        beta = (k == 0) ? 0.0 : gamma / g_prev;
+        const double denom = (k == 0) ? delta : delta - beta * gamma / a_prev;
+        alpha = gamma / denom;
+        if (!(denom > 0.0)) {                        // breakdown: stop, the host reports it
+            if (first) { status[ST_PCG_DONE] = 2; scalars[SC_RRFINAL] = gamma; }
+            return;
+        }
+        if (first) {
+            hist[k] = gamma; hist[cap + k] = alpha; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = gamma;
+            if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = gamma; }
+        }
+    }
+    // ---- r_new of every row into LDS
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int i = t + q * NT;
+        if (i < nvec) rn[i] = cg_rnew(vr[q], vw[q], vs[q], alpha, beta);
+    }
+    __syncthreads();
+    // ---- w_new(row) = S^(row,:) r_new
+    double acc = 0.0;
+    if (r < D) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            if (b0 + q * STRIDE < rend) {
+                const double* v = rn + cj[q] * D;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc += sv[q][c] * v[c];
+            }
+        }
+        for (int b = b0 + NPRE * STRIDE; b < rend; b += STRIDE) {
+            const int jc = dense_row ? b - rbeg : col_idx[b];
+            const double* sb = S + (size_t)b * DD + r * D;
+            const double* v = rn + jc * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc += sb[c] * v[c];
+        }
+    }
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < 8) part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+        double gp = 0.0, dp = 0.0;
+        if (lane < D) {
+            double wn = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) wn += part[ww][lane];
+            const size_t i = (size_t)row * D + lane;
+            const double sn = wi + beta * si;
+            const double pn = ri + beta * pi;
+            const double rnv = rn[i];
+            s_new[i] = sn; p[i] = pn; x[i] = xi_ + alpha * pn; r_new[i] = rnv; w_new[i] = wn;
+            gp = rnv * rnv; dp = wn * rnv;
+        }
+        gp = wave_sum(gp); dp = wave_sum(dp);
+        if (lane == 0) { gd_out[row] = gp; gd_out[nr + row] = dp; }
+    }
+}
+
 // x = Linv^T x^
 template <int D>
 __global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __restrict__ Linv,
