@@ -453,12 +453,11 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
         h->cg_launched = 0;
         return 0;
     }
+    // block-Jacobi factors + the start vectors of the scaled system (r = Linv g, w = s = p = x = 0)
     hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
-                       h->S, h->Linv, h->status);
+                       h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh);
     hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
                        h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug);
-    hipLaunchKernelGGL(k_cg_prepare<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->g, h->Linv,
-                       h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh, h->status);
     if (G) {
         const int ncb = h->ncb, nc = h->nc;
         if (h->side_pending) {                  // the side-stream factorisation still reads A_c / writes its buffer
@@ -492,11 +491,11 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
         if (lag) {
             const int use = h->lci_next;
             h->lci_cur = use;
-            hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr + ncb), dim3(256), border_lds, h->stream,
-                               nr, ncb, h->SZ, h->Lci2[use], h->arow_ptr, h->fine_nnz, h->Saug, 1, h->Ac);
-            hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
-                               h->pw0, h->pw1, h->LciT2[use], h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
-                               h->cg_s[0], h->cg_p, h->cg_xh, 2, h->lag_status, h->status);
+            // borders K, K^T, the coarse-coarse rows and (last workgroup) the coarse right-hand side
+            const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[use], h->tvec, h->cg_r[0], h->cg_w[0],
+                                   h->cg_s[0], h->cg_p, h->cg_xh, 2, h->lag_status, h->status};
+            hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr + ncb + 1), dim3(256), border_lds, h->stream,
+                               nr, ncb, h->SZ, h->Lci2[use], h->arow_ptr, h->fine_nnz, h->Saug, 1, h->Ac, ra);
             HIP_OK(hipEventRecord(h->ev_ac, h->stream));           // A_c complete, buffer use^1 no longer read
             HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
             if (launch_chol(h->side, use ^ 1, h->lag_status)) return -1;
@@ -505,12 +504,11 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
         } else {
             const int buf = h->lci_cur;
             if (launch_chol(h->stream, buf, h->status)) return -1;
-            hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr), dim3(256), border_lds, h->stream,
+            const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[buf], h->tvec, h->cg_r[0], h->cg_w[0],
+                                   h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, nullptr, h->status};
+            hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr + 1), dim3(256), border_lds, h->stream,
                                nr, ncb, h->SZ, h->Lci2[buf], h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1,
-                               (const double*)nullptr);
-            hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
-                               h->pw0, h->pw1, h->LciT2[buf], h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
-                               h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, (const int32_t*)nullptr, h->status);
+                               (const double*)nullptr, ra);
             h->lci_next = buf;
         }
     }

@@ -818,9 +818,13 @@ __global__ __launch_bounds__(256) void k_pcg_update(
 template <int D>
 __global__ __launch_bounds__(256) void k_block_jacobi_factor(
     int nr, const int32_t* __restrict__ diag_slot, const double* __restrict__ S,
-    double* __restrict__ Linv, int32_t* __restrict__ status)
+    double* __restrict__ Linv, int32_t* __restrict__ status,
+    // fused CG only (g != NULL): also the start vectors of the scaled system, r = Linv g, w = s = p = x = 0
+    const double* __restrict__ g, double* __restrict__ r0, double* __restrict__ w0, double* __restrict__ s0,
+    double* __restrict__ p0, double* __restrict__ x0)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g && i == 0) { status[ST_PCG_DONE] = 0; status[ST_PCG_ITERS] = 0; }
     if (i >= nr) return;
     double A[D][D], L[D][D], Li[D][D];
     const double* s = S + (size_t)diag_slot[i] * D * D;
@@ -862,6 +866,16 @@ __global__ __launch_bounds__(256) void k_block_jacobi_factor(
     for (int r = 0; r < D; ++r)
 #pragma unroll
         for (int c = 0; c < D; ++c) m[r * D + c] = Li[r][c];
+    if (g) {
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; ++c) v += Li[r][c] * g[(size_t)i * D + c];
+            const size_t o = (size_t)i * D + r;
+            r0[o] = v; w0[o] = 0.0; s0[o] = 0.0; p0[o] = 0.0; x0[o] = 0.0;
+        }
+    }
 }
 
 // Sout[out_slot[b]] = Linv_i S_ij Linv_j^T  (one 64-thread workgroup per block; S itself is kept)
@@ -1522,6 +1536,25 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
     }
 }
 
+struct CoarseRhsArgs {
+    const int32_t *slo, *shi, *pnode;
+    const double *pw0, *pw1, *LciT;
+    double *tvec, *r, *w, *s, *p, *x;
+    int with_coarse_rows;
+    const int32_t* lag_status;
+    int32_t* status;
+};
+
+template <int D>
+PS_DEV void coarse_rhs_body(
+    int nr, int ncb, const int32_t* __restrict__ slo, const int32_t* __restrict__ shi,
+    const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ LciT, const int32_t* __restrict__ arow_ptr,
+    double* __restrict__ Saug, double* __restrict__ tvec,
+    double* __restrict__ r, double* __restrict__ w, double* __restrict__ s,
+    double* __restrict__ p, double* __restrict__ x,
+    int with_coarse_rows, const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, double* stv);
+
 // K_i = SZ_i Lci^T, written to both borders of the augmented BSR matrix.
 // One workgroup per fine block row i; thread per (r, c) of the D x nc strip.
 // Lagged mode (Ac != NULL): Lci is the inverse factor of the PREVIOUS iteration's A_c, so the
@@ -1531,12 +1564,19 @@ template <int D>
 __global__ __launch_bounds__(256) void k_coarse_border(
     int nr, int ncb, const double* __restrict__ SZ, const double* __restrict__ Lci,
     const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ fine_nnz, double* __restrict__ Saug,
-    int with_coarse_rows, const double* __restrict__ Ac)
+    int with_coarse_rows, const double* __restrict__ Ac,
+    // the LAST workgroup (rhs.r != NULL) runs the coarse right-hand side instead (independent work, one launch less)
+    CoarseRhsArgs rhs)
 {
     constexpr int DD = D * D;
     extern __shared__ __attribute__((aligned(16))) double sT[];     // D x nc
     const int nc = ncb * D;
     const int i = blockIdx.x;
+    if (rhs.r && i == (int)gridDim.x - 1) {
+        coarse_rhs_body<D>(nr, ncb, rhs.slo, rhs.shi, rhs.pnode, rhs.pw0, rhs.pw1, rhs.LciT, arow_ptr, Saug, rhs.tvec,
+                           rhs.r, rhs.w, rhs.s, rhs.p, rhs.x, rhs.with_coarse_rows, rhs.lag_status, rhs.status, sT);
+        return;
+    }
     if (i >= nr) {                                                  // lagged mode: row q of M
         const int q = i - nr;
         for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
@@ -1575,7 +1615,7 @@ __global__ __launch_bounds__(256) void k_coarse_border(
 
 // coarse rows: diagonal block = I ; rhs b~_c = Lci * (P^T g^) ; zero the CG vectors of the coarse rows
 template <int D>
-__global__ __launch_bounds__(1024) void k_coarse_rhs(
+PS_DEV void coarse_rhs_body(
     int nr, int ncb, const int32_t* __restrict__ slo, const int32_t* __restrict__ shi,
     const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
     const double* __restrict__ LciT, const int32_t* __restrict__ arow_ptr,
@@ -1583,7 +1623,7 @@ __global__ __launch_bounds__(1024) void k_coarse_rhs(
     double* __restrict__ r /* fine part holds g^ */, double* __restrict__ w, double* __restrict__ s,
     double* __restrict__ p, double* __restrict__ x,
     int with_coarse_rows /* 1: write the coarse-coarse rows as identity (exact factor); 2: leave them (lagged) */,
-    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status)
+    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, double* stv /* LDS, >= nc doubles */)
 {
     constexpr int DD = D * D;
     const int nc = ncb * D;
@@ -1607,7 +1647,6 @@ __global__ __launch_bounds__(1024) void k_coarse_rhs(
             Saug[(size_t)(arow_ptr[nr + q] + nr + q2) * DD + e] = (q == q2 && e / D == e % D) ? 1.0 : 0.0;
         }
     __syncthreads();
-    __shared__ double stv[400];
     for (int t = threadIdx.x; t < nc; t += blockDim.x) stv[t] = tvec[t];
     __syncthreads();
     for (int base = 0; base < nc; base += blockDim.x / 8) {         // b~_c[t] = sum_{k<=t} Lci[t][k] t_k
@@ -1623,6 +1662,21 @@ __global__ __launch_bounds__(1024) void k_coarse_rhs(
             r[o] = v; w[o] = 0.0; s[o] = 0.0; p[o] = 0.0; x[o] = 0.0;
         }
     }
+}
+
+template <int D>
+__global__ __launch_bounds__(1024) void k_coarse_rhs(
+    int nr, int ncb, const int32_t* __restrict__ slo, const int32_t* __restrict__ shi,
+    const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ LciT, const int32_t* __restrict__ arow_ptr,
+    double* __restrict__ Saug, double* __restrict__ tvec,
+    double* __restrict__ r, double* __restrict__ w, double* __restrict__ s,
+    double* __restrict__ p, double* __restrict__ x, int with_coarse_rows,
+    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status)
+{
+    __shared__ double stv[400];
+    coarse_rhs_body<D>(nr, ncb, slo, shi, pnode, pw0, pw1, LciT, arow_ptr, Saug, tvec, r, w, s, p, x,
+                       with_coarse_rows, lag_status, status, stv);
 }
 
 // x^_i = x~_f,i + pw0_i y[node_i] + pw1_i y[node_i + 1] with y = Lci^T x~_c ;  x_i = Linv_i^T x^_i
