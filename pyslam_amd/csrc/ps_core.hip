@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -785,6 +786,20 @@ int need_device() {
 }
 }  // namespace
 
+namespace {
+// stable counting sort of `v` by an integer key in [0, nkeys): O(n + nkeys), used for the big
+// host-side orderings of ps_problem_create (std::stable_sort was most of its run time)
+template <class T, class KeyFn>
+void counting_sort(std::vector<T>& v, size_t nkeys, KeyFn key) {
+    std::vector<size_t> pos(nkeys + 1, 0);
+    for (const T& x : v) pos[(size_t)key(x) + 1]++;
+    for (size_t k = 0; k < nkeys; ++k) pos[k + 1] += pos[k];
+    std::vector<T> out(v.size());
+    for (const T& x : v) out[pos[(size_t)key(x)]++] = x;
+    v.swap(out);
+}
+}  // namespace
+
 // ===========================================================================
 // C ABI
 // ===========================================================================
@@ -815,6 +830,14 @@ int ps_problem_destroy(ps_problem* h) {
 }
 
 int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) {
+    const bool timing = getenv("PS_CREATE_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "ps_problem_create: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (!d || !out) return fail("null argument");
     *out = nullptr;
     if (d->dof != 6 && d->dof != 3) return fail("dof must be 6 (SE3) or 3 (SE2)");
@@ -874,6 +897,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
 
     if (h->upload(&h->point_vid, point_slot)) return -1;     // device-side 'vid' = internal slot
 
+    lap("parameter tables");
     // ---- observation groups
     std::vector<ObsGroup> og(std::max(1, d->num_obs_groups));
     for (int gi = 0; gi < d->num_obs_groups; ++gi) {
@@ -890,6 +914,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     }
     if (h->upload(&h->ogroups, og)) return -1;
 
+    lap("observation groups");
     // ---- observations sorted by landmark: variable points (by vid) first, then constant points
     std::vector<int64_t> order(N);
     for (long i = 0; i < N; ++i) order[i] = i;
@@ -897,7 +922,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         const int v = point_slot[d->obs_point[i]];
         return v >= 0 ? (int64_t)v : (int64_t)nv + d->obs_point[i];
     };
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return lm_key(a) < lm_key(b); });
+    counting_sort(order, (size_t)nv + (size_t)L + 1, [&](int64_t a) { return lm_key(a); });
     std::vector<LObs> lobs(N);
     std::vector<int32_t> lorig(N), lm_ptr(nv + 1, 0);
     long Nl = 0;
@@ -922,6 +947,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         h->alloc(&h->cvec, (size_t)nv * 3) || h->alloc(&h->dxl, (size_t)nv * 3)) return -1;
     HIP_OK(hipMemsetAsync(h->dxl, 0, std::max<size_t>(1, (size_t)nv * 3) * sizeof(double), h->stream));
 
+    lap("landmark sort + lobs");
     // ---- pose segments (observations on variable poses), chunks of 256
     std::vector<int32_t> pcount(nr + 1, 0);
     for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pcount[r + 1]++; }
@@ -952,6 +978,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     if (h->upload(&h->pitems, pitems) || h->upload(&h->pitem_ptr, pitem_ptr) ||
         h->upload(&h->pobs, pobs) || h->alloc(&h->ppartial, (size_t)pitems.size() * PS_NPOSE_ACC)) return -1;
 
+    lap("pose segments + pobs");
     // ---- pose factors: edges then priors
     const long E = d->num_edges, Q = d->num_priors, F = h->F = E + Q;
     std::vector<FactorGroup> fg(std::max(1, d->num_edge_groups));
@@ -981,6 +1008,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     const int FROW = 3 * DD + 2 * D;
     if (h->alloc(&h->fscratch, (size_t)F * FROW)) return -1;
 
+    lap("pose factors");
     // ---- Schur pairs per landmark (upper-triangle block keys)
     // Landmark tiles: when Z (144 B per row) is much larger than the eight 4 MB L2s, the pair list is
     // cut into tiles of consecutive landmarks (consecutive Z rows) and ONE XCD works through a whole
@@ -1006,6 +1034,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         lm_pairs_before[v + 1] = lm_pairs_before[v] + nvar * (nvar - 1) / 2;
     }
     const long total_pairs = lm_pairs_before[nv];
+    prs.reserve((size_t)total_pairs);
     for (int v = 0; v < nv; ++v) {
         const int tile = (ntiles > 1 && total_pairs > 0)
             ? (int)std::min<long>(ntiles - 1, (long)((double)ntiles * (double)lm_pairs_before[v] / (double)total_pairs)) : 0;
@@ -1021,11 +1050,14 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         }
     }
     h->schur_tiles = ntiles;
-    std::stable_sort(prs.begin(), prs.end(), [](const PairRec& x, const PairRec& y) {
-        return x.tile != y.tile ? x.tile < y.tile : x.key < y.key; });
+    // order by (tile, block row, block column): three stable counting passes, least significant first
+    counting_sort(prs, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)x.key; });
+    counting_sort(prs, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)(x.key >> 32); });
+    if (ntiles > 1) counting_sort(prs, (size_t)ntiles, [](const PairRec& x) { return x.tile; });
     h->npairs = (long)prs.size();
     if (prs.size() >= (1UL << 31)) return fail("too many Schur pairs for 32-bit indexing");
 
+    lap("pair generation + sort");
     // ---- block pattern of the reduced system
     std::vector<uint64_t> keys;                 // upper keys (ri <= rj)
     keys.reserve(prs.size() / 8 + nr + F + d->num_extra_pairs);
@@ -1077,6 +1109,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     h->status = reinterpret_cast<int32_t*>(h->red + h->red_count);
     h->S = h->red; h->g = h->red + (size_t)nnzb * DD; h->red_cost = h->g + (size_t)nr * D;
 
+    lap("block pattern");
     // pair list + one work item (task) per (tile, block) that has pairs
     std::vector<int2> pairs(prs.size());
     std::vector<PairItem> pitm;
@@ -1145,6 +1178,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     }
     prs.clear(); prs.shrink_to_fit();
 
+    lap("pair items + XCD lists");
     // ---- factor contribution lists
     {
         struct C { int32_t slot, off, tr; };
@@ -1181,6 +1215,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
             h->upload(&h->eitems, eitems) || h->upload(&h->gptr, gptr) || h->upload(&h->gitems, gitems)) return -1;
     }
 
+    lap("factor lists");
     // ---- PCG workspace
     const size_t nvec = (size_t)nr * D;
     h->npartA = std::max(1, nr);      // k_pcg_spmv: one workgroup (and one p.q partial) per block row
@@ -1201,6 +1236,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     HIP_OK(hipMemsetAsync(h->p0, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->p1, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
 
+    lap("pcg workspace");
     // ---- scalars
     h->ncost_obs = N > 0 ? std::min(2048, cdiv(N, 256)) : 0;
     h->ncost_fac = F > 0 ? std::min(1024, cdiv(F, 256)) : 0;
@@ -1225,6 +1261,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     if (h->alloc(&h->arrivals, 2)) return -1;
     HIP_OK(hipMemsetAsync(h->arrivals, 0, 2 * sizeof(int32_t), h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
+    lap("scalars + final sync");
     guard.ok = true;
     *out = h;
     return 0;
