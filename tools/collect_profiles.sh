@@ -14,13 +14,13 @@ export TMPDIR=/tmp
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --force-sharded --no-cpu-baseline 2> /dev/null | grep '^{' > "$OUT/bench_sharded_1rank.json"
 BENCH="python $PWD/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- $BENCH > "$OUT/bench_under_rocprof.json" 2> /dev/null)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- $BENCH > "$OUT/bench_under_rocprof.json" 2> /dev/null)
 find /tmp/kt -name '*kernel_stats.csv' -exec cp {} "$OUT/ktrace_kernel_stats.csv" \;
 PMCB="python $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
     i=$((i + 1))
-    (cd /tmp && rocprofv3 --pmc $SET --kernel-trace -d /tmp/pmc$i -o p -- $PMCB > /dev/null 2>&1)
+    (cd /tmp && rocprofv3 --pmc $SET --kernel-trace --output-format csv -d /tmp/pmc$i -o p -- $PMCB > /dev/null 2>&1)
     find /tmp/pmc$i -name '*counter_collection.csv' -exec cp {} "$OUT/pmc_$(echo $SET | tr ' ' '_').csv" \;
 done
 ls -la "$OUT"
