@@ -102,6 +102,10 @@ struct ps_problem {
     int32_t *pnode = nullptr, *slo = nullptr, *shi = nullptr, *run_lo = nullptr, *run_hi = nullptr,
             *arow_ptr = nullptr, *acol_idx = nullptr, *aug_slot = nullptr, *fine_nnz = nullptr;
     double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *tvec = nullptr, *chol_scratch = nullptr;
+    // coarse basis P_iq = w(i,q) B_i: B_i = L_i^T Ad(T_i) (coarse_basis 1, rigid-motion aware) or I (0)
+    int coarse_basis = 1;
+    double *Bmat = nullptr, *bgv = nullptr, *SB = nullptr, *BSZ = nullptr;
+    int32_t* pose_of_rid = nullptr;
     // coarse factor L_c^-1 (and transpose), double-buffered: with "coarse_lag" the factorisation of THIS
     // iteration's A_c runs on a side stream while the CG iterates with the previous iteration's factor
     double *Lci2[2] = {}, *LciT2[2] = {};
@@ -413,6 +417,8 @@ int build_coarse(ps_problem* h) {
         h->upload(&h->pw0, pw0) || h->upload(&h->pw1, pw1) || h->upload(&h->run_lo, rlo) ||
         h->upload(&h->run_hi, rhi) || h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) ||
         h->upload(&h->aug_slot, slot) || h->upload(&h->fine_nnz, fnz)) return -1;
+    if (h->alloc(&h->BSZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Bmat, (size_t)nr * D * D) ||
+        h->alloc(&h->bgv, (size_t)nr * D) || h->alloc(&h->SB, (size_t)aci.size() * D * D)) return -1;
     if (h->alloc(&h->SZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci2[0], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[0], (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci2[1], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[1], (size_t)h->nc * h->nc) ||
@@ -446,29 +452,32 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
     if (rhs_only) {
         // same matrix (and coarse factor) as the last full setup, new right-hand side h->g
         hipLaunchKernelGGL(k_cg_prepare<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->g, h->Linv,
-                           h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh, h->status);
+                           h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh, h->status,
+                           G ? h->Bmat : (const double*)nullptr, h->bgv);
         if (G)
             hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, h->ncb, h->slo, h->shi, h->pnode,
                                h->pw0, h->pw1, h->LciT2[h->lci_cur], h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
-                               h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 2, (const int32_t*)nullptr, h->status);
+                               h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 2, (const int32_t*)nullptr, h->status,
+                               h->bgv);
         h->cg_launched = 0;
         return 0;
     }
     // block-Jacobi factors + the start vectors of the scaled system (r = Linv g, w = s = p = x = 0)
     hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
-                       h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh);
+                       h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
+                       h->poses, h->pose_of_rid, h->coarse_basis, G ? h->Bmat : (double*)nullptr, h->bgv);
     hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
-                       h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug);
+                       h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, G ? h->Bmat : (const double*)nullptr, h->SB);
     if (G) {
         const int ncb = h->ncb, nc = h->nc;
         if (h->side_pending) {                  // the side-stream factorisation still reads A_c / writes its buffer
             HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0));
             h->side_pending = false;
         }
-        hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), 0, h->stream, nr, ncb, h->run_lo, h->run_hi,
-                           h->acol_idx, h->pnode, h->pw0, h->pw1, h->Saug, h->SZ);
+        hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(ncb + 1) * D * D * sizeof(double), h->stream,
+                           nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat, h->BSZ);
         hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
-                           nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->SZ, h->Ac);
+                           nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
         // Exact: factor this iteration's A_c on the solver stream (51 us at C3, serial).  Lagged
         // ("coarse_lag", whole-iteration calls only): build the augmented system with the factor of the
         // PREVIOUS iteration's A_c -- any nonsingular L~ gives a consistent system V^T S^ V with
@@ -494,7 +503,7 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             h->lci_cur = use;
             // borders K, K^T, the coarse-coarse rows and (last workgroup) the coarse right-hand side
             const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[use], h->tvec, h->cg_r[0], h->cg_w[0],
-                                   h->cg_s[0], h->cg_p, h->cg_xh, 2, h->lag_status, h->status};
+                                   h->cg_s[0], h->cg_p, h->cg_xh, 2, h->lag_status, h->status, h->bgv};
             hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr + ncb + 1), dim3(256), border_lds, h->stream,
                                nr, ncb, h->SZ, h->Lci2[use], h->arow_ptr, h->fine_nnz, h->Saug, 1, h->Ac, ra);
             HIP_OK(hipEventRecord(h->ev_ac, h->stream));           // A_c complete, buffer use^1 no longer read
@@ -506,7 +515,7 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             const int buf = h->lci_cur;
             if (launch_chol(h->stream, buf, h->status)) return -1;
             const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[buf], h->tvec, h->cg_r[0], h->cg_w[0],
-                                   h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, nullptr, h->status};
+                                   h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, nullptr, h->status, h->bgv};
             hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr + 1), dim3(256), border_lds, h->stream,
                                nr, ncb, h->SZ, h->Lci2[buf], h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1,
                                (const double*)nullptr, ra);
@@ -561,7 +570,7 @@ void cg_fused_recover(ps_problem* h, const int32_t* gate) {
     const int nr = h->nr;
     if (h->G)
         hipLaunchKernelGGL(k_coarse_recover<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->ncb,
-                           h->pnode, h->pw0, h->pw1, h->Linv, h->Lci2[h->lci_cur], h->cg_xh, h->x, gate);
+                           h->pnode, h->pw0, h->pw1, h->Linv, h->Lci2[h->lci_cur], h->cg_xh, h->x, gate, h->Bmat);
     else
         hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->Linv,
                            h->cg_xh, h->x, gate);
@@ -959,6 +968,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     std::vector<int32_t> pitem_ptr(nr + 1, 0);
     std::vector<int32_t> pose_of_rid(std::max(nr, 1), 0);
     for (int p = 0; p < P; ++p) if (d->pose_rid[p] >= 0) pose_of_rid[d->pose_rid[p]] = p;
+    if (h->upload(&h->pose_of_rid, pose_of_rid)) return -1;
     // chunk of observations per workgroup: 1024 (four per thread) once that still fills the chip
     const int pchunk = Np >= 1024L * 512 ? 1024 : 256;
     for (int r = 0; r < nr; ++r) {
@@ -1603,6 +1613,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_lds") h->cg_lds = value != 0.0;
+    else if (n == "coarse_basis") { h->coarse_basis = value != 0.0; h->lci_next = -1; }
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }

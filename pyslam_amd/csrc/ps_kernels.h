@@ -821,7 +821,12 @@ __global__ __launch_bounds__(256) void k_block_jacobi_factor(
     double* __restrict__ Linv, int32_t* __restrict__ status,
     // fused CG only (g != NULL): also the start vectors of the scaled system, r = Linv g, w = s = p = x = 0
     const double* __restrict__ g, double* __restrict__ r0, double* __restrict__ w0, double* __restrict__ s0,
-    double* __restrict__ p0, double* __restrict__ x0)
+    double* __restrict__ p0, double* __restrict__ x0,
+    // two-level CG (Bmat != NULL): the coarse basis block of this pose, B_i = L_i^T Ad(T_i) (basis 1: a
+    // coarse unknown is a BODY-frame twist eta, the fine correction is x_i = Ad(T_i) eta, x^_i = L_i^T x_i)
+    // or the identity (basis 0: hats directly in the scaled coordinates), and bg_i = B_i^T r_i
+    const double* __restrict__ poses, const int32_t* __restrict__ pose_of_rid, int basis,
+    double* __restrict__ Bmat, double* __restrict__ bg)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (g && i == 0) { status[ST_PCG_DONE] = 0; status[ST_PCG_ITERS] = 0; }
@@ -876,6 +881,49 @@ __global__ __launch_bounds__(256) void k_block_jacobi_factor(
             r0[o] = v; w0[o] = 0.0; s0[o] = 0.0; p0[o] = 0.0; x0[o] = 0.0;
         }
     }
+    if (Bmat) {
+        typedef PoseOps<D> G;
+        double B[D][D];
+        if (basis == 1) {
+            const typename G::T T = G::load(poses + G::W * (size_t)pose_of_rid[i]);
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m2 = a; m2 < D; ++m2) v += L[m2][a] * G::adj(T, m2, c);     // (L^T Ad)[a][c]
+                    B[a][c] = v;
+                }
+        } else {
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int c = 0; c < D; ++c) B[a][c] = (a == c) ? 1.0 : 0.0;
+        }
+        double* bm = Bmat + (size_t)i * D * D;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int c = 0; c < D; ++c) bm[a * D + c] = B[a][c];
+        if (g) {
+            double rr[D];
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < D; ++c) v += Li[r][c] * g[(size_t)i * D + c];
+                rr[r] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double v = 0.0;
+#pragma unroll
+                for (int a = 0; a < D; ++a) v += B[a][c] * rr[a];
+                bg[(size_t)i * D + c] = v;
+            }
+        }
+    }
 }
 
 // Sout[out_slot[b]] = Linv_i S_ij Linv_j^T  (one 64-thread workgroup per block; S itself is kept)
@@ -883,16 +931,19 @@ template <int D>
 __global__ __launch_bounds__(64) void k_scale_blocks(
     int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
     const int32_t* __restrict__ brow_of, const double* __restrict__ Linv, const double* __restrict__ S,
-    const int32_t* __restrict__ out_slot, double* __restrict__ Sout)
+    const int32_t* __restrict__ out_slot, double* __restrict__ Sout,
+    const double* __restrict__ Bmat /* two-level CG: also SB[b] = S^_b B_j, the input of the coarse row sums */,
+    double* __restrict__ SB)
 {
     constexpr int DD = D * D;
-    __shared__ double sS[36], sT[36], sLi[36], sLj[36];
+    __shared__ double sS[36], sT[36], sLi[36], sLj[36], sB[36];
     const int b = blockIdx.x, t = threadIdx.x;
     const int i = brow_of[b], j = col_idx[b];
     if (t < DD) {
         sS[t] = S[(size_t)b * DD + t];
         sLi[t] = Linv[(size_t)i * DD + t];
         sLj[t] = Linv[(size_t)j * DD + t];
+        if (Bmat) sB[t] = Bmat[(size_t)j * DD + t];
     }
     __syncthreads();
     const int r = t / D, c = t % D;
@@ -908,6 +959,15 @@ __global__ __launch_bounds__(64) void k_scale_blocks(
 #pragma unroll
         for (int a = 0; a < D; ++a) v += sT[r * D + a] * sLj[c * D + a];
         Sout[(size_t)out_slot[b] * DD + t] = v;
+        sS[t] = v;
+    }
+    if (!Bmat) return;
+    __syncthreads();
+    if (t < DD) {
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) v += sS[r * D + a] * sB[a * D + c];
+        SB[(size_t)out_slot[b] * DD + t] = v;
     }
 }
 
@@ -916,7 +976,8 @@ template <int D>
 __global__ __launch_bounds__(256) void k_cg_prepare(
     int nr, const double* __restrict__ g, const double* __restrict__ Linv,
     double* __restrict__ r, double* __restrict__ w, double* __restrict__ s,
-    double* __restrict__ p, double* __restrict__ x, int32_t* __restrict__ status)
+    double* __restrict__ p, double* __restrict__ x, int32_t* __restrict__ status,
+    const double* __restrict__ Bmat, double* __restrict__ bg /* two-level: bg_i = B_i^T r_i */)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) { status[ST_PCG_DONE] = 0; status[ST_PCG_ITERS] = 0; }
@@ -926,6 +987,17 @@ __global__ __launch_bounds__(256) void k_cg_prepare(
 #pragma unroll
     for (int c = 0; c < D; ++c) v += Linv[(size_t)i * D * D + rr_ * D + c] * g[(size_t)i * D + c];
     r[t] = v; w[t] = 0.0; s[t] = 0.0; p[t] = 0.0; x[t] = 0.0;
+    if (Bmat) {                                          // column rr_ of B_i against the whole r_i (recomputed: D^2 flops)
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            double ra = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; ++c) ra += Linv[(size_t)i * D * D + a * D + c] * g[(size_t)i * D + c];
+            acc += Bmat[(size_t)i * D * D + a * D + rr_] * ra;
+        }
+        bg[t] = acc;
+    }
 }
 
 PS_DEV double cg_rnew(double r, double w, double s, double alpha, double beta) {
@@ -1356,25 +1428,39 @@ PS_DEV double coarse_weight(int j, int q, const int32_t* __restrict__ pnode,
     return (pnode[j] == q) ? pw0[j] : pw1[j];
 }
 
-// SZ[i][q] (D x D) = sum_j S^_ij w(j,q) over the contiguous run of row i's blocks whose column
-// lies in the support of node q (run_lo / run_hi, precomputed).  One workgroup per fine row.
+// SZ[i][q] (D x D) = sum_j S^_ij B_j w(j,q) over the contiguous run of row i's blocks whose column
+// lies in the support of node q (run_lo / run_hi, precomputed), i.e. (S^ P)_iq with the coarse basis
+// P_jq = w(j,q) B_j; and BSZ[i][q] = B_i^T SZ[i][q], the summand of A_c = P^T S^ P.  One workgroup per fine row.
 template <int D>
 __global__ __launch_bounds__(256) void k_coarse_rowsums(
     int nr, int ncb, const int32_t* __restrict__ run_lo, const int32_t* __restrict__ run_hi,
     const int32_t* __restrict__ acol_idx, const int32_t* __restrict__ pnode,
     const double* __restrict__ pw0, const double* __restrict__ pw1,
-    const double* __restrict__ Saug, double* __restrict__ SZ)
+    const double* __restrict__ SB /* S^_ij B_j per fine block (augmented-matrix slots) */,
+    double* __restrict__ SZ, const double* __restrict__ Bmat, double* __restrict__ BSZ /* B_i^T SZ[i][q] */)
 {
     constexpr int DD = D * D;
+    extern __shared__ double srow[];                     // ncb x DD: this row's SZ blocks, + DD: B_i
     const int i = blockIdx.x, nslot = ncb * DD;
+    double* sBi = srow + nslot;
+    if (threadIdx.x < DD) sBi[threadIdx.x] = Bmat[(size_t)i * DD + threadIdx.x];
     for (int t = threadIdx.x; t < nslot; t += blockDim.x) {
         const int q = t / DD, e = t % DD;
         const int k0 = run_lo[i * ncb + q], k1 = run_hi[i * ncb + q];
         double acc = 0.0;
 #pragma unroll 4
         for (int k = k0; k < k1; ++k)
-            acc += Saug[(size_t)k * DD + e] * coarse_weight(acol_idx[k], q, pnode, pw0, pw1);
+            acc += SB[(size_t)k * DD + e] * coarse_weight(acol_idx[k], q, pnode, pw0, pw1);
         SZ[(size_t)i * nslot + t] = acc;
+        srow[t] = acc;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nslot; t += blockDim.x) {
+        const int q = t / DD, e = t % DD, r = e / D, c = e % D;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) acc += sBi[m * D + r] * srow[q * DD + m * D + c];
+        BSZ[(size_t)i * nslot + t] = acc;
     }
 }
 
@@ -1543,6 +1629,7 @@ struct CoarseRhsArgs {
     int with_coarse_rows;
     const int32_t* lag_status;
     int32_t* status;
+    const double* bg;
 };
 
 template <int D>
@@ -1553,7 +1640,8 @@ PS_DEV void coarse_rhs_body(
     double* __restrict__ Saug, double* __restrict__ tvec,
     double* __restrict__ r, double* __restrict__ w, double* __restrict__ s,
     double* __restrict__ p, double* __restrict__ x,
-    int with_coarse_rows, const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, double* stv);
+    int with_coarse_rows, const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, double* stv,
+    const double* __restrict__ bg);
 
 // K_i = SZ_i Lci^T, written to both borders of the augmented BSR matrix.
 // One workgroup per fine block row i; thread per (r, c) of the D x nc strip.
@@ -1574,7 +1662,7 @@ __global__ __launch_bounds__(256) void k_coarse_border(
     const int i = blockIdx.x;
     if (rhs.r && i == (int)gridDim.x - 1) {
         coarse_rhs_body<D>(nr, ncb, rhs.slo, rhs.shi, rhs.pnode, rhs.pw0, rhs.pw1, rhs.LciT, arow_ptr, Saug, rhs.tvec,
-                           rhs.r, rhs.w, rhs.s, rhs.p, rhs.x, rhs.with_coarse_rows, rhs.lag_status, rhs.status, sT);
+                           rhs.r, rhs.w, rhs.s, rhs.p, rhs.x, rhs.with_coarse_rows, rhs.lag_status, rhs.status, sT, rhs.bg);
         return;
     }
     if (i >= nr) {                                                  // lagged mode: row q of M
@@ -1623,7 +1711,8 @@ PS_DEV void coarse_rhs_body(
     double* __restrict__ r /* fine part holds g^ */, double* __restrict__ w, double* __restrict__ s,
     double* __restrict__ p, double* __restrict__ x,
     int with_coarse_rows /* 1: write the coarse-coarse rows as identity (exact factor); 2: leave them (lagged) */,
-    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, double* stv /* LDS, >= nc doubles */)
+    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, double* stv /* LDS, >= nc doubles */,
+    const double* __restrict__ bg /* B^T g^ per fine row */)
 {
     constexpr int DD = D * D;
     const int nc = ncb * D;
@@ -1636,7 +1725,7 @@ PS_DEV void coarse_rhs_body(
         if (t < nc) {
             const int q = t / D, c = t % D;
             for (int i = slo[q] + sub; i < shi[q]; i += 8)
-                v += coarse_weight(i, q, pnode, pw0, pw1) * r[(size_t)i * D + c];
+                v += coarse_weight(i, q, pnode, pw0, pw1) * bg[(size_t)i * D + c];       // (P^T g^)_q, bg = B^T g^
         }
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
         if (t < nc && sub == 0) tvec[t] = v;
@@ -1672,11 +1761,11 @@ __global__ __launch_bounds__(1024) void k_coarse_rhs(
     double* __restrict__ Saug, double* __restrict__ tvec,
     double* __restrict__ r, double* __restrict__ w, double* __restrict__ s,
     double* __restrict__ p, double* __restrict__ x, int with_coarse_rows,
-    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status)
+    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, const double* __restrict__ bg)
 {
     __shared__ double stv[400];
     coarse_rhs_body<D>(nr, ncb, slo, shi, pnode, pw0, pw1, LciT, arow_ptr, Saug, tvec, r, w, s, p, x,
-                       with_coarse_rows, lag_status, status, stv);
+                       with_coarse_rows, lag_status, status, stv, bg);
 }
 
 // x^_i = x~_f,i + pw0_i y[node_i] + pw1_i y[node_i + 1] with y = Lci^T x~_c ;  x_i = Linv_i^T x^_i
@@ -1685,7 +1774,8 @@ template <int D>
 __global__ __launch_bounds__(256) void k_coarse_recover(
     int nr, int ncb, const int32_t* __restrict__ pnode, const double* __restrict__ pw0,
     const double* __restrict__ pw1, const double* __restrict__ Linv, const double* __restrict__ Lci,
-    const double* __restrict__ xh, double* __restrict__ x, const int32_t* __restrict__ gate)
+    const double* __restrict__ xh, double* __restrict__ x, const int32_t* __restrict__ gate,
+    const double* __restrict__ Bmat)
 {
     __shared__ double sy[192];
     if (gate && !gate[ST_PCG_DONE]) return;
@@ -1706,11 +1796,15 @@ __global__ __launch_bounds__(256) void k_coarse_recover(
     if (t >= nr * D) return;
     const int i = t / D, c = t % D, q = pnode[i];
     const double w0 = pw0[i], w1 = pw1[i];
+    double z[D];                                         // interpolated coarse unknown at pose i
+#pragma unroll
+    for (int m = 0; m < D; ++m) z[m] = w0 * sy[q * D + m] + ((q + 1 < ncb) ? w1 * sy[(q + 1) * D + m] : 0.0);
     double v = 0.0;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-        const double y1 = (q + 1 < ncb) ? sy[(q + 1) * D + a] : 0.0;
-        const double xhat = xh[(size_t)i * D + a] + w0 * sy[q * D + a] + w1 * y1;
+        double xhat = xh[(size_t)i * D + a];
+#pragma unroll
+        for (int m = 0; m < D; ++m) xhat += Bmat[(size_t)i * D * D + a * D + m] * z[m];
         v += Linv[(size_t)i * D * D + a * D + c] * xhat;
     }
     x[t] = v;
