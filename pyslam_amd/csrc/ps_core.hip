@@ -334,9 +334,10 @@ int build_coarse(ps_problem* h) {
     const int Gmax = 63;                           // nc = (G + 1) D <= 384; LDS-resident factorisation up to nc = 96
     // auto: on from 48 reduced poses, ~18 poses per hat interval, at most 12 intervals while the
     // coarse factorisation is LDS-resident; large systems (split mode, no dense border rows) take 24
+    // (dense BA-like rows) or 48 (long sparse pose-graph chains)
     if (G < 0) {
         if (nr < 48) G = 0;
-        else if (nr > h->cg_split_min_rows) G = ((long)h->nnzb > 24L * nr) ? 24 : 0;   // not for long, sparse chains
+        else if (nr > h->cg_split_min_rows) G = ((long)h->nnzb > 24L * nr) ? 24 : 48;  // measured: C4 (BA, 2 000 poses) / C2 (10 000-pose chain)
         else G = std::min(12, std::max(3, (nr + 9) / 18));
     }
     G = std::min(G, Gmax);

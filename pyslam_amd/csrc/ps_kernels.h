@@ -1777,7 +1777,7 @@ __global__ __launch_bounds__(256) void k_coarse_recover(
     const double* __restrict__ xh, double* __restrict__ x, const int32_t* __restrict__ gate,
     const double* __restrict__ Bmat)
 {
-    __shared__ double sy[192];
+    __shared__ double sy[400];                          // nc <= 384 (Gmax = 63 intervals, D = 6)
     if (gate && !gate[ST_PCG_DONE]) return;
     const int nc = ncb * D;
     const double* xc = xh + (size_t)nr * D;

@@ -215,3 +215,23 @@ def test_c3_covariance_columns_solve_the_reference_precision(c3):
         assert np.linalg.norm(res / dg) <= 1e-8 * np.linalg.norm(x * dg), (kind, index)
         k = (index * d + comp) if kind == 0 else (nr * d + index * 3 + comp)
         assert x[k] > 0.                                       # a variance
+
+def test_c2_full_size_first_steps_match_the_reference_algebra():
+    """BASELINE config C2 at full size: 10 000 SE(3) poses, 50 001 edges, Huber, prior on pose 0.  Two
+    Gauss-Newton steps on the device (two-level CG with the rigid-motion-aware coarse basis, relative
+    tolerance 1e-12) against the oracle's sparse direct solves of the reference's normal equations."""
+    import scipy.sparse.linalg as spl
+    lp, _ = synthetic.pose_graph(num_poses=10000, num_loops=40001, dof=6, seed=2)
+    dev = device(lp)
+    cur = lp
+    assert abs(dev.eval_cost(True) - orc.eval_cost(cur)) <= 1e-10 * orc.eval_cost(cur)
+    for _ in range(2):
+        H, b, _ = orc.normal_equations(cur, points_first=False)
+        dx = spl.spsolve(H.tocsc(), b)
+        cur = orc.apply_update(cur, dx, False)
+        cost, nrm, its, rel = dev.gn_iteration(0., 1e-12, 4000, True)
+        assert rel <= 1e-12 and its < 4000                       # the CG converges (it did not before the Ad-aware basis)
+        assert abs(nrm - np.linalg.norm(dx)) <= 1e-6 * np.linalg.norm(dx)
+        assert abs(cost - orc.eval_cost(cur)) <= 1e-6 * cost
+    poses, _ = dev.get_params()
+    assert np.abs(poses - cur.poses).max() < 1e-5

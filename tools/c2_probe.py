@@ -13,7 +13,7 @@ for G in ([int(a) for a in sys.argv[2:]] or [-1, 0]):
     hist = [dev.eval_cost(True)]
     for it in range(6):
         dev.set_profiling(2); dev.stage_times(reset=True)
-        t = time.time(); out = dev.gn_iteration(0., 1e-12, 4000, True); dt = time.time() - t
+        t = time.time(); out = dev.gn_iteration(0., 1e-12, int(os.environ.get("C2_MAXIT", "4000")), True); dt = time.time() - t
         st = {k: round(v[0], 3) for k, v in dev.stage_times(reset=True).items() if v[1]}
         hist.append(out[0])
         print('G', G, 'it', it, 'cost %.6e' % out[0], '%.3f ms' % (dt * 1e3), 'pcg', out[2], 'relres %.1e' % out[3], st)
