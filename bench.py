@@ -68,21 +68,26 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(lp):
-    """The numpy/scipy oracle (a port of the reference's algebra) on the host cores."""
+def cpu_baseline(lp, repeats=5):
+    """The numpy/scipy oracle (a port of the reference's algebra) on the host cores: `repeats` whole
+    iterations of the same workload (about 10 s of CPU work), mean time per iteration."""
     from oracle import gn_oracle as orc
-    t0 = time.perf_counter()
-    P, b, _ = orc.normal_equations(lp, True)                 # residuals, Jacobians, J^T J, -J^T e
-    t1 = time.perf_counter()
-    dx = orc.schur_solve(lp, P, b, True)                     # landmark elimination + sparse reduced solve
-    t2 = time.perf_counter()
-    new = orc.apply_update(lp, dx, True)
-    orc.eval_cost(new); orc.eval_cost(new)                   # the reference's line search: 2 cost passes
-    t3 = time.perf_counter()
-    return {'value': round((t3 - t0) * 1e3, 1), 'unit': 'ms/LM-iter', 'cores': 1, 'kind': 'port',
-            'sample': 'ONE iteration of the same workload (500k blocks): vectorised numpy residual/Jacobian '
-                      '+ scipy CSR J^T J {:.1f} s, CPU Schur + scipy spsolve of the reduced system {:.1f} s, '
-                      'update + 2 cost passes {:.1f} s; numpy/scipy single-threaded'.format(t1 - t0, t2 - t1, t3 - t2),
+    ta = tb = tc = 0.
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        P, b, _ = orc.normal_equations(lp, True)                 # residuals, Jacobians, J^T J, -J^T e
+        t1 = time.perf_counter()
+        dx = orc.schur_solve(lp, P, b, True)                     # landmark elimination + sparse reduced solve
+        t2 = time.perf_counter()
+        new = orc.apply_update(lp, dx, True)
+        orc.eval_cost(new); orc.eval_cost(new)                   # the reference's line search: 2 cost passes
+        t3 = time.perf_counter()
+        ta += t1 - t0; tb += t2 - t1; tc += t3 - t2
+    ta, tb, tc = ta / repeats, tb / repeats, tc / repeats
+    return {'value': round((ta + tb + tc) * 1e3, 1), 'unit': 'ms/LM-iter', 'cores': 1, 'kind': 'port',
+            'sample': '{} iterations of the same workload (500k blocks), mean per iteration: vectorised numpy '
+                      'residual/Jacobian + scipy CSR J^T J {:.2f} s, CPU Schur + scipy spsolve of the reduced system '
+                      '{:.2f} s, update + 2 cost passes {:.2f} s; numpy/scipy single-threaded'.format(repeats, ta, tb, tc),
             'host_cpus': os.cpu_count()}
 
 
