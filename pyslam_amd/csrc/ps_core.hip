@@ -118,6 +118,8 @@ struct ps_problem {
     int32_t* lag_status = nullptr;  // ST_DIAG_FAIL of the side-stream factorisation
     bool coarse_built = false;
     int cg_ablate = 0, schur_ablate = 0, lm_ablate = 0;
+    int direct_max = 90;            // reduced systems up to this many unknowns are solved directly (0: never)
+    double *dA = nullptr, *dLi = nullptr, *dLiT = nullptr;
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;
@@ -332,11 +334,11 @@ int build_coarse(ps_problem* h) {
     const int nr = h->nr, D = h->D;
     int G = h->coarse_req;
     const int Gmax = 63;                           // nc = (G + 1) D <= 384; LDS-resident factorisation up to nc = 96
-    // auto: on from 48 reduced poses, ~18 poses per hat interval, at most 12 intervals while the
+    // auto: on from 16 reduced poses, ~18 poses per hat interval, at most 12 intervals while the
     // coarse factorisation is LDS-resident; large systems (split mode, no dense border rows) take 24
     // (dense BA-like rows) or 48 (long sparse pose-graph chains)
     if (G < 0) {
-        if (nr < 48) G = 0;
+        if (nr < 16) G = 0;                        // (systems up to 90 unknowns are solved directly anyway)
         else if (nr > h->cg_split_min_rows) G = ((long)h->nnzb > 24L * nr) ? 24 : 48;  // measured: C4 (BA, 2 000 poses) / C2 (10 000-pose chain)
         else G = std::min(12, std::max(3, (nr + 9) / 18));
     }
@@ -741,9 +743,35 @@ int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = f
     return 0;
 }
 
+bool use_direct(const ps_problem* h) {
+    return h->pcg_variant == 1 && h->nr > 0 && h->nr * h->D <= h->direct_max;
+}
+
+// small reduced systems: dense blocked Cholesky in LDS instead of CG (enqueue only)
+template <int D>
+int direct_solve_enqueue(ps_problem* h) {
+    const int nr = h->nr, n = nr * D;
+    if (!h->dA && (h->alloc(&h->dA, (size_t)n * n) || h->alloc(&h->dLi, (size_t)n * n) || h->alloc(&h->dLiT, (size_t)n * n)))
+        return -1;
+    hipLaunchKernelGGL(k_bsr_to_dense<D>, dim3(1), dim3(256), 0, h->stream, nr, h->nnzb, h->brow_of, h->col_idx, h->S, h->dA);
+    const size_t chol_lds = 2 * (size_t)n * n * sizeof(double);
+    HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
+    hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, h->stream, nr, h->dA, h->dLi, h->dLiT,
+                       h->status, nullptr);
+    hipLaunchKernelGGL(k_direct_apply<D>, dim3(1), dim3(256), 0, h->stream, n, h->dLi, h->dLiT, h->g, h->x, h->status,
+                       h->scalars);
+    h->cg_launched = 0;
+    return 0;
+}
+
 int solve_reduced(ps_problem* h, double tol, int max_iters, int* iters, double* relres) {
     if (h->nr == 0) { if (iters) *iters = 0; if (relres) *relres = 0.0; return 0; }
     StageTimer t(h, PS_ST_PCG);
+    if (use_direct(h)) {
+        if (h->D == 6 ? direct_solve_enqueue<6>(h) : direct_solve_enqueue<3>(h)) return -1;
+        if (read_scalars(h)) return -1;
+        return cg_report(h, iters, relres);
+    }
     if (h->pcg_variant == 1)
         return h->D == 6 ? cg_fused_run<6>(h, tol, max_iters, iters, relres) : cg_fused_run<3>(h, tol, max_iters, iters, relres);
     return h->D == 6 ? pcg_run<6>(h, tol, max_iters, iters, relres) : pcg_run<3>(h, tol, max_iters, iters, relres);
@@ -760,6 +788,14 @@ template <int D>
 int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int linesearch,
                               int* iters_out, double* relres_out, StageTimer* total) {
     StageTimer tp(h, PS_ST_PCG);
+    if (use_direct(h)) {                                    // small system: three launches, then the (ungated) tail
+        if (direct_solve_enqueue<D>(h)) return -1;
+        tp.stop();
+        if (gn_tail(h, linesearch, nullptr, true)) return -1;
+        if (total) total->stop();
+        if (wait_published(h)) return -1;
+        return cg_report(h, iters_out, relres_out);
+    }
     if (cg_fused_setup<D>(h, max_iters, true)) return -1;
     int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + h->cg_margin : 16;
     for (;;) {
@@ -1516,7 +1552,7 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
 int ps_covariance_begin(ps_problem* h) {
     if (!h) return fail("null argument");
     if (linearize(h, 0.0)) return -1;
-    if (h->nr > 0 && h->pcg_variant == 1) {
+    if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h)) {
         const int rc = h->D == 6 ? cg_fused_setup<6>(h, 16) : cg_fused_setup<3>(h, 16);
         if (rc) return -1;
     }
@@ -1547,7 +1583,11 @@ int ps_covariance_column(ps_problem* h, int kind, int index, int comp, double to
     int its = 0; double rel = 0.0;
     if (h->nr > 0) {
         int rc;
-        if (h->pcg_variant == 1)
+        if (use_direct(h)) {
+            rc = h->D == 6 ? direct_solve_enqueue<6>(h) : direct_solve_enqueue<3>(h);
+            if (!rc) rc = read_scalars(h);
+            if (!rc) rc = cg_report(h, &its, &rel);
+        } else if (h->pcg_variant == 1)
             rc = h->D == 6 ? cg_fused_run<6>(h, tol, max_iters, &its, &rel, true) : cg_fused_run<3>(h, tol, max_iters, &its, &rel, true);
         else
             rc = h->D == 6 ? pcg_run<6>(h, tol, max_iters, &its, &rel) : pcg_run<3>(h, tol, max_iters, &its, &rel);
@@ -1614,6 +1654,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_lds") h->cg_lds = value != 0.0;
+    else if (n == "direct_max_unknowns") { if (value < 0 || value > 90) return fail("direct_max_unknowns must be 0..90"); h->direct_max = (int)value; }
     else if (n == "coarse_basis") { h->coarse_basis = value != 0.0; h->lci_next = -1; }
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }

@@ -1387,6 +1387,53 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused_lds(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Direct solve of SMALL reduced systems (nr * D <= 90 unknowns: the reference's own examples, sliding
+// windows, motion-only problems): BSR -> dense, the LDS-resident blocked Cholesky + inverse of the
+// coarse level (k_coarse_chol), x = L^-T (L^-1 g).  Three launches instead of a CG's 10-40.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_bsr_to_dense(
+    int nr, int nnzb, const int32_t* __restrict__ brow_of, const int32_t* __restrict__ col_idx,
+    const double* __restrict__ S, double* __restrict__ A)
+{
+    constexpr int DD = D * D;
+    const int n = nr * D;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * n; t += gridDim.x * blockDim.x) A[t] = 0.0;
+    // (single workgroup launch: the zero fill above is complete for this workgroup after the barrier)
+    __syncthreads();
+    for (int t = threadIdx.x; t < nnzb * DD; t += blockDim.x) {
+        const int b = t / DD, e = t % DD;
+        A[(size_t)(brow_of[b] * D + e / D) * n + col_idx[b] * D + e % D] = S[t];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_direct_apply(
+    int n, const double* __restrict__ Li, const double* __restrict__ LiT, const double* __restrict__ g,
+    double* __restrict__ x, int32_t* __restrict__ status, double* __restrict__ scalars)
+{
+    __shared__ double sg[96], sy[96];
+    const int t = threadIdx.x;
+    if (t < n) sg[t] = g[t];
+    __syncthreads();
+    if (t < n) {                                         // y = L^-1 g   (row t of Li, k <= t)
+        double v = 0.0;
+        for (int k = 0; k <= t; ++k) v += LiT[(size_t)k * n + t] * sg[k];
+        sy[t] = v;
+    }
+    __syncthreads();
+    if (t < n) {                                         // x = L^-T y   (column t of Li, k >= t)
+        double v = 0.0;
+        for (int k = t; k < n; ++k) v += Li[(size_t)k * n + t] * sy[k];
+        x[t] = v;
+    }
+    if (t == 0) {
+        status[ST_PCG_DONE] = 1; status[ST_PCG_ITERS] = 0;
+        scalars[SC_RR0] = 1.0; scalars[SC_RRFINAL] = 0.0;
+    }
+}
+
 // x = Linv^T x^
 template <int D>
 __global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __restrict__ Linv,
