@@ -118,6 +118,10 @@ struct ps_problem {
     int32_t* lag_status = nullptr;  // ST_DIAG_FAIL of the side-stream factorisation
     bool coarse_built = false;
     int cg_ablate = 0, schur_ablate = 0, lm_ablate = 0;
+    int max_pose_obs = 0;           // most observations on one variable pose
+    int mo_fused = 1;               // motion-only problems: one launch per iteration (k_motion_only_iteration)
+    double* mo_partials = nullptr;
+    bool status_clean = true;       // no failure flag can be pending in the device status words
     int direct_max = 90;            // reduced systems up to this many unknowns are solved directly (0: never)
     double *dA = nullptr, *dLi = nullptr, *dLiT = nullptr;
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
@@ -615,6 +619,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
 
 int linearize(ps_problem* h, double lambda) {
     h->cov_ready = false;
+    h->status_clean = false;
     HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double) + ST_NWORDS * sizeof(int32_t), h->stream));   // [S | g | cost | status]
     if (h->nv > 0) {
         StageTimer t(h, PS_ST_LANDMARK);
@@ -999,6 +1004,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pcount[r + 1]++; }
     for (int r = 0; r < nr; ++r) pcount[r + 1] += pcount[r];
     const long Np = h->Np = pcount[nr];
+    for (int r = 0; r < nr; ++r) h->max_pose_obs = std::max(h->max_pose_obs, pcount[r + 1] - pcount[r]);
     std::vector<int32_t> pidx(Np), fill(pcount.begin(), pcount.end() - 1);
     for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pidx[fill[r]++] = (int32_t)k; }
     std::vector<PItem> pitems;
@@ -1527,6 +1533,32 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
         if (dx_norm_out) *dx_norm_out = std::sqrt(dxp2 + sb[1]);
         return 0;
     }
+    if (h->mo_fused && h->nv == 0 && h->F == 0 && h->nr > 0 && h->D == 6 && h->N == h->Np && h->pcg_variant == 1 &&
+        h->max_pose_obs <= 2048) {
+        // motion-only: block-diagonal reduced system, the whole iteration is ONE launch (one workgroup per pose;
+        // beyond ~2 000 observations per pose one workgroup is slower than the multi-kernel path)
+        StageTimer total(h, PS_ST_TOTAL, 2);
+        h->cov_ready = false;
+        if (!h->mo_partials && h->alloc(&h->mo_partials, 2 * (size_t)h->nr)) return -1;
+        if (!h->status_clean) {
+            HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+            h->status_clean = true;
+        }
+        hipLaunchKernelGGL(k_motion_only_iteration, dim3(h->nr), dim3(PS_MO_THREADS), 0, h->stream, h->nr, h->pitems, h->pitem_ptr,
+                           h->pobs, h->points, h->ogroups, h->poses, lambda, linesearch, h->x, h->mo_partials, h->status,
+                           h->scalars, h->arrivals + 1, h->h_status_dev, h->h_scalars_dev, h->h_seq_dev, ++h->seq);
+        total.stop();
+        if (wait_published(h)) return -1;
+        if (pcg_iters_out) *pcg_iters_out = 0;
+        if (pcg_relres_out) *pcg_relres_out = 0.0;
+        if (h->h_status[ST_DIAG_FAIL]) {
+            h->status_clean = false;
+            return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+        }
+        if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+        if (dx_norm_out) *dx_norm_out = std::sqrt(h->h_scalars[SC_DXP2]);
+        return 0;
+    }
     {
         StageTimer total(h, PS_ST_TOTAL, 2);  // closed before the last synchronising read-back
         if (linearize(h, lambda)) return -1;
@@ -1654,6 +1686,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_lds") h->cg_lds = value != 0.0;
+    else if (n == "fused_motion_only") h->mo_fused = value != 0.0;
     else if (n == "direct_max_unknowns") { if (value < 0 || value > 90) return fail("direct_max_unknowns must be 0..90"); h->direct_max = (int)value; }
     else if (n == "coarse_basis") { h->coarse_basis = value != 0.0; h->lci_next = -1; }
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }

@@ -1858,6 +1858,158 @@ __global__ __launch_bounds__(256) void k_coarse_recover(
 }
 
 // ---------------------------------------------------------------------------
+// Motion-only problems (no variable landmark, no pose factor: the reduced system is block diagonal --
+// reference pipelines/sparse.py:153-161, SURVEY config C5): ONE launch per Gauss-Newton iteration.
+// One workgroup per pose: residuals + Jacobians + IRLS of its observations, 33 sums, 6 x 6 Cholesky
+// solve, retraction, post-step cost; the last workgroup to arrive sums the per-pose {cost, |dx|^2}
+// in pose order and publishes status + scalars to pinned host memory (sequence word).
+// ---------------------------------------------------------------------------
+#define PS_MO_THREADS 512
+__global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
+    int nr, const PItem* __restrict__ items, const int32_t* __restrict__ pitem_ptr,
+    const LObs* __restrict__ pobs, const double* __restrict__ points, const ObsGroup* __restrict__ groups,
+    double* __restrict__ poses, double lambda, int linesearch,
+    double* __restrict__ xout /* nr x 6 */, double* __restrict__ partials /* nr x 2: cost, |dx|^2 */,
+    int32_t* __restrict__ status, double* __restrict__ scalars, int32_t* __restrict__ arrivals,
+    int32_t* __restrict__ hst, double* __restrict__ hsc, long long* __restrict__ hseq, long long seq)
+{
+    constexpr int NWV = PS_MO_THREADS / 64;
+    __shared__ double red[NWV][PS_NPOSE_ACC + 1];
+    __shared__ double tot[PS_NPOSE_ACC + 1];
+    __shared__ double sT[12];
+    __shared__ int s_last;
+    const int rid = blockIdx.x, t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int ib = pitem_ptr[rid], ie = pitem_ptr[rid + 1];
+    const int start = ib < ie ? items[ib].start : 0, end = ib < ie ? items[ie - 1].end : 0;
+    const int pose = ib < ie ? items[ib].pad : 0;
+    Se3 T = se3_load(poses + 12 * (size_t)pose);
+    double acc[PS_NPOSE_ACC + 1];
+#pragma unroll
+    for (int k = 0; k <= PS_NPOSE_ACC; ++k) acc[k] = 0.0;
+    for (int i = start + t; i < end; i += PS_MO_THREADS) {
+        const LObs o = pobs[i];
+        const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
+        ReprojEval ev;
+        reproj_eval<true, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b)
+                acc[n++] += ev.Jp[a] * ev.Jp[b] + ev.Jp[6 + a] * ev.Jp[6 + b] + ev.Jp[12 + a] * ev.Jp[12 + b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            acc[21 + a] -= ev.Jp[a] * ev.r[0] + ev.Jp[6 + a] * ev.r[1] + ev.Jp[12 + a] * ev.r[2];
+            acc[27 + a] += ev.Jp[a] * ev.Jp[a] + ev.Jp[6 + a] * ev.Jp[6 + a] + ev.Jp[12 + a] * ev.Jp[12 + a];
+        }
+        acc[PS_NPOSE_ACC] += ev.cost;
+    }
+#pragma unroll
+    for (int k = 0; k <= PS_NPOSE_ACC; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[w][k] = v;
+    }
+    __syncthreads();
+    if (t <= PS_NPOSE_ACC) {
+        double v = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NWV; ++ww) v += red[ww][t];
+        tot[t] = v;
+    }
+    __syncthreads();
+    double sq = 0.0;
+    if (t == 0) {
+        // H = J^T J (+ lambda diag) = L L^T ;  x = H^-1 g
+        double H[6][6], x[6];
+        bool ok = true;
+        int n = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) { H[a][b] = tot[n]; H[b][a] = tot[n]; ++n; }
+        for (int a = 0; a < 6; ++a) H[a][a] += lambda * tot[27 + a];
+        for (int j = 0; j < 6; ++j) {
+            double d = H[j][j];
+            for (int k = 0; k < j; ++k) d -= H[j][k] * H[j][k];
+            ok = ok && (d > 0.0);
+            const double l = sqrt(d);
+            H[j][j] = l;
+            for (int i = j + 1; i < 6; ++i) {
+                double v = H[i][j];
+                for (int k = 0; k < j; ++k) v -= H[i][k] * H[j][k];
+                H[i][j] = v / l;
+            }
+        }
+        for (int i = 0; i < 6; ++i) {
+            double v = tot[21 + i];
+            for (int k = 0; k < i; ++k) v -= H[i][k] * x[k];
+            x[i] = v / H[i][i];
+        }
+        for (int i = 5; i >= 0; --i) {
+            double v = x[i];
+            for (int k = i + 1; k < 6; ++k) v -= H[k][i] * x[k];
+            x[i] = v / H[i][i];
+        }
+        if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
+        for (int k = 0; k < 6; ++k) { xout[(size_t)rid * 6 + k] = x[k]; sq += x[k] * x[k]; }
+        const Se3 Tn = se3_mul(se3_exp(x), T);
+        se3_store(poses + 12 * (size_t)pose, Tn);
+        se3_store(sT, Tn);
+    }
+    __syncthreads();
+    double cost = tot[PS_NPOSE_ACC];                     // cost at the linearisation point (linesearch == 0)
+    if (linesearch) {                                    // cost after the full step
+        T = se3_load(sT);
+        double c = 0.0;
+        for (int i = start + t; i < end; i += PS_MO_THREADS) {
+            const LObs o = pobs[i];
+            const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
+            ReprojEval ev;
+            reproj_eval<false, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+            c += ev.cost;
+        }
+        c = wave_sum(c);
+        __syncthreads();
+        if (lane == 0) red[w][0] = c;
+        __syncthreads();
+        cost = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NWV; ++ww) cost += red[ww][0];
+    }
+    if (t == 0) {
+        partials[2 * rid] = cost;
+        partials[2 * rid + 1] = sq;
+        __threadfence();                                 // release this pose's results ...
+        s_last = atomicAdd(arrivals, 1) == nr - 1;
+        __threadfence();                                 // ... acquire everybody else's
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last workgroup: fixed-order totals, status, publication
+    double c = 0.0, q = 0.0;
+    for (int i = t; i < nr; i += PS_MO_THREADS) { c += partials[2 * i]; q += partials[2 * i + 1]; }
+    // (fixed order: thread-strided partial sums, then the deterministic block reduction)
+    __shared__ double lds2[32];
+    block_sum2(c, q, lds2);
+    if (t == 0) {
+        *arrivals = 0;
+        scalars[linesearch ? SC_COST : SC_LINCOST] = c;
+        scalars[SC_DXP2] = q; scalars[SC_DXL2] = 0.0;
+        scalars[SC_RR0] = 1.0; scalars[SC_RRFINAL] = 0.0;
+        status[ST_PCG_DONE] = 1; status[ST_PCG_ITERS] = 0;
+    }
+    __syncthreads();
+    __threadfence();
+    if (hst) {
+        if (t < ST_NWORDS) hst[t] = status[t];
+        else if (t < ST_NWORDS + SC_NWORDS) hsc[t - ST_NWORDS] = scalars[t - ST_NWORDS];
+        __syncthreads();
+        if (t == 0) {
+            __threadfence_system();
+            *reinterpret_cast<volatile long long*>(hseq) = seq;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // back-substitution, retraction, cost, small reductions.
 // `gate`: when non-null the kernel returns unless the CG has flagged convergence
 // (status[ST_PCG_DONE]); ps_gn_iteration enqueues this tail right behind the CG launches

@@ -158,3 +158,24 @@ def test_bad_input_is_reported_not_crashed():
         assert np.isfinite(out[0]) or True        # either a finite step (semi-definite CG) or a reported error
     except NativeError:
         pass
+
+def test_fused_motion_only_iteration_matches_the_general_path():
+    """Problems without variable landmarks or pose factors run each Gauss-Newton iteration as ONE launch
+    (k_motion_only_iteration: one workgroup per pose).  Same steps as the multi-kernel path, for both
+    cost conventions (line search on: cost after the step; off: cost at the linearisation point)."""
+    import numpy as np
+    from pyslam_amd import synthetic
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.stereo_ba(num_kf=7, num_lm=300, obs_per_lm=4, half_window=3, seed=11, const_point_fraction=1.0,
+                                loss=__import__('pyslam_amd.losses', fromlist=['HuberLoss']).HuberLoss(2.0))
+    assert lp.num_var_points == 0 and lp.num_reduced >= 5
+    for linesearch in (True, False):
+        a, b = DeviceProblem(lp), DeviceProblem(lp)
+        b.set_option('fused_motion_only', 0)
+        for _ in range(4):
+            ra = a.gn_iteration(0., 1e-13, 100, linesearch)
+            rb = b.gn_iteration(0., 1e-13, 100, linesearch)
+            assert abs(ra[0] - rb[0]) <= 1e-11 * abs(rb[0]) and abs(ra[1] - rb[1]) <= 1e-9 * max(rb[1], 1e-12)
+            assert ra[2] == 0
+        assert np.abs(a.get_params()[0] - b.get_params()[0]).max() < 1e-11
+        assert np.abs(a.get_dx()[0] - b.get_dx()[0]).max() < 1e-9
