@@ -132,6 +132,26 @@ def test_marquardt_damping_matches_oracle():
     assert np.linalg.norm(device_dx_posefirst(dev) - dx) <= 1e-9 * np.linalg.norm(dx)
 
 
+def test_marquardt_damping_on_the_small_problem_paths():
+    """lambda * diag(J^T J) through the direct (<= 90 unknowns) solve and through the one-launch
+    motion-only iteration: the step equals the oracle's damped normal-equation solve."""
+    lam = 0.21
+    # 11 reduced poses x 6 = 66 unknowns: direct Cholesky path (whole-iteration call)
+    lp, _ = synthetic.stereo_ba(12, 300, 5, 4, seed=9)
+    dev = device(lp)
+    dev.gn_iteration(lam, 1e-13, 500, True)
+    P, b, _ = orc.normal_equations(lp, points_first=False, lm_lambda=lam)
+    dx = np.linalg.solve(P.toarray(), b)
+    assert np.linalg.norm(device_dx_posefirst(dev) - dx) <= 1e-9 * np.linalg.norm(dx)
+    # motion-only (all landmarks constant): fused kernel
+    lp, _ = synthetic.stereo_ba(6, 200, 4, 3, seed=4, const_point_fraction=1.0)
+    dev = device(lp)
+    dev.gn_iteration(lam, 1e-13, 500, True)
+    P, b, _ = orc.normal_equations(lp, points_first=False, lm_lambda=lam)
+    dx = np.linalg.solve(P.toarray(), b)
+    assert np.linalg.norm(dev.get_dx()[0].ravel() - dx) <= 1e-10 * np.linalg.norm(dx)
+
+
 def test_medium_pose_graph_solve_matches_oracle_solve():
     """C2 shape at 1/5 scale: 2 000 SE(3) poses, 10 000 edges, Huber loss, prior on pose 0."""
     lp, _ = synthetic.pose_graph(num_poses=2000, num_loops=8001, dof=6, seed=2)
