@@ -124,6 +124,7 @@ struct ps_problem {
     bool status_clean = true;       // no failure flag can be pending in the device status words
     int direct_max = 90;            // reduced systems up to this many unknowns are solved directly (0: never)
     double *dA = nullptr, *dLi = nullptr, *dLiT = nullptr;
+    int big_chol = 1;               // nc > 90: multi-workgroup blocked factorisation (0: one workgroup out of L2)
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;
@@ -340,10 +341,10 @@ int build_coarse(ps_problem* h) {
     const int Gmax = 63;                           // nc = (G + 1) D <= 384; LDS-resident factorisation up to nc = 96
     // auto: on from 16 reduced poses, ~18 poses per hat interval, at most 12 intervals while the
     // coarse factorisation is LDS-resident; large systems (split mode, no dense border rows) take 24
-    // (dense BA-like rows) or 48 (long sparse pose-graph chains)
+    // (32, dense BA-like rows) or 48 (long sparse pose-graph chains)
     if (G < 0) {
         if (nr < 16) G = 0;                        // (systems up to 90 unknowns are solved directly anyway)
-        else if (nr > h->cg_split_min_rows) G = ((long)h->nnzb > 24L * nr) ? 24 : 48;  // measured: C4 (BA, 2 000 poses) / C2 (10 000-pose chain)
+        else if (nr > h->cg_split_min_rows) G = ((long)h->nnzb > 24L * nr) ? 32 : 48;  // measured: C4 (BA, 2 000 poses) / C2 (10 000-pose chain)
         else G = std::min(12, std::max(3, (nr + 9) / 18));
     }
     G = std::min(G, Gmax);
@@ -497,6 +498,24 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
                                            (int)chol_lds));
                 hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, st, ncb, h->Ac, h->Lci2[buf],
                                    h->LciT2[buf], stat, nullptr);
+            } else if (h->big_chol) {
+                // blocked factorisation over the whole chip (chol_scratch: working copy of A_c, then the tiles' inverses)
+                double* A = h->chol_scratch;
+                double* Tinv = A + (size_t)nc * nc;
+                HIP_OK(hipMemcpyAsync(A, h->Ac, (size_t)nc * nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+                const int nsteps = cdiv(nc, PS_BC_W);
+                for (int s2 = 0; s2 < nsteps; ++s2) {
+                    const int j0 = s2 * PS_BC_W, w = std::min(PS_BC_W, nc - j0), m = nc - j0 - w;
+                    hipLaunchKernelGGL(k_bchol_panel, dim3(1), dim3(1024), 0, st, nc, j0, A,
+                                       Tinv + (size_t)s2 * PS_BC_W * PS_BC_W, stat);
+                    if (m > 0) {
+                        const int nt = cdiv(m, 32);
+                        hipLaunchKernelGGL(k_bchol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, nc, j0, w, A);
+                    }
+                }
+                const size_t inv_lds = ((size_t)nc * PS_BC_W + PS_BC_W * PS_BC_W) * sizeof(double);
+                HIP_OK(hipFuncSetAttribute((const void*)k_btri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
+                hipLaunchKernelGGL(k_btri_inverse, dim3(nsteps), dim3(256), inv_lds, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
             } else {
                 hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, st, ncb, h->Ac, h->Lci2[buf],
                                    h->LciT2[buf], stat, h->chol_scratch);
@@ -1686,6 +1705,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_lds") h->cg_lds = value != 0.0;
+    else if (n == "big_chol") h->big_chol = value != 0.0;
     else if (n == "fused_motion_only") h->mo_fused = value != 0.0;
     else if (n == "direct_max_unknowns") { if (value < 0 || value > 90) return fail("direct_max_unknowns must be 0..90"); h->direct_max = (int)value; }
     else if (n == "coarse_basis") { h->coarse_basis = value != 0.0; h->lci_next = -1; }

@@ -1669,6 +1669,144 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
     }
 }
 
+// ---------------------------------------------------------------------------
+// Large coarse matrices (nc > 90: beyond one workgroup's LDS): blocked right-looking Cholesky over the
+// whole chip, PS_BC_W columns per step -- k_bchol_panel (one workgroup: diagonal tile factor + its
+// inverse + the panel below) and k_bchol_update (one workgroup per 32 x 32 tile of the trailing matrix)
+// -- then L^-1 by independent column blocks (k_btri_inverse, one workgroup each, its column block of X
+// in LDS).  ~2 ceil(nc / 24) + 1 launches, 0.2-0.4 ms at nc = 294 ... 384 instead of 2.4 ... 8 ms for the
+// single-workgroup factorisation out of L2.
+// ---------------------------------------------------------------------------
+#define PS_BC_W 24
+__global__ __launch_bounds__(1024) void k_bchol_panel(
+    int nc, int j0, double* __restrict__ A /* nc x nc row-major: lower triangle in, L out */,
+    double* __restrict__ Tinv /* PS_BC_W x PS_BC_W: inverse of this step's diagonal factor */,
+    int32_t* __restrict__ status)
+{
+    __shared__ double sD[PS_BC_W * PS_BC_W], sI[PS_BC_W * PS_BC_W];
+    const int t = threadIdx.x, w = min(PS_BC_W, nc - j0);
+    for (int k = t; k < PS_BC_W * PS_BC_W; k += 1024) {
+        const int r = k / PS_BC_W, c = k % PS_BC_W;
+        sD[k] = (r < w && c <= r) ? A[(size_t)(j0 + r) * nc + j0 + c] : 0.0;
+        sI[k] = 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < w; ++j) {                          // unblocked Cholesky of the w x w tile in LDS
+        if (t == 0) {
+            const double d = sD[j * PS_BC_W + j];
+            if (!(d > 0.0)) atomicAdd(&status[ST_DIAG_FAIL], 1);
+            sD[j * PS_BC_W + j] = sqrt(d);
+        }
+        __syncthreads();
+        const double inv = 1.0 / sD[j * PS_BC_W + j];
+        if (t > j && t < w) sD[t * PS_BC_W + j] *= inv;
+        __syncthreads();
+        for (int k = t; k < w * w; k += 1024) {
+            const int r = k / w, c = k % w;
+            if (c > j && r >= c) sD[r * PS_BC_W + c] -= sD[r * PS_BC_W + j] * sD[c * PS_BC_W + j];
+        }
+        __syncthreads();
+    }
+    if (t < w) {                                           // column t of the inverse by forward substitution
+        for (int r = t; r < w; ++r) {
+            double v = (r == t) ? 1.0 : 0.0;
+            for (int k = t; k < r; ++k) v -= sD[r * PS_BC_W + k] * sI[k * PS_BC_W + t];
+            sI[r * PS_BC_W + t] = v / sD[r * PS_BC_W + r];
+        }
+    }
+    __syncthreads();
+    for (int k = t; k < PS_BC_W * PS_BC_W; k += 1024) {
+        const int r = k / PS_BC_W, c = k % PS_BC_W;
+        Tinv[k] = sI[k];
+        if (r < w && c <= r) A[(size_t)(j0 + r) * nc + j0 + c] = sD[k];
+    }
+    // panel below the tile: L_IJ = A_IJ L_JJ^-T, all results in registers before anything is overwritten
+    const int rows = nc - j0 - w, total = rows * w;
+    double out[9];                                         // ceil(384 * 24 / 1024) = 9 (nc <= 384)
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        const int idx = t + n * 1024;
+        double v = 0.0;
+        if (idx < total) {
+            const int i = j0 + w + idx / w, c = idx % w;
+            for (int k = 0; k <= c; ++k) v += A[(size_t)i * nc + j0 + k] * sI[c * PS_BC_W + k];
+        }
+        out[n] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        const int idx = t + n * 1024;
+        if (idx < total) A[(size_t)(j0 + w + idx / w) * nc + j0 + idx % w] = out[n];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bchol_update(int nc, int j0, int w, double* __restrict__ A)
+{
+    // trailing update A[i][k] -= sum_c L[i][j0+c] L[k][j0+c] on the lower triangle, 32 x 32 tiles
+    __shared__ double sa[32][PS_BC_W + 1], sb[32][PS_BC_W + 1];
+    const int base = j0 + w, m = nc - base, nt = (m + 31) / 32;
+    // blockIdx.x enumerates tiles (ti, tk) with tk <= ti
+    int ti = 0, rem = blockIdx.x;
+    while (rem > ti) { rem -= ti + 1; ++ti; }
+    const int tk = rem;
+    if (ti >= nt) return;
+    const int t = threadIdx.x;
+    for (int k = t; k < 32 * w; k += 256) {
+        const int r = k / w, c = k % w;
+        const int i = base + ti * 32 + r, kk = base + tk * 32 + r;
+        sa[r][c] = i < nc ? A[(size_t)i * nc + j0 + c] : 0.0;
+        sb[r][c] = kk < nc ? A[(size_t)kk * nc + j0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int e = t; e < 32 * 32; e += 256) {
+        const int r = e / 32, c = e % 32;
+        const int i = base + ti * 32 + r, k = base + tk * 32 + c;
+        if (i >= nc || k > i) continue;
+        double v = 0.0;
+#pragma unroll 8
+        for (int q = 0; q < w; ++q) v += sa[r][q] * sb[c][q];
+        A[(size_t)i * nc + k] -= v;
+    }
+}
+
+// X = L^-1 (lower) and its transpose; one workgroup per block of PS_BC_W columns, which keeps its
+// column block of X in LDS (nc x 24 doubles <= 74 KB) and walks the row blocks below the diagonal
+__global__ __launch_bounds__(256) void k_btri_inverse(
+    int nc, const double* __restrict__ L, const double* __restrict__ Tinv_all /* one tile per column block */,
+    double* __restrict__ X, double* __restrict__ XT)
+{
+    extern __shared__ double sX[];                         // nc x PS_BC_W (rows j0 .. nc-1 used) + one tile of t
+    const int J = blockIdx.x, j0 = J * PS_BC_W, w = min(PS_BC_W, nc - j0), t = threadIdx.x;
+    double* sT = sX + (size_t)nc * PS_BC_W;
+    for (int i0 = j0; i0 < nc; i0 += PS_BC_W) {
+        const int wi = min(PS_BC_W, nc - i0);
+        // t = delta - L[I][j0..i0) X[j0..i0)][J]
+        for (int e = t; e < wi * w; e += 256) {
+            const int r = e / w, c = e % w, i = i0 + r;
+            double v = (i == j0 + c) ? 1.0 : 0.0;
+#pragma unroll 4
+            for (int k = j0; k < i0; ++k) v -= L[(size_t)i * nc + k] * sX[(size_t)k * PS_BC_W + c];
+            sT[r * PS_BC_W + c] = v;
+        }
+        __syncthreads();
+        const double* Ti = Tinv_all + (size_t)(i0 / PS_BC_W) * PS_BC_W * PS_BC_W;
+        for (int e = t; e < wi * w; e += 256) {
+            const int r = e / w, c = e % w;
+            double v = 0.0;
+            for (int k = 0; k <= r; ++k) v += Ti[r * PS_BC_W + k] * sT[k * PS_BC_W + c];
+            sX[(size_t)(i0 + r) * PS_BC_W + c] = v;
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < nc * w; e += 256) {
+        const int i = e / w, c = e % w, j = j0 + c;
+        const double v = (i >= j) ? sX[(size_t)i * PS_BC_W + c] : 0.0;
+        X[(size_t)i * nc + j] = v;
+        XT[(size_t)j * nc + i] = v;
+    }
+}
+
 struct CoarseRhsArgs {
     const int32_t *slo, *shi, *pnode;
     const double *pw0, *pw1, *LciT;
@@ -1726,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_coarse_border(
             const int r = t / nc, c = t % nc, q2 = c / D, cc = c % D;
             double v = 0.0;
 #pragma unroll 8
-            for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * Lci[(size_t)c * nc + k];
+            for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * rhs.LciT[(size_t)k * nc + c];   // = Lci[c][k], coalesced over c
             Saug[(size_t)(arow_ptr[nr + q] + nr + q2) * DD + r * D + cc] = v;
         }
         return;
@@ -1741,7 +1879,7 @@ __global__ __launch_bounds__(256) void k_coarse_border(
         const int r = t / nc, c = t % nc, q = c / D, cc = c % D;
         double v = 0.0;
 #pragma unroll 8
-        for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * Lci[(size_t)c * nc + k];
+        for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * rhs.LciT[(size_t)k * nc + c];   // = Lci[c][k], coalesced over c
         Saug[(size_t)(row_slot + q) * DD + r * D + cc] = v;                       // K   (row i, col nr+q)
         if (with_coarse_rows)
             Saug[(size_t)(arow_ptr[nr + q] + i) * DD + cc * D + r] = v;           // K^T (row nr+q, col i)
