@@ -191,8 +191,15 @@ int ps_get_landmark_factors(ps_problem* h, double* cinv /* (nv,6) */, double* c 
 int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /* (N,18) */,
                            double* jpoint /* (N,9) */);  /* IRLS-scaled, original obs order */
 
-/* Tuning knobs: "pcg_variant" (1 = fused single-launch-per-iteration CG on the block-Jacobi
-   scaled system [default], 0 = classic two-launch PCG), "pcg_chunk" (launches between polls). */
+/* Tuning knobs (defaults in brackets):
+     "pcg_variant"        [1] fused single-launch-per-iteration CG on the block-Jacobi scaled system; 0 = classic two-launch PCG
+     "coarse_groups"      [-1 auto] hat-function intervals of the two-level preconditioner, 0 = off
+     "coarse_basis"       [1] coarse unknowns are body-frame twists (P_iq = w L_i^T Ad(T_i)); 0 = hats in scaled coordinates
+     "coarse_lag"         [1] whole-iteration calls build the two-level system with the previous iteration's coarse factor
+     "direct_max_unknowns"[90] reduced systems up to this size are solved by a dense Cholesky instead of CG (0 = never)
+     "fused_motion_only"  [1] problems without variable landmarks / pose factors: one launch per iteration
+     "cg_lds", "big_chol", "cg_margin", "pcg_chunk", "cg_split_min_rows": implementation switches (see ps_core.hip)
+     "cg_ablate", "schur_ablate", "lm_ablate": timing experiments only (results are wrong under ablation) */
 int ps_set_option(ps_problem* h, const char* name, double value);
 
 /* hipEvent stage timers on the handle's stream (the reference has no tracing). */

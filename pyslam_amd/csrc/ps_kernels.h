@@ -1,15 +1,20 @@
 // ps_kernels.h -- device kernels of the Gauss-Newton / LM iteration (gfx950, fp64).
 //
 // Pipeline per iteration:
-//   k_landmark_pass   thread / landmark : H_ll, b_l -> chol -> c_l, Z_i = W_i C^-T
-//   k_pose_pass       WG / pose chunk   : J_p^T J_p - Z Z^T, -J_p^T r - Z c  (tree reduce)
-//   k_pose_finalize   WG / pose         : chunk partials -> diagonal S block, g
-//   k_schur_pairs     wave / S block    : S_ij -= sum Z_i Z_j^T over shared landmarks
-//   k_factor_pass     wave / pose edge  : pose-pose & prior blocks via LDS-staged 6x6 Jacobians
-//   k_factor_assemble thread / S entry  : gather edge blocks into S, g
-//   k_pcg_*           block-Jacobi PCG, 2 launches / iteration
-//   k_backsub         thread / landmark : dx_l = C^-T (c_l - sum Z_i^T dx_p)
-//   k_update_*        retraction, k_cost_* robust cost
+//   k_landmark_pass      16 lanes / landmark  : H_ll, b_l -> chol -> c_l, Z_i = W_i C^-T (LDS-transposed stores)
+//   k_pose_pass          WG / pose chunk      : J_p^T J_p - Z Z^T, -J_p^T r - Z c, Z recomputed in registers
+//   k_pose_finalize      WG / pose            : chunk partials -> diagonal S block, g
+//   k_schur_pairs        wave / (tile, block) : S_ij = -sum Z_i Z_j^T, rows straight into LDS (global_load_lds)
+//   k_schur_combine      wave / block         : tiled mode: partials summed in tile order
+//   k_factor_pass        wave / pose edge     : pose-pose & prior blocks via LDS-staged 6x6 Jacobians
+//   k_factor_assemble    thread / S entry     : gather edge blocks into S, g
+//   reduced solve        k_block_jacobi_factor, k_scale_blocks, k_coarse_* (two-level setup),
+//                        k_cg_fused_lds / k_cg_fused (one launch per CG iteration), k_coarse_recover;
+//                        <= 90 unknowns: k_bsr_to_dense + k_coarse_chol + k_direct_apply;
+//                        classic k_pcg_* (two launches per iteration) kept as an independent variant
+//   k_backsub            16 lanes / landmark  : dx_l = C^-T (c_l - sum Z_i^T dx_p) (+ fused update of points, poses)
+//   k_cost_*, k_reduce3  robust cost, final reductions, results published to pinned host memory
+//   k_motion_only_iteration  WG / pose        : problems without landmarks / factors: the whole iteration
 // Every reduction has a fixed order: results are bitwise reproducible run to run.
 #pragma once
 #include "ps_math.h"
