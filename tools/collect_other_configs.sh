@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run ON THE GPU BOX: the non-bench configurations of SURVEY 8d (C4, C2, C5 / small problems) and the RANSAC step.
+# Output: gpurun_out/<tag>/other_configs.txt  (copied to profiles/<round>_other_configs.txt)
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+{
+echo "# C4: 2 000 keyframes x 500 000 landmarks x 10 observations (tools/c4_probe.py)"
+python tools/c4_probe.py 2>&1 | grep -v amdgpu.ids
+echo
+echo "# C2: 10 000 SE(3) poses, 50 001 edges, Huber (tools/c2_probe.py)"
+python tools/c2_probe.py 2>&1 | grep -v amdgpu.ids
+echo
+echo "# small problems (tools/small_probe.py)"
+python tools/small_probe.py 2>&1 | grep -v amdgpu.ids
+echo
+echo "# frame-to-frame RANSAC (tools/ransac_bench.py)"
+python tools/ransac_bench.py 2>&1 | grep -v amdgpu.ids
+echo
+echo "# ps_problem_create stages (tools/create_time.py, PS_CREATE_TIMING=1)"
+PS_CREATE_TIMING=1 python tools/create_time.py 2>&1 | grep -v amdgpu.ids
+} > "$OUT/other_configs.txt"
+tail -5 "$OUT/other_configs.txt"
