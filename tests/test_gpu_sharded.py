@@ -43,3 +43,67 @@ def test_one_rank_sharded_iteration_equals_the_unsharded_one(dist1, native):
     assert abs(sh.eval_cost(True) - ref.eval_cost(True)) == 0.
     sh.close()
     ref.close()
+
+
+def _two_rank_worker(rank, world, port, out, native):
+    """One of two processes sharing cuda:0: the REAL device code on a landmark shard, the collectives over
+    gloo (RCCL refuses two ranks on one device; the arithmetic of the exchange is the same)."""
+    import torch
+    import torch.distributed as dist
+    from pyslam_amd.distributed import ShardedDeviceProblem, shard_landmarks
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=4000, obs_per_lm=6, half_window=8, seed=3)
+    sp = ShardedDeviceProblem(shard_landmarks(lp, rank, world), dist, native_rccl=False)
+    if native:
+        # drive the core's OWN collective path (ps_set_collective: ps_gn_iteration issues both all-reduces
+        # itself) with a stand-in for ncclAllReduce that sums over gloo -- same signature, in place
+        import ctypes as C
+        from pyslam_amd.distributed import _RawDeviceArray
+
+        def all_reduce(send, recv, count, dtype, op, comm, stream):
+            dist.all_reduce(torch.as_tensor(_RawDeviceArray(recv, count), device='cuda'))
+            return 0
+        cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)(all_reduce)
+        sp.dev.set_collective(C.cast(cb, C.c_void_p).value, 1)
+        sp.native = type('Standin', (), {'close': lambda self: None, 'keep': cb})()
+    trace = [sp.eval_cost(True)]
+    for _ in range(3):
+        trace.append(sp.gn_iteration(0., 1e-12, 1000, True))
+    poses, _ = sp.get_params()
+    if rank == 0:
+        out.put((trace, poses))
+    dist.barrier()
+    sp.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('native', [False, True])
+def test_two_ranks_on_one_gpu_reproduce_the_unsharded_iterations(native):
+    """world_size 2 with the real HIP core in both ranks (one GPU, gloo collectives): sharded linearisation,
+    all-reduce of [S | g | cost], replicated reduced solve, shard-local tail, all-reduce of the shard scalars."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from pyslam_amd.device import DeviceProblem
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, native)) for r in range(2)]
+    for p in procs:
+        p.start()
+    trace, poses = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=4000, obs_per_lm=6, half_window=8, seed=3)
+    ref = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
+    c0 = ref.eval_cost(True)
+    assert abs(trace[0] - c0) <= 1e-12 * c0
+    for k in range(3):
+        cost, nrm, its, rel = ref.gn_iteration(0., 1e-12, 1000, True)
+        assert abs(trace[k + 1][0] - cost) <= 1e-10 * cost + 1e-14           # the shard sums group differently
+        assert abs(trace[k + 1][1] - nrm) <= 1e-9 * nrm
+    assert np.abs(poses - ref.get_params()[0]).max() < 1e-9
+    ref.close()
