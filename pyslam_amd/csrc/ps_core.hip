@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -1106,26 +1108,57 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         lm_pairs_before[v + 1] = lm_pairs_before[v] + nvar * (nvar - 1) / 2;
     }
     const long total_pairs = lm_pairs_before[nv];
-    prs.reserve((size_t)total_pairs);
-    for (int v = 0; v < nv; ++v) {
-        const int tile = (ntiles > 1 && total_pairs > 0)
+    // one unit of work per tile: the tile's pairs in (block row, block column, landmark) order, written to its
+    // slice of prs; tiles are independent, so they are built by a few host threads
+    auto tile_of = [&](int v) {
+        return (ntiles > 1 && total_pairs > 0)
             ? (int)std::min<long>(ntiles - 1, (long)((double)ntiles * (double)lm_pairs_before[v] / (double)total_pairs)) : 0;
-        for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) {
-            const int ra = d->pose_rid[PS_POSE_OF(lobs[a])];
-            if (ra < 0) continue;
-            for (int b = a + 1; b < lm_ptr[v + 1]; ++b) {
-                const int rb = d->pose_rid[PS_POSE_OF(lobs[b])];
-                if (rb < 0) continue;
-                if (ra <= rb) prs.push_back({((uint64_t)ra << 32) | (uint32_t)rb, a, b, tile});
-                else prs.push_back({((uint64_t)rb << 32) | (uint32_t)ra, b, a, tile});
+    };
+    std::vector<int> tile_begin(ntiles + 1, nv);
+    {
+        int t_prev = -1;
+        for (int v = 0; v < nv; ++v) {
+            const int t = tile_of(v);
+            for (int q = t_prev + 1; q <= t; ++q) tile_begin[q] = v;
+            t_prev = std::max(t_prev, t);
+        }
+        tile_begin[ntiles] = nv;
+        for (int q = ntiles - 1; q >= 0; --q) tile_begin[q] = std::min(tile_begin[q], tile_begin[q + 1]);
+    }
+    prs.resize((size_t)total_pairs);
+    auto build_tile = [&](int tile) {
+        const int v0 = tile_begin[tile], v1 = tile_begin[tile + 1];
+        std::vector<PairRec> loc;
+        loc.reserve((size_t)(lm_pairs_before[v1] - lm_pairs_before[v0]));
+        for (int v = v0; v < v1; ++v)
+            for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) {
+                const int ra = d->pose_rid[PS_POSE_OF(lobs[a])];
+                if (ra < 0) continue;
+                for (int b = a + 1; b < lm_ptr[v + 1]; ++b) {
+                    const int rb = d->pose_rid[PS_POSE_OF(lobs[b])];
+                    if (rb < 0) continue;
+                    if (ra <= rb) loc.push_back({((uint64_t)ra << 32) | (uint32_t)rb, a, b, tile});
+                    else loc.push_back({((uint64_t)rb << 32) | (uint32_t)ra, b, a, tile});
+                }
             }
+        // (block row, block column): two stable counting passes, least significant first
+        counting_sort(loc, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)x.key; });
+        counting_sort(loc, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)(x.key >> 32); });
+        std::copy(loc.begin(), loc.end(), prs.begin() + lm_pairs_before[v0]);
+    };
+    {
+        const int nthreads = std::max(1, std::min({ntiles, 16, (int)std::thread::hardware_concurrency()}));
+        if (nthreads <= 1) {
+            for (int t = 0; t < ntiles; ++t) build_tile(t);
+        } else {
+            std::atomic<int> next{0};
+            std::vector<std::thread> pool;
+            for (int k = 0; k < nthreads; ++k)
+                pool.emplace_back([&] { for (int t = next++; t < ntiles; t = next++) build_tile(t); });
+            for (auto& th : pool) th.join();
         }
     }
     h->schur_tiles = ntiles;
-    // order by (tile, block row, block column): three stable counting passes, least significant first
-    counting_sort(prs, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)x.key; });
-    counting_sort(prs, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)(x.key >> 32); });
-    if (ntiles > 1) counting_sort(prs, (size_t)ntiles, [](const PairRec& x) { return x.tile; });
     h->npairs = (long)prs.size();
     if (prs.size() >= (1UL << 31)) return fail("too many Schur pairs for 32-bit indexing");
 
