@@ -68,6 +68,7 @@ struct ps_problem {
     PairItem* pair_xitems = nullptr;   // work items in per-XCD dispatch order
     // tiled Schur (Z larger than the L2s): per-task partial blocks + per-block task lists
     int schur_tiles = 1, ncomb = 0;
+    bool has_diag_tasks = false;    // some landmark is observed twice from one pose: a pair task writes a diagonal block
     double* Spart = nullptr;
     PairItem* comb_items = nullptr;     // slot, slotT, [start, end) into comb_tasks
     int32_t* comb_tasks = nullptr;
@@ -648,20 +649,25 @@ int linearize(ps_problem* h, double lambda) {
                            h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,
                            h->Cinv, h->cvec, h->status, h->lm_ablate);
     }
+    bool fin_in_combine = false;
     if (h->npitems > 0) {
         StageTimer t(h, PS_ST_POSE);
         hipLaunchKernelGGL(k_pose_pass, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
                            h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial);
-        hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
-                           h->ppartial, h->diag_slot, lambda, h->S, h->g);
+        // tiled Schur: the combine launch also finalizes the poses (unless a task writes a diagonal block)
+        fin_in_combine = h->Spart && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6;
+        if (!fin_in_combine)
+            hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
+                               h->ppartial, h->diag_slot, lambda, h->S, h->g);
     }
     if (h->npair_items > 0) {
         StageTimer t(h, PS_ST_SCHUR, 1);
         hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), 0, h->stream,
                            h->pair_per_xcd, h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, h->schur_ablate);
         if (h->Spart)
-            hipLaunchKernelGGL(k_schur_combine, dim3(cdiv(h->ncomb, 4)), dim3(256), 0, h->stream, h->ncomb,
-                               h->comb_items, h->comb_tasks, h->Spart, h->S);
+            hipLaunchKernelGGL(k_schur_combine, dim3(cdiv(h->ncomb, 4) + (fin_in_combine ? cdiv(h->nr, 4) : 0)), dim3(256), 0,
+                               h->stream, h->ncomb, h->comb_items, h->comb_tasks, h->Spart, h->S,
+                               fin_in_combine ? h->nr : 0, h->pitem_ptr, h->ppartial, h->diag_slot, lambda, h->g);
     }
     if (h->F > 0 && h->nr > 0) {
         StageTimer t(h, PS_ST_EDGES);
@@ -1225,6 +1231,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
             const int a = (int)(prs[k].key >> 32), b = (int)(uint32_t)prs[k].key;
             if (!pitm.empty()) pitm.back().end = (int32_t)k;
             pitm.push_back({slot_of(a, b), slot_of(b, a), (int32_t)k, 0});
+            if (a == b) h->has_diag_tasks = true;
             task_tile.push_back(prs[k].tile);
         }
     }

@@ -311,28 +311,35 @@ __global__ __launch_bounds__(256) void k_pose_pass(
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+// one wave (64 lanes, 33 active) per reduced pose: chunk partials -> diagonal S block, g
+PS_DEV void pose_finalize_wave(int rid, int lane, const int32_t* __restrict__ pitem_ptr,
+                               const double* __restrict__ partial, const int32_t* __restrict__ diag_slot,
+                               double lambda, double* __restrict__ S, double* __restrict__ g, double* v /* LDS, 33 */)
+{
+    if (lane < PS_NPOSE_ACC) {
+        double s = 0.0;
+        for (int it = pitem_ptr[rid]; it < pitem_ptr[rid + 1]; ++it) s += partial[(size_t)it * PS_NPOSE_ACC + lane];
+        v[lane] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        const int idx = a * 6 - (a * (a - 1)) / 2 + (b - a);   // upper-triangle packed index
+        double val = v[idx];
+        if (r == c) val += lambda * v[27 + r];
+        S[(size_t)diag_slot[rid] * 36 + lane] += val;
+    }
+    if (lane < 6) g[(size_t)rid * 6 + lane] += v[21 + lane];
+}
+
 __global__ __launch_bounds__(64) void k_pose_finalize(
     int nr, const int32_t* __restrict__ pitem_ptr, const double* __restrict__ partial,
     const int32_t* __restrict__ diag_slot, double lambda,
     double* __restrict__ S, double* __restrict__ g)
 {
     __shared__ double v[PS_NPOSE_ACC];
-    const int rid = blockIdx.x, t = threadIdx.x;
-    if (t < PS_NPOSE_ACC) {
-        double s = 0.0;
-        for (int it = pitem_ptr[rid]; it < pitem_ptr[rid + 1]; ++it) s += partial[(size_t)it * PS_NPOSE_ACC + t];
-        v[t] = s;
-    }
-    __syncthreads();
-    if (t < 36) {
-        const int r = t / 6, c = t % 6;
-        const int a = r < c ? r : c, b = r < c ? c : r;
-        const int idx = a * 6 - (a * (a - 1)) / 2 + (b - a);   // upper-triangle packed index
-        double val = v[idx];
-        if (r == c) val += lambda * v[27 + r];
-        S[(size_t)diag_slot[rid] * 36 + t] += val;
-    }
-    if (t < 6) g[(size_t)rid * 6 + t] += v[21 + t];
+    pose_finalize_wave(blockIdx.x, threadIdx.x, pitem_ptr, partial, diag_slot, lambda, S, g, v);
 }
 
 // ---------------------------------------------------------------------------
@@ -458,8 +465,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // to the mirrored block; one wave per block
 __global__ __launch_bounds__(256) void k_schur_combine(
     int nblocks, const PairItem* __restrict__ items, const int32_t* __restrict__ tasks,
-    const double* __restrict__ Spart, double* __restrict__ S)
+    const double* __restrict__ Spart, double* __restrict__ S,
+    // workgroups beyond the blocks finalize the pose pass (fin_nr > 0; never when a task writes a diagonal block):
+    // one launch less on the critical path
+    int fin_nr, const int32_t* __restrict__ pitem_ptr, const double* __restrict__ ppartial,
+    const int32_t* __restrict__ diag_slot, double lambda, double* __restrict__ g)
 {
+    __shared__ double fin_v[4][PS_NPOSE_ACC];
+    const int nbw = (nblocks + 3) / 4;
+    if ((int)blockIdx.x >= nbw) {
+        const int rid = (blockIdx.x - nbw) * 4 + (threadIdx.x >> 6);
+        if (rid < fin_nr)
+            pose_finalize_wave(rid, threadIdx.x & 63, pitem_ptr, ppartial, diag_slot, lambda, S, g, fin_v[threadIdx.x >> 6]);
+        return;
+    }
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= nblocks || lane >= 36) return;
     const PairItem it = items[b];
