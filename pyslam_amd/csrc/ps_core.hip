@@ -344,10 +344,10 @@ int build_coarse(ps_problem* h) {
     const int Gmax = 63;                           // nc = (G + 1) D <= 384; LDS-resident factorisation up to nc = 96
     // auto: on from 16 reduced poses, ~18 poses per hat interval, at most 12 intervals while the
     // coarse factorisation is LDS-resident; large systems (split mode, no dense border rows) take 24
-    // (32, dense BA-like rows) or 48 (long sparse pose-graph chains)
+    // 48
     if (G < 0) {
         if (nr < 16) G = 0;                        // (systems up to 90 unknowns are solved directly anyway)
-        else if (nr > h->cg_split_min_rows) G = ((long)h->nnzb > 24L * nr) ? 32 : 48;  // measured: C4 (BA, 2 000 poses) / C2 (10 000-pose chain)
+        else if (nr > h->cg_split_min_rows) G = 48;                                    // measured: C4 (BA, 2 000 poses) and C2 (10 000-pose chain)
         else G = std::min(12, std::max(3, (nr + 9) / 18));
     }
     G = std::min(G, Gmax);
@@ -526,15 +526,17 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             return 0;
         };
         const bool lag = allow_lag && h->coarse_lag && !h->cg_split && h->lci_next >= 0;
-        const int border_lds = (int)((size_t)D * nc * sizeof(double));
+        const int rpw = nc >= 192 ? 4 : 1;                 // fine block rows per border workgroup
+        const int border_lds = (int)((size_t)rpw * D * nc * sizeof(double));
+        HIP_OK(hipFuncSetAttribute((const void*)k_coarse_border<D>, hipFuncAttributeMaxDynamicSharedMemorySize, border_lds));
         if (lag) {
             const int use = h->lci_next;
             h->lci_cur = use;
             // borders K, K^T, the coarse-coarse rows and (last workgroup) the coarse right-hand side
             const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[use], h->tvec, h->cg_r[0], h->cg_w[0],
                                    h->cg_s[0], h->cg_p, h->cg_xh, 2, h->lag_status, h->status, h->bgv};
-            hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr + ncb + 1), dim3(256), border_lds, h->stream,
-                               nr, ncb, h->SZ, h->Lci2[use], h->arow_ptr, h->fine_nnz, h->Saug, 1, h->Ac, ra);
+            hipLaunchKernelGGL(k_coarse_border<D>, dim3(cdiv(nr, rpw) + ncb + 1), dim3(256), border_lds, h->stream,
+                               nr, ncb, h->SZ, h->Lci2[use], h->arow_ptr, h->fine_nnz, h->Saug, 1, h->Ac, ra, rpw);
             HIP_OK(hipEventRecord(h->ev_ac, h->stream));           // A_c complete, buffer use^1 no longer read
             HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
             if (launch_chol(h->side, use ^ 1, h->lag_status)) return -1;
@@ -545,9 +547,9 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             if (launch_chol(h->stream, buf, h->status)) return -1;
             const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[buf], h->tvec, h->cg_r[0], h->cg_w[0],
                                    h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, nullptr, h->status, h->bgv};
-            hipLaunchKernelGGL(k_coarse_border<D>, dim3(nr + 1), dim3(256), border_lds, h->stream,
+            hipLaunchKernelGGL(k_coarse_border<D>, dim3(cdiv(nr, rpw) + 1), dim3(256), border_lds, h->stream,
                                nr, ncb, h->SZ, h->Lci2[buf], h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1,
-                               (const double*)nullptr, ra);
+                               (const double*)nullptr, ra, rpw);
             h->lci_next = buf;
         }
     }

@@ -1863,19 +1863,19 @@ __global__ __launch_bounds__(256) void k_coarse_border(
     const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ fine_nnz, double* __restrict__ Saug,
     int with_coarse_rows, const double* __restrict__ Ac,
     // the LAST workgroup (rhs.r != NULL) runs the coarse right-hand side instead (independent work, one launch less)
-    CoarseRhsArgs rhs)
+    CoarseRhsArgs rhs, int rpw /* fine block rows per workgroup: 1 or 4 */)
 {
-    constexpr int DD = D * D;
-    extern __shared__ __attribute__((aligned(16))) double sT[];     // D x nc
+    constexpr int DD = D * D, RPW = 4, RW = RPW * D;                // fine block rows per workgroup
+    extern __shared__ __attribute__((aligned(16))) double sT[];     // RW x nc
     const int nc = ncb * D;
-    const int i = blockIdx.x;
-    if (rhs.r && i == (int)gridDim.x - 1) {
+    const int nfw = rpw == 1 ? nr : (nr + RPW - 1) / RPW;           // workgroups of the fine rows
+    if (rhs.r && (int)blockIdx.x == (int)gridDim.x - 1) {
         coarse_rhs_body<D>(nr, ncb, rhs.slo, rhs.shi, rhs.pnode, rhs.pw0, rhs.pw1, rhs.LciT, arow_ptr, Saug, rhs.tvec,
                            rhs.r, rhs.w, rhs.s, rhs.p, rhs.x, rhs.with_coarse_rows, rhs.lag_status, rhs.status, sT, rhs.bg);
         return;
     }
-    if (i >= nr) {                                                  // lagged mode: row q of M
-        const int q = i - nr;
+    if ((int)blockIdx.x >= nfw) {                                   // lagged mode: row q of M
+        const int q = blockIdx.x - nfw;
         for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
             const int r = t / nc, c = t % nc, rr = q * D + r;
             double v = 0.0;
@@ -1893,20 +1893,52 @@ __global__ __launch_bounds__(256) void k_coarse_border(
         }
         return;
     }
-    for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
-        const int r = t / nc, c = t % nc, q = c / D, cc = c % D;
-        sT[t] = SZ[((size_t)i * ncb + q) * DD + r * D + cc];
+    if (rpw == 1) {                                                 // small coarse levels: one block row per workgroup,
+        const int i = blockIdx.x;                                   // one thread per strip entry (r, c)
+        for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
+            const int r = t / nc, c = t % nc, q = c / D, cc = c % D;
+            sT[t] = SZ[((size_t)i * ncb + q) * DD + r * D + cc];
+        }
+        __syncthreads();
+        const int row_slot = arow_ptr[i] + fine_nnz[i];             // first coarse column block of row i
+        for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
+            const int r = t / nc, c = t % nc, q = c / D, cc = c % D;
+            double v = 0.0;
+#pragma unroll 8
+            for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * rhs.LciT[(size_t)k * nc + c];   // = Lci[c][k], coalesced over c
+            Saug[(size_t)(row_slot + q) * DD + r * D + cc] = v;                       // K   (row i, col nr+q)
+            if (with_coarse_rows)
+                Saug[(size_t)(arow_ptr[nr + q] + i) * DD + cc * D + r] = v;           // K^T (row nr+q, col i)
+        }
+        return;
+    }
+    // large coarse levels (nc >= 192): RPW block rows per workgroup share every element of the inverse factor
+    // they load -- one thread per coarse column c, RW accumulators, the strip values broadcast from LDS
+    const int i0 = blockIdx.x * RPW;
+    for (int t = threadIdx.x; t < RW * nc; t += blockDim.x) {
+        const int rr = t / nc, c = t % nc, q = c / D, cc = c % D, i = i0 + rr / D;
+        sT[t] = i < nr ? SZ[((size_t)i * ncb + q) * DD + (rr % D) * D + cc] : 0.0;
     }
     __syncthreads();
-    const int row_slot = arow_ptr[i] + fine_nnz[i];                 // first coarse column block of row i
-    for (int t = threadIdx.x; t < D * nc; t += blockDim.x) {
-        const int r = t / nc, c = t % nc, q = c / D, cc = c % D;
-        double v = 0.0;
-#pragma unroll 8
-        for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * rhs.LciT[(size_t)k * nc + c];   // = Lci[c][k], coalesced over c
-        Saug[(size_t)(row_slot + q) * DD + r * D + cc] = v;                       // K   (row i, col nr+q)
-        if (with_coarse_rows)
-            Saug[(size_t)(arow_ptr[nr + q] + i) * DD + cc * D + r] = v;           // K^T (row nr+q, col i)
+    for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+        double acc[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) acc[rr] = 0.0;
+        for (int k = 0; k <= c; ++k) {
+            const double l = rhs.LciT[(size_t)k * nc + c];          // = Lci[c][k], coalesced over c
+#pragma unroll
+            for (int rr = 0; rr < RW; ++rr) acc[rr] += sT[rr * nc + k] * l;
+        }
+        const int q = c / D, cc = c % D;
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int i = i0 + rr / D, r = rr % D;
+            if (i >= nr) continue;
+            const int row_slot = arow_ptr[i] + fine_nnz[i];         // first coarse column block of row i
+            Saug[(size_t)(row_slot + q) * DD + r * D + cc] = acc[rr];                   // K   (row i, col nr+q)
+            if (with_coarse_rows)
+                Saug[(size_t)(arow_ptr[nr + q] + i) * DD + cc * D + r] = acc[rr];       // K^T (row nr+q, col i)
+        }
     }
 }
 
