@@ -119,6 +119,8 @@ struct ps_problem {
     hipStream_t side = nullptr;
     hipEvent_t ev_ac = nullptr, ev_chol = nullptr;
     int32_t* lag_status = nullptr;  // ST_DIAG_FAIL of the side-stream factorisation
+    double* Mc = nullptr;           // split mode: dense coarse-coarse block M of the lagged system
+    bool mc_active = false;         // the current system was built with a lagged factor in split mode
     bool coarse_built = false;
     int cg_ablate = 0, schur_ablate = 0, lm_ablate = 0;
     int max_pose_obs = 0;           // most observations on one variable pose
@@ -525,7 +527,9 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             }
             return 0;
         };
-        const bool lag = allow_lag && h->coarse_lag && !h->cg_split && h->lci_next >= 0;
+        const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0;
+        if (lag && h->cg_split && !h->Mc && h->alloc(&h->Mc, (size_t)nc * nc)) return -1;
+        h->mc_active = lag && h->cg_split;
         const int rpw = nc >= 192 ? 4 : 1;                 // fine block rows per border workgroup
         const int border_lds = (int)((size_t)rpw * D * nc * sizeof(double));
         HIP_OK(hipFuncSetAttribute((const void*)k_coarse_border<D>, hipFuncAttributeMaxDynamicSharedMemorySize, border_lds));
@@ -534,9 +538,9 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             h->lci_cur = use;
             // borders K, K^T, the coarse-coarse rows and (last workgroup) the coarse right-hand side
             const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[use], h->tvec, h->cg_r[0], h->cg_w[0],
-                                   h->cg_s[0], h->cg_p, h->cg_xh, 2, h->lag_status, h->status, h->bgv};
+                                   h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 2, h->lag_status, h->status, h->bgv, h->cg_split ? h->Mc : nullptr};
             hipLaunchKernelGGL(k_coarse_border<D>, dim3(cdiv(nr, rpw) + ncb + 1), dim3(256), border_lds, h->stream,
-                               nr, ncb, h->SZ, h->Lci2[use], h->arow_ptr, h->fine_nnz, h->Saug, 1, h->Ac, ra, rpw);
+                               nr, ncb, h->SZ, h->Lci2[use], h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1, h->Ac, ra, rpw);
             HIP_OK(hipEventRecord(h->ev_ac, h->stream));           // A_c complete, buffer use^1 no longer read
             HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
             if (launch_chol(h->side, use ^ 1, h->lag_status)) return -1;
@@ -546,7 +550,7 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             const int buf = h->lci_cur;
             if (launch_chol(h->stream, buf, h->status)) return -1;
             const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[buf], h->tvec, h->cg_r[0], h->cg_w[0],
-                                   h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, nullptr, h->status, h->bgv};
+                                   h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, nullptr, h->status, h->bgv, nullptr};
             hipLaunchKernelGGL(k_coarse_border<D>, dim3(cdiv(nr, rpw) + 1), dim3(256), border_lds, h->stream,
                                nr, ncb, h->SZ, h->Lci2[buf], h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1,
                                (const double*)nullptr, ra, rpw);
@@ -591,7 +595,8 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
         if (h->cg_split)      // fine totals + the coarse rows of this iteration
             hipLaunchKernelGGL(k_cg_reduce_split<D>, dim3(1 + h->ncb), dim3(1024), 0, h->stream, rows, h->ncb,
                                h->cg_gd[nw], h->cg_tot, h->cg_U, h->cg_ab, h->cg_r[o], h->cg_w[o], h->cg_s[o],
-                               h->cg_r[nw], h->cg_w[nw], h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_cgd[nw], h->status);
+                               h->cg_r[nw], h->cg_w[nw], h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_cgd[nw], h->status,
+                               h->mc_active ? h->Mc : (const double*)nullptr);
     }
 }
 

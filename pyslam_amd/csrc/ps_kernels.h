@@ -1052,10 +1052,12 @@ __global__ __launch_bounds__(1024) void k_cg_reduce_split(
     const double* __restrict__ r_old, const double* __restrict__ w_old, const double* __restrict__ s_old,
     double* __restrict__ r_new, double* __restrict__ w_new, double* __restrict__ s_new,
     double* __restrict__ p, double* __restrict__ x, double* __restrict__ cgd_out /* [2 ncb] */,
-    const int32_t* __restrict__ status)
+    const int32_t* __restrict__ status,
+    const double* __restrict__ Mc /* lagged coarse factor: the coarse-coarse block M (nc x nc), NULL = identity */)
 {
     __shared__ double lds[32];
     __shared__ double wpart[16][8];
+    __shared__ double srn[400], mrow[8];
     const int t = threadIdx.x;
     // independent loads first (this kernel is latency-bound: ~26-64 workgroups on 256 CUs)
     const int done = status[ST_PCG_DONE];
@@ -1085,6 +1087,12 @@ __global__ __launch_bounds__(1024) void k_cg_reduce_split(
         const size_t i = (size_t)(nr + q) * D + t;
         ri = r_old[i]; wi = w_old[i]; si = s_old[i]; pi = p[i]; xi_ = x[i];
     }
+    const int nc = ncb * D;
+    double rn_k = 0.0;                                     // r_new of coarse entry t (for the M row products)
+    if (Mc && t < nc) {
+        const size_t i = (size_t)nr * D + t;
+        rn_k = cg_rnew(r_old[i], w_old[i], s_old[i], alpha, beta);
+    }
     if (done) return;
     const int wv = t >> 6, lane = t & 63;
 #pragma unroll
@@ -1092,7 +1100,16 @@ __global__ __launch_bounds__(1024) void k_cg_reduce_split(
         const double v = wave_sum(acc[c]);
         if (lane == 0) wpart[wv][c] = v;
     }
+    if (Mc && t < nc) srn[t] = rn_k;
     __syncthreads();
+    if (Mc && wv < D) {                                    // wave c: row q*D + c of M times r_new (coarse part)
+        const double* mr = Mc + (size_t)(q * D + wv) * nc;
+        double v = 0.0;
+        for (int k = lane; k < nc; k += 64) v += mr[k] * srn[k];
+        v = wave_sum(v);
+        if (lane == 0) mrow[wv] = v;
+    }
+    if (Mc) __syncthreads();
     double gp = 0.0, dp = 0.0;
     if (t < D) {
         double ws = 0.0;
@@ -1100,7 +1117,7 @@ __global__ __launch_bounds__(1024) void k_cg_reduce_split(
         for (int k = 0; k < 16; ++k) ws += wpart[k][t];
         const size_t i = (size_t)(nr + q) * D + t;
         const double rn = cg_rnew(ri, wi, si, alpha, beta);
-        const double wn = ws + rn;                         // identity diagonal block
+        const double wn = ws + (Mc ? mrow[t] : rn);        // coarse-coarse block: M (lagged factor) or the identity
         const double sn = wi + beta * si;
         const double pn = ri + beta * pi;
         s_new[i] = sn; p[i] = pn; x[i] = xi_ + alpha * pn; r_new[i] = rn; w_new[i] = wn;
@@ -1839,6 +1856,7 @@ struct CoarseRhsArgs {
     const int32_t* lag_status;
     int32_t* status;
     const double* bg;
+    double* Mc;                        // split mode + lagged factor: where the rows of M go (else NULL)
 };
 
 template <int D>
@@ -1889,7 +1907,8 @@ __global__ __launch_bounds__(256) void k_coarse_border(
             double v = 0.0;
 #pragma unroll 8
             for (int k = 0; k <= c; ++k) v += sT[r * nc + k] * rhs.LciT[(size_t)k * nc + c];   // = Lci[c][k], coalesced over c
-            Saug[(size_t)(arow_ptr[nr + q] + nr + q2) * DD + r * D + cc] = v;
+            if (rhs.Mc) rhs.Mc[(size_t)(q * D + r) * nc + c] = v;        // split mode: dense M beside the matrix
+            else Saug[(size_t)(arow_ptr[nr + q] + nr + q2) * DD + r * D + cc] = v;
         }
         return;
     }

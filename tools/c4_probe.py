@@ -9,6 +9,7 @@ t = time.time(); lp, _ = synthetic.stereo_ba(kf, lm, 10, 20, seed=1); print('gen
 t = time.time(); dev = DeviceProblem(lp); print('create %.1fs' % (time.time() - t), dev.info)
 for G in ([int(a) for a in sys.argv[3:]] or [-1]):
     dev.set_option('coarse_groups', G)
+    dev.set_option('coarse_lag', float(os.environ.get('C4_LAG', '1')))
     dev.set_params(lp.poses, lp.points)
     dev.snapshot()
     c0 = dev.eval_cost(True)
