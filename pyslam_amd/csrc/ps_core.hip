@@ -527,7 +527,9 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             }
             return 0;
         };
-        const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0;
+        // (long sparse chains in split mode: hundreds of CG iterations dwarf the factorisation, and a stale factor
+        // costs iterations while the trajectory still moves -- C2: 1 320 -> 1 800 in the second GN step -- so no lag there)
+        const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && (!h->cg_split || (long)h->nnzb > 24L * nr);
         if (lag && h->cg_split && !h->Mc && h->alloc(&h->Mc, (size_t)nc * nc)) return -1;
         h->mc_active = lag && h->cg_split;
         const int rpw = nc >= 192 ? 4 : 1;                 // fine block rows per border workgroup
