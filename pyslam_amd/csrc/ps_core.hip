@@ -130,6 +130,10 @@ struct ps_problem {
     int direct_max = 90;            // reduced systems up to this many unknowns are solved directly (0: never)
     double *dA = nullptr, *dLi = nullptr, *dLiT = nullptr;
     int big_chol = 1;               // nc > 90: multi-workgroup blocked factorisation (0: one workgroup out of L2)
+    // explicit two-level PCG (long sparse chains)
+    int explicit_ok = 1;
+    bool cg_explicit = false;
+    double *xstate = nullptr, *xy = nullptr, *xp2 = nullptr;
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;
@@ -360,7 +364,11 @@ int build_coarse(ps_problem* h) {
     const std::vector<int32_t>& ci = h->h_col_idx;
     int maxlen = 0;
     for (int i = 0; i < nr; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
-    const int ncb_pre = G ? G + 1 : 0;
+    // long sparse chains (pose graphs with thousands of poses): the two-level preconditioner is APPLIED
+    // explicitly (restrict, dense coarse solve, prolong: cg_explicit) instead of folded into the matrix --
+    // the folded form drags a dense border of ncb blocks through every row (C2: 49 of 60 blocks per row)
+    h->cg_explicit = h->explicit_ok && G > 0 && nr > h->cg_split_min_rows && (long)h->nnzb <= 24L * nr;
+    const int ncb_pre = (G && !h->cg_explicit) ? G + 1 : 0;
     // pad rows to a common width unless that wastes more than 50 % (hub-like graphs): then CSR
     const bool ell = nr > 0 && (long)(maxlen + ncb_pre) * nr <= (long)(1.5 * (h->nnzb + (long)ncb_pre * nr)) + 64;
     const int wf = ell ? maxlen + ncb_pre : 0;
@@ -391,7 +399,10 @@ int build_coarse(ps_problem* h) {
         const double th = u - k;
         pnode[i] = k; pw0[i] = 1.0 - th; pw1[i] = th;
         for (int q = k; q <= k + 1; ++q) {
-            if ((q == k ? pw0[i] : pw1[i]) == 0.0) continue;
+            // a zero weight at q == k + 1 (row exactly on node k) is skipped; at q == k (the very last row) it is
+            // kept: every row must lie in the support of its own left node, which owns its vector updates in
+            // the explicit PCG (k_xcg_restrict)
+            if (q == k + 1 && pw1[i] == 0.0) continue;
             slo[q] = std::min(slo[q], i); shi[q] = std::max(shi[q], i + 1);
         }
     }
@@ -400,19 +411,19 @@ int build_coarse(ps_problem* h) {
     for (int i = 0; i < nr; ++i) {
         fnz[i] = rp[i + 1] - rp[i];
         for (int b = rp[i]; b < rp[i + 1]; ++b) { slot[b] = (int32_t)aci.size(); aci.push_back(ci[b]); }
-        for (int q = 0; q < ncb; ++q) aci.push_back(nr + q);
+        if (!h->cg_explicit) for (int q = 0; q < ncb; ++q) aci.push_back(nr + q);
         if (ell) while ((int)aci.size() < (i + 1) * wf) aci.push_back(0);     // zero-valued padding blocks
         arp[i + 1] = (int32_t)aci.size();
     }
     const bool split = nr > h->cg_split_min_rows;      // big systems: no dense K^T rows in the matrix
-    h->cg_split = split;
-    for (int q = 0; q < ncb && !split; ++q) {
+    h->cg_split = split && !h->cg_explicit;
+    for (int q = 0; q < ncb && !split; ++q) {       // (explicit mode implies split-sized systems: no coarse rows either)
         for (int i = 0; i < nr; ++i) aci.push_back(i);
         for (int q2 = 0; q2 < ncb; ++q2) aci.push_back(nr + q2);
         arp[nr + q + 1] = (int32_t)aci.size();
     }
-    if (split) {
-        arp.resize(nr + 1);
+    if (split) arp.resize(nr + 1);
+    if (split && !h->cg_explicit) {
         if (h->alloc(&h->cg_U, (size_t)ncb * nr * D) || h->alloc(&h->cg_cgd[0], 2 * (size_t)ncb) ||
             h->alloc(&h->cg_cgd[1], 2 * (size_t)ncb) || h->alloc(&h->cg_ab, 2)) return -1;
     }
@@ -436,6 +447,7 @@ int build_coarse(ps_problem* h) {
         h->alloc(&h->Lci2[0], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[0], (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci2[1], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[1], (size_t)h->nc * h->nc) ||
         h->alloc(&h->tvec, (size_t)h->nc) || h->alloc(&h->chol_scratch, 2 * (size_t)h->nc * h->nc)) return -1;
+    if (h->cg_explicit && (h->alloc(&h->xstate, 8) || h->alloc(&h->xy, (size_t)h->nc) || h->alloc(&h->xp2, (size_t)nr * D))) return -1;
     if (!h->lag_status) {
         if (h->alloc(&h->lag_status, ST_NWORDS)) return -1;
         HIP_OK(hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
@@ -449,6 +461,42 @@ int build_coarse(ps_problem* h) {
     h->lci_next = -1; h->lci_cur = 0;
     if (ensure_cg_buffers(h, h->nr_aug, h->nnzb_aug)) return -1;
     HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)h->nnzb_aug * D * D * sizeof(double), h->stream));
+    return 0;
+}
+
+// factor A_c = L_c L_c^T and form L_c^-1 (+ transpose) into buffer `buf`: LDS-resident single workgroup up to 90
+// unknowns, blocked over the whole chip beyond
+template <int D>
+int coarse_factor(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
+    const int nc = h->nc, ncb = h->ncb;
+    if (nc <= 90) {                                        // 2 nc^2 doubles of dynamic LDS (<= 130 KB)
+        const size_t chol_lds = 2 * (size_t)nc * nc * sizeof(double);
+        HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)chol_lds));
+        hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, st, ncb, h->Ac, h->Lci2[buf],
+                           h->LciT2[buf], stat, nullptr);
+    } else if (h->big_chol) {
+        // blocked factorisation over the whole chip (chol_scratch: working copy of A_c, then the tiles' inverses)
+        double* A = h->chol_scratch;
+        double* Tinv = A + (size_t)nc * nc;
+        HIP_OK(hipMemcpyAsync(A, h->Ac, (size_t)nc * nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+        const int nsteps = cdiv(nc, PS_BC_W);
+        for (int s2 = 0; s2 < nsteps; ++s2) {
+            const int j0 = s2 * PS_BC_W, w = std::min(PS_BC_W, nc - j0), m = nc - j0 - w;
+            hipLaunchKernelGGL(k_bchol_panel, dim3(1), dim3(1024), 0, st, nc, j0, A,
+                               Tinv + (size_t)s2 * PS_BC_W * PS_BC_W, stat);
+            if (m > 0) {
+                const int nt = cdiv(m, 32);
+                hipLaunchKernelGGL(k_bchol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, nc, j0, w, A);
+            }
+        }
+        const size_t inv_lds = ((size_t)nc * PS_BC_W + PS_BC_W * PS_BC_W) * sizeof(double);
+        HIP_OK(hipFuncSetAttribute((const void*)k_btri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
+        hipLaunchKernelGGL(k_btri_inverse, dim3(nsteps), dim3(256), inv_lds, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
+    } else {
+        hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, st, ncb, h->Ac, h->Lci2[buf],
+                           h->LciT2[buf], stat, h->chol_scratch);
+    }
     return 0;
 }
 
@@ -496,37 +544,7 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
         // PREVIOUS iteration's A_c -- any nonsingular L~ gives a consistent system V^T S^ V with
         // V = [I, P L~^-T]; only the coarse-coarse block changes from I to L~^-1 A_c L~^-T -- and factor
         // the current A_c on a side stream while the CG iterates.
-        auto launch_chol = [&](hipStream_t st, int buf, int32_t* stat) -> int {
-            if (nc <= 90) {                                        // 2 nc^2 doubles of dynamic LDS (<= 130 KB)
-                const size_t chol_lds = 2 * (size_t)nc * nc * sizeof(double);
-                HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)chol_lds));
-                hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, st, ncb, h->Ac, h->Lci2[buf],
-                                   h->LciT2[buf], stat, nullptr);
-            } else if (h->big_chol) {
-                // blocked factorisation over the whole chip (chol_scratch: working copy of A_c, then the tiles' inverses)
-                double* A = h->chol_scratch;
-                double* Tinv = A + (size_t)nc * nc;
-                HIP_OK(hipMemcpyAsync(A, h->Ac, (size_t)nc * nc * sizeof(double), hipMemcpyDeviceToDevice, st));
-                const int nsteps = cdiv(nc, PS_BC_W);
-                for (int s2 = 0; s2 < nsteps; ++s2) {
-                    const int j0 = s2 * PS_BC_W, w = std::min(PS_BC_W, nc - j0), m = nc - j0 - w;
-                    hipLaunchKernelGGL(k_bchol_panel, dim3(1), dim3(1024), 0, st, nc, j0, A,
-                                       Tinv + (size_t)s2 * PS_BC_W * PS_BC_W, stat);
-                    if (m > 0) {
-                        const int nt = cdiv(m, 32);
-                        hipLaunchKernelGGL(k_bchol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, nc, j0, w, A);
-                    }
-                }
-                const size_t inv_lds = ((size_t)nc * PS_BC_W + PS_BC_W * PS_BC_W) * sizeof(double);
-                HIP_OK(hipFuncSetAttribute((const void*)k_btri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
-                hipLaunchKernelGGL(k_btri_inverse, dim3(nsteps), dim3(256), inv_lds, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
-            } else {
-                hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, st, ncb, h->Ac, h->Lci2[buf],
-                                   h->LciT2[buf], stat, h->chol_scratch);
-            }
-            return 0;
-        };
+        auto launch_chol = [&](hipStream_t st, int buf, int32_t* stat) -> int { return coarse_factor<D>(h, st, buf, stat); };
         // (long sparse chains in split mode: hundreds of CG iterations dwarf the factorisation, and a stale factor
         // costs iterations while the trajectory still moves -- C2: 1 320 -> 1 800 in the second GN step -- so no lag there)
         const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && (!h->cg_split || (long)h->nnzb > 24L * nr);
@@ -784,6 +802,74 @@ int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = f
     return 0;
 }
 
+// ---- explicit two-level PCG (long sparse chains; kernels k_xcg_*) ---------------------------------
+template <int D>
+int xcg_setup(ps_problem* h, int max_iters) {
+    const int nr = h->nr, ncb = h->ncb, nc = h->nc;
+    if (max_iters + 2 > h->hist_cap) return fail("pcg max_iters exceeds the history buffer (4096)");
+    hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
+                       h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
+                       h->poses, h->pose_of_rid, h->coarse_basis, h->Bmat, h->bgv);
+    hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
+                       h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
+    if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
+    hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(ncb + 1) * D * D * sizeof(double), h->stream,
+                       nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat, h->BSZ);
+    hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
+                       nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
+    if (coarse_factor<D>(h, h->stream, h->lci_cur, h->status)) return -1;
+    h->lci_next = -1;                                  // (no lagging here: the factorisation is noise next to the CG)
+    hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv((long)nc * nc, 256)), dim3(256), 0, h->stream, nc, h->Lci2[h->lci_cur], h->chol_scratch);
+    HIP_OK(hipMemsetAsync(h->xstate, 0, 8 * sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->xp2, 0, (size_t)nr * D * sizeof(double), h->stream));
+    // z_0 = M^-1 r_0 and r_0 . z_0
+    hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode, h->pw0,
+                       h->pw1, h->Bmat, h->cg_r[0], h->cg_r[0], h->cg_w[0], h->cg_p, h->cg_xh, h->cg_gd[1], 0, h->xstate, 1,
+                       h->tvec, h->status);
+    hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, h->chol_scratch, h->tvec, h->xy, h->status);
+    hipLaunchKernelGGL(k_xcg_prolong<D>, dim3(cdiv(nr, PS_XCG_DROWS)), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb, h->pnode,
+                       h->pw0, h->pw1, h->Bmat, h->cg_r[0], h->xy, h->cg_s[0], h->cg_gd[0], h->status);
+    h->cg_launched = 0;
+    return 0;
+}
+
+template <int D>
+void xcg_launch(ps_problem* h, double tol, int count) {
+    const int nr = h->nr, ncb = h->ncb, nc = h->nc;
+    const int n_pq = cdiv(nr, PS_XCG_ROWS), n_rz = cdiv(nr, PS_XCG_DROWS);
+    double* pbuf[2] = {h->cg_p, h->xp2};
+    for (int i = 0; i < count; ++i, ++h->cg_launched) {
+        const int k = h->cg_launched, b = k & 1;
+        hipLaunchKernelGGL(k_xcg_spmv<D>, dim3(n_pq), dim3(64 * PS_XCG_ROWS), 0, h->stream, nr, h->arow_ptr, h->acol_idx,
+                           h->ell_wf, h->Saug, h->cg_s[0], pbuf[b ^ 1], pbuf[b], h->cg_w[0], h->cg_gd[0], n_rz, h->cg_gd[1],
+                           h->xstate, k, tol * tol, h->hist, h->status, h->scalars);
+        hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
+                           h->pw0, h->pw1, h->Bmat, h->cg_r[b], h->cg_r[b ^ 1], h->cg_w[0], pbuf[b], h->cg_xh, h->cg_gd[1],
+                           n_pq, h->xstate, 0, h->tvec, h->status);
+        hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, h->chol_scratch, h->tvec, h->xy, h->status);
+        hipLaunchKernelGGL(k_xcg_prolong<D>, dim3(cdiv(nr, PS_XCG_DROWS)), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb,
+                           h->pnode, h->pw0, h->pw1, h->Bmat, h->cg_r[b ^ 1], h->xy, h->cg_s[0], h->cg_gd[0], h->status);
+    }
+}
+
+// synchronous solve: poll the convergence flag every chunk, then x = Linv^T x^
+template <int D>
+int xcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
+    if (xcg_setup<D>(h, max_iters)) return -1;
+    int chunk = std::max(32, h->last_pcg_iters + 2);
+    bool done = false;
+    while (!done) {
+        const int m = std::min(chunk, max_iters + 1 - h->cg_launched);
+        xcg_launch<D>(h, tol, m);
+        if (read_scalars(h)) return -1;
+        done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 1;
+        chunk = std::max(32, h->cg_launched / 4);
+    }
+    hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)h->nr * D, 256)), dim3(256), 0, h->stream, h->nr, h->Linv,
+                       h->cg_xh, h->x, (const int32_t*)nullptr);
+    return cg_report(h, iters_out, relres_out);
+}
+
 bool use_direct(const ps_problem* h) {
     return h->pcg_variant == 1 && h->nr > 0 && h->nr * h->D <= h->direct_max;
 }
@@ -813,8 +899,12 @@ int solve_reduced(ps_problem* h, double tol, int max_iters, int* iters, double* 
         if (read_scalars(h)) return -1;
         return cg_report(h, iters, relres);
     }
-    if (h->pcg_variant == 1)
+    if (h->pcg_variant == 1) {
+        if (!h->coarse_built && build_coarse(h)) return -1;
+        if (h->cg_explicit)
+            return h->D == 6 ? xcg_run<6>(h, tol, max_iters, iters, relres) : xcg_run<3>(h, tol, max_iters, iters, relres);
         return h->D == 6 ? cg_fused_run<6>(h, tol, max_iters, iters, relres) : cg_fused_run<3>(h, tol, max_iters, iters, relres);
+    }
     return h->D == 6 ? pcg_run<6>(h, tol, max_iters, iters, relres) : pcg_run<3>(h, tol, max_iters, iters, relres);
 }
 
@@ -836,6 +926,14 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         if (total) total->stop();
         if (wait_published(h)) return -1;
         return cg_report(h, iters_out, relres_out);
+    }
+    if (!h->coarse_built && build_coarse(h)) return -1;
+    if (h->cg_explicit) {                                   // long sparse chains: synchronous explicit PCG, then the tail
+        if (xcg_run<D>(h, tol, max_iters, iters_out, relres_out)) return -1;
+        tp.stop();
+        if (gn_tail(h, linesearch, nullptr, true)) return -1;
+        if (total) total->stop();
+        return wait_published(h);
     }
     if (cg_fused_setup<D>(h, max_iters, true)) return -1;
     int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + h->cg_margin : 16;
@@ -1539,6 +1637,7 @@ int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters,
     h->shard_out = true;
     struct Reset { ps_problem* h; ~Reset() { h->shard_out = false; } } reset{h};
     if (first) {
+        if (h->explicit_ok) { h->explicit_ok = 0; h->coarse_built = false; }     // the enqueue-only protocol needs the folded CG
         HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
         if (h->D == 6 ? cg_fused_setup<6>(h, pcg_max_iters, true) : cg_fused_setup<3>(h, pcg_max_iters, true)) return -1;
     }
@@ -1652,7 +1751,8 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
 int ps_covariance_begin(ps_problem* h) {
     if (!h) return fail("null argument");
     if (linearize(h, 0.0)) return -1;
-    if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h)) {
+    if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h) && !h->coarse_built && build_coarse(h)) return -1;
+    if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h) && !h->cg_explicit) {
         const int rc = h->D == 6 ? cg_fused_setup<6>(h, 16) : cg_fused_setup<3>(h, 16);
         if (rc) return -1;
     }
@@ -1687,7 +1787,9 @@ int ps_covariance_column(ps_problem* h, int kind, int index, int comp, double to
             rc = h->D == 6 ? direct_solve_enqueue<6>(h) : direct_solve_enqueue<3>(h);
             if (!rc) rc = read_scalars(h);
             if (!rc) rc = cg_report(h, &its, &rel);
-        } else if (h->pcg_variant == 1)
+        } else if (h->pcg_variant == 1 && h->cg_explicit)
+            rc = h->D == 6 ? xcg_run<6>(h, tol, max_iters, &its, &rel) : xcg_run<3>(h, tol, max_iters, &its, &rel);
+        else if (h->pcg_variant == 1)
             rc = h->D == 6 ? cg_fused_run<6>(h, tol, max_iters, &its, &rel, true) : cg_fused_run<3>(h, tol, max_iters, &its, &rel, true);
         else
             rc = h->D == 6 ? pcg_run<6>(h, tol, max_iters, &its, &rel) : pcg_run<3>(h, tol, max_iters, &its, &rel);
@@ -1754,6 +1856,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_lds") h->cg_lds = value != 0.0;
+    else if (n == "cg_explicit") { h->explicit_ok = value != 0.0; h->coarse_built = false; }
     else if (n == "big_chol") h->big_chol = value != 0.0;
     else if (n == "fused_motion_only") h->mo_fused = value != 0.0;
     else if (n == "direct_max_unknowns") { if (value < 0 || value > 90) return fail("direct_max_unknowns must be 0..90"); h->direct_max = (int)value; }

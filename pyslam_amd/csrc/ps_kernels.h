@@ -1475,6 +1475,203 @@ __global__ __launch_bounds__(256) void k_direct_apply(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Explicit two-level PCG for long sparse chains (pose graphs with thousands of poses).  Same
+// preconditioner as the folded form, M^-1 = I + P A_c^-1 P^T in the scaled coordinates, but APPLIED:
+//   k_xcg_spmv      beta, p = z + beta p (on the fly, also for the neighbours), q = S^ p, partials of p.q
+//   k_xcg_restrict  alpha, r -= alpha q, x += alpha p (owner node), t_q = sum_i w(i,q) B_i^T r_i
+//   k_xcg_coarse    y = A_c^-1 t                      (dense nc x nc matrix-vector product, one wave per row)
+//   k_xcg_prolong   z_i = r_i + B_i (w0 y[n] + w1 y[n+1]), partials of r.z
+// Four small launches per iteration and 288 B x nnzb of matrix traffic, instead of dragging a dense
+// border of ncb blocks through every row (C2: 60 -> 11 blocks per row, 100 -> ~28 us per iteration).
+// xstate: [0] r.z of the previous iteration, [1] threshold, [2] r0.z0
+// ---------------------------------------------------------------------------
+#define PS_XCG_ROWS 4                         // rows (waves) per workgroup of the SpMV
+#define PS_XCG_DROWS 256                      // rows per workgroup of the prolongation
+
+PS_DEV double xcg_total(const double* __restrict__ part, int n, double* lds) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += part[i];
+    return block_sum(v, lds);
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * PS_XCG_ROWS) void k_xcg_spmv(
+    int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx, int wf,
+    const double* __restrict__ S, const double* __restrict__ z, const double* __restrict__ p_old,
+    double* __restrict__ p_new, double* __restrict__ q, const double* __restrict__ rz_part, int n_rz,
+    double* __restrict__ pq_part, double* __restrict__ xstate, int k, double tol2,
+    double* __restrict__ hist, int32_t* __restrict__ status, double* __restrict__ scalars)
+{
+    __shared__ double lds[16];
+    __shared__ double wpq[PS_XCG_ROWS];
+    constexpr int DD = D * D;
+    const int done = status[ST_PCG_DONE];
+    const double rz_prev = xstate[0], thresh_in = xstate[1];
+    double rz = xcg_total(rz_part, n_rz, lds);
+    if (done) return;
+    const double thresh = (k == 0) ? tol2 * rz : thresh_in;
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    if (!(rz > thresh)) {                                 // converged (or rz == 0 / NaN)
+        if (first) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = rz; if (k == 0) scalars[SC_RR0] = rz; }
+        return;
+    }
+    const double beta = (k == 0) ? 0.0 : rz / rz_prev;
+    if (first) {
+        xstate[0] = rz; hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rz;
+        if (k == 0) { xstate[1] = thresh; xstate[2] = rz; scalars[SC_RR0] = rz; }
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * PS_XCG_ROWS + w;
+    double pq = 0.0;
+    if (row < nr) {
+        const int rbeg = wf > 0 ? row * wf : row_ptr[row];
+        const int rend = wf > 0 ? rbeg + wf : row_ptr[row + 1];
+        const int kk = lane >> 3, r = lane & 7;
+        double acc = 0.0;
+        if (r < D) {
+            for (int b = rbeg + kk; b < rend; b += 8) {
+                const size_t j = (size_t)col_idx[b] * D;
+                const double* sb = S + (size_t)b * DD + r * D;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc += sb[c] * (z[j + c] + beta * p_old[j + c]);
+            }
+        }
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        double pn = 0.0;
+        if (lane < D) {
+            const size_t i = (size_t)row * D + lane;
+            pn = z[i] + beta * p_old[i];
+            p_new[i] = pn; q[i] = acc;
+        }
+        pq = wave_sum(lane < D ? pn * acc : 0.0);
+    }
+    if (lane == 0) wpq[w] = pq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < PS_XCG_ROWS; ++ww) v += wpq[ww];
+        pq_part[blockIdx.x] = v;
+    }
+}
+
+// one workgroup per coarse node q: the rows of its support (two hat intervals)
+template <int D>
+__global__ __launch_bounds__(256) void k_xcg_restrict(
+    int nr, int ncb, const int32_t* __restrict__ slo, const int32_t* __restrict__ shi,
+    const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ Bmat, const double* __restrict__ r_old, double* __restrict__ r_new,
+    const double* __restrict__ qv, const double* __restrict__ p, double* __restrict__ x,
+    const double* __restrict__ pq_part, int n_pq, const double* __restrict__ xstate, int init,
+    double* __restrict__ tvec, const int32_t* __restrict__ status)
+{
+    __shared__ double lds[16];
+    __shared__ double wt[4][8];
+    const int done = status[ST_PCG_DONE];
+    double alpha = 0.0;
+    if (!init) {
+        const double pq = xcg_total(pq_part, n_pq, lds);
+        alpha = xstate[0] / pq;
+    }
+    if (done) return;
+    const int qn = blockIdx.x, t = threadIdx.x;
+    double acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0;
+    for (int i = slo[qn] + t; i < shi[qn]; i += 256) {
+        const bool owner = pnode[i] == qn;                 // every row has exactly one left node
+        const double wgt = (pnode[i] == qn) ? pw0[i] : pw1[i];
+        double rn[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const size_t e = (size_t)i * D + c;
+            rn[c] = init ? r_old[e] : r_old[e] - alpha * qv[e];
+            if (owner) {
+                r_new[e] = rn[c];
+                if (!init) x[e] += alpha * p[e];
+            }
+        }
+        const double* B = Bmat + (size_t)i * D * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) v += B[a * D + c] * rn[a];
+            acc[c] += wgt * v;
+        }
+    }
+    const int wv = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const double v = wave_sum(acc[c]);
+        if (lane == 0) wt[wv][c] = v;
+    }
+    __syncthreads();
+    if (t < D) tvec[(size_t)qn * D + t] = ((wt[0][t] + wt[1][t]) + wt[2][t]) + wt[3][t];
+}
+
+// A_c^-1 = Lci^T Lci, dense and symmetric, formed once per solve so that the per-iteration coarse solve
+// is ONE parallel matrix-vector product (a single workgroup walking two triangular factors with dependent
+// L2 loads took ~70 us per iteration)
+__global__ __launch_bounds__(256) void k_xcg_ainv(int nc, const double* __restrict__ Lci, double* __restrict__ Ainv)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nc * nc) return;
+    const int i = e / nc, j = e % nc;
+    double v = 0.0;
+#pragma unroll 4
+    for (int k = (i > j ? i : j); k < nc; ++k) v += Lci[(size_t)k * nc + i] * Lci[(size_t)k * nc + j];
+    Ainv[e] = v;
+}
+
+// y = A_c^-1 t : one wave per row
+__global__ __launch_bounds__(256) void k_xcg_coarse(
+    int nc, const double* __restrict__ Ainv, const double* __restrict__ tvec,
+    double* __restrict__ y, const int32_t* __restrict__ status)
+{
+    if (status[ST_PCG_DONE]) return;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nc) return;
+    double v = 0.0;
+    for (int j = lane; j < nc; j += 64) v += Ainv[(size_t)row * nc + j] * tvec[j];
+    v = wave_sum(v);
+    if (lane == 0) y[row] = v;
+}
+
+template <int D>
+__global__ __launch_bounds__(PS_XCG_DROWS) void k_xcg_prolong(
+    int nr, int ncb, const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ Bmat, const double* __restrict__ r, const double* __restrict__ y,
+    double* __restrict__ z, double* __restrict__ rz_part, const int32_t* __restrict__ status)
+{
+    __shared__ double lds[16];
+    if (status[ST_PCG_DONE]) return;
+    const int i = blockIdx.x * PS_XCG_DROWS + threadIdx.x;
+    double rz = 0.0;
+    if (i < nr) {
+        const int n0 = pnode[i];
+        const double w0 = pw0[i], w1 = pw1[i];
+        double yy[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) yy[m] = w0 * y[n0 * D + m] + ((n0 + 1 < ncb) ? w1 * y[(n0 + 1) * D + m] : 0.0);
+        const double* B = Bmat + (size_t)i * D * D;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const size_t e = (size_t)i * D + a;
+            double v = r[e];
+#pragma unroll
+            for (int m = 0; m < D; ++m) v += B[a * D + m] * yy[m];
+            z[e] = v;
+            rz += r[e] * v;
+        }
+    }
+    rz = block_sum(rz, lds);
+    if (threadIdx.x == 0) rz_part[blockIdx.x] = rz;
+}
+
 // x = Linv^T x^
 template <int D>
 __global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __restrict__ Linv,
