@@ -356,7 +356,13 @@ int build_coarse(ps_problem* h) {
         else if (nr > h->cg_split_min_rows) G = 48;                                    // measured: C4 (BA, 2 000 poses) and C2 (10 000-pose chain)
         else G = std::min(12, std::max(3, (nr + 9) / 18));
     }
-    G = std::min(G, Gmax);
+    // long sparse chains (pose graphs with thousands of poses): the two-level preconditioner is APPLIED
+    // explicitly (restrict, dense coarse solve, prolong: cg_explicit) instead of folded into the matrix --
+    // the folded form drags a dense border of ncb blocks through every row (C2: 49 of 60 blocks per row).
+    // Without a border the coarse level can be much finer: ~one interval per 64 poses, up to 255.
+    h->cg_explicit = h->explicit_ok && G != 0 && nr > h->cg_split_min_rows && (long)h->nnzb <= 24L * nr;
+    if (h->cg_explicit && h->coarse_req < 0) G = std::min(255, std::max(48, nr / 64));      // C2: 150 intervals
+    G = std::min(G, h->cg_explicit ? 255 : Gmax);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
     if (G < 1) G = 0;
     h->G = G; h->coarse_built = true; h->cg_split = false;
@@ -364,10 +370,7 @@ int build_coarse(ps_problem* h) {
     const std::vector<int32_t>& ci = h->h_col_idx;
     int maxlen = 0;
     for (int i = 0; i < nr; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
-    // long sparse chains (pose graphs with thousands of poses): the two-level preconditioner is APPLIED
-    // explicitly (restrict, dense coarse solve, prolong: cg_explicit) instead of folded into the matrix --
-    // the folded form drags a dense border of ncb blocks through every row (C2: 49 of 60 blocks per row)
-    h->cg_explicit = h->explicit_ok && G > 0 && nr > h->cg_split_min_rows && (long)h->nnzb <= 24L * nr;
+    h->cg_explicit = h->cg_explicit && G > 0;
     const int ncb_pre = (G && !h->cg_explicit) ? G + 1 : 0;
     // pad rows to a common width unless that wastes more than 50 % (hub-like graphs): then CSR
     const bool ell = nr > 0 && (long)(maxlen + ncb_pre) * nr <= (long)(1.5 * (h->nnzb + (long)ncb_pre * nr)) + 64;
@@ -491,8 +494,12 @@ int coarse_factor(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
             }
         }
         const size_t inv_lds = ((size_t)nc * PS_BC_W + PS_BC_W * PS_BC_W) * sizeof(double);
-        HIP_OK(hipFuncSetAttribute((const void*)k_btri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
-        hipLaunchKernelGGL(k_btri_inverse, dim3(nsteps), dim3(256), inv_lds, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
+        if (inv_lds <= 150 * 1024) {
+            HIP_OK(hipFuncSetAttribute((const void*)k_btri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
+            hipLaunchKernelGGL(k_btri_inverse, dim3(nsteps), dim3(256), inv_lds, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
+        } else {
+            hipLaunchKernelGGL(k_btri_inverse_big, dim3(nsteps), dim3(256), 0, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
+        }
     } else {
         hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, st, ncb, h->Ac, h->Lci2[buf],
                            h->LciT2[buf], stat, h->chol_scratch);
@@ -824,7 +831,7 @@ int xcg_setup(ps_problem* h, int max_iters) {
     HIP_OK(hipMemsetAsync(h->xp2, 0, (size_t)nr * D * sizeof(double), h->stream));
     // z_0 = M^-1 r_0 and r_0 . z_0
     hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode, h->pw0,
-                       h->pw1, h->Bmat, h->cg_r[0], h->cg_r[0], h->cg_w[0], h->cg_p, h->cg_xh, h->cg_gd[1], 0, h->xstate, 1,
+                       h->pw1, h->Bmat, h->cg_r[0], h->cg_r[0], h->cg_w[0], h->cg_p, h->cg_xh, h->cg_gd[1], 0, h->xstate, -1,
                        h->tvec, h->status);
     hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, h->chol_scratch, h->tvec, h->xy, h->status);
     hipLaunchKernelGGL(k_xcg_prolong<D>, dim3(cdiv(nr, PS_XCG_DROWS)), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb, h->pnode,
@@ -845,7 +852,7 @@ void xcg_launch(ps_problem* h, double tol, int count) {
                            h->xstate, k, tol * tol, h->hist, h->status, h->scalars);
         hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
                            h->pw0, h->pw1, h->Bmat, h->cg_r[b], h->cg_r[b ^ 1], h->cg_w[0], pbuf[b], h->cg_xh, h->cg_gd[1],
-                           n_pq, h->xstate, 0, h->tvec, h->status);
+                           n_pq, h->xstate, k, h->tvec, h->status);
         hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, h->chol_scratch, h->tvec, h->xy, h->status);
         hipLaunchKernelGGL(k_xcg_prolong<D>, dim3(cdiv(nr, PS_XCG_DROWS)), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb,
                            h->pnode, h->pw0, h->pw1, h->Bmat, h->cg_r[b ^ 1], h->xy, h->cg_s[0], h->cg_gd[0], h->status);
@@ -1848,7 +1855,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     const std::string n(name);
     if (n == "pcg_variant") { if (value != 0 && value != 1) return fail("pcg_variant must be 0 or 1"); h->pcg_variant = (int)value; }
     else if (n == "coarse_groups") {
-        if (value < -1 || value > 64) return fail("coarse_groups out of range (-1 auto, 0 off, else number of hat intervals)");
+        if (value < -1 || value > 255) return fail("coarse_groups out of range (-1 auto, 0 off, else number of hat intervals; above 63 only for the explicit two-level PCG)");
         h->coarse_req = (int)value; h->coarse_built = false;
     }
     else if (n == "cg_ablate") h->cg_ablate = (int)value;

@@ -1484,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_direct_apply(
 //   k_xcg_prolong   z_i = r_i + B_i (w0 y[n] + w1 y[n+1]), partials of r.z
 // Four small launches per iteration and 288 B x nnzb of matrix traffic, instead of dragging a dense
 // border of ncb blocks through every row (C2: 60 -> 11 blocks per row, 100 -> ~28 us per iteration).
-// xstate: [0] r.z of the previous iteration, [1] threshold, [2] r0.z0
+// xstate: [1] threshold, [2] r0.z0, [4 + parity] r.z of iteration k (double-buffered by parity)
 // ---------------------------------------------------------------------------
 #define PS_XCG_ROWS 4                         // rows (waves) per workgroup of the SpMV
 #define PS_XCG_DROWS 256                      // rows per workgroup of the prolongation
@@ -1507,7 +1507,9 @@ __global__ __launch_bounds__(64 * PS_XCG_ROWS) void k_xcg_spmv(
     __shared__ double wpq[PS_XCG_ROWS];
     constexpr int DD = D * D;
     const int done = status[ST_PCG_DONE];
-    const double rz_prev = xstate[0], thresh_in = xstate[1];
+    // r.z of the previous iteration sits in the slot of the other parity: workgroup 0 of THIS launch writes
+    // this iteration's slot while later workgroups may still be starting
+    const double rz_prev = xstate[4 + ((k + 1) & 1)], thresh_in = xstate[1];
     double rz = xcg_total(rz_part, n_rz, lds);
     if (done) return;
     const double thresh = (k == 0) ? tol2 * rz : thresh_in;
@@ -1518,7 +1520,7 @@ __global__ __launch_bounds__(64 * PS_XCG_ROWS) void k_xcg_spmv(
     }
     const double beta = (k == 0) ? 0.0 : rz / rz_prev;
     if (first) {
-        xstate[0] = rz; hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rz;
+        xstate[4 + (k & 1)] = rz; hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rz;
         if (k == 0) { xstate[1] = thresh; xstate[2] = rz; scalars[SC_RR0] = rz; }
     }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1565,16 +1567,17 @@ __global__ __launch_bounds__(256) void k_xcg_restrict(
     const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
     const double* __restrict__ Bmat, const double* __restrict__ r_old, double* __restrict__ r_new,
     const double* __restrict__ qv, const double* __restrict__ p, double* __restrict__ x,
-    const double* __restrict__ pq_part, int n_pq, const double* __restrict__ xstate, int init,
+    const double* __restrict__ pq_part, int n_pq, const double* __restrict__ xstate, int k /* < 0: initialisation */,
     double* __restrict__ tvec, const int32_t* __restrict__ status)
 {
     __shared__ double lds[16];
     __shared__ double wt[4][8];
     const int done = status[ST_PCG_DONE];
+    const int init = k < 0;
     double alpha = 0.0;
     if (!init) {
         const double pq = xcg_total(pq_part, n_pq, lds);
-        alpha = xstate[0] / pq;
+        alpha = xstate[4 + (k & 1)] / pq;
     }
     if (done) return;
     const int qn = blockIdx.x, t = threadIdx.x;
@@ -1959,23 +1962,28 @@ __global__ __launch_bounds__(1024) void k_bchol_panel(
         if (r < w && c <= r) A[(size_t)(j0 + r) * nc + j0 + c] = sD[k];
     }
     // panel below the tile: L_IJ = A_IJ L_JJ^-T, all results in registers before anything is overwritten
+    // (rows are independent: a row's outputs only read that row's own w entries, so the panel is walked in
+    // slabs of 9 * 1024 entries, each computed into registers, then written)
     const int rows = nc - j0 - w, total = rows * w;
-    double out[9];                                         // ceil(384 * 24 / 1024) = 9 (nc <= 384)
+    for (int base = 0; base < total; base += 9 * 1024) {
+        double out[9];
 #pragma unroll
-    for (int n = 0; n < 9; ++n) {
-        const int idx = t + n * 1024;
-        double v = 0.0;
-        if (idx < total) {
-            const int i = j0 + w + idx / w, c = idx % w;
-            for (int k = 0; k <= c; ++k) v += A[(size_t)i * nc + j0 + k] * sI[c * PS_BC_W + k];
+        for (int n = 0; n < 9; ++n) {
+            const int idx = base + t + n * 1024;
+            double v = 0.0;
+            if (idx < total) {
+                const int i = j0 + w + idx / w, c = idx % w;
+                for (int k = 0; k <= c; ++k) v += A[(size_t)i * nc + j0 + k] * sI[c * PS_BC_W + k];
+            }
+            out[n] = v;
         }
-        out[n] = v;
-    }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int n = 0; n < 9; ++n) {
-        const int idx = t + n * 1024;
-        if (idx < total) A[(size_t)(j0 + w + idx / w) * nc + j0 + idx % w] = out[n];
+        for (int n = 0; n < 9; ++n) {
+            const int idx = base + t + n * 1024;
+            if (idx < total) A[(size_t)(j0 + w + idx / w) * nc + j0 + idx % w] = out[n];
+        }
+        __syncthreads();
     }
 }
 
@@ -2066,6 +2074,44 @@ PS_DEV void coarse_rhs_body(
     double* __restrict__ p, double* __restrict__ x,
     int with_coarse_rows, const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, double* stv,
     const double* __restrict__ bg);
+
+// the same for coarse levels whose column block does not fit LDS (nc > 768): the column block of X is kept in
+// X itself (global, L2-resident) -- a workgroup only ever re-reads what it wrote itself
+__global__ __launch_bounds__(256) void k_btri_inverse_big(
+    int nc, const double* __restrict__ L, const double* __restrict__ Tinv_all,
+    double* __restrict__ X, double* __restrict__ XT)
+{
+    __shared__ double sT[PS_BC_W * PS_BC_W];
+    const int J = blockIdx.x, j0 = J * PS_BC_W, w = min(PS_BC_W, nc - j0), t = threadIdx.x;
+    for (int e = t; e < j0 * w; e += 256) {                 // the strictly upper part of the column block is zero
+        const int i = e / w, c = e % w;
+        X[(size_t)i * nc + j0 + c] = 0.0;
+        XT[(size_t)(j0 + c) * nc + i] = 0.0;
+    }
+    for (int i0 = j0; i0 < nc; i0 += PS_BC_W) {
+        const int wi = min(PS_BC_W, nc - i0);
+        for (int e = t; e < wi * w; e += 256) {
+            const int r = e / w, c = e % w, i = i0 + r;
+            double v = (i == j0 + c) ? 1.0 : 0.0;
+#pragma unroll 4
+            for (int k = j0; k < i0; ++k) v -= L[(size_t)i * nc + k] * X[(size_t)k * nc + j0 + c];
+            sT[r * PS_BC_W + c] = v;
+        }
+        __syncthreads();
+        const double* Ti = Tinv_all + (size_t)(i0 / PS_BC_W) * PS_BC_W * PS_BC_W;
+        for (int e = t; e < wi * w; e += 256) {
+            const int r = e / w, c = e % w;
+            double v = 0.0;
+            for (int k = 0; k <= r; ++k) v += Ti[r * PS_BC_W + k] * sT[k * PS_BC_W + c];
+            const int i = i0 + r, j = j0 + c;
+            v = (i >= j) ? v : 0.0;
+            X[(size_t)i * nc + j] = v;
+            XT[(size_t)j * nc + i] = v;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
 
 // K_i = SZ_i Lci^T, written to both borders of the augmented BSR matrix.
 // One workgroup per fine block row i; thread per (r, c) of the D x nc strip.

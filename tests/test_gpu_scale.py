@@ -255,3 +255,23 @@ def test_c2_full_size_first_steps_match_the_reference_algebra():
         assert abs(cost - orc.eval_cost(cur)) <= 1e-6 * cost
     poses, _ = dev.get_params()
     assert np.abs(poses - cur.poses).max() < 1e-5
+
+def test_explicit_and_folded_two_level_cg_agree_on_a_long_chain():
+    """Long sparse chains run the two-level PCG with the preconditioner APPLIED (k_xcg_*: restrict, dense coarse
+    solve, prolong) instead of folded into the matrix.  Same operator: same step, similar iteration counts at the
+    same number of coarse intervals; and the much finer coarse level it makes affordable needs far fewer."""
+    lp, _ = synthetic.pose_graph(num_poses=3000, num_loops=12001, dof=6, seed=5)
+    out = {}
+    for name, explicit, groups in (('folded', 0, 48), ('explicit', 1, 48), ('explicit_fine', 1, 150)):
+        dev = device(lp)
+        dev.set_option('cg_explicit', explicit)
+        dev.set_option('coarse_groups', groups)
+        dev.linearize(0.)
+        its, rel = dev.solve_reduced(1e-13, 4000)
+        assert rel <= 1e-13
+        out[name] = (its, device_dx_posefirst(dev))
+    ref = out['folded'][1]
+    for name in ('explicit', 'explicit_fine'):
+        assert np.linalg.norm(out[name][1] - ref) <= 1e-8 * np.linalg.norm(ref), name
+    assert abs(out['explicit'][0] - out['folded'][0]) <= 0.1 * out['folded'][0] + 5
+    assert out['explicit_fine'][0] < 0.6 * out['explicit'][0]
