@@ -493,13 +493,8 @@ int coarse_factor(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
                 hipLaunchKernelGGL(k_bchol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, nc, j0, w, A);
             }
         }
-        const size_t inv_lds = ((size_t)nc * PS_BC_W + PS_BC_W * PS_BC_W) * sizeof(double);
-        if (inv_lds <= 150 * 1024) {
-            HIP_OK(hipFuncSetAttribute((const void*)k_btri_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds));
-            hipLaunchKernelGGL(k_btri_inverse, dim3(nsteps), dim3(256), inv_lds, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
-        } else {
-            hipLaunchKernelGGL(k_btri_inverse_big, dim3(nsteps), dim3(256), 0, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
-        }
+        const size_t inv_lds = ((size_t)nc + PS_BC_W) * PS_BI_CW * sizeof(double);
+        hipLaunchKernelGGL(k_btri_inverse, dim3(cdiv(nc, PS_BI_CW)), dim3(256), inv_lds, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
     } else {
         hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, st, ncb, h->Ac, h->Lci2[buf],
                            h->LciT2[buf], stat, h->chol_scratch);

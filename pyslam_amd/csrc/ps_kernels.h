@@ -2016,38 +2016,43 @@ __global__ __launch_bounds__(256) void k_bchol_update(int nc, int j0, int w, dou
     }
 }
 
-// X = L^-1 (lower) and its transpose; one workgroup per block of PS_BC_W columns, which keeps its
-// column block of X in LDS (nc x 24 doubles <= 74 KB) and walks the row blocks below the diagonal
+// X = L^-1 (lower) and its transpose.  Columns of X are independent forward substitutions: one workgroup per
+// PS_BI_CW columns (nc / 4 workgroups: the whole chip, not 16-40 of its CUs), its column block of X in LDS
+// (nc x 4 doubles), walking the 24-row blocks below the diagonal with the diagonal tiles' inverses.
+#define PS_BI_CW 4
 __global__ __launch_bounds__(256) void k_btri_inverse(
-    int nc, const double* __restrict__ L, const double* __restrict__ Tinv_all /* one tile per column block */,
+    int nc, const double* __restrict__ L, const double* __restrict__ Tinv_all /* one 24 x 24 tile per row block */,
     double* __restrict__ X, double* __restrict__ XT)
 {
-    extern __shared__ double sX[];                         // nc x PS_BC_W (rows j0 .. nc-1 used) + one tile of t
-    const int J = blockIdx.x, j0 = J * PS_BC_W, w = min(PS_BC_W, nc - j0), t = threadIdx.x;
-    double* sT = sX + (size_t)nc * PS_BC_W;
-    for (int i0 = j0; i0 < nc; i0 += PS_BC_W) {
+    extern __shared__ double sX[];                         // nc x PS_BI_CW, + one 24 x PS_BI_CW tile
+    const int j0 = blockIdx.x * PS_BI_CW, w = min(PS_BI_CW, nc - j0), t = threadIdx.x;
+    double* sT = sX + (size_t)nc * PS_BI_CW;
+    const int ib = (j0 / PS_BC_W) * PS_BC_W;               // first row block that can be non-zero
+    for (int e = t; e < ib * w; e += 256) sX[(size_t)(e / w) * PS_BI_CW + e % w] = 0.0;
+    __syncthreads();
+    for (int i0 = ib; i0 < nc; i0 += PS_BC_W) {
         const int wi = min(PS_BC_W, nc - i0);
-        // t = delta - L[I][j0..i0) X[j0..i0)][J]
+        // t = delta - L[I][ib .. i0) X[ib .. i0)][cols]
         for (int e = t; e < wi * w; e += 256) {
             const int r = e / w, c = e % w, i = i0 + r;
             double v = (i == j0 + c) ? 1.0 : 0.0;
 #pragma unroll 4
-            for (int k = j0; k < i0; ++k) v -= L[(size_t)i * nc + k] * sX[(size_t)k * PS_BC_W + c];
-            sT[r * PS_BC_W + c] = v;
+            for (int k = ib; k < i0; ++k) v -= L[(size_t)i * nc + k] * sX[(size_t)k * PS_BI_CW + c];
+            sT[r * PS_BI_CW + c] = v;
         }
         __syncthreads();
         const double* Ti = Tinv_all + (size_t)(i0 / PS_BC_W) * PS_BC_W * PS_BC_W;
         for (int e = t; e < wi * w; e += 256) {
             const int r = e / w, c = e % w;
             double v = 0.0;
-            for (int k = 0; k <= r; ++k) v += Ti[r * PS_BC_W + k] * sT[k * PS_BC_W + c];
-            sX[(size_t)(i0 + r) * PS_BC_W + c] = v;
+            for (int k = 0; k <= r; ++k) v += Ti[r * PS_BC_W + k] * sT[k * PS_BI_CW + c];
+            sX[(size_t)(i0 + r) * PS_BI_CW + c] = v;
         }
         __syncthreads();
     }
     for (int e = t; e < nc * w; e += 256) {
         const int i = e / w, c = e % w, j = j0 + c;
-        const double v = (i >= j) ? sX[(size_t)i * PS_BC_W + c] : 0.0;
+        const double v = (i >= j) ? sX[(size_t)i * PS_BI_CW + c] : 0.0;
         X[(size_t)i * nc + j] = v;
         XT[(size_t)j * nc + i] = v;
     }
