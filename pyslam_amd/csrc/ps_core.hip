@@ -486,7 +486,7 @@ int coarse_factor(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
         const int nsteps = cdiv(nc, PS_BC_W);
         for (int s2 = 0; s2 < nsteps; ++s2) {
             const int j0 = s2 * PS_BC_W, w = std::min(PS_BC_W, nc - j0), m = nc - j0 - w;
-            hipLaunchKernelGGL(k_bchol_panel, dim3(1), dim3(1024), 0, st, nc, j0, A,
+            hipLaunchKernelGGL(k_bchol_panel, dim3(std::max(1, cdiv((long)m * w, 1024))), dim3(256), 0, st, nc, j0, A,
                                Tinv + (size_t)s2 * PS_BC_W * PS_BC_W, stat);
             if (m > 0) {
                 const int nt = cdiv(m, 32);

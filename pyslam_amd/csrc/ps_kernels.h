@@ -1919,14 +1919,18 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
 // single-workgroup factorisation out of L2.
 // ---------------------------------------------------------------------------
 #define PS_BC_W 24
-__global__ __launch_bounds__(1024) void k_bchol_panel(
-    int nc, int j0, double* __restrict__ A /* nc x nc row-major: lower triangle in, L out */,
+__global__ __launch_bounds__(256) void k_bchol_panel(
+    int nc, int j0, double* __restrict__ A /* nc x nc row-major: lower triangle in, L (below the tiles) out */,
     double* __restrict__ Tinv /* PS_BC_W x PS_BC_W: inverse of this step's diagonal factor */,
     int32_t* __restrict__ status)
 {
+    // Every workgroup factors the (tiny) diagonal tile itself -- 24 sequential steps in LDS, cheaper than a
+    // launch boundary -- and then owns a slab of 1024 panel entries, so the panel below the tile is spread over
+    // the chip.  The tile's factor itself is never needed again (only its inverse, Tinv), so nobody writes the
+    // tile back and the redundant readers do not race with a writer.
     __shared__ double sD[PS_BC_W * PS_BC_W], sI[PS_BC_W * PS_BC_W];
     const int t = threadIdx.x, w = min(PS_BC_W, nc - j0);
-    for (int k = t; k < PS_BC_W * PS_BC_W; k += 1024) {
+    for (int k = t; k < PS_BC_W * PS_BC_W; k += 256) {
         const int r = k / PS_BC_W, c = k % PS_BC_W;
         sD[k] = (r < w && c <= r) ? A[(size_t)(j0 + r) * nc + j0 + c] : 0.0;
         sI[k] = 0.0;
@@ -1935,14 +1939,14 @@ __global__ __launch_bounds__(1024) void k_bchol_panel(
     for (int j = 0; j < w; ++j) {                          // unblocked Cholesky of the w x w tile in LDS
         if (t == 0) {
             const double d = sD[j * PS_BC_W + j];
-            if (!(d > 0.0)) atomicAdd(&status[ST_DIAG_FAIL], 1);
+            if (!(d > 0.0) && blockIdx.x == 0) atomicAdd(&status[ST_DIAG_FAIL], 1);
             sD[j * PS_BC_W + j] = sqrt(d);
         }
         __syncthreads();
         const double inv = 1.0 / sD[j * PS_BC_W + j];
         if (t > j && t < w) sD[t * PS_BC_W + j] *= inv;
         __syncthreads();
-        for (int k = t; k < w * w; k += 1024) {
+        for (int k = t; k < w * w; k += 256) {
             const int r = k / w, c = k % w;
             if (c > j && r >= c) sD[r * PS_BC_W + c] -= sD[r * PS_BC_W + j] * sD[c * PS_BC_W + j];
         }
@@ -1956,34 +1960,27 @@ __global__ __launch_bounds__(1024) void k_bchol_panel(
         }
     }
     __syncthreads();
-    for (int k = t; k < PS_BC_W * PS_BC_W; k += 1024) {
-        const int r = k / PS_BC_W, c = k % PS_BC_W;
-        Tinv[k] = sI[k];
-        if (r < w && c <= r) A[(size_t)(j0 + r) * nc + j0 + c] = sD[k];
+    if (blockIdx.x == 0)
+        for (int k = t; k < PS_BC_W * PS_BC_W; k += 256) Tinv[k] = sI[k];
+    // this workgroup's slab of the panel below the tile: L_IJ = A_IJ L_JJ^-T.  A row's outputs only read that
+    // row's own w entries; they are all computed into registers before anything is overwritten.
+    const int total = (nc - j0 - w) * w, base = blockIdx.x * 1024;
+    double out[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int idx = base + t + n * 256;
+        double v = 0.0;
+        if (idx < total) {
+            const int i = j0 + w + idx / w, c = idx % w;
+            for (int k = 0; k <= c; ++k) v += A[(size_t)i * nc + j0 + k] * sI[c * PS_BC_W + k];
+        }
+        out[n] = v;
     }
-    // panel below the tile: L_IJ = A_IJ L_JJ^-T, all results in registers before anything is overwritten
-    // (rows are independent: a row's outputs only read that row's own w entries, so the panel is walked in
-    // slabs of 9 * 1024 entries, each computed into registers, then written)
-    const int rows = nc - j0 - w, total = rows * w;
-    for (int base = 0; base < total; base += 9 * 1024) {
-        double out[9];
+    __syncthreads();
 #pragma unroll
-        for (int n = 0; n < 9; ++n) {
-            const int idx = base + t + n * 1024;
-            double v = 0.0;
-            if (idx < total) {
-                const int i = j0 + w + idx / w, c = idx % w;
-                for (int k = 0; k <= c; ++k) v += A[(size_t)i * nc + j0 + k] * sI[c * PS_BC_W + k];
-            }
-            out[n] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int n = 0; n < 9; ++n) {
-            const int idx = base + t + n * 1024;
-            if (idx < total) A[(size_t)(j0 + w + idx / w) * nc + j0 + idx % w] = out[n];
-        }
-        __syncthreads();
+    for (int n = 0; n < 4; ++n) {
+        const int idx = base + t + n * 256;
+        if (idx < total) A[(size_t)(j0 + w + idx / w) * nc + j0 + idx % w] = out[n];
     }
 }
 
