@@ -114,6 +114,7 @@ struct ps_problem {
     double *Lci2[2] = {}, *LciT2[2] = {};
     int lci_cur = 0;                // buffer the current augmented system was built with
     int lci_next = -1;              // buffer holding (or receiving, see side_pending) the newest factor; -1: none
+    bool xcg_side_todo = false;     // explicit PCG: lagged setup whose side-stream half is not enqueued yet
     bool side_pending = false;      // a side-stream factorisation is in flight: wait for ev_chol before reuse
     int coarse_lag = 1;
     hipStream_t side = nullptr;
@@ -361,7 +362,8 @@ int build_coarse(ps_problem* h) {
     // the folded form drags a dense border of ncb blocks through every row (C2: 49 of 60 blocks per row).
     // Without a border the coarse level can be much finer: ~one interval per 64 poses, up to 255.
     h->cg_explicit = h->explicit_ok && G != 0 && nr > h->cg_split_min_rows && (long)h->nnzb <= 24L * nr;
-    if (h->cg_explicit && h->coarse_req < 0) G = std::min(255, std::max(48, nr / 64));      // C2: 150 intervals
+    // (the factorisation of A_c runs beside the CG on the side stream from the second iteration on, so a large coarse level is cheap)
+    if (h->cg_explicit && h->coarse_req < 0) G = std::min(255, std::max(48, nr / 40));      // C2: 250 intervals
     G = std::min(G, h->cg_explicit ? 255 : Gmax);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
     if (G < 1) G = 0;
@@ -456,7 +458,9 @@ int build_coarse(ps_problem* h) {
         HIP_OK(hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
     }
     if (!h->side) {
-        HIP_OK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        int prio_lo = 0, prio_hi = 0;                      // lowest priority: the side work must not delay the CG launches
+        HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
         HIP_OK(hipEventCreateWithFlags(&h->ev_ac, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&h->ev_chol, hipEventDisableTiming));
     }
@@ -493,8 +497,22 @@ int coarse_factor(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
                 hipLaunchKernelGGL(k_bchol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, nc, j0, w, A);
             }
         }
-        const size_t inv_lds = ((size_t)nc + PS_BC_W) * PS_BI_CW * sizeof(double);
+        // L^-1: diagonal blocks by substitution, the rest merged level by level with triangular products
+        // (the explicit PCG only reads the lower triangle of L^-1 and overwrites the transpose: no zero fill there)
+        const bool dense_out = nc > PS_BI_S0 && !h->cg_explicit;
+        if (dense_out) {
+            HIP_OK(hipMemsetAsync(h->Lci2[buf], 0, (size_t)nc * nc * sizeof(double), st));
+            HIP_OK(hipMemsetAsync(h->LciT2[buf], 0, (size_t)nc * nc * sizeof(double), st));
+        }
+        const size_t inv_lds = ((size_t)PS_BI_S0 + PS_BC_W) * PS_BI_CW * sizeof(double);
         hipLaunchKernelGGL(k_btri_inverse, dim3(cdiv(nc, PS_BI_CW)), dim3(256), inv_lds, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
+        for (int s2 = PS_BI_S0; s2 < nc; s2 *= 2) {
+            const int pairs = cdiv(nc, 2 * s2), nt = cdiv(s2, PS_BM_T);
+            for (int stage = 0; stage < 2; ++stage)
+                hipLaunchKernelGGL(k_btri_merge, dim3(pairs * nt * nt), dim3(256), 0, st, nc, s2, stage, A, h->Lci2[buf], h->LciT2[buf]);
+        }
+        if (dense_out)
+            hipLaunchKernelGGL(k_btri_clear, dim3(cdiv((long)nc * nc, 256)), dim3(256), 0, st, nc, h->LciT2[buf]);
     } else {
         hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, st, ncb, h->Ac, h->Lci2[buf],
                            h->LciT2[buf], stat, h->chol_scratch);
@@ -806,7 +824,7 @@ int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = f
 
 // ---- explicit two-level PCG (long sparse chains; kernels k_xcg_*) ---------------------------------
 template <int D>
-int xcg_setup(ps_problem* h, int max_iters) {
+int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     const int nr = h->nr, ncb = h->ncb, nc = h->nc;
     if (max_iters + 2 > h->hist_cap) return fail("pcg max_iters exceeds the history buffer (4096)");
     hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
@@ -819,19 +837,49 @@ int xcg_setup(ps_problem* h, int max_iters) {
                        nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat, h->BSZ);
     hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
                        nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
-    if (coarse_factor<D>(h, h->stream, h->lci_cur, h->status)) return -1;
-    h->lci_next = -1;                                  // (no lagging here: the factorisation is noise next to the CG)
-    hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv((long)nc * nc, 256)), dim3(256), 0, h->stream, nc, h->Lci2[h->lci_cur], h->chol_scratch);
+    // A_c^-1 lives in LciT2[b] (the transposed factor is not used on this path).  It only PRECONDITIONS here, so any
+    // symmetric positive definite stand-in keeps the CG exact: whole-iteration calls use the inverse formed from the
+    // PREVIOUS iteration's A_c and factor the current one on the side stream while the CG iterates (the factorisation,
+    // triangular inverse and product are 5.6 ms of the 12 ms iteration at C2 with 256 nodes).
+    const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0;
+    const int32_t* lagst = nullptr;
+    h->xcg_side_todo = false;
+    if (lag) {
+        h->lci_cur = h->lci_next;
+        HIP_OK(hipEventRecord(h->ev_ac, h->stream));       // A_c complete; the side work is enqueued by xcg_side_enqueue
+        h->xcg_side_todo = true;
+        lagst = h->lag_status;
+    } else {
+        const int buf = h->lci_cur;
+        if (coarse_factor<D>(h, h->stream, buf, h->status)) return -1;
+        hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, h->stream, nc, h->Lci2[buf], (float*)h->LciT2[buf]);
+        h->lci_next = buf;
+    }
     HIP_OK(hipMemsetAsync(h->xstate, 0, 8 * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->xp2, 0, (size_t)nr * D * sizeof(double), h->stream));
     // z_0 = M^-1 r_0 and r_0 . z_0
     hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode, h->pw0,
                        h->pw1, h->Bmat, h->cg_r[0], h->cg_r[0], h->cg_w[0], h->cg_p, h->cg_xh, h->cg_gd[1], 0, h->xstate, -1,
                        h->tvec, h->status);
-    hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, h->chol_scratch, h->tvec, h->xy, h->status);
+    hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, (const float*)h->LciT2[h->lci_cur], h->tvec, h->xy, h->status, lagst);
     hipLaunchKernelGGL(k_xcg_prolong<D>, dim3(cdiv(nr, PS_XCG_DROWS)), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb, h->pnode,
                        h->pw0, h->pw1, h->Bmat, h->cg_r[0], h->xy, h->cg_s[0], h->cg_gd[0], h->status);
     h->cg_launched = 0;
+    return 0;
+}
+
+// the side-stream half of a lagged setup, enqueued AFTER the first chunk of CG launches so that its ~130 launches
+// do not sit in front of them on the host
+template <int D>
+int xcg_side_enqueue(ps_problem* h) {
+    if (!h->xcg_side_todo) return 0;
+    h->xcg_side_todo = false;
+    const int nc = h->nc, nb = h->lci_cur ^ 1;
+    HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
+    if (coarse_factor<D>(h, h->side, nb, h->lag_status)) return -1;
+    hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, h->side, nc, h->Lci2[nb], (float*)h->LciT2[nb]);
+    HIP_OK(hipEventRecord(h->ev_chol, h->side));
+    h->lci_next = nb; h->side_pending = true;
     return 0;
 }
 
@@ -848,7 +896,7 @@ void xcg_launch(ps_problem* h, double tol, int count) {
         hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
                            h->pw0, h->pw1, h->Bmat, h->cg_r[b], h->cg_r[b ^ 1], h->cg_w[0], pbuf[b], h->cg_xh, h->cg_gd[1],
                            n_pq, h->xstate, k, h->tvec, h->status);
-        hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, h->chol_scratch, h->tvec, h->xy, h->status);
+        hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, (const float*)h->LciT2[h->lci_cur], h->tvec, h->xy, h->status, (const int32_t*)nullptr);
         hipLaunchKernelGGL(k_xcg_prolong<D>, dim3(cdiv(nr, PS_XCG_DROWS)), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb,
                            h->pnode, h->pw0, h->pw1, h->Bmat, h->cg_r[b ^ 1], h->xy, h->cg_s[0], h->cg_gd[0], h->status);
     }
@@ -856,13 +904,14 @@ void xcg_launch(ps_problem* h, double tol, int count) {
 
 // synchronous solve: poll the convergence flag every chunk, then x = Linv^T x^
 template <int D>
-int xcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
-    if (xcg_setup<D>(h, max_iters)) return -1;
+int xcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out, bool allow_lag = false) {
+    if (xcg_setup<D>(h, max_iters, allow_lag)) return -1;
     int chunk = std::max(32, h->last_pcg_iters + 2);
     bool done = false;
     while (!done) {
         const int m = std::min(chunk, max_iters + 1 - h->cg_launched);
         xcg_launch<D>(h, tol, m);
+        if (xcg_side_enqueue<D>(h)) return -1;
         if (read_scalars(h)) return -1;
         done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 1;
         chunk = std::max(32, h->cg_launched / 4);
@@ -931,7 +980,7 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
     }
     if (!h->coarse_built && build_coarse(h)) return -1;
     if (h->cg_explicit) {                                   // long sparse chains: synchronous explicit PCG, then the tail
-        if (xcg_run<D>(h, tol, max_iters, iters_out, relres_out)) return -1;
+        if (xcg_run<D>(h, tol, max_iters, iters_out, relres_out, true)) return -1;
         tp.stop();
         if (gn_tail(h, linesearch, nullptr, true)) return -1;
         if (total) total->stop();

@@ -1618,28 +1618,79 @@ __global__ __launch_bounds__(256) void k_xcg_restrict(
 
 // A_c^-1 = Lci^T Lci, dense and symmetric, formed once per solve so that the per-iteration coarse solve
 // is ONE parallel matrix-vector product (a single workgroup walking two triangular factors with dependent
-// L2 loads took ~70 us per iteration)
-__global__ __launch_bounds__(256) void k_xcg_ainv(int nc, const double* __restrict__ Lci, double* __restrict__ Ainv)
+// L2 loads took ~70 us per iteration).  One workgroup per 64 x 64 tile of the lower triangle (mirrored on
+// store), 4 x 4 outputs per thread, rows of Lci staged through LDS 16 at a time.
+#define PS_AI_T 64
+#define PS_AI_K 16
+__global__ __launch_bounds__(256) void k_xcg_ainv(int nc, const double* __restrict__ Lci, float* __restrict__ Ainv)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nc * nc) return;
-    const int i = e / nc, j = e % nc;
-    double v = 0.0;
-#pragma unroll 4
-    for (int k = (i > j ? i : j); k < nc; ++k) v += Lci[(size_t)k * nc + i] * Lci[(size_t)k * nc + j];
-    Ainv[e] = v;
+    __shared__ double As[PS_AI_K][PS_AI_T + 4];
+    __shared__ double Bs[PS_AI_K][PS_AI_T + 4];
+    // tile (ti >= tj) from the linear index
+    int ti = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+    while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
+    const int tj = blockIdx.x - ti * (ti + 1) / 2;
+    const int i0 = ti * PS_AI_T, j0 = tj * PS_AI_T;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k0 = i0; k0 < nc; k0 += PS_AI_K) {            // Lci[k][i] = 0 for k < i, and i >= i0 >= j
+#pragma unroll
+        for (int e = t; e < PS_AI_K * PS_AI_T; e += 256) {
+            const int kk = e >> 6, c = e & 63, k = k0 + kk;
+            const int ia = i0 + c, jb = j0 + c;
+            As[kk][c] = (k < nc && ia < nc && k >= ia) ? Lci[(size_t)k * nc + ia] : 0.0;
+            Bs[kk][c] = (k < nc && jb < nc && k >= jb) ? Lci[(size_t)k * nc + jb] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < PS_AI_K; ++kk) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { av[a] = As[kk][ty * 4 + a]; bv[a] = Bs[kk][tx * 4 + a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
+            if (i < nc && j < nc) {
+                const float v = (float)acc[a][b];          // (both triangles get the SAME rounded value: still symmetric)
+                if (ti != tj || i >= j) { Ainv[(size_t)i * nc + j] = v; Ainv[(size_t)j * nc + i] = v; }
+            }
+        }
 }
 
-// y = A_c^-1 t : one wave per row
+// y = A_c^-1 t : one wave per row.  The inverse is kept in fp32 -- it only preconditions (any symmetric positive
+// definite approximation keeps the CG exact), and this product is bound by reading it (19 -> 9.4 MB at nc = 1536).
 __global__ __launch_bounds__(256) void k_xcg_coarse(
-    int nc, const double* __restrict__ Ainv, const double* __restrict__ tvec,
-    double* __restrict__ y, const int32_t* __restrict__ status)
+    int nc, const float* __restrict__ Ainv, const double* __restrict__ tvec,
+    double* __restrict__ y, int32_t* __restrict__ status, const int32_t* __restrict__ lag_status)
 {
+    if (lag_status && blockIdx.x == 0 && threadIdx.x == 0 && lag_status[ST_DIAG_FAIL]) atomicAdd(&status[ST_DIAG_FAIL], 1);
     if (status[ST_PCG_DONE]) return;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= nc) return;
+    const float* a = Ainv + (size_t)row * nc;
     double v = 0.0;
-    for (int j = lane; j < nc; j += 64) v += Ainv[(size_t)row * nc + j] * tvec[j];
+    if ((nc & 1) == 0) {
+        for (int j = 2 * lane; j < nc; j += 128) {
+            const float2 f = *reinterpret_cast<const float2*>(a + j);
+            v += (double)f.x * tvec[j] + (double)f.y * tvec[j + 1];
+        }
+    } else {
+        for (int j = lane; j < nc; j += 64) v += (double)a[j] * tvec[j];
+    }
     v = wave_sum(v);
     if (lane == 0) y[row] = v;
 }
@@ -2013,28 +2064,35 @@ __global__ __launch_bounds__(256) void k_bchol_update(int nc, int j0, int w, dou
     }
 }
 
-// X = L^-1 (lower) and its transpose.  Columns of X are independent forward substitutions: one workgroup per
-// PS_BI_CW columns (nc / 4 workgroups: the whole chip, not 16-40 of its CUs), its column block of X in LDS
-// (nc x 4 doubles), walking the 24-row blocks below the diagonal with the diagonal tiles' inverses.
+// X = L^-1 (lower) and its transpose, in two parts.
+// (1) k_btri_inverse: the PS_BI_S0 x PS_BI_S0 diagonal blocks.  Columns of X are independent forward substitutions:
+//     one workgroup per PS_BI_CW columns (the whole chip), its column block of X in LDS, walking the 24-row blocks
+//     below the diagonal (down to the end of its diagonal block) with the diagonal tiles' inverses.
+// (2) k_btri_merge: the blocks below, level by level (s = S0, 2 S0, ...): [[X11, 0], [X21, X22]] with
+//     X21 = -X22 (L21 X11) -- two triangular matrix products per level, 64 x 64 tiles over the whole chip,
+//     instead of ever longer substitutions whose L traffic grows as nc^3 / 4 out of L2 (1.9 ms at nc = 1536).
+//     The intermediate L21 X11 lives in the (zero) strictly lower triangle of XT and is cleared by k_btri_clear.
 #define PS_BI_CW 4
+#define PS_BI_S0 192
 __global__ __launch_bounds__(256) void k_btri_inverse(
     int nc, const double* __restrict__ L, const double* __restrict__ Tinv_all /* one 24 x 24 tile per row block */,
     double* __restrict__ X, double* __restrict__ XT)
 {
-    extern __shared__ double sX[];                         // nc x PS_BI_CW, + one 24 x PS_BI_CW tile
+    extern __shared__ double sX[];                         // S0 x PS_BI_CW, + one 24 x PS_BI_CW tile
     const int j0 = blockIdx.x * PS_BI_CW, w = min(PS_BI_CW, nc - j0), t = threadIdx.x;
-    double* sT = sX + (size_t)nc * PS_BI_CW;
+    const int b0 = (j0 / PS_BI_S0) * PS_BI_S0, b1 = min(nc, b0 + PS_BI_S0);   // this column block's diagonal block
+    double* sT = sX + (size_t)PS_BI_S0 * PS_BI_CW;
     const int ib = (j0 / PS_BC_W) * PS_BC_W;               // first row block that can be non-zero
-    for (int e = t; e < ib * w; e += 256) sX[(size_t)(e / w) * PS_BI_CW + e % w] = 0.0;
+    for (int e = t; e < (ib - b0) * w; e += 256) sX[(size_t)(e / w) * PS_BI_CW + e % w] = 0.0;
     __syncthreads();
-    for (int i0 = ib; i0 < nc; i0 += PS_BC_W) {
-        const int wi = min(PS_BC_W, nc - i0);
+    for (int i0 = ib; i0 < b1; i0 += PS_BC_W) {
+        const int wi = min(PS_BC_W, b1 - i0);
         // t = delta - L[I][ib .. i0) X[ib .. i0)][cols]
         for (int e = t; e < wi * w; e += 256) {
             const int r = e / w, c = e % w, i = i0 + r;
             double v = (i == j0 + c) ? 1.0 : 0.0;
 #pragma unroll 4
-            for (int k = ib; k < i0; ++k) v -= L[(size_t)i * nc + k] * sX[(size_t)k * PS_BI_CW + c];
+            for (int k = ib; k < i0; ++k) v -= L[(size_t)i * nc + k] * sX[(size_t)(k - b0) * PS_BI_CW + c];
             sT[r * PS_BI_CW + c] = v;
         }
         __syncthreads();
@@ -2043,16 +2101,86 @@ __global__ __launch_bounds__(256) void k_btri_inverse(
             const int r = e / w, c = e % w;
             double v = 0.0;
             for (int k = 0; k <= r; ++k) v += Ti[r * PS_BC_W + k] * sT[k * PS_BI_CW + c];
-            sX[(size_t)(i0 + r) * PS_BI_CW + c] = v;
+            sX[(size_t)(i0 + r - b0) * PS_BI_CW + c] = v;
         }
         __syncthreads();
     }
-    for (int e = t; e < nc * w; e += 256) {
-        const int i = e / w, c = e % w, j = j0 + c;
-        const double v = (i >= j) ? sX[(size_t)i * PS_BI_CW + c] : 0.0;
+    for (int e = t; e < (b1 - b0) * w; e += 256) {         // (everything outside the diagonal blocks was zeroed by the host)
+        const int i = b0 + e / w, c = e % w, j = j0 + c;
+        const double v = (i >= j) ? sX[(size_t)(i - b0) * PS_BI_CW + c] : 0.0;
         X[(size_t)i * nc + j] = v;
         XT[(size_t)j * nc + i] = v;
     }
+}
+
+// one level of the merge.  stage 0: T = L21 X11 (into XT's lower triangle); stage 1: X21 = -X22 T (to X and XT).
+// Pair p of the level: rows r0 = (2p+1) s .. r0 + s, columns c0 = 2 p s .. c0 + s.  grid = pairs x tiles x tiles.
+#define PS_BM_T 64
+#define PS_BM_K 16
+__global__ __launch_bounds__(256) void k_btri_merge(
+    int nc, int s, int stage, const double* __restrict__ L, double* __restrict__ X, double* __restrict__ XT)
+{
+    __shared__ double As[PS_BM_K][PS_BM_T + 4];
+    __shared__ double Bs[PS_BM_K][PS_BM_T + 4];
+    const int nt = (s + PS_BM_T - 1) / PS_BM_T;
+    const int pair = blockIdx.x / (nt * nt), tile = blockIdx.x % (nt * nt);
+    const int r0 = (2 * pair + 1) * s, c0 = 2 * pair * s;
+    if (r0 >= nc) return;
+    const int M = min(s, nc - r0);
+    const int i0 = (tile / nt) * PS_BM_T, j0 = (tile % nt) * PS_BM_T;
+    if (i0 >= M) return;
+    // C[i][j] = sum_k A[i][k] B[k][j], i < M, j < s, k < (stage ? M : s)
+    //   stage 0: A = L[r0 + i][c0 + k], B = X[c0 + k][c0 + j] (zero for k < j)
+    //   stage 1: A = X[r0 + i][r0 + k] (zero for k > i), B = T[r0 + k][c0 + j]
+    const double* A = stage ? X + (size_t)r0 * nc + r0 : L + (size_t)r0 * nc + c0;
+    const double* B = stage ? XT + (size_t)r0 * nc + c0 : X + (size_t)c0 * nc + c0;
+    const int K = stage ? M : s;
+    const int kbeg = stage ? 0 : j0, kend = stage ? min(K, i0 + PS_BM_T) : K;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k0 = kbeg; k0 < kend; k0 += PS_BM_K) {
+#pragma unroll
+        for (int e = t; e < PS_BM_K * PS_BM_T; e += 256) {
+            const int ai = e >> 4, ak = e & 15;            // A: 16 consecutive k of one row
+            As[ak][ai] = (i0 + ai < M && k0 + ak < kend) ? A[(size_t)(i0 + ai) * nc + k0 + ak] : 0.0;
+            const int bk = e >> 6, bj = e & 63;            // B: 64 consecutive j of one k
+            Bs[bk][bj] = (k0 + bk < kend && j0 + bj < s) ? B[(size_t)(k0 + bk) * nc + j0 + bj] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < PS_BM_K; ++kk) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { av[a] = As[kk][ty * 4 + a]; bv[a] = Bs[kk][tx * 4 + a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
+            if (i >= M || j >= s) continue;
+            if (stage == 0) XT[(size_t)(r0 + i) * nc + c0 + j] = acc[a][b];
+            else { X[(size_t)(r0 + i) * nc + c0 + j] = -acc[a][b]; XT[(size_t)(c0 + j) * nc + r0 + i] = -acc[a][b]; }
+        }
+}
+
+// XT's strictly lower triangle back to zero (it carried the merge intermediates)
+__global__ __launch_bounds__(256) void k_btri_clear(int nc, double* __restrict__ XT)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)nc * nc) return;
+    const int i = (int)(e / nc), j = (int)(e % nc);
+    if (j < i && i / PS_BI_S0 != j / PS_BI_S0) XT[e] = 0.0;
 }
 
 struct CoarseRhsArgs {
@@ -2076,44 +2204,6 @@ PS_DEV void coarse_rhs_body(
     double* __restrict__ p, double* __restrict__ x,
     int with_coarse_rows, const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, double* stv,
     const double* __restrict__ bg);
-
-// the same for coarse levels whose column block does not fit LDS (nc > 768): the column block of X is kept in
-// X itself (global, L2-resident) -- a workgroup only ever re-reads what it wrote itself
-__global__ __launch_bounds__(256) void k_btri_inverse_big(
-    int nc, const double* __restrict__ L, const double* __restrict__ Tinv_all,
-    double* __restrict__ X, double* __restrict__ XT)
-{
-    __shared__ double sT[PS_BC_W * PS_BC_W];
-    const int J = blockIdx.x, j0 = J * PS_BC_W, w = min(PS_BC_W, nc - j0), t = threadIdx.x;
-    for (int e = t; e < j0 * w; e += 256) {                 // the strictly upper part of the column block is zero
-        const int i = e / w, c = e % w;
-        X[(size_t)i * nc + j0 + c] = 0.0;
-        XT[(size_t)(j0 + c) * nc + i] = 0.0;
-    }
-    for (int i0 = j0; i0 < nc; i0 += PS_BC_W) {
-        const int wi = min(PS_BC_W, nc - i0);
-        for (int e = t; e < wi * w; e += 256) {
-            const int r = e / w, c = e % w, i = i0 + r;
-            double v = (i == j0 + c) ? 1.0 : 0.0;
-#pragma unroll 4
-            for (int k = j0; k < i0; ++k) v -= L[(size_t)i * nc + k] * X[(size_t)k * nc + j0 + c];
-            sT[r * PS_BC_W + c] = v;
-        }
-        __syncthreads();
-        const double* Ti = Tinv_all + (size_t)(i0 / PS_BC_W) * PS_BC_W * PS_BC_W;
-        for (int e = t; e < wi * w; e += 256) {
-            const int r = e / w, c = e % w;
-            double v = 0.0;
-            for (int k = 0; k <= r; ++k) v += Ti[r * PS_BC_W + k] * sT[k * PS_BC_W + c];
-            const int i = i0 + r, j = j0 + c;
-            v = (i >= j) ? v : 0.0;
-            X[(size_t)i * nc + j] = v;
-            XT[(size_t)j * nc + i] = v;
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-}
 
 // K_i = SZ_i Lci^T, written to both borders of the augmented BSR matrix.
 // One workgroup per fine block row i; thread per (r, c) of the D x nc strip.
