@@ -448,7 +448,7 @@ int build_coarse(ps_problem* h) {
         h->upload(&h->aug_slot, slot) || h->upload(&h->fine_nnz, fnz)) return -1;
     if (h->alloc(&h->BSZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Bmat, (size_t)nr * D * D) ||
         h->alloc(&h->bgv, (size_t)nr * D) || h->alloc(&h->SB, (size_t)aci.size() * D * D)) return -1;
-    if (h->alloc(&h->SZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
+    if ((!h->cg_explicit && h->alloc(&h->SZ, (size_t)nr * ncb * D * D)) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci2[0], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[0], (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci2[1], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[1], (size_t)h->nc * h->nc) ||
         h->alloc(&h->tvec, (size_t)h->nc) || h->alloc(&h->chol_scratch, 2 * (size_t)h->nc * h->nc)) return -1;
@@ -556,9 +556,9 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             h->side_pending = false;
         }
         hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(ncb + 1) * D * D * sizeof(double), h->stream,
-                           nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat, h->BSZ);
+                           nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat, h->BSZ, 0);
         hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
-                           nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
+                           nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac, (const int32_t*)nullptr, (const int32_t*)nullptr);
         // Exact: factor this iteration's A_c on the solver stream (51 us at C3, serial).  Lagged
         // ("coarse_lag", whole-iteration calls only): build the augmented system with the factor of the
         // PREVIOUS iteration's A_c -- any nonsingular L~ gives a consistent system V^T S^ V with
@@ -834,9 +834,9 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
                        h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
     if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
     hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(ncb + 1) * D * D * sizeof(double), h->stream,
-                       nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat, h->BSZ);
+                       nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, (double*)nullptr, h->Bmat, h->BSZ, 1);
     hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
-                       nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
+                       nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac, h->run_lo, h->run_hi);
     // A_c^-1 lives in LciT2[b] (the transposed factor is not used on this path).  It only PRECONDITIONS here, so any
     // symmetric positive definite stand-in keeps the CG exact: whole-iteration calls use the inverse formed from the
     // PREVIOUS iteration's A_c and factor the current one on the side stream while the CG iterates (the factorisation,

@@ -1776,7 +1776,8 @@ __global__ __launch_bounds__(256) void k_coarse_rowsums(
     const int32_t* __restrict__ acol_idx, const int32_t* __restrict__ pnode,
     const double* __restrict__ pw0, const double* __restrict__ pw1,
     const double* __restrict__ SB /* S^_ij B_j per fine block (augmented-matrix slots) */,
-    double* __restrict__ SZ, const double* __restrict__ Bmat, double* __restrict__ BSZ /* B_i^T SZ[i][q] */)
+    double* __restrict__ SZ /* NULL: not needed (explicit PCG) */, const double* __restrict__ Bmat,
+    double* __restrict__ BSZ /* B_i^T SZ[i][q] */, int sparse /* skip the blocks of empty runs (k_coarse_matrix does too) */)
 {
     constexpr int DD = D * D;
     extern __shared__ double srow[];                     // ncb x DD: this row's SZ blocks, + DD: B_i
@@ -1790,12 +1791,13 @@ __global__ __launch_bounds__(256) void k_coarse_rowsums(
 #pragma unroll 4
         for (int k = k0; k < k1; ++k)
             acc += SB[(size_t)k * DD + e] * coarse_weight(acol_idx[k], q, pnode, pw0, pw1);
-        SZ[(size_t)i * nslot + t] = acc;
+        if (SZ) SZ[(size_t)i * nslot + t] = acc;
         srow[t] = acc;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < nslot; t += blockDim.x) {
         const int q = t / DD, e = t % DD, r = e / D, c = e % D;
+        if (sparse && run_lo[i * ncb + q] >= run_hi[i * ncb + q]) continue;
         double acc = 0.0;
 #pragma unroll
         for (int m = 0; m < D; ++m) acc += sBi[m * D + r] * srow[q * DD + m * D + c];
@@ -1808,7 +1810,9 @@ template <int D>
 __global__ __launch_bounds__(256) void k_coarse_matrix(
     int nr, int ncb, const int32_t* __restrict__ slo, const int32_t* __restrict__ shi,
     const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
-    const double* __restrict__ SZ, double* __restrict__ Ac)
+    const double* __restrict__ SZ, double* __restrict__ Ac,
+    const int32_t* __restrict__ run_lo /* non-NULL: sparse rows, skip the (unwritten) blocks of empty runs */,
+    const int32_t* __restrict__ run_hi)
 {
     constexpr int DD = D * D;
     const int nc = ncb * D;
@@ -1816,6 +1820,11 @@ __global__ __launch_bounds__(256) void k_coarse_matrix(
     if (t >= ncb * ncb * DD) return;
     const int e = t % DD, q2 = (t / DD) % ncb, q = t / (DD * ncb);
     double acc = 0.0;
+    if (run_lo) {
+        for (int i = slo[q]; i < shi[q]; ++i)
+            if (run_lo[i * ncb + q2] < run_hi[i * ncb + q2])
+                acc += coarse_weight(i, q, pnode, pw0, pw1) * SZ[((size_t)i * ncb + q2) * DD + e];
+    } else
 #pragma unroll 8
     for (int i = slo[q]; i < shi[q]; ++i)
         acc += coarse_weight(i, q, pnode, pw0, pw1) * SZ[((size_t)i * ncb + q2) * DD + e];
