@@ -357,13 +357,16 @@ int build_coarse(ps_problem* h) {
         else if (nr > h->cg_split_min_rows) G = 48;                                    // measured: C4 (BA, 2 000 poses) and C2 (10 000-pose chain)
         else G = std::min(12, std::max(3, (nr + 9) / 18));
     }
-    // long sparse chains (pose graphs with thousands of poses): the two-level preconditioner is APPLIED
-    // explicitly (restrict, dense coarse solve, prolong: cg_explicit) instead of folded into the matrix --
-    // the folded form drags a dense border of ncb blocks through every row (C2: 49 of 60 blocks per row).
-    // Without a border the coarse level can be much finer: ~one interval per 64 poses, up to 255.
-    h->cg_explicit = h->explicit_ok && G != 0 && nr > h->cg_split_min_rows && (long)h->nnzb <= 24L * nr;
-    // (the factorisation of A_c runs beside the CG on the side stream from the second iteration on, so a large coarse level is cheap)
-    if (h->cg_explicit && h->coarse_req < 0) G = std::min(255, std::max(48, nr / 40));      // C2: 250 intervals
+    // large reduced systems (more than cg_split_min_rows poses): the two-level preconditioner is APPLIED explicitly
+    // (restrict, dense coarse solve, prolong: cg_explicit) instead of folded into the matrix -- the folded form drags
+    // a dense border of ncb blocks through every row (C2: 49 of 60 blocks per row).  Without a border the coarse
+    // level can be much finer, and its factorisation runs beside the CG on the side stream from the second
+    // iteration on.  Pose-graph-like rows (C2: 11 blocks per row, hundreds of CG iterations): one interval per 40
+    // poses, up to 255; bundle-adjustment rows (C4: 80 blocks per row, ~20 iterations -- the factorisation must fit
+    // beside a short CG): one per 20 poses, up to 112 (C4: 42 iterations / 3.7 ms folded at 48 -> 20 / 2.6 ms at 100).
+    h->cg_explicit = h->explicit_ok && G != 0 && nr > h->cg_split_min_rows;
+    if (h->cg_explicit && h->coarse_req < 0)
+        G = (long)h->nnzb <= 24L * nr ? std::min(255, std::max(48, nr / 40)) : std::min(112, std::max(48, nr / 20));
     G = std::min(G, h->cg_explicit ? 255 : Gmax);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
     if (G < 1) G = 0;

@@ -63,12 +63,14 @@ def test_c3_gn_iteration_matches_staged_calls_bitwise(c3):
 
 def test_c3_all_solver_variants_agree(c3):
     ref = None
-    for variant, groups, split in ((1, -1, False), (1, 0, False), (0, 0, False), (1, 24, True)):
+    # (large-system modes forced onto C3: folded two-level CG in split mode, and the explicitly applied preconditioner)
+    for variant, groups, split in ((1, -1, None), (1, 0, None), (0, 0, None), (1, 24, 'folded'), (1, 24, 'explicit')):
         dev = device(c3)
         dev.set_option('pcg_variant', variant)
         dev.set_option('coarse_groups', groups)
         if split:
             dev.set_option('cg_split_min_rows', 0)
+            dev.set_option('cg_explicit', float(split == 'explicit'))
         dev.linearize(0.)
         its, rel = dev.solve_reduced(1e-13, 3000)
         dev.backsub()

@@ -10,10 +10,11 @@ t = time.time(); dev = DeviceProblem(lp); print('create %.1fs' % (time.time() - 
 for G in ([int(a) for a in sys.argv[3:]] or [-1]):
     dev.set_option('coarse_groups', G)
     dev.set_option('coarse_lag', float(os.environ.get('C4_LAG', '1')))
+    dev.set_option('cg_explicit', float(os.environ.get('C4_EXPLICIT', '1')))      # 0: folded split mode
     dev.set_params(lp.poses, lp.points)
     dev.snapshot()
     c0 = dev.eval_cost(True)
-    for it in range(3):
+    for it in range(4):
         dev.restore(); dev.set_profiling(2); dev.stage_times(reset=True)
         t = time.time(); out = dev.gn_iteration(0., 1e-12, 3000, True); dt = time.time() - t
         st = {k: round(v[0], 3) for k, v in dev.stage_times(reset=True).items() if v[1]}
