@@ -142,6 +142,7 @@ struct ps_problem {
     // split mode (large systems): coarse rows are owned by k_cg_reduce_split
     bool cg_split = false;
     int cg_split_min_rows = 1024;
+    int cg_explicit_min_rows = -1;  // explicit two-level PCG beyond this many reduced poses (-1: 400 for pose-graph rows, 540 for BA rows)
     double *cg_U = nullptr, *cg_cgd[2] = {}, *cg_ab = nullptr;
     int cg_launched = 0;            // CG launches enqueued since the last setup
     bool cov_ready = false;         // ps_covariance_begin has linearised and set the reduced solver up; cleared by linearize()
@@ -357,16 +358,20 @@ int build_coarse(ps_problem* h) {
         else if (nr > h->cg_split_min_rows) G = 48;                                    // measured: C4 (BA, 2 000 poses) and C2 (10 000-pose chain)
         else G = std::min(12, std::max(3, (nr + 9) / 18));
     }
-    // large reduced systems (more than cg_split_min_rows poses): the two-level preconditioner is APPLIED explicitly
+    // large reduced systems (more than cg_explicit_min_rows poses): the two-level preconditioner is APPLIED explicitly
     // (restrict, dense coarse solve, prolong: cg_explicit) instead of folded into the matrix -- the folded form drags
     // a dense border of ncb blocks through every row (C2: 49 of 60 blocks per row).  Without a border the coarse
     // level can be much finer, and its factorisation runs beside the CG on the side stream from the second
     // iteration on.  Pose-graph-like rows (C2: 11 blocks per row, hundreds of CG iterations): one interval per 40
     // poses, up to 255; bundle-adjustment rows (C4: 80 blocks per row, ~20 iterations -- the factorisation must fit
     // beside a short CG): one per 20 poses, up to 112 (C4: 42 iterations / 3.7 ms folded at 48 -> 20 / 2.6 ms at 100).
-    h->cg_explicit = h->explicit_ok && G != 0 && nr > h->cg_split_min_rows;
+    // Measured crossover against the folded single-launch CG (whose coarse level is capped at 12 intervals):
+    // pose graphs 400 poses (600: 2.6 -> 1.4 ms, 1 000: 6.1 -> 1.5 ms), bundle adjustment 540 (700: 1.67 -> 1.28 ms).
+    const bool sparse_rows = (long)h->nnzb <= 24L * nr;
+    const int xmin = std::min(h->cg_split_min_rows, h->cg_explicit_min_rows >= 0 ? h->cg_explicit_min_rows : (sparse_rows ? 400 : 540));
+    h->cg_explicit = h->explicit_ok && G != 0 && nr > xmin;
     if (h->cg_explicit && h->coarse_req < 0)
-        G = (long)h->nnzb <= 24L * nr ? std::min(255, std::max(48, nr / 40)) : std::min(112, std::max(48, nr / 20));
+        G = sparse_rows ? std::min(255, std::max(48, nr / 40)) : std::min(112, std::max(48, nr / 20));
     G = std::min(G, h->cg_explicit ? 255 : Gmax);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
     if (G < 1) G = 0;
@@ -1917,6 +1922,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "coarse_basis") { h->coarse_basis = value != 0.0; h->lci_next = -1; }
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
+    else if (n == "cg_explicit_min_rows") { h->cg_explicit_min_rows = (int)value; h->coarse_built = false; }
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }
     else return fail("unknown option: " + n);
     return 0;

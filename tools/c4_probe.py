@@ -10,6 +10,7 @@ t = time.time(); dev = DeviceProblem(lp); print('create %.1fs' % (time.time() - 
 for G in ([int(a) for a in sys.argv[3:]] or [-1]):
     dev.set_option('coarse_groups', G)
     dev.set_option('coarse_lag', float(os.environ.get('C4_LAG', '1')))
+    if 'C4_SPLIT_MIN' in os.environ: dev.set_option('cg_split_min_rows', float(os.environ['C4_SPLIT_MIN']))
     dev.set_option('cg_explicit', float(os.environ.get('C4_EXPLICIT', '1')))      # 0: folded split mode
     dev.set_params(lp.poses, lp.points)
     dev.snapshot()
