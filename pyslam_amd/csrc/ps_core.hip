@@ -987,12 +987,29 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         return cg_report(h, iters_out, relres_out);
     }
     if (!h->coarse_built && build_coarse(h)) return -1;
-    if (h->cg_explicit) {                                   // long sparse chains: synchronous explicit PCG, then the tail
-        if (xcg_run<D>(h, tol, max_iters, iters_out, relres_out, true)) return -1;
-        tp.stop();
-        if (gn_tail(h, linesearch, nullptr, true)) return -1;
-        if (total) total->stop();
-        return wait_published(h);
+    if (h->cg_explicit) {                                   // explicit two-level PCG, same one-synchronisation protocol
+        if (xcg_setup<D>(h, max_iters, true)) return -1;
+        int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + 2 : 32;
+        for (;;) {
+            count = std::min(count, max_iters + 1 - h->cg_launched);
+            xcg_launch<D>(h, tol, count);
+            if (xcg_side_enqueue<D>(h)) return -1;
+            hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)h->nr * D, 256)), dim3(256), 0, h->stream, h->nr, h->Linv,
+                               h->cg_xh, h->x, (const int32_t*)h->status);
+            tp.stop();
+            if (gn_tail(h, linesearch, h->status, true)) return -1;
+            if (total) total->stop();
+            if (wait_published(h)) return -1;
+            if (h->h_status[ST_PCG_DONE] != 0) break;
+            if (h->cg_launched >= max_iters + 1) {          // not converged within max_iters: take the step anyway
+                hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)h->nr * D, 256)), dim3(256), 0, h->stream, h->nr, h->Linv,
+                                   h->cg_xh, h->x, (const int32_t*)nullptr);
+                if (gn_tail(h, linesearch, nullptr, true) || wait_published(h)) return -1;
+                break;
+            }
+            count = std::max(8, h->cg_launched / 2);
+        }
+        return cg_report(h, iters_out, relres_out);
     }
     if (cg_fused_setup<D>(h, max_iters, true)) return -1;
     int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + h->cg_margin : 16;
