@@ -108,6 +108,9 @@ struct ps_problem {
     // coarse basis P_iq = w(i,q) B_i: B_i = L_i^T Ad(T_i) (coarse_basis 1, rigid-motion aware) or I (0)
     int coarse_basis = 1;
     double *Bmat = nullptr, *bgv = nullptr, *SB = nullptr, *BSZ = nullptr;
+    int32_t *ent_ptr = nullptr, *ent_q = nullptr, *ent_lo = nullptr, *ent_hi = nullptr;   // explicit PCG: non-empty (row, node) runs
+    int32_t *seg_ptr = nullptr, *seg_ent = nullptr, *seg_row = nullptr;                     // ... grouped by (node, node') for A_c
+    int max_row_ents = 0;
     int32_t* pose_of_rid = nullptr;
     // coarse factor L_c^-1 (and transpose), double-buffered: with "coarse_lag" the factorisation of THIS
     // iteration's A_c runs on a side stream while the CG iterates with the previous iteration's factor
@@ -347,6 +350,14 @@ int ensure_cg_buffers(ps_problem* h, int rows, int blocks) {
 // Coarse nodes (hat functions over the reduced-pose index) + the augmented BSR pattern
 // [[S^, K], [K^T, I]].  coarse_req = number of intervals G (ncb = G + 1 nodes).
 int build_coarse(ps_problem* h) {
+    const bool timing = getenv("PS_CREATE_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "build_coarse: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const int nr = h->nr, D = h->D;
     int G = h->coarse_req;
     const int Gmax = 63;                           // nc = (G + 1) D <= 384; LDS-resident factorisation up to nc = 96
@@ -440,27 +451,64 @@ int build_coarse(ps_problem* h) {
         if (h->alloc(&h->cg_U, (size_t)ncb * nr * D) || h->alloc(&h->cg_cgd[0], 2 * (size_t)ncb) ||
             h->alloc(&h->cg_cgd[1], 2 * (size_t)ncb) || h->alloc(&h->cg_ab, 2)) return -1;
     }
+    lap("nodes + augmented pattern");
     // contiguous run of augmented-matrix blocks of fine row i whose column lies in supp(q)
-    std::vector<int32_t> rlo((size_t)nr * ncb), rhi((size_t)nr * ncb);
-    for (int i = 0; i < nr; ++i)
+    // (slo / shi increase with q and the row's columns are sorted: two pointers sweep each row once)
+    std::vector<int32_t> rlo, rhi, eptr, eq, elo, ehi;
+    if (h->cg_explicit) eptr.assign(nr + 1, 0); else { rlo.resize((size_t)nr * ncb); rhi.resize((size_t)nr * ncb); }
+    h->max_row_ents = 0;
+    for (int i = 0; i < nr; ++i) {
+        int lo = rp[i], hi = rp[i];
+        const int end = rp[i + 1];
         for (int q = 0; q < ncb; ++q) {
-            const int32_t* lo = std::lower_bound(ci.data() + rp[i], ci.data() + rp[i + 1], slo[q]);
-            const int32_t* hi = std::lower_bound(ci.data() + rp[i], ci.data() + rp[i + 1], shi[q]);
-            rlo[(size_t)i * ncb + q] = arp[i] + (int32_t)(lo - (ci.data() + rp[i]));
-            rhi[(size_t)i * ncb + q] = arp[i] + (int32_t)(hi - (ci.data() + rp[i]));
+            while (lo < end && ci[lo] < slo[q]) ++lo;
+            while (hi < end && ci[hi] < shi[q]) ++hi;
+            if (!h->cg_explicit) {
+                rlo[(size_t)i * ncb + q] = arp[i] + (lo - rp[i]);
+                rhi[(size_t)i * ncb + q] = arp[i] + (hi - rp[i]);
+            } else if (lo < hi) {                          // explicit PCG: only the non-empty runs, listed per row
+                eq.push_back(q); elo.push_back(arp[i] + (lo - rp[i])); ehi.push_back(arp[i] + (hi - rp[i]));
+            }
         }
+        if (h->cg_explicit) {
+            eptr[i + 1] = (int32_t)eq.size();
+            h->max_row_ents = std::max(h->max_row_ents, eptr[i + 1] - eptr[i]);
+        }
+    }
+    if (h->cg_explicit) {
+        // segments: for every node pair (q, q') the entries (i in supp(q), node q') in row order
+        std::vector<int32_t> sptr((size_t)ncb * ncb + 1, 0), sent, srow;
+        for (int q = 0; q < ncb; ++q)
+            for (int i = slo[q]; i < shi[q]; ++i)
+                for (int e = eptr[i]; e < eptr[i + 1]; ++e) sptr[(size_t)q * ncb + eq[e] + 1]++;
+        for (size_t k = 0; k < (size_t)ncb * ncb; ++k) sptr[k + 1] += sptr[k];
+        sent.resize(sptr.back()); srow.resize(sptr.back());
+        std::vector<int32_t> pos(sptr.begin(), sptr.end() - 1);
+        for (int q = 0; q < ncb; ++q)
+            for (int i = slo[q]; i < shi[q]; ++i)
+                for (int e = eptr[i]; e < eptr[i + 1]; ++e) {
+                    const int32_t at = pos[(size_t)q * ncb + eq[e]]++;
+                    sent[at] = e; srow[at] = i;
+                }
+        if (h->upload(&h->ent_ptr, eptr) || h->upload(&h->ent_q, eq) || h->upload(&h->ent_lo, elo) ||
+            h->upload(&h->ent_hi, ehi) || h->upload(&h->seg_ptr, sptr) || h->upload(&h->seg_ent, sent) ||
+            h->upload(&h->seg_row, srow)) return -1;
+    }
+    lap("runs");
     h->ncb = ncb; h->nc = ncb * D; h->nr_aug = nr + ncb; h->nnzb_aug = (int)aci.size();
     if (h->upload(&h->pnode, pnode) || h->upload(&h->slo, slo) || h->upload(&h->shi, shi) ||
-        h->upload(&h->pw0, pw0) || h->upload(&h->pw1, pw1) || h->upload(&h->run_lo, rlo) ||
-        h->upload(&h->run_hi, rhi) || h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) ||
+        h->upload(&h->pw0, pw0) || h->upload(&h->pw1, pw1) || (!h->cg_explicit && (h->upload(&h->run_lo, rlo) ||
+        h->upload(&h->run_hi, rhi))) || h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) ||
         h->upload(&h->aug_slot, slot) || h->upload(&h->fine_nnz, fnz)) return -1;
-    if (h->alloc(&h->BSZ, (size_t)nr * ncb * D * D) || h->alloc(&h->Bmat, (size_t)nr * D * D) ||
+    lap("uploads");
+    if (h->alloc(&h->BSZ, (h->cg_explicit ? eq.size() : (size_t)nr * ncb) * D * D) || h->alloc(&h->Bmat, (size_t)nr * D * D) ||
         h->alloc(&h->bgv, (size_t)nr * D) || h->alloc(&h->SB, (size_t)aci.size() * D * D)) return -1;
     if ((!h->cg_explicit && h->alloc(&h->SZ, (size_t)nr * ncb * D * D)) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci2[0], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[0], (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci2[1], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[1], (size_t)h->nc * h->nc) ||
         h->alloc(&h->tvec, (size_t)h->nc) || h->alloc(&h->chol_scratch, 2 * (size_t)h->nc * h->nc)) return -1;
     if (h->cg_explicit && (h->alloc(&h->xstate, 8) || h->alloc(&h->xy, (size_t)h->nc) || h->alloc(&h->xp2, (size_t)nr * D))) return -1;
+    lap("allocations");
     if (!h->lag_status) {
         if (h->alloc(&h->lag_status, ST_NWORDS)) return -1;
         HIP_OK(hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
@@ -564,9 +612,9 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             h->side_pending = false;
         }
         hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(ncb + 1) * D * D * sizeof(double), h->stream,
-                           nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat, h->BSZ, 0);
+                           nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat, h->BSZ);
         hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
-                           nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac, (const int32_t*)nullptr, (const int32_t*)nullptr);
+                           nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
         // Exact: factor this iteration's A_c on the solver stream (51 us at C3, serial).  Lagged
         // ("coarse_lag", whole-iteration calls only): build the augmented system with the factor of the
         // PREVIOUS iteration's A_c -- any nonsingular L~ gives a consistent system V^T S^ V with
@@ -841,10 +889,10 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
                        h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
     if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
-    hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(ncb + 1) * D * D * sizeof(double), h->stream,
-                       nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, (double*)nullptr, h->Bmat, h->BSZ, 1);
-    hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
-                       nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac, h->run_lo, h->run_hi);
+    hipLaunchKernelGGL(k_xcoarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(h->max_row_ents + 1) * D * D * sizeof(double), h->stream,
+                       nr, h->ent_ptr, h->ent_q, h->ent_lo, h->ent_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->Bmat, h->BSZ);
+    hipLaunchKernelGGL(k_xcoarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
+                       ncb, h->seg_ptr, h->seg_ent, h->seg_row, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
     // A_c^-1 lives in LciT2[b] (the transposed factor is not used on this path).  It only PRECONDITIONS here, so any
     // symmetric positive definite stand-in keeps the CG exact: whole-iteration calls use the inverse formed from the
     // PREVIOUS iteration's A_c and factor the current one on the side stream while the CG iterates (the factorisation,

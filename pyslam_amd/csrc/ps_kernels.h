@@ -1776,8 +1776,7 @@ __global__ __launch_bounds__(256) void k_coarse_rowsums(
     const int32_t* __restrict__ acol_idx, const int32_t* __restrict__ pnode,
     const double* __restrict__ pw0, const double* __restrict__ pw1,
     const double* __restrict__ SB /* S^_ij B_j per fine block (augmented-matrix slots) */,
-    double* __restrict__ SZ /* NULL: not needed (explicit PCG) */, const double* __restrict__ Bmat,
-    double* __restrict__ BSZ /* B_i^T SZ[i][q] */, int sparse /* skip the blocks of empty runs (k_coarse_matrix does too) */)
+    double* __restrict__ SZ, const double* __restrict__ Bmat, double* __restrict__ BSZ /* B_i^T SZ[i][q] */)
 {
     constexpr int DD = D * D;
     extern __shared__ double srow[];                     // ncb x DD: this row's SZ blocks, + DD: B_i
@@ -1791,13 +1790,12 @@ __global__ __launch_bounds__(256) void k_coarse_rowsums(
 #pragma unroll 4
         for (int k = k0; k < k1; ++k)
             acc += SB[(size_t)k * DD + e] * coarse_weight(acol_idx[k], q, pnode, pw0, pw1);
-        if (SZ) SZ[(size_t)i * nslot + t] = acc;
+        SZ[(size_t)i * nslot + t] = acc;
         srow[t] = acc;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < nslot; t += blockDim.x) {
         const int q = t / DD, e = t % DD, r = e / D, c = e % D;
-        if (sparse && run_lo[i * ncb + q] >= run_hi[i * ncb + q]) continue;
         double acc = 0.0;
 #pragma unroll
         for (int m = 0; m < D; ++m) acc += sBi[m * D + r] * srow[q * DD + m * D + c];
@@ -1810,9 +1808,7 @@ template <int D>
 __global__ __launch_bounds__(256) void k_coarse_matrix(
     int nr, int ncb, const int32_t* __restrict__ slo, const int32_t* __restrict__ shi,
     const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
-    const double* __restrict__ SZ, double* __restrict__ Ac,
-    const int32_t* __restrict__ run_lo /* non-NULL: sparse rows, skip the (unwritten) blocks of empty runs */,
-    const int32_t* __restrict__ run_hi)
+    const double* __restrict__ SZ, double* __restrict__ Ac)
 {
     constexpr int DD = D * D;
     const int nc = ncb * D;
@@ -1820,14 +1816,63 @@ __global__ __launch_bounds__(256) void k_coarse_matrix(
     if (t >= ncb * ncb * DD) return;
     const int e = t % DD, q2 = (t / DD) % ncb, q = t / (DD * ncb);
     double acc = 0.0;
-    if (run_lo) {
-        for (int i = slo[q]; i < shi[q]; ++i)
-            if (run_lo[i * ncb + q2] < run_hi[i * ncb + q2])
-                acc += coarse_weight(i, q, pnode, pw0, pw1) * SZ[((size_t)i * ncb + q2) * DD + e];
-    } else
 #pragma unroll 8
     for (int i = slo[q]; i < shi[q]; ++i)
         acc += coarse_weight(i, q, pnode, pw0, pw1) * SZ[((size_t)i * ncb + q2) * DD + e];
+    Ac[(size_t)(q * D + e / D) * nc + q2 * D + e % D] = acc;
+}
+
+// The same two steps for the explicit PCG (hundreds of coarse nodes, a row touches a handful of them): only the
+// non-empty (row, node) runs exist, as ENTRIES listed per row (ent_ptr / ent_q / ent_lo / ent_hi) -- a dense
+// nr x ncb array of 6 x 6 blocks is 723 MB at C2 and clearing that allocation alone costs 30 ms.
+//   k_xcoarse_rowsums : BSZ[e] = B_i^T sum_{k in run(e)} S^_ik B_k w(k, q_e)      one workgroup per fine row
+//   k_xcoarse_matrix  : A_c[q][q'] = sum over the SEGMENT (q, q') of w(i, q) BSZ[e]  one thread per output entry;
+//                       a segment lists the entries (i in supp(q), q_e = q') in row order (host-built, fixed order)
+template <int D>
+__global__ __launch_bounds__(256) void k_xcoarse_rowsums(
+    int nr, const int32_t* __restrict__ ent_ptr, const int32_t* __restrict__ ent_q,
+    const int32_t* __restrict__ ent_lo, const int32_t* __restrict__ ent_hi,
+    const int32_t* __restrict__ acol_idx, const int32_t* __restrict__ pnode,
+    const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ SB, const double* __restrict__ Bmat, double* __restrict__ BSZ)
+{
+    constexpr int DD = D * D;
+    extern __shared__ double srow[];                     // (entries of this row) x DD, + DD: B_i
+    const int i = blockIdx.x, e0 = ent_ptr[i], n = (ent_ptr[i + 1] - e0) * DD;
+    double* sBi = srow + n;
+    if (threadIdx.x < DD) sBi[threadIdx.x] = Bmat[(size_t)i * DD + threadIdx.x];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int e = e0 + t / DD, el = t % DD, q = ent_q[e];
+        double acc = 0.0;
+#pragma unroll 4
+        for (int k = ent_lo[e]; k < ent_hi[e]; ++k)
+            acc += SB[(size_t)k * DD + el] * coarse_weight(acol_idx[k], q, pnode, pw0, pw1);
+        srow[t] = acc;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int el = t % DD, r = el / D, c = el % D, base = t - el;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) acc += sBi[m * D + r] * srow[base + m * D + c];
+        BSZ[(size_t)e0 * DD + t] = acc;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_xcoarse_matrix(
+    int ncb, const int32_t* __restrict__ seg_ptr /* ncb * ncb + 1 */, const int32_t* __restrict__ seg_ent,
+    const int32_t* __restrict__ seg_row, const int32_t* __restrict__ pnode, const double* __restrict__ pw0,
+    const double* __restrict__ pw1, const double* __restrict__ BSZ, double* __restrict__ Ac)
+{
+    constexpr int DD = D * D;
+    const int nc = ncb * D;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncb * ncb * DD) return;
+    const int e = t % DD, q2 = (t / DD) % ncb, q = t / (DD * ncb);
+    double acc = 0.0;
+    for (int s = seg_ptr[q * ncb + q2]; s < seg_ptr[q * ncb + q2 + 1]; ++s)
+        acc += coarse_weight(seg_row[s], q, pnode, pw0, pw1) * BSZ[(size_t)seg_ent[s] * DD + e];
     Ac[(size_t)(q * D + e / D) * nc + q2 * D + e % D] = acc;
 }
 
