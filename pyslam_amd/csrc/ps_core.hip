@@ -1040,8 +1040,12 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + 2 : 32;
         for (;;) {
             count = std::min(count, max_iters + 1 - h->cg_launched);
-            xcg_launch<D>(h, tol, count);
+            // (the side-stream factorisation goes in after the first few iterations' launches: early enough to
+            // finish beside the CG, late enough not to delay its start on the host)
+            const int head = std::min(count, 12);
+            xcg_launch<D>(h, tol, head);
             if (xcg_side_enqueue<D>(h)) return -1;
+            xcg_launch<D>(h, tol, count - head);
             hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)h->nr * D, 256)), dim3(256), 0, h->stream, h->nr, h->Linv,
                                h->cg_xh, h->x, (const int32_t*)h->status);
             tp.stop();
