@@ -368,7 +368,58 @@ def case_ransac():
     print('  ransac: best hypothesis has {} / {} inliers ({} true outliers)'.format(len(inl), N, bad.size))
 
 
+def case_metrics():
+    """TrajectoryMetrics (reference metrics.py:7-300): every metric on a seeded 80-pose SE(3) trajectory, in both
+    conventions, plus the .mat file the reference's savemat writes (a data fixture for loadmat)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_metrics', os.path.join(REF, 'pyslam', 'metrics.py'))
+    ref_metrics = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_metrics)
+    rng = np.random.default_rng(21)
+    n = 80
+    gt, est = [liegroups.SE3.identity()], [liegroups.SE3.identity()]
+    for k in range(1, n):
+        step = np.array([0.5, 0., 0., 0., 0., 0.05]) + 0.01 * rng.standard_normal(6)
+        gt.append(liegroups.SE3.exp(step).dot(gt[-1]))
+        est.append(liegroups.SE3.exp(step + 0.004 * rng.standard_normal(6)).dot(est[-1]))
+    # the trajectories above are world-to-vehicle chains (T_k0): hand them over as 'Tvw'; and their inverses as 'Twv'
+    out = {'gt_Tvw': np.array([T.as_matrix() for T in gt]), 'est_Tvw': np.array([T.as_matrix() for T in est])}
+    lengths = [2., 5., 10.]
+    for conv in ('Tvw', 'Twv'):
+        pg = gt if conv == 'Tvw' else [T.inv() for T in gt]
+        pe = est if conv == 'Tvw' else [T.inv() for T in est]
+        tm = ref_metrics.TrajectoryMetrics(pg, pe, convention=conv)
+        o = {'rel_dists': tm.rel_dists, 'cum_dists': tm.cum_dists,
+             'endpoint': np.array(tm.endpoint_error()),
+             'endpoint_seg_cm_deg': np.array(tm.endpoint_error(range(10, 41), 'cm', 'deg'))}
+        errs, avg = tm.segment_errors(lengths)
+        o['segment_errs'], o['segment_avg'] = errs, avg
+        errs, avg = tm.segment_errors([0.2, 0.5], trans_unit='dm', rot_unit='deg')
+        o['segment_errs_dm_deg'], o['segment_avg_dm_deg'] = errs, avg
+        o['traj_trans'], o['traj_rot'] = tm.traj_errors()
+        o['traj_trans_seg'], o['traj_rot_seg'] = tm.traj_errors(range(5, 30), 'mm', 'deg')
+        for d in (1, 3):
+            o['rel_trans_%d' % d], o['rel_rot_%d' % d] = tm.rel_errors(delta=d)
+        for et in ('traj', 'rel'):
+            o['norms_' + et] = np.array(tm.error_norms(error_type=et))
+            o['mean_' + et] = np.array(tm.mean_err(error_type=et))
+            o['cum_' + et] = np.array(tm.cum_err(error_type=et))
+            o['rms_' + et] = np.array(tm.rms_err(error_type=et))
+        o['rms_rel_delta3'] = np.array(tm.rms_err(error_type='rel', delta=3))
+        out.update({conv + '_' + k: v for k, v in o.items()})
+        if conv == 'Tvw':
+            tm.savemat(os.path.join(OUT, 'metrics_reference_Tvw.mat'), extras={'note': 'written by the reference'})
+    out['segment_lengths'] = np.array(lengths)
+    save('metrics', **out)
+    print('  metrics: 80 poses, travelled %.1f m, endpoint error %.4f m' % (out['Tvw_cum_dists'][-1], out['Tvw_endpoint'][0]))
+
+
 def main():
+    if len(sys.argv) > 1:                      # only the named cases: python oracle/gen_golden.py metrics ransac
+        os.makedirs(OUT, exist_ok=True)
+        for name in sys.argv[1:]:
+            globals()['case_' + name]()
+        return
     os.makedirs(OUT, exist_ok=True)
     case_losses_sensors()
     case_blocks()
@@ -378,6 +429,7 @@ def main():
     _posegraph_example(6)
     case_motion_only()
     case_ransac()
+    case_metrics()
 
     lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=60, obs_per_lm=4, half_window=3, seed=5,
                                 loss=ref_losses_huber(1.5), const_point_fraction=0.1)
