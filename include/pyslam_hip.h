@@ -231,6 +231,44 @@ int ps_ransac_frame_to_frame(const double* pts_1, const double* pts_2, const dou
                              double thresh, double* T_all, int32_t* counts, int32_t* best_index,
                              int32_t* best_count, double* T_best, uint8_t* best_mask);
 
+/* Dense photometric alignment: one SE(3) pose, one residual per reference pixel --
+   PhotometricResidualSE3 (pyslam/residuals/photometric_residual.py:38-161) inside Problem's Gauss-Newton
+   iteration with element-wise IRLS (pyslam/problem.py:279-360), as the dense VO pipeline runs it per pyramid
+   level (pyslam/pipelines/dense.py:157-194).  The pixel tables are what the residual's constructor
+   precomputes (:44-81); they are copied to the device at create time. */
+typedef struct ps_photo ps_photo;
+typedef struct ps_photo_desc {
+    int32_t num_pixels;
+    const double* pt_ref;        /* num_pixels x 3: triangulated reference points (:80) */
+    const double* im_ref;        /* num_pixels: reference intensities */
+    const double* im_jac;        /* num_pixels x 2: reference image gradient (dI/du, dI/dv) */
+    const double* tri_jac_d;     /* num_pixels x 3: d point / d depth (column 2 of the triangulation Jacobian, :116) */
+    int32_t height, width;       /* tracking image */
+    const double* im_track;      /* height x width, row-major */
+    double cam[5];               /* cu cv fu fv b */
+    int32_t cam_type;            /* 0 stereo (u, v, disparity), 1 RGB-D (u, v, depth) */
+    int32_t cam_w, cam_h;        /* validity bounds of the camera model (is_valid_measurement) */
+    double intensity_covar, depth_covar;   /* stiffness^-2 (:57-58) */
+    int32_t loss_id;             /* 0 L2, 1 L1, 2 Cauchy, 3 Huber, 4 Tukey, 5 t-distribution */
+    double loss_k;
+} ps_photo_desc;
+
+int ps_photometric_create(const ps_photo_desc* desc, void* hip_stream, ps_photo** out);
+int ps_photometric_destroy(ps_photo* h);
+/* pose = T_track_ref as 12 doubles: R row-major, then t */
+int ps_photometric_set_pose(ps_photo* h, const double* pose12);
+int ps_photometric_get_pose(ps_photo* h, double* pose12);
+/* sum of loss(r) over the valid pixels, and their number (evaluate() compresses invalid pixels away, :106) */
+int ps_photometric_eval_cost(ps_photo* h, double* cost, int64_t* num_valid);
+/* H = J~^T J~ (6 x 6, row-major), b = -J~^T r~, cost at the current pose (parity / debugging) */
+int ps_photometric_normal_equations(ps_photo* h, double* H36, double* b6, double* cost, int64_t* num_valid);
+/* One Gauss-Newton iteration: dx = H^-1 b in [translation; rotation] order, then
+     split_params == 0: T <- exp(dx) T          (one SE3 parameter, liegroups perturb)
+     split_params == 1: R <- exp(dx[3:6]) R, t += dx[0:3]   (separate SO3 / translation parameters, dense.py:185)
+   cost: after the step when linesearch != 0 (Problem's degenerate line search always lands on the full step,
+   pyslam/problem.py:362-398), else the cost of the linearisation point (:188-192). */
+int ps_photometric_iteration(ps_photo* h, int32_t split_params, int32_t linesearch, double* dx6, double* cost);
+
 #ifdef __cplusplus
 }
 #endif

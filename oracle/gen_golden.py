@@ -414,6 +414,65 @@ def case_metrics():
     print('  metrics: 80 poses, travelled %.1f m, endpoint error %.4f m' % (out['Tvw_cum_dists'][-1], out['Tvw_endpoint'][0]))
 
 
+def case_photometric():
+    """PhotometricResidualSE3 (reference residuals/photometric_residual.py:38-161) on the exactly rendered plane scene
+    of pyslam_amd.synthetic.photometric_scene: residual + Jacobian at two poses, and the dense pipeline's
+    Gauss-Newton solve (options of pipelines/dense.py:31-36, Huber(10), one SE3 parameter and the (SO3, t) pair).
+
+    The reference's image lookup cannot run as committed (utils.py:36-37, :75 index one-element arrays at [1];
+    its own test fails, and np.int is gone from numpy 2): the module-level name ``bilinear_interpolate`` the
+    residual calls is pointed at scipy.ndimage.map_coordinates(order=1, mode='nearest') -- bilinear weights with
+    the border rows / columns repeated, i.e. what the reference body computes for every pixel that passes
+    is_valid_measurement -- which is independent of this build's own restatement.  Everything else that executes
+    is the reference's code."""
+    import scipy.ndimage
+    import pyslam.residuals.photometric_residual as ref_photo
+
+    def lookup(im, x, y):
+        return scipy.ndimage.map_coordinates(np.asarray(im, dtype=float), [np.asarray(y, float), np.asarray(x, float)],
+                                             order=1, mode='nearest')
+    ref_photo.bilinear_interpolate = lookup
+    out = {}
+    for tag, rgbd in (('stereo', False), ('rgbd', True)):
+        sc = synthetic.photometric_scene(h=40, w=56, seed=5, rgbd=rgbd, noise=0.5)
+        cu, cv, fu, fv, b, w, h = sc['cam']
+        cam = ref_sensors.RGBDCamera(cu, cv, fu, fv, w, h) if rgbd else ref_sensors.StereoCamera(cu, cv, fu, fv, b, w, h)
+        cam.compute_pixel_grid()
+        depth = sc['depth_ref'].copy()
+        depth[3, 5] = np.nan; depth[10, 7] = -1.                    # invalid reference pixels are filtered (:64-69)
+        res = ref_photo.PhotometricResidualSE3(cam, sc['im_ref'], depth, sc['im_track'], sc['im_jac'],
+                                               1.0, 2.0, min_grad=2.0)
+        o = dict(cam=np.array(sc['cam'], dtype=float), im_ref=sc['im_ref'], depth_ref=depth, im_track=sc['im_track'],
+                 im_jac=sc['im_jac'], T_true=sc['T_true'], intensity_stiffness=np.array(1.0),
+                 depth_stiffness=np.array(2.0), min_grad=np.array(2.0), num_pixels=np.array(len(res.im_ref)),
+                 pt_ref=res.pt_ref, triang_jac=res.triang_jac)
+        for k, xi in enumerate(([0., 0, 0, 0, 0, 0], [0.05, -0.04, 0.3, 0.02, 0.03, -0.05])):
+            T = liegroups.SE3.exp(np.array(xi))
+            r, J = res.evaluate([T], [True])
+            o['T%d' % k], o['r%d' % k], o['J%d' % k] = T.as_matrix(), r, J[0]
+            r2, J2 = res.evaluate([T.rot, T.trans], [True, True])
+            assert np.array_equal(r, r2)
+            o['Jrot%d' % k], o['Jtrans%d' % k] = J2[0], J2[1]
+        for form in ('se3', 'split'):
+            opt = example_options(max_nondecreasing_steps=5, min_cost_decrease=0.99, max_iters=30, linesearch_max_iters=0)
+            prob = ref_problem.Problem(opt)
+            if form == 'se3':
+                prob.add_residual_block(res, ['T_1_0'], loss=ref_losses.HuberLoss(10.0))
+                prob.initialize_params({'T_1_0': liegroups.SE3.identity()})
+            else:
+                prob.add_residual_block(res, ['R_1_0', 't_1_0_1'], loss=ref_losses.HuberLoss(10.0))
+                prob.initialize_params({'R_1_0': liegroups.SO3.identity(), 't_1_0_1': np.zeros(3)})
+            params = prob.solve()
+            Tf = params['T_1_0'] if form == 'se3' else liegroups.SE3(params['R_1_0'], params['t_1_0_1'])
+            o['solve_%s_cost_history' % form] = np.array(prob._cost_history)
+            o['solve_%s_T' % form] = Tf.as_matrix()
+            err = liegroups.SE3.from_matrix(sc['T_true']).dot(Tf.inv()).log()
+            print('  photometric %s %s: %d pixels, %d iterations, |log(T_true T^-1)| = %.2e' % (
+                tag, form, len(res.im_ref), len(prob._cost_history) - 1, np.linalg.norm(err)))
+        out.update({tag + '_' + k: v for k, v in o.items()})
+    save('photometric', **out)
+
+
 def main():
     if len(sys.argv) > 1:                      # only the named cases: python oracle/gen_golden.py metrics ransac
         os.makedirs(OUT, exist_ok=True)
@@ -430,6 +489,7 @@ def main():
     case_motion_only()
     case_ransac()
     case_metrics()
+    case_photometric()
 
     lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=60, obs_per_lm=4, half_window=3, seed=5,
                                 loss=ref_losses_huber(1.5), const_point_fraction=0.1)

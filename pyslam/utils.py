@@ -1,1 +1,1 @@
-from pyslam_amd.utils import invsqrt, stackmul  # noqa: F401
+from pyslam_amd.utils import invsqrt, stackmul, bilinear_interpolate  # noqa: F401

@@ -44,6 +44,15 @@ class ProblemInfo(C.Structure):
     ]
 
 
+class PhotoDesc(C.Structure):
+    _fields_ = [
+        ('num_pixels', C.c_int32), ('pt_ref', c_f64p), ('im_ref', c_f64p), ('im_jac', c_f64p), ('tri_jac_d', c_f64p),
+        ('height', C.c_int32), ('width', C.c_int32), ('im_track', c_f64p),
+        ('cam', C.c_double * 5), ('cam_type', C.c_int32), ('cam_w', C.c_int32), ('cam_h', C.c_int32),
+        ('intensity_covar', C.c_double), ('depth_covar', C.c_double), ('loss_id', C.c_int32), ('loss_k', C.c_double),
+    ]
+
+
 # every symbol include/pyslam_hip.h declares: name -> (restype, argtypes)
 H = C.c_void_p
 SIGNATURES = {
@@ -85,6 +94,13 @@ SIGNATURES = {
     'ps_ransac_cost': (C.c_int, [c_f64p, C.c_int32, c_f64p, c_f64p, C.c_int32, c_f64p, C.c_double, c_u8p, c_i32p]),
     'ps_ransac_frame_to_frame': (C.c_int, [c_f64p, c_f64p, c_f64p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f64p,
                                            C.c_double, c_f64p, c_i32p, c_i32p, c_i32p, c_f64p, c_u8p]),
+    'ps_photometric_create': (C.c_int, [C.POINTER(PhotoDesc), C.c_void_p, C.POINTER(H)]),
+    'ps_photometric_destroy': (C.c_int, [H]),
+    'ps_photometric_set_pose': (C.c_int, [H, c_f64p]),
+    'ps_photometric_get_pose': (C.c_int, [H, c_f64p]),
+    'ps_photometric_eval_cost': (C.c_int, [H, c_f64p, C.POINTER(C.c_int64)]),
+    'ps_photometric_normal_equations': (C.c_int, [H, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_int64)]),
+    'ps_photometric_iteration': (C.c_int, [H, C.c_int32, C.c_int32, c_f64p, c_f64p]),
     'ps_dense_normal_solve': (C.c_int, [c_f64p, c_f64p, C.c_int32, C.c_int32, c_f64p, c_f64p]),
 }
 

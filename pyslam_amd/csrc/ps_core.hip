@@ -14,12 +14,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "pyslam_hip.h"
 #include "ps_kernels.h"
 #include "ps_ransac.h"
+#include "ps_photo.h"
 
 namespace {
 
@@ -2122,6 +2124,129 @@ int ps_ransac_frame_to_frame(const double* pts_1, const double* pts_2, const dou
     if (best_mask) HIP_OK(hipMemcpy(best_mask, dbm.p, (size_t)num_pts, hipMemcpyDeviceToHost));
     if (T_all) HIP_OK(hipMemcpy(T_all, dT.p, (size_t)num_hyp * 16 * sizeof(double), hipMemcpyDeviceToHost));
     if (counts) HIP_OK(hipMemcpy(counts, dcnt.p, (size_t)num_hyp * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- dense photometric alignment (reference pyslam/residuals/photometric_residual.py) ------------------
+struct ps_photo {
+    hipStream_t stream = nullptr;
+    PhotoArgs args{};
+    std::vector<void*> allocs;
+    double *pose = nullptr, *partials = nullptr, *out = nullptr;
+    int nparts = 0;
+    double h_out[PS_PHOTO_NOUT];
+    int upload(const double** dst, const double* src, size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(double)) != hipSuccess) return fail("hipMalloc failed");
+        allocs.push_back(p);
+        if (n && hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+        *dst = (const double*)p;
+        return 0;
+    }
+    ~ps_photo() { for (void* p : allocs) hipFree(p); }
+};
+
+namespace {
+int photo_pass(ps_photo* h, int with_normal, int update) {
+    hipLaunchKernelGGL(k_photo_pass, dim3(h->nparts), dim3(256), 0, h->stream, h->args, (const double*)h->pose, with_normal,
+                       h->partials);
+    hipLaunchKernelGGL(k_photo_finish, dim3(1), dim3(256), 0, h->stream, h->nparts, (const double*)h->partials, with_normal,
+                       update, h->pose, h->out);
+    return 0;
+}
+int photo_fetch(ps_photo* h) {
+    HIP_OK(hipMemcpyAsync(h->h_out, h->out, sizeof(h->h_out), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+}  // namespace
+
+int ps_photometric_create(const ps_photo_desc* d, void* stream, ps_photo** out) {
+    if (!d || !out) return fail("null argument");
+    *out = nullptr;
+    if (d->num_pixels < 0 || d->height <= 0 || d->width <= 0) return fail("bad image or pixel count");
+    if (d->num_pixels > 0 && (!d->pt_ref || !d->im_ref || !d->im_jac || !d->tri_jac_d)) return fail("null pixel table");
+    if (!d->im_track) return fail("null tracking image");
+    if (d->cam_type != 0 && d->cam_type != 1) return fail("cam_type must be 0 (stereo) or 1 (RGB-D)");
+    if (d->loss_id < 0 || d->loss_id > 5) return fail("unknown loss id");
+    if (need_device()) return -1;
+    std::unique_ptr<ps_photo> h(new ps_photo);
+    h->stream = (hipStream_t)stream;
+    PhotoArgs& a = h->args;
+    const size_t n = (size_t)d->num_pixels;
+    a.n = d->num_pixels; a.h = d->height; a.w = d->width;
+    if (h->upload(&a.pt_ref, d->pt_ref, 3 * n) || h->upload(&a.im_ref, d->im_ref, n) ||
+        h->upload(&a.im_jac, d->im_jac, 2 * n) || h->upload(&a.tri_jac_d, d->tri_jac_d, 3 * n) ||
+        h->upload(&a.image, d->im_track, (size_t)d->height * d->width)) return -1;
+    a.cu = d->cam[0]; a.cv = d->cam[1]; a.fu = d->cam[2]; a.fv = d->cam[3]; a.b = d->cam[4];
+    a.cam_type = d->cam_type; a.cam_w = (double)d->cam_w; a.cam_h = (double)d->cam_h;
+    a.var_i = d->intensity_covar; a.var_d = d->depth_covar;
+    a.loss_id = d->loss_id; a.loss_k = d->loss_k;
+    h->nparts = std::max(1, cdiv(d->num_pixels, 256 * PS_PHOTO_PPT));
+    const double ident[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    const double* tmp = nullptr;
+    if (h->upload(&tmp, ident, 12)) return -1;
+    h->pose = const_cast<double*>(tmp);
+    std::vector<double> zeros((size_t)h->nparts * PS_PHOTO_NACC + PS_PHOTO_NOUT, 0.0);
+    if (h->upload(&tmp, zeros.data(), (size_t)h->nparts * PS_PHOTO_NACC)) return -1;
+    h->partials = const_cast<double*>(tmp);
+    if (h->upload(&tmp, zeros.data(), (size_t)PS_PHOTO_NOUT)) return -1;
+    h->out = const_cast<double*>(tmp);
+    *out = h.release();
+    return 0;
+}
+
+int ps_photometric_destroy(ps_photo* h) {
+    if (!h) return 0;
+    if (h->stream) hipStreamSynchronize(h->stream); else hipDeviceSynchronize();
+    delete h;
+    return 0;
+}
+
+int ps_photometric_set_pose(ps_photo* h, const double* pose12) {
+    if (!h || !pose12) return fail("null argument");
+    HIP_OK(hipMemcpyAsync(h->pose, pose12, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ps_photometric_get_pose(ps_photo* h, double* pose12) {
+    if (!h || !pose12) return fail("null argument");
+    HIP_OK(hipMemcpyAsync(pose12, h->pose, 12 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ps_photometric_eval_cost(ps_photo* h, double* cost, int64_t* num_valid) {
+    if (!h) return fail("null handle");
+    if (photo_pass(h, 0, 0) || photo_fetch(h)) return -1;
+    if (cost) *cost = h->h_out[42];
+    if (num_valid) *num_valid = (int64_t)h->h_out[43];
+    return 0;
+}
+
+int ps_photometric_normal_equations(ps_photo* h, double* H36, double* b6, double* cost, int64_t* num_valid) {
+    if (!h) return fail("null handle");
+    if (photo_pass(h, 1, 0) || photo_fetch(h)) return -1;
+    if (H36) std::copy(h->h_out, h->h_out + 36, H36);
+    if (b6) std::copy(h->h_out + 36, h->h_out + 42, b6);
+    if (cost) *cost = h->h_out[42];
+    if (num_valid) *num_valid = (int64_t)h->h_out[43];
+    return 0;
+}
+
+int ps_photometric_iteration(ps_photo* h, int32_t split_params, int32_t linesearch, double* dx6, double* cost) {
+    if (!h) return fail("null handle");
+    if (photo_pass(h, 1, split_params ? 2 : 1) || photo_fetch(h)) return -1;
+    if (h->h_out[43] < 6.0) return fail("photometric alignment: fewer than 6 valid pixels");
+    if (h->h_out[50] != 0.0) return fail("photometric alignment: normal equations are not positive definite");
+    if (dx6) std::copy(h->h_out + 44, h->h_out + 50, dx6);
+    double c = h->h_out[42];
+    if (linesearch) {
+        if (photo_pass(h, 0, 0) || photo_fetch(h)) return -1;
+        c = h->h_out[42];
+    }
+    if (cost) *cost = c;
     return 0;
 }
 

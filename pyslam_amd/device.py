@@ -232,3 +232,88 @@ def dense_normal_solve(J, r, want_covariance=False):
     cov = np.zeros((n, n)) if want_covariance else None
     nat.check(lib.ps_dense_normal_solve(nat.f64p(J), nat.f64p(r), m, n, nat.f64p(dx), nat.f64p(cov)))
     return (dx, cov) if want_covariance else dx
+
+
+class PhotometricDevice:
+    """Device side of a Problem whose only block is a PhotometricResidualSE3 (include/pyslam_hip.h:
+    ps_photometric_*): the pixel tables live in HBM, one call runs a whole Gauss-Newton iteration.
+    Exposes the subset of DeviceProblem's interface that Problem.solve() drives."""
+
+    def __init__(self, block, loss, split_params, stream=None):
+        from pyslam_amd.lowering import _loss_id_k
+        lib = nat.require_gpu()
+        self._lib = lib
+        self.split_params = bool(split_params)
+        t = block.device_tables()
+        d = nat.PhotoDesc()
+        self._keep = t
+        d.num_pixels = t['pt_ref'].shape[0]
+        d.pt_ref, d.im_ref = nat.f64p(t['pt_ref']), nat.f64p(t['im_ref'])
+        d.im_jac, d.tri_jac_d = nat.f64p(t['im_jac']), nat.f64p(t['tri_jac_d'])
+        d.height, d.width = t['im_track'].shape
+        d.im_track = nat.f64p(t['im_track'])
+        for k in range(5):
+            d.cam[k] = t['cam'][k]
+        d.cam_type, d.cam_w, d.cam_h = t['cam_type'], t['cam_w'], t['cam_h']
+        d.intensity_covar, d.depth_covar = t['intensity_covar'], t['depth_covar']
+        lid, lk = _loss_id_k(loss)
+        d.loss_id, d.loss_k = int(lid), float(lk)
+        self.num_pixels = d.num_pixels
+        self._h = nat.H()
+        nat.check(lib.ps_photometric_create(C.byref(d), C.c_void_p(stream or 0), C.byref(self._h)))
+        self._keep = None
+        self._saved = None
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.ps_photometric_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- pose: (R, t) <-> 12 doubles -----------------------------------
+    def set_pose(self, R, t):
+        row = np.concatenate([np.asarray(R, dtype=float).reshape(9), np.asarray(t, dtype=float).reshape(3)])
+        nat.check(self._lib.ps_photometric_set_pose(self._h, nat.f64p(row)))
+
+    def get_pose(self):
+        row = np.zeros(12)
+        nat.check(self._lib.ps_photometric_get_pose(self._h, nat.f64p(row)))
+        return row[:9].reshape(3, 3).copy(), row[9:].copy()
+
+    def snapshot(self):
+        self._saved = self.get_pose()
+
+    def restore(self):
+        self.set_pose(*self._saved)
+
+    # ---- evaluation ----------------------------------------------------
+    def eval_cost(self, include_all_constant=True):
+        cost, n = C.c_double(), C.c_int64()
+        nat.check(self._lib.ps_photometric_eval_cost(self._h, C.byref(cost), C.byref(n)))
+        self.num_valid = n.value
+        return cost.value
+
+    def normal_equations(self):
+        Hm, b = np.zeros((6, 6)), np.zeros(6)
+        cost, n = C.c_double(), C.c_int64()
+        nat.check(self._lib.ps_photometric_normal_equations(self._h, nat.f64p(Hm), nat.f64p(b), C.byref(cost), C.byref(n)))
+        return Hm, b, cost.value, n.value
+
+    def step(self, linesearch):
+        """One iteration in place: (dx in [translation; rotation] order, cost)."""
+        dx, cost = np.zeros(6), C.c_double()
+        nat.check(self._lib.ps_photometric_iteration(self._h, int(self.split_params), int(bool(linesearch)),
+                                                     nat.f64p(dx), C.byref(cost)))
+        return dx, cost.value
+
+    def gn_iteration(self, lam, pcg_tol, pcg_max_iters, linesearch):
+        """Same tuple as DeviceProblem.gn_iteration: (cost, |dx|, solver iterations, relative residual)."""
+        if lam:
+            raise ValueError('the photometric device path has no damping (Options.lm_lambda must be 0)')
+        dx, cost = self.step(linesearch)
+        return cost, float(np.linalg.norm(dx)), 0, 0.0

@@ -104,9 +104,39 @@ class Problem:
         return lowering.lower(pd, self.residual_blocks, self.block_param_keys,
                               self.block_loss_functions, self.constant_param_keys)
 
+    def _photometric_form(self):
+        """'se3' / 'split' when the problem is ONE PhotometricResidualSE3 block on variable parameters (the dense VO
+        pipeline's per-pyramid-level problem, reference pipelines/dense.py:174-186), else None."""
+        if len(self.residual_blocks) != 1 or getattr(self.residual_blocks[0], 'KIND', None) != 'photometric':
+            return None
+        keys = self.block_param_keys[0]
+        if any(k in self.constant_param_keys for k in keys) or set(keys) != set(self.param_dict.keys()):
+            return None
+        return {1: 'se3', 2: 'split'}.get(len(keys))
+
+    def _get_photometric_device(self, param_dict=None):
+        from pyslam_amd.device import PhotometricDevice
+        form = self._photometric_form()
+        block, loss, keys = self.residual_blocks[0], self.block_loss_functions[0], self.block_param_keys[0]
+        sig = ('photometric', form, id(block), id(loss))
+        if self._device is None or self._device_sig != sig:
+            if self._device is not None:
+                self._device.close()
+            self._device = PhotometricDevice(block, loss, form == 'split')
+            self._device_sig = sig
+        pd = self.param_dict if param_dict is None else param_dict
+        if form == 'se3':
+            T = pd[keys[0]]
+            self._device.set_pose(T.rot.as_matrix(), T.trans)
+        else:
+            self._device.set_pose(pd[keys[0]].as_matrix(), pd[keys[1]])
+        return self._device
+
     def _get_device(self, param_dict=None):
         """DeviceProblem for the current structure; parameters refreshed from param_dict."""
         from pyslam_amd.device import DeviceProblem
+        if self._photometric_form():
+            return self._get_photometric_device(param_dict)
         lp = self._lower(param_dict)
         sig = (len(self.residual_blocks), tuple(self.param_dict.keys()), tuple(self.constant_param_keys),
                lp.num_obs, lp.num_edges, lp.num_priors)
@@ -122,6 +152,21 @@ class Problem:
 
     def _write_back(self, dev):
         """Copy the device parameter tables into the live param_dict objects."""
+        form = self._photometric_form()
+        if form:
+            R, t = dev.get_pose()
+            keys = self.block_param_keys[0]
+            if form == 'se3':
+                self.param_dict[keys[0]].rot.mat = R
+                self.param_dict[keys[0]].trans = t
+            else:
+                self.param_dict[keys[0]].mat = R
+                val = self.param_dict[keys[1]]
+                if isinstance(val, np.ndarray):
+                    val[...] = t
+                else:
+                    self.param_dict[keys[1]] = t
+            return
         lp = dev.lp
         poses, points = dev.get_params()
         for key, row in zip(lp.pose_keys, poses):
@@ -243,6 +288,19 @@ class Problem:
             dev = self._get_device()
         except NotLowerable:
             return self._solve_one_iter_host()
+        if self._photometric_form():
+            saved = dev.get_pose()
+            dxd, cost = dev.step(opt.linesearch_max_iters > 0)
+            dev.set_pose(*saved)
+            dx = np.zeros(6)
+            keys = self.block_param_keys[0]
+            if len(keys) == 1:
+                dx[self._update_partition_dict[keys[0]]] = dxd
+            else:
+                dx[self._update_partition_dict[keys[0]]] = dxd[3:6]
+                dx[self._update_partition_dict[keys[1]]] = dxd[0:3]
+            self.solver_stats.append((0, 0.0))
+            return dx, cost
         saved = dev.get_params()
         dev.linearize(opt.lm_lambda)
         its, rel = dev.solve_reduced(opt.pcg_tol, opt.pcg_max_iters)
@@ -319,6 +377,18 @@ class Problem:
                 from pyslam_amd.device import dense_normal_solve
                 J, e, _ = self._host_jacobian()
                 _, self._covariance_matrix = dense_normal_solve(J, e, want_covariance=True)
+                return
+            if self._photometric_form():
+                # 6 x 6: the device forms J~^T J~ over all pixels; its inverse in the reference's unknown order
+                Hm = dev.normal_equations()[0]
+                keys = self.block_param_keys[0]
+                order = np.empty(6, dtype=int)
+                if len(keys) == 1:
+                    order[self._update_partition_dict[keys[0]]] = np.arange(6)
+                else:
+                    order[self._update_partition_dict[keys[0]]] = np.arange(3, 6)
+                    order[self._update_partition_dict[keys[1]]] = np.arange(0, 3)
+                self._covariance_matrix = np.linalg.inv(Hm[np.ix_(order, order)])
                 return
             dev.covariance_begin()
             self._cov_device = dev

@@ -286,3 +286,49 @@ def to_objects(lp, ns, options=None, points_first=True):
     if const:
         problem.set_parameters_constant(const)
     return problem
+
+
+def photometric_scene(h=48, w=64, seed=5, xi_true=(0.03, -0.02, 0.04, 0.01, -0.015, 0.02), rgbd=False,
+                      noise=0.0, fu=None):
+    """A textured plane seen from two poses, rendered EXACTLY (no warping): the intensity is a smooth function of
+    the 3-D point, the plane n.P = c is given in the reference frame, and every tracking-image pixel is the
+    intensity at the intersection of its ray with that plane.
+
+    Returns camera parameters ``cam`` = (cu, cv, fu, fv, b, w, h) (b = 0 and depth instead of disparity when
+    ``rgbd``), ``im_ref`` (h, w), ``depth_ref`` (disparity or depth, (h, w)), ``im_track`` (h, w), ``im_jac``
+    (2, h, w) central-difference gradient of im_ref, and ``T_true`` (4 x 4, track <- ref).
+    The inputs of the reference's PhotometricResidualSE3 (photometric_residual.py:44-46)."""
+    rng = np.random.default_rng(seed)
+    fu = float(fu if fu is not None else 0.9 * w)
+    cu, cv, fv, b = 0.5 * w - 0.5, 0.5 * h - 0.5, fu, 0.25
+    n = np.array([0.15, -0.1, 1.0]); n /= np.linalg.norm(n)
+    c = 4.0
+    freq = rng.uniform(0.6, 2.2, size=(6, 3)) * rng.choice([-1., 1.], size=(6, 3))
+    phase = rng.uniform(0, 2 * np.pi, 6)
+    amp = rng.uniform(10., 30., 6)
+
+    def intensity(P):
+        return 100. + np.sum(amp * np.sin(P @ freq.T + phase), axis=-1)
+
+    u, v = np.meshgrid(np.arange(w, dtype=float), np.arange(h, dtype=float), indexing='xy')
+    rays = np.stack([(u - cu) / fu, (v - cv) / fv, np.ones_like(u)], axis=-1)
+    # reference view: P = s d with n.P = c
+    s_ref = c / (rays @ n)
+    P_ref = rays * s_ref[..., None]
+    im_ref = intensity(P_ref)
+    z_ref = P_ref[..., 2]
+    depth_ref = z_ref if rgbd else fu * b / z_ref
+    # tracking view: P_ref = R^T (s d' - t)
+    T = SE3.exp(np.asarray(xi_true, dtype=float))
+    R, t = T.rot.as_matrix(), np.asarray(T.trans, dtype=float)
+    Rt_n = R @ n                                   # n . R^T x = (R n) . x
+    s_trk = (c + Rt_n @ t) / (rays @ Rt_n)
+    P_in_ref = (rays * s_trk[..., None] - t) @ R    # rows: R^T (s d' - t)
+    im_track = intensity(P_in_ref)
+    if noise:
+        im_ref = im_ref + noise * rng.standard_normal(im_ref.shape)
+        im_track = im_track + noise * rng.standard_normal(im_track.shape)
+    gy, gx = np.gradient(im_ref)
+    cam = (cu, cv, fu, fv, 0. if rgbd else b, w, h)
+    return dict(cam=cam, im_ref=im_ref, depth_ref=depth_ref, im_track=im_track, im_jac=np.stack([gx, gy]),
+                T_true=T.as_matrix(), rgbd=rgbd)

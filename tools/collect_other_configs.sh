@@ -17,6 +17,9 @@ echo
 echo "# frame-to-frame RANSAC (tools/ransac_bench.py)"
 python tools/ransac_bench.py 2>&1 | grep -v amdgpu.ids
 echo
+echo "# dense photometric alignment, 640 x 480 (tools/photo_bench.py)"
+python tools/photo_bench.py 2>&1 | grep -v amdgpu.ids
+echo
 echo "# ps_problem_create stages (tools/create_time.py, PS_CREATE_TIMING=1)"
 PS_CREATE_TIMING=1 python tools/create_time.py 2>&1 | grep -v amdgpu.ids
 } > "$OUT/other_configs.txt"
