@@ -366,9 +366,11 @@ int build_coarse(ps_problem* h) {
     // auto: on from 16 reduced poses, ~18 poses per hat interval, at most 12 intervals while the
     // coarse factorisation is LDS-resident; large systems (split mode, no dense border rows) take 24
     // 48
+    const bool sparse_rows = (long)h->nnzb <= 24L * nr;       // pose-graph-like rows (C2: 11 blocks per row)
     if (G < 0) {
         if (nr < 16) G = 0;                        // (systems up to 90 unknowns are solved directly anyway)
         else if (nr > h->cg_split_min_rows) G = 48;                                    // measured: C4 (BA, 2 000 poses) and C2 (10 000-pose chain)
+        else if (sparse_rows && nr >= 150) G = std::min(36, nr / 10);    // pose graphs: 200 poses 67 -> 51 iterations, 350: 85 -> 48
         else G = std::min(12, std::max(3, (nr + 9) / 18));
     }
     // large reduced systems (more than cg_explicit_min_rows poses): the two-level preconditioner is APPLIED explicitly
@@ -380,7 +382,6 @@ int build_coarse(ps_problem* h) {
     // beside a short CG): one per 20 poses, up to 112 (C4: 42 iterations / 3.7 ms folded at 48 -> 20 / 2.6 ms at 100).
     // Measured crossover against the folded single-launch CG (whose coarse level is capped at 12 intervals):
     // pose graphs 400 poses (600: 2.6 -> 1.4 ms, 1 000: 6.1 -> 1.5 ms), bundle adjustment 540 (700: 1.67 -> 1.28 ms).
-    const bool sparse_rows = (long)h->nnzb <= 24L * nr;
     const int xmin = std::min(h->cg_split_min_rows, h->cg_explicit_min_rows >= 0 ? h->cg_explicit_min_rows : (sparse_rows ? 400 : 540));
     h->cg_explicit = h->explicit_ok && G != 0 && nr > xmin;
     if (h->cg_explicit && h->coarse_req < 0)

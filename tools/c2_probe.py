@@ -10,6 +10,7 @@ t = time.time(); dev = DeviceProblem(lp); print('create %.2fs' % (time.time() - 
 for G in ([int(a) for a in sys.argv[2:]] or [-1, 0]):
     dev.set_option('coarse_groups', G)
     if 'C2_SPLIT_MIN' in os.environ: dev.set_option('cg_split_min_rows', float(os.environ['C2_SPLIT_MIN']))
+    if 'C2_EXPLICIT' in os.environ: dev.set_option('cg_explicit', float(os.environ['C2_EXPLICIT']))
     dev.set_params(lp.poses, lp.points)
     hist = [dev.eval_cost(True)]
     for it in range(6):
