@@ -1769,15 +1769,28 @@ int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters,
     h->shard_out = true;
     struct Reset { ps_problem* h; ~Reset() { h->shard_out = false; } } reset{h};
     if (first) {
-        if (h->explicit_ok) { h->explicit_ok = 0; h->coarse_built = false; }     // the enqueue-only protocol needs the folded CG
         HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
-        if (h->D == 6 ? cg_fused_setup<6>(h, pcg_max_iters, true) : cg_fused_setup<3>(h, pcg_max_iters, true)) return -1;
+        if (!h->coarse_built && build_coarse(h)) return -1;
+        if (h->cg_explicit) { if (h->D == 6 ? xcg_setup<6>(h, pcg_max_iters, true) : xcg_setup<3>(h, pcg_max_iters, true)) return -1; }
+        else if (h->D == 6 ? cg_fused_setup<6>(h, pcg_max_iters, true) : cg_fused_setup<3>(h, pcg_max_iters, true)) return -1;
     }
-    int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + h->cg_margin : 16) : std::max(8, h->cg_launched / 2);
-    count = std::min(count, pcg_max_iters + 2 - h->cg_launched);
+    // (the explicit PCG runs iteration k in launch group k: one group less than the fused CG's launches)
+    const int limit = pcg_max_iters + (h->cg_explicit ? 1 : 2);
+    const int margin = h->cg_explicit ? 2 : h->cg_margin;
+    int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : (h->cg_explicit ? 32 : 16)) : std::max(8, h->cg_launched / 2);
+    count = std::min(count, limit - h->cg_launched);
     const bool last = count <= 0;
-    if (h->D == 6) { if (!last) cg_fused_launch<6>(h, pcg_tol, count); cg_fused_recover<6>(h, last ? nullptr : h->status); }
-    else { if (!last) cg_fused_launch<3>(h, pcg_tol, count); cg_fused_recover<3>(h, last ? nullptr : h->status); }
+    const int32_t* gate = last ? nullptr : h->status;
+    if (h->cg_explicit) {
+        if (!last) {
+            const int head = std::min(count, 12);           // (see gn_solve_and_finish_async)
+            if (h->D == 6) { xcg_launch<6>(h, pcg_tol, head); if (xcg_side_enqueue<6>(h)) return -1; xcg_launch<6>(h, pcg_tol, count - head); }
+            else { xcg_launch<3>(h, pcg_tol, head); if (xcg_side_enqueue<3>(h)) return -1; xcg_launch<3>(h, pcg_tol, count - head); }
+        }
+        if (h->D == 6) hipLaunchKernelGGL(k_cg_unscale<6>, dim3(cdiv((long)h->nr * 6, 256)), dim3(256), 0, h->stream, h->nr, h->Linv, h->cg_xh, h->x, gate);
+        else hipLaunchKernelGGL(k_cg_unscale<3>, dim3(cdiv((long)h->nr * 3, 256)), dim3(256), 0, h->stream, h->nr, h->Linv, h->cg_xh, h->x, gate);
+    } else if (h->D == 6) { if (!last) cg_fused_launch<6>(h, pcg_tol, count); cg_fused_recover<6>(h, gate); }
+    else { if (!last) cg_fused_launch<3>(h, pcg_tol, count); cg_fused_recover<3>(h, gate); }
     if (gn_tail(h, linesearch, last ? nullptr : h->status)) return -1;
     return last ? 1 : 0;
 }

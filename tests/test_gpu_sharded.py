@@ -24,7 +24,10 @@ def dist1():
 
 
 @pytest.mark.parametrize('native', [True, False])
-def test_one_rank_sharded_iteration_equals_the_unsharded_one(dist1, native):
+@pytest.mark.parametrize('explicit', [False, True])
+def test_one_rank_sharded_iteration_equals_the_unsharded_one(dist1, native, explicit):
+    """explicit: the large-system solver (explicitly applied two-level preconditioner, side-stream coarse inverse)
+    forced onto the small problem -- the sharded protocol must drive it too (C4-sized shards use it by default)."""
     import torch
     from pyslam_amd.device import DeviceProblem
     from pyslam_amd.distributed import ShardedDeviceProblem
@@ -32,6 +35,10 @@ def test_one_rank_sharded_iteration_equals_the_unsharded_one(dist1, native):
     ref = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
     sh = ShardedDeviceProblem(lp, dist1, native_rccl=native)
     assert (sh.native is not None) == native
+    if explicit:
+        for d in (ref, sh.dev):
+            d.set_option('cg_explicit_min_rows', 0)
+            d.set_option('cg_split_min_rows', 0)
     for _ in range(3):
         a = ref.gn_iteration(0., 1e-12, 1000, True)
         b = sh.gn_iteration(0., 1e-12, 1000, True)
