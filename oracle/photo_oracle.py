@@ -1,7 +1,7 @@
 """CPU restatement of the reference's dense photometric alignment step
 (pyslam/residuals/photometric_residual.py:38-161 inside pyslam/problem.py:182-194, 279-360).
 
-TEST INFRASTRUCTURE ONLY: imported by tests/ and tools/ timing scripts as the checker / CPU baseline,
+TEST INFRASTRUCTURE ONLY: imported by tests/ as the checker,
 never by the product path.  Works on plain tables (the constructor's outputs), one pixel per row, written
 with explicit per-pixel formulas rather than the product class's stacked einsum expressions.
 Pinned against tests/golden/photometric.npz, which oracle/gen_golden.py produced by running the reference

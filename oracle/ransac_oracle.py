@@ -1,7 +1,7 @@
 """CPU restatement of the reference's frame-to-frame RANSAC (pyslam/pipelines/ransac.py).
 
-TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and tools/ timing
-scripts as the checker / CPU baseline, never by the product path (pyslam_amd has no CPU path).
+TEST INFRASTRUCTURE ONLY: imported by tests/ (including the tests/bench_*.py timing scripts) and
+__graft_entry__.smoke() as the checker / CPU baseline, never by the product path (pyslam_amd has no CPU path).
 Pinned against tests/golden/ransac.npz, which oracle/gen_golden.py produced by running the
 verbatim reference (FrameToFrameRANSAC.perform_ransac under a fixed numpy seed).
 """

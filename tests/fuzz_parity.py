@@ -2,7 +2,7 @@
 constant fractions, windows) -- one whole Gauss-Newton iteration on the device (ps_gn_iteration) against the oracle's
 step (normal equations + sparse direct solve + update + cost).  Covers the small-system direct solve, the folded
 two-level CG at several coarse sizes, the explicit PCG (forced through cg_explicit_min_rows) and the motion-only kernel.
-usage: python tools/fuzz_parity.py [num_cases] [first_seed]"""
+usage: python tests/fuzz_parity.py [num_cases] [first_seed]"""
 import os, sys, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np

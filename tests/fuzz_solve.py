@@ -1,7 +1,7 @@
 """Randomised sweep of the whole solve(): seeded random small problems are turned into Problem objects
 (synthetic.to_objects -> add_residual_block / initialize_params / set_parameters_constant), solved through the
 public API on the device, and compared with the oracle's solve (reference control flow + sparse direct solves):
-same number of iterations, same cost history, same final parameters.  usage: python tools/fuzz_solve.py [cases] [seed0]"""
+same number of iterations, same cost history, same final parameters.  usage: python tests/fuzz_solve.py [cases] [seed0]"""
 import os, sys, time
 root = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, 'tests')]

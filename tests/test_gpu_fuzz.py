@@ -1,4 +1,4 @@
-"""Randomised parity sweep (tools/fuzz_parity.py): seeded random BA / pose-graph / motion-only problems with random
+"""Randomised parity sweep (tests/fuzz_parity.py): seeded random BA / pose-graph / motion-only problems with random
 sizes, losses and solver modes (direct, folded two-level CG, explicit PCG, no coarse level); one device iteration
 against the oracle's step.  1 500 further seeds were run when this was written (0 failures)."""
 import os
@@ -6,7 +6,7 @@ import sys
 
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
@@ -17,7 +17,7 @@ def test_random_problems_match_the_oracle_step():
 
 @pytest.mark.gpu
 def test_random_problems_solve_like_the_oracle():
-    """tools/fuzz_solve.py: the whole solve() through the public Problem API (objects -> lowering -> device) against the
+    """tests/fuzz_solve.py: the whole solve() through the public Problem API (objects -> lowering -> device) against the
     oracle's solve: same iteration count, cost history and final poses under random Options (line search on/off,
     non-decreasing steps, iteration caps).  1 580 further seeds were run when this was written (0 failures)."""
     import fuzz_solve

@@ -14,8 +14,8 @@ echo
 echo "# small problems (tools/small_probe.py)"
 python tools/small_probe.py 2>&1 | grep -v amdgpu.ids
 echo
-echo "# frame-to-frame RANSAC (tools/ransac_bench.py)"
-python tools/ransac_bench.py 2>&1 | grep -v amdgpu.ids
+echo "# frame-to-frame RANSAC (tests/bench_ransac.py)"
+python tests/bench_ransac.py 2>&1 | grep -v amdgpu.ids
 echo
 echo "# dense photometric alignment, 640 x 480 (tools/photo_bench.py)"
 python tools/photo_bench.py 2>&1 | grep -v amdgpu.ids
