@@ -141,6 +141,8 @@ struct ps_problem {
     bool cg_explicit = false;
     double *xstate = nullptr, *xy = nullptr, *xp2 = nullptr;
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
+    int prof_every = 1;             // profiling level 1: time the Schur kernel of every n-th linearisation only
+    long prof_tick = 0;
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;
     double* cg_tot = nullptr;
@@ -216,6 +218,7 @@ struct StageTimer {
     int slot = -1;
     StageTimer(ps_problem* h_, int st, int level = 2) : h(h_), stage(st) {
         if (h->profiling < level) return;
+        if (h->profiling == 1 && h->prof_every > 1 && h->prof_tick % h->prof_every != 0) return;   // sampled launches only
         if (h->ev_used + 2 > h->ev_pool.size()) {
             for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); h->ev_pool.push_back(e); }
         }
@@ -747,6 +750,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
 }
 
 int linearize(ps_problem* h, double lambda) {
+    ++h->prof_tick;
     h->cov_ready = false;
     h->status_clean = false;
     HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double) + ST_NWORDS * sizeof(int32_t), h->stream));   // [S | g | cost | status]
@@ -2006,6 +2010,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "fused_motion_only") h->mo_fused = value != 0.0;
     else if (n == "direct_max_unknowns") { if (value < 0 || value > 90) return fail("direct_max_unknowns must be 0..90"); h->direct_max = (int)value; }
     else if (n == "coarse_basis") { h->coarse_basis = value != 0.0; h->lci_next = -1; }
+    else if (n == "profile_every") { if (value < 1) return fail("profile_every must be >= 1"); h->prof_every = (int)value; }
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
     else if (n == "cg_explicit_min_rows") { h->cg_explicit_min_rows = (int)value; h->coarse_built = false; }
