@@ -1690,15 +1690,19 @@ int ps_apply_update(ps_problem* h, double step) {
 
 int ps_snapshot_params(ps_problem* h) {
     if (!h) return fail("null argument");
-    if (h->P) HIP_OK(hipMemcpyAsync(h->poses_snap, h->poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    if (h->L) HIP_OK(hipMemcpyAsync(h->points_snap, h->points, (size_t)h->L * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
+    if (n1 + n2)
+        hipLaunchKernelGGL(k_copy2, dim3((unsigned)std::min<size_t>(2048, cdiv((long)(n1 + n2), 256))), dim3(256), 0, h->stream,
+                           n1, (const double*)h->poses, h->poses_snap, n2, (const double*)h->points, h->points_snap);
     return 0;
 }
 
 int ps_restore_params(ps_problem* h) {
     if (!h) return fail("null argument");
-    if (h->P) HIP_OK(hipMemcpyAsync(h->poses, h->poses_snap, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    if (h->L) HIP_OK(hipMemcpyAsync(h->points, h->points_snap, (size_t)h->L * 3 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
+    if (n1 + n2)
+        hipLaunchKernelGGL(k_copy2, dim3((unsigned)std::min<size_t>(2048, cdiv((long)(n1 + n2), 256))), dim3(256), 0, h->stream,
+                           n1, (const double*)h->poses_snap, h->poses, n2, (const double*)h->points_snap, h->points);
     return 0;
 }
 

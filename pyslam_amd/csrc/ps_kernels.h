@@ -1428,6 +1428,16 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused_lds(
     }
 }
 
+// parameter snapshot / restore: both tables in ONE launch (two hipMemcpyAsync are two blit launches, ~5 us each)
+__global__ __launch_bounds__(256) void k_copy2(size_t n1, const double* __restrict__ a_src, double* __restrict__ a_dst,
+                                               size_t n2, const double* __restrict__ b_src, double* __restrict__ b_dst)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += stride) {
+        if (i < n1) a_dst[i] = a_src[i]; else b_dst[i - n1] = b_src[i - n1];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Direct solve of SMALL reduced systems (nr * D <= 90 unknowns: the reference's own examples, sliding
 // windows, motion-only problems): BSR -> dense, the LDS-resident blocked Cholesky + inverse of the
