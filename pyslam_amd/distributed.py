@@ -147,12 +147,22 @@ class ShardedDeviceProblem:
         self.info = dict(self.dev.info)
         # GPU: let the HIP core drive RCCL itself (one ABI call + one sync per iteration)
         self.native = None
-        if device_factory is None and native_rccl:
+        import os
+        if device_factory is None and native_rccl and os.environ.get('PYSLAM_AMD_NATIVE_RCCL', '1') != '0':
             try:
                 self.native = NativeRccl(dist)
                 self.dev.set_collective(self.native.allreduce_ptr, self.native.comm.value)
             except Exception as e:                       # fall back to torch.distributed collectives
                 print('pyslam_amd: native RCCL unavailable ({}); using torch.distributed'.format(e))
+                self.native = None
+            # the choice must be the same on every rank (a rank that fell back alone would wait in a different
+            # collective than its peers): native only if it came up everywhere
+            flag = torch.tensor([1 if self.native is not None else 0], dtype=torch.int32,
+                                device=self.dev.reduce_tensor.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and self.native is not None:
+                self.dev.set_collective(0, 0)
+                self.native.close()
                 self.native = None
         self._scal = torch.zeros(2, dtype=torch.float64, device=self.dev.reduce_tensor.device)
 
