@@ -72,7 +72,7 @@ def run(n_cases, seed0=0, verbose=True):
                 new2 = orc.apply_update(new, dx2, points_first=False)
                 want2 = orc.eval_cost(new2, True) if linesearch else lin2
                 poses2, points2 = dev.get_params()
-                e2 = max(abs(cost2 - want2) / max(abs(want2), 1e-300), float(np.abs(poses2 - new2.poses).max()) if poses2.size else 0.)
+                e2 = max(abs(cost2 - want2) / max(abs(want2), 1e-9 * abs(c0), 1e-300), float(np.abs(poses2 - new2.poses).max()) if poses2.size else 0.)
                 # (a nearly converged second step amplifies the first step's 1e-9 differences: looser bound)
                 if not (e2 < 1e-5):
                     ok = False
