@@ -143,6 +143,7 @@ struct ps_problem {
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     int prof_every = 1;             // profiling level 1: time the Schur kernel of every n-th linearisation only
     long prof_tick = 0;
+    int cg_fallbacks = 0;           // solves repeated with the classic PCG after a breakdown of the pipelined CG
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;
     double* cg_tot = nullptr;
@@ -725,8 +726,12 @@ int cg_report(ps_problem* h, int* iters_out, double* relres_out) {
         h->lci_next = -1;                               // never reuse a factor from a failed solve
         return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
     }
-    if (h->h_status[ST_PCG_DONE] == 2)
-        return fail("CG breakdown: the reduced system is not positive definite");
+    if (h->h_status[ST_PCG_DONE] == 2) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "CG breakdown: the reduced system is not positive definite (iteration %d, relative residual %.2e)",
+                 h->h_status[ST_PCG_ITERS], rr0 > 0.0 ? std::sqrt(rrf / rr0) : 0.0);
+        return fail(buf);
+    }
     return 0;
 }
 
@@ -744,6 +749,12 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
         HIP_OK(hipStreamSynchronize(h->stream));
         done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 2;
         chunk = h->pcg_chunk;
+    }
+    if (h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL]) {
+        // the pipelined (Chronopoulos-Gear) recurrences lost positivity -- rounding on an ill-conditioned system, seen on
+        // unit right-hand sides of covariance columns -- : repeat with the classic two-launch block-Jacobi PCG
+        ++h->cg_fallbacks;
+        return pcg_run<D>(h, tol, max_iters, iters_out, relres_out);
     }
     cg_fused_recover<D>(h, nullptr);
     return cg_report(h, iters_out, relres_out);
@@ -1081,6 +1092,13 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         if (gn_tail(h, linesearch, h->status, true)) return -1;
         if (total) total->stop();                       // close the iteration timer before the sync
         if (wait_published(h)) return -1;               // k_reduce3 has published status + scalars to host memory
+        if (h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL]) {
+            // breakdown of the pipelined recurrences (the gated tail applied nothing): classic PCG, then the tail
+            ++h->cg_fallbacks;
+            if (pcg_run<D>(h, tol, max_iters, iters_out, relres_out)) return -1;
+            if (gn_tail(h, linesearch, nullptr, true) || wait_published(h)) return -1;
+            return 0;
+        }
         if (h->h_status[ST_PCG_DONE] != 0) break;
         if (h->cg_launched >= max_iters + 2) {          // not converged within max_iters: take the step anyway
             cg_fused_recover<D>(h, nullptr);

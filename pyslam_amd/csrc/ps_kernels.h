@@ -1742,7 +1742,7 @@ __global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __rest
                                                      const double* __restrict__ xh, double* __restrict__ x,
                                                      const int32_t* __restrict__ gate)
 {
-    if (gate && !gate[ST_PCG_DONE]) return;
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nr * D) return;
     const int i = t / D, c = t % D;
@@ -2437,7 +2437,7 @@ __global__ __launch_bounds__(256) void k_coarse_recover(
     const double* __restrict__ Bmat)
 {
     __shared__ double sy[400];                          // nc <= 384 (Gmax = 63 intervals, D = 6)
-    if (gate && !gate[ST_PCG_DONE]) return;
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
     const int nc = ncb * D;
     const double* xc = xh + (size_t)nr * D;
     for (int base = 0; base < nc; base += blockDim.x / 8) {
@@ -2665,7 +2665,7 @@ __global__ __launch_bounds__(256) void k_backsub(
     int P, double* __restrict__ poses, double* __restrict__ sq_part_p)
 {
     __shared__ double lds[16];
-    if (gate && !gate[ST_PCG_DONE]) return;
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
     if ((int)blockIdx.x >= nblk_l) {
         typedef PoseOps<6> G;
         const int i = (blockIdx.x - nblk_l) * blockDim.x + threadIdx.x;
@@ -2726,7 +2726,7 @@ __global__ __launch_bounds__(256) void k_update_poses(
 {
     typedef PoseOps<D> G;
     __shared__ double lds[16];
-    if (gate && !gate[ST_PCG_DONE]) return;
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double sq = 0.0;
     const int rid = (i < P) ? pose_rid[i] : -1;
@@ -2750,7 +2750,7 @@ __global__ __launch_bounds__(256) void k_update_points(
     int nv, const int32_t* __restrict__ lm_point, const double* __restrict__ dxl,
     double step, double* __restrict__ points, const int32_t* __restrict__ gate)
 {
-    if (gate && !gate[ST_PCG_DONE]) return;
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 3 * nv) return;
     points[3 * (size_t)lm_point[t / 3] + t % 3] += step * dxl[t];
@@ -2764,7 +2764,7 @@ __global__ __launch_bounds__(256) void k_cost_reproj(
     int include_all, double* __restrict__ partials, const int32_t* __restrict__ gate)
 {
     __shared__ double lds[16];
-    if (gate && !gate[ST_PCG_DONE]) return;
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
     double c = 0.0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const LObs o = lobs[i];
@@ -2790,7 +2790,7 @@ __global__ __launch_bounds__(256) void k_cost_factors(
 {
     typedef PoseOps<D> G;
     __shared__ double lds[16];
-    if (gate && !gate[ST_PCG_DONE]) return;
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
     double cst = 0.0;
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
         const int i = f_i[f], j = f_j[f];
@@ -2842,7 +2842,7 @@ __global__ __launch_bounds__(256) void k_reduce3(
     int32_t* __restrict__ arrivals /* device word, 0 between launches */, long long* __restrict__ hseq, long long seq)
 {
     __shared__ double lds[16];
-    const bool open = !(gate && !gate[ST_PCG_DONE]);
+    const bool open = !(gate && gate[ST_PCG_DONE] != 1);
     if (hst && blockIdx.x == 0) {
         const int t = threadIdx.x;
         if (t < ST_NWORDS) hst[t] = status[t];

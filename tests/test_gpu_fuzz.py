@@ -22,3 +22,12 @@ def test_random_problems_solve_like_the_oracle():
     non-decreasing steps, iteration caps).  1 580 further seeds were run when this was written (0 failures)."""
     import fuzz_solve
     assert fuzz_solve.run(60, seed0=4000, verbose=False) == 0
+
+
+@pytest.mark.gpu
+def test_random_covariance_columns_solve_the_oracle_system():
+    """tests/fuzz_cov.py: covariance columns of random small problems under random solver modes against the oracle's
+    normal matrix (P x = e_k).  This sweep found the breakdown of the pipelined CG on unit right-hand sides of SE(2)
+    graphs (fixed by the classic-PCG fallback); 600 seeds were clean when this was written."""
+    import fuzz_cov
+    assert fuzz_cov.run(80, seed0=100, verbose=False) == 0
