@@ -51,6 +51,20 @@ def run(n_cases, seed0=0, verbose=True):
                 e_p = np.abs(got - ref_lp.poses).max()
                 ok = ok and e_p < 1e-6
                 msg = 'iterations %d, pose error %.1e' % (len(hist) - 1, e_p)
+                if ok and case % 4 == 0 and ref_lp.num_reduced * ref_lp.dof + 3 * ref_lp.num_var_points <= 1200:
+                    # compute_covariance / get_covariance_block at the solution, in the reference's unknown order
+                    Pm, _, _ = orc.normal_equations(ref_lp, points_first=pf)
+                    cov = np.linalg.inv(Pm.toarray())
+                    problem.compute_covariance()
+                    part = problem._update_partition_dict
+                    keys = list(part.keys())
+                    k0, k1 = keys[int(rng.integers(len(keys)))], keys[int(rng.integers(len(keys)))]
+                    got_c = np.atleast_2d(problem.get_covariance_block(k0, k1))
+                    r0, r1 = part[k0], part[k1]
+                    want_c = np.atleast_2d(cov[r0.start:r0.stop, r1.start:r1.stop])
+                    e_c = np.abs(got_c - want_c).max() / max(np.abs(cov).max(), 1e-300)
+                    ok = e_c < 1e-6
+                    msg += ', covariance block error %.1e' % e_c
             else:
                 msg = 'iterations %d vs %d: %s | %s' % (len(hist) - 1, len(want) - 1, hist[-3:], want[-3:])
         except Exception as e:      # noqa: BLE001
