@@ -54,9 +54,12 @@ def run(n_cases, seed0=0, verbose=True):
         linesearch = bool(rng.integers(2))
         try:
             c0 = dev.eval_cost(True)
-            cost, nrm, its, rel = dev.gn_iteration(0., 1e-13, 4000, linesearch)
+            lam = float(rng.choice([0., 0., 0., 1e-3, 0.1]))      # Marquardt damping lambda * diag(J^T J)
+            cost, nrm, its, rel = dev.gn_iteration(lam, 1e-13, 4000, linesearch)
             poses, points = dev.get_params()
-            dx, lin_cost = orc.gauss_newton_step(lp, points_first=False)
+            import scipy.sparse.linalg as spla
+            Pl, bl, lin_cost = orc.normal_equations(lp, points_first=False, lm_lambda=lam)
+            dx = np.atleast_1d(spla.spsolve(Pl.tocsc(), bl))
             new = orc.apply_update(lp, dx, points_first=False)
             want = orc.eval_cost(new, True) if linesearch else lin_cost
             e_c0 = abs(c0 - orc.eval_cost(lp, True)) / max(abs(c0), 1e-300)
@@ -74,14 +77,14 @@ def run(n_cases, seed0=0, verbose=True):
                 poses2, points2 = dev.get_params()
                 e2 = max(abs(cost2 - want2) / max(abs(want2), 1e-9 * abs(c0), 1e-300), float(np.abs(poses2 - new2.poses).max()) if poses2.size else 0.)
                 # (a nearly converged second step amplifies the first step's 1e-9 differences: looser bound)
-                if not (e2 < 1e-5):
+                if not (e2 < 1e-5) and not (its2 >= 4000 and mode == 'nocoarse'):
                     ok = False
                     print('   (case %d second iteration: cost/pose error %.1e, cg %d)' % (case, e2, its2), flush=True)
             if not ok and its >= 4000 and mode == 'nocoarse':
                 ok = True          # a long chain with the coarse level switched off does not converge in 4 000 iterations: expected
             if not ok and its > 0 and its < 4000:
                 # ill-conditioned system or a wrong solve?  the device step must satisfy the ORACLE's normal equations
-                Pm, bv, _ = orc.normal_equations(lp, points_first=False)
+                Pm, bv, _ = orc.normal_equations(lp, points_first=False, lm_lambda=lam)
                 xp, xl = dev.get_dx()
                 xd = np.concatenate([xp.ravel(), xl.ravel()])
                 res = np.linalg.norm(Pm @ xd - bv) / np.linalg.norm(bv)
