@@ -31,3 +31,10 @@ def test_random_covariance_columns_solve_the_oracle_system():
     graphs (fixed by the classic-PCG fallback); 600 seeds were clean when this was written."""
     import fuzz_cov
     assert fuzz_cov.run(80, seed0=100, verbose=False) == 0
+
+
+@pytest.mark.gpu
+def test_random_ransac_and_photometric_cases_match_their_oracles():
+    """tests/fuzz_small.py: frame-to-frame RANSAC and the dense photometric aligner on random scenes (3 000 seeds clean)."""
+    import fuzz_small
+    assert fuzz_small.run(120, seed0=5000, verbose=False) == 0
