@@ -20,16 +20,25 @@ def run(n_cases, seed0=0, verbose=True):
     t_start = time.time()
     for case in range(seed0, seed0 + n_cases):
         rng = np.random.default_rng(1000 + case)
-        kind = rng.choice(['ba', 'ba', 'pg3', 'pg2', 'mo'])
+        kind = rng.choice(['ba', 'ba', 'mix', 'pg3', 'pg2', 'mo'])
         loss = LOSSES[rng.integers(len(LOSSES))]()
         opts = {}
-        if kind == 'ba':
+        if kind in ('ba', 'mix'):
             kf = int(rng.choice([3, 5, 9, 17, 24, 33, 40, 70, 130, 260, 300]))
             obs = int(rng.integers(2, min(kf, 7) + 1))
             lm = int(rng.integers(max(10, 30 * kf // obs), 30 * kf // obs + 15 * kf + 20))      # >= 30 observations per keyframe
             lp, _ = synthetic.stereo_ba(num_kf=kf, num_lm=lm, obs_per_lm=obs, half_window=int(rng.integers(obs, 3 * obs + 2)),
                                         seed=case, loss=loss, const_point_fraction=float(rng.choice([0., 0., 0.1, 0.3])))
             desc = 'BA kf %d lm %d obs %d' % (kf, lm, obs)
+            if kind == 'mix':
+                # reprojection blocks AND pose-pose edges / a prior over the same keyframes (odometry + loop closures
+                # next to the visual constraints): the edge tables of a pose graph with as many poses
+                pg, _ = synthetic.pose_graph(num_poses=kf, num_loops=int(rng.integers(0, 2 * kf)), dof=6, seed=case + 1,
+                                             loss=LOSSES[rng.integers(len(LOSSES))](), orientation_loops=bool(rng.integers(3) == 0))
+                for name in ('e_i', 'e_j', 'e_Tobs_inv', 'e_grp', 'u_i', 'u_Tobs_inv', 'u_grp', 'stiffd', 'edge_groups'):
+                    setattr(lp, name, getattr(pg, name).copy())
+                lp.validate()
+                desc = 'BA+edges kf %d lm %d edges %d' % (kf, lm, lp.num_edges)
         elif kind in ('pg3', 'pg2'):
             P = int(rng.choice([4, 7, 15, 16, 17, 31, 32, 33, 90, 151, 200, 450, 700]))
             lp, _ = synthetic.pose_graph(num_poses=P, num_loops=int(rng.integers(0, 4 * P)), dof=6 if kind == 'pg3' else 3,
