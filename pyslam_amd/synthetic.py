@@ -198,6 +198,20 @@ def pose_graph(num_poses=10000, num_loops=40001, dof=6, seed=2, loss=None,
 # ---------------------------------------------------------------------------
 # C5: sliding-window stereo VO (one pose, N fixed points, robust loss)
 # ---------------------------------------------------------------------------
+def with_pose_edges(lp, num_loops, seed, loss=None, orientation_loops=False):
+    """A stereo-BA problem plus the odometry / loop-closure edges and the first-pose prior of a pose graph over the same
+    keyframes (mixed visual + relative-pose constraints, as sliding-window VO with odometry would pose them).  The edge
+    measurements come from ``pose_graph``'s own trajectory, so they disagree with the visual constraints: a valid
+    (if unhappy) nonlinear least-squares problem for parity tests."""
+    pg, _ = pose_graph(num_poses=lp.num_poses, num_loops=num_loops, dof=6, seed=seed, loss=loss,
+                       orientation_loops=orientation_loops)
+    out = lp.copy()
+    for name in ('e_i', 'e_j', 'e_Tobs_inv', 'e_grp', 'u_i', 'u_Tobs_inv', 'u_grp', 'stiffd', 'edge_groups'):
+        setattr(out, name, getattr(pg, name).copy())
+    out.validate()
+    return out
+
+
 def motion_only(num_pts=256, seed=3, loss=None, outlier_fraction=0.2):
     loss = loss if loss is not None else losses.CauchyLoss(3.0)
     cam5 = np.array(STEREO_BA_CAMERA[:5])
