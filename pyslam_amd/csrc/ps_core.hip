@@ -721,6 +721,10 @@ int cg_report(ps_problem* h, int* iters_out, double* relres_out) {
     if (iters_out) *iters_out = h->h_status[ST_PCG_ITERS];
     const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
     if (relres_out) *relres_out = rr0 > 0.0 ? std::sqrt(rrf / rr0) : 0.0;
+    if (h->h_status[ST_LM_FAIL]) {                           // (its NaNs also spoil the reduced system: report the cause)
+        h->lci_next = -1;
+        return fail("a landmark block H_ll is not positive definite");
+    }
     if (h->h_status[ST_DIAG_FAIL]) {
         if (h->lag_status) hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream);
         h->lci_next = -1;                               // never reuse a factor from a failed solve
