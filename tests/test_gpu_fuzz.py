@@ -38,3 +38,10 @@ def test_random_ransac_and_photometric_cases_match_their_oracles():
     """tests/fuzz_small.py: frame-to-frame RANSAC and the dense photometric aligner on random scenes (3 000 seeds clean)."""
     import fuzz_small
     assert fuzz_small.run(120, seed0=5000, verbose=False) == 0
+
+
+@pytest.mark.gpu
+def test_random_landmark_shards_add_up():
+    """tests/fuzz_shards.py: 2-6 landmark shards of random (also mixed, damped) problems sum to the unsharded system."""
+    import fuzz_shards
+    assert fuzz_shards.run(40, seed0=900, verbose=False) == 0
