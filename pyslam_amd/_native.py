@@ -111,6 +111,26 @@ class NativeError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so.7; the core links /opt/rocm's under the same soname.  Whichever is
+    loaded first serves both (the dynamic loader dedups by soname), and torch on top of ROCm's copy finds no GPU
+    ("ProcessGroupNCCL is only supported with GPUs").  So when torch is installed its runtime goes in first -- without
+    importing torch: the multi-GPU driver and callers' own torch code keep working whatever the import order."""
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:       # noqa: BLE001  (best effort: without it the core still runs on ROCm's runtime)
+        pass
+
+
 def load():
     """dlopen the HIP core; raise loudly if it is missing (no CPU fallback)."""
     global _lib
@@ -120,6 +140,7 @@ def load():
         raise NativeError(
             "{} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). pyslam_amd has no CPU solver path.".format(LIB_PATH))
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

@@ -198,16 +198,26 @@ def pose_graph(num_poses=10000, num_loops=40001, dof=6, seed=2, loss=None,
 # ---------------------------------------------------------------------------
 # C5: sliding-window stereo VO (one pose, N fixed points, robust loss)
 # ---------------------------------------------------------------------------
-def with_pose_edges(lp, num_loops, seed, loss=None, orientation_loops=False):
+def with_pose_edges(lp, num_loops, seed, loss=None, orientation_loops=False, truth_poses=None):
     """A stereo-BA problem plus the odometry / loop-closure edges and the first-pose prior of a pose graph over the same
-    keyframes (mixed visual + relative-pose constraints, as sliding-window VO with odometry would pose them).  The edge
-    measurements come from ``pose_graph``'s own trajectory, so they disagree with the visual constraints: a valid
-    (if unhappy) nonlinear least-squares problem for parity tests."""
+    keyframes (mixed visual + relative-pose constraints, as sliding-window VO with odometry would pose them).  Without
+    ``truth_poses`` the edge measurements come from ``pose_graph``'s own trajectory and disagree with the visual
+    constraints (a valid, if unhappy, problem for single-step parity); with the BA's true poses they are consistent."""
     pg, _ = pose_graph(num_poses=lp.num_poses, num_loops=num_loops, dof=6, seed=seed, loss=loss,
                        orientation_loops=orientation_loops)
     out = lp.copy()
     for name in ('e_i', 'e_j', 'e_Tobs_inv', 'e_grp', 'u_i', 'u_Tobs_inv', 'u_grp', 'stiffd', 'edge_groups'):
         setattr(out, name, getattr(pg, name).copy())
+    if truth_poses is not None:
+        # measurements of the BA's own true trajectory (+ 1 % noise): visual and relative-pose constraints agree
+        T = np.asarray(truth_poses)
+        rng = np.random.default_rng([seed, 9])
+        rel = np.einsum('nij,njk->nik', T[out.e_j], _inv_many(T[out.e_i]))
+        meas = np.einsum('nij,njk->nik', _exp_many(0.01 * rng.standard_normal((out.e_i.size, 6))), rel)
+        meas[out.e_grp == 2, :3, 3] = 0.               # rotation-only loop closures: T_obs = (C_obs, 0)
+        out.e_Tobs_inv = pack_pose_matrices(_inv_many(meas)) if out.e_i.size else out.e_Tobs_inv
+        if out.u_i.size:
+            out.u_Tobs_inv = pack_pose_matrices(_inv_many(T[out.u_i]))
     out.validate()
     return out
 

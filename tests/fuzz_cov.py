@@ -21,11 +21,11 @@ def run(n_cases, seed0=0, verbose=True):
         kind = rng.choice(['ba', 'ba', 'pg3', 'pg2'])
         if kind == 'ba':
             kf, obs = int(rng.choice([3, 6, 12, 20, 40])), int(rng.integers(2, 5))
-            lp, _ = synthetic.stereo_ba(num_kf=kf, num_lm=int(rng.integers(30 * kf // obs, 30 * kf // obs + 60)), obs_per_lm=min(obs, kf),
+            lp, truth = synthetic.stereo_ba(num_kf=kf, num_lm=int(rng.integers(30 * kf // obs, 30 * kf // obs + 60)), obs_per_lm=min(obs, kf),
                                         half_window=int(rng.integers(obs, 2 * obs + 3)), seed=case, loss=loss,
                                         const_point_fraction=float(rng.choice([0., 0.2])))
             if kf >= 3 and rng.integers(3) == 0:        # + pose-pose edges and a prior over the same keyframes
-                lp = synthetic.with_pose_edges(lp, int(rng.integers(0, 2 * kf)), case + 1, loss=loss)
+                lp = synthetic.with_pose_edges(lp, int(rng.integers(0, 2 * kf)), case + 1, loss=loss, truth_poses=truth['poses'])
         else:
             P = int(rng.choice([5, 14, 17, 40, 120, 300]))
             lp, _ = synthetic.pose_graph(num_poses=P, num_loops=int(rng.integers(1, 3 * P)), dof=6 if kind == 'pg3' else 3,

@@ -24,11 +24,11 @@ def run(n_cases, seed0=0, verbose=True):
         kind = rng.choice(['ba', 'pg3', 'pg2'])
         if kind == 'ba':
             kf, obs = int(rng.choice([3, 4, 6, 10, 18])), int(rng.integers(2, 4))
-            lp, _ = synthetic.stereo_ba(num_kf=kf, num_lm=int(rng.integers(30 * kf // obs, 60 * kf // obs)), obs_per_lm=obs,
+            lp, truth = synthetic.stereo_ba(num_kf=kf, num_lm=int(rng.integers(30 * kf // obs, 60 * kf // obs)), obs_per_lm=obs,
                                         half_window=int(rng.integers(obs, 2 * obs + 2)), seed=case, loss=loss,
                                         const_point_fraction=float(rng.choice([0., 0.2])))
             if kf >= 3 and rng.integers(3) == 0:        # + pose-pose edges and a prior over the same keyframes
-                lp = synthetic.with_pose_edges(lp, int(rng.integers(0, 2 * kf)), case + 1, loss=loss)
+                lp = synthetic.with_pose_edges(lp, int(rng.integers(0, 2 * kf)), case + 1, loss=loss, truth_poses=truth['poses'])
         else:
             P = int(rng.choice([4, 6, 12, 17, 40]))
             lp, _ = synthetic.pose_graph(num_poses=P, num_loops=int(rng.integers(1, 3 * P)), dof=6 if kind == 'pg3' else 3,

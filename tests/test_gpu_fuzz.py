@@ -45,3 +45,5 @@ def test_random_landmark_shards_add_up():
     """tests/fuzz_shards.py: 2-6 landmark shards of random (also mixed, damped) problems sum to the unsharded system."""
     import fuzz_shards
     assert fuzz_shards.run(40, seed0=900, verbose=False) == 0
+    # the sharded driver itself with one rank (native RCCL and torch.distributed paths, explicit / folded CG)
+    assert fuzz_shards.run_one_rank(24, seed0=900, verbose=False) == 0
