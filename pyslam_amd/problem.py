@@ -281,8 +281,9 @@ class Problem:
     def solve_one_iter(self):
         """One Gauss-Newton step: (step * dx, cost); parameters are NOT updated
         (reference problem.py:182-194)."""
-        if not self._update_partition_dict:
-            self._update_partition_dict = self._get_update_partition_dict()
+        # the reference orders dx by the CURRENT non-constant parameters (block_cidx_dict is rebuilt on every call,
+        # problem.py:294-303): recompute, a partition left by an earlier solve() may be stale after freeze / release
+        self._update_partition_dict = self._get_update_partition_dict()
         opt = self.options
         try:
             dev = self._get_device()
@@ -365,8 +366,7 @@ class Problem:
 
     def compute_covariance(self):
         try:
-            if not self._update_partition_dict:
-                self._update_partition_dict = self._get_update_partition_dict()
+            self._update_partition_dict = self._get_update_partition_dict()      # (never stale: see solve_one_iter)
             self._covariance_matrix = None
             self._cov_columns = {}
             try:

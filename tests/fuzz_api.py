@@ -1,0 +1,109 @@
+"""Randomised sweep of Problem-API SEQUENCES: one Problem object lives through several solves while parameters are
+frozen / released (set_parameters_constant / _variable), with eval_cost, solve_one_iter and compute_covariance calls in
+between -- the device handle is reused or rebuilt as the structure changes (pyslam_amd/problem.py:_get_device).  After
+every change the current object graph is lowered again and the oracle solves that table; cost histories and final
+parameters must agree.  usage: python tests/fuzz_api.py [cases] [seed0]"""
+import os, sys, time
+root = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [root, os.path.join(root, 'tests')]
+import numpy as np
+from oracle import gn_oracle as orc
+from pyslam_amd import synthetic, losses
+from test_host_api import build_namespace
+
+LOSSES = [lambda: losses.L2Loss(), lambda: losses.HuberLoss(1.5), lambda: losses.CauchyLoss(3.0)]
+
+
+def run(n_cases, seed0=0, verbose=True):
+    bad = 0
+    ns = build_namespace()
+    t0 = time.time()
+    for case in range(seed0, seed0 + n_cases):
+        rng = np.random.default_rng(64000 + case)
+        loss = LOSSES[rng.integers(len(LOSSES))]()
+        kind = rng.choice(['ba', 'mix', 'pg3', 'pg2'])
+        if kind in ('ba', 'mix'):
+            kf, obs = int(rng.choice([4, 6, 10, 18])), int(rng.integers(2, 4))
+            lp, truth = synthetic.stereo_ba(num_kf=kf, num_lm=int(rng.integers(40 * kf // obs, 70 * kf // obs)), obs_per_lm=obs,
+                                            half_window=int(rng.integers(obs, 2 * obs + 2)), seed=case, loss=loss)
+            if kind == 'mix':
+                lp = synthetic.with_pose_edges(lp, int(rng.integers(0, 2 * kf)), case + 1, loss=loss, truth_poses=truth['poses'])
+        else:
+            P = int(rng.choice([5, 9, 17, 40]))
+            lp, _ = synthetic.pose_graph(num_poses=P, num_loops=int(rng.integers(P, 3 * P)), dof=6 if kind == 'pg3' else 3, seed=case, loss=loss)
+        opts = dict(allow_nondecreasing_steps=True, max_nondecreasing_steps=3, linesearch_max_iters=int(rng.choice([0, 10])),
+                    max_iters=int(rng.choice([3, 20])), min_cost_decrease=0.99)
+        pf = bool(rng.integers(2))
+        opt = ns.Options()
+        for k, v in opts.items():
+            setattr(opt, k, v)
+        log = []
+        try:
+            problem = synthetic.to_objects(lp, ns, opt, points_first=pf)
+            pose_keys = [k for k in problem.param_dict if k.startswith('T')]
+            point_keys = [k for k in problem.param_dict if k.startswith('pt')]
+            ok, msg = True, ''
+            for step in range(int(rng.integers(2, 5))):
+                op = rng.choice(['freeze_poses', 'release', 'freeze_points', 'perturb', 'nothing'])
+                if op == 'freeze_poses' and len(pose_keys) > 3:
+                    problem.set_parameters_constant([str(k) for k in rng.choice(pose_keys[1:], size=min(2, len(pose_keys) - 2), replace=False)])
+                elif op == 'release':
+                    frozen = [k for k in problem.constant_param_keys if k not in (pose_keys[:1])]
+                    if frozen:
+                        problem.set_parameters_variable(frozen[: int(rng.integers(1, len(frozen) + 1))])
+                elif op == 'freeze_points' and point_keys:
+                    problem.set_parameters_constant([str(k) for k in rng.choice(point_keys, size=min(5, len(point_keys)), replace=False)])
+                elif op == 'perturb':
+                    for k in pose_keys[1:3]:
+                        if k not in problem.constant_param_keys:
+                            problem.param_dict[k].perturb(0.01 * rng.standard_normal(problem.param_dict[k].dof))
+                log.append(op)
+                cur = problem._lower()
+                if cur.num_reduced == 0 and cur.num_var_points == 0:
+                    continue
+                c_dev = problem.eval_cost()
+                c_orc = orc.eval_cost(cur, True)
+                if rng.integers(3) == 0:
+                    dx, _ = problem.solve_one_iter()              # must not move the parameters
+                    if abs(problem.eval_cost() - c_dev) > 1e-12 * abs(c_dev):
+                        ok, msg = False, 'solve_one_iter moved the parameters'
+                        break
+                ref_lp, ref = orc.solve(cur, opts, points_first=pf)
+                problem.solve()
+                hist, want = np.array(problem._cost_history), ref['cost_history']
+                after = problem._lower()
+                e_p = np.abs(after.poses - ref_lp.poses).max() if after.num_poses else 0.
+                e_l = np.abs(after.points - ref_lp.points).max() if after.num_points else 0.
+                big = want > 1e-9 * want[0]
+                if not (abs(c_dev - c_orc) <= 1e-10 * abs(c_orc) and len(hist) == len(want) and np.allclose(hist[big], want[big], rtol=1e-6)
+                        and e_p < 1e-6 and e_l < 1e-5):
+                    ok, msg = False, 'step %d (%s): cost %.3e vs %.3e, iterations %d vs %d, pose %.1e point %.1e' % (
+                        step, op, c_dev, c_orc, len(hist) - 1, len(want) - 1, e_p, e_l)
+                    break
+                if rng.integers(4) == 0:
+                    problem.compute_covariance()
+                    part = problem._update_partition_dict
+                    if part:
+                        k0 = list(part.keys())[int(rng.integers(len(part)))]
+                        Pm, _, _ = orc.normal_equations(after, points_first=pf)
+                        if Pm.shape[0] <= 1200:
+                            cov = np.linalg.inv(Pm.toarray())
+                            r0 = part[k0]
+                            e_c = np.abs(np.atleast_2d(problem.get_covariance_block(k0, k0)) - cov[r0.start:r0.stop, r0.start:r0.stop]).max() / np.abs(cov).max()
+                            if e_c > 1e-6:
+                                ok, msg = False, 'covariance block %s error %.1e' % (k0, e_c)
+                                break
+            msg = msg or 'ops %s' % log
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            ok, msg = False, 'EXCEPTION %r after %s\\n%s' % (e, log, traceback.format_exc()[-400:])
+        bad += not ok
+        if verbose and (not ok or case % 20 == 0):
+            print('%s case %d %s poses %d obs %d edges %d  %s' % ('ok  ' if ok else 'FAIL', case, kind, lp.num_poses, lp.num_obs, lp.num_edges, msg), flush=True)
+    if verbose:
+        print('%d cases, %d failures, %.0f s' % (n_cases, bad, time.time() - t0))
+    return bad
+
+
+if __name__ == '__main__':
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)

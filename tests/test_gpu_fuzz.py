@@ -47,3 +47,12 @@ def test_random_landmark_shards_add_up():
     assert fuzz_shards.run(40, seed0=900, verbose=False) == 0
     # the sharded driver itself with one rank (native RCCL and torch.distributed paths, explicit / folded CG)
     assert fuzz_shards.run_one_rank(24, seed0=900, verbose=False) == 0
+
+
+@pytest.mark.gpu
+def test_random_api_sequences_match_the_oracle():
+    """tests/fuzz_api.py: one Problem through several solves with parameters frozen / released / perturbed in between,
+    eval_cost, solve_one_iter and compute_covariance calls interleaved (device handle reused or rebuilt).  This sweep
+    found solve_one_iter using the partition of an earlier solve() after parameters had been released."""
+    import fuzz_api
+    assert fuzz_api.run(50, seed0=300, verbose=False) == 0
