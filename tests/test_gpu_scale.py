@@ -277,3 +277,27 @@ def test_explicit_and_folded_two_level_cg_agree_on_a_long_chain():
         assert np.linalg.norm(out[name][1] - ref) <= 1e-8 * np.linalg.norm(ref), name
     assert abs(out['explicit'][0] - out['folded'][0]) <= 0.1 * out['folded'][0] + 5
     assert out['explicit_fine'][0] < 0.6 * out['explicit'][0]
+
+
+@pytest.mark.parametrize('kf,lm,with_edges', [(560, 14000, False), (640, 12000, True)])
+def test_mid_size_ba_uses_the_explicit_pcg_and_matches_the_oracle(kf, lm, with_edges):
+    """Beyond 540 reduced poses bundle adjustment runs the explicitly applied two-level preconditioner by default
+    (second iteration: with the lagged side-stream coarse inverse); two Gauss-Newton iterations against the oracle's
+    CPU Schur solve, also with pose-pose edges and a prior over the same keyframes."""
+    from pyslam_amd import losses
+    loss = losses.HuberLoss(1.5) if with_edges else losses.L2Loss()
+    lp, truth = synthetic.stereo_ba(num_kf=kf, num_lm=lm, obs_per_lm=6, half_window=12, seed=kf, loss=loss)
+    if with_edges:
+        lp = synthetic.with_pose_edges(lp, kf, kf + 1, loss=loss, truth_poses=truth['poses'])
+    dev = device(lp)
+    cur = lp
+    for it in range(2):
+        cost, nrm, its, rel = dev.gn_iteration(0., 1e-13, 4000, True)
+        P, b, _ = orc.normal_equations(cur, points_first=False)
+        dx = orc.schur_solve(cur, P, b, points_first=False)
+        cur = orc.apply_update(cur, dx, points_first=False)
+        want = orc.eval_cost(cur, True)
+        poses, points = dev.get_params()
+        assert 0 < its < 200 and rel <= 1e-12
+        assert abs(cost - want) <= 1e-9 * want and abs(nrm - np.linalg.norm(dx)) <= 1e-8 * np.linalg.norm(dx)
+        assert np.abs(poses - cur.poses).max() < 1e-9 and np.abs(points - cur.points).max() < 1e-8
