@@ -1,0 +1,521 @@
+// ps_k_linearize.h -- landmark pass, pose pass, Schur pair / combine kernels, pose-pose and prior factors.
+// Part of ps_kernels.h (included from there, in this order; not a stand-alone header).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// landmark pass: 16 lanes cooperate on one landmark (4 landmarks per wave), one observation
+// per lane: loads of the 32-byte records and stores of the 144-byte Z rows are contiguous
+// across lanes, residual + both Jacobians are evaluated ONCE, and H_ll / b_l are reduced with
+// a 4-step xor butterfly inside the 16-lane group (fixed order => deterministic).
+// Landmarks with more than 16 observations loop (lane j takes observations j, j+16, ...) and
+// re-evaluate in a second sweep to emit Z.
+// ---------------------------------------------------------------------------
+#define PS_LM_GROUP 16
+
+PS_DEV double group16_sum(double v) {          // a 16-lane group is exactly one DPP row
+    v = dpp_shift_add<0x111, 0xf, 0xf>(v);
+    v = dpp_shift_add<0x112, 0xf, 0xf>(v);
+    v = dpp_shift_add<0x114, 0xf, 0xe>(v);
+    v = dpp_shift_add<0x118, 0xf, 0xc>(v);      // lane 15 of the row holds the group total
+    return __shfl(v, (int)(threadIdx.x & 63) | 15, 64);
+}
+
+PS_DEV void lm_emit_z(const ReprojEval& ev, double M00, double M10, double M11, double M20, double M21,
+                      double M22, double* __restrict__ z) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const double w0 = ev.Jp[a] * ev.Jl[0] + ev.Jp[6 + a] * ev.Jl[3] + ev.Jp[12 + a] * ev.Jl[6];
+        const double w1 = ev.Jp[a] * ev.Jl[1] + ev.Jp[6 + a] * ev.Jl[4] + ev.Jp[12 + a] * ev.Jl[7];
+        const double w2 = ev.Jp[a] * ev.Jl[2] + ev.Jp[6 + a] * ev.Jl[5] + ev.Jp[12 + a] * ev.Jl[8];
+        z[3 * a] = w0 * M00;
+        z[3 * a + 1] = w0 * M10 + w1 * M11;
+        z[3 * a + 2] = w0 * M20 + w1 * M21 + w2 * M22;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_landmark_pass(
+    int nv, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_point,
+    const LObs* __restrict__ lobs, const double* __restrict__ poses,
+    const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
+    const ObsGroup* __restrict__ groups, double lambda,
+    double* __restrict__ Z, double* __restrict__ Cinv, double* __restrict__ cvec,
+    int32_t* __restrict__ status, int ablate)
+{
+    const int v = blockIdx.x * (blockDim.x / PS_LM_GROUP) + threadIdx.x / PS_LM_GROUP;
+    const int sub = threadIdx.x & (PS_LM_GROUP - 1);
+    const bool live = v < nv;                       // whole 16-lane groups are live or not
+    int b = 0, e = 0;
+    double pw[3] = {0.0, 0.0, 0.0};
+    if (live) {
+        b = lm_ptr[v]; e = lm_ptr[v + 1];
+        const int pt = lm_point[v];
+        pw[0] = points[3 * pt]; pw[1] = points[3 * pt + 1]; pw[2] = points[3 * pt + 2];
+    }
+    const bool single = (e - b) <= PS_LM_GROUP;     // the common case: one observation per lane
+
+    double H00 = 0, H10 = 0, H11 = 0, H20 = 0, H21 = 0, H22 = 0, b0 = 0, b1 = 0, b2 = 0;
+    ReprojEval ev;
+    bool have = false, variable_pose = false;
+    for (int i = b + sub; i < e; i += PS_LM_GROUP) {
+        const LObs o = lobs[i];
+        const int pose = PS_POSE_OF(o);
+        const Se3 T = se3_load(poses + 12 * pose);
+        variable_pose = pose_rid[pose] >= 0;
+        reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        have = true;
+        const double* J = ev.Jl;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            H00 += J[3 * k] * J[3 * k];
+            H10 += J[3 * k + 1] * J[3 * k];
+            H11 += J[3 * k + 1] * J[3 * k + 1];
+            H20 += J[3 * k + 2] * J[3 * k];
+            H21 += J[3 * k + 2] * J[3 * k + 1];
+            H22 += J[3 * k + 2] * J[3 * k + 2];
+            b0 -= J[3 * k] * ev.r[k];
+            b1 -= J[3 * k + 1] * ev.r[k];
+            b2 -= J[3 * k + 2] * ev.r[k];
+        }
+    }
+    H00 = group16_sum(H00); H10 = group16_sum(H10); H11 = group16_sum(H11);
+    H20 = group16_sum(H20); H21 = group16_sum(H21); H22 = group16_sum(H22);
+    b0 = group16_sum(b0); b1 = group16_sum(b1); b2 = group16_sum(b2);
+
+    const double damp = 1.0 + lambda;
+    H00 *= damp; H11 *= damp; H22 *= damp;
+    // H_ll = C C^T
+    const double l00 = sqrt(H00);
+    const double l10 = H10 / l00, l20 = H20 / l00;
+    const double d1 = H11 - l10 * l10;
+    const double l11 = sqrt(d1);
+    const double l21 = (H21 - l20 * l10) / l11;
+    const double d2 = H22 - l20 * l20 - l21 * l21;
+    const double l22 = sqrt(d2);
+    // M = C^-1 (lower)
+    const double M00 = 1.0 / l00, M11 = 1.0 / l11, M22 = 1.0 / l22;
+    const double M10 = -l10 * M00 * M11;
+    const double M21 = -l21 * M11 * M22;
+    const double M20 = -(l20 * M00 + l21 * M10) * M22;
+    if (live && sub == 0) {
+        if (!(H00 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) atomicAdd(&status[ST_LM_FAIL], 1);
+        double* ci = Cinv + 6 * (size_t)v;
+        ci[0] = M00; ci[1] = M10; ci[2] = M11; ci[3] = M20; ci[4] = M21; ci[5] = M22;
+        double* cv = cvec + 3 * (size_t)v;
+        cv[0] = M00 * b0;
+        cv[1] = M10 * b0 + M11 * b1;
+        cv[2] = M20 * b0 + M21 * b1 + M22 * b2;
+    }
+    // ---- Z rows.  Common case (every landmark of the wave has <= 16 observations): the wave's rows are
+    // one contiguous range of Z, so they are transposed through LDS and stored as whole 16-byte pieces by
+    // consecutive lanes (1 KB per store instruction) instead of 18 stride-144 8-byte stores per lane.
+    __shared__ __attribute__((aligned(16))) double zst[4][64 * 18];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (__ballot(single || !live) == ~0ull && !(ablate & 2)) {
+        const int row0 = __shfl(b, 0, 64);                       // dead groups carry b = e = 0
+        const int eend = max(max(__shfl(e, 0, 64), __shfl(e, 16, 64)), max(__shfl(e, 32, 64), __shfl(e, 48, 64)));
+        const int nrows = eend - row0;
+        if (have) {
+            double z[18];
+            if (variable_pose) lm_emit_z(ev, M00, M10, M11, M20, M21, M22, z);
+            else {
+#pragma unroll
+                for (int k = 0; k < 18; ++k) z[k] = 0.0;         // rows of constant poses are never read
+            }
+            double2* dst = reinterpret_cast<double2*>(&zst[wv][18 * (b + sub - row0)]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dst[k] = make_double2(z[2 * k], z[2 * k + 1]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!(ablate & 1)) {
+            const double2* src = reinterpret_cast<const double2*>(zst[wv]);
+            double2* out = reinterpret_cast<double2*>(Z + 18 * (size_t)row0);
+            for (int k = lane; k < nrows * 9; k += 64) out[k] = src[k];
+        }
+        return;
+    }
+    if (!live) return;
+    if (single) {
+        if (have && variable_pose && !(ablate & 1)) lm_emit_z(ev, M00, M10, M11, M20, M21, M22, Z + 18 * (size_t)(b + sub));
+        return;
+    }
+    for (int i = b + sub; i < e; i += PS_LM_GROUP) {
+        const LObs o = lobs[i];
+        const int pose = PS_POSE_OF(o);
+        if (pose_rid[pose] < 0) continue;
+        const Se3 T = se3_load(poses + 12 * pose);
+        reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        lm_emit_z(ev, M00, M10, M11, M20, M21, M22, Z + 18 * (size_t)i);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pose pass: 33 sums per chunk = 21 (upper J^T J - Z Z^T) + 6 (g) + 6 (diag J^T J, for damping)
+// ---------------------------------------------------------------------------
+// One workgroup per chunk of one pose's observations (256, or 1024 = four per thread on big
+// problems so that the 33 wave reductions are paid once per four observations).  Observation
+// records come from a pose-sorted copy (contiguous) that carries the landmark slot, and the pose
+// is uniform per workgroup.  The Z row of an observation is NOT read back from HBM (144 B each,
+// scattered: that read alone cost 15 of this kernel's 37 us): it is recomputed in registers from
+// the Jacobians this kernel evaluates anyway and the landmark's 48-byte factor C^-1 (an L2-resident
+// table) -- lm_emit_z on the same inputs, so the values are those the landmark pass stored.
+#define PS_NPOSE_ACC 33
+typedef const __attribute__((address_space(1))) void* ps_gptr_t;
+typedef __attribute__((address_space(3))) void* ps_lptr_t;
+
+__global__ __launch_bounds__(256) void k_pose_pass(
+    const PItem* __restrict__ items,
+    const LObs* __restrict__ pobs /* observation records in pose order, landmark slot + 1 in the pose bits */,
+    const double* __restrict__ poses, const double* __restrict__ points,
+    const ObsGroup* __restrict__ groups, const double* __restrict__ Cinv,
+    const double* __restrict__ cvec, double* __restrict__ partial)
+{
+    __shared__ double red[4][PS_NPOSE_ACC];
+    const PItem it = items[blockIdx.x];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const Se3 T = se3_load(poses + 12 * (size_t)it.pad);          // pad = pose table index of this chunk
+    double acc[PS_NPOSE_ACC];
+#pragma unroll
+    for (int k = 0; k < PS_NPOSE_ACC; ++k) acc[k] = 0.0;
+    for (int i = it.start + threadIdx.x; i < it.end; i += 256) {
+        const LObs o = pobs[i];
+        const int v = PS_POSE_OF(o) - 1;                           // -1: constant landmark, no Schur term
+        const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
+        double m[6] = {0, 0, 0, 0, 0, 0}, c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if (v >= 0) {
+            const double* ci = Cinv + 6 * (size_t)v;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[k] = ci[k];
+            c0 = cvec[3 * (size_t)v]; c1 = cvec[3 * (size_t)v + 1]; c2 = cvec[3 * (size_t)v + 2];
+        }
+        ReprojEval ev;
+        reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b)
+                acc[n++] += ev.Jp[a] * ev.Jp[b] + ev.Jp[6 + a] * ev.Jp[6 + b] + ev.Jp[12 + a] * ev.Jp[12 + b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            acc[21 + a] -= ev.Jp[a] * ev.r[0] + ev.Jp[6 + a] * ev.r[1] + ev.Jp[12 + a] * ev.r[2];
+            acc[27 + a] += ev.Jp[a] * ev.Jp[a] + ev.Jp[6 + a] * ev.Jp[6 + a] + ev.Jp[12 + a] * ev.Jp[12 + a];
+        }
+        if (v >= 0) {
+            double z[18];
+            lm_emit_z(ev, m[0], m[1], m[2], m[3], m[4], m[5], z);
+            n = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b)
+                    acc[n++] -= z[3 * a] * z[3 * b] + z[3 * a + 1] * z[3 * b + 1] + z[3 * a + 2] * z[3 * b + 2];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+                acc[21 + a] -= z[3 * a] * c0 + z[3 * a + 1] * c1 + z[3 * a + 2] * c2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PS_NPOSE_ACC; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) red[w][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < PS_NPOSE_ACC)
+        partial[(size_t)blockIdx.x * PS_NPOSE_ACC + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// one wave (64 lanes, 33 active) per reduced pose: chunk partials -> diagonal S block, g
+PS_DEV void pose_finalize_wave(int rid, int lane, const int32_t* __restrict__ pitem_ptr,
+                               const double* __restrict__ partial, const int32_t* __restrict__ diag_slot,
+                               double lambda, double* __restrict__ S, double* __restrict__ g, double* v /* LDS, 33 */)
+{
+    if (lane < PS_NPOSE_ACC) {
+        double s = 0.0;
+        for (int it = pitem_ptr[rid]; it < pitem_ptr[rid + 1]; ++it) s += partial[(size_t)it * PS_NPOSE_ACC + lane];
+        v[lane] = s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        const int idx = a * 6 - (a * (a - 1)) / 2 + (b - a);   // upper-triangle packed index
+        double val = v[idx];
+        if (r == c) val += lambda * v[27 + r];
+        S[(size_t)diag_slot[rid] * 36 + lane] += val;
+    }
+    if (lane < 6) g[(size_t)rid * 6 + lane] += v[21 + lane];
+}
+
+__global__ __launch_bounds__(64) void k_pose_finalize(
+    int nr, const int32_t* __restrict__ pitem_ptr, const double* __restrict__ partial,
+    const int32_t* __restrict__ diag_slot, double lambda,
+    double* __restrict__ S, double* __restrict__ g)
+{
+    __shared__ double v[PS_NPOSE_ACC];
+    pose_finalize_wave(blockIdx.x, threadIdx.x, pitem_ptr, partial, diag_slot, lambda, S, g, v);
+}
+
+// ---------------------------------------------------------------------------
+// Schur off-diagonal blocks: one wave per reduced-system block
+// ---------------------------------------------------------------------------
+// XCD-aware work order: workgroup b runs on XCD b % 8 (observed dispatch rule; affects speed
+// only), and order[] lists, per XCD, the blocks of a CONTIGUOUS range of block rows.  All blocks
+// that share pose ri's Z rows (and, for neighbouring rows, pose rj's) then hit the same 4 MB L2
+// instead of being re-fetched by all eight.
+//
+// Z rows are 144 B and scattered, so a lane-per-pair gather issues 18 fully divergent 16-byte
+// loads per pair (41 M L1 accesses at C3).  Instead each wave moves the 64 rows of a 32-pair
+// chunk straight into LDS with global_load_lds_dwordx4 (no staging registers, no ds_write pass):
+// 9 consecutive lanes fetch the 9 x 16 B of ONE row, 7 rows per instruction, and because the
+// LDS destination of lane l is base + 16 l the rows land at their natural 144-byte stride, which
+// is conflict-free for the ds_read_b128 of the compute phase.  Two lanes share a pair (lane
+// p + 32 h accumulates block rows 3h .. 3h+2), so a lane carries 18 accumulators instead of 36:
+// ~9 KB of LDS and < 128 VGPRs per wave => 4 waves per SIMD, twice the loads in flight of the
+// register-staged 64-pair version.  Waves never share LDS data: no workgroup barrier.
+#define PS_SP_PAIRS 32                        // pairs per chunk: rows a_0..a_31, b_0..b_31
+#define PS_SP_LDS_PER_WAVE 1152               // doubles: 64 rows x 18
+
+// sum over the 32 lanes of each wave half with DPP row operations (fixed order): lane 31 / 63
+// end up with the total of lanes 0-31 / 32-63
+PS_DEV double half_sum_dpp(double v) {
+    v = dpp_shift_add<0x111, 0xf, 0xf>(v);  // row_shr:1
+    v = dpp_shift_add<0x112, 0xf, 0xf>(v);  // row_shr:2
+    v = dpp_shift_add<0x114, 0xf, 0xe>(v);  // row_shr:4
+    v = dpp_shift_add<0x118, 0xf, 0xc>(v);  // row_shr:8
+    v = dpp_shift_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_schur_pairs(
+    int per_xcd, const PairItem* __restrict__ xitems /* [8][per_xcd], slot < 0: padding */,
+    const int2* __restrict__ pairs, const double* __restrict__ Z, double* __restrict__ S,
+    double* __restrict__ Spart /* tiled mode: one partial block per task position, else NULL */, int ablate)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4 * PS_SP_LDS_PER_WAVE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* rows = smem + wv * PS_SP_LDS_PER_WAVE;
+    const int local = (blockIdx.x >> 3) * 4 + wv;
+    if (local >= per_xcd) return;
+    const size_t pos = (size_t)(blockIdx.x & 7) * per_xcd + local;
+    const PairItem it = xitems[pos];
+    if (it.slot < 0) return;
+    const int p = lane & 31, hf = lane >> 5;                    // pair in the chunk, half of the block
+    const int slot = lane / 9, piece = lane - 9 * slot;         // fetch role; lane 63: slot 7 (idle)
+    const int32_t* flat = reinterpret_cast<const int32_t*>(pairs) + hf;
+    double acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0.0;
+    // lane l holds the Z row index of LDS row l of a chunk (a_p for l < 32, b_p above); the index
+    // loads run two chunks ahead of the row fetches so that no chunk waits on them
+    int mine = (it.start + p < it.end) ? flat[2 * (size_t)(it.start + p)] : -1;
+    int mine1 = (it.start + PS_SP_PAIRS + p < it.end) ? flat[2 * (size_t)(it.start + PS_SP_PAIRS + p)] : -1;
+    for (int base = it.start; base < it.end; base += PS_SP_PAIRS) {
+        const int n = min(PS_SP_PAIRS, it.end - base);
+        // ---- cooperative fetch: instruction k brings rows 7k .. 7k+6 into LDS.  All ten index
+        // shuffles are issued first (one wait), the next-but-one chunk's indices are requested
+        // BEFORE the rows so that the single vmcnt(0) below never waits on a younger load.
+        int zrow[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) zrow[k] = __shfl(mine, (7 * k + slot) & 63, 64);
+        const int nb = base + 2 * PS_SP_PAIRS;
+        const int mine2 = (nb + p < it.end) ? flat[2 * (size_t)(nb + p)] : -1;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int r = 7 * k + slot;
+            if (slot < 7 && r < 2 * PS_SP_PAIRS && zrow[k] >= 0 && !(ablate & 2))
+                __builtin_amdgcn_global_load_lds((ps_gptr_t)(Z + 18 * (size_t)zrow[k] + 2 * piece),
+                                                 (ps_lptr_t)(rows + 126 * k), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): rows have landed in LDS
+        __builtin_amdgcn_wave_barrier();
+        if (p < n && !(ablate & 1)) {
+            double za[9];
+            const double* pa = rows + 18 * p + 9 * hf;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) za[k] = pa[k];
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh) {
+                double zb[10];
+                // columns 3bh .. 3bh+2 need b-row entries 9bh .. 9bh+8; read 16-byte aligned
+                const double2* pb = reinterpret_cast<const double2*>(rows + 18 * (PS_SP_PAIRS + p) + 8 * bh);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { const double2 v = pb[k]; zb[2 * k] = v.x; zb[2 * k + 1] = v.y; }
+                const double* q = zb + bh;                      // q[0..8] = entries 9bh .. 9bh+8
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)
+                        acc[6 * a + 3 * bh + b] += za[3 * a] * q[3 * b] + za[3 * a + 1] * q[3 * b + 1] + za[3 * a + 2] * q[3 * b + 2];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                        // LDS reads done before the next fetch lands
+        mine = mine1; mine1 = mine2;
+    }
+    // ---- reduce the 18 accumulators over the 32 lanes of each half (DPP, fixed order); lanes 31
+    // and 63 publish the 36 block entries through LDS for the coalesced, mirrored write
+    double* sums = rows;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+        const double t = half_sum_dpp(acc[k]);
+        if (p == 31) sums[18 * hf + k] = t;                     // entry (3 hf + k / 6, k % 6) = 18 hf + k
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+        const int r = lane / 6, c = lane % 6;
+        const double mine_v = sums[lane];
+        if (Spart) {
+            Spart[pos * 36 + lane] = mine_v;
+        } else if (it.slot == it.slotT) {                       // duplicate observation: a diagonal block
+            S[(size_t)it.slot * 36 + lane] -= mine_v + sums[c * 6 + r];
+        } else {                                                // off-diagonal blocks are still zero here
+            S[(size_t)it.slot * 36 + lane] = -mine_v;
+            S[(size_t)it.slotT * 36 + c * 6 + r] = -mine_v;
+        }
+    }
+}
+
+// tiled mode: sum the (tile, block) partials of every block in tile order and apply them to S and
+// to the mirrored block; one wave per block
+__global__ __launch_bounds__(256) void k_schur_combine(
+    int nblocks, const PairItem* __restrict__ items, const int32_t* __restrict__ tasks,
+    const double* __restrict__ Spart, double* __restrict__ S,
+    // workgroups beyond the blocks finalize the pose pass (fin_nr > 0; never when a task writes a diagonal block):
+    // one launch less on the critical path
+    int fin_nr, const int32_t* __restrict__ pitem_ptr, const double* __restrict__ ppartial,
+    const int32_t* __restrict__ diag_slot, double lambda, double* __restrict__ g)
+{
+    __shared__ double fin_v[4][PS_NPOSE_ACC];
+    const int nbw = (nblocks + 3) / 4;
+    if ((int)blockIdx.x >= nbw) {
+        const int rid = (blockIdx.x - nbw) * 4 + (threadIdx.x >> 6);
+        if (rid < fin_nr)
+            pose_finalize_wave(rid, threadIdx.x & 63, pitem_ptr, ppartial, diag_slot, lambda, S, g, fin_v[threadIdx.x >> 6]);
+        return;
+    }
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= nblocks || lane >= 36) return;
+    const PairItem it = items[b];
+    const int r = lane / 6, c = lane % 6;
+    double v = 0.0, vt = 0.0;
+    for (int k = it.start; k < it.end; ++k) {
+        const double* q = Spart + (size_t)tasks[k] * 36;
+        v += q[lane];
+        vt += q[c * 6 + r];
+    }
+    if (it.slot == it.slotT) {
+        S[(size_t)it.slot * 36 + lane] -= v + vt;
+    } else {
+        S[(size_t)it.slot * 36 + lane] -= v;
+        S[(size_t)it.slotT * 36 + lane] -= vt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pose-pose / prior factors: one wave per factor, Jacobians staged in LDS.
+// scratch row per factor: [H11 | H12 | H22 | g1 | g2]  (3 D^2 + 2 D doubles)
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_factor_pass(
+    int nf, const int32_t* __restrict__ f_i, const int32_t* __restrict__ f_j,
+    const double* __restrict__ f_Tinv, const int32_t* __restrict__ f_grp,
+    const FactorGroup* __restrict__ groups, const double* __restrict__ poses,
+    double* __restrict__ scratch)
+{
+    typedef PoseOps<D> G;
+    constexpr int DD = D * D, ROW = 3 * DD + 2 * D;
+    __shared__ double sJ1[4][36], sJ2[4][36], sr[4][6];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + w;
+    const bool live = f < nf;
+    const bool act = live && lane < DD;
+    const int r = lane / D, c = lane % D;
+    bool binary = false;
+    if (live) {
+        const int i = f_i[f], j = f_j[f];
+        binary = i >= 0;
+        const FactorGroup& grp = groups[f_grp[f]];
+        const typename G::T T2 = G::load(poses + G::W * (size_t)j);
+        const typename G::T To = G::load(f_Tinv + G::W * (size_t)f);
+        typename G::T E, T21 = T2;
+        if (binary) {
+            const typename G::T T1i = G::inv(G::load(poses + G::W * (size_t)i));
+            E = G::mul(T2, G::mul(T1i, To));            // T_2 (T_1^-1 T_obs^-1)
+            T21 = G::mul(T2, T1i);
+        } else {
+            E = G::mul(T2, To);
+        }
+        double xi[D], s[D];
+        G::log(E, xi);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double rk = 0.0;
+            bool present = false;               // an all-zero stiffness row is an absent residual row
+#pragma unroll                                  // (rotation-only edges, lowering.py): no weight, no 0 * inf
+            for (int m = 0; m < D; ++m) { rk += grp.S[k * D + m] * xi[m]; present = present || grp.S[k * D + m] != 0.0; }
+            s[k] = present ? sqrt(ps_loss_weight(grp.loss_id, grp.loss_k, rk)) : 0.0;
+            if (lane == 0) sr[w][k] = s[k] * rk;
+        }
+        if (act) {
+            // row r of J~ (scaled by s_r): J1 = -S Ad(T_2 T_1^-1), J2 = S
+            double sk = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) if (k == r) sk = s[k];
+            double j1 = 0.0;
+            if (binary) {
+#pragma unroll
+                for (int m = 0; m < D; ++m) j1 -= grp.S[r * D + m] * G::adj(T21, m, c);
+            }
+            sJ1[w][lane] = sk * j1;
+            sJ2[w][lane] = sk * grp.S[lane];
+        }
+    }
+    __syncthreads();
+    if (!act) return;
+    double h11 = 0.0, h12 = 0.0, h22 = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        h11 += sJ1[w][k * D + r] * sJ1[w][k * D + c];
+        h12 += sJ1[w][k * D + r] * sJ2[w][k * D + c];
+        h22 += sJ2[w][k * D + r] * sJ2[w][k * D + c];
+    }
+    double* out = scratch + (size_t)f * ROW;
+    out[lane] = h11; out[DD + lane] = h12; out[2 * DD + lane] = h22;
+    if (c == 0) {
+        double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { g1 -= sJ1[w][k * D + r] * sr[w][k]; g2 -= sJ2[w][k * D + r] * sr[w][k]; }
+        out[3 * DD + r] = g1; out[3 * DD + D + r] = g2;
+    }
+}
+
+// gather factor blocks into S (one thread per entry of every touched block) and g
+template <int D>
+__global__ __launch_bounds__(256) void k_factor_assemble(
+    int nslots, const int32_t* __restrict__ eslots, const int32_t* __restrict__ eptr,
+    const int2* __restrict__ eitems /* (scratch offset, transpose) */,
+    const int32_t* __restrict__ slot_is_diag,
+    int ng, const int32_t* __restrict__ gptr, const int32_t* __restrict__ gitems,
+    const double* __restrict__ scratch, double lambda, double* __restrict__ S, double* __restrict__ g)
+{
+    constexpr int DD = D * D;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nslots * DD) {
+        const int si = t / DD, e = t % DD, r = e / D, c = e % D;
+        double s = 0.0;
+        for (int k = eptr[si]; k < eptr[si + 1]; ++k) {
+            const int2 itx = eitems[k];
+            s += scratch[(size_t)itx.x + (itx.y ? c * D + r : e)];
+        }
+        const int slot = eslots[si];
+        if (r == c && slot_is_diag[si]) s *= (1.0 + lambda);
+        S[(size_t)slot * DD + e] += s;
+    }
+    const int u = t - nslots * DD;
+    if (u >= 0 && u < ng * D) {
+        const int rid = u / D, r = u % D;
+        double s = 0.0;
+        for (int k = gptr[rid]; k < gptr[rid + 1]; ++k) s += scratch[(size_t)gitems[k] + r];
+        g[(size_t)rid * D + r] += s;
+    }
+}

@@ -1,0 +1,225 @@
+// ps_k_pcg_classic.h -- classic two-launch block-Jacobi PCG (independent variant and fallback).
+// Part of ps_kernels.h (included from there, in this order; not a stand-alone header).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// block-Jacobi PCG on the reduced system (BSR, D x D blocks, both triangles)
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_block_jacobi(
+    int nr, const int32_t* __restrict__ diag_slot, const double* __restrict__ S,
+    double* __restrict__ Minv, int32_t* __restrict__ status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nr) return;
+    double A[D][D], L[D][D], Li[D][D];
+    const double* s = S + (size_t)diag_slot[i] * D * D;
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) { A[r][c] = s[r * D + c]; L[r][c] = 0.0; Li[r][c] = 0.0; }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        ok = ok && (d > 0.0);
+        const double l = sqrt(d);
+        L[j][j] = l;
+#pragma unroll
+        for (int i2 = j + 1; i2 < D; ++i2) {
+            double v = A[i2][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= L[i2][k] * L[j][k];
+            L[i2][j] = v / l;
+        }
+    }
+    // Li = L^-1 (lower), column by column
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        Li[c][c] = 1.0 / L[c][c];
+#pragma unroll
+        for (int r = c + 1; r < D; ++r) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = c; k < r; ++k) v -= L[r][k] * Li[k][c];
+            Li[r][c] = v / L[r][r];
+        }
+    }
+    if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
+    double* m = Minv + (size_t)i * D * D;     // A^-1 = Li^T Li
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = (r > c ? r : c); k < D; ++k) v += Li[k][r] * Li[k][c];
+            m[r * D + c] = v;
+        }
+}
+
+// vector-update kernels: each wave owns 64/D whole block rows (a block row never
+// straddles two waves, so its D lanes read r[] before any of them overwrites it)
+#define PS_PCG_BRW(D) (64 / (D))
+#define PS_PCG_BR(D) (4 * PS_PCG_BRW(D))
+
+// x = 0, r = g, z = M^-1 r, partial r.z and r.r
+template <int D>
+__global__ __launch_bounds__(256) void k_pcg_init(
+    int nr, const double* __restrict__ g, const double* __restrict__ Minv,
+    double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+    double* __restrict__ rz_part, double* __restrict__ rr_part, int32_t* __restrict__ status)
+{
+    __shared__ double lds[16];
+    const int t = threadIdx.x;
+    const int lane_ = t & 63;
+    const int brow = blockIdx.x * PS_PCG_BR(D) + (t >> 6) * PS_PCG_BRW(D) + lane_ / D, rr_ = lane_ % D;
+    double prz = 0.0, prr = 0.0;
+    if (lane_ < PS_PCG_BRW(D) * D && brow < nr) {
+        double rn[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) rn[c] = g[(size_t)brow * D + c];
+        double zi = 0.0, ri = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            zi += Minv[(size_t)brow * D * D + rr_ * D + c] * rn[c];
+            if (c == rr_) ri = rn[c];
+        }
+        const size_t i = (size_t)brow * D + rr_;
+        x[i] = 0.0; r[i] = ri; z[i] = zi;
+        prz = zi * ri; prr = ri * ri;
+    }
+    const double a = block_sum(prz, lds);
+    const double b = block_sum(prr, lds);
+    if (t == 0) { rz_part[blockIdx.x] = a; rr_part[blockIdx.x] = b; }
+    if (blockIdx.x == 0 && t == 0) { status[ST_PCG_DONE] = 0; status[ST_PCG_ITERS] = 0; }
+}
+
+// A: (beta from the partials) p = z + beta p_old on the fly; q = S p; partial p.q
+template <int D>
+__global__ __launch_bounds__(256) void k_pcg_spmv(
+    int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+    const double* __restrict__ S, const double* __restrict__ z,
+    const double* __restrict__ p_old, double* __restrict__ p_new, double* __restrict__ q,
+    const double* __restrict__ rz_part, const double* __restrict__ rr_part, int npartB,
+    double* __restrict__ pq_part, double* __restrict__ hist, int k, double tol2,
+    int32_t* __restrict__ status, double* __restrict__ scalars)
+{
+    __shared__ double lds[4][8];
+    constexpr int DD = D * D;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // Every load below is independent: issue them all before the first branch so the
+    // kernel pays ONE memory latency here instead of a chain (these kernels are a few us
+    // long and latency-, not bandwidth-bound).
+    const int done = status[ST_PCG_DONE];
+    const int row = blockIdx.x;
+    const int rbeg = row_ptr[row], rend = row_ptr[row + 1];
+    const double rz_prev = hist[k > 0 ? k - 1 : 0];
+    const double thresh_in = scalars[SC_THRESH];
+    double rz = 0.0, rr = 0.0;
+    for (int i = lane; i < npartB; i += 64) { rz += rz_part[i]; rr += rr_part[i]; }
+    const int kk = lane >> 3, r = lane & 7;
+    const int b0 = rbeg + w * 8 + kk;
+    int cj = 0;
+    if (b0 < rend) cj = col_idx[b0];
+    if (done) return;
+    rz = wave_sum(rz); rr = wave_sum(rr);
+    // convergence in the PRECONDITIONED norm r^T M^-1 r: invariant to the block scaling of the
+    // system (a 1e12 prior next to unit-weight loop closures), unlike ||r||_2 / ||g||_2
+    (void)rr;
+    const double thresh = (k == 0) ? tol2 * rz : thresh_in;
+    const bool first_wave = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (!(rz > thresh)) {                      // converged (also catches rz == 0 and NaN)
+        if (first_wave) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = rz; if (k == 0) scalars[SC_RR0] = rz; }
+        return;
+    }
+    const double beta = (k == 0) ? 0.0 : rz / rz_prev;
+    if (first_wave) {
+        hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rz;
+        if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = rz; }
+    }
+    // one workgroup per block row; a wave pass covers 8 blocks x D rows (lane = 8*blk + row),
+    // so the row's blocks are fetched with 32-way memory parallelism instead of one at a time
+    double acc = 0.0;
+    if (r < D) {
+        for (int b = b0; b < rend; b += 32) {
+            const size_t j = (size_t)(b == b0 ? cj : col_idx[b]) * D;
+            const double* sb = S + (size_t)b * DD + r * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc += sb[c] * (z[j + c] + beta * p_old[j + c]);
+        }
+    }
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < 8) lds[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+        double pq = 0.0;
+        if (lane < D) {
+            const double qr = ((lds[0][lane] + lds[1][lane]) + lds[2][lane]) + lds[3][lane];
+            const size_t i = (size_t)row * D + lane;
+            const double pn = z[i] + beta * p_old[i];
+            p_new[i] = pn; q[i] = qr;
+            pq = pn * qr;
+        }
+        pq = wave_sum(pq);
+        if (lane == 0) pq_part[row] = pq;
+    }
+}
+
+// B: alpha = rz / p.q ; x += alpha p ; r -= alpha q ; z = M^-1 r ; partial r.z, r.r
+template <int D>
+__global__ __launch_bounds__(256) void k_pcg_update(
+    int nr, const double* __restrict__ Minv, const double* __restrict__ p,
+    const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r,
+    double* __restrict__ z, const double* __restrict__ pq_part, int npartA,
+    const double* __restrict__ hist, int k, double* __restrict__ rz_part,
+    double* __restrict__ rr_part, const int32_t* __restrict__ status)
+{
+    __shared__ double lds[16];
+    const int t = threadIdx.x;
+    // all loads first (independent of alpha), then the reduction that yields alpha
+    const int done = status[ST_PCG_DONE];
+    const double rzk = hist[k];
+    double pq = 0.0;
+    for (int i = t; i < npartA; i += 256) pq += pq_part[i];
+    const int lane_ = t & 63;
+    const int brow = blockIdx.x * PS_PCG_BR(D) + (t >> 6) * PS_PCG_BRW(D) + lane_ / D, rr_ = lane_ % D;
+    const bool act = lane_ < PS_PCG_BRW(D) * D && brow < nr;
+    double rv[D], qv[D], mv[D], pi = 0.0, xi_ = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) { rv[c] = 0.0; qv[c] = 0.0; mv[c] = 0.0; }
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            rv[c] = r[(size_t)brow * D + c];
+            qv[c] = q[(size_t)brow * D + c];
+            mv[c] = Minv[(size_t)brow * D * D + rr_ * D + c];
+        }
+        pi = p[(size_t)brow * D + rr_];
+        xi_ = x[(size_t)brow * D + rr_];
+    }
+    if (done) return;
+    pq = block_sum(pq, lds);
+    const double alpha = rzk / pq;
+    double prz = 0.0, prr = 0.0;
+    if (act) {
+        double zi = 0.0, ri = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const double rn = rv[c] - alpha * qv[c];
+            zi += mv[c] * rn;
+            if (c == rr_) ri = rn;
+        }
+        const size_t i = (size_t)brow * D + rr_;
+        x[i] = xi_ + alpha * pi;
+        r[i] = ri; z[i] = zi;       // same-wave lanes have already loaded r[] (see PS_PCG_BRW)
+        prz = zi * ri; prr = ri * ri;
+    }
+    const double a = block_sum(prz, lds);
+    const double b = block_sum(prr, lds);
+    if (t == 0) { rz_part[blockIdx.x] = a; rr_part[blockIdx.x] = b; }
+}

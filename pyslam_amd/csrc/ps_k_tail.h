@@ -1,0 +1,515 @@
+// ps_k_tail.h -- one-launch motion-only iteration, covariance right-hand side, back-substitution, updates, costs, final reductions, dense normal equations.
+// Part of ps_kernels.h (included from there, in this order; not a stand-alone header).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// Motion-only problems (no variable landmark, no pose factor: the reduced system is block diagonal --
+// reference pipelines/sparse.py:153-161, SURVEY config C5): ONE launch per Gauss-Newton iteration.
+// One workgroup per pose: residuals + Jacobians + IRLS of its observations, 33 sums, 6 x 6 Cholesky
+// solve, retraction, post-step cost; the last workgroup to arrive sums the per-pose {cost, |dx|^2}
+// in pose order and publishes status + scalars to pinned host memory (sequence word).
+// ---------------------------------------------------------------------------
+#define PS_MO_THREADS 512
+__global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
+    int nr, const PItem* __restrict__ items, const int32_t* __restrict__ pitem_ptr,
+    const LObs* __restrict__ pobs, const double* __restrict__ points, const ObsGroup* __restrict__ groups,
+    double* __restrict__ poses, double lambda, int linesearch,
+    double* __restrict__ xout /* nr x 6 */, double* __restrict__ partials /* nr x 2: cost, |dx|^2 */,
+    int32_t* __restrict__ status, double* __restrict__ scalars, int32_t* __restrict__ arrivals,
+    int32_t* __restrict__ hst, double* __restrict__ hsc, long long* __restrict__ hseq, long long seq)
+{
+    constexpr int NWV = PS_MO_THREADS / 64;
+    __shared__ double red[NWV][PS_NPOSE_ACC + 1];
+    __shared__ double tot[PS_NPOSE_ACC + 1];
+    __shared__ double sT[12];
+    __shared__ int s_last;
+    const int rid = blockIdx.x, t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int ib = pitem_ptr[rid], ie = pitem_ptr[rid + 1];
+    const int start = ib < ie ? items[ib].start : 0, end = ib < ie ? items[ie - 1].end : 0;
+    const int pose = ib < ie ? items[ib].pad : 0;
+    Se3 T = se3_load(poses + 12 * (size_t)pose);
+    double acc[PS_NPOSE_ACC + 1];
+#pragma unroll
+    for (int k = 0; k <= PS_NPOSE_ACC; ++k) acc[k] = 0.0;
+    for (int i = start + t; i < end; i += PS_MO_THREADS) {
+        const LObs o = pobs[i];
+        const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
+        ReprojEval ev;
+        reproj_eval<true, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b)
+                acc[n++] += ev.Jp[a] * ev.Jp[b] + ev.Jp[6 + a] * ev.Jp[6 + b] + ev.Jp[12 + a] * ev.Jp[12 + b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            acc[21 + a] -= ev.Jp[a] * ev.r[0] + ev.Jp[6 + a] * ev.r[1] + ev.Jp[12 + a] * ev.r[2];
+            acc[27 + a] += ev.Jp[a] * ev.Jp[a] + ev.Jp[6 + a] * ev.Jp[6 + a] + ev.Jp[12 + a] * ev.Jp[12 + a];
+        }
+        acc[PS_NPOSE_ACC] += ev.cost;
+    }
+#pragma unroll
+    for (int k = 0; k <= PS_NPOSE_ACC; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) red[w][k] = v;
+    }
+    __syncthreads();
+    if (t <= PS_NPOSE_ACC) {
+        double v = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NWV; ++ww) v += red[ww][t];
+        tot[t] = v;
+    }
+    __syncthreads();
+    double sq = 0.0;
+    if (t == 0) {
+        // H = J^T J (+ lambda diag) = L L^T ;  x = H^-1 g
+        double H[6][6], x[6];
+        bool ok = true;
+        int n = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) { H[a][b] = tot[n]; H[b][a] = tot[n]; ++n; }
+        for (int a = 0; a < 6; ++a) H[a][a] += lambda * tot[27 + a];
+        for (int j = 0; j < 6; ++j) {
+            double d = H[j][j];
+            for (int k = 0; k < j; ++k) d -= H[j][k] * H[j][k];
+            ok = ok && (d > 0.0);
+            const double l = sqrt(d);
+            H[j][j] = l;
+            for (int i = j + 1; i < 6; ++i) {
+                double v = H[i][j];
+                for (int k = 0; k < j; ++k) v -= H[i][k] * H[j][k];
+                H[i][j] = v / l;
+            }
+        }
+        for (int i = 0; i < 6; ++i) {
+            double v = tot[21 + i];
+            for (int k = 0; k < i; ++k) v -= H[i][k] * x[k];
+            x[i] = v / H[i][i];
+        }
+        for (int i = 5; i >= 0; --i) {
+            double v = x[i];
+            for (int k = i + 1; k < 6; ++k) v -= H[k][i] * x[k];
+            x[i] = v / H[i][i];
+        }
+        if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
+        for (int k = 0; k < 6; ++k) { xout[(size_t)rid * 6 + k] = x[k]; sq += x[k] * x[k]; }
+        const Se3 Tn = se3_mul(se3_exp(x), T);
+        se3_store(poses + 12 * (size_t)pose, Tn);
+        se3_store(sT, Tn);
+    }
+    __syncthreads();
+    double cost = tot[PS_NPOSE_ACC];                     // cost at the linearisation point (linesearch == 0)
+    if (linesearch) {                                    // cost after the full step
+        T = se3_load(sT);
+        double c = 0.0;
+        for (int i = start + t; i < end; i += PS_MO_THREADS) {
+            const LObs o = pobs[i];
+            const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
+            ReprojEval ev;
+            reproj_eval<false, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+            c += ev.cost;
+        }
+        c = wave_sum(c);
+        __syncthreads();
+        if (lane == 0) red[w][0] = c;
+        __syncthreads();
+        cost = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NWV; ++ww) cost += red[ww][0];
+    }
+    if (t == 0) {
+        partials[2 * rid] = cost;
+        partials[2 * rid + 1] = sq;
+        __threadfence();                                 // release this pose's results ...
+        s_last = atomicAdd(arrivals, 1) == nr - 1;
+        __threadfence();                                 // ... acquire everybody else's
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last workgroup: fixed-order totals, status, publication
+    double c = 0.0, q = 0.0;
+    for (int i = t; i < nr; i += PS_MO_THREADS) { c += partials[2 * i]; q += partials[2 * i + 1]; }
+    // (fixed order: thread-strided partial sums, then the deterministic block reduction)
+    __shared__ double lds2[32];
+    block_sum2(c, q, lds2);
+    if (t == 0) {
+        *arrivals = 0;
+        scalars[linesearch ? SC_COST : SC_LINCOST] = c;
+        scalars[SC_DXP2] = q; scalars[SC_DXL2] = 0.0;
+        scalars[SC_RR0] = 1.0; scalars[SC_RRFINAL] = 0.0;
+        status[ST_PCG_DONE] = 1; status[ST_PCG_ITERS] = 0;
+    }
+    __syncthreads();
+    __threadfence();
+    if (hst) {
+        if (t < ST_NWORDS) hst[t] = status[t];
+        else if (t < ST_NWORDS + SC_NWORDS) hsc[t - ST_NWORDS] = scalars[t - ST_NWORDS];
+        __syncthreads();
+        if (t == 0) {
+            __threadfence_system();
+            *reinterpret_cast<volatile long long*>(hseq) = seq;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// back-substitution, retraction, cost, small reductions.
+// `gate`: when non-null the kernel returns unless the CG has flagged convergence
+// (status[ST_PCG_DONE]); ps_gn_iteration enqueues this tail right behind the CG launches
+// without a host synchronisation and re-runs it in the rare case the CG needed more launches.
+// ---------------------------------------------------------------------------
+// covariance column (ps_covariance_column): right-hand side of H x = e_k in Schur form.  g and cvec
+// are zero on entry.  kind 0: g[index*D + comp] = 1.  kind 1 (landmark slot `index`): c = column
+// comp of M = C^-1, and g_j -= Z_j c for every observation of the landmark on a variable pose
+// (one thread walks them: duplicates of a pose accumulate in a fixed order).
+__global__ __launch_bounds__(64) void k_cov_rhs(
+    int kind, int index, int comp, int D, const int32_t* __restrict__ lm_ptr, const LObs* __restrict__ lobs,
+    const int32_t* __restrict__ pose_rid, const double* __restrict__ Z, const double* __restrict__ Cinv,
+    double* __restrict__ g, double* __restrict__ cvec)
+{
+    if (threadIdx.x != 0) return;
+    if (kind == 0) { g[(size_t)index * D + comp] = 1.0; return; }
+    const double* m = Cinv + 6 * (size_t)index;          // M00 M10 M11 M20 M21 M22
+    double c[3] = {0.0, 0.0, 0.0};
+    if (comp == 0) { c[0] = m[0]; c[1] = m[1]; c[2] = m[3]; }
+    else if (comp == 1) { c[1] = m[2]; c[2] = m[4]; }
+    else c[2] = m[5];
+    cvec[3 * (size_t)index] = c[0]; cvec[3 * (size_t)index + 1] = c[1]; cvec[3 * (size_t)index + 2] = c[2];
+    for (int i = lm_ptr[index]; i < lm_ptr[index + 1]; ++i) {
+        const int rid = pose_rid[PS_POSE_OF(lobs[i])];
+        if (rid < 0) continue;
+        const double* z = Z + 18 * (size_t)i;
+        for (int a = 0; a < 6; ++a) g[(size_t)rid * 6 + a] -= z[3 * a] * c[0] + z[3 * a + 1] * c[1] + z[3 * a + 2] * c[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_backsub(
+    int nv, const int32_t* __restrict__ lm_ptr, const LObs* __restrict__ lobs,
+    const int32_t* __restrict__ pose_rid, const double* __restrict__ Z,
+    const double* __restrict__ Cinv, const double* __restrict__ cvec,
+    const double* __restrict__ xp, double* __restrict__ dxl,
+    double* __restrict__ sq_part /* one partial of ||dx_l||^2 per workgroup */,
+    const int32_t* __restrict__ gate,
+    // fused full-step update (NULL points: back-substitution only).  Workgroups >= nblk_l retract the
+    // SE(3) poses instead (nothing in the back-substitution reads `poses` or `points`).
+    int nblk_l, const int32_t* __restrict__ lm_point, double* __restrict__ points,
+    int P, double* __restrict__ poses, double* __restrict__ sq_part_p)
+{
+    __shared__ double lds[16];
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
+    if ((int)blockIdx.x >= nblk_l) {
+        typedef PoseOps<6> G;
+        const int i = (blockIdx.x - nblk_l) * blockDim.x + threadIdx.x;
+        double sq = 0.0;
+        const int rid = (i < P) ? pose_rid[i] : -1;
+        if (rid >= 0) {
+            double xi[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { xi[k] = xp[(size_t)rid * 6 + k]; sq += xi[k] * xi[k]; }
+            G::store(poses + G::W * (size_t)i, G::mul(G::exp(xi), G::load(poses + G::W * (size_t)i)));
+        }
+        sq = block_sum(sq, lds);
+        if (threadIdx.x == 0) sq_part_p[blockIdx.x - nblk_l] = sq;
+        return;
+    }
+    // 16 lanes per landmark, one observation per lane (same mapping as k_landmark_pass)
+    const int v = blockIdx.x * (blockDim.x / PS_LM_GROUP) + threadIdx.x / PS_LM_GROUP;
+    const int sub = threadIdx.x & (PS_LM_GROUP - 1);
+    const bool live = v < nv;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (live) {
+        for (int i = lm_ptr[v] + sub; i < lm_ptr[v + 1]; i += PS_LM_GROUP) {
+            const int rid = pose_rid[PS_POSE_OF(lobs[i])];
+            if (rid < 0) continue;
+            const double* z = Z + 18 * (size_t)i;
+            const double* x = xp + 6 * (size_t)rid;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double xa = x[a];
+                a0 -= z[3 * a] * xa; a1 -= z[3 * a + 1] * xa; a2 -= z[3 * a + 2] * xa;
+            }
+        }
+    }
+    a0 = group16_sum(a0); a1 = group16_sum(a1); a2 = group16_sum(a2);
+    double sq = 0.0;
+    if (live && sub == 0) {
+        a0 += cvec[3 * (size_t)v]; a1 += cvec[3 * (size_t)v + 1]; a2 += cvec[3 * (size_t)v + 2];
+        const double* m = Cinv + 6 * (size_t)v;    // dx = M^T a
+        const double d0 = m[0] * a0 + m[1] * a1 + m[3] * a2;
+        const double d1 = m[2] * a1 + m[4] * a2;
+        const double d2 = m[5] * a2;
+        dxl[3 * (size_t)v] = d0; dxl[3 * (size_t)v + 1] = d1; dxl[3 * (size_t)v + 2] = d2;
+        sq = d0 * d0 + d1 * d1 + d2 * d2;
+        if (points) {
+            double* pt = points + 3 * (size_t)lm_point[v];
+            pt[0] += d0; pt[1] += d1; pt[2] += d2;
+        }
+    }
+    sq = block_sum(sq, lds);
+    if (threadIdx.x == 0) sq_part[blockIdx.x] = sq;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_update_poses(
+    int P, const int32_t* __restrict__ pose_rid, const double* __restrict__ xp,
+    double step, double* __restrict__ poses, double* __restrict__ sq_part /* per workgroup, or null */,
+    const int32_t* __restrict__ gate)
+{
+    typedef PoseOps<D> G;
+    __shared__ double lds[16];
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double sq = 0.0;
+    const int rid = (i < P) ? pose_rid[i] : -1;
+    if (rid >= 0) {
+        double xi[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double v = xp[(size_t)rid * D + k];
+            sq += v * v;
+            xi[k] = step * v;
+        }
+        G::store(poses + G::W * (size_t)i, G::mul(G::exp(xi), G::load(poses + G::W * (size_t)i)));
+    }
+    if (sq_part) {
+        sq = block_sum(sq, lds);
+        if (threadIdx.x == 0) sq_part[blockIdx.x] = sq;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_update_points(
+    int nv, const int32_t* __restrict__ lm_point, const double* __restrict__ dxl,
+    double step, double* __restrict__ points, const int32_t* __restrict__ gate)
+{
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * nv) return;
+    points[3 * (size_t)lm_point[t / 3] + t % 3] += step * dxl[t];
+}
+
+// robust cost of the reprojection blocks: one partial per workgroup
+__global__ __launch_bounds__(256) void k_cost_reproj(
+    long n, const LObs* __restrict__ lobs, const double* __restrict__ poses,
+    const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
+    const int32_t* __restrict__ point_vid, const ObsGroup* __restrict__ groups,
+    int include_all, double* __restrict__ partials, const int32_t* __restrict__ gate)
+{
+    __shared__ double lds[16];
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
+    double c = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const LObs o = lobs[i];
+        const int pose = PS_POSE_OF(o);
+        if (!include_all && pose_rid[pose] < 0 && point_vid[o.point] < 0) continue;
+        const Se3 T = se3_load(poses + 12 * pose);
+        const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
+        ReprojEval ev;
+        reproj_eval<false, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        c += ev.cost;
+    }
+    c = block_sum(c, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = c;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_cost_factors(
+    int nf, const int32_t* __restrict__ f_i, const int32_t* __restrict__ f_j,
+    const double* __restrict__ f_Tinv, const int32_t* __restrict__ f_grp,
+    const FactorGroup* __restrict__ groups, const double* __restrict__ poses,
+    const int32_t* __restrict__ pose_rid, int include_all, double* __restrict__ partials,
+    const int32_t* __restrict__ gate)
+{
+    typedef PoseOps<D> G;
+    __shared__ double lds[16];
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
+    double cst = 0.0;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
+        const int i = f_i[f], j = f_j[f];
+        if (!include_all && pose_rid[j] < 0 && (i < 0 || pose_rid[i] < 0)) continue;
+        const FactorGroup& grp = groups[f_grp[f]];
+        const typename G::T T2 = G::load(poses + G::W * (size_t)j);
+        const typename G::T To = G::load(f_Tinv + G::W * (size_t)f);
+        typename G::T E;
+        if (i >= 0) E = G::mul(T2, G::mul(G::inv(G::load(poses + G::W * (size_t)i)), To));
+        else E = G::mul(T2, To);
+        double xi[D];
+        G::log(E, xi);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double rk = 0.0;
+#pragma unroll
+            for (int m = 0; m < D; ++m) rk += grp.S[k * D + m] * xi[m];
+            cst += ps_loss_rho(grp.loss_id, grp.loss_k, rk);
+        }
+    }
+    cst = block_sum(cst, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = cst;
+}
+
+__global__ __launch_bounds__(256) void k_sumsq_partials(
+    long n, const double* __restrict__ v, double scale, double* __restrict__ partials)
+{
+    __shared__ double lds[16];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double a = scale * v[i];
+        s += a * a;
+    }
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// up to three independent sums in ONE launch: workgroup b reduces partials_b[0..n_b) into out_b
+// (fixed order).  Used for {cost, ||dx_pose||^2, ||dx_point||^2} at the end of an iteration.
+__global__ __launch_bounds__(256) void k_reduce3(
+    int n0, const double* __restrict__ p0, double* __restrict__ o0,
+    int n1, const double* __restrict__ p1, double* __restrict__ o1,
+    int n2, const double* __restrict__ p2, double* __restrict__ o2, const int32_t* __restrict__ gate,
+    // publish (hst != NULL): the status words and the scalar slots go straight to pinned host memory, and
+    // the last workgroup to finish stamps a sequence number behind them, so the host ends the iteration
+    // by watching that word instead of paying two device-to-host copies and a stream synchronisation
+    const int32_t* __restrict__ status, const double* __restrict__ scalars,
+    int32_t* __restrict__ hst, double* __restrict__ hsc,
+    int32_t* __restrict__ arrivals /* device word, 0 between launches */, long long* __restrict__ hseq, long long seq)
+{
+    __shared__ double lds[16];
+    const bool open = !(gate && gate[ST_PCG_DONE] != 1);
+    if (hst && blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t < ST_NWORDS) hst[t] = status[t];
+        else if (t < ST_NWORDS + SC_NWORDS) {
+            const int k = t - ST_NWORDS;                 // slots owned by a reduction below are written there
+            if (!open || (o0 != scalars + k && o1 != scalars + k && o2 != scalars + k)) hsc[k] = scalars[k];
+        }
+    }
+    const int n = blockIdx.x == 0 ? n0 : (blockIdx.x == 1 ? n1 : n2);
+    const double* p = blockIdx.x == 0 ? p0 : (blockIdx.x == 1 ? p1 : p2);
+    double* o = blockIdx.x == 0 ? o0 : (blockIdx.x == 1 ? o1 : o2);
+    if (open && o) {                                     // block-uniform condition
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+        s = block_sum(s, lds);
+        if (threadIdx.x == 0) {
+            o[0] = s;
+            if (hsc && o >= scalars && o < scalars + SC_NWORDS) hsc[o - scalars] = s;
+        }
+    }
+    if (hseq) {
+        __syncthreads();                                 // every host-bound store of this workgroup is issued
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            if (atomicAdd(arrivals, 1) == (int)gridDim.x - 1) {
+                *arrivals = 0;
+                __threadfence_system();
+                *reinterpret_cast<volatile long long*>(hseq) = seq;
+            }
+        }
+    }
+}
+
+// sharded iteration: status, scalars and the all-reduced {cost, ||dx_point||^2} to pinned host memory,
+// then the sequence word the host is watching (single workgroup)
+__global__ __launch_bounds__(64) void k_publish(
+    const int32_t* __restrict__ status, const double* __restrict__ scalars, const double* __restrict__ shard,
+    int32_t* __restrict__ hst, double* __restrict__ hsc, double* __restrict__ hshard,
+    long long* __restrict__ hseq, long long seq)
+{
+    const int t = threadIdx.x;
+    if (t < ST_NWORDS) hst[t] = status[t];
+    else if (t < ST_NWORDS + SC_NWORDS) hsc[t - ST_NWORDS] = scalars[t - ST_NWORDS];
+    else if (t < ST_NWORDS + SC_NWORDS + 2) hshard[t - ST_NWORDS - SC_NWORDS] = shard[t - ST_NWORDS - SC_NWORDS];
+    __syncthreads();
+    if (t == 0) {
+        __threadfence_system();
+        *reinterpret_cast<volatile long long*>(hseq) = seq;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(int n, const double* __restrict__ partials,
+                                                          double* __restrict__ out)
+{
+    __shared__ double lds[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// debug tap: IRLS-scaled residual / Jacobian blocks in ORIGINAL observation order
+__global__ __launch_bounds__(256) void k_debug_reproj(
+    long n, const LObs* __restrict__ lobs, const int32_t* __restrict__ lorig,
+    const double* __restrict__ poses, const double* __restrict__ points,
+    const ObsGroup* __restrict__ groups, double* __restrict__ r, double* __restrict__ jp,
+    double* __restrict__ jl)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const LObs o = lobs[i];
+    const Se3 T = se3_load(poses + 12 * PS_POSE_OF(o));
+    const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
+    ReprojEval ev;
+    reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+    const size_t k = (size_t)lorig[i];
+    for (int a = 0; a < 3; ++a) r[3 * k + a] = ev.r[a];
+    for (int a = 0; a < 18; ++a) jp[18 * k + a] = ev.Jp[a];
+    for (int a = 0; a < 9; ++a) jl[9 * k + a] = ev.Jl[a];
+}
+
+// ---------------------------------------------------------------------------
+// dense generic path: H = J^T J, g = -J^T r, in-place Cholesky solve (one workgroup)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_normal(int m, int n, const double* __restrict__ J,
+                                                       const double* __restrict__ r,
+                                                       double* __restrict__ H, double* __restrict__ g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n * n) {
+        const int a = t / n, b = t % n;
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += J[(size_t)k * n + a] * J[(size_t)k * n + b];
+        H[t] = s;
+    }
+    if (t < n) {
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s -= J[(size_t)k * n + t] * r[k];
+        g[t] = s;
+    }
+}
+
+// H (n x n, row-major, overwritten by its lower Cholesky factor); B (n x nrhs, row-major) <- H^-1 B
+__global__ __launch_bounds__(256) void k_dense_chol_solve(int n, int nrhs, double* __restrict__ H,
+                                                           double* __restrict__ B, int32_t* __restrict__ status)
+{
+    const int t = threadIdx.x;
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        if (t == 0) {
+            double d = H[(size_t)j * n + j];
+            for (int k = 0; k < j; ++k) d -= H[(size_t)j * n + k] * H[(size_t)j * n + k];
+            if (!(d > 0.0)) atomicAdd(&status[ST_DIAG_FAIL], 1);
+            H[(size_t)j * n + j] = sqrt(d);
+        }
+        __syncthreads();
+        const double l = H[(size_t)j * n + j];
+        for (int i = j + 1 + t; i < n; i += 256) {
+            double v = H[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) v -= H[(size_t)i * n + k] * H[(size_t)j * n + k];
+            H[(size_t)i * n + j] = v / l;
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < nrhs; c += 256) {            // one right-hand side per thread
+        for (int i = 0; i < n; ++i) {                // L y = b
+            double v = B[(size_t)i * nrhs + c];
+            for (int k = 0; k < i; ++k) v -= H[(size_t)i * n + k] * B[(size_t)k * nrhs + c];
+            B[(size_t)i * nrhs + c] = v / H[(size_t)i * n + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {           // L^T x = y
+            double v = B[(size_t)i * nrhs + c];
+            for (int k = i + 1; k < n; ++k) v -= H[(size_t)k * n + i] * B[(size_t)k * nrhs + c];
+            B[(size_t)i * nrhs + c] = v / H[(size_t)i * n + i];
+        }
+    }
+}

@@ -1,0 +1,270 @@
+// ps_k_xcg.h -- explicit two-level PCG for large reduced systems.
+// Part of ps_kernels.h (included from there, in this order; not a stand-alone header).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// Explicit two-level PCG for long sparse chains (pose graphs with thousands of poses).  Same
+// preconditioner as the folded form, M^-1 = I + P A_c^-1 P^T in the scaled coordinates, but APPLIED:
+//   k_xcg_spmv      beta, p = z + beta p (on the fly, also for the neighbours), q = S^ p, partials of p.q
+//   k_xcg_restrict  alpha, r -= alpha q, x += alpha p (owner node), t_q = sum_i w(i,q) B_i^T r_i
+//   k_xcg_coarse    y = A_c^-1 t                      (dense nc x nc matrix-vector product, one wave per row)
+//   k_xcg_prolong   z_i = r_i + B_i (w0 y[n] + w1 y[n+1]), partials of r.z
+// Four small launches per iteration and 288 B x nnzb of matrix traffic, instead of dragging a dense
+// border of ncb blocks through every row (C2: 60 -> 11 blocks per row, 100 -> ~28 us per iteration).
+// xstate: [1] threshold, [2] r0.z0, [4 + parity] r.z of iteration k (double-buffered by parity)
+// ---------------------------------------------------------------------------
+#define PS_XCG_ROWS 4                         // rows (waves) per workgroup of the SpMV
+#define PS_XCG_DROWS 256                      // rows per workgroup of the prolongation
+
+PS_DEV double xcg_total(const double* __restrict__ part, int n, double* lds) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += part[i];
+    return block_sum(v, lds);
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * PS_XCG_ROWS) void k_xcg_spmv(
+    int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx, int wf,
+    const double* __restrict__ S, const double* __restrict__ z, const double* __restrict__ p_old,
+    double* __restrict__ p_new, double* __restrict__ q, const double* __restrict__ rz_part, int n_rz,
+    double* __restrict__ pq_part, double* __restrict__ xstate, int k, double tol2,
+    double* __restrict__ hist, int32_t* __restrict__ status, double* __restrict__ scalars)
+{
+    __shared__ double lds[16];
+    __shared__ double wpq[PS_XCG_ROWS];
+    constexpr int DD = D * D;
+    const int done = status[ST_PCG_DONE];
+    // r.z of the previous iteration sits in the slot of the other parity: workgroup 0 of THIS launch writes
+    // this iteration's slot while later workgroups may still be starting
+    const double rz_prev = xstate[4 + ((k + 1) & 1)], thresh_in = xstate[1];
+    double rz = xcg_total(rz_part, n_rz, lds);
+    if (done) return;
+    const double thresh = (k == 0) ? tol2 * rz : thresh_in;
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    if (!(rz > thresh)) {                                 // converged (or rz == 0 / NaN)
+        if (first) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = rz; if (k == 0) scalars[SC_RR0] = rz; }
+        return;
+    }
+    const double beta = (k == 0) ? 0.0 : rz / rz_prev;
+    if (first) {
+        xstate[4 + (k & 1)] = rz; hist[k] = rz; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = rz;
+        if (k == 0) { xstate[1] = thresh; xstate[2] = rz; scalars[SC_RR0] = rz; }
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * PS_XCG_ROWS + w;
+    double pq = 0.0;
+    if (row < nr) {
+        const int rbeg = wf > 0 ? row * wf : row_ptr[row];
+        const int rend = wf > 0 ? rbeg + wf : row_ptr[row + 1];
+        const int kk = lane >> 3, r = lane & 7;
+        double acc = 0.0;
+        if (r < D) {
+            for (int b = rbeg + kk; b < rend; b += 8) {
+                const size_t j = (size_t)col_idx[b] * D;
+                const double* sb = S + (size_t)b * DD + r * D;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc += sb[c] * (z[j + c] + beta * p_old[j + c]);
+            }
+        }
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        double pn = 0.0;
+        if (lane < D) {
+            const size_t i = (size_t)row * D + lane;
+            pn = z[i] + beta * p_old[i];
+            p_new[i] = pn; q[i] = acc;
+        }
+        pq = wave_sum(lane < D ? pn * acc : 0.0);
+    }
+    if (lane == 0) wpq[w] = pq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < PS_XCG_ROWS; ++ww) v += wpq[ww];
+        pq_part[blockIdx.x] = v;
+    }
+}
+
+// one workgroup per coarse node q: the rows of its support (two hat intervals)
+template <int D>
+__global__ __launch_bounds__(256) void k_xcg_restrict(
+    int nr, int ncb, const int32_t* __restrict__ slo, const int32_t* __restrict__ shi,
+    const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ Bmat, const double* __restrict__ r_old, double* __restrict__ r_new,
+    const double* __restrict__ qv, const double* __restrict__ p, double* __restrict__ x,
+    const double* __restrict__ pq_part, int n_pq, const double* __restrict__ xstate, int k /* < 0: initialisation */,
+    double* __restrict__ tvec, const int32_t* __restrict__ status)
+{
+    __shared__ double lds[16];
+    __shared__ double wt[4][8];
+    const int done = status[ST_PCG_DONE];
+    const int init = k < 0;
+    double alpha = 0.0;
+    if (!init) {
+        const double pq = xcg_total(pq_part, n_pq, lds);
+        alpha = xstate[4 + (k & 1)] / pq;
+    }
+    if (done) return;
+    const int qn = blockIdx.x, t = threadIdx.x;
+    double acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0;
+    for (int i = slo[qn] + t; i < shi[qn]; i += 256) {
+        const bool owner = pnode[i] == qn;                 // every row has exactly one left node
+        const double wgt = (pnode[i] == qn) ? pw0[i] : pw1[i];
+        double rn[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const size_t e = (size_t)i * D + c;
+            rn[c] = init ? r_old[e] : r_old[e] - alpha * qv[e];
+            if (owner) {
+                r_new[e] = rn[c];
+                if (!init) x[e] += alpha * p[e];
+            }
+        }
+        const double* B = Bmat + (size_t)i * D * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) v += B[a * D + c] * rn[a];
+            acc[c] += wgt * v;
+        }
+    }
+    const int wv = t >> 6, lane = t & 63;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const double v = wave_sum(acc[c]);
+        if (lane == 0) wt[wv][c] = v;
+    }
+    __syncthreads();
+    if (t < D) tvec[(size_t)qn * D + t] = ((wt[0][t] + wt[1][t]) + wt[2][t]) + wt[3][t];
+}
+
+// A_c^-1 = Lci^T Lci, dense and symmetric, formed once per solve so that the per-iteration coarse solve
+// is ONE parallel matrix-vector product (a single workgroup walking two triangular factors with dependent
+// L2 loads took ~70 us per iteration).  One workgroup per 64 x 64 tile of the lower triangle (mirrored on
+// store), 4 x 4 outputs per thread, rows of Lci staged through LDS 16 at a time.
+#define PS_AI_T 64
+#define PS_AI_K 16
+__global__ __launch_bounds__(256) void k_xcg_ainv(int nc, const double* __restrict__ Lci, float* __restrict__ Ainv)
+{
+    __shared__ double As[PS_AI_K][PS_AI_T + 4];
+    __shared__ double Bs[PS_AI_K][PS_AI_T + 4];
+    // tile (ti >= tj) from the linear index
+    int ti = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+    while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
+    const int tj = blockIdx.x - ti * (ti + 1) / 2;
+    const int i0 = ti * PS_AI_T, j0 = tj * PS_AI_T;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k0 = i0; k0 < nc; k0 += PS_AI_K) {            // Lci[k][i] = 0 for k < i, and i >= i0 >= j
+#pragma unroll
+        for (int e = t; e < PS_AI_K * PS_AI_T; e += 256) {
+            const int kk = e >> 6, c = e & 63, k = k0 + kk;
+            const int ia = i0 + c, jb = j0 + c;
+            As[kk][c] = (k < nc && ia < nc && k >= ia) ? Lci[(size_t)k * nc + ia] : 0.0;
+            Bs[kk][c] = (k < nc && jb < nc && k >= jb) ? Lci[(size_t)k * nc + jb] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < PS_AI_K; ++kk) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { av[a] = As[kk][ty * 4 + a]; bv[a] = Bs[kk][tx * 4 + a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
+            if (i < nc && j < nc) {
+                const float v = (float)acc[a][b];          // (both triangles get the SAME rounded value: still symmetric)
+                if (ti != tj || i >= j) { Ainv[(size_t)i * nc + j] = v; Ainv[(size_t)j * nc + i] = v; }
+            }
+        }
+}
+
+// y = A_c^-1 t : one wave per row.  The inverse is kept in fp32 -- it only preconditions (any symmetric positive
+// definite approximation keeps the CG exact), and this product is bound by reading it (19 -> 9.4 MB at nc = 1536).
+__global__ __launch_bounds__(256) void k_xcg_coarse(
+    int nc, const float* __restrict__ Ainv, const double* __restrict__ tvec,
+    double* __restrict__ y, int32_t* __restrict__ status, const int32_t* __restrict__ lag_status)
+{
+    if (lag_status && blockIdx.x == 0 && threadIdx.x == 0 && lag_status[ST_DIAG_FAIL]) atomicAdd(&status[ST_DIAG_FAIL], 1);
+    if (status[ST_PCG_DONE]) return;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nc) return;
+    const float* a = Ainv + (size_t)row * nc;
+    double v = 0.0;
+    if ((nc & 1) == 0) {
+        for (int j = 2 * lane; j < nc; j += 128) {
+            const float2 f = *reinterpret_cast<const float2*>(a + j);
+            v += (double)f.x * tvec[j] + (double)f.y * tvec[j + 1];
+        }
+    } else {
+        for (int j = lane; j < nc; j += 64) v += (double)a[j] * tvec[j];
+    }
+    v = wave_sum(v);
+    if (lane == 0) y[row] = v;
+}
+
+template <int D>
+__global__ __launch_bounds__(PS_XCG_DROWS) void k_xcg_prolong(
+    int nr, int ncb, const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ Bmat, const double* __restrict__ r, const double* __restrict__ y,
+    double* __restrict__ z, double* __restrict__ rz_part, const int32_t* __restrict__ status)
+{
+    __shared__ double lds[16];
+    if (status[ST_PCG_DONE]) return;
+    const int i = blockIdx.x * PS_XCG_DROWS + threadIdx.x;
+    double rz = 0.0;
+    if (i < nr) {
+        const int n0 = pnode[i];
+        const double w0 = pw0[i], w1 = pw1[i];
+        double yy[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) yy[m] = w0 * y[n0 * D + m] + ((n0 + 1 < ncb) ? w1 * y[(n0 + 1) * D + m] : 0.0);
+        const double* B = Bmat + (size_t)i * D * D;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const size_t e = (size_t)i * D + a;
+            double v = r[e];
+#pragma unroll
+            for (int m = 0; m < D; ++m) v += B[a * D + m] * yy[m];
+            z[e] = v;
+            rz += r[e] * v;
+        }
+    }
+    rz = block_sum(rz, lds);
+    if (threadIdx.x == 0) rz_part[blockIdx.x] = rz;
+}
+
+// x = Linv^T x^
+template <int D>
+__global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __restrict__ Linv,
+                                                     const double* __restrict__ xh, double* __restrict__ x,
+                                                     const int32_t* __restrict__ gate)
+{
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nr * D) return;
+    const int i = t / D, c = t % D;
+    double v = 0.0;
+#pragma unroll
+    for (int a = 0; a < D; ++a) v += Linv[(size_t)i * D * D + a * D + c] * xh[(size_t)i * D + a];
+    x[t] = v;
+}
