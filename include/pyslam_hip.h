@@ -199,7 +199,7 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /
      "direct_max_unknowns"[90] reduced systems up to this size are solved by a dense Cholesky instead of CG (0 = never)
      "fused_motion_only"  [1] problems without variable landmarks / pose factors: one launch per iteration
      "cg_explicit"        [1] long sparse chains: apply the two-level preconditioner (k_xcg_*) instead of folding it in
-     "cg_lds", "profile_every", "big_chol", "cg_margin", "pcg_chunk", "cg_split_min_rows", "cg_explicit_min_rows": implementation switches (see ps_core.hip)
+     "cg_lds", "profile_every", "big_chol", "cg_margin", "pcg_chunk", "cg_split_min_rows", "cg_explicit_min_rows": implementation switches (see ps_set_option in csrc/ps_abi_solver.h)
      "cg_ablate", "schur_ablate", "lm_ablate": timing experiments only (results are wrong under ablation) */
 int ps_set_option(ps_problem* h, const char* name, double value);
 

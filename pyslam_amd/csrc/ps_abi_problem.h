@@ -1,0 +1,499 @@
+// ps_abi_problem.h -- C ABI: error state, ps_problem_create / destroy (table upload, pair lists, XCD tiles).
+// Part of ps_core.hip (one translation unit; included from there, in this order).
+
+
+const char* ps_last_error(void) { return g_err.c_str(); }
+
+int ps_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ps_problem_destroy(ps_problem* h) {
+    if (!h) return 0;
+    hipStreamSynchronize(h->stream);
+    if (h->side) hipStreamSynchronize(h->side);
+    for (void* p : h->allocs) hipFree(p);
+    if (h->h_scalars) hipHostFree(h->h_scalars);
+    if (h->h_status) hipHostFree(h->h_status);
+    if (h->h_seq) hipHostFree(h->h_seq);
+    if (h->h_shard) hipHostFree(h->h_shard);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); }
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) {
+    const bool timing = getenv("PS_CREATE_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "ps_problem_create: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    if (!d || !out) return fail("null argument");
+    *out = nullptr;
+    if (d->dof != 6 && d->dof != 3) return fail("dof must be 6 (SE3) or 3 (SE2)");
+    if (d->num_obs > 0 && d->dof != 6) return fail("reprojection blocks need SE(3) poses");
+    if (d->num_poses >= (1 << 24)) return fail("more than 2^24 poses");
+    if (d->num_obs_groups > 255) return fail("more than 255 observation groups");
+    if (d->num_obs >= (1L << 31) / 18) return fail("too many observations for 32-bit indexing");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible");
+
+    ps_problem* h = new ps_problem();
+    struct Guard { ps_problem* h; bool ok = false; ~Guard() { if (!ok) ps_problem_destroy(h); } } guard{h};
+    if (stream) h->stream = (hipStream_t)stream;
+    else { HIP_OK(hipStreamCreate(&h->stream)); h->own_stream = true; }
+    const int D = h->D = d->dof;
+    const int PW = h->PW = (D == 6 ? 12 : 6);
+    const int DD = D * D;
+    h->P = d->num_poses; h->L = d->num_points; h->N = d->num_obs;
+    const int P = h->P, L = h->L;
+    const long N = h->N;
+
+    // ---- parameter tables
+    if (h->upload(&h->poses, d->poses, (size_t)P * PW)) return -1;
+    if (h->upload(&h->points, d->points, (size_t)L * 3)) return -1;
+    if (h->upload(&h->pose_rid, d->pose_rid, (size_t)P)) return -1;
+    if (h->alloc(&h->poses_snap, (size_t)P * PW) || h->alloc(&h->points_snap, (size_t)L * 3)) return -1;
+    int nr = 0, nv = 0;
+    for (int i = 0; i < P; ++i) if (d->pose_rid[i] >= 0) nr = std::max(nr, d->pose_rid[i] + 1);
+    for (int i = 0; i < L; ++i) if (d->point_vid[i] >= 0) nv = std::max(nv, d->point_vid[i] + 1);
+    h->nr = nr; h->nv = nv;
+    std::vector<int32_t> point_of_vid(nv, -1);
+    for (int i = 0; i < L; ++i) if (d->point_vid[i] >= 0) point_of_vid[d->point_vid[i]] = i;
+    for (int v = 0; v < nv; ++v) if (point_of_vid[v] < 0) return fail("point_vid is not a dense 0..nv-1 numbering");
+    // Internal landmark order ("slots"): by the lowest pose index that observes the landmark, so the
+    // Z rows a pose (and a reduced-system block row) touches come from a compact address range and
+    // stay in the 4 MB per-XCD L2, whatever order the caller numbered the landmarks in.
+    std::vector<int32_t> first_pose(L, INT32_MAX);
+    for (long i = 0; i < N; ++i) {
+        const int pt = d->obs_point[i];
+        if (pt >= 0 && pt < L) first_pose[pt] = std::min(first_pose[pt], d->obs_pose[i]);
+    }
+    std::vector<int32_t>& vid_of_slot = h->h_vid_of_slot;
+    vid_of_slot.resize(nv);
+    for (int v = 0; v < nv; ++v) vid_of_slot[v] = v;
+    std::stable_sort(vid_of_slot.begin(), vid_of_slot.end(), [&](int32_t a, int32_t b) {
+        return first_pose[point_of_vid[a]] < first_pose[point_of_vid[b]]; });
+    std::vector<int32_t> lm_point(nv), point_slot(L, -1);
+    for (int s2 = 0; s2 < nv; ++s2) { lm_point[s2] = point_of_vid[vid_of_slot[s2]]; point_slot[lm_point[s2]] = s2; }
+    {
+        std::vector<char> seen(nr, 0);
+        for (int i = 0; i < P; ++i) if (d->pose_rid[i] >= 0) {
+            if (seen[d->pose_rid[i]]) return fail("pose_rid has duplicates");
+            seen[d->pose_rid[i]] = 1;
+        }
+        for (int i = 0; i < nr; ++i) if (!seen[i]) return fail("pose_rid is not a dense 0..nr-1 numbering");
+    }
+
+    if (h->upload(&h->point_vid, point_slot)) return -1;     // device-side 'vid' = internal slot
+
+    lap("parameter tables");
+    // ---- observation groups
+    std::vector<ObsGroup> og(std::max(1, d->num_obs_groups));
+    for (int gi = 0; gi < d->num_obs_groups; ++gi) {
+        const double* row = d->obs_groups + 4 * gi;
+        const int cam = (int)row[0], st = (int)row[1];
+        if (cam < 0 || cam >= d->num_cams || st < 0 || st >= d->num_stiff3) return fail("obs group index out of range");
+        const double* c = d->cams + 5 * cam;
+        ObsGroup& o = og[gi];
+        o.cu = c[0]; o.cv = c[1]; o.fu = c[2]; o.fv = c[3];
+        o.cam_type = c[4] < 0.0 ? 1 : 0;            // cams row: baseline b >= 0 = stereo, b = -1 = RGB-D
+        o.b = o.cam_type ? 0.0 : c[4];
+        for (int k = 0; k < 9; ++k) o.S[k] = d->stiff3[9 * st + k];
+        o.loss_id = (int)row[2]; o.loss_k = row[3];
+    }
+    if (h->upload(&h->ogroups, og)) return -1;
+
+    lap("observation groups");
+    // ---- observations sorted by landmark: variable points (by vid) first, then constant points
+    std::vector<int64_t> order(N);
+    for (long i = 0; i < N; ++i) order[i] = i;
+    auto lm_key = [&](long i) -> int64_t {
+        const int v = point_slot[d->obs_point[i]];
+        return v >= 0 ? (int64_t)v : (int64_t)nv + d->obs_point[i];
+    };
+    counting_sort(order, (size_t)nv + (size_t)L + 1, [&](int64_t a) { return lm_key(a); });
+    std::vector<LObs> lobs(N);
+    std::vector<int32_t> lorig(N), lm_ptr(nv + 1, 0);
+    long Nl = 0;
+    for (long k = 0; k < N; ++k) {
+        const long i = order[k];
+        const int pose = d->obs_pose[i], pt = d->obs_point[i], grp = d->obs_grp[i];
+        if (pose < 0 || pose >= P || pt < 0 || pt >= L || grp < 0 || grp >= d->num_obs_groups)
+            return fail("observation index out of range");
+        LObs& o = lobs[k];
+        o.u = d->obs_uvd[3 * i]; o.v = d->obs_uvd[3 * i + 1]; o.d = d->obs_uvd[3 * i + 2];
+        o.pose_grp = (int32_t)((uint32_t)pose | ((uint32_t)grp << 24));
+        o.point = pt;
+        lorig[k] = (int32_t)i;
+        const int v = point_slot[pt];
+        if (v >= 0) { lm_ptr[v + 1] += 1; ++Nl; }
+    }
+    for (int v = 0; v < nv; ++v) lm_ptr[v + 1] += lm_ptr[v];
+    h->Nl = Nl;
+    if (h->upload(&h->lobs, lobs) || h->upload(&h->lorig, lorig) || h->upload(&h->lm_ptr, lm_ptr) ||
+        h->upload(&h->lm_point, lm_point)) return -1;
+    if (h->alloc(&h->Z, (size_t)Nl * 18) || h->alloc(&h->Cinv, (size_t)nv * 6) ||
+        h->alloc(&h->cvec, (size_t)nv * 3) || h->alloc(&h->dxl, (size_t)nv * 3)) return -1;
+    HIP_OK(hipMemsetAsync(h->dxl, 0, std::max<size_t>(1, (size_t)nv * 3) * sizeof(double), h->stream));
+
+    lap("landmark sort + lobs");
+    // ---- pose segments (observations on variable poses), chunks of 256
+    std::vector<int32_t> pcount(nr + 1, 0);
+    for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pcount[r + 1]++; }
+    for (int r = 0; r < nr; ++r) pcount[r + 1] += pcount[r];
+    const long Np = h->Np = pcount[nr];
+    for (int r = 0; r < nr; ++r) h->max_pose_obs = std::max(h->max_pose_obs, pcount[r + 1] - pcount[r]);
+    std::vector<int32_t> pidx(Np), fill(pcount.begin(), pcount.end() - 1);
+    for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pidx[fill[r]++] = (int32_t)k; }
+    std::vector<PItem> pitems;
+    std::vector<int32_t> pitem_ptr(nr + 1, 0);
+    std::vector<int32_t> pose_of_rid(std::max(nr, 1), 0);
+    for (int p = 0; p < P; ++p) if (d->pose_rid[p] >= 0) pose_of_rid[d->pose_rid[p]] = p;
+    if (h->upload(&h->pose_of_rid, pose_of_rid)) return -1;
+    // chunk of observations per workgroup: 1024 (four per thread) once that still fills the chip
+    const int pchunk = Np >= 1024L * 512 ? 1024 : 256;
+    for (int r = 0; r < nr; ++r) {
+        for (int s = pcount[r]; s < pcount[r + 1]; s += pchunk)
+            pitems.push_back({r, s, std::min(s + pchunk, pcount[r + 1]), pose_of_rid[r]});
+        pitem_ptr[r + 1] = (int32_t)pitems.size();
+    }
+    // pose-sorted copy of the observation records; the pose bits (uniform per chunk) carry the landmark slot + 1
+    if (nv >= (1 << 24) - 1) return fail("too many variable landmarks for the 24-bit slot field");
+    std::vector<LObs> pobs((size_t)Np);
+    for (long k = 0; k < Np; ++k) {
+        pobs[k] = lobs[pidx[k]];
+        const int slot = point_slot[pobs[k].point];              // -1: constant point
+        pobs[k].pose_grp = (int32_t)(((uint32_t)PS_GRP_OF(pobs[k]) << 24) | (uint32_t)(slot + 1));
+    }
+    h->npitems = (int)pitems.size();
+    if (h->upload(&h->pitems, pitems) || h->upload(&h->pitem_ptr, pitem_ptr) ||
+        h->upload(&h->pobs, pobs) || h->alloc(&h->ppartial, (size_t)pitems.size() * PS_NPOSE_ACC)) return -1;
+
+    lap("pose segments + pobs");
+    // ---- pose factors: edges then priors
+    const long E = d->num_edges, Q = d->num_priors, F = h->F = E + Q;
+    std::vector<FactorGroup> fg(std::max(1, d->num_edge_groups));
+    for (int gi = 0; gi < d->num_edge_groups; ++gi) {
+        const double* row = d->edge_groups + 3 * gi;
+        const int st = (int)row[0];
+        if (st < 0 || st >= d->num_stiffd) return fail("edge group stiffness index out of range");
+        std::memset(&fg[gi], 0, sizeof(FactorGroup));
+        for (int k = 0; k < DD; ++k) fg[gi].S[k] = d->stiffd[(size_t)DD * st + k];
+        fg[gi].loss_id = (int)row[1]; fg[gi].loss_k = row[2];
+    }
+    std::vector<int32_t> f_i(F), f_j(F), f_grp(F);
+    std::vector<double> f_T((size_t)F * PW);
+    for (long f = 0; f < E; ++f) {
+        f_i[f] = d->e_i[f]; f_j[f] = d->e_j[f]; f_grp[f] = d->e_grp[f];
+        std::memcpy(&f_T[(size_t)f * PW], d->e_Tobs_inv + (size_t)f * PW, PW * sizeof(double));
+    }
+    for (long u = 0; u < Q; ++u) {
+        f_i[E + u] = -1; f_j[E + u] = d->u_i[u]; f_grp[E + u] = d->u_grp[u];
+        std::memcpy(&f_T[(size_t)(E + u) * PW], d->u_Tobs_inv + (size_t)u * PW, PW * sizeof(double));
+    }
+    for (long f = 0; f < F; ++f)
+        if (f_j[f] < 0 || f_j[f] >= P || f_i[f] >= P || f_grp[f] < 0 || f_grp[f] >= d->num_edge_groups)
+            return fail("pose factor index out of range");
+    if (h->upload(&h->fgroups, fg) || h->upload(&h->f_i, f_i) || h->upload(&h->f_j, f_j) ||
+        h->upload(&h->f_grp, f_grp) || h->upload(&h->f_Tinv, f_T)) return -1;
+    const int FROW = 3 * DD + 2 * D;
+    if (h->alloc(&h->fscratch, (size_t)F * FROW)) return -1;
+
+    lap("pose factors");
+    // ---- Schur pairs per landmark (upper-triangle block keys)
+    // Landmark tiles: when Z (144 B per row) is much larger than the eight 4 MB L2s, the pair list is
+    // cut into tiles of consecutive landmarks (consecutive Z rows) and ONE XCD works through a whole
+    // tile: a Z row is then only ever requested by one L2 instead of by up to eight.  A block that
+    // receives pairs from several tiles gets one partial per (tile, block) task, summed in tile order
+    // by k_schur_combine (fixed order => deterministic).  Measured at C3 (72 MB of Z): 8 tiles of 9 MB
+    // beat both no tiling (71 -> 65 us) and L2-sized 2-4 MB tiles (71-82 us: five times more tasks,
+    // and the per-task prologue/epilogue costs more than the extra L2 hits save).
+    std::vector<PairRec> prs;
+    int ntiles = 1;
+    {
+        const double zbytes = 144.0 * (double)lm_ptr[nv];
+        double tile_kb = 9216.0, min_mb = 16.0;
+        if (const char* e = getenv("PS_SCHUR_TILE_KB")) tile_kb = atof(e);
+        if (const char* e = getenv("PS_SCHUR_TILE_MIN_MB")) min_mb = atof(e);
+        if (tile_kb > 0 && zbytes > min_mb * 1048576.0)
+            ntiles = 8 * (int)std::ceil(zbytes / (8.0 * tile_kb * 1024.0));
+    }
+    std::vector<long> lm_pairs_before(nv + 1, 0);
+    for (int v = 0; v < nv; ++v) {
+        long nvar = 0;
+        for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) nvar += d->pose_rid[PS_POSE_OF(lobs[a])] >= 0;
+        lm_pairs_before[v + 1] = lm_pairs_before[v] + nvar * (nvar - 1) / 2;
+    }
+    const long total_pairs = lm_pairs_before[nv];
+    // one unit of work per tile: the tile's pairs in (block row, block column, landmark) order, written to its
+    // slice of prs; tiles are independent, so they are built by a few host threads
+    auto tile_of = [&](int v) {
+        return (ntiles > 1 && total_pairs > 0)
+            ? (int)std::min<long>(ntiles - 1, (long)((double)ntiles * (double)lm_pairs_before[v] / (double)total_pairs)) : 0;
+    };
+    std::vector<int> tile_begin(ntiles + 1, nv);
+    {
+        int t_prev = -1;
+        for (int v = 0; v < nv; ++v) {
+            const int t = tile_of(v);
+            for (int q = t_prev + 1; q <= t; ++q) tile_begin[q] = v;
+            t_prev = std::max(t_prev, t);
+        }
+        tile_begin[ntiles] = nv;
+        for (int q = ntiles - 1; q >= 0; --q) tile_begin[q] = std::min(tile_begin[q], tile_begin[q + 1]);
+    }
+    prs.resize((size_t)total_pairs);
+    auto build_tile = [&](int tile) {
+        const int v0 = tile_begin[tile], v1 = tile_begin[tile + 1];
+        std::vector<PairRec> loc;
+        loc.reserve((size_t)(lm_pairs_before[v1] - lm_pairs_before[v0]));
+        for (int v = v0; v < v1; ++v)
+            for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) {
+                const int ra = d->pose_rid[PS_POSE_OF(lobs[a])];
+                if (ra < 0) continue;
+                for (int b = a + 1; b < lm_ptr[v + 1]; ++b) {
+                    const int rb = d->pose_rid[PS_POSE_OF(lobs[b])];
+                    if (rb < 0) continue;
+                    if (ra <= rb) loc.push_back({((uint64_t)ra << 32) | (uint32_t)rb, a, b, tile});
+                    else loc.push_back({((uint64_t)rb << 32) | (uint32_t)ra, b, a, tile});
+                }
+            }
+        // (block row, block column): two stable counting passes, least significant first
+        counting_sort(loc, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)x.key; });
+        counting_sort(loc, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)(x.key >> 32); });
+        std::copy(loc.begin(), loc.end(), prs.begin() + lm_pairs_before[v0]);
+    };
+    {
+        const int nthreads = std::max(1, std::min({ntiles, 16, (int)std::thread::hardware_concurrency()}));
+        if (nthreads <= 1) {
+            for (int t = 0; t < ntiles; ++t) build_tile(t);
+        } else {
+            std::atomic<int> next{0};
+            std::vector<std::thread> pool;
+            for (int k = 0; k < nthreads; ++k)
+                pool.emplace_back([&] { for (int t = next++; t < ntiles; t = next++) build_tile(t); });
+            for (auto& th : pool) th.join();
+        }
+    }
+    h->schur_tiles = ntiles;
+    h->npairs = (long)prs.size();
+    if (prs.size() >= (1UL << 31)) return fail("too many Schur pairs for 32-bit indexing");
+
+    lap("pair generation + sort");
+    // ---- block pattern of the reduced system
+    std::vector<uint64_t> keys;                 // upper keys (ri <= rj)
+    keys.reserve(prs.size() / 8 + nr + F + d->num_extra_pairs);
+    for (int r = 0; r < nr; ++r) keys.push_back(((uint64_t)r << 32) | (uint32_t)r);
+    for (size_t k = 0; k < prs.size(); ++k) if (k == 0 || prs[k].key != prs[k - 1].key) keys.push_back(prs[k].key);
+    for (long f = 0; f < E; ++f) {
+        const int ra = d->pose_rid[f_i[f]], rb = d->pose_rid[f_j[f]];
+        if (ra >= 0 && rb >= 0 && ra != rb)
+            keys.push_back(((uint64_t)std::min(ra, rb) << 32) | (uint32_t)std::max(ra, rb));
+    }
+    for (long k = 0; k < d->num_extra_pairs; ++k) {
+        const int ra = d->extra_pair_i[k], rb = d->extra_pair_j[k];
+        if (ra < 0 || rb < 0 || ra >= nr || rb >= nr) return fail("extra pair index out of range");
+        keys.push_back(((uint64_t)std::min(ra, rb) << 32) | (uint32_t)std::max(ra, rb));
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    std::vector<int32_t>& row_ptr = h->h_row_ptr;
+    std::vector<int32_t>& col_idx = h->h_col_idx;
+    row_ptr.assign(nr + 1, 0);
+    for (uint64_t k : keys) {
+        const int a = (int)(k >> 32), b = (int)(uint32_t)k;
+        row_ptr[a + 1]++;
+        if (a != b) row_ptr[b + 1]++;
+    }
+    for (int r = 0; r < nr; ++r) row_ptr[r + 1] += row_ptr[r];
+    const long nnzb_l = row_ptr[nr];
+    if (nnzb_l * DD >= (1L << 31)) return fail("reduced system too large for 32-bit block offsets");
+    const int nnzb = h->nnzb = (int)nnzb_l;
+    col_idx.assign(nnzb, 0);
+    {
+        std::vector<int32_t> f2(row_ptr.begin(), row_ptr.end() - 1);
+        // lower part first needs sorted columns per row: insert (b,a) pairs in key order gives
+        // ascending a for row b; then (a,b) gives ascending b >= a.  Do two passes.
+        for (uint64_t k : keys) { const int a = (int)(k >> 32), b = (int)(uint32_t)k; if (a != b) col_idx[f2[b]++] = a; }
+        for (uint64_t k : keys) { const int a = (int)(k >> 32), b = (int)(uint32_t)k; col_idx[f2[a]++] = b; }
+    }
+    auto slot_of = [&](int a, int b) -> int {
+        const int32_t* lo = col_idx.data() + row_ptr[a];
+        const int32_t* hi = col_idx.data() + row_ptr[a + 1];
+        const int32_t* it = std::lower_bound(lo, hi, b);
+        return (it != hi && *it == b) ? (int)(it - col_idx.data()) : -1;
+    };
+    std::vector<int32_t> diag_slot(nr);
+    for (int r = 0; r < nr; ++r) diag_slot[r] = slot_of(r, r);
+    if (h->upload(&h->row_ptr, row_ptr) || h->upload(&h->col_idx, col_idx) || h->upload(&h->diag_slot, diag_slot)) return -1;
+    h->red_count = (long)nnzb * DD + (long)nr * D + 2;
+    if (h->alloc(&h->red, (size_t)h->red_count + ST_NWORDS / 2)) return -1;       // + the status words: one memset clears both
+    h->status = reinterpret_cast<int32_t*>(h->red + h->red_count);
+    h->S = h->red; h->g = h->red + (size_t)nnzb * DD; h->red_cost = h->g + (size_t)nr * D;
+
+    lap("block pattern");
+    // pair list + one work item (task) per (tile, block) that has pairs
+    std::vector<int2> pairs(prs.size());
+    std::vector<PairItem> pitm;
+    std::vector<int32_t> task_tile;
+    for (size_t k = 0; k < prs.size(); ++k) {
+        pairs[k] = make_int2(prs[k].a, prs[k].b);
+        if (k == 0 || prs[k].key != prs[k - 1].key || prs[k].tile != prs[k - 1].tile) {
+            const int a = (int)(prs[k].key >> 32), b = (int)(uint32_t)prs[k].key;
+            if (!pitm.empty()) pitm.back().end = (int32_t)k;
+            pitm.push_back({slot_of(a, b), slot_of(b, a), (int32_t)k, 0});
+            if (a == b) h->has_diag_tasks = true;
+            task_tile.push_back(prs[k].tile);
+        }
+    }
+    if (!pitm.empty()) pitm.back().end = (int32_t)prs.size();
+    h->npair_items = (int)pitm.size();
+    if (h->upload(&h->pairs, pairs)) return -1;
+    {   // per-XCD work lists.  Untiled: items are sorted by block row, so equal contiguous shares of
+        // the PAIRS (not of the items) give each XCD a contiguous range of block rows with balanced
+        // work.  Tiled: XCD x takes tiles x, x + 8, ... (tiles hold equal pair counts).
+        std::vector<std::vector<int32_t>> lists(8);
+        const double total = (double)pairs.size();
+        for (size_t k = 0; k < pitm.size(); ++k) {
+            const int x = ntiles > 1 ? (task_tile[k] & 7)
+                                     : (total > 0 ? std::min(7, (int)(8.0 * pitm[k].start / total)) : 0);
+            lists[x].push_back((int32_t)k);
+        }
+        // longest tasks first (within each tile): the short ones fill the tail of the XCD's schedule
+        if (!getenv("PS_SCHUR_NO_LPT"))
+            for (auto& l : lists)
+                std::stable_sort(l.begin(), l.end(), [&](int32_t x, int32_t y) {
+                    if (task_tile[x] != task_tile[y]) return task_tile[x] < task_tile[y];
+                    return pitm[x].end - pitm[x].start > pitm[y].end - pitm[y].start; });
+        size_t mx = 0;
+        for (auto& l : lists) mx = std::max(mx, l.size());
+        mx = std::max<size_t>((mx + 3) / 4 * 4, 4);
+        std::vector<PairItem> xit(8 * mx, PairItem{-1, -1, 0, 0});
+        std::vector<int32_t> pos_of_task(pitm.size(), -1);
+        for (int x = 0; x < 8; ++x)
+            for (size_t q = 0; q < lists[x].size(); ++q) {
+                xit[x * mx + q] = pitm[lists[x][q]];
+                pos_of_task[lists[x][q]] = (int32_t)(x * mx + q);
+            }
+        h->pair_per_xcd = (int)mx;
+        if (h->upload(&h->pair_xitems, xit)) return -1;
+        if (ntiles > 1 && !pitm.empty()) {
+            // per-block task lists in tile order (tasks are numbered tile-major); partials are
+            // addressed by dispatch position
+            std::vector<std::pair<int32_t, int32_t>> bt(pitm.size());      // (slot, task)
+            for (size_t k = 0; k < pitm.size(); ++k) bt[k] = {pitm[k].slot, (int32_t)k};
+            std::stable_sort(bt.begin(), bt.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) {
+                return x.first < y.first; });
+            std::vector<PairItem> citm;
+            std::vector<int32_t> ctasks(bt.size());
+            for (size_t k = 0; k < bt.size(); ++k) {
+                ctasks[k] = pos_of_task[bt[k].second];
+                if (k == 0 || bt[k].first != bt[k - 1].first) {
+                    if (!citm.empty()) citm.back().end = (int32_t)k;
+                    citm.push_back({pitm[bt[k].second].slot, pitm[bt[k].second].slotT, (int32_t)k, 0});
+                }
+            }
+            citm.back().end = (int32_t)bt.size();
+            h->ncomb = (int)citm.size();
+            if (h->upload(&h->comb_items, citm) || h->upload(&h->comb_tasks, ctasks)) return -1;
+            if (h->alloc(&h->Spart, xit.size() * 36)) return -1;
+        }
+    }
+    prs.clear(); prs.shrink_to_fit();
+
+    lap("pair items + XCD lists");
+    // ---- factor contribution lists
+    {
+        struct C { int32_t slot, off, tr; };
+        std::vector<C> cs;
+        std::vector<std::vector<int32_t>> gl(nr);
+        for (long f = 0; f < F; ++f) {
+            const int ra = f_i[f] >= 0 ? d->pose_rid[f_i[f]] : -1, rb = d->pose_rid[f_j[f]];
+            const int32_t base = (int32_t)(f * FROW);
+            if ((size_t)f * FROW >= (1UL << 31)) return fail("too many pose factors for 32-bit scratch offsets");
+            if (ra >= 0) { cs.push_back({diag_slot[ra], base, 0}); gl[ra].push_back(base + 3 * DD); }
+            if (rb >= 0) { cs.push_back({diag_slot[rb], base + 2 * DD, 0}); gl[rb].push_back(base + 3 * DD + D); }
+            if (ra >= 0 && rb >= 0) {
+                if (ra == rb) return fail("pose-pose edge connects a pose with itself");
+                cs.push_back({slot_of(ra, rb), base + DD, 0});
+                cs.push_back({slot_of(rb, ra), base + DD, 1});
+            }
+        }
+        std::stable_sort(cs.begin(), cs.end(), [](const C& x, const C& y) { return x.slot < y.slot; });
+        std::vector<int32_t> eslots, eptr, ediag, gptr(nr + 1, 0), gitems;
+        std::vector<int2> eitems(cs.size());
+        for (size_t k = 0; k < cs.size(); ++k) {
+            eitems[k] = make_int2(cs[k].off, cs[k].tr);
+            if (k == 0 || cs[k].slot != cs[k - 1].slot) { eslots.push_back(cs[k].slot); eptr.push_back((int32_t)k); }
+        }
+        eptr.push_back((int32_t)cs.size());
+        for (int32_t s : eslots) {
+            // diagonal iff the slot is some row's diag slot: find its row by binary search on row_ptr
+            const int row = (int)(std::upper_bound(row_ptr.begin(), row_ptr.end(), s) - row_ptr.begin()) - 1;
+            ediag.push_back(col_idx[s] == row ? 1 : 0);
+        }
+        for (int r = 0; r < nr; ++r) { gptr[r + 1] = gptr[r] + (int32_t)gl[r].size(); gitems.insert(gitems.end(), gl[r].begin(), gl[r].end()); }
+        h->nes = (int)eslots.size();
+        if (h->upload(&h->eslots, eslots) || h->upload(&h->eptr, eptr) || h->upload(&h->eslot_diag, ediag) ||
+            h->upload(&h->eitems, eitems) || h->upload(&h->gptr, gptr) || h->upload(&h->gitems, gitems)) return -1;
+    }
+
+    lap("factor lists");
+    // ---- PCG workspace
+    const size_t nvec = (size_t)nr * D;
+    h->npartA = std::max(1, nr);      // k_pcg_spmv: one workgroup (and one p.q partial) per block row
+    h->npartB = std::max(1, cdiv(nr, D == 6 ? PS_PCG_BR(6) : PS_PCG_BR(3)));
+    h->hist_cap = 4098;            // classic PCG uses [0,cap); the fused CG needs 2*cap (gamma | alpha)
+    if (h->alloc(&h->x, nvec) || h->alloc(&h->r, nvec) || h->alloc(&h->z, nvec) || h->alloc(&h->p0, nvec) ||
+        h->alloc(&h->p1, nvec) || h->alloc(&h->q, nvec) || h->alloc(&h->Minv, (size_t)nr * DD) ||
+        h->alloc(&h->rz_part, h->npartB) || h->alloc(&h->rr_part, h->npartB) || h->alloc(&h->pq_part, h->npartA) ||
+        h->alloc(&h->hist, 2 * (size_t)h->hist_cap)) return -1;
+    {
+        std::vector<int32_t> brow_of(nnzb), ident(nnzb);
+        for (int r = 0; r < nr; ++r) for (int b = row_ptr[r]; b < row_ptr[r + 1]; ++b) brow_of[b] = r;
+        for (int b = 0; b < nnzb; ++b) ident[b] = b;
+        if (h->upload(&h->brow_of, brow_of) || h->upload(&h->ident_slot, ident)) return -1;
+        if (h->alloc(&h->Linv, (size_t)nr * DD)) return -1;
+    }
+    HIP_OK(hipMemsetAsync(h->x, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->p0, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->p1, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
+
+    lap("pcg workspace");
+    // ---- scalars
+    h->ncost_obs = N > 0 ? std::min(2048, cdiv(N, 256)) : 0;
+    h->ncost_fac = F > 0 ? std::min(1024, cdiv(F, 256)) : 0;
+    if (h->alloc(&h->cost_partials, (size_t)std::max(h->ncost_obs + h->ncost_fac, 512) + 8) ||
+        h->alloc(&h->scalars, SC_NWORDS)) return -1;
+    HIP_OK(hipMemsetAsync(h->scalars, 0, SC_NWORDS * sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+    h->nsq_l = nv > 0 ? cdiv(nv, 256 / PS_LM_GROUP) : 0;
+    h->nsq_p = nr > 0 ? cdiv(P, 256) : 0;
+    if (h->alloc(&h->sq_part_l, (size_t)h->nsq_l) || h->alloc(&h->sq_part_p, (size_t)h->nsq_p) ||
+        h->alloc(&h->shard_buf, 2)) return -1;
+    HIP_OK(hipMemsetAsync(h->shard_buf, 0, 2 * sizeof(double), h->stream));
+    HIP_OK(hipHostMalloc((void**)&h->h_scalars, SC_NWORDS * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostMalloc((void**)&h->h_status, ST_NWORDS * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostGetDevicePointer((void**)&h->h_scalars_dev, h->h_scalars, 0));
+    HIP_OK(hipHostGetDevicePointer((void**)&h->h_status_dev, h->h_status, 0));
+    HIP_OK(hipHostMalloc((void**)&h->h_seq, sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostMalloc((void**)&h->h_shard, 2 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostGetDevicePointer((void**)&h->h_shard_dev, h->h_shard, 0));
+    HIP_OK(hipHostGetDevicePointer((void**)&h->h_seq_dev, h->h_seq, 0));
+    *h->h_seq = 0;
+    if (h->alloc(&h->arrivals, 2)) return -1;
+    HIP_OK(hipMemsetAsync(h->arrivals, 0, 2 * sizeof(int32_t), h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    lap("scalars + final sync");
+    guard.ok = true;
+    *out = h;
+    return 0;
+}

@@ -1,0 +1,199 @@
+// ps_abi_small.h -- C ABI: frame-to-frame RANSAC and dense photometric alignment.
+// Part of ps_core.hip (one translation unit; included from there, in this order).
+
+// ---- frame-to-frame RANSAC (reference pyslam/pipelines/ransac.py) -------------------------------
+int ps_ransac_transforms(const double* pts_1, const double* pts_2, int32_t batch, int32_t n, double* T_out) {
+    if (!pts_1 || !pts_2 || !T_out || batch < 0 || n <= 0) return fail("bad argument");
+    if (batch == 0) return 0;
+    if (need_device()) return -1;
+    const size_t nb = (size_t)batch * n * 3 * sizeof(double);
+    DevBuf a, b, t;
+    if (a.get(nb) || b.get(nb) || t.get((size_t)batch * 16 * sizeof(double))) return -1;
+    HIP_OK(hipMemcpy(a.p, pts_1, nb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(b.p, pts_2, nb, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ransac_transforms, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, a.as<double>(), b.as<double>(),
+                       t.as<double>());
+    HIP_OK(hipMemcpy(T_out, t.p, (size_t)batch * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ps_ransac_cost(const double* T, int32_t num_hyp, const double* pts_1, const double* obs_2, int32_t num_pts,
+                   const double* cam5, double thresh, uint8_t* masks, int32_t* counts) {
+    if (!T || !pts_1 || !obs_2 || !cam5 || num_hyp < 0 || num_pts < 0) return fail("bad argument");
+    if (num_hyp == 0) return 0;
+    if (need_device()) return -1;
+    DevBuf dT, dp, dobs, dcam, dcnt, dmask;
+    const size_t pb = (size_t)num_pts * 3 * sizeof(double);
+    if (dT.get((size_t)num_hyp * 16 * sizeof(double)) || dp.get(pb) || dobs.get(pb) || dcam.get(5 * sizeof(double)) ||
+        dcnt.get((size_t)num_hyp * sizeof(int32_t)) || dmask.get((size_t)num_hyp * num_pts)) return -1;
+    HIP_OK(hipMemcpy(dT.p, T, (size_t)num_hyp * 16 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dp.p, pts_1, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dobs.p, obs_2, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dcam.p, cam5, 5 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ransac_hypotheses, dim3(num_hyp), dim3(256), 0, 0, num_pts, 0, (const int32_t*)nullptr,
+                       dp.as<double>(), (const double*)nullptr, dobs.as<double>(), dcam.as<double>(), thresh,
+                       dT.as<double>(), dcnt.as<int32_t>(), dmask.as<uint8_t>());
+    if (masks) HIP_OK(hipMemcpy(masks, dmask.p, (size_t)num_hyp * num_pts, hipMemcpyDeviceToHost));
+    if (counts) HIP_OK(hipMemcpy(counts, dcnt.p, (size_t)num_hyp * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_OK(hipDeviceSynchronize());
+    return 0;
+}
+
+int ps_ransac_frame_to_frame(const double* pts_1, const double* pts_2, const double* obs_2, int32_t num_pts,
+                             const int32_t* sample_idx, int32_t num_hyp, int32_t set_size, const double* cam5,
+                             double thresh, double* T_all, int32_t* counts, int32_t* best_index,
+                             int32_t* best_count, double* T_best, uint8_t* best_mask) {
+    if (!pts_1 || !pts_2 || !obs_2 || !sample_idx || !cam5 || num_pts <= 0 || num_hyp <= 0 || set_size <= 0)
+        return fail("bad argument");
+    for (size_t k = 0; k < (size_t)num_hyp * set_size; ++k)
+        if (sample_idx[k] < 0 || sample_idx[k] >= num_pts) return fail("sample index out of range");
+    if (need_device()) return -1;
+    DevBuf dp1, dp2, dobs, dcam, didx, dT, dcnt, dmask, dbest, dTb, dbm;
+    const size_t pb = (size_t)num_pts * 3 * sizeof(double);
+    if (dp1.get(pb) || dp2.get(pb) || dobs.get(pb) || dcam.get(5 * sizeof(double)) ||
+        didx.get((size_t)num_hyp * set_size * sizeof(int32_t)) || dT.get((size_t)num_hyp * 16 * sizeof(double)) ||
+        dcnt.get((size_t)num_hyp * sizeof(int32_t)) || dmask.get((size_t)num_hyp * num_pts) ||
+        dbest.get(2 * sizeof(int32_t)) || dTb.get(16 * sizeof(double)) || dbm.get((size_t)num_pts)) return -1;
+    HIP_OK(hipMemcpy(dp1.p, pts_1, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dp2.p, pts_2, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dobs.p, obs_2, pb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dcam.p, cam5, 5 * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(didx.p, sample_idx, (size_t)num_hyp * set_size * sizeof(int32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ransac_hypotheses, dim3(num_hyp), dim3(256), 0, 0, num_pts, set_size, didx.as<int32_t>(),
+                       dp1.as<double>(), dp2.as<double>(), dobs.as<double>(), dcam.as<double>(), thresh,
+                       dT.as<double>(), dcnt.as<int32_t>(), dmask.as<uint8_t>());
+    hipLaunchKernelGGL(k_ransac_best, dim3(1), dim3(256), 0, 0, num_hyp, num_pts, dcnt.as<int32_t>(), dT.as<double>(),
+                       dmask.as<uint8_t>(), dbest.as<int32_t>(), dTb.as<double>(), dbm.as<uint8_t>());
+    int32_t bi[2];
+    HIP_OK(hipMemcpy(bi, dbest.p, sizeof(bi), hipMemcpyDeviceToHost));
+    if (best_index) *best_index = bi[0];
+    if (best_count) *best_count = bi[1];
+    if (T_best) HIP_OK(hipMemcpy(T_best, dTb.p, 16 * sizeof(double), hipMemcpyDeviceToHost));
+    if (best_mask) HIP_OK(hipMemcpy(best_mask, dbm.p, (size_t)num_pts, hipMemcpyDeviceToHost));
+    if (T_all) HIP_OK(hipMemcpy(T_all, dT.p, (size_t)num_hyp * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    if (counts) HIP_OK(hipMemcpy(counts, dcnt.p, (size_t)num_hyp * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- dense photometric alignment (reference pyslam/residuals/photometric_residual.py) ------------------
+struct ps_photo {
+    hipStream_t stream = nullptr;
+    PhotoArgs args{};
+    std::vector<void*> allocs;
+    double *pose = nullptr, *partials = nullptr, *out = nullptr;
+    int nparts = 0;
+    double h_out[PS_PHOTO_NOUT];
+    int upload(const double** dst, const double* src, size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(double)) != hipSuccess) return fail("hipMalloc failed");
+        allocs.push_back(p);
+        if (n && hipMemcpy(p, src, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+        *dst = (const double*)p;
+        return 0;
+    }
+    ~ps_photo() { for (void* p : allocs) hipFree(p); }
+};
+
+namespace {
+int photo_pass(ps_photo* h, int with_normal, int update) {
+    hipLaunchKernelGGL(k_photo_pass, dim3(h->nparts), dim3(256), 0, h->stream, h->args, (const double*)h->pose, with_normal,
+                       h->partials);
+    hipLaunchKernelGGL(k_photo_finish, dim3(1), dim3(256), 0, h->stream, h->nparts, (const double*)h->partials, with_normal,
+                       update, h->pose, h->out);
+    return 0;
+}
+int photo_fetch(ps_photo* h) {
+    HIP_OK(hipMemcpyAsync(h->h_out, h->out, sizeof(h->h_out), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+}  // namespace
+
+int ps_photometric_create(const ps_photo_desc* d, void* stream, ps_photo** out) {
+    if (!d || !out) return fail("null argument");
+    *out = nullptr;
+    if (d->num_pixels < 0 || d->height <= 0 || d->width <= 0) return fail("bad image or pixel count");
+    if (d->num_pixels > 0 && (!d->pt_ref || !d->im_ref || !d->im_jac || !d->tri_jac_d)) return fail("null pixel table");
+    if (!d->im_track) return fail("null tracking image");
+    if (d->cam_type != 0 && d->cam_type != 1) return fail("cam_type must be 0 (stereo) or 1 (RGB-D)");
+    if (d->loss_id < 0 || d->loss_id > 5) return fail("unknown loss id");
+    if (need_device()) return -1;
+    std::unique_ptr<ps_photo> h(new ps_photo);
+    h->stream = (hipStream_t)stream;
+    PhotoArgs& a = h->args;
+    const size_t n = (size_t)d->num_pixels;
+    a.n = d->num_pixels; a.h = d->height; a.w = d->width;
+    if (h->upload(&a.pt_ref, d->pt_ref, 3 * n) || h->upload(&a.im_ref, d->im_ref, n) ||
+        h->upload(&a.im_jac, d->im_jac, 2 * n) || h->upload(&a.tri_jac_d, d->tri_jac_d, 3 * n) ||
+        h->upload(&a.image, d->im_track, (size_t)d->height * d->width)) return -1;
+    a.cu = d->cam[0]; a.cv = d->cam[1]; a.fu = d->cam[2]; a.fv = d->cam[3]; a.b = d->cam[4];
+    a.cam_type = d->cam_type; a.cam_w = (double)d->cam_w; a.cam_h = (double)d->cam_h;
+    a.var_i = d->intensity_covar; a.var_d = d->depth_covar;
+    a.loss_id = d->loss_id; a.loss_k = d->loss_k;
+    h->nparts = std::max(1, cdiv(d->num_pixels, 256 * PS_PHOTO_PPT));
+    const double ident[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    const double* tmp = nullptr;
+    if (h->upload(&tmp, ident, 12)) return -1;
+    h->pose = const_cast<double*>(tmp);
+    std::vector<double> zeros((size_t)h->nparts * PS_PHOTO_NACC + PS_PHOTO_NOUT, 0.0);
+    if (h->upload(&tmp, zeros.data(), (size_t)h->nparts * PS_PHOTO_NACC)) return -1;
+    h->partials = const_cast<double*>(tmp);
+    if (h->upload(&tmp, zeros.data(), (size_t)PS_PHOTO_NOUT)) return -1;
+    h->out = const_cast<double*>(tmp);
+    *out = h.release();
+    return 0;
+}
+
+int ps_photometric_destroy(ps_photo* h) {
+    if (!h) return 0;
+    if (h->stream) hipStreamSynchronize(h->stream); else hipDeviceSynchronize();
+    delete h;
+    return 0;
+}
+
+int ps_photometric_set_pose(ps_photo* h, const double* pose12) {
+    if (!h || !pose12) return fail("null argument");
+    HIP_OK(hipMemcpyAsync(h->pose, pose12, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ps_photometric_get_pose(ps_photo* h, double* pose12) {
+    if (!h || !pose12) return fail("null argument");
+    HIP_OK(hipMemcpyAsync(pose12, h->pose, 12 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ps_photometric_eval_cost(ps_photo* h, double* cost, int64_t* num_valid) {
+    if (!h) return fail("null handle");
+    if (photo_pass(h, 0, 0) || photo_fetch(h)) return -1;
+    if (cost) *cost = h->h_out[42];
+    if (num_valid) *num_valid = (int64_t)h->h_out[43];
+    return 0;
+}
+
+int ps_photometric_normal_equations(ps_photo* h, double* H36, double* b6, double* cost, int64_t* num_valid) {
+    if (!h) return fail("null handle");
+    if (photo_pass(h, 1, 0) || photo_fetch(h)) return -1;
+    if (H36) std::copy(h->h_out, h->h_out + 36, H36);
+    if (b6) std::copy(h->h_out + 36, h->h_out + 42, b6);
+    if (cost) *cost = h->h_out[42];
+    if (num_valid) *num_valid = (int64_t)h->h_out[43];
+    return 0;
+}
+
+int ps_photometric_iteration(ps_photo* h, int32_t split_params, int32_t linesearch, double* dx6, double* cost) {
+    if (!h) return fail("null handle");
+    if (photo_pass(h, 1, split_params ? 2 : 1) || photo_fetch(h)) return -1;
+    if (h->h_out[43] < 6.0) return fail("photometric alignment: fewer than 6 valid pixels");
+    if (h->h_out[50] != 0.0) return fail("photometric alignment: normal equations are not positive definite");
+    if (dx6) std::copy(h->h_out + 44, h->h_out + 50, dx6);
+    double c = h->h_out[42];
+    if (linesearch) {
+        if (photo_pass(h, 0, 0) || photo_fetch(h)) return -1;
+        c = h->h_out[42];
+    }
+    if (cost) *cost = c;
+    return 0;
+}

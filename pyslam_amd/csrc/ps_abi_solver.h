@@ -1,0 +1,457 @@
+// ps_abi_solver.h -- C ABI: staged calls, whole iterations, sharded protocol, covariance columns, options, profiling, dense normal solve.
+// Part of ps_core.hip (one translation unit; included from there, in this order).
+
+int ps_get_info(ps_problem* h, ps_problem_info* info) {
+    if (!h || !info) return fail("null argument");
+    info->dof = h->D; info->num_poses = h->P; info->num_reduced = h->nr; info->num_points = h->L;
+    info->num_var_points = h->nv; info->num_obs = h->N; info->num_edges = h->F; info->num_priors = 0;
+    info->reduced_nnzb = h->nnzb; info->num_pairs = h->npairs; info->reduce_count = h->red_count;
+    info->device_bytes = (int64_t)h->dev_bytes;
+    return 0;
+}
+
+int ps_eval_cost(ps_problem* h, int include_all_constant, double* cost) {
+    if (!h || !cost) return fail("null argument");
+    if (cost_pass(h, include_all_constant, SC_COST)) return -1;
+    if (read_scalars(h)) return -1;
+    *cost = h->h_scalars[SC_COST];
+    return 0;
+}
+
+int ps_linearize(ps_problem* h, double lambda) {
+    if (!h) return fail("null argument");
+    return linearize(h, lambda);
+}
+
+int ps_reduce_buffer(ps_problem* h, void** dev_ptr, int64_t* count) {
+    if (!h || !dev_ptr || !count) return fail("null argument");
+    *dev_ptr = h->red; *count = h->red_count;
+    return 0;
+}
+
+int ps_solve_reduced(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
+    if (!h) return fail("null argument");
+    const int rc = solve_reduced(h, tol, max_iters, iters_out, relres_out);
+    if (rc == 0 && h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    return rc;
+}
+
+int ps_backsub(ps_problem* h) {
+    if (!h) return fail("null argument");
+    return backsub(h);
+}
+
+int ps_get_dx(ps_problem* h, double* dx_pose, double* dx_point) {
+    if (!h) return fail("null argument");
+    std::vector<double> tmp;
+    if (dx_pose && h->nr) HIP_OK(hipMemcpyAsync(dx_pose, h->x, (size_t)h->nr * h->D * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (dx_point && h->nv) {
+        tmp.resize((size_t)h->nv * 3);
+        HIP_OK(hipMemcpyAsync(tmp.data(), h->dxl, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (sync(h)) return -1;
+    for (int s2 = 0; dx_point && s2 < h->nv; ++s2)       // internal slot order -> the caller's vid order
+        std::memcpy(dx_point + 3 * (size_t)h->h_vid_of_slot[s2], &tmp[3 * (size_t)s2], 3 * sizeof(double));
+    return 0;
+}
+
+int ps_step_norm2(ps_problem* h, double* norm2) {
+    if (!h || !norm2) return fail("null argument");
+    if (step_norm(h) || read_scalars(h)) return -1;
+    *norm2 = h->h_scalars[SC_DXP2] + h->h_scalars[SC_DXL2];
+    return 0;
+}
+
+int ps_apply_update(ps_problem* h, double step) {
+    if (!h) return fail("null argument");
+    return apply_update(h, step);
+}
+
+int ps_snapshot_params(ps_problem* h) {
+    if (!h) return fail("null argument");
+    const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
+    if (n1 + n2)
+        hipLaunchKernelGGL(k_copy2, dim3((unsigned)std::min<size_t>(2048, cdiv((long)(n1 + n2), 256))), dim3(256), 0, h->stream,
+                           n1, (const double*)h->poses, h->poses_snap, n2, (const double*)h->points, h->points_snap);
+    return 0;
+}
+
+int ps_restore_params(ps_problem* h) {
+    if (!h) return fail("null argument");
+    const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
+    if (n1 + n2)
+        hipLaunchKernelGGL(k_copy2, dim3((unsigned)std::min<size_t>(2048, cdiv((long)(n1 + n2), 256))), dim3(256), 0, h->stream,
+                           n1, (const double*)h->poses_snap, h->poses, n2, (const double*)h->points_snap, h->points);
+    return 0;
+}
+
+int ps_get_params(ps_problem* h, double* poses, double* points) {
+    if (!h) return fail("null argument");
+    if (poses && h->P) HIP_OK(hipMemcpyAsync(poses, h->poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (points && h->L) HIP_OK(hipMemcpyAsync(points, h->points, (size_t)h->L * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int ps_set_params(ps_problem* h, const double* poses, const double* points) {
+    if (!h) return fail("null argument");
+    if (poses && h->P) HIP_OK(hipMemcpyAsync(h->poses, poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (points && h->L) HIP_OK(hipMemcpyAsync(h->points, points, (size_t)h->L * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return sync(h);
+}
+
+int ps_gn_finish(ps_problem* h, int linesearch, double* cost_out, double* dx_pose_norm2, double* dx_point_norm2) {
+    if (!h) return fail("null argument");
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
+    if (gn_tail(h, linesearch, nullptr)) return -1;
+    if (read_scalars(h)) return -1;
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+    if (dx_pose_norm2) *dx_pose_norm2 = h->h_scalars[SC_DXP2];
+    if (dx_point_norm2) *dx_point_norm2 = h->h_scalars[SC_DXL2];
+    return 0;
+}
+
+int ps_gn_solve_finish(ps_problem* h, double pcg_tol, int pcg_max_iters, int linesearch, double* cost_out,
+                       double* dx_pose_norm2, double* dx_point_norm2, int* pcg_iters_out, double* pcg_relres_out) {
+    if (!h) return fail("null argument");
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
+    if (h->nr > 0 && h->pcg_variant == 1) {
+        const int rc = h->D == 6
+            ? gn_solve_and_finish_async<6>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, nullptr)
+            : gn_solve_and_finish_async<3>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, nullptr);
+        if (rc) return -1;
+    } else {
+        if (solve_reduced(h, pcg_tol, pcg_max_iters, pcg_iters_out, pcg_relres_out)) return -1;
+        if (gn_tail(h, linesearch, nullptr)) return -1;
+        if (read_scalars(h)) return -1;
+    }
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+    if (dx_pose_norm2) *dx_pose_norm2 = h->h_scalars[SC_DXP2];
+    if (dx_point_norm2) *dx_point_norm2 = h->h_scalars[SC_DXL2];
+    return 0;
+}
+
+int ps_set_collective(ps_problem* h, void* nccl_all_reduce_fn, void* nccl_comm) {
+    if (!h) return fail("null argument");
+    h->nccl_allreduce = (ps_problem::allreduce_fn)nccl_all_reduce_fn;
+    h->nccl_comm = nccl_comm;
+    return 0;
+}
+
+int ps_shard_buffer(ps_problem* h, void** dev_ptr) {
+    if (!h || !dev_ptr) return fail("null argument");
+    *dev_ptr = h->shard_buf;
+    return 0;
+}
+
+// Sharded second half WITHOUT a host synchronisation: (first != 0: CG setup,) CG launches, gated
+// tail; cost and ||dx_point||^2 of this shard land in ps_shard_buffer for the caller's all-reduce.
+// Returns 1 when this was the last, ungated pass (max_iters exhausted), else 0.
+int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters, int linesearch, int first) {
+    if (!h) return fail("null argument");
+    if (h->nr == 0 || h->pcg_variant != 1) return fail("ps_gn_solve_finish_enqueue needs the fused CG and a reduced system");
+    h->shard_out = true;
+    struct Reset { ps_problem* h; ~Reset() { h->shard_out = false; } } reset{h};
+    if (first) {
+        HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
+        if (!h->coarse_built && build_coarse(h)) return -1;
+        if (h->cg_explicit) { if (h->D == 6 ? xcg_setup<6>(h, pcg_max_iters, true) : xcg_setup<3>(h, pcg_max_iters, true)) return -1; }
+        else if (h->D == 6 ? cg_fused_setup<6>(h, pcg_max_iters, true) : cg_fused_setup<3>(h, pcg_max_iters, true)) return -1;
+    }
+    // (the explicit PCG runs iteration k in launch group k: one group less than the fused CG's launches)
+    const int limit = pcg_max_iters + (h->cg_explicit ? 1 : 2);
+    const int margin = h->cg_explicit ? 2 : h->cg_margin;
+    int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : (h->cg_explicit ? 32 : 16)) : std::max(8, h->cg_launched / 2);
+    count = std::min(count, limit - h->cg_launched);
+    const bool last = count <= 0;
+    const int32_t* gate = last ? nullptr : h->status;
+    if (h->cg_explicit) {
+        if (!last) {
+            const int head = std::min(count, 12);           // (see gn_solve_and_finish_async)
+            if (h->D == 6) { xcg_launch<6>(h, pcg_tol, head); if (xcg_side_enqueue<6>(h)) return -1; xcg_launch<6>(h, pcg_tol, count - head); }
+            else { xcg_launch<3>(h, pcg_tol, head); if (xcg_side_enqueue<3>(h)) return -1; xcg_launch<3>(h, pcg_tol, count - head); }
+        }
+        if (h->D == 6) hipLaunchKernelGGL(k_cg_unscale<6>, dim3(cdiv((long)h->nr * 6, 256)), dim3(256), 0, h->stream, h->nr, h->Linv, h->cg_xh, h->x, gate);
+        else hipLaunchKernelGGL(k_cg_unscale<3>, dim3(cdiv((long)h->nr * 3, 256)), dim3(256), 0, h->stream, h->nr, h->Linv, h->cg_xh, h->x, gate);
+    } else if (h->D == 6) { if (!last) cg_fused_launch<6>(h, pcg_tol, count); cg_fused_recover<6>(h, gate); }
+    else { if (!last) cg_fused_launch<3>(h, pcg_tol, count); cg_fused_recover<3>(h, gate); }
+    if (gn_tail(h, linesearch, last ? nullptr : h->status)) return -1;
+    return last ? 1 : 0;
+}
+
+// Synchronise and read back: done flag, the (all-reduced) shard buffer, ||dx_pose||^2, CG statistics.
+int ps_gn_result(ps_problem* h, int* done, double* shard2 /* [2] */, double* dx_pose_norm2,
+                 int* pcg_iters_out, double* pcg_relres_out) {
+    if (!h) return fail("null argument");
+    double sb[2] = {0.0, 0.0};
+    HIP_OK(hipMemcpyAsync(sb, h->shard_buf, sizeof(sb), hipMemcpyDeviceToHost, h->stream));
+    if (read_scalars(h)) return -1;
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (done) *done = h->h_status[ST_PCG_DONE];
+    if (shard2) { shard2[0] = sb[0]; shard2[1] = sb[1]; }
+    if (dx_pose_norm2) *dx_pose_norm2 = h->h_scalars[SC_DXP2];
+    return cg_report(h, pcg_iters_out, pcg_relres_out);
+}
+
+int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters, int linesearch,
+                    double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out) {
+    if (!h) return fail("null argument");
+    if (h->nccl_allreduce && h->nccl_comm) {
+        // landmark-sharded iteration, everything on the solver's stream in ONE call:
+        // linearize -> RCCL sum of [S | g | cost] -> replicated CG + gated shard-local tail ->
+        // RCCL sum of {cost, ||dx_point||^2} -> one synchronisation
+        if (h->nr == 0 || h->pcg_variant != 1) return fail("the sharded iteration needs the fused CG and a reduced system");
+        enum { NCCL_F64 = 8, NCCL_SUM = 0 };
+        StageTimer total(h, PS_ST_TOTAL, 2);
+        if (linearize(h, lambda)) return -1;
+        if (h->nccl_allreduce(h->red, h->red, (size_t)h->red_count, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
+            return fail("ncclAllReduce of the reduced system failed");
+        int first = 1, done = 0;
+        double sb[2] = {0.0, 0.0}, dxp2 = 0.0;
+        for (;;) {
+            const int last = ps_gn_solve_finish_enqueue(h, pcg_tol, pcg_max_iters, linesearch, first);
+            if (last < 0) return -1;
+            if (h->nccl_allreduce(h->shard_buf, h->shard_buf, 2, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
+                return fail("ncclAllReduce of the shard scalars failed");
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, h->stream, h->status, h->scalars, h->shard_buf,
+                               h->h_status_dev, h->h_scalars_dev, h->h_shard_dev, h->h_seq_dev, ++h->seq);
+            total.stop();
+            if (wait_published(h)) return -1;
+            if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+            done = h->h_status[ST_PCG_DONE];
+            sb[0] = h->h_shard[0]; sb[1] = h->h_shard[1];
+            dxp2 = h->h_scalars[SC_DXP2];
+            if (cg_report(h, pcg_iters_out, pcg_relres_out)) return -1;
+            if (done || last) break;
+            first = 0;
+        }
+        if (cost_out) *cost_out = sb[0];
+        if (dx_norm_out) *dx_norm_out = std::sqrt(dxp2 + sb[1]);
+        return 0;
+    }
+    if (h->mo_fused && h->nv == 0 && h->F == 0 && h->nr > 0 && h->D == 6 && h->N == h->Np && h->pcg_variant == 1 &&
+        h->max_pose_obs <= 2048) {
+        // motion-only: block-diagonal reduced system, the whole iteration is ONE launch (one workgroup per pose;
+        // beyond ~2 000 observations per pose one workgroup is slower than the multi-kernel path)
+        StageTimer total(h, PS_ST_TOTAL, 2);
+        h->cov_ready = false;
+        if (!h->mo_partials && h->alloc(&h->mo_partials, 2 * (size_t)h->nr)) return -1;
+        if (!h->status_clean) {
+            HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+            h->status_clean = true;
+        }
+        hipLaunchKernelGGL(k_motion_only_iteration, dim3(h->nr), dim3(PS_MO_THREADS), 0, h->stream, h->nr, h->pitems, h->pitem_ptr,
+                           h->pobs, h->points, h->ogroups, h->poses, lambda, linesearch, h->x, h->mo_partials, h->status,
+                           h->scalars, h->arrivals + 1, h->h_status_dev, h->h_scalars_dev, h->h_seq_dev, ++h->seq);
+        total.stop();
+        if (wait_published(h)) return -1;
+        if (pcg_iters_out) *pcg_iters_out = 0;
+        if (pcg_relres_out) *pcg_relres_out = 0.0;
+        if (h->h_status[ST_DIAG_FAIL]) {
+            h->status_clean = false;
+            return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+        }
+        if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+        if (dx_norm_out) *dx_norm_out = std::sqrt(h->h_scalars[SC_DXP2]);
+        return 0;
+    }
+    {
+        StageTimer total(h, PS_ST_TOTAL, 2);  // closed before the last synchronising read-back
+        if (linearize(h, lambda)) return -1;
+        if (h->nr > 0 && h->pcg_variant == 1) {
+            const int rc = h->D == 6
+                ? gn_solve_and_finish_async<6>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, &total)
+                : gn_solve_and_finish_async<3>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, &total);
+            if (rc) return -1;
+        } else {
+            if (solve_reduced(h, pcg_tol, pcg_max_iters, pcg_iters_out, pcg_relres_out)) return -1;
+            if (gn_tail(h, linesearch, nullptr)) return -1;
+            total.stop();
+            if (read_scalars(h)) return -1;
+        }
+    }
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+    // a slot whose reduction did not run (no reduced poses / no variable landmarks) is stale: count it as 0
+    if (dx_norm_out) *dx_norm_out = std::sqrt((h->nr > 0 ? h->h_scalars[SC_DXP2] : 0.0) + (h->nv > 0 ? h->h_scalars[SC_DXL2] : 0.0));
+    return 0;
+}
+
+int ps_covariance_begin(ps_problem* h) {
+    if (!h) return fail("null argument");
+    if (linearize(h, 0.0)) return -1;
+    if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h) && !h->coarse_built && build_coarse(h)) return -1;
+    if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h) && !h->cg_explicit) {
+        const int rc = h->D == 6 ? cg_fused_setup<6>(h, 16) : cg_fused_setup<3>(h, 16);
+        if (rc) return -1;
+    }
+    if (read_scalars(h)) return -1;
+    if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
+    if (h->h_status[ST_DIAG_FAIL]) return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+    if (h->h_slot_of_vid.size() != h->h_vid_of_slot.size()) {
+        h->h_slot_of_vid.assign(h->h_vid_of_slot.size(), 0);
+        for (size_t s2 = 0; s2 < h->h_vid_of_slot.size(); ++s2) h->h_slot_of_vid[h->h_vid_of_slot[s2]] = (int32_t)s2;
+    }
+    h->cov_ready = true;
+    return 0;
+}
+
+int ps_covariance_column(ps_problem* h, int kind, int index, int comp, double tol, int max_iters,
+                         int* iters_out, double* relres_out) {
+    if (!h) return fail("null argument");
+    if (!h->cov_ready) return fail("ps_covariance_column: call ps_covariance_begin first (any linearisation invalidates it)");
+    if (kind == 0 ? (index < 0 || index >= h->nr || comp < 0 || comp >= h->D)
+                  : (kind != 1 || index < 0 || index >= h->nv || comp < 0 || comp >= 3))
+        return fail("ps_covariance_column: parameter index / component out of range");
+    // right-hand side of H x = e in Schur form: c_l = C_l^-1 r_l, g = r_p - sum_l Z_l c_l
+    if (h->nr) HIP_OK(hipMemsetAsync(h->g, 0, (size_t)h->nr * h->D * sizeof(double), h->stream));
+    if (h->nv) HIP_OK(hipMemsetAsync(h->cvec, 0, (size_t)h->nv * 3 * sizeof(double), h->stream));
+    const int slot = kind == 1 ? h->h_slot_of_vid[index] : index;
+    hipLaunchKernelGGL(k_cov_rhs, dim3(1), dim3(64), 0, h->stream, kind, slot, comp, h->D, h->lm_ptr, h->lobs,
+                       h->pose_rid, h->Z, h->Cinv, h->g, h->cvec);
+    int its = 0; double rel = 0.0;
+    if (h->nr > 0) {
+        int rc;
+        if (use_direct(h)) {
+            rc = h->D == 6 ? direct_solve_enqueue<6>(h) : direct_solve_enqueue<3>(h);
+            if (!rc) rc = read_scalars(h);
+            if (!rc) rc = cg_report(h, &its, &rel);
+        } else if (h->pcg_variant == 1 && h->cg_explicit)
+            rc = h->D == 6 ? xcg_run<6>(h, tol, max_iters, &its, &rel) : xcg_run<3>(h, tol, max_iters, &its, &rel);
+        else if (h->pcg_variant == 1)
+            rc = h->D == 6 ? cg_fused_run<6>(h, tol, max_iters, &its, &rel, true) : cg_fused_run<3>(h, tol, max_iters, &its, &rel, true);
+        else
+            rc = h->D == 6 ? pcg_run<6>(h, tol, max_iters, &its, &rel) : pcg_run<3>(h, tol, max_iters, &its, &rel);
+        if (rc) return -1;
+    }
+    if (backsub(h)) return -1;
+    if (iters_out) *iters_out = its;
+    if (relres_out) *relres_out = rel;
+    return 0;
+}
+
+int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx, double* vals, double* g) {
+    if (!h) return fail("null argument");
+    if (row_ptr) std::memcpy(row_ptr, h->h_row_ptr.data(), h->h_row_ptr.size() * sizeof(int32_t));
+    if (col_idx) std::memcpy(col_idx, h->h_col_idx.data(), h->h_col_idx.size() * sizeof(int32_t));
+    if (vals && h->nnzb) HIP_OK(hipMemcpyAsync(vals, h->S, (size_t)h->nnzb * h->D * h->D * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (g && h->nr) HIP_OK(hipMemcpyAsync(g, h->g, (size_t)h->nr * h->D * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+int ps_get_landmark_factors(ps_problem* h, double* cinv, double* c) {
+    if (!h) return fail("null argument");
+    std::vector<double> t6((size_t)h->nv * 6), t3((size_t)h->nv * 3);
+    if (h->nv) {
+        HIP_OK(hipMemcpyAsync(t6.data(), h->Cinv, t6.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(t3.data(), h->cvec, t3.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (sync(h)) return -1;
+    for (int s2 = 0; s2 < h->nv; ++s2) {
+        const size_t v = (size_t)h->h_vid_of_slot[s2];
+        if (cinv) std::memcpy(cinv + 6 * v, &t6[6 * (size_t)s2], 6 * sizeof(double));
+        if (c) std::memcpy(c + 3 * v, &t3[3 * (size_t)s2], 3 * sizeof(double));
+    }
+    return 0;
+}
+
+int ps_debug_reproj_blocks(ps_problem* h, double* r, double* jpose, double* jpoint) {
+    if (!h || !r || !jpose || !jpoint) return fail("null argument");
+    if (h->N == 0) return 0;
+    double *dr, *djp, *djl;
+    HIP_OK(hipMalloc((void**)&dr, (size_t)h->N * 3 * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&djp, (size_t)h->N * 18 * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&djl, (size_t)h->N * 9 * sizeof(double)));
+    hipLaunchKernelGGL(k_debug_reproj, dim3(cdiv(h->N, 256)), dim3(256), 0, h->stream, h->N, h->lobs, h->lorig,
+                       h->poses, h->points, h->ogroups, dr, djp, djl);
+    hipMemcpyAsync(r, dr, (size_t)h->N * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(jpose, djp, (size_t)h->N * 18 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    hipMemcpyAsync(jpoint, djl, (size_t)h->N * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    const int rc = sync(h);
+    hipFree(dr); hipFree(djp); hipFree(djl);
+    return rc;
+}
+
+int ps_set_option(ps_problem* h, const char* name, double value) {
+    if (!h || !name) return fail("null argument");
+    const std::string n(name);
+    if (n == "pcg_variant") { if (value != 0 && value != 1) return fail("pcg_variant must be 0 or 1"); h->pcg_variant = (int)value; }
+    else if (n == "coarse_groups") {
+        if (value < -1 || value > 255) return fail("coarse_groups out of range (-1 auto, 0 off, else number of hat intervals; above 63 only for the explicit two-level PCG)");
+        h->coarse_req = (int)value; h->coarse_built = false;
+    }
+    else if (n == "cg_ablate") h->cg_ablate = (int)value;
+    else if (n == "schur_ablate") h->schur_ablate = (int)value;
+    else if (n == "lm_ablate") h->lm_ablate = (int)value;
+    else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
+    else if (n == "cg_lds") h->cg_lds = value != 0.0;
+    else if (n == "cg_explicit") { h->explicit_ok = value != 0.0; h->coarse_built = false; }
+    else if (n == "big_chol") h->big_chol = value != 0.0;
+    else if (n == "fused_motion_only") h->mo_fused = value != 0.0;
+    else if (n == "direct_max_unknowns") { if (value < 0 || value > 90) return fail("direct_max_unknowns must be 0..90"); h->direct_max = (int)value; }
+    else if (n == "coarse_basis") { h->coarse_basis = value != 0.0; h->lci_next = -1; }
+    else if (n == "profile_every") { if (value < 1) return fail("profile_every must be >= 1"); h->prof_every = (int)value; }
+    else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
+    else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
+    else if (n == "cg_explicit_min_rows") { h->cg_explicit_min_rows = (int)value; h->coarse_built = false; }
+    else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }
+    else return fail("unknown option: " + n);
+    return 0;
+}
+
+int ps_set_profiling(ps_problem* h, int enabled) {
+    if (!h) return fail("null argument");
+    h->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
+    return 0;
+}
+
+int ps_get_stage_times(ps_problem* h, double* ms, int64_t* counts, int reset) {
+    if (!h) return fail("null argument");
+    if (!h->pending.empty() && sync(h)) return -1;       // staged calls only enqueue: collect their events
+    for (int i = 0; i < PS_NUM_STAGES; ++i) {
+        if (ms) ms[i] = h->stage_ms[i];
+        if (counts) counts[i] = h->stage_n[i];
+        if (reset) { h->stage_ms[i] = 0.0; h->stage_n[i] = 0; }
+    }
+    return 0;
+}
+
+int ps_dense_normal_solve(const double* J, const double* r, int32_t m, int32_t n, double* dx, double* covariance) {
+    if (!J || !r || !dx || m <= 0 || n <= 0) return fail("bad argument");
+    if (n > 2048) return fail("generic (host-evaluated) path supports at most 2048 unknowns");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible");
+    double *dJ = nullptr, *dr = nullptr, *dH = nullptr, *dB = nullptr;
+    int32_t* dst = nullptr;
+    const int nrhs = covariance ? n + 1 : 1;
+    HIP_OK(hipMalloc((void**)&dJ, (size_t)m * n * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&dr, (size_t)m * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&dH, (size_t)n * n * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&dB, (size_t)n * nrhs * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&dst, ST_NWORDS * sizeof(int32_t)));
+    HIP_OK(hipMemset(dst, 0, ST_NWORDS * sizeof(int32_t)));
+    HIP_OK(hipMemcpy(dJ, J, (size_t)m * n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dr, r, (size_t)m * sizeof(double), hipMemcpyHostToDevice));
+    double* dg = nullptr;
+    HIP_OK(hipMalloc((void**)&dg, (size_t)n * sizeof(double)));
+    hipLaunchKernelGGL(k_dense_normal, dim3(cdiv((long)n * n, 256)), dim3(256), 0, 0, m, n, dJ, dr, dH, dg);
+    // B = [g | I]
+    std::vector<double> B((size_t)n * nrhs, 0.0), gh(n);
+    HIP_OK(hipMemcpy(gh.data(), dg, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { B[(size_t)i * nrhs] = gh[i]; if (covariance) B[(size_t)i * nrhs + 1 + i] = 1.0; }
+    HIP_OK(hipMemcpy(dB, B.data(), B.size() * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dense_chol_solve, dim3(1), dim3(256), 0, 0, n, nrhs, dH, dB, dst);
+    HIP_OK(hipMemcpy(B.data(), dB, B.size() * sizeof(double), hipMemcpyDeviceToHost));
+    int32_t st[ST_NWORDS];
+    HIP_OK(hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        dx[i] = B[(size_t)i * nrhs];
+        if (covariance) for (int j = 0; j < n; ++j) covariance[(size_t)i * n + j] = B[(size_t)i * nrhs + 1 + j];
+    }
+    hipFree(dJ); hipFree(dr); hipFree(dH); hipFree(dB); hipFree(dst); hipFree(dg);
+    if (st[ST_DIAG_FAIL]) return fail("normal matrix is not positive definite");
+    return 0;
+}

@@ -1,0 +1,696 @@
+// ps_host_cg.h -- host side of the reduced solve: stage timers, classic PCG driver, coarse-level construction, fused-CG setup / launch / recovery.
+// Part of ps_core.hip (one translation unit; included from there, in this order).
+
+namespace {
+
+// ---- stage timers ---------------------------------------------------------
+struct StageTimer {
+    ps_problem* h;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    int slot = -1;
+    StageTimer(ps_problem* h_, int st, int level = 2) : h(h_), stage(st) {
+        if (h->profiling < level) return;
+        if (h->profiling == 1 && h->prof_every > 1 && h->prof_tick % h->prof_every != 0) return;   // sampled launches only
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); h->ev_pool.push_back(e); }
+        }
+        slot = (int)h->ev_used;
+        a = h->ev_pool[h->ev_used++];
+        b = h->ev_pool[h->ev_used++];
+        hipEventRecord(a, h->stream);
+    }
+    void stop() {                        // idempotent; the destructor calls it too
+        if (!a) return;
+        hipEventRecord(b, h->stream);
+        h->pending.push_back({stage, slot});
+        a = nullptr;
+    }
+    ~StageTimer() { stop(); }
+};
+
+void drain_timers(ps_problem* h) {      // call after a stream synchronisation
+    for (auto& pr : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[pr.second], h->ev_pool[pr.second + 1]) == hipSuccess) {
+            h->stage_ms[pr.first] += ms;
+            h->stage_n[pr.first] += 1;
+        }
+    }
+    h->pending.clear();
+    h->ev_used = 0;
+}
+
+int sync(ps_problem* h) {
+    HIP_OK(hipStreamSynchronize(h->stream));
+    drain_timers(h);
+    return 0;
+}
+
+// End of a published iteration: watch the sequence word k_reduce3's last workgroup writes to pinned host
+// memory (a few microseconds cheaper than a stream synchronisation); falls back to the synchronisation
+// when stage timers need their events or the word does not show up in ~1 s.
+int wait_published(ps_problem* h) {
+    volatile long long* w = h->h_seq;
+    for (long spins = 0; spins < 400000000L; ++spins) {
+        if (*w == h->seq) {
+            if (h->pending.empty()) return 0;
+            // stage timers: everything up to k_reduce3 has completed; an event recorded behind it may
+            // need a moment more
+            HIP_OK(hipEventSynchronize(h->ev_pool[h->pending.back().second + 1]));
+            drain_timers(h);
+            return 0;
+        }
+        __builtin_ia32_pause();
+    }
+    return sync(h);
+}
+
+int read_scalars(ps_problem* h) {
+    HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+
+// ---- structure building ---------------------------------------------------
+struct PairRec { uint64_t key; int32_t a, b, tile; };
+
+template <int D>
+int launch_factor_pass(ps_problem* h, double lambda) {
+    if (h->F == 0) return 0;
+    hipLaunchKernelGGL(k_factor_pass<D>, dim3(cdiv(h->F, 4)), dim3(256), 0, h->stream, (int)h->F, h->f_i,
+                       h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->fscratch);
+    const long threads = (long)h->nes * D * D + (long)h->nr * D;
+    hipLaunchKernelGGL(k_factor_assemble<D>, dim3(cdiv(threads, 256)), dim3(256), 0, h->stream, h->nes,
+                       h->eslots, h->eptr, h->eitems, h->eslot_diag, h->nr, h->gptr, h->gitems,
+                       h->fscratch, lambda, h->S, h->g);
+    return 0;
+}
+
+template <int D>
+int pcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
+    const int nr = h->nr;
+    if (max_iters + 2 > h->hist_cap) return fail("pcg max_iters exceeds the history buffer (4096)");
+    hipLaunchKernelGGL(k_block_jacobi<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
+                       h->S, h->Minv, h->status);
+    hipLaunchKernelGGL(k_pcg_init<D>, dim3(h->npartB), dim3(256), 0, h->stream, nr, h->g, h->Minv, h->x,
+                       h->r, h->z, h->rz_part, h->rr_part, h->status);
+    const double tol2 = tol * tol;
+    int k = 0;
+    int chunk = std::max(4, h->last_pcg_iters + 1);
+    bool done = false;
+    while (!done) {
+        const int n = std::min(chunk, max_iters + 1 - k);   // +1: the launch that only detects convergence
+        for (int i = 0; i < n; ++i, ++k) {
+            double* pold = (k & 1) ? h->p1 : h->p0;
+            double* pnew = (k & 1) ? h->p0 : h->p1;
+            hipLaunchKernelGGL(k_pcg_spmv<D>, dim3(h->npartA), dim3(256), 0, h->stream, nr, h->row_ptr,
+                               h->col_idx, h->S, h->z, pold, pnew, h->q, h->rz_part, h->rr_part, h->npartB,
+                               h->pq_part, h->hist, k, tol2, h->status, h->scalars);
+            if (k < max_iters)
+                hipLaunchKernelGGL(k_pcg_update<D>, dim3(h->npartB), dim3(256), 0, h->stream, nr, h->Minv,
+                                   pnew, h->q, h->x, h->r, h->z, h->pq_part, h->npartA, h->hist, k,
+                                   h->rz_part, h->rr_part, h->status);
+        }
+        HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        done = h->h_status[ST_PCG_DONE] != 0 || k > max_iters;
+        chunk = 8;
+    }
+    h->last_pcg_iters = h->h_status[ST_PCG_ITERS];
+    if (iters_out) *iters_out = h->h_status[ST_PCG_ITERS];
+    const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
+    if (relres_out) *relres_out = rr0 > 0.0 ? std::sqrt(rrf / rr0) : 0.0;
+    if (h->h_status[ST_DIAG_FAIL])
+        return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+    return 0;
+}
+
+int ensure_cg_buffers(ps_problem* h, int rows, int blocks) {
+    const int D = h->D;
+    if ((size_t)rows <= h->cg_cap && h->Saug && (size_t)blocks <= h->saug_cap) return 0;
+    const size_t nvec = (size_t)rows * D;
+    if (h->alloc(&h->cg_xh, nvec)) return -1;
+    for (int k = 0; k < 2; ++k)
+        if (h->alloc(&h->cg_r[k], nvec) || h->alloc(&h->cg_w[k], nvec) || h->alloc(&h->cg_s[k], nvec) ||
+            h->alloc(&h->cg_gd[k], 2 * (size_t)std::max(rows, 1))) return -1;
+    double* pv = nullptr;
+    if (h->alloc(&pv, nvec)) return -1;
+    h->cg_p = pv;                                  // the fused CG's search direction (own rows only)
+    if (h->alloc(&h->Saug, (size_t)std::max(blocks, 1) * D * D)) return -1;
+    HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)std::max(blocks, 1) * D * D * sizeof(double), h->stream));
+    h->cg_cap = rows; h->saug_cap = (size_t)std::max(blocks, 1);
+    if (!h->cg_tot && h->alloc(&h->cg_tot, 2)) return -1;
+    return 0;
+}
+
+// Coarse nodes (hat functions over the reduced-pose index) + the augmented BSR pattern
+// [[S^, K], [K^T, I]].  coarse_req = number of intervals G (ncb = G + 1 nodes).
+int build_coarse(ps_problem* h) {
+    const bool timing = getenv("PS_CREATE_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "build_coarse: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    const int nr = h->nr, D = h->D;
+    int G = h->coarse_req;
+    const int Gmax = 63;                           // nc = (G + 1) D <= 384; LDS-resident factorisation up to nc = 96
+    // auto: on from 16 reduced poses, ~18 poses per hat interval, at most 12 intervals while the
+    // coarse factorisation is LDS-resident; large systems (split mode, no dense border rows) take 24
+    // 48
+    const bool sparse_rows = (long)h->nnzb <= 24L * nr;       // pose-graph-like rows (C2: 11 blocks per row)
+    if (G < 0) {
+        if (nr < 16) G = 0;                        // (systems up to 90 unknowns are solved directly anyway)
+        else if (nr > h->cg_split_min_rows) G = 48;                                    // measured: C4 (BA, 2 000 poses) and C2 (10 000-pose chain)
+        else if (sparse_rows && nr >= 150) G = std::min(36, nr / 10);    // pose graphs: 200 poses 67 -> 51 iterations, 350: 85 -> 48
+        else if (!sparse_rows && nr > 250) G = std::min(32, nr / 16);    // BA: 400 keyframes 31 -> 19 iterations (0.81 -> 0.70 ms), 500: 39 -> 17
+        else G = std::min(12, std::max(3, (nr + 9) / 18));
+    }
+    // large reduced systems (more than cg_explicit_min_rows poses): the two-level preconditioner is APPLIED explicitly
+    // (restrict, dense coarse solve, prolong: cg_explicit) instead of folded into the matrix -- the folded form drags
+    // a dense border of ncb blocks through every row (C2: 49 of 60 blocks per row).  Without a border the coarse
+    // level can be much finer, and its factorisation runs beside the CG on the side stream from the second
+    // iteration on.  Pose-graph-like rows (C2: 11 blocks per row, hundreds of CG iterations): one interval per 40
+    // poses, up to 255; bundle-adjustment rows (C4: 80 blocks per row, ~20 iterations -- the factorisation must fit
+    // beside a short CG): one per 20 poses, up to 112 (C4: 42 iterations / 3.7 ms folded at 48 -> 20 / 2.6 ms at 100).
+    // Measured crossover against the folded single-launch CG (whose coarse level is capped at 12 intervals):
+    // pose graphs 400 poses (600: 2.6 -> 1.4 ms, 1 000: 6.1 -> 1.5 ms), bundle adjustment 540 (700: 1.67 -> 1.28 ms).
+    const int xmin = std::min(h->cg_split_min_rows, h->cg_explicit_min_rows >= 0 ? h->cg_explicit_min_rows : (sparse_rows ? 400 : 540));
+    h->cg_explicit = h->explicit_ok && G != 0 && nr > xmin;
+    if (h->cg_explicit && h->coarse_req < 0)
+        G = sparse_rows ? std::min(255, std::max(48, nr / 40)) : std::min(112, std::max(48, nr / 20));
+    G = std::min(G, h->cg_explicit ? 255 : Gmax);
+    if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
+    if (G < 1) G = 0;
+    h->G = G; h->coarse_built = true; h->cg_split = false;
+    const std::vector<int32_t>& rp = h->h_row_ptr;
+    const std::vector<int32_t>& ci = h->h_col_idx;
+    int maxlen = 0;
+    for (int i = 0; i < nr; ++i) maxlen = std::max(maxlen, rp[i + 1] - rp[i]);
+    h->cg_explicit = h->cg_explicit && G > 0;
+    const int ncb_pre = (G && !h->cg_explicit) ? G + 1 : 0;
+    // pad rows to a common width unless that wastes more than 50 % (hub-like graphs): then CSR
+    const bool ell = nr > 0 && (long)(maxlen + ncb_pre) * nr <= (long)(1.5 * (h->nnzb + (long)ncb_pre * nr)) + 64;
+    const int wf = ell ? maxlen + ncb_pre : 0;
+    const int wc = ell ? nr + ncb_pre : 0;       // coarse rows: K^T (nr blocks) + the coarse-coarse row (ncb blocks)
+    h->ell_wf = wf; h->ell_wc = wc;
+    if (G == 0) {
+        h->ncb = h->nc = 0; h->nr_aug = nr;
+        if (!ell) { h->nnzb_aug = h->nnzb; h->arow_ptr = h->row_ptr; h->acol_idx = h->col_idx; h->aug_slot = h->ident_slot;
+                    return ensure_cg_buffers(h, nr, h->nnzb); }
+        std::vector<int32_t> arp(nr + 1), aci((size_t)nr * wf, 0), slot(h->nnzb);
+        for (int i = 0; i < nr; ++i) {
+            arp[i] = i * wf;
+            for (int b = rp[i]; b < rp[i + 1]; ++b) { slot[b] = i * wf + (b - rp[i]); aci[slot[b]] = ci[b]; }
+        }
+        arp[nr] = nr * wf;
+        h->nnzb_aug = nr * wf;
+        if (h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) || h->upload(&h->aug_slot, slot)) return -1;
+        if (ensure_cg_buffers(h, nr, h->nnzb_aug)) return -1;
+        HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)h->nnzb_aug * D * D * sizeof(double), h->stream));
+        return 0;
+    }
+    const int ncb = G + 1;
+    std::vector<int32_t> pnode(nr), slo(ncb, nr), shi(ncb, 0);
+    std::vector<double> pw0(nr), pw1(nr);
+    for (int i = 0; i < nr; ++i) {
+        const double u = (double)i * G / (double)(nr - 1);
+        const int k = std::min(G - 1, (int)u);
+        const double th = u - k;
+        pnode[i] = k; pw0[i] = 1.0 - th; pw1[i] = th;
+        for (int q = k; q <= k + 1; ++q) {
+            // a zero weight at q == k + 1 (row exactly on node k) is skipped; at q == k (the very last row) it is
+            // kept: every row must lie in the support of its own left node, which owns its vector updates in
+            // the explicit PCG (k_xcg_restrict)
+            if (q == k + 1 && pw1[i] == 0.0) continue;
+            slo[q] = std::min(slo[q], i); shi[q] = std::max(shi[q], i + 1);
+        }
+    }
+    std::vector<int32_t> arp(nr + ncb + 1, 0), aci, slot(h->nnzb), fnz(nr);
+    aci.reserve((size_t)h->nnzb + 2 * (size_t)nr * ncb + ncb);
+    for (int i = 0; i < nr; ++i) {
+        fnz[i] = rp[i + 1] - rp[i];
+        for (int b = rp[i]; b < rp[i + 1]; ++b) { slot[b] = (int32_t)aci.size(); aci.push_back(ci[b]); }
+        if (!h->cg_explicit) for (int q = 0; q < ncb; ++q) aci.push_back(nr + q);
+        if (ell) while ((int)aci.size() < (i + 1) * wf) aci.push_back(0);     // zero-valued padding blocks
+        arp[i + 1] = (int32_t)aci.size();
+    }
+    const bool split = nr > h->cg_split_min_rows;      // big systems: no dense K^T rows in the matrix
+    h->cg_split = split && !h->cg_explicit;
+    for (int q = 0; q < ncb && !split; ++q) {       // (explicit mode implies split-sized systems: no coarse rows either)
+        for (int i = 0; i < nr; ++i) aci.push_back(i);
+        for (int q2 = 0; q2 < ncb; ++q2) aci.push_back(nr + q2);
+        arp[nr + q + 1] = (int32_t)aci.size();
+    }
+    if (split) arp.resize(nr + 1);
+    if (split && !h->cg_explicit) {
+        if (h->alloc(&h->cg_U, (size_t)ncb * nr * D) || h->alloc(&h->cg_cgd[0], 2 * (size_t)ncb) ||
+            h->alloc(&h->cg_cgd[1], 2 * (size_t)ncb) || h->alloc(&h->cg_ab, 2)) return -1;
+    }
+    lap("nodes + augmented pattern");
+    // contiguous run of augmented-matrix blocks of fine row i whose column lies in supp(q)
+    // (slo / shi increase with q and the row's columns are sorted: two pointers sweep each row once)
+    std::vector<int32_t> rlo, rhi, eptr, eq, elo, ehi;
+    if (h->cg_explicit) eptr.assign(nr + 1, 0); else { rlo.resize((size_t)nr * ncb); rhi.resize((size_t)nr * ncb); }
+    h->max_row_ents = 0;
+    for (int i = 0; i < nr; ++i) {
+        int lo = rp[i], hi = rp[i];
+        const int end = rp[i + 1];
+        for (int q = 0; q < ncb; ++q) {
+            while (lo < end && ci[lo] < slo[q]) ++lo;
+            while (hi < end && ci[hi] < shi[q]) ++hi;
+            if (!h->cg_explicit) {
+                rlo[(size_t)i * ncb + q] = arp[i] + (lo - rp[i]);
+                rhi[(size_t)i * ncb + q] = arp[i] + (hi - rp[i]);
+            } else if (lo < hi) {                          // explicit PCG: only the non-empty runs, listed per row
+                eq.push_back(q); elo.push_back(arp[i] + (lo - rp[i])); ehi.push_back(arp[i] + (hi - rp[i]));
+            }
+        }
+        if (h->cg_explicit) {
+            eptr[i + 1] = (int32_t)eq.size();
+            h->max_row_ents = std::max(h->max_row_ents, eptr[i + 1] - eptr[i]);
+        }
+    }
+    if (h->cg_explicit) {
+        // segments: for every node pair (q, q') the entries (i in supp(q), node q') in row order
+        std::vector<int32_t> sptr((size_t)ncb * ncb + 1, 0), sent, srow;
+        for (int q = 0; q < ncb; ++q)
+            for (int i = slo[q]; i < shi[q]; ++i)
+                for (int e = eptr[i]; e < eptr[i + 1]; ++e) sptr[(size_t)q * ncb + eq[e] + 1]++;
+        for (size_t k = 0; k < (size_t)ncb * ncb; ++k) sptr[k + 1] += sptr[k];
+        sent.resize(sptr.back()); srow.resize(sptr.back());
+        std::vector<int32_t> pos(sptr.begin(), sptr.end() - 1);
+        for (int q = 0; q < ncb; ++q)
+            for (int i = slo[q]; i < shi[q]; ++i)
+                for (int e = eptr[i]; e < eptr[i + 1]; ++e) {
+                    const int32_t at = pos[(size_t)q * ncb + eq[e]]++;
+                    sent[at] = e; srow[at] = i;
+                }
+        if (h->upload(&h->ent_ptr, eptr) || h->upload(&h->ent_q, eq) || h->upload(&h->ent_lo, elo) ||
+            h->upload(&h->ent_hi, ehi) || h->upload(&h->seg_ptr, sptr) || h->upload(&h->seg_ent, sent) ||
+            h->upload(&h->seg_row, srow)) return -1;
+    }
+    lap("runs");
+    h->ncb = ncb; h->nc = ncb * D; h->nr_aug = nr + ncb; h->nnzb_aug = (int)aci.size();
+    if (h->upload(&h->pnode, pnode) || h->upload(&h->slo, slo) || h->upload(&h->shi, shi) ||
+        h->upload(&h->pw0, pw0) || h->upload(&h->pw1, pw1) || (!h->cg_explicit && (h->upload(&h->run_lo, rlo) ||
+        h->upload(&h->run_hi, rhi))) || h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) ||
+        h->upload(&h->aug_slot, slot) || h->upload(&h->fine_nnz, fnz)) return -1;
+    lap("uploads");
+    if (h->alloc(&h->BSZ, (h->cg_explicit ? eq.size() : (size_t)nr * ncb) * D * D) || h->alloc(&h->Bmat, (size_t)nr * D * D) ||
+        h->alloc(&h->bgv, (size_t)nr * D) || h->alloc(&h->SB, (size_t)aci.size() * D * D)) return -1;
+    if ((!h->cg_explicit && h->alloc(&h->SZ, (size_t)nr * ncb * D * D)) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
+        h->alloc(&h->Lci2[0], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[0], (size_t)h->nc * h->nc) ||
+        h->alloc(&h->Lci2[1], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[1], (size_t)h->nc * h->nc) ||
+        h->alloc(&h->tvec, (size_t)h->nc) || h->alloc(&h->chol_scratch, 2 * (size_t)h->nc * h->nc)) return -1;
+    if (h->cg_explicit && (h->alloc(&h->xstate, 8) || h->alloc(&h->xy, (size_t)h->nc) || h->alloc(&h->xp2, (size_t)nr * D))) return -1;
+    lap("allocations");
+    if (!h->lag_status) {
+        if (h->alloc(&h->lag_status, ST_NWORDS)) return -1;
+        HIP_OK(hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+    }
+    if (!h->side) {
+        int prio_lo = 0, prio_hi = 0;                      // lowest priority: the side work must not delay the CG launches
+        HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_ac, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_chol, hipEventDisableTiming));
+    }
+    if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
+    h->lci_next = -1; h->lci_cur = 0;
+    if (ensure_cg_buffers(h, h->nr_aug, h->nnzb_aug)) return -1;
+    HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)h->nnzb_aug * D * D * sizeof(double), h->stream));
+    return 0;
+}
+
+// factor A_c = L_c L_c^T and form L_c^-1 (+ transpose) into buffer `buf`: LDS-resident single workgroup up to 90
+// unknowns, blocked over the whole chip beyond
+template <int D>
+int coarse_factor(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
+    const int nc = h->nc, ncb = h->ncb;
+    if (nc <= 90) {                                        // 2 nc^2 doubles of dynamic LDS (<= 130 KB)
+        const size_t chol_lds = 2 * (size_t)nc * nc * sizeof(double);
+        HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)chol_lds));
+        hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, st, ncb, h->Ac, h->Lci2[buf],
+                           h->LciT2[buf], stat, nullptr);
+    } else if (h->big_chol) {
+        // blocked factorisation over the whole chip (chol_scratch: working copy of A_c, then the tiles' inverses)
+        double* A = h->chol_scratch;
+        double* Tinv = A + (size_t)nc * nc;
+        HIP_OK(hipMemcpyAsync(A, h->Ac, (size_t)nc * nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+        const int nsteps = cdiv(nc, PS_BC_W);
+        for (int s2 = 0; s2 < nsteps; ++s2) {
+            const int j0 = s2 * PS_BC_W, w = std::min(PS_BC_W, nc - j0), m = nc - j0 - w;
+            hipLaunchKernelGGL(k_bchol_panel, dim3(std::max(1, cdiv((long)m * w, 1024))), dim3(256), 0, st, nc, j0, A,
+                               Tinv + (size_t)s2 * PS_BC_W * PS_BC_W, stat);
+            if (m > 0) {
+                const int nt = cdiv(m, 32);
+                hipLaunchKernelGGL(k_bchol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, nc, j0, w, A);
+            }
+        }
+        // L^-1: diagonal blocks by substitution, the rest merged level by level with triangular products
+        // (the explicit PCG only reads the lower triangle of L^-1 and overwrites the transpose: no zero fill there)
+        const bool dense_out = nc > PS_BI_S0 && !h->cg_explicit;
+        if (dense_out) {
+            HIP_OK(hipMemsetAsync(h->Lci2[buf], 0, (size_t)nc * nc * sizeof(double), st));
+            HIP_OK(hipMemsetAsync(h->LciT2[buf], 0, (size_t)nc * nc * sizeof(double), st));
+        }
+        const size_t inv_lds = ((size_t)PS_BI_S0 + PS_BC_W) * PS_BI_CW * sizeof(double);
+        hipLaunchKernelGGL(k_btri_inverse, dim3(cdiv(nc, PS_BI_CW)), dim3(256), inv_lds, st, nc, A, Tinv, h->Lci2[buf], h->LciT2[buf]);
+        for (int s2 = PS_BI_S0; s2 < nc; s2 *= 2) {
+            const int pairs = cdiv(nc, 2 * s2), nt = cdiv(s2, PS_BM_T);
+            for (int stage = 0; stage < 2; ++stage)
+                hipLaunchKernelGGL(k_btri_merge, dim3(pairs * nt * nt), dim3(256), 0, st, nc, s2, stage, A, h->Lci2[buf], h->LciT2[buf]);
+        }
+        if (dense_out)
+            hipLaunchKernelGGL(k_btri_clear, dim3(cdiv((long)nc * nc, 256)), dim3(256), 0, st, nc, h->LciT2[buf]);
+    } else {
+        hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, st, ncb, h->Ac, h->Lci2[buf],
+                           h->LciT2[buf], stat, h->chol_scratch);
+    }
+    return 0;
+}
+
+template <int D>
+int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rhs_only = false) {
+    const int nr = h->nr, cap = h->hist_cap;
+    if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
+    if (!h->coarse_built && build_coarse(h)) return -1;
+    h->cg_two_level_reduce = h->nr_aug > 2048 || h->cg_split;
+    h->cg_short_rows = (long)h->nnzb_aug <= 24L * h->nr_aug;       // pose-graph-like rows: one wave per row
+    const int G = h->G, rows = h->nr_aug;
+    const int32_t* rp = h->arow_ptr;
+    const int32_t* ci = h->acol_idx;
+    if (rhs_only) {
+        // same matrix (and coarse factor) as the last full setup, new right-hand side h->g
+        hipLaunchKernelGGL(k_cg_prepare<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->g, h->Linv,
+                           h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh, h->status,
+                           G ? h->Bmat : (const double*)nullptr, h->bgv);
+        if (G)
+            hipLaunchKernelGGL(k_coarse_rhs<D>, dim3(1), dim3(1024), 0, h->stream, nr, h->ncb, h->slo, h->shi, h->pnode,
+                               h->pw0, h->pw1, h->LciT2[h->lci_cur], h->arow_ptr, h->Saug, h->tvec, h->cg_r[0], h->cg_w[0],
+                               h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 2, (const int32_t*)nullptr, h->status,
+                               h->bgv);
+        h->cg_launched = 0;
+        return 0;
+    }
+    // block-Jacobi factors + the start vectors of the scaled system (r = Linv g, w = s = p = x = 0)
+    hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
+                       h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
+                       h->poses, h->pose_of_rid, h->coarse_basis, G ? h->Bmat : (double*)nullptr, h->bgv);
+    hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
+                       h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, G ? h->Bmat : (const double*)nullptr, h->SB);
+    if (G) {
+        const int ncb = h->ncb, nc = h->nc;
+        if (h->side_pending) {                  // the side-stream factorisation still reads A_c / writes its buffer
+            HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0));
+            h->side_pending = false;
+        }
+        hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(ncb + 1) * D * D * sizeof(double), h->stream,
+                           nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat, h->BSZ);
+        hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
+                           nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
+        // Exact: factor this iteration's A_c on the solver stream (51 us at C3, serial).  Lagged
+        // ("coarse_lag", whole-iteration calls only): build the augmented system with the factor of the
+        // PREVIOUS iteration's A_c -- any nonsingular L~ gives a consistent system V^T S^ V with
+        // V = [I, P L~^-T]; only the coarse-coarse block changes from I to L~^-1 A_c L~^-T -- and factor
+        // the current A_c on a side stream while the CG iterates.
+        auto launch_chol = [&](hipStream_t st, int buf, int32_t* stat) -> int { return coarse_factor<D>(h, st, buf, stat); };
+        // (long sparse chains in split mode: hundreds of CG iterations dwarf the factorisation, and a stale factor
+        // costs iterations while the trajectory still moves -- C2: 1 320 -> 1 800 in the second GN step -- so no lag there)
+        const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && (!h->cg_split || (long)h->nnzb > 24L * nr);
+        if (lag && h->cg_split && !h->Mc && h->alloc(&h->Mc, (size_t)nc * nc)) return -1;
+        h->mc_active = lag && h->cg_split;
+        const int rpw = nc >= 192 ? 4 : 1;                 // fine block rows per border workgroup
+        const int border_lds = (int)((size_t)rpw * D * nc * sizeof(double));
+        HIP_OK(hipFuncSetAttribute((const void*)k_coarse_border<D>, hipFuncAttributeMaxDynamicSharedMemorySize, border_lds));
+        if (lag) {
+            const int use = h->lci_next;
+            h->lci_cur = use;
+            // borders K, K^T, the coarse-coarse rows and (last workgroup) the coarse right-hand side
+            const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[use], h->tvec, h->cg_r[0], h->cg_w[0],
+                                   h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 2, h->lag_status, h->status, h->bgv, h->cg_split ? h->Mc : nullptr};
+            hipLaunchKernelGGL(k_coarse_border<D>, dim3(cdiv(nr, rpw) + ncb + 1), dim3(256), border_lds, h->stream,
+                               nr, ncb, h->SZ, h->Lci2[use], h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1, h->Ac, ra, rpw);
+            HIP_OK(hipEventRecord(h->ev_ac, h->stream));           // A_c complete, buffer use^1 no longer read
+            HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
+            if (launch_chol(h->side, use ^ 1, h->lag_status)) return -1;
+            HIP_OK(hipEventRecord(h->ev_chol, h->side));
+            h->lci_next = use ^ 1; h->side_pending = true;
+        } else {
+            const int buf = h->lci_cur;
+            if (launch_chol(h->stream, buf, h->status)) return -1;
+            const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[buf], h->tvec, h->cg_r[0], h->cg_w[0],
+                                   h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, nullptr, h->status, h->bgv, nullptr};
+            hipLaunchKernelGGL(k_coarse_border<D>, dim3(cdiv(nr, rpw) + 1), dim3(256), border_lds, h->stream,
+                               nr, ncb, h->SZ, h->Lci2[buf], h->arow_ptr, h->fine_nnz, h->Saug, h->cg_split ? 0 : 1,
+                               (const double*)nullptr, ra, rpw);
+            h->lci_next = buf;
+        }
+    }
+    h->cg_launched = 0;
+    return 0;
+}
+
+// enqueue `count` more CG launches (launch n runs iteration k = n - 1; converged launches exit at once)
+template <int D>
+void cg_fused_launch(ps_problem* h, double tol, int count) {
+    const int cap = h->hist_cap;
+    const int rows = h->cg_split ? h->nr : h->nr_aug;      // matrix rows handled by k_cg_fused
+    const int ncbs = h->cg_split ? h->ncb : 0;
+    const double tol2 = tol * tol;
+    for (int i = 0; i < count; ++i, ++h->cg_launched) {
+        const int n = h->cg_launched, o = n & 1, nw = o ^ 1;
+        // large systems: totals of the previous launch's partials come from a reduce launch
+        const double* tot = h->cg_two_level_reduce ? h->cg_tot : nullptr;
+        if (tot && !h->cg_split && n > 0)
+            hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(1024), 0, h->stream, rows, h->cg_gd[o], h->cg_tot, h->status);
+#define PS_CG_LAUNCH(NWV)                                                                                          \
+        hipLaunchKernelGGL((k_cg_fused<D, NWV>), dim3(rows), dim3(64 * NWV), 0, h->stream, rows, h->arow_ptr,           \
+                           h->acol_idx, h->Saug, h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw],        \
+                           h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,      \
+                           h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc, h->cg_ablate, tot, ncbs,              \
+                           h->fine_nnz, h->cg_cgd[o], h->cg_U, h->cg_ab)
+        if (h->cg_lds && !h->cg_short_rows && !h->cg_split && !tot && !h->cg_ablate && rows <= 1024 &&
+            (long)rows * D <= PS_CGV_MAX) {
+            // small systems: the whole CG vector goes through LDS, one global round trip per launch
+            hipLaunchKernelGGL((k_cg_fused_lds<D, 8>), dim3(rows), dim3(512), 0, h->stream, rows, h->arow_ptr,
+                               h->acol_idx, h->Saug, h->cg_r[o], h->cg_w[o], h->cg_s[o], h->cg_r[nw], h->cg_w[nw],
+                               h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_gd[o], h->cg_gd[nw], h->hist, cap, n - 1, tol2,
+                               h->status, h->scalars, h->nr, h->ell_wf, h->ell_wc);
+        }
+        else if (h->cg_short_rows) { PS_CG_LAUNCH(1); }
+        else if (rows > 1024) { PS_CG_LAUNCH(4); }      // many rows: smaller workgroups, more of them in flight
+        else { PS_CG_LAUNCH(8); }
+#undef PS_CG_LAUNCH
+        if (h->cg_split)      // fine totals + the coarse rows of this iteration
+            hipLaunchKernelGGL(k_cg_reduce_split<D>, dim3(1 + h->ncb), dim3(1024), 0, h->stream, rows, h->ncb,
+                               h->cg_gd[nw], h->cg_tot, h->cg_U, h->cg_ab, h->cg_r[o], h->cg_w[o], h->cg_s[o],
+                               h->cg_r[nw], h->cg_w[nw], h->cg_s[nw], h->cg_p, h->cg_xh, h->cg_cgd[nw], h->status,
+                               h->mc_active ? h->Mc : (const double*)nullptr);
+    }
+}
+
+// x = L^-T (x^_f + P y): gated on the CG's convergence flag when `gate` is given
+template <int D>
+void cg_fused_recover(ps_problem* h, const int32_t* gate) {
+    const int nr = h->nr;
+    if (h->G)
+        hipLaunchKernelGGL(k_coarse_recover<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->ncb,
+                           h->pnode, h->pw0, h->pw1, h->Linv, h->Lci2[h->lci_cur], h->cg_xh, h->x, gate, h->Bmat);
+    else
+        hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->Linv,
+                           h->cg_xh, h->x, gate);
+}
+
+int cg_report(ps_problem* h, int* iters_out, double* relres_out) {
+    h->last_pcg_iters = h->h_status[ST_PCG_ITERS];
+    if (iters_out) *iters_out = h->h_status[ST_PCG_ITERS];
+    const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
+    if (relres_out) *relres_out = rr0 > 0.0 ? std::sqrt(rrf / rr0) : 0.0;
+    if (h->h_status[ST_LM_FAIL]) {                           // (its NaNs also spoil the reduced system: report the cause)
+        h->lci_next = -1;
+        return fail("a landmark block H_ll is not positive definite");
+    }
+    if (h->h_status[ST_DIAG_FAIL]) {
+        if (h->lag_status) hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream);
+        h->lci_next = -1;                               // never reuse a factor from a failed solve
+        return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+    }
+    if (h->h_status[ST_PCG_DONE] == 2) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "CG breakdown: the reduced system is not positive definite (iteration %d, relative residual %.2e)",
+                 h->h_status[ST_PCG_ITERS], rr0 > 0.0 ? std::sqrt(rrf / rr0) : 0.0);
+        return fail(buf);
+    }
+    return 0;
+}
+
+// synchronous solve (staged API): poll the convergence flag every chunk
+template <int D>
+int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out, bool rhs_only = false) {
+    if (cg_fused_setup<D>(h, max_iters, false, rhs_only)) return -1;
+    int chunk = std::max(h->pcg_chunk, h->last_pcg_iters + 2);
+    bool done = false;
+    while (!done) {
+        const int m = std::min(chunk, max_iters + 2 - h->cg_launched);
+        cg_fused_launch<D>(h, tol, m);
+        HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 2;
+        chunk = h->pcg_chunk;
+    }
+    if (h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL]) {
+        // the pipelined (Chronopoulos-Gear) recurrences lost positivity -- rounding on an ill-conditioned system, seen on
+        // unit right-hand sides of covariance columns -- : repeat with the classic two-launch block-Jacobi PCG
+        ++h->cg_fallbacks;
+        return pcg_run<D>(h, tol, max_iters, iters_out, relres_out);
+    }
+    cg_fused_recover<D>(h, nullptr);
+    return cg_report(h, iters_out, relres_out);
+}
+
+int linearize(ps_problem* h, double lambda) {
+    ++h->prof_tick;
+    h->cov_ready = false;
+    h->status_clean = false;
+    HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double) + ST_NWORDS * sizeof(int32_t), h->stream));   // [S | g | cost | status]
+    if (h->nv > 0) {
+        StageTimer t(h, PS_ST_LANDMARK);
+        hipLaunchKernelGGL(k_landmark_pass, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr,
+                           h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,
+                           h->Cinv, h->cvec, h->status, h->lm_ablate);
+    }
+    bool fin_in_combine = false;
+    if (h->npitems > 0) {
+        StageTimer t(h, PS_ST_POSE);
+        hipLaunchKernelGGL(k_pose_pass, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
+                           h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial);
+        // tiled Schur: the combine launch also finalizes the poses (unless a task writes a diagonal block)
+        fin_in_combine = h->Spart && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6;
+        if (!fin_in_combine)
+            hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
+                               h->ppartial, h->diag_slot, lambda, h->S, h->g);
+    }
+    if (h->npair_items > 0) {
+        StageTimer t(h, PS_ST_SCHUR, 1);
+        hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), 0, h->stream,
+                           h->pair_per_xcd, h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, h->schur_ablate);
+        if (h->Spart)
+            hipLaunchKernelGGL(k_schur_combine, dim3(cdiv(h->ncomb, 4) + (fin_in_combine ? cdiv(h->nr, 4) : 0)), dim3(256), 0,
+                               h->stream, h->ncomb, h->comb_items, h->comb_tasks, h->Spart, h->S,
+                               fin_in_combine ? h->nr : 0, h->pitem_ptr, h->ppartial, h->diag_slot, lambda, h->g);
+    }
+    if (h->F > 0 && h->nr > 0) {
+        StageTimer t(h, PS_ST_EDGES);
+        if (h->D == 6) launch_factor_pass<6>(h, lambda); else launch_factor_pass<3>(h, lambda);
+    }
+    return 0;
+}
+
+// cost partials into cost_partials[0..n); returns n.  The caller reduces them.
+int cost_partials_pass(ps_problem* h, int include_all, const int32_t* gate) {
+    int n = 0;
+    if (h->N > 0) {
+        hipLaunchKernelGGL(k_cost_reproj, dim3(h->ncost_obs), dim3(256), 0, h->stream, h->N, h->lobs, h->poses,
+                           h->points, h->pose_rid, h->point_vid, h->ogroups, include_all, h->cost_partials, gate);
+        n += h->ncost_obs;
+    }
+    if (h->F > 0) {
+        if (h->D == 6)
+            hipLaunchKernelGGL(k_cost_factors<6>, dim3(h->ncost_fac), dim3(256), 0, h->stream, (int)h->F, h->f_i,
+                               h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->pose_rid, include_all,
+                               h->cost_partials + n, gate);
+        else
+            hipLaunchKernelGGL(k_cost_factors<3>, dim3(h->ncost_fac), dim3(256), 0, h->stream, (int)h->F, h->f_i,
+                               h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->pose_rid, include_all,
+                               h->cost_partials + n, gate);
+        n += h->ncost_fac;
+    }
+    return n;
+}
+
+int cost_pass(ps_problem* h, int include_all, int scalar_slot) {
+    StageTimer t(h, PS_ST_COST);
+    const int n = cost_partials_pass(h, include_all, nullptr);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, n, h->cost_partials,
+                       h->scalars + scalar_slot);
+    return 0;
+}
+
+int backsub(ps_problem* h, const int32_t* gate = nullptr, bool fuse_update = false) {
+    if (h->nv == 0) return 0;
+    StageTimer t(h, PS_ST_BACKSUB);
+    if (fuse_update)       // + full-step landmark update + SE(3) retraction of the poses in the same launch
+        hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l + h->nsq_p), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
+                           h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate,
+                           h->nsq_l, h->lm_point, h->points, h->P, h->poses, h->sq_part_p);
+    else
+        hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
+                           h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate,
+                           h->nsq_l, (const int32_t*)nullptr, (double*)nullptr, 0, (double*)nullptr, (double*)nullptr);
+    return 0;
+}
+
+int step_norm(ps_problem* h) {
+    // standalone ||dx||^2 (ps_step_norm2): partial sums of squares of x and dxl, then two small reduces
+    double* part = h->cost_partials;
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
+    if (h->nr > 0) {
+        const int b = std::min(256, cdiv((long)h->nr * h->D, 256));
+        hipLaunchKernelGGL(k_sumsq_partials, dim3(b), dim3(256), 0, h->stream, (long)h->nr * h->D, h->x, 1.0, part);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, b, part, h->scalars + SC_DXP2);
+    }
+    if (h->nv > 0) {
+        const int b = std::min(256, cdiv((long)h->nv * 3, 256));
+        hipLaunchKernelGGL(k_sumsq_partials, dim3(b), dim3(256), 0, h->stream, (long)h->nv * 3, h->dxl, 1.0, part + 256);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, b, part + 256, h->scalars + SC_DXL2);
+    }
+    return 0;
+}
+
+int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool with_norm = false) {
+    StageTimer t(h, PS_ST_UPDATE);
+    if (h->nr > 0) {
+        double* sq = with_norm ? h->sq_part_p : nullptr;
+        if (h->D == 6)
+            hipLaunchKernelGGL(k_update_poses<6>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses, sq, gate);
+        else
+            hipLaunchKernelGGL(k_update_poses<3>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses, sq, gate);
+    }
+    if (h->nv > 0)
+        hipLaunchKernelGGL(k_update_points, dim3(cdiv((long)h->nv * 3, 256)), dim3(256), 0, h->stream, h->nv,
+                           h->lm_point, h->dxl, step, h->points, gate);
+    return 0;
+}
+
+// back-substitution, update, cost and ||dx||^2 with ONE final reduction launch.  `gate` (device
+// status words) makes every kernel a no-op until the CG has flagged convergence.
+int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = false) {
+    // line-search order (cost AFTER the step): back-substitution, landmark update and pose retraction
+    // are one launch when the problem has landmarks (then D == 6)
+    const bool fused = linesearch && h->nv > 0 && h->nr > 0 && h->D == 6;
+    if (backsub(h, gate, fused)) return -1;
+    int ncost = 0;
+    if (!linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 0, gate); }
+    if (!fused && apply_update(h, 1.0, gate, true)) return -1;
+    if (linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 1, gate); }
+    double* o_cost = h->shard_out ? h->shard_buf : h->scalars + (linesearch ? SC_COST : SC_LINCOST);
+    double* o_dxl = h->shard_out ? h->shard_buf + 1 : h->scalars + SC_DXL2;
+    hipLaunchKernelGGL(k_reduce3, dim3(3), dim3(256), 0, h->stream,
+                       ncost, h->cost_partials, o_cost,
+                       h->nsq_p, h->sq_part_p, h->nr > 0 ? h->scalars + SC_DXP2 : nullptr,
+                       h->nsq_l, h->sq_part_l, (h->nv > 0 || h->shard_out) ? o_dxl : nullptr, gate,
+                       h->status, h->scalars, publish ? h->h_status_dev : nullptr, publish ? h->h_scalars_dev : nullptr,
+                       h->arrivals, publish ? h->h_seq_dev : nullptr, publish ? ++h->seq : 0LL);
+    return 0;
+}
+
+}  // namespace

@@ -1,0 +1,246 @@
+// ps_host_iteration.h -- explicit two-level PCG driver, linearisation, tail, the one-synchronisation Gauss-Newton iteration, small host helpers.
+// Part of ps_core.hip (one translation unit; included from there, in this order).
+
+namespace {
+
+// ---- explicit two-level PCG (long sparse chains; kernels k_xcg_*) ---------------------------------
+template <int D>
+int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
+    const int nr = h->nr, ncb = h->ncb, nc = h->nc;
+    if (max_iters + 2 > h->hist_cap) return fail("pcg max_iters exceeds the history buffer (4096)");
+    hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
+                       h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
+                       h->poses, h->pose_of_rid, h->coarse_basis, h->Bmat, h->bgv);
+    hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
+                       h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
+    if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
+    hipLaunchKernelGGL(k_xcoarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(h->max_row_ents + 1) * D * D * sizeof(double), h->stream,
+                       nr, h->ent_ptr, h->ent_q, h->ent_lo, h->ent_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->Bmat, h->BSZ);
+    hipLaunchKernelGGL(k_xcoarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
+                       ncb, h->seg_ptr, h->seg_ent, h->seg_row, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
+    // A_c^-1 lives in LciT2[b] (the transposed factor is not used on this path).  It only PRECONDITIONS here, so any
+    // symmetric positive definite stand-in keeps the CG exact: whole-iteration calls use the inverse formed from the
+    // PREVIOUS iteration's A_c and factor the current one on the side stream while the CG iterates (the factorisation,
+    // triangular inverse and product are 5.6 ms of the 12 ms iteration at C2 with 256 nodes).
+    const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0;
+    const int32_t* lagst = nullptr;
+    h->xcg_side_todo = false;
+    if (lag) {
+        h->lci_cur = h->lci_next;
+        HIP_OK(hipEventRecord(h->ev_ac, h->stream));       // A_c complete; the side work is enqueued by xcg_side_enqueue
+        h->xcg_side_todo = true;
+        lagst = h->lag_status;
+    } else {
+        const int buf = h->lci_cur;
+        if (coarse_factor<D>(h, h->stream, buf, h->status)) return -1;
+        hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, h->stream, nc, h->Lci2[buf], (float*)h->LciT2[buf]);
+        h->lci_next = buf;
+    }
+    HIP_OK(hipMemsetAsync(h->xstate, 0, 8 * sizeof(double), h->stream));
+    HIP_OK(hipMemsetAsync(h->xp2, 0, (size_t)nr * D * sizeof(double), h->stream));
+    // z_0 = M^-1 r_0 and r_0 . z_0
+    hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode, h->pw0,
+                       h->pw1, h->Bmat, h->cg_r[0], h->cg_r[0], h->cg_w[0], h->cg_p, h->cg_xh, h->cg_gd[1], 0, h->xstate, -1,
+                       h->tvec, h->status);
+    hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, (const float*)h->LciT2[h->lci_cur], h->tvec, h->xy, h->status, lagst);
+    hipLaunchKernelGGL(k_xcg_prolong<D>, dim3(cdiv(nr, PS_XCG_DROWS)), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb, h->pnode,
+                       h->pw0, h->pw1, h->Bmat, h->cg_r[0], h->xy, h->cg_s[0], h->cg_gd[0], h->status);
+    h->cg_launched = 0;
+    return 0;
+}
+
+// the side-stream half of a lagged setup, enqueued AFTER the first chunk of CG launches so that its ~130 launches
+// do not sit in front of them on the host
+template <int D>
+int xcg_side_enqueue(ps_problem* h) {
+    if (!h->xcg_side_todo) return 0;
+    h->xcg_side_todo = false;
+    const int nc = h->nc, nb = h->lci_cur ^ 1;
+    HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
+    if (coarse_factor<D>(h, h->side, nb, h->lag_status)) return -1;
+    hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, h->side, nc, h->Lci2[nb], (float*)h->LciT2[nb]);
+    HIP_OK(hipEventRecord(h->ev_chol, h->side));
+    h->lci_next = nb; h->side_pending = true;
+    return 0;
+}
+
+template <int D>
+void xcg_launch(ps_problem* h, double tol, int count) {
+    const int nr = h->nr, ncb = h->ncb, nc = h->nc;
+    const int n_pq = cdiv(nr, PS_XCG_ROWS), n_rz = cdiv(nr, PS_XCG_DROWS);
+    double* pbuf[2] = {h->cg_p, h->xp2};
+    for (int i = 0; i < count; ++i, ++h->cg_launched) {
+        const int k = h->cg_launched, b = k & 1;
+        hipLaunchKernelGGL(k_xcg_spmv<D>, dim3(n_pq), dim3(64 * PS_XCG_ROWS), 0, h->stream, nr, h->arow_ptr, h->acol_idx,
+                           h->ell_wf, h->Saug, h->cg_s[0], pbuf[b ^ 1], pbuf[b], h->cg_w[0], h->cg_gd[0], n_rz, h->cg_gd[1],
+                           h->xstate, k, tol * tol, h->hist, h->status, h->scalars);
+        hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
+                           h->pw0, h->pw1, h->Bmat, h->cg_r[b], h->cg_r[b ^ 1], h->cg_w[0], pbuf[b], h->cg_xh, h->cg_gd[1],
+                           n_pq, h->xstate, k, h->tvec, h->status);
+        hipLaunchKernelGGL(k_xcg_coarse, dim3(cdiv(nc, 4)), dim3(256), 0, h->stream, nc, (const float*)h->LciT2[h->lci_cur], h->tvec, h->xy, h->status, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_xcg_prolong<D>, dim3(cdiv(nr, PS_XCG_DROWS)), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb,
+                           h->pnode, h->pw0, h->pw1, h->Bmat, h->cg_r[b ^ 1], h->xy, h->cg_s[0], h->cg_gd[0], h->status);
+    }
+}
+
+// synchronous solve: poll the convergence flag every chunk, then x = Linv^T x^
+template <int D>
+int xcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out, bool allow_lag = false) {
+    if (xcg_setup<D>(h, max_iters, allow_lag)) return -1;
+    int chunk = std::max(32, h->last_pcg_iters + 2);
+    bool done = false;
+    while (!done) {
+        const int m = std::min(chunk, max_iters + 1 - h->cg_launched);
+        xcg_launch<D>(h, tol, m);
+        if (xcg_side_enqueue<D>(h)) return -1;
+        if (read_scalars(h)) return -1;
+        done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 1;
+        chunk = std::max(32, h->cg_launched / 4);
+    }
+    hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)h->nr * D, 256)), dim3(256), 0, h->stream, h->nr, h->Linv,
+                       h->cg_xh, h->x, (const int32_t*)nullptr);
+    return cg_report(h, iters_out, relres_out);
+}
+
+bool use_direct(const ps_problem* h) {
+    return h->pcg_variant == 1 && h->nr > 0 && h->nr * h->D <= h->direct_max;
+}
+
+// small reduced systems: dense blocked Cholesky in LDS instead of CG (enqueue only)
+template <int D>
+int direct_solve_enqueue(ps_problem* h) {
+    const int nr = h->nr, n = nr * D;
+    if (!h->dA && (h->alloc(&h->dA, (size_t)n * n) || h->alloc(&h->dLi, (size_t)n * n) || h->alloc(&h->dLiT, (size_t)n * n)))
+        return -1;
+    hipLaunchKernelGGL(k_bsr_to_dense<D>, dim3(1), dim3(256), 0, h->stream, nr, h->nnzb, h->brow_of, h->col_idx, h->S, h->dA);
+    const size_t chol_lds = 2 * (size_t)n * n * sizeof(double);
+    HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
+    hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, h->stream, nr, h->dA, h->dLi, h->dLiT,
+                       h->status, nullptr);
+    hipLaunchKernelGGL(k_direct_apply<D>, dim3(1), dim3(256), 0, h->stream, n, h->dLi, h->dLiT, h->g, h->x, h->status,
+                       h->scalars);
+    h->cg_launched = 0;
+    return 0;
+}
+
+int solve_reduced(ps_problem* h, double tol, int max_iters, int* iters, double* relres) {
+    if (h->nr == 0) { if (iters) *iters = 0; if (relres) *relres = 0.0; return 0; }
+    StageTimer t(h, PS_ST_PCG);
+    if (use_direct(h)) {
+        if (h->D == 6 ? direct_solve_enqueue<6>(h) : direct_solve_enqueue<3>(h)) return -1;
+        if (read_scalars(h)) return -1;
+        return cg_report(h, iters, relres);
+    }
+    if (h->pcg_variant == 1) {
+        if (!h->coarse_built && build_coarse(h)) return -1;
+        if (h->cg_explicit)
+            return h->D == 6 ? xcg_run<6>(h, tol, max_iters, iters, relres) : xcg_run<3>(h, tol, max_iters, iters, relres);
+        return h->D == 6 ? cg_fused_run<6>(h, tol, max_iters, iters, relres) : cg_fused_run<3>(h, tol, max_iters, iters, relres);
+    }
+    return h->D == 6 ? pcg_run<6>(h, tol, max_iters, iters, relres) : pcg_run<3>(h, tol, max_iters, iters, relres);
+}
+
+}  // namespace
+
+namespace {
+// ONE-synchronisation iteration for the fused CG: the CG launches (as many as the previous solve
+// needed, plus a margin), the recovery of x and the whole tail are enqueued back to back; the tail
+// kernels are gated on the device-side convergence flag, so if the CG needed more launches than
+// predicted the host simply enqueues more and repeats the (until then no-op) tail.
+template <int D>
+int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int linesearch,
+                              int* iters_out, double* relres_out, StageTimer* total) {
+    StageTimer tp(h, PS_ST_PCG);
+    if (use_direct(h)) {                                    // small system: three launches, then the (ungated) tail
+        if (direct_solve_enqueue<D>(h)) return -1;
+        tp.stop();
+        if (gn_tail(h, linesearch, nullptr, true)) return -1;
+        if (total) total->stop();
+        if (wait_published(h)) return -1;
+        return cg_report(h, iters_out, relres_out);
+    }
+    if (!h->coarse_built && build_coarse(h)) return -1;
+    if (h->cg_explicit) {                                   // explicit two-level PCG, same one-synchronisation protocol
+        if (xcg_setup<D>(h, max_iters, true)) return -1;
+        int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + 2 : 32;
+        for (;;) {
+            count = std::min(count, max_iters + 1 - h->cg_launched);
+            // (the side-stream factorisation goes in after the first few iterations' launches: early enough to
+            // finish beside the CG, late enough not to delay its start on the host)
+            const int head = std::min(count, 12);
+            xcg_launch<D>(h, tol, head);
+            if (xcg_side_enqueue<D>(h)) return -1;
+            xcg_launch<D>(h, tol, count - head);
+            hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)h->nr * D, 256)), dim3(256), 0, h->stream, h->nr, h->Linv,
+                               h->cg_xh, h->x, (const int32_t*)h->status);
+            tp.stop();
+            if (gn_tail(h, linesearch, h->status, true)) return -1;
+            if (total) total->stop();
+            if (wait_published(h)) return -1;
+            if (h->h_status[ST_PCG_DONE] != 0) break;
+            if (h->cg_launched >= max_iters + 1) {          // not converged within max_iters: take the step anyway
+                hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)h->nr * D, 256)), dim3(256), 0, h->stream, h->nr, h->Linv,
+                                   h->cg_xh, h->x, (const int32_t*)nullptr);
+                if (gn_tail(h, linesearch, nullptr, true) || wait_published(h)) return -1;
+                break;
+            }
+            count = std::max(8, h->cg_launched / 2);
+        }
+        return cg_report(h, iters_out, relres_out);
+    }
+    if (cg_fused_setup<D>(h, max_iters, true)) return -1;
+    int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + h->cg_margin : 16;
+    for (;;) {
+        count = std::min(count, max_iters + 2 - h->cg_launched);
+        cg_fused_launch<D>(h, tol, count);
+        cg_fused_recover<D>(h, h->status);
+        tp.stop();
+        if (gn_tail(h, linesearch, h->status, true)) return -1;
+        if (total) total->stop();                       // close the iteration timer before the sync
+        if (wait_published(h)) return -1;               // k_reduce3 has published status + scalars to host memory
+        if (h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL]) {
+            // breakdown of the pipelined recurrences (the gated tail applied nothing): classic PCG, then the tail
+            ++h->cg_fallbacks;
+            if (pcg_run<D>(h, tol, max_iters, iters_out, relres_out)) return -1;
+            if (gn_tail(h, linesearch, nullptr, true) || wait_published(h)) return -1;
+            return 0;
+        }
+        if (h->h_status[ST_PCG_DONE] != 0) break;
+        if (h->cg_launched >= max_iters + 2) {          // not converged within max_iters: take the step anyway
+            cg_fused_recover<D>(h, nullptr);
+            if (gn_tail(h, linesearch, nullptr, true) || wait_published(h)) return -1;
+            break;
+        }
+        count = std::max(8, h->cg_launched / 2);
+    }
+    return cg_report(h, iters_out, relres_out);
+}
+}  // namespace
+
+namespace {
+struct DevBuf {                      // scoped device allocation for the stateless entry points
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : fail("hipMalloc failed"); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+int need_device() {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible");
+    return 0;
+}
+}  // namespace
+
+namespace {
+// stable counting sort of `v` by an integer key in [0, nkeys): O(n + nkeys), used for the big
+// host-side orderings of ps_problem_create (std::stable_sort was most of its run time)
+template <class T, class KeyFn>
+void counting_sort(std::vector<T>& v, size_t nkeys, KeyFn key) {
+    std::vector<size_t> pos(nkeys + 1, 0);
+    for (const T& x : v) pos[(size_t)key(x) + 1]++;
+    for (size_t k = 0; k < nkeys; ++k) pos[k + 1] += pos[k];
+    std::vector<T> out(v.size());
+    for (const T& x : v) out[pos[(size_t)key(x)]++] = x;
+    v.swap(out);
+}
+}  // namespace
