@@ -531,29 +531,62 @@ int cg_report(ps_problem* h, int* iters_out, double* relres_out) {
     return 0;
 }
 
-// synchronous solve (staged API): poll the convergence flag every chunk
+// synchronous solve (staged API): poll the convergence flag every chunk.
+// A breakdown of the pipelined (Chronopoulos-Gear) recurrences -- delta - beta gamma / alpha <= 0 long before convergence:
+// rounding on the singular folded system, seen on the unit right-hand sides of covariance columns of pose graphs -- is
+// answered by RESTARTS: keep the iterate, form the true residual g - S x, and solve for the correction with the same
+// matrix and two-level preconditioner (up to three times; then the classic two-launch block-Jacobi PCG).
 template <int D>
 int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out, bool rhs_only = false) {
-    if (cg_fused_setup<D>(h, max_iters, false, rhs_only)) return -1;
-    int chunk = std::max(h->pcg_chunk, h->last_pcg_iters + 2);
-    bool done = false;
-    while (!done) {
-        const int m = std::min(chunk, max_iters + 2 - h->cg_launched);
-        cg_fused_launch<D>(h, tol, m);
-        HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipStreamSynchronize(h->stream));
-        done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 2;
-        chunk = h->pcg_chunk;
-    }
-    if (h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL]) {
-        // the pipelined (Chronopoulos-Gear) recurrences lost positivity -- rounding on an ill-conditioned system, seen on
-        // unit right-hand sides of covariance columns -- : repeat with the classic two-launch block-Jacobi PCG
+    const int nvec = h->nr * D;
+    double* xacc = h->q;                  // the classic PCG's buffers are free while the fused CG runs
+    double* gsaved = h->z;
+    int restarts = 0, total_its = 0;
+    double reduced = 1.0;                 // residual reduction achieved by the passes so far
+    bool rhs = rhs_only;
+    for (;;) {
+        const double tol_pass = std::min(0.1, tol / reduced);
+        if (cg_fused_setup<D>(h, max_iters, false, rhs)) return -1;
+        int chunk = std::max(h->pcg_chunk, h->last_pcg_iters + 2);
+        bool done = false;
+        while (!done) {
+            const int m = std::min(chunk, max_iters + 2 - h->cg_launched);
+            cg_fused_launch<D>(h, tol_pass, m);
+            HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_OK(hipStreamSynchronize(h->stream));
+            done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 2;
+            chunk = h->pcg_chunk;
+        }
+        total_its += h->h_status[ST_PCG_ITERS];
+        if (h->h_status[ST_PCG_DONE] != 2 || h->h_status[ST_DIAG_FAIL]) break;
+        const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
+        const double rho = rr0 > 0.0 ? std::sqrt(rrf / rr0) : 1.0;
         ++h->cg_fallbacks;
-        return pcg_run<D>(h, tol, max_iters, iters_out, relres_out);
+        if (restarts == 3 || !(rho < 0.5)) {                // no progress to keep: start over with the classic PCG
+            if (restarts) HIP_OK(hipMemcpyAsync(h->g, gsaved, (size_t)nvec * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            return pcg_run<D>(h, tol, max_iters, iters_out, relres_out);
+        }
+        cg_fused_recover<D>(h, nullptr);                    // x of this pass
+        if (restarts == 0) HIP_OK(hipMemcpyAsync(gsaved, h->g, (size_t)nvec * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        hipLaunchKernelGGL(k_vec_accumulate, dim3(cdiv(nvec, 256)), dim3(256), 0, h->stream, nvec, (const double*)h->x, xacc, restarts == 0);
+        hipLaunchKernelGGL(k_bsr_residual<D>, dim3(cdiv(nvec, 256)), dim3(256), 0, h->stream, h->nr, h->row_ptr, h->col_idx, h->S,
+                           (const double*)xacc, (const double*)gsaved, h->g);
+        reduced *= rho;
+        rhs = true;
+        ++restarts;
     }
     cg_fused_recover<D>(h, nullptr);
-    return cg_report(h, iters_out, relres_out);
+    if (restarts) {                                         // x = (sum of the earlier passes) + this correction; g as it was
+        hipLaunchKernelGGL(k_vec_accumulate, dim3(cdiv(nvec, 256)), dim3(256), 0, h->stream, nvec, (const double*)xacc, h->x, 0);
+        HIP_OK(hipMemcpyAsync(h->g, gsaved, (size_t)nvec * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    int its = 0; double rel = 0.0;
+    const int rc = cg_report(h, &its, &rel);
+    if (iters_out) *iters_out = total_its;
+    if (relres_out) *relres_out = rel * reduced;
+    h->last_pcg_iters = total_its;
+    return rc;
 }
 
 int linearize(ps_problem* h, double lambda) {

@@ -658,3 +658,29 @@ __global__ __launch_bounds__(256) void k_direct_apply(
         scalars[SC_RR0] = 1.0; scalars[SC_RRFINAL] = 0.0;
     }
 }
+
+// ---- restart after a breakdown of the pipelined recurrences (rare; host-driven, see cg_fused_run) ----------------
+// xacc (+)= x, then g = gsaved - S xacc: the next pass solves for the correction with the same matrix and preconditioner
+__global__ __launch_bounds__(256) void k_vec_accumulate(int n, const double* __restrict__ x, double* __restrict__ xacc, int first)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) xacc[t] = first ? x[t] : xacc[t] + x[t];
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_bsr_residual(
+    int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx, const double* __restrict__ S,
+    const double* __restrict__ x, const double* __restrict__ gsaved, double* __restrict__ g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nr * D) return;
+    const int i = t / D, r = t % D;
+    double v = gsaved[t];
+    for (int b = row_ptr[i]; b < row_ptr[i + 1]; ++b) {
+        const double* sb = S + (size_t)b * D * D + r * D;
+        const double* xv = x + (size_t)col_idx[b] * D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) v -= sb[c] * xv[c];
+    }
+    g[t] = v;
+}
