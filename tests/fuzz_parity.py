@@ -97,7 +97,8 @@ def run(n_cases, seed0=0, verbose=True):
                 if not (e2 < (1e-5 if its2 < 300 else 1e-3)) and not (its2 >= 4000 and mode == 'nocoarse'):
                     # numerically singular second system (a diverged step: condition numbers of 1e20)?  then only the
                     # residual on the oracle's system is meaningful
-                    P2, b2, _ = orc.normal_equations(new, points_first=False)
+                    at = lp.copy(); at.poses[...] = poses; at.points[...] = points       # the device's own linearisation point
+                    P2, b2, _ = orc.normal_equations(at, points_first=False)
                     xp2, xl2 = dev.get_dx()
                     res2 = np.linalg.norm(P2 @ np.concatenate([xp2.ravel(), xl2.ravel()]) - b2) / np.linalg.norm(b2)
                     if res2 < 1e-8:
