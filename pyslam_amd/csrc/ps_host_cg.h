@@ -559,7 +559,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
             chunk = h->pcg_chunk;
         }
         total_its += h->h_status[ST_PCG_ITERS];
-        if (h->h_status[ST_PCG_DONE] != 2 || h->h_status[ST_DIAG_FAIL]) break;
+        if (h->h_status[ST_PCG_DONE] != 2 || h->h_status[ST_DIAG_FAIL] || h->h_status[ST_LM_FAIL]) break;
         const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
         const double rho = rr0 > 0.0 ? std::sqrt(rrf / rr0) : 1.0;
         ++h->cg_fallbacks;

@@ -198,7 +198,7 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         if (gn_tail(h, linesearch, h->status, true)) return -1;
         if (total) total->stop();                       // close the iteration timer before the sync
         if (wait_published(h)) return -1;               // k_reduce3 has published status + scalars to host memory
-        if (h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL]) {
+        if (h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL] && !h->h_status[ST_LM_FAIL]) {
             // breakdown of the pipelined recurrences (the gated tail applied nothing): the synchronous solver on the same
             // matrix (it restarts from the iterate it reaches, and ends at the classic PCG if that fails too), then the tail
             if (cg_fused_run<D>(h, tol, max_iters, iters_out, relres_out, true)) return -1;

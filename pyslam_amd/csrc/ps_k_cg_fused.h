@@ -374,8 +374,9 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused(
         const double gamma = gs, delta = ds;
         const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
         const bool first = (blockIdx.x == 0 && t == 0);
-        if (!(gamma > thresh)) {                     // converged (or gamma == 0 / NaN)
-            if (first) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
+        if (!(gamma > thresh)) {                     // converged (gamma == 0 too); NaN (a failed block upstream) = breakdown:
+            //                                              the gated tail must not apply it
+            if (first) { status[ST_PCG_DONE] = (gamma != gamma) ? 2 : 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
             return;
         }
         beta = (k == 0) ? 0.0 : gamma / g_prev;
@@ -537,8 +538,9 @@ __global__ __launch_bounds__(64 * NW) void k_cg_fused_lds(
         const double gamma = gs, delta = ds;
         const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
         const bool first = (blockIdx.x == 0 && t == 0);
-        if (!(gamma > thresh)) {                     // converged (or gamma == 0 / NaN)
-            if (first) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
+        if (!(gamma > thresh)) {                     // converged (gamma == 0 too); NaN (a failed block upstream) = breakdown:
+            //                                              the gated tail must not apply it
+            if (first) { status[ST_PCG_DONE] = (gamma != gamma) ? 2 : 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
             return;
         }
         beta = (k == 0) ? 0.0 : gamma / g_prev;

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * PS_XCG_ROWS) void k_xcg_spmv(
     const double thresh = (k == 0) ? tol2 * rz : thresh_in;
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
     if (!(rz > thresh)) {                                 // converged (or rz == 0 / NaN)
-        if (first) { status[ST_PCG_DONE] = 1; scalars[SC_RRFINAL] = rz; if (k == 0) scalars[SC_RR0] = rz; }
+        if (first) { status[ST_PCG_DONE] = (rz != rz) ? 2 : 1; scalars[SC_RRFINAL] = rz; if (k == 0) scalars[SC_RR0] = rz; }
         return;
     }
     const double beta = (k == 0) ? 0.0 : rz / rz_prev;

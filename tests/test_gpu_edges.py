@@ -179,3 +179,20 @@ def test_fused_motion_only_iteration_matches_the_general_path():
             assert ra[2] == 0
         assert np.abs(a.get_params()[0] - b.get_params()[0]).max() < 1e-11
         assert np.abs(a.get_dx()[0] - b.get_dx()[0]).max() < 1e-9
+
+
+def test_a_failed_landmark_block_raises_and_applies_nothing():
+    """Tukey weights that vanish on every observation leave H_ll = 0: the iteration must report the landmark block (not
+    the NaNs it causes downstream) and leave the parameter tables untouched -- the CG's convergence test treats a NaN
+    residual as a breakdown, so the gated tail stays closed."""
+    from pyslam_amd import losses
+    from pyslam_amd._native import NativeError
+    for kf in (6, 30):                                    # direct small solve / fused CG
+        lp, _ = synthetic.stereo_ba(num_kf=kf, num_lm=40 * kf, obs_per_lm=4, half_window=5, seed=2, loss=losses.TukeyLoss(1e-9))
+        dev = device(lp)
+        before = dev.get_params()
+        with pytest.raises(NativeError, match='landmark block'):
+            dev.gn_iteration(0., 1e-12, 500, True)
+        after = dev.get_params()
+        if kf == 30:
+            assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
