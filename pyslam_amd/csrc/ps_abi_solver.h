@@ -163,7 +163,7 @@ int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters,
     }
     // (the explicit PCG runs iteration k in launch group k: one group less than the fused CG's launches)
     const int limit = pcg_max_iters + (h->cg_explicit ? 1 : 2);
-    const int margin = h->cg_explicit ? 2 : h->cg_margin;
+    const int margin = (h->cg_explicit || h->last_pcg_iters == h->prev_pcg_iters) ? std::min(2, h->cg_margin) : h->cg_margin;
     int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : (h->cg_explicit ? 32 : 16)) : std::max(8, h->cg_launched / 2);
     count = std::min(count, limit - h->cg_launched);
     const bool last = count <= 0;

@@ -143,6 +143,7 @@ struct ps_problem {
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     int prof_every = 1;             // profiling level 1: time the Schur kernel of every n-th linearisation only
     long prof_tick = 0;
+    int prev_pcg_iters = -1;        // iteration count of the solve before the last one (launch-count prediction)
     int cg_fallbacks = 0;           // solves repeated with the classic PCG after a breakdown of the pipelined CG
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;

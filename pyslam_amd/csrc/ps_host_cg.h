@@ -509,6 +509,7 @@ void cg_fused_recover(ps_problem* h, const int32_t* gate) {
 }
 
 int cg_report(ps_problem* h, int* iters_out, double* relres_out) {
+    h->prev_pcg_iters = h->last_pcg_iters;
     h->last_pcg_iters = h->h_status[ST_PCG_ITERS];
     if (iters_out) *iters_out = h->h_status[ST_PCG_ITERS];
     const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
