@@ -1,28 +1,37 @@
 #!/usr/bin/env python
-"""bench.py -- ms per Gauss-Newton/LM iteration on the BASELINE stereo-BA workload.
+"""bench.py -- ms per Gauss-Newton/LM iteration on the BASELINE stereo-BA workloads.
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one full iteration of the hot path on the synthetic stereo bundle
-adjustment C3 of SURVEY.md section 8d (200 keyframes, 50 000 landmarks,
-500 000 reprojection blocks = 1.5 M residual rows): residuals + Jacobians +
-IRLS weights, J^T J assembly, Schur elimination of the landmarks, block-PCG on
-the reduced pose system (relative tolerance 1e-12, the parity setting),
-back-substitution, retraction and the post-step cost pass -- i.e. exactly what
-the reference's ``Problem.solve_one_iter`` + update does (pyslam/problem.py:145-156).
-Every step starts from the same linearisation point (a device-side restore of
-the initial parameters), so all K steps do identical work.
+One "step" = one full iteration of the hot path: residuals + Jacobians + IRLS
+weights, J^T J assembly, Schur elimination of the landmarks, block-PCG on the
+reduced pose system (relative tolerance 1e-12, the parity setting),
+back-substitution, retraction and the post-step cost pass -- exactly what the
+reference's ``Problem.solve_one_iter`` + update does (pyslam/problem.py:145-156).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling --
-every rank owns its own 50 000 landmarks / 500 000 observations over the SAME
-200 keyframes; the reduced pose system [S | g | cost] is summed with one RCCL
-all-reduce per iteration (issued by the HIP core itself on the solver's stream)
-and then solved redundantly on every rank; a second 2-double all-reduce sums
-the shards' cost and landmark step norm.
+N = 1: workload C3 of SURVEY.md section 8d (200 keyframes, 50 000 landmarks,
+500 000 reprojection blocks = 1.5 M residual rows), the configuration
+BASELINE.json's metric is quoted on.  ``value`` is the steady-state figure (every
+timed step starts from the same linearisation point: a device-side restore of the
+initial parameters, so all K steps do identical work); next to it the line carries
+``trajectory_ms_per_iter`` (5 consecutive iterations of a real solve, no restore:
+the lagged coarse factor and the CG launch-count prediction are live) and
+``c4_single_gpu_ms`` (the north star's 2 000-keyframe / 500 000-landmark problem on
+this one GPU -- the strong-scaling base).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of
+the fixed C4 problem (2 000 keyframes, 500 000 landmarks, 5 M blocks; BASELINE.json
+configs[3]): every rank generates the same problem and keeps landmark shard
+``rank`` of N (``shard_landmarks``); the reduced pose system [upper(S) | g | cost | flag]
+is summed with one RCCL all-reduce per iteration (issued by the HIP core itself on
+the solver's stream) and then solved redundantly on every rank; a second small
+all-reduce sums the shards' cost and landmark step norm.  Rank 0 also times the
+unsharded C4 problem on its own GPU after the timed region (``c4_single_gpu_ms``).
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -38,7 +47,10 @@ HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 PCG_TOL = 1e-12
 PCG_MAX = 1000
 
-KF, LM_PER_GPU, OBS_PER_LM, HALF_WINDOW = 200, 50000, 10, 20
+C3 = dict(num_kf=200, num_lm=50000, seed=0)
+C4 = dict(num_kf=2000, num_lm=500000, seed=1)
+OBS_PER_LM, HALF_WINDOW = 10, 20
+SPSOLVE_FULL_C3_RECORDED_S = 288.0      # tests/bench_cpu_solvers.py on an MI355X box's host (round 1)
 
 
 def algorithmic_bytes(info, n_pcg, dof=6):
@@ -46,32 +58,48 @@ def algorithmic_bytes(info, n_pcg, dof=6):
     N, L, P, nnzb = info['num_obs'], info['num_var_points'], info['num_reduced'], info['reduced_nnzb']
     blk = 8 * dof * dof
     b_iter = 496 * N + 264 * L + 960 * P + blk * nnzb * (1 + n_pcg)
-    # k_schur_pairs: every Z row read once (144 B / observation) + every off-diagonal
-    # block of S written once (both triangles)
+    # k_schur_pairs: every Z row read once (144 B / observation in the survey's model) + every
+    # off-diagonal block of S written once (both triangles)
     b_schur = 144 * N + blk * (nnzb - P)
-    b_spmv = blk * nnzb + 3 * 8 * dof * P          # k_pcg_spmv: S once, z/p_old in, p_new/q out
+    b_spmv = blk * nnzb + 3 * 8 * dof * P          # one CG launch: S once, three vectors
     return b_iter, b_schur, b_spmv
+
+
+def kernel_source_sha():
+    """Hash of the HIP sources: ties a committed PMC pass to the build it was taken on."""
+    h = hashlib.sha256()
+    d = os.path.join(REPO, 'pyslam_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), 'rb') as fh:
+            h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json:
     separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, read
-    traffic corrected x2 as MI355X_MICROARCH.md prescribes for gfx950).  None if not collected."""
+    traffic corrected x2 as MI355X_MICROARCH.md prescribes for gfx950) + the source hash of the
+    build the passes were taken on.  (None, ...) if not collected."""
     try:
         with open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')) as f:
             table = json.load(f)
         total = table[kernel]['hbm_bytes_corrected']
         if kernel == 'k_schur_pairs' and 'k_schur_combine' in table:    # tiled mode: the pair kernel's partials are
             total += table['k_schur_combine']['hbm_bytes_corrected']    # summed by a second, small kernel (same timer)
-        return total
+        meta = table.get('_meta', {})
+        return total, meta.get('source_sha'), meta.get('git_head')
     except Exception:
-        return None
+        return None, None, None
 
 
 def cpu_baseline(lp, repeats=5):
     """The numpy/scipy oracle (a port of the reference's algebra) on the host cores: `repeats` whole
-    iterations of the same workload (about 10 s of CPU work), mean time per iteration."""
+    iterations of the same workload (about 10 s of CPU work), mean time per iteration; plus the
+    reference-faithful linear solve (scipy spsolve of the FULL normal equations, pyslam/problem.py:186) on
+    a bounded sample, next to the CPU Schur complement on the same sample (SURVEY.md section 8d ii)."""
+    import scipy.sparse.linalg as spla
     from oracle import gn_oracle as orc
+    from pyslam_amd import synthetic
     ta = tb = tc = 0.
     for _ in range(repeats):
         t0 = time.perf_counter()
@@ -84,11 +112,83 @@ def cpu_baseline(lp, repeats=5):
         t3 = time.perf_counter()
         ta += t1 - t0; tb += t2 - t1; tc += t3 - t2
     ta, tb, tc = ta / repeats, tb / repeats, tc / repeats
+    # reference-faithful: SuperLU on the full normal equations, landmarks-first (the reference's parameter order)
+    small = dict(num_kf=100, num_lm=5000)
+    lps, _ = synthetic.stereo_ba(obs_per_lm=OBS_PER_LM, half_window=HALF_WINDOW, seed=0, **small)
+    Ps, bs, _ = orc.normal_equations(lps, True)
+    t0 = time.perf_counter(); dxf = spla.spsolve(Ps, bs); t_full = time.perf_counter() - t0
+    t0 = time.perf_counter(); dxs = orc.schur_solve(lps, Ps, bs, True); t_schur = time.perf_counter() - t0
     return {'value': round((ta + tb + tc) * 1e3, 1), 'unit': 'ms/LM-iter', 'cores': 1, 'kind': 'port',
             'sample': '{} iterations of the same workload (500k blocks), mean per iteration: vectorised numpy '
                       'residual/Jacobian + scipy CSR J^T J {:.2f} s, CPU Schur + scipy spsolve of the reduced system '
                       '{:.2f} s, update + 2 cost passes {:.2f} s; numpy/scipy single-threaded'.format(repeats, ta, tb, tc),
-            'host_cpus': os.cpu_count()}
+            'host_cpus': os.cpu_count(),
+            'spsolve_full_s': round(t_full, 2),
+            'spsolve_full_sample': 'scipy.sparse.linalg.spsolve on the FULL normal equations (reference problem.py:186) of a '
+                                   '{num_kf}-keyframe x {num_lm}-landmark x 10 stereo BA ({n} blocks, {u} unknowns): {f:.2f} s; '
+                                   'CPU Schur + spsolve of the reduced system on the same matrix: {s:.2f} s; |dx_full - dx_schur| / |dx| = '
+                                   '{e:.1e}'.format(n=lps.num_obs, u=Ps.shape[0], f=t_full, s=t_schur,
+                                                    e=float(np.linalg.norm(dxf - dxs) / np.linalg.norm(dxf)), **small),
+            'spsolve_full_c3_recorded_s': SPSOLVE_FULL_C3_RECORDED_S,
+            'spsolve_full_c3_note': 'recorded (tests/bench_cpu_solvers.py, round 1, same host type): one spsolve call on the '
+                                    'full 151 194-unknown C3 system; not re-run here (exceeds the time bound)'}
+
+
+def time_steps(dev, steps, warmup, fence):
+    """W untimed + K timed steady-state steps (restore + iteration); -> (seconds, last result)."""
+    def step():
+        dev.restore()
+        return dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)
+    out = None
+    for _ in range(warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    fence()
+    return time.perf_counter() - t0, out
+
+
+def trajectory(dev, iters=5):
+    """`iters` consecutive Gauss-Newton iterations from the perturbed start WITHOUT restoring the
+    linearisation point: what a real solve() pays (stale lagged coarse factor, CG launch-count misses)."""
+    import torch
+    dev.restore()
+    torch.cuda.synchronize()
+    per, its, costs = [], [], []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        cost, _, n, _ = dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)     # synchronises (results are read back)
+        per.append((time.perf_counter() - t0) * 1e3)
+        its.append(n); costs.append(cost)
+    dev.restore()
+    return {'mean': round(float(np.mean(per)), 4), 'per_iter': [round(p, 4) for p in per], 'pcg_iters': its,
+            'cost': costs, 'note': '{} consecutive iterations from the perturbed start, no restore, host wall clock per '
+                                   'ps_gn_iteration call (each call ends with its one synchronisation)'.format(iters)}
+
+
+def c4_single_gpu(stream, steps=5, warmup=2):
+    """The unsharded C4 problem on the current GPU: steady-state ms per iteration + stage breakdown."""
+    import torch
+    from pyslam_amd import synthetic
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.stereo_ba(obs_per_lm=OBS_PER_LM, half_window=HALF_WINDOW, **C4)
+    dev = DeviceProblem(lp, stream=stream)
+    dev.snapshot()
+    sec, out = time_steps(dev, steps, warmup, torch.cuda.synchronize)
+    dev.set_profiling(2)
+    for _ in range(3):
+        dev.restore(); dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)
+    st = dev.stage_times(reset=True)
+    dev.set_profiling(0)
+    traj = trajectory(dev, 4)
+    res = {'ms': round(sec * 1e3 / steps, 4), 'pcg_iters': out[2], 'blocks': dev.info['num_obs'],
+           'reduced_blocks': dev.info['reduced_nnzb'], 'device_bytes': dev.info['device_bytes'],
+           'stage_ms': {k: round(v[0] / v[1], 4) for k, v in st.items() if v[1] > 0},
+           'trajectory_ms_per_iter': traj['per_iter'], 'trajectory_pcg_iters': traj['pcg_iters']}
+    dev.close()
+    return res
 
 
 def main():
@@ -96,9 +196,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--kf', type=int, default=KF)
-    ap.add_argument('--lm', type=int, default=LM_PER_GPU)
+    ap.add_argument('--kf', type=int, default=None, help='override the keyframe count of the workload')
+    ap.add_argument('--lm', type=int, default=None, help='override the landmark count of the workload')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-c4', action='store_true', help='skip the single-GPU C4 leg')
     ap.add_argument('--force-sharded', action='store_true',
                     help='use the multi-GPU driver (RCCL all-reduce) even with one rank (testing)')
     args = ap.parse_args()
@@ -119,16 +220,21 @@ def main():
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    lp, _ = synthetic.stereo_ba(num_kf=args.kf, num_lm=args.lm, obs_per_lm=OBS_PER_LM,
-                                half_window=HALF_WINDOW, seed=0,
-                                lm_offset=rank * args.lm, lm_total=world * args.lm)
+    cfg = dict(C4 if world > 1 else C3)
+    name = 'C4' if world > 1 else 'C3'
+    if args.kf: cfg['num_kf'] = args.kf
+    if args.lm: cfg['num_lm'] = args.lm
+    lp_full, _ = synthetic.stereo_ba(obs_per_lm=OBS_PER_LM, half_window=HALF_WINDOW, **cfg)
 
+    stream = torch.cuda.current_stream().cuda_stream
     if dist is not None:
-        from pyslam_amd.distributed import ShardedDeviceProblem
+        from pyslam_amd.distributed import ShardedDeviceProblem, shard_landmarks
+        lp = shard_landmarks(lp_full, rank, world)               # the FIXED problem, split N ways (strong scaling)
         dev = ShardedDeviceProblem(lp, dist)
     else:
         from pyslam_amd.device import DeviceProblem
-        dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
+        lp = lp_full
+        dev = DeviceProblem(lp, stream=stream)
     info = dev.info
     dev.snapshot()                                           # the common linearisation point
 
@@ -142,11 +248,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    core = dev.dev if hasattr(dev, 'dev') else dev
     for _ in range(args.warmup):
         out = step()
     # timed region: ONE hipEvent pair around the dominant (Schur) kernel, on every 4th iteration
     # (an event pair costs ~8 us of pipeline bubbles: the kernel is timed on every 4th step of the timed region)
-    (dev.dev if hasattr(dev, 'dev') else dev).set_option('profile_every', 4)
+    core.set_option('profile_every', 4)
     dev.set_profiling(1)
     dev.stage_times(reset=True)
     fence()
@@ -157,7 +264,7 @@ def main():
     elapsed = time.perf_counter() - t0
     stages = dev.stage_times(reset=True)
     # untimed: a few more steps with an event pair around every stage, for the breakdown only
-    (dev.dev if hasattr(dev, 'dev') else dev).set_option('profile_every', 1)
+    core.set_option('profile_every', 1)
     dev.set_profiling(2)
     for _ in range(5):
         step()
@@ -172,11 +279,12 @@ def main():
         elapsed = float(t.item())
     cost, dx_norm, n_pcg, relres = out
     ms_per_step = elapsed * 1e3 / args.steps
+    traj = trajectory(dev) if dist is None else None         # (sharded: every rank would have to follow; single GPU only)
 
     if rank == 0:
         b_iter, b_schur, b_spmv = algorithmic_bytes(info, n_pcg)
         stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in stages.items() if v[1] > 0}
-        # dominant kernel: the Schur pair kernel is ONE launch per iteration; PCG is 2*n_pcg launches
+        # dominant kernel: the Schur pair kernel is ONE launch per iteration; the CG is n_pcg + 2 launches
         sch = stage_ms.get('schur_pairs', 0.0)
         pcg_per_iter = stage_ms.get('pcg', 0.0) / max(n_pcg, 1)
         if sch >= pcg_per_iter * 1.0 and sch > 0:
@@ -184,30 +292,49 @@ def main():
         else:
             kern, dur_ms, nbytes = 'void k_cg_fused<6>', pcg_per_iter, b_spmv
         achieved = nbytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        traffic, traffic_sha, traffic_head = pmc_traffic(kern)
+        sha = kernel_source_sha()
+        if traffic is not None and traffic_sha != sha:
+            print('bench.py: WARNING profiles/pmc_traffic.json was collected on kernel sources {} but this build is {}: '
+                  'roofline.traffic is stale (re-run tools/collect_profiles.sh)'.format(traffic_sha, sha), file=sys.stderr)
+        total_blocks = lp_full.num_obs
         line = {
             'metric': 'ms/LM-iter (Jac build + J^T J + Schur solve), stereo BA @ 500k residuals',
             'value': round(ms_per_step, 4), 'unit': 'ms/LM-iter', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'higher_is_better': False, 'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
-            'config': {'workload': 'C3 stereo BA: {} keyframes x {} landmarks/GPU x {} obs/landmark = {} '
-                                   'reprojection blocks/GPU (3 rows each), L2 loss, pose 0 constant'.format(
-                                       args.kf, args.lm, OBS_PER_LM, info['num_obs']),
-                       'parallelism': 'landmark-sharded x{} + RCCL all-reduce of the reduced pose system'.format(world)
+            'config': {'workload': '{} stereo BA: {} keyframes x {} landmarks x {} obs/landmark = {} reprojection blocks '
+                                   '(3 rows each), L2 loss, pose 0 constant{}'.format(
+                                       name, cfg['num_kf'], cfg['num_lm'], OBS_PER_LM, total_blocks,
+                                       '; FIXED problem, landmark shard 1/{} per GPU ({} blocks on rank 0)'.format(world, info['num_obs'])
+                                       if world > 1 else ''),
+                       'parallelism': 'landmark-sharded x{} + RCCL all-reduce of the reduced pose system (upper triangle)'.format(world)
                        if world > 1 else 'single GPU',
                        'pcg_tol': PCG_TOL, 'pcg_iters': n_pcg, 'pcg_relres': relres,
                        'reduced_blocks': info['reduced_nnzb'], 'schur_pairs': info['num_pairs'],
                        'cost_after_step': cost, 'step_norm': dx_norm},
-            'residual_blocks_per_s': round(info['num_obs'] * world / (ms_per_step * 1e-3), 1),
+            'residual_blocks_per_s': round(total_blocks / (ms_per_step * 1e-3), 1),
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'stage_ms_note': 'schur_pairs: hipEvent pair inside the timed region, on every 4th step; the other stages and iteration_total '
                              '(GPU time of one iteration) from 5 extra untimed steps with an event pair around every stage',
+            'value_note': 'steady state: every timed step restores the same linearisation point (repeated first iteration); '
+                          'trajectory_ms_per_iter is the same solve without the restore',
             'iteration_algorithmic_GBps': round(b_iter / (ms_per_step * 1e-3) / 1e9, 2),
             'roofline': {'bound': 'hbm', 'kernel': kern, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': pmc_traffic(kern),
+                         'traffic': traffic, 'traffic_source_sha': traffic_sha, 'traffic_git_head': traffic_head,
+                         'build_source_sha': sha, 'traffic_stale': bool(traffic is not None and traffic_sha != sha),
                          'algorithmic_bytes_per_launch': int(nbytes), 'avg_launch_ms': round(dur_ms, 5)},
         }
+        if traj is not None:
+            line['trajectory_ms_per_iter'] = traj
+        if not args.no_c4 and not args.kf and not args.lm:
+            if dist is None:
+                dev.close()                                      # free the C3 tables first
+            c4 = c4_single_gpu(stream)
+            line['c4_single_gpu_ms'] = c4['ms']
+            line['c4_single_gpu'] = c4
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(lp)
         print(json.dumps(line))

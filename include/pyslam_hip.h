@@ -80,7 +80,7 @@ typedef struct ps_problem_info {
     int64_t num_obs, num_edges, num_priors;
     int64_t reduced_nnzb;        /* blocks in the reduced (Schur) system, both triangles      */
     int64_t num_pairs;           /* off-diagonal Schur contributions (upper triangle)         */
-    int64_t reduce_count;        /* doubles in the all-reduce payload [S | g | cost]          */
+    int64_t reduce_count;        /* doubles in the all-reduce payload [upper(S) | g | cost | flag] */
     int64_t device_bytes;        /* HBM held by the handle                                    */
 } ps_problem_info;
 
@@ -110,9 +110,16 @@ int ps_eval_cost(ps_problem* h, int include_all_constant, double* cost);
    lambda: Marquardt damping added as lambda*diag(J^T J); 0 = the reference's GN. */
 int ps_linearize(ps_problem* h, double lambda);
 
-/* Device pointer + length of the contiguous payload [S values | g | cost] a
-   multi-GPU caller all-reduces (sum) between ps_linearize and ps_solve_reduced. */
+/* Exchange buffer of the landmark-sharded (multi-GPU) iteration: the contiguous payload
+   [upper block triangle of S incl. diagonal | g | cost (2) | failure flag] a caller all-reduces (sum)
+   between ps_linearize and ps_solve_reduced.  ps_shard_pack gathers it from the reduced system (S is
+   exactly symmetric: only one triangle travels), ps_shard_unpack scatters the sum back, mirrors the upper
+   blocks into the lower triangle and raises the landmark-failure status on EVERY rank if any shard
+   reported a non-positive-definite H_ll (ranks fail together, none is left waiting in a collective).
+   Enqueue-only, on the handle's stream.  SURVEY.md section 8e. */
 int ps_reduce_buffer(ps_problem* h, void** dev_ptr, int64_t* count);
+int ps_shard_pack(ps_problem* h);
+int ps_shard_unpack(ps_problem* h);
 
 /* Block-Jacobi PCG on the reduced system; replaces the splinalg.spsolve call of
    pyslam/problem.py:186 together with ps_backsub.  Stops when the preconditioned residual

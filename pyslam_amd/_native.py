@@ -64,6 +64,8 @@ SIGNATURES = {
     'ps_eval_cost': (C.c_int, [H, C.c_int, c_f64p]),
     'ps_linearize': (C.c_int, [H, C.c_double]),
     'ps_reduce_buffer': (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'ps_shard_pack': (C.c_int, [H]),
+    'ps_shard_unpack': (C.c_int, [H]),
     'ps_solve_reduced': (C.c_int, [H, C.c_double, C.c_int, C.POINTER(C.c_int), c_f64p]),
     'ps_backsub': (C.c_int, [H]),
     'ps_get_dx': (C.c_int, [H, c_f64p, c_f64p]),

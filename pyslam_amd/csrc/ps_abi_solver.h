@@ -5,7 +5,8 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
     if (!h || !info) return fail("null argument");
     info->dof = h->D; info->num_poses = h->P; info->num_reduced = h->nr; info->num_points = h->L;
     info->num_var_points = h->nv; info->num_obs = h->N; info->num_edges = h->F; info->num_priors = 0;
-    info->reduced_nnzb = h->nnzb; info->num_pairs = h->npairs; info->reduce_count = h->red_count;
+    info->reduced_nnzb = h->nnzb; info->num_pairs = h->npairs;
+    info->reduce_count = ((long)h->nnzb + h->nr) / 2 * h->D * h->D + (long)h->nr * h->D + 3;
     info->device_bytes = (int64_t)h->dev_bytes;
     return 0;
 }
@@ -23,9 +24,52 @@ int ps_linearize(ps_problem* h, double lambda) {
     return linearize(h, lambda);
 }
 
+// exchange buffer of the landmark-sharded iteration: slot lists of the upper block triangle + the buffer itself
+static int ensure_shard_pack(ps_problem* h) {
+    if (h->shard_pack) return 0;
+    const int nr = h->nr, DD = h->D * h->D;
+    std::vector<int32_t> up, upT;
+    for (int r = 0; r < nr; ++r)
+        for (int b = h->h_row_ptr[r]; b < h->h_row_ptr[r + 1]; ++b) {
+            const int c = h->h_col_idx[b];
+            if (c < r) continue;
+            up.push_back(b);
+            const int32_t* lo = h->h_col_idx.data() + h->h_row_ptr[c];
+            const int32_t* hi = h->h_col_idx.data() + h->h_row_ptr[c + 1];
+            const int32_t* it = std::lower_bound(lo, hi, r);
+            if (it == hi || *it != r) return fail("reduced block pattern is not symmetric");
+            upT.push_back((int32_t)(it - h->h_col_idx.data()));
+        }
+    h->nup = (long)up.size();
+    h->pack_count = h->nup * DD + (long)nr * h->D + 2 + 1;
+    if (h->upload(&h->up_slot, up) || h->upload(&h->upT_slot, upT) || h->alloc(&h->shard_pack, (size_t)h->pack_count)) return -1;
+    return 0;
+}
+
 int ps_reduce_buffer(ps_problem* h, void** dev_ptr, int64_t* count) {
     if (!h || !dev_ptr || !count) return fail("null argument");
-    *dev_ptr = h->red; *count = h->red_count;
+    if (ensure_shard_pack(h)) return -1;
+    *dev_ptr = h->shard_pack; *count = h->pack_count;
+    return 0;
+}
+
+int ps_shard_pack(ps_problem* h) {
+    if (!h) return fail("null argument");
+    if (ensure_shard_pack(h)) return -1;
+    const long ntail = (long)h->nr * h->D + 2;
+    const int nb = (int)std::min<long>(4096, cdiv(h->pack_count, 256));
+    if (h->D == 6) hipLaunchKernelGGL(k_shard_pack<6>, dim3(nb), dim3(256), 0, h->stream, h->nup, h->up_slot, h->S, ntail, h->g, h->status, h->shard_pack);
+    else hipLaunchKernelGGL(k_shard_pack<3>, dim3(nb), dim3(256), 0, h->stream, h->nup, h->up_slot, h->S, ntail, h->g, h->status, h->shard_pack);
+    return 0;
+}
+
+int ps_shard_unpack(ps_problem* h) {
+    if (!h) return fail("null argument");
+    if (ensure_shard_pack(h)) return -1;
+    const long ntail = (long)h->nr * h->D + 2;
+    const int nb = (int)std::min<long>(4096, cdiv(h->pack_count, 256));
+    if (h->D == 6) hipLaunchKernelGGL(k_shard_unpack<6>, dim3(nb), dim3(256), 0, h->stream, h->nup, h->up_slot, h->upT_slot, h->shard_pack, h->S, ntail, h->g, h->status);
+    else hipLaunchKernelGGL(k_shard_unpack<3>, dim3(nb), dim3(256), 0, h->stream, h->nup, h->up_slot, h->upT_slot, h->shard_pack, h->S, ntail, h->g, h->status);
     return 0;
 }
 
@@ -207,8 +251,11 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
         enum { NCCL_F64 = 8, NCCL_SUM = 0 };
         StageTimer total(h, PS_ST_TOTAL, 2);
         if (linearize(h, lambda)) return -1;
-        if (h->nccl_allreduce(h->red, h->red, (size_t)h->red_count, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
+        // ONE sum over ranks of [upper(S) | g | cost | failure flag]
+        if (ps_shard_pack(h)) return -1;
+        if (h->nccl_allreduce(h->shard_pack, h->shard_pack, (size_t)h->pack_count, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
             return fail("ncclAllReduce of the reduced system failed");
+        if (ps_shard_unpack(h)) return -1;
         int first = 1, done = 0;
         double sb[2] = {0.0, 0.0}, dxp2 = 0.0;
         for (;;) {

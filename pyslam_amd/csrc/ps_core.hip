@@ -171,6 +171,10 @@ struct ps_problem {
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     allreduce_fn nccl_allreduce = nullptr;
     void* nccl_comm = nullptr;
+    // sharded exchange buffer [upper(S) | g | cost | flag] (k_shard_pack / k_shard_unpack), built on first use
+    double* shard_pack = nullptr;
+    int32_t *up_slot = nullptr, *upT_slot = nullptr;
+    long nup = 0, pack_count = 0;
     double* shard_buf = nullptr;    // {cost, ||dx_point||^2} of this landmark shard, for the caller's all-reduce
     bool shard_out = false;         // k_reduce3 writes cost / ||dx_point||^2 there instead of into scalars
     double *sq_part_l = nullptr, *sq_part_p = nullptr;   // per-workgroup partials of ||dx_point||^2, ||dx_pose||^2

@@ -513,3 +513,47 @@ __global__ __launch_bounds__(256) void k_dense_chol_solve(int n, int nrhs, doubl
         }
     }
 }
+
+// ---------------------------------------------------------------------------
+// landmark-sharded iteration: the exchange buffer of the ONE sum all-reduce per iteration
+//   pack = [upper block triangle of S incl. the diagonal (nup blocks) | g | cost (2) | failure flag]
+// S is exactly symmetric (the Schur and factor kernels mirror every off-diagonal block), so ranks exchange
+// the upper triangle only -- C4: 23 MB instead of 46 MB over xGMI -- and k_shard_unpack mirrors it back.
+// The flag carries ST_LM_FAIL of every shard to all ranks: they fail together instead of one rank leaving
+// the others waiting in the next collective.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_shard_pack(
+    long nup, const int32_t* __restrict__ up_slot, const double* __restrict__ S,
+    long ntail, const double* __restrict__ tail /* g | cost */, const int32_t* __restrict__ status,
+    double* __restrict__ pack)
+{
+    constexpr int DD = D * D;
+    const long total = nup * DD + ntail + 1;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        if (t < nup * DD) pack[t] = S[(size_t)up_slot[t / DD] * DD + t % DD];
+        else if (t < total - 1) pack[t] = tail[t - nup * DD];
+        else pack[t] = status[ST_LM_FAIL] != 0 ? 1.0 : 0.0;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_shard_unpack(
+    long nup, const int32_t* __restrict__ up_slot, const int32_t* __restrict__ upT_slot,
+    const double* __restrict__ pack, double* __restrict__ S, long ntail, double* __restrict__ tail,
+    int32_t* __restrict__ status)
+{
+    constexpr int DD = D * D;
+    const long total = nup * DD + ntail + 1;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        if (t < nup * DD) {
+            const long b = t / DD;
+            const int e = (int)(t % DD), r = e / D, c = e % D;
+            const double v = pack[t];
+            const int s1 = up_slot[b], s2 = upT_slot[b];
+            S[(size_t)s1 * DD + e] = v;
+            if (s2 != s1) S[(size_t)s2 * DD + c * D + r] = v;
+        } else if (t < total - 1) tail[t - nup * DD] = pack[t];
+        else if (pack[t] != 0.0) status[ST_LM_FAIL] = 1;        // some shard's H_ll was not positive definite
+    }
+}

@@ -170,10 +170,17 @@ class DeviceProblem:
         nat.check(self._lib.ps_set_params(self._h, nat.f64p(p), nat.f64p(q)))
 
     def reduce_buffer(self):
-        """(device pointer, number of doubles) of [S | g | cost] for the multi-GPU all-reduce."""
+        """(device pointer, number of doubles) of the exchange buffer [upper(S) | g | cost | flag] the
+        multi-GPU driver all-reduces between shard_pack() and shard_unpack()."""
         ptr, n = C.c_void_p(), C.c_int64()
         nat.check(self._lib.ps_reduce_buffer(self._h, C.byref(ptr), C.byref(n)))
         return ptr.value, n.value
+
+    def shard_pack(self):
+        nat.check(self._lib.ps_shard_pack(self._h))
+
+    def shard_unpack(self):
+        nat.check(self._lib.ps_shard_unpack(self._h))
 
     # ---- parity taps ---------------------------------------------------
     def reduced_system(self):

@@ -5,7 +5,8 @@ Landmarks -- and therefore observations -- are partitioned across ranks; the
 pose table is replicated.  Per iteration:
 
     ps_linearize            shard-local: residuals, Jacobians, H_ll, Z, partial S, g
-    ONE sum all-reduce      [S values | g | cost] on the device buffer the core exposes
+    ONE sum all-reduce      [upper block triangle of S | g | cost | failure flag], packed by the core
+                            (ps_shard_pack / ps_shard_unpack): S is symmetric, one triangle travels
     ps_gn_solve_finish      replicated, deterministic reduced solve (identical dx_pose on every
                             rank) + shard-local back-substitution, update, cost; one host sync
     scalar all-reduce       (cost, ||dx_point||^2)
@@ -118,6 +119,10 @@ class _RawDeviceArray:
                                          'version': 2, 'strides': None}
 
 
+# tests (no GPU) may install a stand-in here: callable (lp_shard, extra_pairs) -> device; None = the HIP core
+DEVICE_FACTORY = None
+
+
 def _default_device_factory(lp, extra_pairs):
     import torch
     from pyslam_amd.device import DeviceProblem
@@ -142,6 +147,7 @@ class ShardedDeviceProblem:
         extra = np.setdiff1d(union, mine)
         pairs = ((extra >> 32).astype(np.int32), (extra & 0xFFFFFFFF).astype(np.int32))
         self.pattern_keys = union
+        device_factory = device_factory or DEVICE_FACTORY
         self.dev = (device_factory or _default_device_factory)(lp_shard, pairs)
         self.lp = lp_shard
         self.info = dict(self.dev.info)
@@ -177,7 +183,11 @@ class ShardedDeviceProblem:
         if self.native is not None:
             return self.dev.gn_iteration(lm_lambda, pcg_tol, pcg_max_iters, linesearch)
         self.dev.linearize(lm_lambda)
+        if hasattr(self.dev, 'shard_pack'):
+            self.dev.shard_pack()                             # [upper(S) | g | cost | failure flag]
         self.dist.all_reduce(self.dev.reduce_tensor)          # RCCL sum over xGMI, on the solver's stream
+        if hasattr(self.dev, 'shard_unpack'):
+            self.dev.shard_unpack()                           # mirrored back into S; a shard's failure reaches every rank
         if hasattr(self.dev, 'shard_tensor'):
             # fully asynchronous second half: the shard's {cost, ||dx_l||^2} are all-reduced on the
             # device; ONE synchronisation per iteration (gn_result)
@@ -215,3 +225,98 @@ class ShardedDeviceProblem:
         self.dev.close()
         if self.native is not None:
             self.native.close()
+
+
+def landmark_bounds(lp, world):
+    """The contiguous landmark ranges shard_landmarks cuts (len world + 1)."""
+    L = lp.num_points
+    if world == 1:
+        return [0, L]
+    counts = np.bincount(lp.obs_point, minlength=L).astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    return [int(np.searchsorted(cum, cum[-1] * r / world, side='left')) for r in range(world)] + [L]
+
+
+class ShardedProblemView:
+    """What ``Problem.solve()`` drives when ``Options.devices`` routes it to the multi-GPU path: it is handed the
+    FULL lowered problem on every rank (every process runs the same script on the same Problem), keeps this rank's
+    landmark shard in HBM and presents the interface of DeviceProblem -- parameters in and out are the full tables
+    (poses are replicated; landmark rows are gathered from their owners), the iteration is ShardedDeviceProblem's.
+    Covariance columns are not sharded: they are solved on a replica of the whole problem on this rank's GPU."""
+
+    def __init__(self, lp, dist, device_factory=None, native_rccl=True):
+        self.lp, self.dist = lp, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.bounds = landmark_bounds(lp, self.world)
+        self.sharded = ShardedDeviceProblem(shard_landmarks(lp, self.rank, self.world), dist,
+                                            device_factory=device_factory, native_rccl=native_rccl)
+        self.dof = lp.dof
+        self.info = dict(self.sharded.info)
+        self._replica = None
+
+    # ---- parameters: full tables <-> this rank's shard ---------------------
+    def set_params(self, poses=None, points=None):
+        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self.sharded.dev.set_params(poses, None if points is None else np.ascontiguousarray(points[lo:hi]))
+
+    def get_params(self):
+        poses, mine = self.sharded.get_params()
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, mine)
+        return poses, np.concatenate(parts).reshape(-1, 3)
+
+    def get_dx(self):
+        """(dx_pose, dx_point) of the last iteration in the FULL problem's device order."""
+        xp, xl = self.sharded.dev.get_dx()
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, xl)
+        return xp, np.concatenate(parts).reshape(-1, 3)
+
+    def snapshot(self):
+        self.sharded.snapshot()
+
+    def restore(self):
+        self.sharded.restore()
+
+    # ---- hot path ----------------------------------------------------------
+    def eval_cost(self, include_all_constant=True):
+        return self.sharded.eval_cost(include_all_constant)
+
+    def gn_iteration(self, lm_lambda=0., pcg_tol=1e-12, pcg_max_iters=1000, linesearch=True):
+        return self.sharded.gn_iteration(lm_lambda, pcg_tol, pcg_max_iters, linesearch)
+
+    # ---- staged calls (Problem.solve_one_iter): one sharded iteration, then the parameters go back -----------
+    def linearize(self, lm_lambda=0.):
+        self._staged_lambda = lm_lambda
+
+    def solve_reduced(self, tol=1e-12, max_iters=1000):
+        self.sharded.snapshot()
+        self._staged = self.sharded.gn_iteration(self._staged_lambda, tol, max_iters, True)
+        self._staged_dx = self.get_dx()
+        self.sharded.restore()
+        return self._staged[2], self._staged[3]
+
+    def backsub(self):
+        pass                                               # (part of the sharded iteration above)
+
+    def apply_update(self, step=1.0):
+        """Only the full step of the reference's degenerate line search (problem.py:362-398) is ever applied."""
+        self.sharded.dev.apply_update(step)
+
+    # ---- covariance: a replica of the whole problem on this rank's GPU --------------------------------------
+    def covariance_begin(self):
+        from pyslam_amd.device import DeviceProblem
+        poses, points = self.get_params()
+        if self._replica is None:
+            self._replica = DeviceProblem(self.lp)
+        self._replica.set_params(poses, points)
+        self._replica.covariance_begin()
+
+    def covariance_column(self, kind, index, comp, tol=1e-13, max_iters=4000):
+        return self._replica.covariance_column(kind, index, comp, tol, max_iters)
+
+    def close(self):
+        self.sharded.close()
+        if self._replica is not None:
+            self._replica.close()
+            self._replica = None

@@ -141,6 +141,21 @@ class LoweredProblem:
         if self.num_priors:
             assert self.u_grp.max() < self.edge_groups.shape[0]
 
+    # everything except the parameter VALUES (poses, points): measurements, stiffness / loss / camera
+    # groups, connectivity, constant masks, key order
+    STRUCTURE_FIELDS = ('pose_rid', 'point_vid', 'obs_pose', 'obs_point', 'obs_uvd', 'obs_grp', 'cams', 'stiff3',
+                        'obs_groups', 'e_i', 'e_j', 'e_Tobs_inv', 'e_grp', 'u_i', 'u_Tobs_inv', 'u_grp', 'stiffd',
+                        'edge_groups')
+
+    def same_tables(self, other):
+        """True when `other` differs from this problem at most in the parameter values: the tables
+        resident in HBM (pyslam_amd/device.py) are then still valid and only poses / points need a refresh."""
+        if self.dof != other.dof or self.pose_keys != other.pose_keys or self.point_keys != other.point_keys:
+            return False
+        if self.poses.shape != other.poses.shape or self.points.shape != other.points.shape:
+            return False
+        return all(np.array_equal(getattr(self, f), getattr(other, f)) for f in self.STRUCTURE_FIELDS)
+
     def copy(self):
         out = LoweredProblem()
         for k, v in self.__dict__.items():
@@ -213,11 +228,20 @@ class _Interner:
         return (np.stack(self.rows) if self.rows else np.zeros((0, width))).reshape(-1, width)
 
 
+_DEVICE_LOSSES = (_losses.L2Loss, _losses.L1Loss, _losses.CauchyLoss, _losses.HuberLoss,
+                  _losses.TukeyLoss, _losses.TDistributionLoss)
+
+# the observation record carries the group index in 8 bits (csrc/ps_kernels.h: PS_GRP_OF)
+MAX_OBS_GROUPS = 255
+
+
 def _loss_id_k(loss):
-    lid = getattr(loss, 'LOSS_ID', None)
-    if lid is None:
+    """(device loss id, k) of a loss object.  Only the built-in classes THEMSELVES have a device
+    restatement (csrc/ps_math.h: ps_loss_rho / ps_loss_weight): a user subclass may override loss() /
+    weight(), which the reference would call (problem.py:351-360), so it takes the host-evaluated path."""
+    if type(loss) not in _DEVICE_LOSSES:
         raise NotLowerable("loss {} has no device restatement".format(type(loss).__name__))
-    return float(lid), float(getattr(loss, 'k', 0.))
+    return float(loss.LOSS_ID), float(getattr(loss, 'k', 0.))
 
 
 def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
@@ -277,7 +301,6 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
         for k in keys:
             if k not in param_dict:
                 raise KeyError(k)
-        lid, lk = _loss_id_k(loss)   # cheap attribute reads
         if kind in ('reproj', 'reproj_motion_only', 'reproj_motion_only_batch'):
             cam = block.camera
             if getattr(cam, 'CAMERA_ID', None) not in (0, 1):
@@ -289,6 +312,7 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
             if g is None:
                 if np.size(block.stiffness) != 9:
                     raise NotLowerable("reprojection stiffness must be 3x3")
+                lid, lk = _loss_id_k(loss)
                 g = ogrp.add([cams.add(cam.intrinsics()), st3.add(block.stiffness), lid, lk])
                 ogrp_cache[gkey] = g
             if kind == 'reproj':
@@ -318,6 +342,7 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
             if g is None:
                 if np.size(block.stiffness) != dof * dof:
                     raise NotLowerable("pose stiffness must be dof x dof")
+                lid, lk = _loss_id_k(loss)
                 g = egrp.add([std.add(block.stiffness), lid, lk])
                 egrp_cache[gkey] = g
             if kind == 'pose_pose':
@@ -344,6 +369,7 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
             if g is None:
                 S6 = np.zeros((6, 6))
                 S6[3:, 3:] = np.asarray(block.stiffness, dtype=F64).reshape(3, 3)
+                lid, lk = _loss_id_k(loss)
                 g = egrp.add([std.add(S6), lid, lk])
                 egrp_cache[gkey] = g
             Tinv = np.zeros(12)
@@ -354,6 +380,11 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
             e_g.append(g)
         else:
             raise NotLowerable("block {} has no typed device kernel".format(type(block).__name__))
+    if len(ogrp.rows) > MAX_OBS_GROUPS:
+        # e.g. a per-observation stiffness: more distinct (camera, stiffness, loss) combinations than the
+        # observation record's 8-bit group field addresses -> host-evaluated path (sparse normal equations)
+        raise NotLowerable("{} distinct (camera, stiffness, loss) observation groups; the typed device tables "
+                           "hold at most {}".format(len(ogrp.rows), MAX_OBS_GROUPS))
 
     lp.poses, lp.pose_rid = poses, rid
     lp.points = np.array(points + fixed_points).reshape(-1, 3)

@@ -50,6 +50,10 @@ class Options:
         self.lm_lambda = 0.             # Marquardt damping lambda * diag(J^T J); 0 = Gauss-Newton
         self.pcg_tol = 1e-12            # relative residual of the reduced (Schur) solve
         self.pcg_max_iters = 2000
+        # None / 1: this process's GPU.  'auto': landmark-sharded over the torch.distributed process group when one
+        # with more than one rank exists (every rank runs the same script on the same Problem: one process per GPU).
+        # 'all' or the world size: sharded, an error without a process group.
+        self.devices = None
 
 
 class Problem:
@@ -67,6 +71,7 @@ class Problem:
 
         self._device = None
         self._device_sig = None
+        self._device_route = None
         self.solver_stats = []          # per iteration: (pcg iterations, pcg relative residual)
 
     # ------------------------------------------------------------------
@@ -138,17 +143,50 @@ class Problem:
         if self._photometric_form():
             return self._get_photometric_device(param_dict)
         lp = self._lower(param_dict)
-        sig = (len(self.residual_blocks), tuple(self.param_dict.keys()), tuple(self.constant_param_keys),
-               lp.num_obs, lp.num_edges, lp.num_priors)
-        if self._device is not None and self._device_sig == sig:
-            self._device.set_params(lp.poses, lp.points)
-            self._device.lp = lp
+        # The resident tables are reused only if EVERYTHING but the parameter values is unchanged: measurements,
+        # stiffness / loss / camera groups, connectivity, constant masks (the reference re-reads all of it on every
+        # iteration, problem.py:338-360, so an edited block.obs, loss.k or a swapped block must take effect).
+        dev = self._device
+        if dev is not None and self._device_sig == 'tables' and dev.lp.same_tables(lp) and \
+                self._device_route == self._route():
+            dev.set_params(lp.poses, lp.points)
+            dev.lp = lp
         else:
-            if self._device is not None:
-                self._device.close()
-            self._device = DeviceProblem(lp)
-            self._device_sig = sig
+            if dev is not None:
+                dev.close()
+            self._device = self._make_device(lp)
+            self._device_sig = 'tables'
+            self._device_route = self._route()
         return self._device
+
+    def _route(self):
+        """'sharded' when Options.devices asks for the landmark-sharded multi-GPU driver and a
+        torch.distributed process group exists (one process per GPU), else 'single'."""
+        want = getattr(self.options, 'devices', None)
+        if want in (None, 1, 'single'):
+            return 'single'
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            dist = None
+        up = dist is not None and dist.is_available() and dist.is_initialized()
+        if want == 'auto':
+            return 'sharded' if up and dist.get_world_size() > 1 else 'single'
+        if not up:
+            raise RuntimeError("Options.devices = {!r} needs an initialised torch.distributed process group "
+                               "(one process per GPU, backend 'nccl')".format(want))
+        if isinstance(want, int) and want != dist.get_world_size():
+            raise RuntimeError("Options.devices = {} but the process group has {} ranks".format(want, dist.get_world_size()))
+        return 'sharded'
+
+    def _make_device(self, lp):
+        """Upload the tables: one GPU, or this rank's landmark shard of them behind the same interface."""
+        from pyslam_amd.device import DeviceProblem
+        if self._route() == 'single':
+            return DeviceProblem(lp)
+        import torch.distributed as dist
+        from pyslam_amd.distributed import ShardedProblemView
+        return ShardedProblemView(lp, dist)
 
     def _write_back(self, dev):
         """Copy the device parameter tables into the live param_dict objects."""

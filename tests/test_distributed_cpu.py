@@ -67,6 +67,27 @@ class OracleShardDevice:
         return cost, float(self.dxp @ self.dxp), float(dxl @ dxl)
 
 
+    # parameter tables in and out (what Problem.solve drives through ShardedProblemView)
+    def get_params(self):
+        return self.lp.poses.copy(), self.lp.points.copy()
+
+    def set_params(self, poses=None, points=None):
+        self.lp = self.lp.copy()
+        if poses is not None:
+            self.lp.poses = np.array(poses, dtype=float)
+        if points is not None:
+            self.lp.points = np.array(points, dtype=float).reshape(-1, 3)
+
+    def snapshot(self):
+        self._snap = self.get_params()
+
+    def restore(self):
+        self.set_params(*self._snap)
+
+    def close(self):
+        pass
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -138,3 +159,52 @@ def test_pose_graph_factors_live_on_rank0_only():
     s0, s1 = shard_landmarks(lp, 0, 2), shard_landmarks(lp, 1, 2)
     assert s0.num_edges == lp.num_edges and s0.num_priors == lp.num_priors
     assert s1.num_edges == 0 and s1.num_priors == 0
+
+
+def _solve_worker(rank, world, port, out):
+    """Problem.solve() through the public API with Options.devices = 'auto': every rank runs the same script on the
+    same Problem; the tables are sharded by landmark behind it."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_api import build_namespace
+    import pyslam_amd.distributed as D
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    D.DEVICE_FACTORY = lambda l, e: OracleShardDevice(l, e)
+    lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=90, obs_per_lm=4, half_window=3, seed=11)
+    ns = build_namespace()
+    opts = ns.Options()
+    opts.devices = 'auto'
+    opts.allow_nondecreasing_steps = True
+    opts.max_nondecreasing_steps = 3
+    problem = synthetic.to_objects(lp, ns, options=opts)
+    assert problem._route() == 'sharded'
+    params = problem.solve()
+    poses = np.stack([params[k].as_matrix() for k in lp.pose_keys])
+    points = np.stack([params[k] for k in lp.point_keys])
+    if rank == 0:
+        out.put((list(problem._cost_history), poses, points, type(problem._device).__name__))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_problem_solve_routes_to_the_sharded_driver():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_solve_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    hist, poses, points, devname = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert devname == 'ShardedProblemView'
+    lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=90, obs_per_lm=4, half_window=3, seed=11)
+    final, trace = orc.solve(lp, dict(allow_nondecreasing_steps=True, max_nondecreasing_steps=3), points_first=True)
+    ref = trace['cost_history']
+    assert len(hist) == len(ref) and np.allclose(hist, ref, rtol=1e-7, atol=1e-18)
+    from pyslam_amd.lowering import pose_rows_to_matrices
+    assert np.abs(poses - pose_rows_to_matrices(final.poses, 6)).max() < 1e-8
+    assert np.abs(points - final.points).max() < 1e-8

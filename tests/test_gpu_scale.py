@@ -301,3 +301,63 @@ def test_mid_size_ba_uses_the_explicit_pcg_and_matches_the_oracle(kf, lm, with_e
         assert 0 < its < 200 and rel <= 1e-12
         assert abs(cost - want) <= 1e-9 * want and abs(nrm - np.linalg.norm(dx)) <= 1e-8 * np.linalg.norm(dx)
         assert np.abs(poses - cur.poses).max() < 1e-9 and np.abs(points - cur.points).max() < 1e-8
+
+
+# ---------------------------------------------------------------------------
+# C4: the north star's target size (BASELINE.json configs[3]): 2 000 keyframes, 500 000 landmarks,
+# 5 M reprojection blocks = 15 M residual rows, 1 511 994 unknowns.  The reference cannot run it;
+# parity is through the size-independent properties, against the oracle's (reference algebra) matrix.
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def c4():
+    lp, _ = synthetic.stereo_ba(2000, 500000, 10, 20, seed=1)
+    return lp
+
+
+def test_c4_step_solves_the_reference_normal_equations(c4):
+    dev = device(c4)
+    assert dev.info['num_obs'] == 5000000 and dev.info['num_reduced'] == 1999
+    c0 = dev.eval_cost(True)
+    assert abs(c0 - orc.eval_cost(c4)) <= 1e-11 * c0
+    cost, nrm, its, rel = dev.gn_iteration(0., 1e-12, 2000, True)       # the whole-iteration call the bench times
+    dx = device_dx_posefirst(dev)
+    P, b, lin_cost = orc.normal_equations(c4, points_first=False)        # reference algebra (oracle), 185 M non-zeros
+    res = P.dot(dx) - b
+    assert np.linalg.norm(res) <= 1e-9 * np.linalg.norm(b), (its, rel)
+    n = 6 * c4.num_reduced
+    assert np.linalg.norm(res[n:]) <= 1e-11 * np.linalg.norm(b[n:])       # landmark part: exact (direct) solve
+    assert abs(nrm - np.linalg.norm(dx)) <= 1e-10 * nrm
+    assert abs(cost - orc.eval_cost(orc.apply_update(c4, dx, points_first=False))) <= 1e-9 * cost
+    assert cost < 0.05 * c0
+    # a second iteration (lagged side-stream coarse inverse, predicted launch count) still converges to tolerance
+    cost2, nrm2, its2, rel2 = dev.gn_iteration(0., 1e-12, 2000, True)
+    assert rel2 <= 1e-12 and cost2 < cost
+
+
+def test_c4_four_landmark_shards_sum_to_the_unsharded_reduced_system(c4):
+    """The 4-GPU split of the FIXED C4 problem (bench.py --gpus 4), checked on ONE GPU: every shard
+    built with the union block pattern; S, g and the cost summed on the host equal the unsharded ones."""
+    full = device(c4)
+    full.linearize(0.)
+    rp, ci, vals, g = full.reduced_system()
+    cost_full = full.eval_cost(True)
+    full.close()
+    union = pose_pair_keys(c4)
+    acc_v, acc_g, cost, nobs = np.zeros_like(vals), np.zeros_like(g), 0., 0
+    world = 4
+    for r in range(world):
+        sh = shard_landmarks(c4, r, world)
+        nobs += sh.num_obs
+        assert abs(sh.num_obs - c4.num_obs / world) <= 0.01 * c4.num_obs   # balanced by observation count
+        extra = np.setdiff1d(union, pose_pair_keys(sh))
+        dev = device(sh, extra_pairs=((extra >> 32).astype(np.int32), (extra & 0xFFFFFFFF).astype(np.int32)))
+        dev.linearize(0.)
+        rp2, ci2, v2, g2 = dev.reduced_system()
+        assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)       # identical pattern on every rank
+        acc_v += v2; acc_g += g2
+        cost += dev.eval_cost(True)
+        dev.close()
+    assert nobs == c4.num_obs
+    assert np.abs(acc_v - vals).max() <= 1e-11 * np.abs(vals).max()
+    assert np.abs(acc_g - g).max() <= 1e-11 * np.abs(g).max()
+    assert abs(cost - cost_full) <= 1e-12 * cost

@@ -311,3 +311,57 @@ def test_orientation_residual_lowers_to_a_rotation_only_edge():
     assert np.allclose(r[0, :3], 0.) and np.allclose(r[0, 3:], r_ref, atol=1e-14)
     assert np.allclose(J1[0, 3:], j1_ref, atol=1e-14) and np.allclose(J2[0, 3:], j2_ref, atol=1e-14)
     assert not J1[0, :3].any() and not J2[0, :3].any()
+
+
+def test_loss_subclass_and_group_overflow_are_not_lowered():
+    """A user subclass of a built-in loss may override loss() / weight(): it must not be lowered to the parent's
+    device formula.  More (camera, stiffness, loss) groups than the 8-bit group field holds: NotLowerable
+    (the host-evaluated path then runs), not an error out of ps_problem_create."""
+    from liegroups import SE3
+    from pyslam.losses import HuberLoss, L2Loss
+    from pyslam.sensors import StereoCamera
+    from pyslam.residuals import ReprojectionResidual
+    from pyslam_amd import lowering
+    from pyslam_amd.lowering import NotLowerable
+
+    class MyHuber(HuberLoss):
+        def weight(self, x):
+            return np.ones_like(np.asarray(x, dtype=float))
+    cam = StereoCamera(640., 480., 1000., 1000., 0.25, 1280, 960)
+    params = {'T': SE3.identity(), 'p': np.array([0., 0., 10.])}
+    block = ReprojectionResidual(cam, np.array([640., 480., 25.]), np.eye(3))
+    assert lowering.lower(params, [block], [['T', 'p']], [HuberLoss(1.)], []).obs_groups[0, 2] == 3
+    with pytest.raises(NotLowerable):
+        lowering.lower(params, [block], [['T', 'p']], [MyHuber(1.)], [])
+    # one stiffness per observation
+    blocks = [ReprojectionResidual(cam, np.array([640., 480., 25.]), (1. + 0.01 * i) * np.eye(3)) for i in range(300)]
+    loss = L2Loss()
+    with pytest.raises(NotLowerable):
+        lowering.lower(params, blocks, [['T', 'p']] * 300, [loss] * 300, [])
+    ok = lowering.lower(params, blocks[:255], [['T', 'p']] * 255, [loss] * 255, [])
+    assert ok.obs_groups.shape[0] == 255
+
+
+def test_same_tables_sees_every_edit_but_parameter_values():
+    """Problem keeps its HBM tables between calls only while nothing but the parameter VALUES changed."""
+    import pyslam_amd.synthetic as synthetic
+    lp = golden_lp(load_golden('ba_tiny_huber'))
+    problem = synthetic.to_objects(lp, build_namespace())
+    a = problem._lower()
+    assert a.same_tables(problem._lower())
+    problem.param_dict[a.point_keys[0]][0] += 0.5                      # a parameter value: tables still valid
+    problem.param_dict[a.pose_keys[1]].perturb(0.01 * np.ones(6))
+    b = problem._lower()
+    assert a.same_tables(b) and not np.array_equal(a.points, b.points) and not np.array_equal(a.poses, b.poses)
+    problem.block_loss_functions[0].k *= 2.                            # loss parameter
+    assert not a.same_tables(problem._lower())
+    problem.block_loss_functions[0].k /= 2.
+    assert a.same_tables(problem._lower())
+    problem.residual_blocks[3].obs[1] += 1.                            # a measurement, edited in place
+    assert not a.same_tables(problem._lower())
+    problem.residual_blocks[3].obs[1] -= 1.
+    problem.residual_blocks[0], problem.residual_blocks[1] = problem.residual_blocks[1], problem.residual_blocks[0]
+    assert not a.same_tables(problem._lower())                         # same counts, different connectivity
+    problem.residual_blocks[0], problem.residual_blocks[1] = problem.residual_blocks[1], problem.residual_blocks[0]
+    problem.set_parameters_constant(a.point_keys[2])
+    assert not a.same_tables(problem._lower())
