@@ -140,7 +140,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     h->Nl = Nl;
     if (h->upload(&h->lobs, lobs) || h->upload(&h->lorig, lorig) || h->upload(&h->lm_ptr, lm_ptr) ||
         h->upload(&h->lm_point, lm_point)) return -1;
-    if (h->alloc(&h->Z, (size_t)Nl * 18) || h->alloc(&h->Cinv, (size_t)nv * 6) ||
+    if (h->alloc(&h->Z, (size_t)Nl * PS_ZROW) || h->alloc(&h->Cinv, (size_t)nv * 6) ||
         h->alloc(&h->cvec, (size_t)nv * 3) || h->alloc(&h->dxl, (size_t)nv * 3)) return -1;
     HIP_OK(hipMemsetAsync(h->dxl, 0, std::max<size_t>(1, (size_t)nv * 3) * sizeof(double), h->stream));
 
@@ -219,7 +219,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     std::vector<PairRec> prs;
     int ntiles = 1;
     {
-        const double zbytes = 144.0 * (double)lm_ptr[nv];
+        const double zbytes = 8.0 * PS_ZROW * (double)lm_ptr[nv];
         double tile_kb = 9216.0, min_mb = 16.0;
         if (const char* e = getenv("PS_SCHUR_TILE_KB")) tile_kb = atof(e);
         if (const char* e = getenv("PS_SCHUR_TILE_MIN_MB")) min_mb = atof(e);

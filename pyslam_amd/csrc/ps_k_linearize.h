@@ -4,7 +4,7 @@
 
 // ---------------------------------------------------------------------------
 // landmark pass: 16 lanes cooperate on one landmark (4 landmarks per wave), one observation
-// per lane: loads of the 32-byte records and stores of the 144-byte Z rows are contiguous
+// per lane: loads of the 32-byte records and stores of the 128-byte Z rows are contiguous
 // across lanes, residual + both Jacobians are evaluated ONCE, and H_ll / b_l are reduced with
 // a 4-step xor butterfly inside the 16-lane group (fixed order => deterministic).
 // Landmarks with more than 16 observations loop (lane j takes observations j, j+16, ...) and
@@ -20,17 +20,47 @@ PS_DEV double group16_sum(double v) {          // a 16-lane group is exactly one
     return __shfl(v, (int)(threadIdx.x & 63) | 15, 64);
 }
 
-PS_DEV void lm_emit_z(const ReprojEval& ev, double M00, double M10, double M11, double M20, double M21,
-                      double M22, double* __restrict__ z) {
+// ---------------------------------------------------------------------------
+// The eliminated-landmark row of an observation, Z_i = W_i C^-T (6 x 3, W_i = J~p^T J~l, H_ll = C C^T), in 12 numbers:
+// J~p = A [I | -pc^] with A = diag(sqrt w) S Jc (3 x 3) and pc = T p the point in the camera frame, so
+//     J~p^T = [I; pc^] A^T     and     Z_i = [I; pc^] (A^T J~l C^-T) = [M; pc^ M],   M = A^T J~l C^-T  (3 x 3).
+// HBM holds (M, pc) per observation, padded to ONE aligned 128-byte line ("Z row": M row-major (9) | pc (3) | reduced
+// index of the pose as a double (-1: constant pose) | 3 unused) instead of the 18 entries of Z (144 B, two lines per
+// gather): the Schur pair kernel fetches one line per row, the back-substitution reads 128 B per observation and no
+// observation record.  Every consumer expands the lower half pc^ M with the same three cross products (zrow_expand),
+// so the diagonal blocks (pose pass), the off-diagonal blocks (pair kernel) and the back-substitution see one Z.
+// ---------------------------------------------------------------------------
+#define PS_ZROW 16
+
+// M = (top three rows of J~p^T) J~l C^-T; (M00 .. M22) = C^-1 (lower triangular)
+PS_DEV void lm_emit_m(const ReprojEval& ev, double M00, double M10, double M11, double M20, double M21,
+                      double M22, double* __restrict__ m) {
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+    for (int a = 0; a < 3; ++a) {
         const double w0 = ev.Jp[a] * ev.Jl[0] + ev.Jp[6 + a] * ev.Jl[3] + ev.Jp[12 + a] * ev.Jl[6];
         const double w1 = ev.Jp[a] * ev.Jl[1] + ev.Jp[6 + a] * ev.Jl[4] + ev.Jp[12 + a] * ev.Jl[7];
         const double w2 = ev.Jp[a] * ev.Jl[2] + ev.Jp[6 + a] * ev.Jl[5] + ev.Jp[12 + a] * ev.Jl[8];
-        z[3 * a] = w0 * M00;
-        z[3 * a + 1] = w0 * M10 + w1 * M11;
-        z[3 * a + 2] = w0 * M20 + w1 * M21 + w2 * M22;
+        m[3 * a] = w0 * M00;
+        m[3 * a + 1] = w0 * M10 + w1 * M11;
+        m[3 * a + 2] = w0 * M20 + w1 * M21 + w2 * M22;
     }
+}
+
+// l = pc^ m (3 x 3, row-major): column k of l is pc x (column k of m)
+PS_DEV void zrow_cross(const double* __restrict__ m, const double* __restrict__ pc, double* __restrict__ l) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        l[k] = pc[1] * m[6 + k] - pc[2] * m[3 + k];
+        l[3 + k] = pc[2] * m[k] - pc[0] * m[6 + k];
+        l[6 + k] = pc[0] * m[3 + k] - pc[1] * m[k];
+    }
+}
+
+// z (6 x 3, row-major) = [m; pc^ m]
+PS_DEV void zrow_expand(const double* __restrict__ m, const double* __restrict__ pc, double* __restrict__ z) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) z[k] = m[k];
+    zrow_cross(m, pc, z + 9);
 }
 
 __global__ __launch_bounds__(256) void k_landmark_pass(
@@ -56,11 +86,13 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
     double H00 = 0, H10 = 0, H11 = 0, H20 = 0, H21 = 0, H22 = 0, b0 = 0, b1 = 0, b2 = 0;
     ReprojEval ev;
     bool have = false, variable_pose = false;
+    int rid_of_obs = -1;
     for (int i = b + sub; i < e; i += PS_LM_GROUP) {
         const LObs o = lobs[i];
         const int pose = PS_POSE_OF(o);
         const Se3 T = se3_load(poses + 12 * pose);
-        variable_pose = pose_rid[pose] >= 0;
+        rid_of_obs = pose_rid[pose];
+        variable_pose = rid_of_obs >= 0;
         reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
         have = true;
         const double* J = ev.Jl;
@@ -105,46 +137,51 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
         cv[1] = M10 * b0 + M11 * b1;
         cv[2] = M20 * b0 + M21 * b1 + M22 * b2;
     }
-    // ---- Z rows.  Common case (every landmark of the wave has <= 16 observations): the wave's rows are
-    // one contiguous range of Z, so they are transposed through LDS and stored as whole 16-byte pieces by
-    // consecutive lanes (1 KB per store instruction) instead of 18 stride-144 8-byte stores per lane.
-    __shared__ __attribute__((aligned(16))) double zst[4][64 * 18];
+    // ---- Z rows (one 128-byte line each).  Common case (every landmark of the wave has <= 16 observations): the
+    // wave's rows are one contiguous range of Z, so they are staged in LDS and stored as whole 16-byte pieces by
+    // consecutive lanes (1 KB per store instruction).
+    __shared__ __attribute__((aligned(16))) double zst[4][64 * PS_ZROW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (__ballot(single || !live) == ~0ull && !(ablate & 2)) {
         const int row0 = __shfl(b, 0, 64);                       // dead groups carry b = e = 0
         const int eend = max(max(__shfl(e, 0, 64), __shfl(e, 16, 64)), max(__shfl(e, 32, 64), __shfl(e, 48, 64)));
         const int nrows = eend - row0;
         if (have) {
-            double z[18];
-            if (variable_pose) lm_emit_z(ev, M00, M10, M11, M20, M21, M22, z);
-            else {
+            double z[PS_ZROW];
 #pragma unroll
-                for (int k = 0; k < 18; ++k) z[k] = 0.0;         // rows of constant poses are never read
+            for (int k = 0; k < PS_ZROW; ++k) z[k] = 0.0;        // rows of constant poses are never read
+            z[12] = -1.0;
+            if (variable_pose) {
+                lm_emit_m(ev, M00, M10, M11, M20, M21, M22, z);
+                z[9] = ev.pc[0]; z[10] = ev.pc[1]; z[11] = ev.pc[2];
+                z[12] = (double)rid_of_obs;
             }
-            double2* dst = reinterpret_cast<double2*>(&zst[wv][18 * (b + sub - row0)]);
+            double2* dst = reinterpret_cast<double2*>(&zst[wv][PS_ZROW * (b + sub - row0)]);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) dst[k] = make_double2(z[2 * k], z[2 * k + 1]);
+            for (int k = 0; k < PS_ZROW / 2; ++k) dst[k] = make_double2(z[2 * k], z[2 * k + 1]);
         }
         __builtin_amdgcn_wave_barrier();
         if (!(ablate & 1)) {
             const double2* src = reinterpret_cast<const double2*>(zst[wv]);
-            double2* out = reinterpret_cast<double2*>(Z + 18 * (size_t)row0);
-            for (int k = lane; k < nrows * 9; k += 64) out[k] = src[k];
+            double2* out = reinterpret_cast<double2*>(Z + PS_ZROW * (size_t)row0);
+            for (int k = lane; k < nrows * (PS_ZROW / 2); k += 64) out[k] = src[k];
         }
         return;
     }
     if (!live) return;
-    if (single) {
-        if (have && variable_pose && !(ablate & 1)) lm_emit_z(ev, M00, M10, M11, M20, M21, M22, Z + 18 * (size_t)(b + sub));
-        return;
-    }
-    for (int i = b + sub; i < e; i += PS_LM_GROUP) {
+    for (int i = b + sub; i < e; i += PS_LM_GROUP) {             // long tracks: a second sweep re-evaluates
         const LObs o = lobs[i];
         const int pose = PS_POSE_OF(o);
-        if (pose_rid[pose] < 0) continue;
-        const Se3 T = se3_load(poses + 12 * pose);
-        reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
-        lm_emit_z(ev, M00, M10, M11, M20, M21, M22, Z + 18 * (size_t)i);
+        double* z = Z + PS_ZROW * (size_t)i;
+        const int rid = pose_rid[pose];
+        z[12] = (double)rid;
+        if (rid < 0 || (ablate & 1)) continue;
+        if (!single) {
+            const Se3 T = se3_load(poses + 12 * pose);
+            reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        }
+        lm_emit_m(ev, M00, M10, M11, M20, M21, M22, z);
+        z[9] = ev.pc[0]; z[10] = ev.pc[1]; z[11] = ev.pc[2];
     }
 }
 
@@ -157,7 +194,7 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
 // is uniform per workgroup.  The Z row of an observation is NOT read back from HBM (144 B each,
 // scattered: that read alone cost 15 of this kernel's 37 us): it is recomputed in registers from
 // the Jacobians this kernel evaluates anyway and the landmark's 48-byte factor C^-1 (an L2-resident
-// table) -- lm_emit_z on the same inputs, so the values are those the landmark pass stored.
+// table) -- lm_emit_m + zrow_expand on the same inputs, so the values are those every consumer of the stored row forms.
 #define PS_NPOSE_ACC 33
 typedef const __attribute__((address_space(1))) void* ps_gptr_t;
 typedef __attribute__((address_space(3))) void* ps_lptr_t;
@@ -201,8 +238,9 @@ __global__ __launch_bounds__(256) void k_pose_pass(
             acc[27 + a] += ev.Jp[a] * ev.Jp[a] + ev.Jp[6 + a] * ev.Jp[6 + a] + ev.Jp[12 + a] * ev.Jp[12 + a];
         }
         if (v >= 0) {
-            double z[18];
-            lm_emit_z(ev, m[0], m[1], m[2], m[3], m[4], m[5], z);
+            double m9[9], z[18];
+            lm_emit_m(ev, m[0], m[1], m[2], m[3], m[4], m[5], m9);
+            zrow_expand(m9, ev.pc, z);
             n = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
@@ -264,17 +302,21 @@ __global__ __launch_bounds__(64) void k_pose_finalize(
 // that share pose ri's Z rows (and, for neighbouring rows, pose rj's) then hit the same 4 MB L2
 // instead of being re-fetched by all eight.
 //
-// Z rows are 144 B and scattered, so a lane-per-pair gather issues 18 fully divergent 16-byte
-// loads per pair (41 M L1 accesses at C3).  Instead each wave moves the 64 rows of a 32-pair
-// chunk straight into LDS with global_load_lds_dwordx4 (no staging registers, no ds_write pass):
-// 9 consecutive lanes fetch the 9 x 16 B of ONE row, 7 rows per instruction, and because the
-// LDS destination of lane l is base + 16 l the rows land at their natural 144-byte stride, which
-// is conflict-free for the ds_read_b128 of the compute phase.  Two lanes share a pair (lane
-// p + 32 h accumulates block rows 3h .. 3h+2), so a lane carries 18 accumulators instead of 36:
-// ~9 KB of LDS and < 128 VGPRs per wave => 4 waves per SIMD, twice the loads in flight of the
-// register-staged 64-pair version.  Waves never share LDS data: no workgroup barrier.
+// Z rows are scattered, so a lane-per-pair gather issues fully divergent 16-byte loads (41 M L1
+// accesses at C3 with the 144-byte rows of round 1).  Instead each wave moves the 64 rows of a
+// 32-pair chunk straight into LDS with global_load_lds_dwordx4 (no staging registers, no ds_write
+// pass).  A stored row is ONE aligned 128-byte line (M | pc | rid | pad, see PS_ZROW): 7 consecutive
+// lanes fetch its first 7 x 16 B, 9 rows per instruction, and because the LDS destination of lane l
+// is base + 16 l the rows land at a 112-byte stride, which is conflict-free for the ds_read_b128 of
+// the compute phase (28 banks per row: 16 consecutive rows start on 16 distinct multiples of 4).  One L2
+// request per row instead of two for the 144-byte rows (8.8 M -> 4.6 M line requests per launch at C3;
+// the kernel is bound by exactly that request stream).  Two lanes share a pair
+// (lane p + 32 h accumulates block rows 3h .. 3h+2: h = 0 from M_a, h = 1 from pc_a^ M_a; the b row is
+// expanded to [M_b; pc_b^ M_b] by both), so a lane carries 18 accumulators: 7 KB of LDS and < 128
+// VGPRs per wave => 4 waves per SIMD.  Waves never share LDS data: no workgroup barrier.
 #define PS_SP_PAIRS 32                        // pairs per chunk: rows a_0..a_31, b_0..b_31
-#define PS_SP_LDS_PER_WAVE 1152               // doubles: 64 rows x 18
+#define PS_SP_ROWD 14                         // doubles per row in LDS (7 x 16 B of the 128-byte line)
+#define PS_SP_LDS_PER_WAVE (64 * PS_SP_ROWD)  // doubles: 64 rows x 14
 
 // sum over the 32 lanes of each wave half with DPP row operations (fixed order): lane 31 / 63
 // end up with the total of lanes 0-31 / 32-63
@@ -301,7 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const PairItem it = xitems[pos];
     if (it.slot < 0) return;
     const int p = lane & 31, hf = lane >> 5;                    // pair in the chunk, half of the block
-    const int slot = lane / 9, piece = lane - 9 * slot;         // fetch role; lane 63: slot 7 (idle)
+    const int slot = lane / 7, piece = lane - 7 * slot;         // fetch role; lane 63: slot 9 (idle)
     const int32_t* flat = reinterpret_cast<const int32_t*>(pairs) + hf;
     double acc[18];
 #pragma unroll
@@ -312,42 +354,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     int mine1 = (it.start + PS_SP_PAIRS + p < it.end) ? flat[2 * (size_t)(it.start + PS_SP_PAIRS + p)] : -1;
     for (int base = it.start; base < it.end; base += PS_SP_PAIRS) {
         const int n = min(PS_SP_PAIRS, it.end - base);
-        // ---- cooperative fetch: instruction k brings rows 7k .. 7k+6 into LDS.  All ten index
+        // ---- cooperative fetch: instruction k brings rows 9k .. 9k+8 into LDS.  All eight index
         // shuffles are issued first (one wait), the next-but-one chunk's indices are requested
         // BEFORE the rows so that the single vmcnt(0) below never waits on a younger load.
-        int zrow[10];
+        int zrow[8];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) zrow[k] = __shfl(mine, (7 * k + slot) & 63, 64);
+        for (int k = 0; k < 8; ++k) zrow[k] = __shfl(mine, (9 * k + slot) & 63, 64);
         const int nb = base + 2 * PS_SP_PAIRS;
         const int mine2 = (nb + p < it.end) ? flat[2 * (size_t)(nb + p)] : -1;
 #pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            const int r = 7 * k + slot;
-            if (slot < 7 && r < 2 * PS_SP_PAIRS && zrow[k] >= 0 && !(ablate & 2))
-                __builtin_amdgcn_global_load_lds((ps_gptr_t)(Z + 18 * (size_t)zrow[k] + 2 * piece),
-                                                 (ps_lptr_t)(rows + 126 * k), 16, 0, 0);
+        for (int k = 0; k < 8; ++k) {
+            const int r = 9 * k + slot;
+            if (slot < 9 && r < 2 * PS_SP_PAIRS && zrow[k] >= 0 && !(ablate & 2))
+                __builtin_amdgcn_global_load_lds((ps_gptr_t)(Z + PS_ZROW * (size_t)zrow[k] + 2 * piece),
+                                                 (ps_lptr_t)(rows + 9 * PS_SP_ROWD * k), 16, 0, 0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): rows have landed in LDS
         __builtin_amdgcn_wave_barrier();
         if (p < n && !(ablate & 1)) {
-            double za[9];
-            const double* pa = rows + 18 * p + 9 * hf;
+            double ma[12], mb[12], A[9], Lb[9];
+            const double2* pa = reinterpret_cast<const double2*>(rows + PS_SP_ROWD * p);
+            const double2* pb = reinterpret_cast<const double2*>(rows + PS_SP_ROWD * (PS_SP_PAIRS + p));
 #pragma unroll
-            for (int k = 0; k < 9; ++k) za[k] = pa[k];
-#pragma unroll
-            for (int bh = 0; bh < 2; ++bh) {
-                double zb[10];
-                // columns 3bh .. 3bh+2 need b-row entries 9bh .. 9bh+8; read 16-byte aligned
-                const double2* pb = reinterpret_cast<const double2*>(rows + 18 * (PS_SP_PAIRS + p) + 8 * bh);
-#pragma unroll
-                for (int k = 0; k < 5; ++k) { const double2 v = pb[k]; zb[2 * k] = v.x; zb[2 * k + 1] = v.y; }
-                const double* q = zb + bh;                      // q[0..8] = entries 9bh .. 9bh+8
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b)
-                        acc[6 * a + 3 * bh + b] += za[3 * a] * q[3 * b] + za[3 * a + 1] * q[3 * b + 1] + za[3 * a + 2] * q[3 * b + 2];
+            for (int k = 0; k < 6; ++k) {
+                const double2 va = pa[k], vb = pb[k];
+                ma[2 * k] = va.x; ma[2 * k + 1] = va.y; mb[2 * k] = vb.x; mb[2 * k + 1] = vb.y;
             }
+            // this lane's three rows of Z_a: M_a (h = 0) or pc_a^ M_a (h = 1); both halves of Z_b
+            zrow_cross(ma, ma + 9, A);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) A[k] = hf ? A[k] : ma[k];
+            zrow_cross(mb, mb + 9, Lb);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    acc[6 * a + b] += A[3 * a] * mb[3 * b] + A[3 * a + 1] * mb[3 * b + 1] + A[3 * a + 2] * mb[3 * b + 2];
+                    acc[6 * a + 3 + b] += A[3 * a] * Lb[3 * b] + A[3 * a + 1] * Lb[3 * b + 1] + A[3 * a + 2] * Lb[3 * b + 2];
+                }
         }
         __builtin_amdgcn_wave_barrier();                        // LDS reads done before the next fetch lands
         mine = mine1; mine1 = mine2;

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(64) void k_cov_rhs(
     for (int i = lm_ptr[index]; i < lm_ptr[index + 1]; ++i) {
         const int rid = pose_rid[PS_POSE_OF(lobs[i])];
         if (rid < 0) continue;
-        const double* z = Z + 18 * (size_t)i;
+        double z[18];
+        zrow_expand(Z + PS_ZROW * (size_t)i, Z + PS_ZROW * (size_t)i + 9, z);
         for (int a = 0; a < 6; ++a) g[(size_t)rid * 6 + a] -= z[3 * a] * c[0] + z[3 * a + 1] * c[1] + z[3 * a + 2] * c[2];
     }
 }
@@ -221,15 +222,21 @@ __global__ __launch_bounds__(256) void k_backsub(
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     if (live) {
         for (int i = lm_ptr[v] + sub; i < lm_ptr[v + 1]; i += PS_LM_GROUP) {
-            const int rid = pose_rid[PS_POSE_OF(lobs[i])];
-            if (rid < 0) continue;
-            const double* z = Z + 18 * (size_t)i;
-            const double* x = xp + 6 * (size_t)rid;
+            // the whole 128-byte row: M (9) | pc (3) | reduced pose index (no observation record, no pose_rid gather)
+            const double2* zq = reinterpret_cast<const double2*>(Z + PS_ZROW * (size_t)i);
+            double z[14];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const double xa = x[a];
-                a0 -= z[3 * a] * xa; a1 -= z[3 * a + 1] * xa; a2 -= z[3 * a + 2] * xa;
-            }
+            for (int k = 0; k < 7; ++k) { const double2 t = zq[k]; z[2 * k] = t.x; z[2 * k + 1] = t.y; }
+            const int rid = (int)z[12];
+            if (rid < 0) continue;
+            const double* x = xp + 6 * (size_t)rid;
+            // Z^T x = M^T (x_rho - pc x x_phi)
+            const double y0 = x[0] - (z[10] * x[5] - z[11] * x[4]);
+            const double y1 = x[1] - (z[11] * x[3] - z[9] * x[5]);
+            const double y2 = x[2] - (z[9] * x[4] - z[10] * x[3]);
+            a0 -= z[0] * y0 + z[3] * y1 + z[6] * y2;
+            a1 -= z[1] * y0 + z[4] * y1 + z[7] * y2;
+            a2 -= z[2] * y0 + z[5] * y1 + z[8] * y2;
         }
     }
     a0 = group16_sum(a0); a1 = group16_sum(a1); a2 = group16_sum(a2);

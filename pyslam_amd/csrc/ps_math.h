@@ -280,6 +280,7 @@ struct ReprojEval {
     double Jp[18];      // sqrt(w) * J_pose, row-major 3x6
     double Jl[9];       // sqrt(w) * J_point, row-major 3x3
     double cost;        // sum rho(r_k)
+    double pc[3];       // the point in the camera frame, T p (J_pose = S Jc [I | -pc^])
 };
 
 template <bool WITH_JP, bool WITH_JL>
@@ -287,6 +288,7 @@ PS_DEV void reproj_eval(const Se3& T, const double* __restrict__ pw, const doubl
                         const ObsGroup& g, ReprojEval& o) {
     double pc[3];
     se3_apply(T, pw, pc);
+    o.pc[0] = pc[0]; o.pc[1] = pc[1]; o.pc[2] = pc[2];
     const double iz = 1.0 / pc[2];
     const double e0 = g.fu * pc[0] * iz + g.cu - uvd[0];
     const double e1 = g.fv * pc[1] * iz + g.cv - uvd[1];

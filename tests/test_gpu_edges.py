@@ -214,7 +214,7 @@ def test_problem_edits_between_solves_reach_the_device():
     dev0 = problem._device
     assert abs(c0 - oracle_cost()) <= 1e-12 * c0
     # parameter values only: same handle
-    problem.param_dict[lp.point_keys[0]][1] += 0.3
+    problem.param_dict[problem._lower().point_keys[0]][1] += 0.3
     c1 = problem.eval_cost()
     assert problem._device is dev0 and c1 != c0 and abs(c1 - oracle_cost()) <= 1e-12 * c1
     # loss parameter
