@@ -12,6 +12,9 @@ int ps_device_count(void) {
 
 int ps_problem_destroy(ps_problem* h) {
     if (!h) return 0;
+    if (getenv("PS_HOST_TIMING") && h->host_calls)
+        fprintf(stderr, "ps_gn_iteration: %ld calls, %.1f us per call on the host, of which %.1f us waiting for the GPU (%ld waits)\n",
+                h->host_calls, h->host_call_ns * 1e-3 / h->host_calls, h->host_wait_ns * 1e-3 / h->host_calls, h->host_waits);
     hipStreamSynchronize(h->stream);
     if (h->side) hipStreamSynchronize(h->side);
     for (void* p : h->allocs) hipFree(p);

@@ -243,6 +243,10 @@ int ps_gn_result(ps_problem* h, int* done, double* shard2 /* [2] */, double* dx_
 int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters, int linesearch,
                     double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out) {
     if (!h) return fail("null argument");
+    struct CallClock {
+        ps_problem* h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~CallClock() { h->host_call_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); ++h->host_calls; }
+    } cc{h};
     if (h->nccl_allreduce && h->nccl_comm) {
         // landmark-sharded iteration, everything on the solver's stream in ONE call:
         // linearize -> RCCL sum of [S | g | cost] -> replicated CG + gated shard-local tail ->
@@ -434,12 +438,13 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "schur_ablate") h->schur_ablate = (int)value;
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
+    else if (n == "coarse_lag_x") { h->lagx = value != 0.0; h->lci_next = -1; h->side_todo = false; }
     else if (n == "cg_lds") h->cg_lds = value != 0.0;
     else if (n == "cg_explicit") { h->explicit_ok = value != 0.0; h->coarse_built = false; }
     else if (n == "big_chol") h->big_chol = value != 0.0;
     else if (n == "fused_motion_only") h->mo_fused = value != 0.0;
     else if (n == "direct_max_unknowns") { if (value < 0 || value > 90) return fail("direct_max_unknowns must be 0..90"); h->direct_max = (int)value; }
-    else if (n == "coarse_basis") { h->coarse_basis = value != 0.0; h->lci_next = -1; }
+    else if (n == "coarse_basis") { h->coarse_basis = value != 0.0; h->lci_next = -1; h->side_todo = false; }
     else if (n == "profile_every") { if (value < 1) return fail("profile_every must be >= 1"); h->prof_every = (int)value; }
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }

@@ -109,7 +109,18 @@ struct ps_problem {
     double *pw0 = nullptr, *pw1 = nullptr, *SZ = nullptr, *Ac = nullptr, *tvec = nullptr, *chol_scratch = nullptr;
     // coarse basis P_iq = w(i,q) B_i: B_i = L_i^T Ad(T_i) (coarse_basis 1, rigid-motion aware) or I (0)
     int coarse_basis = 1;
-    double *Bmat = nullptr, *bgv = nullptr, *SB = nullptr, *BSZ = nullptr;
+    double *Bmat = nullptr, *bgv = nullptr, *SB = nullptr, *BSZ = nullptr;   // Bmat: the basis the CURRENT system was built with
+    // lagged three-launch setup (k_rows_setup): basis blocks and X = P L_c^-T double-buffered with the coarse factor
+    double *Bmat2[2] = {}, *X2[2] = {}, *Mpart = nullptr;
+    bool lagx_ok = false;           // the problem's shape allows it (folded, not split, nc <= 96, rows <= PS_RS_MAXROW blocks)
+    int lagx = 1;                   // option "coarse_lag_x"
+    bool side_todo = false;         // the next X (from SB / the basis in buffer side_buf) is still to be formed on the side stream
+    int side_buf = 0;
+    bool side_ready = false;        // the host has synchronised with the solver stream since the side stream's inputs were enqueued
+    double host_wait_ns = 0.0, host_call_ns = 0.0;   // PS_HOST_TIMING
+    long host_waits = 0, host_calls = 0;
+    size_t rows_lds = 0;
+    bool rows_attr_set = false, rows_lci_lds = false;
     int32_t *ent_ptr = nullptr, *ent_q = nullptr, *ent_lo = nullptr, *ent_hi = nullptr;   // explicit PCG: non-empty (row, node) runs
     int32_t *seg_ptr = nullptr, *seg_ent = nullptr, *seg_row = nullptr;                     // ... grouped by (node, node') for A_c
     int max_row_ents = 0;

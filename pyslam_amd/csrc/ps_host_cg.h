@@ -44,6 +44,7 @@ void drain_timers(ps_problem* h) {      // call after a stream synchronisation
 int sync(ps_problem* h) {
     HIP_OK(hipStreamSynchronize(h->stream));
     drain_timers(h);
+    if (h->side_todo) h->side_ready = true;     // whatever produced the side stream's inputs has completed
     return 0;
 }
 
@@ -52,8 +53,13 @@ int sync(ps_problem* h) {
 // when stage timers need their events or the word does not show up in ~1 s.
 int wait_published(ps_problem* h) {
     volatile long long* w = h->h_seq;
+    struct WaitClock {                  // PS_HOST_TIMING: how long the host waits here (= how far ahead of the GPU its enqueueing ran)
+        ps_problem* h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~WaitClock() { h->host_wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); ++h->host_waits; }
+    } wc{h};
     for (long spins = 0; spins < 400000000L; ++spins) {
         if (*w == h->seq) {
+            if (h->side_todo) h->side_ready = true;
             if (h->pending.empty()) return 0;
             // stage timers: everything up to k_reduce3 has completed; an event recorded behind it may
             // need a moment more
@@ -301,8 +307,20 @@ int build_coarse(ps_problem* h) {
         h->upload(&h->run_hi, rhi))) || h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) ||
         h->upload(&h->aug_slot, slot) || h->upload(&h->fine_nnz, fnz)) return -1;
     lap("uploads");
-    if (h->alloc(&h->BSZ, (h->cg_explicit ? eq.size() : (size_t)nr * ncb) * D * D) || h->alloc(&h->Bmat, (size_t)nr * D * D) ||
+    if (h->alloc(&h->BSZ, (h->cg_explicit ? eq.size() : (size_t)nr * ncb) * D * D) || h->alloc(&h->Bmat2[0], (size_t)nr * D * D) ||
         h->alloc(&h->bgv, (size_t)nr * D) || h->alloc(&h->SB, (size_t)aci.size() * D * D)) return -1;
+    h->Bmat = h->Bmat2[0];
+    // lagged three-launch setup: folded single-launch CG only, LDS-resident coarse factor, rows that fit the LDS layout
+    h->lagx_ok = !h->cg_explicit && !split && h->nc <= 96 && maxlen <= PS_RS_MAXROW;
+    h->side_todo = false; h->rows_attr_set = false;
+    if (h->lagx_ok) {
+        if (h->alloc(&h->Bmat2[1], (size_t)nr * D * D) || h->alloc(&h->X2[0], (size_t)nr * D * h->nc) ||
+            h->alloc(&h->X2[1], (size_t)nr * D * h->nc) || h->alloc(&h->Mpart, (size_t)nr * h->nc * (h->nc + 1))) return -1;
+        h->rows_lds = ((size_t)4 * maxlen * D * D + (size_t)D * (3 * h->nc + 1) + D * D + 3 * PS_RS_MAXROW) * sizeof(double)
+                      + (PS_RS_MAXROW + 3 * 64) * sizeof(int32_t);
+        h->rows_lci_lds = h->rows_lds + (size_t)h->nc * h->nc * sizeof(double) <= 160 * 1024;   // L~^-T beside it, when it fits
+        if (h->rows_lci_lds) h->rows_lds += (size_t)h->nc * h->nc * sizeof(double);
+    }
     if ((!h->cg_explicit && h->alloc(&h->SZ, (size_t)nr * ncb * D * D)) || h->alloc(&h->Ac, (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci2[0], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[0], (size_t)h->nc * h->nc) ||
         h->alloc(&h->Lci2[1], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[1], (size_t)h->nc * h->nc) ||
@@ -399,8 +417,39 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
         h->cg_launched = 0;
         return 0;
     }
+    if (h->side_pending) {                  // the side stream still reads SB / the basis and writes its factor buffer
+        HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0));
+        h->side_pending = false;
+    }
+    if (G && h->lagx_ok && h->lagx && allow_lag && h->coarse_lag && h->lci_next >= 0) {
+        // ---- three launches: everything coarse (basis, factor, X = P L_c^-T) is the previous iteration's
+        const int ncb = h->ncb, nc = h->nc;
+        const int use = h->lci_next, nb = use ^ 1;
+        h->lci_cur = use;
+        h->Bmat = h->Bmat2[use];
+        hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 4)), dim3(256), 0, h->stream, nr, h->diag_slot,
+                           h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
+                           h->poses, h->pose_of_rid, h->coarse_basis, h->Bmat2[nb], h->bgv);
+        if (!h->rows_attr_set) {
+            HIP_OK(hipFuncSetAttribute((const void*)k_rows_setup<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rows_lds));
+            h->rows_attr_set = true;
+        }
+        hipLaunchKernelGGL(k_rows_setup<D>, dim3(nr), dim3(PS_RS_THREADS), h->rows_lds, h->stream, nr, ncb, h->row_ptr, h->col_idx,
+                           h->aug_slot, h->S, h->Linv, h->Bmat2[use], h->Bmat2[nb], h->arow_ptr, h->fine_nnz,
+                           h->run_lo, h->run_hi, h->pnode, h->pw0, h->pw1, h->LciT2[use], h->X2[use], h->cg_r[0],
+                           h->Saug, h->SB, h->Mpart, h->rows_lci_lds ? 1 : 0, getenv("PS_RS_ABLATE") ? atoi(getenv("PS_RS_ABLATE")) : 0);
+        hipLaunchKernelGGL(k_coarse_mreduce<D>, dim3(cdiv((long)nc * (nc + 1) * 8, 256)), dim3(256), 0, h->stream, nr, ncb,
+                           h->shi, h->Mpart, h->pnode, h->arow_ptr, h->Saug, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p,
+                           h->cg_xh, h->lag_status, h->status);
+        h->mc_active = false;
+        h->side_todo = true; h->side_ready = false; h->side_buf = nb;
+        h->cg_launched = 0;
+        return 0;
+    }
+    h->side_todo = false;                                   // the exact path below recomputes everything coarse
+    if (G) h->Bmat = h->Bmat2[h->lagx_ok ? h->lci_cur : 0];
     // block-Jacobi factors + the start vectors of the scaled system (r = Linv g, w = s = p = x = 0)
-    hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
+    hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 4)), dim3(256), 0, h->stream, nr, h->diag_slot,
                        h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
                        h->poses, h->pose_of_rid, h->coarse_basis, G ? h->Bmat : (double*)nullptr, h->bgv);
     hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
@@ -423,7 +472,8 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
         auto launch_chol = [&](hipStream_t st, int buf, int32_t* stat) -> int { return coarse_factor<D>(h, st, buf, stat); };
         // (long sparse chains in split mode: hundreds of CG iterations dwarf the factorisation, and a stale factor
         // costs iterations while the trajectory still moves -- C2: 1 320 -> 1 800 in the second GN step -- so no lag there)
-        const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && (!h->cg_split || (long)h->nnzb > 24L * nr);
+        const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && (!h->cg_split || (long)h->nnzb > 24L * nr) &&
+                         !(h->lagx_ok && h->lagx);          // (such systems take the three-launch path above instead)
         if (lag && h->cg_split && !h->Mc && h->alloc(&h->Mc, (size_t)nc * nc)) return -1;
         h->mc_active = lag && h->cg_split;
         const int rpw = nc >= 192 ? 4 : 1;                 // fine block rows per border workgroup
@@ -445,6 +495,9 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
         } else {
             const int buf = h->lci_cur;
             if (launch_chol(h->stream, buf, h->status)) return -1;
+            if (h->lagx_ok)                                 // X = P L_c^-T for a lagged setup of the next iteration
+                hipLaunchKernelGGL(k_coarse_xbuild<D>, dim3(cdiv((long)nr * D * nc, 256)), dim3(256), 0, h->stream, nr, ncb,
+                                   h->pnode, h->pw0, h->pw1, h->Bmat, h->Lci2[buf], h->X2[buf]);
             const CoarseRhsArgs ra{h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->LciT2[buf], h->tvec, h->cg_r[0], h->cg_w[0],
                                    h->cg_s[0], h->cg_p, h->cg_xh, h->cg_split ? 0 : 1, nullptr, h->status, h->bgv, nullptr};
             hipLaunchKernelGGL(k_coarse_border<D>, dim3(cdiv(nr, rpw) + 1), dim3(256), border_lds, h->stream,
@@ -455,6 +508,33 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
     }
     h->cg_launched = 0;
     return 0;
+}
+
+// Three-launch setup: form the NEXT X = P L_c^-T on the side stream -- row sums with the basis of the last set-up (its
+// S^_ij B_j are in SB), A_c, factorisation, k_coarse_xbuild.  Called at the start of a whole-iteration call, so the
+// work runs beside the linearisation kernels (enqueued right behind them: the GPU is idle when a call starts, nothing
+// may delay its first kernels); its inputs were written by the previous call, and the host has synchronised with the
+// solver stream since (side_ready), hence no event is needed to order the side work behind them.
+template <int D>
+int cg_side_kick(ps_problem* h) {
+    if (!h->side_todo || !h->side_ready) return 0;     // (not ready: no host synchronisation since the producer was enqueued)
+    h->side_todo = false;
+    const int nr = h->nr, ncb = h->ncb, nc = h->nc, nb = h->side_buf;
+    hipLaunchKernelGGL(k_coarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(ncb + 1) * D * D * sizeof(double), h->side,
+                       nr, ncb, h->run_lo, h->run_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->SZ, h->Bmat2[nb], h->BSZ);
+    hipLaunchKernelGGL(k_coarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->side,
+                       nr, ncb, h->slo, h->shi, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
+    if (coarse_factor<D>(h, h->side, nb, h->lag_status)) return -1;
+    hipLaunchKernelGGL(k_coarse_xbuild<D>, dim3(cdiv((long)nr * D * nc, 256)), dim3(256), 0, h->side, nr, ncb,
+                       h->pnode, h->pw0, h->pw1, h->Bmat2[nb], h->Lci2[nb], h->X2[nb]);
+    HIP_OK(hipEventRecord(h->ev_chol, h->side));
+    h->lci_next = nb; h->side_pending = true;
+    return 0;
+}
+
+int side_kick(ps_problem* h) {
+    if (!h->side_todo) return 0;
+    return h->D == 6 ? cg_side_kick<6>(h) : cg_side_kick<3>(h);
 }
 
 // enqueue `count` more CG launches (launch n runs iteration k = n - 1; converged launches exit at once)
@@ -625,7 +705,7 @@ int linearize(ps_problem* h, double lambda) {
         StageTimer t(h, PS_ST_EDGES);
         if (h->D == 6) launch_factor_pass<6>(h, lambda); else launch_factor_pass<3>(h, lambda);
     }
-    return 0;
+    return side_kick(h);                        // next coarse operator: side stream, beside the kernels above
 }
 
 // cost partials into cost_partials[0..n); returns n.  The caller reduces them.

@@ -8,7 +8,7 @@ template <int D>
 int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     const int nr = h->nr, ncb = h->ncb, nc = h->nc;
     if (max_iters + 2 > h->hist_cap) return fail("pcg max_iters exceeds the history buffer (4096)");
-    hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 256)), dim3(256), 0, h->stream, nr, h->diag_slot,
+    hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 4)), dim3(256), 0, h->stream, nr, h->diag_slot,
                        h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
                        h->poses, h->pose_of_rid, h->coarse_basis, h->Bmat, h->bgv);
     hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,

@@ -718,3 +718,230 @@ __global__ __launch_bounds__(256) void k_coarse_recover(
     }
     x[t] = v;
 }
+
+// ---------------------------------------------------------------------------
+// Lagged two-level setup in THREE launches (whole-iteration calls from the second Gauss-Newton iteration on).
+// Any V = [I, X] gives a consistent augmented system V^T S^ V = [[S^, K], [K^T, M]], K = S^ X, M = X^T K (Griebel);
+// the exact set-up takes X = P L_c^-T from THIS iteration's coarse matrix (five dependent launches + a 51 us serial
+// factorisation).  Here X~ = P~ L~^-T comes ENTIRELY from the previous iteration -- basis blocks B~_i = L~_i^T Ad(T~_i)
+// and coarse factor L~ -- so nothing coarse sits between the block-Jacobi factors and the CG:
+//   k_block_jacobi_factor   L_i^-1, g^, and the CURRENT basis B_i (for the next iteration's X)
+//   k_rows_setup            one workgroup per fine row: S^_ij = L_i^-1 S_ij L_j^-T  -> matrix;  SZ~_i = sum_j S^_ij P~_j;
+//                           K_i = SZ~_i L~^-T -> both borders;  this row's part of M and of the coarse right-hand side,
+//                           X~_i^T [K_i | g^_i];  and S^_ij B_j with the current basis for the side stream
+//   k_coarse_mreduce        M = sum_i X~_i^T K_i (fixed order), coarse right-hand side, coarse CG vectors
+// The next X~ (row sums with the current basis, A_c, its factorisation, k_coarse_xbuild) is formed on the low-priority
+// side stream at the start of the NEXT call, beside the linearisation kernels.
+// ---------------------------------------------------------------------------
+#define PS_RS_THREADS 1024
+#define PS_RS_MAXROW 96                 // fine blocks per row the LDS layout holds (4 x 96 x 288 B + strips < 160 KB)
+
+template <int D>
+__global__ __launch_bounds__(PS_RS_THREADS) void k_rows_setup(
+    int nr, int ncb, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+    const int32_t* __restrict__ aug_slot, const double* __restrict__ S, const double* __restrict__ Linv,
+    const double* __restrict__ Blag, const double* __restrict__ Bcur,
+    const int32_t* __restrict__ arow_ptr, const int32_t* __restrict__ fine_nnz,
+    const int32_t* __restrict__ run_lo, const int32_t* __restrict__ run_hi,
+    const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ LciT /* lagged L~^-1, transposed */, const double* __restrict__ X /* lagged X~: nr x D x nc */,
+    const double* __restrict__ ghat /* g^ (nr x D) */,
+    double* __restrict__ Saug, double* __restrict__ SB, double* __restrict__ Mpart /* nr x nc x (nc + 1) */,
+    int lci_in_lds /* the LDS allocation has room for L~^-T (nc x nc) */, int ablate)
+{
+    constexpr int DD = D * D;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int i = blockIdx.x, t = threadIdx.x, NT = blockDim.x;
+    const int nc = ncb * D, nf = row_ptr[i + 1] - row_ptr[i], rp = row_ptr[i], n36 = nf * DD;
+    double* sS = lds;                       // nf x DD: S_ij, then L_i^-1 S_ij, then S^_ij
+    double* sLj = sS + n36;                 // nf x DD: L_j^-1
+    double* sBl = sLj + n36;                // nf x DD: lagged basis B~_j, then S^_ij B~_j
+    double* sBc = sBl + n36;                // nf x DD: current basis B_j
+    double* sT = sBc + n36;                 // D x nc: SZ~_i
+    double* sK = sT + D * nc;               // D x (nc + 1): K_i | g^_i
+    double* sX = sK + D * (nc + 1);         // D x nc: X~_i
+    double* sLi = sX + D * nc;              // DD: L_i^-1
+    double* sW = sLi + DD;                  // nf x 2: hat weights of column j; then nf: its left node (as double)
+    double* sL = sW + 3 * PS_RS_MAXROW;     // nc x nc: L~^-T (when it fits)
+    int32_t* sI = reinterpret_cast<int32_t*>(sL + (lci_in_lds ? nc * nc : 0));   // index words: one round trip with the data
+    int32_t* sSlot = sI;                    // nf: slot of block k in the augmented matrix
+    int32_t* sRun = sSlot + PS_RS_MAXROW;   // 2 ncb: run_lo / run_hi of this row, relative to its first block
+    int32_t* sCrow = sRun + 2 * 64;         // ncb: first block of coarse row q
+    // ---- every input of the row in one memory round trip (the gathers through col_idx: two)
+    const int a_rp = arow_ptr[i];
+    for (int idx = t; idx < n36; idx += NT) {
+        const int k = idx / DD, e = idx - k * DD, b = rp + k, j = col_idx[b];
+        sS[idx] = S[(size_t)b * DD + e];
+        sLj[idx] = Linv[(size_t)j * DD + e];
+        sBl[idx] = Blag[(size_t)j * DD + e];
+        sBc[idx] = Bcur[(size_t)j * DD + e];
+    }
+    for (int k = t; k < nf; k += NT) {
+        const int j = col_idx[rp + k];
+        sW[2 * k] = pw0[j]; sW[2 * k + 1] = pw1[j]; sW[2 * PS_RS_MAXROW + k] = (double)pnode[j];
+        sSlot[k] = aug_slot[rp + k];
+    }
+    for (int q = t; q < ncb; q += NT) {
+        sRun[q] = run_lo[i * ncb + q] - a_rp; sRun[64 + q] = run_hi[i * ncb + q] - a_rp;
+        sCrow[q] = arow_ptr[nr + q];
+    }
+    for (int idx = t; idx < D * nc; idx += NT) sX[idx] = X[(size_t)i * D * nc + idx];
+    if (lci_in_lds && !(ablate & 1)) for (int idx = t; idx < nc * nc; idx += NT) sL[idx] = LciT[idx];
+    if (t < DD) sLi[t] = Linv[(size_t)i * DD + t];
+    if (t < D) sK[t * (nc + 1) + nc] = ghat[(size_t)i * D + t];
+    const int row_slot = a_rp + fine_nnz[i];                        // first coarse column block of row i
+    const int a0 = pnode[i] * D;
+    __syncthreads();
+    // ---- per block, by ONE wave (lane = entry (r, c); wave barriers only): S^_ij = L_i^-1 S_ij L_j^-T -> matrix;
+    // S^_ij B~_j (lagged basis: this iteration's borders); S^_ij B_j (current basis: the side stream's input)
+    {
+        // (stage by stage over ALL of the wave's blocks, so that the LDS latencies of independent blocks overlap)
+        constexpr int NB = (PS_RS_MAXROW + PS_RS_THREADS / 64 - 1) / (PS_RS_THREADS / 64);
+        const int wv = t >> 6, lane = t & 63, nwv = NT >> 6;
+        const bool act = lane < DD && !(ablate & 2);
+        const int r = act ? lane / D : 0, c = act ? lane - (lane / D) * D : 0;
+        double v[NB], v2[NB];
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int k = wv + m * nwv;
+            v[m] = 0.0;
+            if (act && k < nf) {
+#pragma unroll
+                for (int a = 0; a < D; ++a) v[m] += sLi[r * D + a] * sS[k * DD + a * D + c];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < NB; ++m) { const int k = wv + m * nwv; if (act && k < nf) sS[k * DD + lane] = v[m]; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int k = wv + m * nwv;
+            v[m] = 0.0;
+            if (act && k < nf) {
+#pragma unroll
+                for (int a = 0; a < D; ++a) v[m] += sS[k * DD + r * D + a] * sLj[k * DD + c * D + a];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int k = wv + m * nwv;
+            if (act && k < nf) { sS[k * DD + lane] = v[m]; Saug[(size_t)sSlot[k] * DD + lane] = v[m]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int k = wv + m * nwv;
+            v[m] = v2[m] = 0.0;
+            if (act && k < nf) {
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double sv = sS[k * DD + r * D + a];
+                    v[m] += sv * sBl[k * DD + a * D + c];
+                    v2[m] += sv * sBc[k * DD + a * D + c];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+            const int k = wv + m * nwv;
+            if (act && k < nf) { sBl[k * DD + lane] = v[m]; SB[(size_t)sSlot[k] * DD + lane] = v2[m]; }
+        }
+    }
+    __syncthreads();
+    // ---- SZ~_i[q] = sum over the run of row i's blocks whose column lies in supp(q) of w(j, q) S^_ij B~_j
+    for (int idx = t; idx < ncb * DD; idx += NT) {
+        const int q = idx / DD, e = idx - q * DD, r = e / D, c = e - r * D;
+        const int k0 = sRun[q], k1 = sRun[64 + q];
+        double acc = 0.0;
+        for (int k = k0; k < k1; ++k)
+            acc += sBl[k * DD + e] * (((int)sW[2 * PS_RS_MAXROW + k] == q) ? sW[2 * k] : sW[2 * k + 1]);
+        sT[r * nc + q * D + c] = acc;
+    }
+    __syncthreads();
+    // ---- K_i = SZ~_i L~^-T, to both borders of the augmented matrix
+    const double* Lt = lci_in_lds ? sL : LciT;
+    for (int idx = t; idx < 2 * D * nc && !(ablate & 4); idx += NT) {      // two lanes per entry: even / odd terms of the sum
+        const int o = idx >> 1, par = idx & 1;
+        const int r = o / nc, c = o - r * nc, q = c / D, cc = c - q * D;
+        double v = 0.0;
+#pragma unroll 8
+        for (int k = par; k <= c; k += 2) v += sT[r * nc + k] * Lt[(size_t)k * nc + c];     // = L~^-1[c][k]
+        v += __shfl_xor(v, 1, 64);
+        if (par) continue;
+        sK[r * (nc + 1) + c] = v;
+        Saug[(size_t)(row_slot + q) * DD + r * D + cc] = v;                            // K   (row i, col nr+q)
+        Saug[(size_t)(sCrow[q] + i) * DD + cc * D + r] = v;                            // K^T (row nr+q, col i)
+    }
+    __syncthreads();
+    // ---- this row's part of M = X~^T K and of the coarse right-hand side X~^T g^ (rows below the row's first node are zero)
+    const int ncol = nc + 1;
+    for (int idx = t; idx < (nc - a0) * ncol && !(ablate & 8); idx += NT) {
+        const int a = a0 + idx / ncol, c = idx % ncol;
+        double v = 0.0;
+#pragma unroll
+        for (int r = 0; r < D; ++r) v += sX[r * nc + a] * sK[r * ncol + c];
+        Mpart[((size_t)i * nc + a) * ncol + c] = v;
+    }
+}
+
+// M[a][c] = sum_i Mpart[i][a][c] over the rows that reach coarse row a (i < shi[node(a)]), in row order: 8 lanes per
+// output + a 3-step butterfly (fixed order).  Column nc is the coarse right-hand side; the coarse CG vectors are cleared.
+template <int D>
+__global__ __launch_bounds__(256) void k_coarse_mreduce(
+    int nr, int ncb, const int32_t* __restrict__ shi, const double* __restrict__ Mpart,
+    const int32_t* __restrict__ pnode, const int32_t* __restrict__ arow_ptr, double* __restrict__ Saug,
+    double* __restrict__ r, double* __restrict__ w, double* __restrict__ s, double* __restrict__ p, double* __restrict__ x,
+    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status)
+{
+    constexpr int DD = D * D;
+    const int nc = ncb * D, ncol = nc + 1;
+    const int o = (blockIdx.x * blockDim.x + threadIdx.x) / 8, sub = threadIdx.x & 7;
+    // a lagged factor whose (side-stream) factorisation failed poisons this solve: report it
+    if (blockIdx.x == 0 && threadIdx.x == 0 && lag_status && lag_status[ST_DIAG_FAIL]) atomicAdd(&status[ST_DIAG_FAIL], 1);
+    const bool live = o < nc * ncol;
+    const int a = live ? o / ncol : 0, c = live ? o % ncol : 0;
+    double v = 0.0;
+    if (live) {
+        const int iend = shi[a / D];
+#pragma unroll 4
+        for (int i = sub; i < iend; i += 8) v += Mpart[((size_t)i * nc + a) * ncol + c];
+    }
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    if (!live || sub != 0) return;
+    if (c < nc) {
+        const int q = a / D, rr = a % D, q2 = c / D, cc = c % D;
+        Saug[(size_t)(arow_ptr[nr + q] + nr + q2) * DD + rr * D + cc] = v;
+    } else {
+        const size_t oo = (size_t)nr * D + a;
+        r[oo] = v; w[oo] = 0.0; s[oo] = 0.0; p[oo] = 0.0; x[oo] = 0.0;
+    }
+}
+
+// X_i = P_i L_c^-T (D x nc per fine row): X[i][r][a] = sum over the row's two nodes q of w(i,q) sum_m B_i[r][m] L_c^-1[a][qD+m]
+template <int D>
+__global__ __launch_bounds__(256) void k_coarse_xbuild(
+    int nr, int ncb, const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ Bmat, const double* __restrict__ Lci, double* __restrict__ X)
+{
+    constexpr int DD = D * D;
+    const int nc = ncb * D;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)nr * D * nc) return;
+    const int i = (int)(t / (D * nc)), rem = (int)(t % (D * nc)), r = rem / nc, a = rem % nc;
+    const int q0 = pnode[i];
+    double v = 0.0;
+#pragma unroll
+    for (int dq = 0; dq < 2; ++dq) {
+        const int q = q0 + dq;
+        const double wq = dq == 0 ? pw0[i] : pw1[i];
+        if (q >= ncb || wq == 0.0 || q * D > a) continue;          // L_c^-1 is lower triangular
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) acc += Bmat[(size_t)i * DD + r * D + m] * Lci[(size_t)a * nc + q * D + m];
+        v += wq * acc;
+    }
+    X[t] = v;
+}
