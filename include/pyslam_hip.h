@@ -82,6 +82,9 @@ typedef struct ps_problem_info {
     int64_t num_pairs;           /* off-diagonal Schur contributions (upper triangle)         */
     int64_t reduce_count;        /* doubles in the all-reduce payload [upper(S) | g | cost | flag] */
     int64_t device_bytes;        /* HBM held by the handle                                    */
+    int64_t cg_restarts;         /* restarts of the pipelined CG so far: its recurrences broke down (rounding drift out of
+                                    range(V^T) on the singular folded system) and the solve went on
+                                    from the true residual                                    */
 } ps_problem_info;
 
 enum { PS_NUM_STAGES = 10 };
@@ -206,6 +209,8 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /
      "direct_max_unknowns"[90] reduced systems up to this size are solved by a dense Cholesky instead of CG (0 = never)
      "fused_motion_only"  [1] problems without variable landmarks / pose factors: one launch per iteration
      "cg_explicit"        [1] long sparse chains: apply the two-level preconditioner (k_xcg_*) instead of folding it in
+     "coarse_lag_x"       [1] ... and with the previous iteration's basis and X = P L_c^-T too: three set-up launches (k_rows_setup)
+     "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual
      "cg_lds", "profile_every", "big_chol", "cg_margin", "pcg_chunk", "cg_split_min_rows", "cg_explicit_min_rows": implementation switches (see ps_set_option in csrc/ps_abi_solver.h)
      "cg_ablate", "schur_ablate", "lm_ablate": timing experiments only (results are wrong under ablation) */
 int ps_set_option(ps_problem* h, const char* name, double value);

@@ -8,6 +8,7 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
     info->reduced_nnzb = h->nnzb; info->num_pairs = h->npairs;
     info->reduce_count = ((long)h->nnzb + h->nr) / 2 * h->D * h->D + (long)h->nr * h->D + 3;
     info->device_bytes = (int64_t)h->dev_bytes;
+    info->cg_restarts = h->cg_fallbacks;
     return 0;
 }
 
@@ -438,6 +439,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "schur_ablate") h->schur_ablate = (int)value;
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
+    else if (n == "cg_force_restart") h->cg_force_restart = value != 0.0;
     else if (n == "coarse_lag_x") { h->lagx = value != 0.0; h->lci_next = -1; h->side_todo = false; }
     else if (n == "cg_lds") h->cg_lds = value != 0.0;
     else if (n == "cg_explicit") { h->explicit_ok = value != 0.0; h->coarse_built = false; }

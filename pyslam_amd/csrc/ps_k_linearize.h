@@ -456,9 +456,15 @@ __global__ __launch_bounds__(256) void k_schur_combine(
 }
 
 // ---------------------------------------------------------------------------
-// pose-pose / prior factors: one wave per factor, Jacobians staged in LDS.
-// scratch row per factor: [H11 | H12 | H22 | g1 | g2]  (3 D^2 + 2 D doubles)
+// pose-pose / prior factors.  scratch row per factor: [H11 | H12 | H22 | g1 | g2]  (3 D^2 + 2 D doubles)
+// A workgroup takes 64 factors in two phases:
+//   1. one THREAD per factor: E = T_2 T_1^-1 T_obs^-1, xi = log(E) (acos, sin, tan, a square root and the inverse
+//      left Jacobian: ~800 instructions), r = S xi, the IRLS scales s_k = sqrt(w(r_k)); s, s r and T_2 T_1^-1 go to LDS.
+//      (Round 1 ran this part in all 64 lanes of one wave per factor: 64 copies of the same logarithm.)
+//   2. one WAVE per factor, lane (r, c): the scaled Jacobians J1 = -diag(s) S Ad(T_2 T_1^-1), J2 = diag(s) S in LDS,
+//      then the three D x D products and the two gradient pieces.
 // ---------------------------------------------------------------------------
+#define PS_FP_FACTORS 64
 template <int D>
 __global__ __launch_bounds__(256) void k_factor_pass(
     int nf, const int32_t* __restrict__ f_i, const int32_t* __restrict__ f_j,
@@ -467,18 +473,16 @@ __global__ __launch_bounds__(256) void k_factor_pass(
     double* __restrict__ scratch)
 {
     typedef PoseOps<D> G;
-    constexpr int DD = D * D, ROW = 3 * DD + 2 * D;
-    __shared__ double sJ1[4][36], sJ2[4][36], sr[4][6];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int f = blockIdx.x * 4 + w;
-    const bool live = f < nf;
-    const bool act = live && lane < DD;
-    const int r = lane / D, c = lane % D;
-    bool binary = false;
-    if (live) {
-        const int i = f_i[f], j = f_j[f];
-        binary = i >= 0;
-        const FactorGroup& grp = groups[f_grp[f]];
+    constexpr int DD = D * D, ROW = 3 * DD + 2 * D, FPB = PS_FP_FACTORS;
+    __shared__ double sS[FPB][D], sSr[FPB][D], sT21[FPB][G::W];
+    __shared__ int32_t sBin[FPB], sGrp[FPB];
+    __shared__ double sJ1[4][36], sJ2[4][36];
+    const int f0 = blockIdx.x * FPB;
+    if (threadIdx.x < FPB && f0 + (int)threadIdx.x < nf) {
+        const int fl = threadIdx.x, f = f0 + fl;
+        const int i = f_i[f], j = f_j[f], gi = f_grp[f];
+        const bool binary = i >= 0;
+        const FactorGroup& grp = groups[gi];
         const typename G::T T2 = G::load(poses + G::W * (size_t)j);
         const typename G::T To = G::load(f_Tinv + G::W * (size_t)f);
         typename G::T E, T21 = T2;
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(256) void k_factor_pass(
         } else {
             E = G::mul(T2, To);
         }
-        double xi[D], s[D];
+        double xi[D];
         G::log(E, xi);
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -497,39 +501,53 @@ __global__ __launch_bounds__(256) void k_factor_pass(
             bool present = false;               // an all-zero stiffness row is an absent residual row
 #pragma unroll                                  // (rotation-only edges, lowering.py): no weight, no 0 * inf
             for (int m = 0; m < D; ++m) { rk += grp.S[k * D + m] * xi[m]; present = present || grp.S[k * D + m] != 0.0; }
-            s[k] = present ? sqrt(ps_loss_weight(grp.loss_id, grp.loss_k, rk)) : 0.0;
-            if (lane == 0) sr[w][k] = s[k] * rk;
+            const double sk = present ? sqrt(ps_loss_weight(grp.loss_id, grp.loss_k, rk)) : 0.0;
+            sS[fl][k] = sk;
+            sSr[fl][k] = sk * rk;
         }
+        G::store(sT21[fl], T21);
+        sBin[fl] = binary ? 1 : 0;
+        sGrp[fl] = gi;
+    }
+    __syncthreads();
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool act = lane < DD;
+    const int r = act ? lane / D : 0, c = act ? lane - (lane / D) * D : 0;
+    for (int q = 0; q < FPB / 4; ++q) {
+        const int fl = w * (FPB / 4) + q, f = f0 + fl;
+        if (f >= nf) break;                                   // (uniform per wave)
+        const FactorGroup& grp = groups[sGrp[fl]];
         if (act) {
             // row r of J~ (scaled by s_r): J1 = -S Ad(T_2 T_1^-1), J2 = S
-            double sk = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) if (k == r) sk = s[k];
+            const double sk = sS[fl][r];
             double j1 = 0.0;
-            if (binary) {
+            if (sBin[fl]) {
+                const typename G::T T21 = G::load(sT21[fl]);
 #pragma unroll
                 for (int m = 0; m < D; ++m) j1 -= grp.S[r * D + m] * G::adj(T21, m, c);
             }
             sJ1[w][lane] = sk * j1;
             sJ2[w][lane] = sk * grp.S[lane];
         }
-    }
-    __syncthreads();
-    if (!act) return;
-    double h11 = 0.0, h12 = 0.0, h22 = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+            double h11 = 0.0, h12 = 0.0, h22 = 0.0;
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        h11 += sJ1[w][k * D + r] * sJ1[w][k * D + c];
-        h12 += sJ1[w][k * D + r] * sJ2[w][k * D + c];
-        h22 += sJ2[w][k * D + r] * sJ2[w][k * D + c];
-    }
-    double* out = scratch + (size_t)f * ROW;
-    out[lane] = h11; out[DD + lane] = h12; out[2 * DD + lane] = h22;
-    if (c == 0) {
-        double g1 = 0.0, g2 = 0.0;
+            for (int k = 0; k < D; ++k) {
+                h11 += sJ1[w][k * D + r] * sJ1[w][k * D + c];
+                h12 += sJ1[w][k * D + r] * sJ2[w][k * D + c];
+                h22 += sJ2[w][k * D + r] * sJ2[w][k * D + c];
+            }
+            double* out = scratch + (size_t)f * ROW;
+            out[lane] = h11; out[DD + lane] = h12; out[2 * DD + lane] = h22;
+            if (c == 0) {
+                double g1 = 0.0, g2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < D; ++k) { g1 -= sJ1[w][k * D + r] * sr[w][k]; g2 -= sJ2[w][k * D + r] * sr[w][k]; }
-        out[3 * DD + r] = g1; out[3 * DD + D + r] = g2;
+                for (int k = 0; k < D; ++k) { g1 -= sJ1[w][k * D + r] * sSr[fl][k]; g2 -= sJ2[w][k * D + r] * sSr[fl][k]; }
+                out[3 * DD + r] = g1; out[3 * DD + D + r] = g2;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

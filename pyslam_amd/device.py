@@ -213,6 +213,12 @@ class DeviceProblem:
         nat.check(self._lib.ps_debug_reproj_blocks(self._h, nat.f64p(r), nat.f64p(jp), nat.f64p(jl)))
         return r, jp, jl
 
+    def cg_restarts(self):
+        """Restarts of the pipelined CG so far (ps_problem_info.cg_restarts)."""
+        info = nat.ProblemInfo()
+        nat.check(self._lib.ps_get_info(self._h, C.byref(info)))
+        return int(info.cg_restarts)
+
     def set_option(self, name, value):
         nat.check(self._lib.ps_set_option(self._h, name.encode(), float(value)))
 

@@ -99,7 +99,7 @@ def run(n_cases, seed0=0, verbose=True):
         except Exception as e:      # noqa: BLE001
             import traceback
             ok, msg = False, 'EXCEPTION %r after %s; oracle cost history %s' % (e, log, locals().get('ref', {}).get('cost_history') if isinstance(locals().get('ref'), dict) else None)
-        if not ok and 'landmark block' in msg and locals().get('cur') is not None:
+        if not ok and 'landmark block' in msg and locals().get('cur') is not None and not os.environ.get('FUZZ_API_NOSKIP'):
             # a landmark whose 3 x 3 block is singular to rounding (rays nearly parallel after an update): the device
             # refuses it, the reference's LU silently produces a huge step; nothing to compare
             try:
@@ -111,12 +111,34 @@ def run(n_cases, seed0=0, verbose=True):
                     ok, msg = True, 'degenerate landmark in the reference trajectory, skipped'
             except Exception:       # noqa: BLE001
                 pass
-        if not ok and isinstance(locals().get('ref'), dict):
-            # a solve whose reference cost history jumps up and down is chaotic (weak two-view landmarks under a robust
-            # loss): rounding-level differences pick different trajectories, nothing to compare
-            hh = np.asarray(ref['cost_history'])
-            if hh.size > 2 and (np.any(hh[1:] > 1.5 * hh[:-1]) or (np.any(hh[2:] > hh[1:-1]) and 'history rel err' in msg)):
-                ok, msg = True, 'unstable reference solve, skipped: ' + msg[:60]
+        if not ok and 'history rel err' in msg and locals().get('cur') is not None and not os.environ.get('FUZZ_API_NOSKIP'):
+            # Is the reference's OWN result determined by its inputs to the tolerance of the comparison?  Re-run the oracle
+            # with the landmarks (or, without landmarks, the poses) perturbed by 1e-13 relative: undamped Gauss-Newton with
+            # the reference's degenerate line search can amplify a rounding-level difference by 1e3 per iteration around a
+            # minimum it oscillates about (tools/diag_fuzz_api.py, case 701050: 1e-13 -> 1e-11 -> 2e-10 -> 3e-3).  Only if
+            # the oracle's two histories separate by more than the test's own tolerance is the case set aside.
+            try:
+                pert = cur.copy()
+                g2 = np.random.default_rng(1)
+                if pert.num_var_points:
+                    pert.points = pert.points * (1. + 1e-13 * g2.standard_normal(pert.points.shape))
+                else:
+                    pert.poses = pert.poses * (1. + 1e-13 * g2.standard_normal(pert.poses.shape))
+                _, ref2 = orc.solve(pert, opts, points_first=pf)
+                h1, h2 = np.asarray(ref['cost_history']), np.asarray(ref2['cost_history'])
+                n = min(len(h1), len(h2))
+                sens = float(np.max(np.abs(h1[:n] - h2[:n]) / np.abs(h1[:n]))) if len(h1) == len(h2) else np.inf
+                if sens > 1e-6:
+                    ok, msg = True, 'reference not determined by its inputs (1e-13 perturbation -> %.1e in its own history), skipped: %s' % (sens, msg[:60])
+            except Exception:       # noqa: BLE001
+                pass
+        if not ok and os.environ.get('FUZZ_API_DUMP') and locals().get('cur') is not None:
+            # the tables the failing solve started from (diagnosis offline, tools/diag_fuzz_api.py)
+            os.makedirs(os.environ['FUZZ_API_DUMP'], exist_ok=True)
+            np.savez(os.path.join(os.environ['FUZZ_API_DUMP'], 'fuzz_api_case_%d.npz' % case), lp_dof=cur.dof, pf=pf,
+                     device_history=np.asarray(problem._cost_history), opts_keys=np.array(list(opts.keys())),
+                     opts_vals=np.array([float(v) for v in opts.values()]),
+                     **{'lp_' + k: getattr(cur, k) for k in cur.STRUCTURE_FIELDS + ('poses', 'points')})
         bad += not ok
         if verbose and (not ok or case % 20 == 0):
             print('%s case %d %s poses %d obs %d edges %d  %s' % ('ok  ' if ok else 'FAIL', case, kind, lp.num_poses, lp.num_obs, lp.num_edges, msg), flush=True)

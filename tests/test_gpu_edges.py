@@ -270,3 +270,36 @@ def test_c3_through_the_public_api_equals_the_tables_path():
     print('\\nC3 through the public API: build 500k block objects {:.2f} s | lowering walk {:.2f} s | solve() {:.2f} s '
           '(lowering + ps_problem_create + 2 iterations + write-back) | ps_problem_create alone {:.2f} s | 2 iterations '
           'on resident tables {:.1f} ms'.format(t1 - t0, t2 - t1, t3 - t2, t4 - t3, (t5 - t4) * 1e3))
+
+
+def test_forced_restart_of_the_pipelined_cg_reaches_the_same_solution():
+    """The restart path of the fused CG (a breakdown of its recurrences: the residual has drifted out of range(V^T) of
+    the singular folded system, tools/cg_drift.py) driven by the test hook "cg_force_restart": the first pass stops at
+    1e-4, the solver keeps the iterate, forms the true residual g - S x and solves for the correction.  Same step as the
+    uninterrupted solve, for the fine-only, the folded two-level and the covariance-column paths."""
+    lp, _ = synthetic.stereo_ba(num_kf=60, num_lm=5000, obs_per_lm=6, half_window=9, seed=21)
+    for groups in (-1, 0):
+        ref, dev = device(lp), device(lp)
+        for d in (ref, dev):
+            d.set_option('coarse_groups', groups)
+            d.linearize(0.)
+        dev.set_option('cg_force_restart', 1)
+        its_r, rel_r = ref.solve_reduced(1e-13, 2000)
+        its_d, rel_d = dev.solve_reduced(1e-13, 2000)
+        assert ref.cg_restarts() == 0 and dev.cg_restarts() == 1
+        assert rel_d <= 1e-12 and its_d >= its_r                 # two passes cost at least as many iterations
+        ref.backsub(); dev.backsub()
+        a = np.concatenate([x.ravel() for x in ref.get_dx()])
+        b = np.concatenate([x.ravel() for x in dev.get_dx()])
+        assert np.linalg.norm(a - b) <= 1e-10 * np.linalg.norm(a)
+        # the reduced right-hand side is restored after the restart (it is rewritten to hold the true residual)
+        assert np.array_equal(ref.reduced_system()[3], dev.reduced_system()[3])
+    # covariance column through the restart
+    pg, _ = synthetic.pose_graph(num_poses=200, num_loops=300, dof=3, seed=5)
+    ref, dev = device(pg), device(pg)
+    dev.set_option('cg_force_restart', 1)
+    ref.covariance_begin(); dev.covariance_begin()
+    xa = ref.covariance_column(0, 120, 1)[0]
+    xb = dev.covariance_column(0, 120, 1)[0]
+    assert dev.cg_restarts() >= 1
+    assert np.abs(xa - xb).max() <= 1e-9 * np.abs(xa).max()

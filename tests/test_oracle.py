@@ -1,9 +1,10 @@
 """Pins the numpy oracle (oracle/gn_oracle.py) against golden vectors produced
 by the verbatim reference (oracle/gen_golden.py).  CPU only."""
 import numpy as np
+import os
 import pytest
 
-from conftest import load_golden, golden_lp, golden_options, SOLVE_CASES, rel_err
+from conftest import load_golden, REPO, golden_lp, golden_options, SOLVE_CASES, rel_err
 from oracle import gn_oracle as orc
 
 
@@ -88,3 +89,54 @@ def test_losses_tables():
                                      ('tukey', 3.), ('tdist', 5.)]):
         assert np.allclose(orc.loss_rho(lid, k, x), g[name + '_loss'], rtol=1e-14, atol=0, equal_nan=True)
         assert np.allclose(orc.loss_weight(lid, k, x), g[name + '_weight'], rtol=1e-14, atol=0, equal_nan=True)
+
+
+def test_fuzz_api_case_701050_is_not_determined_by_its_inputs():
+    """tests/fuzz_api.py case 701050 (round-1 VERDICT): device and oracle cost histories agree to 1e-11, 3e-10, 7e-4 over
+    three iterations of a solve restarted at a converged state.  Diagnosis, pinned here on the tables the failing solve
+    started from: the ORACLE's own history moves by as much when its landmarks are perturbed by 1e-13 (relative) --
+    undamped Gauss-Newton oscillating about a minimum, normal matrix condition number 2.5e14 -- so the third iterate is
+    not a quantity two implementations can be compared on.  (tools/diag_fuzz_api.py prints the whole analysis.)"""
+    from pyslam_amd.lowering import LoweredProblem
+    g = load_golden('fuzz_api_case_701050')
+    lp = LoweredProblem(dof=int(g['lp_dof']))
+    for k, v in g.items():
+        if k.startswith('lp_') and k != 'lp_dof':
+            setattr(lp, k[3:], np.array(v))
+    lp = lp.finalize()
+    opts = dict(allow_nondecreasing_steps=True, max_nondecreasing_steps=3, linesearch_max_iters=10, max_iters=20,
+                min_cost_decrease=0.99)
+    pf = bool(g['pf'])
+    _, a = orc.solve(lp, opts, points_first=pf)
+    pert = lp.copy()
+    pert.points = pert.points * (1. + 1e-13 * np.random.default_rng(1).standard_normal(pert.points.shape))
+    _, b = orc.solve(pert, opts, points_first=pf)
+    ha, hb, hd = np.asarray(a['cost_history']), np.asarray(b['cost_history']), g['device_history']
+    assert len(ha) == len(hb) == len(hd) == 4
+    dev = np.abs(hd - ha) / ha                       # device vs oracle (recorded on the MI355X)
+    own = np.abs(hb - ha) / ha                       # oracle vs oracle, inputs perturbed by 1e-13
+    assert dev[0] < 1e-15 and dev[1] < 1e-10 and dev[2] < 1e-9
+    assert own[3] > 1e-4 and own[3] > dev[3]          # the reference's own sensitivity exceeds the discrepancy
+    assert own[1] < 1e-9                              # ... and the early iterates ARE comparable (and agree)
+
+
+def test_pipelined_cg_residual_leaves_the_range_of_the_folded_system():
+    """Root cause of the pipelined CG's breakdowns on the folded (singular, consistent) two-level system, emulated in
+    numpy (tools/cg_drift.py): in float64 the recurrence residual drifts out of range(V^T) -- its coarse part stops
+    being X^T times its fine part -- by the time the true residual has dropped ten orders; 80-bit arithmetic keeps the
+    drift four orders smaller, restoring the invariant removes it.  The device answers a breakdown by restarting from
+    the true residual, which IS that projection."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('cg_drift', os.path.join(REPO, 'tools', 'cg_drift.py'))
+    cgd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cgd)
+    lp, H = cgd.build(0, P=120)
+    S, Linv, X = cgd.setup(H, lp.dof, 12)
+    e = np.zeros(H.shape[0]); e[60 * lp.dof] = 1.
+    bf = Linv @ e
+    f64 = cgd.cg_cgear(S, X, bf, np.float64)
+    prj = cgd.cg_cgear(S, X, bf, np.float64, fix='project')
+    f80 = cgd.cg_cgear(S, X, bf, np.longdouble)
+    assert f64[-1][2] > 1e-3 and f64[-1][2] > 100 * f80[-1][2]      # O(1e-2..1) in double, orders less in long double
+    assert prj[-1][2] == 0. and prj[-1][3] < 1e-12                  # projected: invariant exact, converged
+    assert f64[-1][3] < 1e-11                                       # (this column still converges: drift, not yet breakdown)
