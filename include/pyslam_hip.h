@@ -226,6 +226,16 @@ int ps_get_stage_times(ps_problem* h, double* ms /* PS_NUM_STAGES */, int64_t* c
 int ps_dense_normal_solve(const double* J, const double* r, int32_t m, int32_t n,
                           double* dx, double* covariance /* n*n or NULL */);
 
+/* The same path beyond the dense solver's size: J (m x n) and its transpose as CSR in HBM, Jacobi-preconditioned CG
+   on J^T J dx = rhs without forming J^T J; rhs = -J^T r (a Gauss-Newton step; `rhs` NULL) or the caller's `rhs`
+   (a unit vector: one covariance column; `r` may then be NULL).  Replaces scipy's sparse LU (pyslam/problem.py:186)
+   for problems with user-defined blocks / losses / parameters and more than 2048 unknowns.  Stops at a relative
+   preconditioned residual of `tol` or after max_iters iterations (the step is returned either way). */
+int ps_sparse_normal_solve(int32_t m, int32_t n, const int32_t* j_row_ptr, const int32_t* j_col, const double* j_val,
+                           const int32_t* jt_row_ptr, const int32_t* jt_col, const double* jt_val,
+                           const double* r, const double* rhs, double tol, int32_t max_iters,
+                           double* dx, int32_t* iters_out, double* relres_out);
+
 /* Frame-to-frame RANSAC, the step before the motion-only solve in the reference's sparse VO pipeline
    (pyslam/pipelines/sparse.py:148-150).  Stateless; host pointers in, host pointers out.
    ps_ransac_transforms   -- compute_transform_fast (pyslam/pipelines/ransac.py:13-67): `batch` rigid

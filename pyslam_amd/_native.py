@@ -104,6 +104,8 @@ SIGNATURES = {
     'ps_photometric_normal_equations': (C.c_int, [H, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_int64)]),
     'ps_photometric_iteration': (C.c_int, [H, C.c_int32, C.c_int32, c_f64p, c_f64p]),
     'ps_dense_normal_solve': (C.c_int, [c_f64p, c_f64p, C.c_int32, C.c_int32, c_f64p, c_f64p]),
+    'ps_sparse_normal_solve': (C.c_int, [C.c_int32, C.c_int32, c_i32p, c_i32p, c_f64p, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p,
+                                         C.c_double, C.c_int32, c_f64p, c_i32p, c_f64p]),
 }
 
 _lib = None

@@ -197,3 +197,64 @@ int ps_photometric_iteration(ps_photo* h, int32_t split_params, int32_t linesear
     if (cost) *cost = c;
     return 0;
 }
+
+// ---- host-evaluated generic path at scale: CG on J^T J dx = rhs, J sparse in HBM (csrc/ps_sparse.h) -----------------
+int ps_sparse_normal_solve(int32_t m, int32_t n, const int32_t* j_row_ptr, const int32_t* j_col, const double* j_val,
+                           const int32_t* jt_row_ptr, const int32_t* jt_col, const double* jt_val,
+                           const double* r, const double* rhs, double tol, int32_t max_iters,
+                           double* dx, int32_t* iters_out, double* relres_out) {
+    if (!j_row_ptr || !j_col || !j_val || !jt_row_ptr || !jt_col || !jt_val || !dx || m <= 0 || n <= 0 || (!r && !rhs))
+        return fail("bad argument");
+    if (need_device()) return -1;
+    const size_t nnz = (size_t)j_row_ptr[m];
+    if ((size_t)jt_row_ptr[n] != nnz) return fail("J and its transpose have different numbers of non-zeros");
+    DevBuf bJr, bJc, bJv, bTr, bTc, bTv, be, bb, bM, bx, br, bz, bp, bq, by, bpart, bsc;
+    const int nb = std::max(1, std::min(1024, cdiv(n, 256)));
+    if (bJr.get((size_t)(m + 1) * 4) || bJc.get(nnz * 4) || bJv.get(nnz * 8) || bTr.get((size_t)(n + 1) * 4) ||
+        bTc.get(nnz * 4) || bTv.get(nnz * 8) || be.get((size_t)m * 8) || bb.get((size_t)n * 8) || bM.get((size_t)n * 8) ||
+        bx.get((size_t)n * 8) || br.get((size_t)n * 8) || bz.get((size_t)n * 8) || bp.get((size_t)n * 8) ||
+        bq.get((size_t)n * 8) || by.get((size_t)m * 8) || bpart.get((size_t)nb * 8) || bsc.get(SPS_N * 8)) return -1;
+    HIP_OK(hipMemcpy(bJr.p, j_row_ptr, (size_t)(m + 1) * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bJc.p, j_col, nnz * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bJv.p, j_val, nnz * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bTr.p, jt_row_ptr, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bTc.p, jt_col, nnz * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bTv.p, jt_val, nnz * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(bsc.p, 0, SPS_N * 8));
+    hipStream_t st = 0;
+    const int gm = cdiv(m, 256), gn = cdiv(n, 256);
+    if (rhs) HIP_OK(hipMemcpy(bb.p, rhs, (size_t)n * 8, hipMemcpyHostToDevice));
+    else {                                                          // rhs = -J^T r
+        HIP_OK(hipMemcpy(be.p, r, (size_t)m * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_sp_spmv, dim3(gn), dim3(256), 0, st, n, bTr.as<int32_t>(), bTc.as<int32_t>(), bTv.as<double>(),
+                           be.as<double>(), bb.as<double>(), -1.0);
+    }
+    hipLaunchKernelGGL(k_sp_diag, dim3(gn), dim3(256), 0, st, n, bTr.as<int32_t>(), bTv.as<double>(), bM.as<double>());
+    hipLaunchKernelGGL(k_sp_init, dim3(nb), dim3(256), 0, st, n, bb.as<double>(), bM.as<double>(), bx.as<double>(),
+                       br.as<double>(), bz.as<double>(), bp.as<double>(), bpart.as<double>());
+    hipLaunchKernelGGL(k_sp_scalars, dim3(1), dim3(256), 0, st, nb, bpart.as<double>(), bsc.as<double>(), (int)SPS_RZ, tol * tol, 1);
+    double sc[SPS_N] = {};
+    int launched = 0;
+    while (launched < max_iters) {
+        const int chunk = std::min(32, max_iters - launched);
+        for (int k = 0; k < chunk; ++k, ++launched) {
+            hipLaunchKernelGGL(k_sp_dir, dim3(nb), dim3(256), 0, st, n, bz.as<double>(), bp.as<double>(), bsc.as<double>());
+            hipLaunchKernelGGL(k_sp_spmv, dim3(gm), dim3(256), 0, st, m, bJr.as<int32_t>(), bJc.as<int32_t>(), bJv.as<double>(),
+                               bp.as<double>(), by.as<double>(), 1.0);
+            hipLaunchKernelGGL(k_sp_spmv, dim3(gn), dim3(256), 0, st, n, bTr.as<int32_t>(), bTc.as<int32_t>(), bTv.as<double>(),
+                               by.as<double>(), bq.as<double>(), 1.0);
+            hipLaunchKernelGGL(k_sp_dot, dim3(nb), dim3(256), 0, st, n, bp.as<double>(), bq.as<double>(), bpart.as<double>());
+            hipLaunchKernelGGL(k_sp_scalars, dim3(1), dim3(256), 0, st, nb, bpart.as<double>(), bsc.as<double>(), (int)SPS_PQ, tol * tol, 0);
+            hipLaunchKernelGGL(k_sp_update, dim3(nb), dim3(256), 0, st, n, bp.as<double>(), bq.as<double>(), bM.as<double>(),
+                               bx.as<double>(), br.as<double>(), bz.as<double>(), bsc.as<double>(), bpart.as<double>());
+            hipLaunchKernelGGL(k_sp_scalars, dim3(1), dim3(256), 0, st, nb, bpart.as<double>(), bsc.as<double>(), (int)SPS_RZ, tol * tol, 0);
+        }
+        HIP_OK(hipMemcpy(sc, bsc.p, sizeof(sc), hipMemcpyDeviceToHost));
+        if (sc[SPS_DONE] != 0.0) break;
+    }
+    HIP_OK(hipMemcpy(dx, bx.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (iters_out) *iters_out = (int32_t)sc[SPS_ITERS];
+    if (relres_out) *relres_out = sc[SPS_RZ0] > 0.0 ? std::sqrt(sc[SPS_RZ] / sc[SPS_RZ0]) : 0.0;
+    if (sc[SPS_DONE] == 2.0) return fail("sparse normal-equation CG broke down (J^T J is not positive semi-definite to rounding, or a NaN in J)");
+    return 0;
+}

@@ -22,6 +22,7 @@
 #include "ps_kernels.h"
 #include "ps_ransac.h"
 #include "ps_photo.h"
+#include "ps_sparse.h"
 
 namespace {
 

@@ -247,6 +247,27 @@ def dense_normal_solve(J, r, want_covariance=False):
     return (dx, cov) if want_covariance else dx
 
 
+def sparse_normal_solve(J, r=None, rhs=None, tol=1e-12, max_iters=10000):
+    """Host-evaluated generic path beyond the dense solver: (J^T J) dx = -J^T r (or = rhs) by CG on the device with J
+    (scipy CSR) resident in HBM.  -> (dx, iterations, relative preconditioned residual)."""
+    lib = nat.require_gpu()
+    J = J.tocsr()
+    J.sort_indices()
+    Jt = J.T.tocsr()
+    Jt.sort_indices()
+    m, n = J.shape
+    a = [np.ascontiguousarray(x, dtype=t) for x, t in ((J.indptr, np.int32), (J.indices, np.int32), (J.data, np.float64),
+                                                        (Jt.indptr, np.int32), (Jt.indices, np.int32), (Jt.data, np.float64))]
+    rr = None if r is None else np.ascontiguousarray(r, dtype=np.float64).reshape(-1)
+    bb = None if rhs is None else np.ascontiguousarray(rhs, dtype=np.float64).reshape(-1)
+    dx = np.zeros(n)
+    its, rel = C.c_int32(), C.c_double()
+    nat.check(lib.ps_sparse_normal_solve(m, n, nat.i32p(a[0]), nat.i32p(a[1]), nat.f64p(a[2]), nat.i32p(a[3]), nat.i32p(a[4]),
+                                         nat.f64p(a[5]), nat.f64p(rr), nat.f64p(bb), float(tol), int(max_iters), nat.f64p(dx),
+                                         C.byref(its), C.byref(rel)))
+    return dx, its.value, rel.value
+
+
 class PhotometricDevice:
     """Device side of a Problem whose only block is a PhotometricResidualSE3 (include/pyslam_hip.h:
     ps_photometric_*): the pixel tables live in HBM, one call runs a whole Gauss-Newton iteration.

@@ -14,7 +14,8 @@ attributes the reference's tests read).  What differs is where the work runs:
   scalars per iteration and runs the reference's termination logic on them;
 * problems with user-defined blocks / parameters are evaluated through the
   block protocol on the host (that is user Python code) and only the normal
-  equations are formed and solved on the device (ps_dense_normal_solve).
+  equations are formed and solved on the device (ps_dense_normal_solve; beyond 2048
+  unknowns J goes up as CSR and the device runs CG on J^T J: ps_sparse_normal_solve).
 
 There is no CPU solver: without the HIP library or a GPU, solve() raises.
 """
@@ -355,12 +356,18 @@ class Problem:
         return dx, cost
 
     # ---- generic (host-evaluated) path ---------------------------------
+    # Unknowns up to which the host-evaluated path forms J dense and solves by Cholesky on the device
+    # (ps_dense_normal_solve); beyond it J travels as CSR and the device runs CG on the normal equations
+    # (ps_sparse_normal_solve) -- the reference's sparse LU has no such limit (pyslam/problem.py:186).
+    DENSE_GENERIC_LIMIT = 2048
+
     def _host_jacobian(self):
-        """Dense IRLS-scaled J~, e~ and cost by walking the blocks (reference
-        problem.py:338-360); used only for blocks without a device kernel."""
+        """IRLS-scaled J~ (scipy CSR, block-sparse: one dense (rows x dof) piece per block and parameter), e~ and cost
+        by walking the blocks (reference problem.py:338-360); used only for blocks without a device kernel."""
+        import scipy.sparse as sp
         part = self._update_partition_dict
         n = max([r.stop for r in part.values()] + [0])
-        rows, es, cost = [], [], 0.
+        rows_i, cols_i, vals, es, cost, m = [], [], [], [], 0., 0
         for block, keys, loss in zip(self.residual_blocks, self.block_param_keys,
                                      self.block_loss_functions):
             params = [self.param_dict[key] for key in keys]
@@ -368,22 +375,34 @@ class Problem:
             if not any(want):
                 continue
             residual, jacobians = block.evaluate(params, want)
-            residual = np.atleast_1d(residual)
-            s = np.sqrt(loss.weight(residual))
-            Jrow = np.zeros((residual.size, n))
+            residual = np.atleast_1d(residual).reshape(-1)
+            s = np.sqrt(np.asarray(loss.weight(residual), dtype=float)).reshape(-1)
+            nres = residual.size
             for key, jac in zip(keys, jacobians):
                 if jac is not None:
-                    jac = np.asarray(jac, dtype=float).reshape(residual.size, -1)
-                    Jrow[:, part[key].start:part[key].stop] += s[:, None] * jac
-            rows.append(Jrow)
+                    jac = s[:, None] * np.asarray(jac, dtype=float).reshape(nres, -1)
+                    c0 = part[key].start
+                    rows_i.append(np.repeat(np.arange(m, m + nres), jac.shape[1]))
+                    cols_i.append(np.tile(np.arange(c0, c0 + jac.shape[1]), nres))
+                    vals.append(jac.ravel())
             es.append(s * residual)
             cost += np.sum(loss.loss(residual))
-        return np.vstack(rows), np.concatenate(es), cost
+            m += nres
+        J = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows_i), np.concatenate(cols_i))), shape=(m, n))
+        J.sum_duplicates()                       # a parameter listed twice in one block: its Jacobian pieces add up
+        return J, np.concatenate(es), cost
+
+    def _generic_step(self, J, e):
+        from pyslam_amd.device import dense_normal_solve, sparse_normal_solve
+        if J.shape[1] <= self.DENSE_GENERIC_LIMIT:
+            return dense_normal_solve(J.toarray(), e)
+        dx, its, rel = sparse_normal_solve(J, r=e, tol=self.options.pcg_tol, max_iters=max(self.options.pcg_max_iters, 10 * J.shape[1]))
+        self.solver_stats.append((its, rel))
+        return dx
 
     def _solve_one_iter_host(self):
-        from pyslam_amd.device import dense_normal_solve
         J, e, cost = self._host_jacobian()
-        dx = dense_normal_solve(J, e)
+        dx = self._generic_step(J, e)
         if self.options.linesearch_max_iters > 0:
             test = copy.deepcopy(self.param_dict)
             for k, r in self._update_partition_dict.items():
@@ -406,6 +425,8 @@ class Problem:
         try:
             self._update_partition_dict = self._get_update_partition_dict()      # (never stale: see solve_one_iter)
             self._covariance_matrix = None
+            self._cov_sparse_J = None
+            self._cov_device = None
             self._cov_columns = {}
             try:
                 dev = self._get_device()
@@ -414,7 +435,10 @@ class Problem:
             if dev is None:
                 from pyslam_amd.device import dense_normal_solve
                 J, e, _ = self._host_jacobian()
-                _, self._covariance_matrix = dense_normal_solve(J, e, want_covariance=True)
+                if J.shape[1] <= self.DENSE_GENERIC_LIMIT:
+                    _, self._covariance_matrix = dense_normal_solve(J.toarray(), e, want_covariance=True)
+                else:
+                    self._cov_sparse_J = J           # columns on demand (get_covariance_block): CG with a unit right-hand side
                 return
             if self._photometric_form():
                 # 6 x 6: the device forms J~^T J~ over all pixels; its inverse in the reference's unknown order
@@ -475,6 +499,15 @@ class Problem:
         try:
             r0 = self._update_partition_dict[param0]
             r1 = self._update_partition_dict[param1]
+            if self._covariance_matrix is None and getattr(self, '_cov_sparse_J', None) is not None:
+                from pyslam_amd.device import sparse_normal_solve
+                J = self._cov_sparse_J
+                cols = np.zeros((r0.stop - r0.start, r1.stop - r1.start))
+                for c, k in enumerate(range(r1.start, r1.stop)):
+                    rhs = np.zeros(J.shape[1]); rhs[k] = 1.
+                    x, _, _ = sparse_normal_solve(J, rhs=rhs, tol=1e-13, max_iters=20 * J.shape[1])
+                    cols[:, c] = x[r0.start:r0.stop]
+                return np.squeeze(cols)
             if self._covariance_matrix is None and getattr(self, '_cov_device', None) is not None:
                 return np.squeeze(self._covariance_columns(param1)[r0.start:r0.stop, :])
             return np.squeeze(self._covariance_matrix[r0.start:r0.stop, r1.start:r1.stop])

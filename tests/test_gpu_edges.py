@@ -303,3 +303,86 @@ def test_forced_restart_of_the_pipelined_cg_reaches_the_same_solution():
     xb = dev.covariance_column(0, 120, 1)[0]
     assert dev.cg_restarts() >= 1
     assert np.abs(xa - xb).max() <= 1e-9 * np.abs(xa).max()
+
+
+class _Smooth:
+    """A user-defined block (no KIND tag, no device kernel): s * (p0 - p1)."""
+
+    def __init__(self, s):
+        self.s = s
+
+    def evaluate(self, params, compute_jacobians=None):
+        r = np.atleast_1d(self.s * (np.asarray(params[0], dtype=float) - np.asarray(params[1], dtype=float))).reshape(-1)
+        if not compute_jacobians:
+            return r
+        return r, [np.array([[self.s]]) if compute_jacobians[0] else None,
+                   np.array([[-self.s]]) if compute_jacobians[1] else None]
+
+
+def test_generic_path_beyond_the_dense_limit_runs_sparse_cg_on_the_device():
+    """User-defined blocks keep a problem on the host-evaluated path; beyond 2048 unknowns (the dense Cholesky's limit)
+    the Jacobian goes to the device as CSR and the normal equations are solved there by CG (ps_sparse_normal_solve) --
+    the reference solves such a problem with its sparse LU.  1 200 parabolas (3 600 unknowns) tied to
+    their neighbours by a user-defined smoothness block: the step equals scipy's direct solve of the same normal
+    equations, solve() converges to the minimiser, and a covariance block (columns on demand) equals the inverse's."""
+    import scipy.sparse.linalg as spla
+    from pyslam.problem import Options, Problem
+    from pyslam.residuals import QuadraticResidual
+    from pyslam.losses import HuberLoss
+    rng = np.random.default_rng(8)
+    problem = Problem(Options())
+    N = 1200
+    params = {}
+    for k in range(N):
+        a, b, c = 1. + 0.1 * np.sin(0.01 * k), -2. + 0.05 * k / N, 0.5
+        for x in (-2., -0.5, 0.7, 1.5, 3.):
+            y = a * x * x + b * x + c + 0.01 * rng.standard_normal()
+            problem.add_residual_block(QuadraticResidual(x, y, 2.0), ['a%d' % k, 'b%d' % k, 'c%d' % k], HuberLoss(5.0))
+        params.update({'a%d' % k: 0., 'b%d' % k: 0., 'c%d' % k: 0.})
+        if k:
+            problem.add_residual_block(_Smooth(0.3), ['a%d' % (k - 1), 'a%d' % k])
+    problem.initialize_params(params)
+    problem._update_partition_dict = problem._get_update_partition_dict()
+    J, e, _ = problem._host_jacobian()
+    assert J.shape == (5 * N + N - 1, 3 * N) and J.shape[1] > problem.DENSE_GENERIC_LIMIT
+    dx, cost = problem.solve_one_iter()
+    ref = spla.spsolve((J.T @ J).tocsc(), -(J.T @ e))
+    assert np.linalg.norm(dx - ref) <= 1e-9 * np.linalg.norm(ref)
+    assert problem.solver_stats[-1][0] > 0 and problem.solver_stats[-1][1] <= problem.options.pcg_tol
+    out = problem.solve()
+    assert abs(out['a600'] - (1. + 0.1 * np.sin(6.))) < 0.02 and abs(out['c7'] - 0.5) < 0.05
+    problem.compute_covariance()
+    J2, _, _ = problem._host_jacobian()
+    cov = np.linalg.inv((J2.T @ J2).toarray())
+    r0, r1 = problem._update_partition_dict['b17'], problem._update_partition_dict['a18']
+    got = problem.get_covariance_block('b17', 'a18')
+    assert abs(got - cov[r0.start, r1.start]) <= 1e-8 * np.abs(cov).max()
+    got = problem.get_covariance_block('c900', 'c900')
+    r0 = problem._update_partition_dict['c900']
+    assert abs(got - cov[r0.start, r0.start]) <= 1e-8 * cov[r0.start, r0.start]
+
+
+def test_per_observation_stiffness_falls_to_the_host_evaluated_path_and_solves():
+    """More (camera, stiffness, loss) groups than the observation record's 8-bit group field: lowering says
+    NotLowerable (not an error out of ps_problem_create) and the host-evaluated path solves it -- same step as the
+    typed device path on the same problem with the stiffnesses quantised into 255 groups would give is NOT required;
+    the check is against scipy on the block protocol's own Jacobian."""
+    import scipy.sparse.linalg as spla
+    from conftest import load_golden, golden_lp
+    from test_host_api import build_namespace
+    ns = build_namespace()
+    lp = golden_lp(load_golden('ba_small'))
+    problem = synthetic.to_objects(lp, ns)
+    rng = np.random.default_rng(4)
+    for b in problem.residual_blocks:                         # one stiffness per observation
+        b.stiffness = b.stiffness * (1. + 0.2 * rng.random())
+    from pyslam_amd.lowering import NotLowerable
+    with pytest.raises(NotLowerable):
+        problem._lower()
+    dx, cost = problem.solve_one_iter()
+    J, e, _ = problem._host_jacobian()
+    ref = spla.spsolve((J.T @ J).tocsc(), -(J.T @ e))
+    assert np.linalg.norm(dx - ref) <= 1e-8 * np.linalg.norm(ref)
+    c0 = problem.eval_cost()
+    problem.solve()
+    assert problem._cost_history[-1] < 0.05 * c0 and len(problem._cost_history) >= 3
