@@ -314,6 +314,9 @@ __global__ __launch_bounds__(64) void k_pose_finalize(
 // (lane p + 32 h accumulates block rows 3h .. 3h+2: h = 0 from M_a, h = 1 from pc_a^ M_a; the b row is
 // expanded to [M_b; pc_b^ M_b] by both), so a lane carries 18 accumulators: 7 KB of LDS and < 128
 // VGPRs per wave => 4 waves per SIMD.  Waves never share LDS data: no workgroup barrier.
+#ifndef PS_SP_WAVES
+#define PS_SP_WAVES 4                         // waves per SIMD the register budget is held to (128 VGPRs; 5 = 96 VGPRs spills: 60 -> 80 us)
+#endif
 #define PS_SP_PAIRS 32                        // pairs per chunk: rows a_0..a_31, b_0..b_31
 #define PS_SP_ROWD 14                         // doubles per row in LDS (7 x 16 B of the 128-byte line)
 #define PS_SP_LDS_PER_WAVE (64 * PS_SP_ROWD)  // doubles: 64 rows x 14
@@ -329,7 +332,7 @@ PS_DEV double half_sum_dpp(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_schur_pairs(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_SP_WAVES, 8))) void k_schur_pairs(
     int per_xcd, const PairItem* __restrict__ xitems /* [8][per_xcd], slot < 0: padding */,
     const int2* __restrict__ pairs, const double* __restrict__ Z, double* __restrict__ S,
     double* __restrict__ Spart /* tiled mode: one partial block per task position, else NULL */, int ablate)
@@ -372,26 +375,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): rows have landed in LDS
         __builtin_amdgcn_wave_barrier();
         if (p < n && !(ablate & 1)) {
-            double ma[12], mb[12], A[9], Lb[9];
-            const double2* pa = reinterpret_cast<const double2*>(rows + PS_SP_ROWD * p);
+            // this lane's three rows of Z_a: M_a (h = 0) or pc_a^ M_a (h = 1) ...
+            double A[9];
+            {
+                double ma[12];
+                const double2* pa = reinterpret_cast<const double2*>(rows + PS_SP_ROWD * p);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { const double2 va = pa[k]; ma[2 * k] = va.x; ma[2 * k + 1] = va.y; }
+                zrow_cross(ma, ma + 9, A);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) A[k] = hf ? A[k] : ma[k];
+            }
+            // ... against both halves of Z_b, one after the other (M_b is dead once pc_b^ M_b is formed: fewer live registers)
+            double mb[12];
             const double2* pb = reinterpret_cast<const double2*>(rows + PS_SP_ROWD * (PS_SP_PAIRS + p));
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const double2 va = pa[k], vb = pb[k];
-                ma[2 * k] = va.x; ma[2 * k + 1] = va.y; mb[2 * k] = vb.x; mb[2 * k + 1] = vb.y;
-            }
-            // this lane's three rows of Z_a: M_a (h = 0) or pc_a^ M_a (h = 1); both halves of Z_b
-            zrow_cross(ma, ma + 9, A);
+            for (int k = 0; k < 6; ++k) { const double2 vb = pb[k]; mb[2 * k] = vb.x; mb[2 * k + 1] = vb.y; }
 #pragma unroll
-            for (int k = 0; k < 9; ++k) A[k] = hf ? A[k] : ma[k];
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    acc[6 * a + b] += A[3 * a] * mb[3 * b] + A[3 * a + 1] * mb[3 * b + 1] + A[3 * a + 2] * mb[3 * b + 2];
+            double Lb[9];
             zrow_cross(mb, mb + 9, Lb);
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    acc[6 * a + b] += A[3 * a] * mb[3 * b] + A[3 * a + 1] * mb[3 * b + 1] + A[3 * a + 2] * mb[3 * b + 2];
+                for (int b = 0; b < 3; ++b)
                     acc[6 * a + 3 + b] += A[3 * a] * Lb[3 * b] + A[3 * a + 1] * Lb[3 * b + 1] + A[3 * a + 2] * Lb[3 * b + 2];
-                }
         }
         __builtin_amdgcn_wave_barrier();                        // LDS reads done before the next fetch lands
         mine = mine1; mine1 = mine2;

@@ -63,29 +63,25 @@ class TrajectoryMetrics:
     """
 
     def __init__(self, poses_gt, poses_est, convention='Twv'):
-        convention = str(np.asarray(convention).ravel()[0]) if not isinstance(convention, str) else convention
-        if convention == 'Twv':
-            Twv_gt, Twv_est = list(poses_gt), list(poses_est)
-        elif convention == 'Tvw':
-            Twv_gt = [T.inv() for T in poses_gt]
-            Twv_est = [T.inv() for T in poses_est]
-        else:
+        if not isinstance(convention, str):                 # (loadmat hands strings back as arrays)
+            convention = str(np.asarray(convention).ravel()[0])
+        to_world = {'Twv': lambda T: T, 'Tvw': lambda T: T.inv()}.get(convention)
+        if to_world is None:
             raise ValueError('convention must be \'Tvw\' or \'Twv\'')
-
-        if len(Twv_gt) != len(Twv_est):
-            valid_length = min((len(Twv_gt), len(Twv_est)))
-            print('WARNING: poses_gt has length {} but poses_est has length {}. Truncating to {}.'.format(
-                len(Twv_gt), len(Twv_est), valid_length))
-            Twv_gt = Twv_gt[:valid_length]
-            Twv_est = Twv_est[:valid_length]
+        n_gt, n_est = len(poses_gt), len(poses_est)
+        n = min(n_gt, n_est)
+        if n_gt != n_est:                                   # the reference truncates to the common prefix and says so
+            print('WARNING: poses_gt has length {} but poses_est has length {}. Truncating to {}.'.format(n_gt, n_est, n))
 
         self.convention = convention
-        self.Twv_gt = Twv_gt
-        self.Twv_est = Twv_est
-        self.pose_type = type(Twv_gt[0])
-        self.num_poses = len(self.Twv_gt)
-        self._Rg, self._tg = _stack(Twv_gt)
-        self._Re, self._te = _stack(Twv_est)
+        # vehicle-to-world poses, as the reference's public attributes (lists of liegroups objects) ...
+        self.Twv_gt = [to_world(T) for T in poses_gt[:n]]
+        self.Twv_est = [to_world(T) for T in poses_est[:n]]
+        self.pose_type = type(self.Twv_gt[0])
+        self.num_poses = n
+        # ... and stacked once for the batched metrics
+        self._Rg, self._tg = _stack(self.Twv_gt)
+        self._Re, self._te = _stack(self.Twv_est)
         self.rel_dists, self.cum_dists = self._compute_distances()
 
     # ---- helpers -------------------------------------------------------------------------------
