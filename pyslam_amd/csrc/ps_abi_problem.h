@@ -413,6 +413,165 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     prs.clear(); prs.shrink_to_fit();
 
     lap("pair items + XCD lists");
+    // ---- streaming Schur kernel (k_schur_stream): landmark tiles, per-tile block tables, per-lane-pair entry lists
+    {
+        // OFF unless PS_SCHUR_STREAM=1: measured slower than the gather kernel on MI355X (C3 0.112-0.137 ms against 0.060,
+        // C4 0.79 against 0.57 ms): 57 MB of partial blocks written and read back plus 28 MB of padded entry words
+        // outweigh the 9x fewer L2 requests, which L2 / Infinity Cache absorb well enough.
+        const char* env = getenv("PS_SCHUR_STREAM");
+        h->stream_mode = env ? atoi(env) : 0;                   // 0 off (default), 1 on whenever it can be built
+        if (h->stream_mode != 0 && total_pairs > 0 && D == 6) {
+            std::vector<StreamTile> tiles;
+            std::vector<StreamSub> subs;
+            std::vector<uint32_t> ents;
+            std::vector<std::pair<int32_t, int32_t>> part_of;   // (block slot, partial index): combine lists
+            std::vector<int32_t> part_slotT;
+            bool ok = true;
+            std::vector<int32_t> blk_of_key_epoch(0);           // open-addressing map key -> local block, reset per tile
+            struct KV { uint64_t key; int32_t val; };
+            std::vector<KV> table(4096, KV{~0ULL, -1});
+            std::vector<uint32_t> used;
+            auto find_or_add = [&](uint64_t key, int32_t next) -> int32_t {
+                size_t i = (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 52) & 4095;
+                for (;;) {
+                    if (table[i].key == key) return table[i].val;
+                    if (table[i].key == ~0ULL) { table[i] = KV{key, next}; used.push_back((uint32_t)i); return next; }
+                    i = (i + 1) & 4095;
+                }
+            };
+            auto rid_of = [&](int row) { return d->pose_rid[PS_POSE_OF(lobs[row])]; };
+            long part_total = 0, ent_pairs = 0;
+            // Tiles are cut by the accumulator capacity (PS_ST_CAP blocks) AND by a landmark count that leaves the chip
+            // enough workgroups: a multiple of its 256 CUs, about 5 M pairs per round of 256 tiles (C3: 256 tiles of 196
+            // landmarks, C4: 1 024 of 489).  Fewer, larger tiles would write fewer partial blocks but leave CUs idle.
+            long ttarget = 256L * std::max<long>(1, std::lround((double)total_pairs / 5.0e6));
+            if (const char* e2 = getenv("PS_ST_TILES")) ttarget = std::max(1L, atol(e2));
+            const int tile_lm_cap = std::max(32, cdiv(nv, ttarget));
+            int v = 0;
+            while (v < nv && ok) {
+                // grow the tile landmark by landmark while its block set fits the accumulators of one workgroup
+                for (uint32_t i : used) table[i] = KV{~0ULL, -1};
+                used.clear();
+                int nblk = 0;
+                const int v0 = v;
+                std::vector<uint64_t> keys_local;
+                for (; v < nv && v - v0 < tile_lm_cap; ++v) {
+                    const int a0 = lm_ptr[v], a1 = lm_ptr[v + 1];
+                    if (a1 - a0 >= 65536) { ok = false; break; }
+                    const size_t used_before = used.size();
+                    int added = 0;
+                    for (int a = a0; a < a1; ++a) {
+                        const int ra = rid_of(a);
+                        if (ra < 0) continue;
+                        for (int b = a + 1; b < a1; ++b) {
+                            const int rb = rid_of(b);
+                            if (rb < 0) continue;
+                            const uint64_t key = ((uint64_t)std::min(ra, rb) << 32) | (uint32_t)std::max(ra, rb);
+                            if (find_or_add(key, nblk + added) == nblk + added) { keys_local.push_back(key); ++added; }
+                        }
+                    }
+                    if (nblk + added > PS_ST_CAP) {              // this landmark does not fit any more: undo it, close the tile
+                        for (size_t q = used_before; q < used.size(); ++q) table[used[q]] = KV{~0ULL, -1};
+                        used.resize(used_before);
+                        keys_local.resize(nblk);
+                        if (v == v0) ok = false;                  // a single landmark with more pairs than accumulators
+                        break;
+                    }
+                    nblk += added;
+                }
+                if (!ok) break;
+                if (nblk == 0) continue;                          // landmarks without a pair (seen by < 2 variable poses)
+                const int v1 = v;
+                // local block numbering: ascending key (fixed, independent of the hash order)
+                std::vector<int32_t> order(nblk), local_of(nblk);
+                for (int b = 0; b < nblk; ++b) order[b] = b;
+                std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return keys_local[x] < keys_local[y]; });
+                for (int b = 0; b < nblk; ++b) local_of[order[b]] = b;
+                StreamTile tl{};
+                tl.row0 = lm_ptr[v0]; tl.sub0 = (int32_t)subs.size(); tl.part0 = (int32_t)part_total; tl.nblk = nblk;
+                for (int b = 0; b < nblk; ++b) {
+                    const uint64_t key = keys_local[order[b]];
+                    const int ra = (int)(key >> 32), rb = (int)(uint32_t)key;
+                    part_of.push_back({slot_of(ra, rb), (int32_t)(part_total + b)});
+                    part_slotT.push_back(slot_of(rb, ra));
+                    if (ra == rb) h->has_diag_tasks = true;
+                }
+                part_total += nblk;
+                // sub-tiles: <= PS_ST_SUBROWS rows each, cut at landmark boundaries, about equal
+                const int nrows_t = lm_ptr[v1] - lm_ptr[v0];
+                const int nsub = std::max(1, cdiv(nrows_t, PS_ST_SUBROWS));
+                const int target = cdiv(nrows_t, nsub);            // rows per sub-tile aimed at
+                int vs = v0;
+                while (vs < v1) {
+                    int ve = vs + 1;
+                    while (ve < v1 && lm_ptr[ve] - lm_ptr[vs] < target && lm_ptr[ve + 1] - lm_ptr[vs] <= PS_ST_SUBROWS) ++ve;
+                    if (lm_ptr[ve] - lm_ptr[vs] > PS_ST_SUBROWS) { ok = false; break; }     // one landmark longer than a sub-tile
+                    StreamSub sb{};
+                    sb.row = lm_ptr[vs]; sb.nrows = lm_ptr[ve] - lm_ptr[vs];
+                    // per (slot q, lane pair): the row pairs of its block inside this sub-tile, in landmark order
+                    std::vector<std::vector<uint32_t>> lists((size_t)PS_ST_SLOTS * PS_ST_PAIRS);
+                    for (int vv = vs; vv < ve; ++vv)
+                        for (int a = lm_ptr[vv]; a < lm_ptr[vv + 1]; ++a) {
+                            const int ra = rid_of(a);
+                            if (ra < 0) continue;
+                            for (int b = a + 1; b < lm_ptr[vv + 1]; ++b) {
+                                const int rb = rid_of(b);
+                                if (rb < 0) continue;
+                                const uint64_t key = ((uint64_t)std::min(ra, rb) << 32) | (uint32_t)std::max(ra, rb);
+                                const int lb = local_of[find_or_add(key, -1)];
+                                const int la = (ra <= rb ? a : b) - sb.row, lbr = (ra <= rb ? b : a) - sb.row;
+                                lists[(size_t)(lb / PS_ST_PAIRS) * PS_ST_PAIRS + lb % PS_ST_PAIRS].push_back((uint32_t)la | ((uint32_t)lbr << 16));
+                                ++ent_pairs;
+                            }
+                        }
+                    for (int q = 0; q < PS_ST_SLOTS; ++q)
+                        for (int w = 0; w < PS_ST_THREADS / 64; ++w) {
+                            size_t steps = 0;
+                            for (int l = 0; l < 64; ++l) steps = std::max(steps, lists[(size_t)q * PS_ST_PAIRS + w * 64 + l].size());
+                            const size_t nbatch = (steps + 7) / 8;           // batches of 8 steps, lane major inside a batch
+                            sb.off[q][w] = (int32_t)(ents.size() / 4); sb.steps[q][w] = (int32_t)nbatch;
+                            for (size_t bt = 0; bt < nbatch; ++bt)
+                                for (int l = 0; l < 64; ++l) {
+                                    const auto& li = lists[(size_t)q * PS_ST_PAIRS + w * 64 + l];
+                                    for (size_t k = 0; k < 8; ++k) ents.push_back(bt * 8 + k < li.size() ? li[bt * 8 + k] : PS_ST_NONE);
+                                }
+                        }
+                    subs.push_back(sb);
+                    vs = ve;
+                }
+                if (!ok) break;
+                tl.nsub = (int32_t)subs.size() - tl.sub0;
+                tiles.push_back(tl);
+                if (ents.size() / 4 >= (1UL << 31) - (1UL << 20)) ok = false;
+            }
+            // worth it only if a partial block collects several pairs (else the partials outweigh the gathers)
+            const double pairs_per_partial = part_total ? (double)total_pairs / (double)part_total : 0.0;
+            if (ok && !tiles.empty() && (h->stream_mode == 1 || pairs_per_partial >= 4.0)) {
+                // combine lists: per block slot its partials in tile order
+                std::stable_sort(part_of.begin(), part_of.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) {
+                    return x.first < y.first; });
+                std::vector<PairItem> citm;
+                std::vector<int32_t> ctasks(part_of.size());
+                for (size_t k = 0; k < part_of.size(); ++k) {
+                    ctasks[k] = part_of[k].second;
+                    if (k == 0 || part_of[k].first != part_of[k - 1].first) {
+                        if (!citm.empty()) citm.back().end = (int32_t)k;
+                        citm.push_back({part_of[k].first, part_slotT[part_of[k].second], (int32_t)k, 0});
+                    }
+                }
+                citm.back().end = (int32_t)part_of.size();
+                h->st_ntiles = (int)tiles.size(); h->st_ncomb = (int)citm.size();
+                if (h->upload(&h->st_tiles, tiles) || h->upload(&h->st_subs, subs) || h->upload(&h->st_entries, ents) ||
+                    h->upload(&h->st_comb_items, citm) || h->upload(&h->st_comb_tasks, ctasks) ||
+                    h->alloc(&h->st_part, (size_t)part_total * 36)) return -1;
+                h->use_stream = true;
+                if (timing) fprintf(stderr, "ps_problem_create: streaming Schur: %d tiles, %zu sub-tiles, %ld partial blocks (%.1f pairs each), "
+                                            "%.1f MB of entry words (%.2fx the pairs)\n", h->st_ntiles, subs.size(), part_total, pairs_per_partial,
+                                    ents.size() * 4e-6, (double)ents.size() / (double)std::max<long>(1, ent_pairs));
+            }
+        }
+    }
+    lap("streaming Schur lists");
     // ---- factor contribution lists
     {
         struct C { int32_t slot, off, tr; };

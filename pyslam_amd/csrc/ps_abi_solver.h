@@ -437,6 +437,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     }
     else if (n == "cg_ablate") h->cg_ablate = (int)value;
     else if (n == "schur_ablate") h->schur_ablate = (int)value;
+    else if (n == "schur_stream") { if (value != 0.0 && !h->st_tiles) return fail("schur_stream: the streaming lists were not built for this problem"); h->use_stream = value != 0.0; }
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_force_restart") h->cg_force_restart = value != 0.0;

@@ -75,6 +75,17 @@ struct ps_problem {
     double* Spart = nullptr;
     PairItem* comb_items = nullptr;     // slot, slotT, [start, end) into comb_tasks
     int32_t* comb_tasks = nullptr;
+    // streaming Schur kernel (k_schur_stream): landmark tiles, sub-tiles, entry words, partial blocks + their combine lists
+    int stream_mode = 0;            // PS_SCHUR_STREAM: 0 off (default: measured slower than the gather kernel), 1 whenever it can be built
+    bool use_stream = false;
+    int st_ntiles = 0, st_ncomb = 0;
+    StreamTile* st_tiles = nullptr;
+    StreamSub* st_subs = nullptr;
+    uint32_t* st_entries = nullptr;
+    double* st_part = nullptr;
+    PairItem* st_comb_items = nullptr;
+    int32_t* st_comb_tasks = nullptr;
+    bool st_attr_set = false;
     // factors
     FactorGroup* fgroups = nullptr;
     int32_t *f_i = nullptr, *f_j = nullptr, *f_grp = nullptr;

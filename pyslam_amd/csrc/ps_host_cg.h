@@ -689,12 +689,24 @@ int linearize(ps_problem* h, double lambda) {
         hipLaunchKernelGGL(k_pose_pass, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
                            h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial);
         // tiled Schur: the combine launch also finalizes the poses (unless a task writes a diagonal block)
-        fin_in_combine = h->Spart && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6;
+        fin_in_combine = (h->Spart || h->use_stream) && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6;
         if (!fin_in_combine)
             hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
                                h->ppartial, h->diag_slot, lambda, h->S, h->g);
     }
-    if (h->npair_items > 0) {
+    if (h->npair_items > 0 && h->use_stream) {
+        StageTimer t(h, PS_ST_SCHUR, 1);
+        const size_t lds = (size_t)PS_ST_SUBROWS * PS_ST_ROWD * sizeof(double);
+        if (!h->st_attr_set) {
+            HIP_OK(hipFuncSetAttribute((const void*)k_schur_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->st_attr_set = true;
+        }
+        hipLaunchKernelGGL(k_schur_stream, dim3(h->st_ntiles), dim3(PS_ST_THREADS), lds, h->stream, h->st_tiles, h->st_subs,
+                           reinterpret_cast<const uint4*>(h->st_entries), h->Z, h->st_part, h->schur_ablate);
+        hipLaunchKernelGGL(k_schur_combine, dim3(cdiv(h->st_ncomb, 4) + (fin_in_combine ? cdiv(h->nr, 4) : 0)), dim3(256), 0,
+                           h->stream, h->st_ncomb, h->st_comb_items, h->st_comb_tasks, h->st_part, h->S,
+                           fin_in_combine ? h->nr : 0, h->pitem_ptr, h->ppartial, h->diag_slot, lambda, h->g);
+    } else if (h->npair_items > 0) {
         StageTimer t(h, PS_ST_SCHUR, 1);
         hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), 0, h->stream,
                            h->pair_per_xcd, h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, h->schur_ablate);

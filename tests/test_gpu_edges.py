@@ -386,3 +386,32 @@ def test_per_observation_stiffness_falls_to_the_host_evaluated_path_and_solves()
     c0 = problem.eval_cost()
     problem.solve()
     assert problem._cost_history[-1] < 0.05 * c0 and len(problem._cost_history) >= 3
+
+
+def test_streaming_schur_kernel_builds_the_same_reduced_system(monkeypatch):
+    """k_schur_stream (landmark tiles, block accumulators in registers, Z rows read once; off by default -- measured
+    slower than the gather kernel, DESIGN.md section 5 -- and enabled with PS_SCHUR_STREAM=1) against the default
+    k_schur_pairs: same reduced system to rounding (the partial sums group differently), duplicate observations of
+    one pose included, and bitwise reproducible run to run."""
+    lp, _ = synthetic.stereo_ba(num_kf=70, num_lm=6000, obs_per_lm=7, half_window=10, seed=13)
+    dup = np.arange(0, lp.num_obs, 97)                        # a few landmarks seen twice from the same pose
+    lp.obs_pose = np.concatenate([lp.obs_pose, lp.obs_pose[dup]])
+    lp.obs_point = np.concatenate([lp.obs_point, lp.obs_point[dup]])
+    lp.obs_uvd = np.concatenate([lp.obs_uvd, lp.obs_uvd[dup] + 0.3])
+    lp.obs_grp = np.concatenate([lp.obs_grp, lp.obs_grp[dup]])
+    lp = lp.finalize()
+    ref = device(lp)
+    ref.linearize(0.)
+    _, _, vals, g = ref.reduced_system()
+    monkeypatch.setenv('PS_SCHUR_STREAM', '1')
+    monkeypatch.setenv('PS_ST_TILES', '24')
+    out = []
+    for _ in range(2):
+        dev = device(lp)
+        dev.linearize(0.)
+        out.append(dev.reduced_system())
+        dev.close()
+    assert np.array_equal(out[0][2], out[1][2])
+    assert np.abs(out[0][2] - vals).max() <= 1e-12 * np.abs(vals).max() and np.array_equal(out[0][3], g)
+    dev = device(lp)
+    assert dev.gn_iteration(0., 1e-12, 500, True)[0] < dev.eval_cost(True) * 1.0000001
