@@ -10,8 +10,10 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, 'gpurun_out', tag), os.path.join(root, 'profiles')
 os.makedirs(dst, exist_ok=True)
 for a, b in (('bench.json', '_c3_bench.json'), ('bench_under_rocprof.json', '_c3_bench_under_rocprof.json'),
-             ('bench_sharded_1rank.json', '_c3_bench_sharded_1rank_rccl.json'), ('ktrace_kernel_stats.csv', '_c3_kernel_stats.csv')):
-    shutil.copy(os.path.join(src, a), os.path.join(dst, rnd + b))
+             ('bench_sharded_1rank.json', '_c3_bench_sharded_1rank_rccl.json'), ('ktrace_kernel_stats.csv', '_c3_kernel_stats.csv'),
+             ('bench_sharded_1rank_c4.json', '_c4_bench_sharded_1rank_rccl.json'), ('c4_kernel_stats.csv', '_c4_kernel_stats.csv')):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, rnd + b))
 
 def short(name):
     return name.split('(')[0].strip()
@@ -39,9 +41,18 @@ for k in sorted(acc):
         wk = sum(acc[k]['WRITE_SIZE']) / len(acc[k]['WRITE_SIZE'])
         traffic[k] = {'fetch_kb': round(fk, 1), 'write_kb': round(wk, 1), 'hbm_bytes_corrected': int(round((2 * fk + wk) * 1024))}
 open(os.path.join(dst, rnd + '_c3_pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
+# the build the passes were taken on: bench.py compares source_sha with the sources it runs and flags a stale table
+import subprocess
+sha = open(os.path.join(src, 'source_sha.txt')).read().strip() if os.path.exists(os.path.join(src, 'source_sha.txt')) else None
+try:
+    head = subprocess.check_output(['git', '-C', root, 'rev-parse', '--short=12', 'HEAD']).decode().strip()
+except Exception:
+    head = None
+traffic['_meta'] = {'source_sha': sha, 'git_head': head, 'round': rnd, 'tag': tag,
+                    'note': 'per-launch averages of separate rocprofv3 --pmc passes of `bench.py --steps 5 --warmup 2`; read traffic = 2 x FETCH_SIZE (gfx950)'}
 json.dump(traffic, open(os.path.join(dst, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
 b = json.load(open(os.path.join(src, 'bench.json')))
 print('bench', b['value'], b['stage_ms'], b['roofline'], b.get('cpu_baseline', {}).get('value'))
 for k in ('k_schur_pairs', 'k_schur_combine', 'k_landmark_pass', 'k_pose_pass', 'k_backsub'):
-    if k in traffic:
+    if k in traffic and k != '_meta':
         print(k, traffic[k])
