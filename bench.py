@@ -335,6 +335,8 @@ def main():
             c4 = c4_single_gpu(stream)
             line['c4_single_gpu_ms'] = c4['ms']
             line['c4_single_gpu'] = c4
+            if world > 1:                                    # same problem, same run, one GPU of this node: the strong-scaling base
+                line['speedup_vs_c4_single_gpu'] = round(c4['ms'] / ms_per_step, 3)
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(lp)
         print(json.dumps(line))

@@ -210,6 +210,8 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /
      "fused_motion_only"  [1] problems without variable landmarks / pose factors: one launch per iteration
      "cg_explicit"        [1] long sparse chains: apply the two-level preconditioner (k_xcg_*) instead of folding it in
      "coarse_lag_x"       [1] ... and with the previous iteration's basis and X = P L_c^-T too: three set-up launches (k_rows_setup)
+     "coarse_refresh_every" [1] explicit two-level PCG: only every k-th lagged set-up takes the newest coarse inverse and starts the
+                              next side-stream factorisation (landmark-sharded runs whose iteration is shorter than that factorisation)
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual
      "cg_lds", "profile_every", "big_chol", "cg_margin", "pcg_chunk", "cg_split_min_rows", "cg_explicit_min_rows": implementation switches (see ps_set_option in csrc/ps_abi_solver.h)
      "cg_ablate", "schur_ablate", "lm_ablate": timing experiments only (results are wrong under ablation) */

@@ -162,6 +162,8 @@ struct ps_problem {
     // explicit two-level PCG (long sparse chains)
     int explicit_ok = 1;
     bool cg_explicit = false;
+    int xcg_refresh_every = 1;      // option "coarse_refresh_every": lagged set-ups between two refreshes of the coarse inverse
+    long xcg_lag_count = 0;
     double *xstate = nullptr, *xy = nullptr, *xp2 = nullptr;
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     int prof_every = 1;             // profiling level 1: time the Schur kernel of every n-th linearisation only

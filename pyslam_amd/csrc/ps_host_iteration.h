@@ -13,28 +13,39 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
                        h->poses, h->pose_of_rid, h->coarse_basis, h->Bmat, h->bgv);
     hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
                        h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
-    if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
-    hipLaunchKernelGGL(k_xcoarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(h->max_row_ents + 1) * D * D * sizeof(double), h->stream,
-                       nr, h->ent_ptr, h->ent_q, h->ent_lo, h->ent_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->Bmat, h->BSZ);
-    hipLaunchKernelGGL(k_xcoarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
-                       ncb, h->seg_ptr, h->seg_ent, h->seg_row, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
     // A_c^-1 lives in LciT2[b] (the transposed factor is not used on this path).  It only PRECONDITIONS here, so any
     // symmetric positive definite stand-in keeps the CG exact: whole-iteration calls use the inverse formed from the
     // PREVIOUS iteration's A_c and factor the current one on the side stream while the CG iterates (the factorisation,
     // triangular inverse and product are 5.6 ms of the 12 ms iteration at C2 with 256 nodes).
+    // "coarse_refresh_every" = k > 1 (landmark-sharded runs on many GPUs, where an iteration is shorter than the side
+    // stream's factorisation -- C4 on 8 GPUs: ~1.1 ms against 1.6 ms): only every k-th lagged set-up consumes the newest
+    // inverse and starts the next factorisation; the set-ups in between HOLD the inverse they have, assemble no A_c and
+    // do not wait for the side stream.  A fixed schedule, not a completion poll: results stay reproducible run to run.
     const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0;
+    const bool hold = lag && h->xcg_refresh_every > 1 && (h->xcg_lag_count % h->xcg_refresh_every) != 0;
     const int32_t* lagst = nullptr;
     h->xcg_side_todo = false;
+    if (!hold) {
+        if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
+        hipLaunchKernelGGL(k_xcoarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(h->max_row_ents + 1) * D * D * sizeof(double), h->stream,
+                           nr, h->ent_ptr, h->ent_q, h->ent_lo, h->ent_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->Bmat, h->BSZ);
+        hipLaunchKernelGGL(k_xcoarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
+                           ncb, h->seg_ptr, h->seg_ent, h->seg_row, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
+    }
     if (lag) {
-        h->lci_cur = h->lci_next;
-        HIP_OK(hipEventRecord(h->ev_ac, h->stream));       // A_c complete; the side work is enqueued by xcg_side_enqueue
-        h->xcg_side_todo = true;
-        lagst = h->lag_status;
+        if (!hold) {
+            h->lci_cur = h->lci_next;
+            HIP_OK(hipEventRecord(h->ev_ac, h->stream));   // A_c complete; the side work is enqueued by xcg_side_enqueue
+            h->xcg_side_todo = true;
+            lagst = h->lag_status;
+        }
+        ++h->xcg_lag_count;
     } else {
         const int buf = h->lci_cur;
         if (coarse_factor<D>(h, h->stream, buf, h->status)) return -1;
         hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, h->stream, nc, h->Lci2[buf], (float*)h->LciT2[buf]);
         h->lci_next = buf;
+        h->xcg_lag_count = 0;
     }
     HIP_OK(hipMemsetAsync(h->xstate, 0, 8 * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->xp2, 0, (size_t)nr * D * sizeof(double), h->stream));

@@ -170,6 +170,12 @@ class ShardedDeviceProblem:
                 self.dev.set_collective(0, 0)
                 self.native.close()
                 self.native = None
+        # Many ranks: the shard-local kernels shrink with 1 / world, the replicated reduced solve does not, and the
+        # side-stream factorisation of a large coarse level (C4: 1.6 ms) would then outlast the iteration (~1.1 ms on
+        # 8 GPUs) and stall the next set-up.  Refresh the lagged coarse inverse every second iteration there (a fixed
+        # schedule: same on every rank, reproducible).  Not measured on hardware: one GPU per box here.
+        if self.world >= 4 and hasattr(self.dev, 'set_option'):
+            self.dev.set_option('coarse_refresh_every', 2)
         self._scal = torch.zeros(2, dtype=torch.float64, device=self.dev.reduce_tensor.device)
 
     # ---- iteration -----------------------------------------------------
