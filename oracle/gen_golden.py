@@ -473,6 +473,15 @@ def case_photometric():
     save('photometric', **out)
 
 
+def case_ba_8k():
+    """The largest BA the verbatim reference solves here in minutes (up to ~8 k blocks; its bmat
+    bookkeeping is O(parameters x blocks), ~40 s per iteration at this size): 40 keyframes, 1 000 landmarks, 8 000
+    reprojection blocks, Huber loss, three Gauss-Newton iterations.  Bridges the reference-run goldens (<= 2 000 blocks
+    before) and the property-based checks at C3 / C4 size."""
+    lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=1000, obs_per_lm=8, half_window=9, seed=8, loss=ref_losses_huber(2.0))
+    solve_case('ba_8k', lp, example_options(max_iters=2))
+
+
 def main():
     if len(sys.argv) > 1:                      # only the named cases: python oracle/gen_golden.py metrics ransac
         os.makedirs(OUT, exist_ok=True)

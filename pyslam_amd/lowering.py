@@ -208,6 +208,17 @@ class NotLowerable(Exception):
     kernel; Problem then takes the host-evaluated generic path."""
 
 
+def refresh_params(param_dict, lp):
+    """Parameter VALUES only, in the order of an existing LoweredProblem (Options.static_blocks: the blocks are declared
+    unchanged, so the walk over them is skipped): (poses (P, pose_width), points (L, 3)); rows of `points` beyond the
+    keyed landmarks (the constant points of motion-only blocks) are kept."""
+    poses = np.stack([pack_pose(param_dict[k]) for k in lp.pose_keys]) if lp.pose_keys else lp.poses.copy()
+    points = lp.points.copy()
+    if lp.point_keys:
+        points[:len(lp.point_keys)] = np.array([param_dict[k] for k in lp.point_keys], dtype=F64).reshape(-1, 3)
+    return _f(poses, (-1, lp.pose_width)), _f(points, (-1, 3))
+
+
 class _Interner:
     """Small table of distinct rows keyed by the identity / bytes of the source."""
 

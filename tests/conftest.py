@@ -43,7 +43,7 @@ def golden_options(g):
 
 
 SOLVE_CASES = ['stereo_ba_example', 'posegraph_2d_example', 'posegraph_3d_example',
-               'ba_tiny_huber', 'ba_tiny_nolinesearch', 'ba_small', 'pg_small_huber',
+               'ba_tiny_huber', 'ba_tiny_nolinesearch', 'ba_small', 'ba_8k', 'pg_small_huber',
                'pg2d_small_huber', 'motion_only_cauchy', 'pg_orientation_huber']
 
 

@@ -267,6 +267,15 @@ def test_c3_through_the_public_api_equals_the_tables_path():
     got = problem._device.get_params()
     assert np.array_equal(got[0], poses) and np.array_equal(got[1], points)
     assert np.array_equal(problem.param_dict[lp.point_keys[123]], points[123])
+    # Options.static_blocks: a second solve re-reads only the parameter values (no walk over the 500 000 blocks)
+    problem.options.static_blocks = True
+    t6 = time.perf_counter()
+    c_again = problem.eval_cost()
+    t7 = time.perf_counter()
+    assert c_again == trace[1][0]
+    problem.param_dict[lp.point_keys[7]][2] += 0.01
+    assert problem.eval_cost() != c_again
+    print('\\nOptions.static_blocks: eval_cost on resident tables {:.3f} s (parameter refresh only)'.format(t7 - t6))
     print('\\nC3 through the public API: build 500k block objects {:.2f} s | lowering walk {:.2f} s | solve() {:.2f} s '
           '(lowering + ps_problem_create + 2 iterations + write-back) | ps_problem_create alone {:.2f} s | 2 iterations '
           'on resident tables {:.1f} ms'.format(t1 - t0, t2 - t1, t3 - t2, t4 - t3, (t5 - t4) * 1e3))
