@@ -212,13 +212,21 @@ def main():
 
     import torch
     from pyslam_amd import synthetic
+    # test hooks (a one-GPU box): PYSLAM_BENCH_ONE_GPU=1 puts every rank on cuda:0, PYSLAM_BENCH_BACKEND=gloo carries the
+    # collectives over the host (RCCL refuses two ranks on one device) -- the multi-rank code path end to end, minus RCCL
+    if os.environ.get('PYSLAM_BENCH_ONE_GPU'):
+        local_rank = 0
+    backend = os.environ.get('PYSLAM_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = dict(C4 if world > 1 else C3)
     name = 'C4' if world > 1 else 'C3'

@@ -480,19 +480,15 @@ int ps_dense_normal_solve(const double* J, const double* r, int32_t m, int32_t n
     if (n > 2048) return fail("generic (host-evaluated) path supports at most 2048 unknowns");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible");
-    double *dJ = nullptr, *dr = nullptr, *dH = nullptr, *dB = nullptr;
-    int32_t* dst = nullptr;
     const int nrhs = covariance ? n + 1 : 1;
-    HIP_OK(hipMalloc((void**)&dJ, (size_t)m * n * sizeof(double)));
-    HIP_OK(hipMalloc((void**)&dr, (size_t)m * sizeof(double)));
-    HIP_OK(hipMalloc((void**)&dH, (size_t)n * n * sizeof(double)));
-    HIP_OK(hipMalloc((void**)&dB, (size_t)n * nrhs * sizeof(double)));
-    HIP_OK(hipMalloc((void**)&dst, ST_NWORDS * sizeof(int32_t)));
+    DevBuf bJ, br, bH, bB, bst, bg;                   // scoped: released on every return path
+    if (bJ.get((size_t)m * n * sizeof(double)) || br.get((size_t)m * sizeof(double)) || bH.get((size_t)n * n * sizeof(double)) ||
+        bB.get((size_t)n * nrhs * sizeof(double)) || bst.get(ST_NWORDS * sizeof(int32_t)) || bg.get((size_t)n * sizeof(double))) return -1;
+    double *dJ = bJ.as<double>(), *dr = br.as<double>(), *dH = bH.as<double>(), *dB = bB.as<double>(), *dg = bg.as<double>();
+    int32_t* dst = bst.as<int32_t>();
     HIP_OK(hipMemset(dst, 0, ST_NWORDS * sizeof(int32_t)));
     HIP_OK(hipMemcpy(dJ, J, (size_t)m * n * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(dr, r, (size_t)m * sizeof(double), hipMemcpyHostToDevice));
-    double* dg = nullptr;
-    HIP_OK(hipMalloc((void**)&dg, (size_t)n * sizeof(double)));
     hipLaunchKernelGGL(k_dense_normal, dim3(cdiv((long)n * n, 256)), dim3(256), 0, 0, m, n, dJ, dr, dH, dg);
     // B = [g | I]
     std::vector<double> B((size_t)n * nrhs, 0.0), gh(n);
@@ -507,7 +503,6 @@ int ps_dense_normal_solve(const double* J, const double* r, int32_t m, int32_t n
         dx[i] = B[(size_t)i * nrhs];
         if (covariance) for (int j = 0; j < n; ++j) covariance[(size_t)i * n + j] = B[(size_t)i * nrhs + 1 + j];
     }
-    hipFree(dJ); hipFree(dr); hipFree(dH); hipFree(dB); hipFree(dst); hipFree(dg);
     if (st[ST_DIAG_FAIL]) return fail("normal matrix is not positive definite");
     return 0;
 }

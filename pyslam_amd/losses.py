@@ -4,7 +4,9 @@ Mirrors the loss protocol of reference pyslam/losses.py:8-214 (``loss``,
 ``influence``, ``weight`` on an (m,) residual; ctor argument ``k``).  The
 reference evaluates these through numba ufuncs; here they are plain numpy
 expressions on the host, and the device restatement lives in
-csrc/ps_loss.h (selected by ``LOSS_ID`` during lowering).
+csrc/ps_math.h (ps_loss_rho / ps_loss_weight, selected by ``LOSS_ID`` during lowering;
+only the six classes below THEMSELVES are lowered -- a subclass may override loss() /
+weight(), so it takes the host-evaluated path: pyslam_amd/lowering.py:_loss_id_k).
 
 Reference quirks kept on purpose:
 * ``L2Loss.weight`` returns ``np.ones(x.size)`` (flat), losses.py:16-17;
@@ -13,7 +15,7 @@ Reference quirks kept on purpose:
 """
 import numpy as np
 
-# ids shared with the HIP side (csrc/ps_loss.h)
+# ids shared with the HIP side (csrc/ps_math.h)
 LOSS_L2, LOSS_L1, LOSS_CAUCHY, LOSS_HUBER, LOSS_TUKEY, LOSS_TDIST = range(6)
 
 
