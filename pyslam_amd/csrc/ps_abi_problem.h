@@ -161,8 +161,11 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     std::vector<int32_t> pose_of_rid(std::max(nr, 1), 0);
     for (int p = 0; p < P; ++p) if (d->pose_rid[p] >= 0) pose_of_rid[d->pose_rid[p]] = p;
     if (h->upload(&h->pose_of_rid, pose_of_rid)) return -1;
-    // chunk of observations per workgroup: 1024 (four per thread) once that still fills the chip
-    const int pchunk = Np >= 1024L * 512 ? 1024 : 256;
+    // chunk of observations per workgroup: 512 (two per thread) once that still fills the chip
+    // (measured with the LDS-transposed reduction of k_pose_pass: 256 / 512 / 1024 observations per workgroup give
+    //  28.3 / 25.9 / 28.6 us at C3 and 0.218 / 0.192 / 0.202 ms at C4)
+    int pchunk = Np >= 512L * 256 ? 512 : 256;
+    if (const char* e = getenv("PS_POSE_CHUNK")) pchunk = std::max(256, atoi(e) / 256 * 256);
     for (int r = 0; r < nr; ++r) {
         for (int s = pcount[r]; s < pcount[r + 1]; s += pchunk)
             pitems.push_back({r, s, std::min(s + pchunk, pcount[r + 1]), pose_of_rid[r]});

@@ -63,7 +63,10 @@ PS_DEV void zrow_expand(const double* __restrict__ m, const double* __restrict__
     zrow_cross(m, pc, z + 9);
 }
 
-__global__ __launch_bounds__(256) void k_landmark_pass(
+#ifndef PS_LM_WAVES
+#define PS_LM_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES, 8))) void k_landmark_pass(
     int nv, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_point,
     const LObs* __restrict__ lobs, const double* __restrict__ poses,
     const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
@@ -196,10 +199,16 @@ __global__ __launch_bounds__(256) void k_landmark_pass(
 // the Jacobians this kernel evaluates anyway and the landmark's 48-byte factor C^-1 (an L2-resident
 // table) -- lm_emit_m + zrow_expand on the same inputs, so the values are those every consumer of the stored row forms.
 #define PS_NPOSE_ACC 33
+#ifndef PS_POSE_TRANSPOSE
+#define PS_POSE_TRANSPOSE 1
+#endif
 typedef const __attribute__((address_space(1))) void* ps_gptr_t;
 typedef __attribute__((address_space(3))) void* ps_lptr_t;
 
-__global__ __launch_bounds__(256) void k_pose_pass(
+#ifndef PS_POSE_WAVES
+#define PS_POSE_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_POSE_WAVES, 8))) void k_pose_pass(
     const PItem* __restrict__ items,
     const LObs* __restrict__ pobs /* observation records in pose order, landmark slot + 1 in the pose bits */,
     const double* __restrict__ poses, const double* __restrict__ points,
@@ -207,6 +216,9 @@ __global__ __launch_bounds__(256) void k_pose_pass(
     const double* __restrict__ cvec, double* __restrict__ partial)
 {
     __shared__ double red[4][PS_NPOSE_ACC];
+#if PS_POSE_TRANSPOSE
+    __shared__ double tr[4][64 * 17];
+#endif
     const PItem it = items[blockIdx.x];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const Se3 T = se3_load(poses + 12 * (size_t)it.pad);          // pad = pose table index of this chunk
@@ -252,11 +264,34 @@ __global__ __launch_bounds__(256) void k_pose_pass(
                 acc[21 + a] -= z[3 * a] * c0 + z[3 * a + 1] * c1 + z[3 * a + 2] * c2;
         }
     }
+#if PS_POSE_TRANSPOSE
+    // 33 sums over the wave's 64 lanes through LDS: every lane stores its accumulators ([lane][17], two halves), lane k
+    // adds up column k (64 conflict-free reads, fixed order) -- ~290 instructions per wave instead of the ~730 of 33 DPP
+    // butterflies, which cost as much as the evaluation itself when a thread holds one observation (C3)
+    {
+        double* trw = tr[w];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int k0 = 17 * h2, nk = h2 ? PS_NPOSE_ACC - 17 : 17;
+#pragma unroll
+            for (int k = 0; k < 17; ++k) if (k < nk) trw[lane * 17 + k] = acc[k0 + k];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nk) {
+                double s = 0.0;
+#pragma unroll 8
+                for (int l = 0; l < 64; ++l) s += trw[l * 17 + lane];
+                red[w][k0 + lane] = s;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+#else
 #pragma unroll
     for (int k = 0; k < PS_NPOSE_ACC; ++k) {
         const double s = wave_sum(acc[k]);
         if (lane == 0) red[w][k] = s;
     }
+#endif
     __syncthreads();
     if (threadIdx.x < PS_NPOSE_ACC)
         partial[(size_t)blockIdx.x * PS_NPOSE_ACC + threadIdx.x] =
