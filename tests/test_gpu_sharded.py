@@ -114,3 +114,36 @@ def test_two_ranks_on_one_gpu_reproduce_the_unsharded_iterations(native):
         assert abs(trace[k + 1][1] - nrm) <= 1e-9 * nrm
     assert np.abs(poses - ref.get_params()[0]).max() < 1e-9
     ref.close()
+
+
+def test_problem_solve_with_devices_option_on_a_one_rank_group(dist1):
+    """Options.devices = 'all' routes Problem.solve() / eval_cost() / solve_one_iter() / compute_covariance() through
+    ShardedProblemView (landmark shard + native RCCL) -- with one rank the results are those of the single-GPU route."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import load_golden, golden_lp
+    from test_host_api import build_namespace
+    ns = build_namespace()
+    lp = golden_lp(load_golden('ba_small'))
+    out = {}
+    for devices in (None, 'all'):
+        opts = ns.Options()
+        opts.allow_nondecreasing_steps = True
+        opts.max_nondecreasing_steps = 3
+        opts.devices = devices
+        problem = synthetic.to_objects(lp, ns, options=opts)
+        c0 = problem.eval_cost()
+        dx, c1 = problem.solve_one_iter()
+        assert problem.eval_cost() == c0                        # solve_one_iter does not move the parameters
+        problem.solve()
+        problem.compute_covariance()
+        key = [k for k in problem.param_dict if k.startswith('T')][3]
+        out[devices] = (c0, dx, c1, list(problem._cost_history), problem._lower(), problem.get_covariance_block(key, key),
+                        type(problem._device).__name__)
+    a, b = out[None], out['all']
+    assert b[6] == 'ShardedProblemView' and a[6] == 'DeviceProblem'
+    assert a[0] == b[0] and abs(a[2] - b[2]) <= 1e-12 * a[2]
+    assert np.linalg.norm(a[1] - b[1]) <= 1e-9 * np.linalg.norm(a[1])
+    assert len(a[3]) == len(b[3]) and np.allclose(a[3], b[3], rtol=1e-9)
+    assert np.abs(a[4].poses - b[4].poses).max() < 1e-9 and np.abs(a[4].points - b[4].points).max() < 1e-8
+    assert np.abs(a[5] - b[5]).max() <= 1e-9 * np.abs(a[5]).max()
