@@ -85,6 +85,8 @@ typedef struct ps_problem_info {
     int64_t cg_restarts;         /* restarts of the pipelined CG so far: its recurrences broke down (rounding drift out of
                                     range(V^T) on the singular folded system) and the solve went on
                                     from the true residual                                    */
+    int64_t cg_kernel_launches;  /* kernels enqueued for iterations of the reduced solve so far (1 per iteration for the
+                                    folded CG, 3 or 4 for the explicit two-level PCG, 2 for the classic PCG)            */
 } ps_problem_info;
 
 enum { PS_NUM_STAGES = 10 };
@@ -212,6 +214,8 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /
      "coarse_lag_x"       [1] ... and with the previous iteration's basis and X = P L_c^-T too: three set-up launches (k_rows_setup)
      "coarse_refresh_every" [1] explicit two-level PCG: only every k-th lagged set-up takes the newest coarse inverse and starts the
                               next side-stream factorisation (landmark-sharded runs whose iteration is shorter than that factorisation)
+     "xcg_restrict_fused" [1] explicit two-level PCG: three launches per iteration (restriction in the SpMV epilogue, t by recurrence)
+                              instead of four
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual
      "cg_lds", "profile_every", "big_chol", "cg_margin", "pcg_chunk", "cg_split_min_rows", "cg_explicit_min_rows": implementation switches (see ps_set_option in csrc/ps_abi_solver.h)
      "cg_ablate", "schur_ablate", "lm_ablate": timing experiments only (results are wrong under ablation) */

@@ -40,7 +40,7 @@ class ProblemInfo(C.Structure):
         ('num_points', C.c_int32), ('num_var_points', C.c_int32),
         ('num_obs', C.c_int64), ('num_edges', C.c_int64), ('num_priors', C.c_int64),
         ('reduced_nnzb', C.c_int64), ('num_pairs', C.c_int64), ('reduce_count', C.c_int64),
-        ('device_bytes', C.c_int64), ('cg_restarts', C.c_int64),
+        ('device_bytes', C.c_int64), ('cg_restarts', C.c_int64), ('cg_kernel_launches', C.c_int64),
     ]
 
 

@@ -9,6 +9,7 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
     info->reduce_count = ((long)h->nnzb + h->nr) / 2 * h->D * h->D + (long)h->nr * h->D + 3;
     info->device_bytes = (int64_t)h->dev_bytes;
     info->cg_restarts = h->cg_fallbacks;
+    info->cg_kernel_launches = h->cg_kernel_launches;
     return 0;
 }
 
@@ -441,6 +442,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_force_restart") h->cg_force_restart = value != 0.0;
+    else if (n == "xcg_restrict_fused") h->xcg_rt = value != 0;
     else if (n == "coarse_refresh_every") { if (value < 1 || value > 16) return fail("coarse_refresh_every must be 1..16"); h->xcg_refresh_every = (int)value; }
     else if (n == "coarse_lag_x") { h->lagx = value != 0.0; h->lci_next = -1; h->side_todo = false; }
     else if (n == "cg_lds") h->cg_lds = value != 0.0;

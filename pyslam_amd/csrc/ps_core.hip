@@ -165,6 +165,12 @@ struct ps_problem {
     int xcg_refresh_every = 1;      // option "coarse_refresh_every": lagged set-ups between two refreshes of the coarse inverse
     long xcg_lag_count = 0;
     double *xstate = nullptr, *xy = nullptr, *xp2 = nullptr;
+    // ... three-launch form (restriction folded into the SpMV epilogue + a recurrence for t)
+    int xcg_rt = 1;                 // option "xcg_restrict_fused"
+    bool xcg_rt_ok = false;         // every SpMV workgroup touches at most PS_XCG_NSLOT coarse nodes
+    int xcg_rt_rows = PS_XCG_ROWS_RT;
+    int32_t *xcg_wg_out = nullptr, *xcg_nptr = nullptr;
+    double *tq_part = nullptr, *tvec2 = nullptr;
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     int prof_every = 1;             // profiling level 1: time the Schur kernel of every n-th linearisation only
     long prof_tick = 0;
@@ -180,6 +186,7 @@ struct ps_problem {
     int cg_explicit_min_rows = -1;  // explicit two-level PCG beyond this many reduced poses (-1: 400 for pose-graph rows, 540 for BA rows)
     double *cg_U = nullptr, *cg_cgd[2] = {}, *cg_ab = nullptr;
     int cg_launched = 0;            // CG launches enqueued since the last setup
+    long cg_kernel_launches = 0;    // kernels enqueued for CG / PCG iterations since creation (ps_problem_info)
     bool cov_ready = false;         // ps_covariance_begin has linearised and set the reduced solver up; cleared by linearize()
     std::vector<int32_t> h_slot_of_vid;
     int ell_wf = 0, ell_wc = 0;     // two-class ELL widths of the CG matrix (0 = CSR)

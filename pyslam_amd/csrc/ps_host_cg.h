@@ -107,6 +107,7 @@ int pcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* re
     bool done = false;
     while (!done) {
         const int n = std::min(chunk, max_iters + 1 - k);   // +1: the launch that only detects convergence
+        h->cg_kernel_launches += 2L * n;
         for (int i = 0; i < n; ++i, ++k) {
             double* pold = (k & 1) ? h->p1 : h->p0;
             double* pnew = (k & 1) ? h->p0 : h->p1;
@@ -326,6 +327,32 @@ int build_coarse(ps_problem* h) {
         h->alloc(&h->Lci2[1], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[1], (size_t)h->nc * h->nc) ||
         h->alloc(&h->tvec, (size_t)h->nc) || h->alloc(&h->chol_scratch, 2 * (size_t)h->nc * h->nc)) return -1;
     if (h->cg_explicit && (h->alloc(&h->xstate, 8) || h->alloc(&h->xy, (size_t)h->nc) || h->alloc(&h->xp2, (size_t)nr * D))) return -1;
+    h->xcg_rt_ok = false;
+    if (h->cg_explicit && ncb <= 256) {
+        // three-launch form: records of P^T q per (SpMV workgroup, node it touches), a node's records contiguous and in
+        // workgroup order (the order k_xcg_coarse_rt sums them in)
+        if (const char* e = getenv("PS_XCG_ROWS_RT")) h->xcg_rt_rows = atoi(e);
+        const int R = h->xcg_rt_rows, nwg = cdiv(nr, R);
+        std::vector<int32_t> wgo((size_t)nwg * PS_XCG_NSLOT, -1), nptr(ncb + 1, 0);
+        bool ok = true;
+        for (int g = 0; g < nwg && ok; ++g) {
+            const int first = g * R, last = std::min(nr, first + R) - 1;
+            const int span = pnode[last] + 1 - pnode[first];
+            if (span >= PS_XCG_NSLOT) ok = false;
+            else for (int s2 = 0; s2 <= span; ++s2) nptr[pnode[first] + s2 + 1]++;
+        }
+        if (ok) {
+            for (int q = 0; q < ncb; ++q) nptr[q + 1] += nptr[q];
+            std::vector<int32_t> pos(nptr.begin(), nptr.end() - 1);
+            for (int g = 0; g < nwg; ++g) {
+                const int first = g * R, last = std::min(nr, first + R) - 1;
+                for (int s2 = 0; s2 <= pnode[last] + 1 - pnode[first]; ++s2) wgo[(size_t)g * PS_XCG_NSLOT + s2] = pos[pnode[first] + s2]++;
+            }
+            if (h->upload(&h->xcg_wg_out, wgo) || h->upload(&h->xcg_nptr, nptr) ||
+                h->alloc(&h->tq_part, (size_t)std::max(1, (int)nptr[ncb]) * D) || h->alloc(&h->tvec2, (size_t)h->nc)) return -1;
+            h->xcg_rt_ok = true;
+        }
+    }
     lap("allocations");
     if (!h->lag_status) {
         if (h->alloc(&h->lag_status, ST_NWORDS)) return -1;
@@ -544,6 +571,7 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
     const int rows = h->cg_split ? h->nr : h->nr_aug;      // matrix rows handled by k_cg_fused
     const int ncbs = h->cg_split ? h->ncb : 0;
     const double tol2 = tol * tol;
+    h->cg_kernel_launches += count;
     for (int i = 0; i < count; ++i, ++h->cg_launched) {
         const int n = h->cg_launched, o = n & 1, nw = o ^ 1;
         // large systems: totals of the previous launch's partials come from a reduce launch

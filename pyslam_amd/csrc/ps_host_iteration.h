@@ -78,13 +78,36 @@ int xcg_side_enqueue(ps_problem* h) {
 template <int D>
 void xcg_launch(ps_problem* h, double tol, int count) {
     const int nr = h->nr, ncb = h->ncb, nc = h->nc;
-    const int n_pq = cdiv(nr, PS_XCG_ROWS), n_rz = cdiv(nr, PS_XCG_DROWS);
+    const int n_rz = cdiv(nr, PS_XCG_DROWS);
     double* pbuf[2] = {h->cg_p, h->xp2};
+    if (h->xcg_rt && h->xcg_rt_ok) {                        // three launches per iteration
+        const int R = h->xcg_rt_rows, n_pq = cdiv(nr, R);
+        h->cg_kernel_launches += 3L * count;
+        const XcgRestrictArgs ra{h->Bmat, h->pnode, h->pw0, h->pw1, h->xcg_wg_out, h->tq_part};
+        double* tb[2] = {h->tvec, h->tvec2};
+        for (int i = 0; i < count; ++i, ++h->cg_launched) {
+            const int k = h->cg_launched, b = k & 1;
+#define PS_XCG_SPMV_RT(RR) hipLaunchKernelGGL((k_xcg_spmv<D, RR, true>), dim3(n_pq), dim3(64 * RR), 0, h->stream, nr,             \
+                               h->arow_ptr, h->acol_idx, h->ell_wf, h->Saug, h->cg_s[0], pbuf[b ^ 1], pbuf[b], h->cg_w[0],       \
+                               h->cg_gd[0], n_rz, h->cg_gd[1], h->xstate, k, tol * tol, h->hist, h->status, h->scalars, ra)
+            if (R == 4) PS_XCG_SPMV_RT(4); else if (R == 8) PS_XCG_SPMV_RT(8); else PS_XCG_SPMV_RT(16);
+#undef PS_XCG_SPMV_RT
+            hipLaunchKernelGGL(k_xcg_coarse_rt<D>, dim3(cdiv(nc, PS_XCG_CROWS)), dim3(64 * PS_XCG_CROWS), 0, h->stream, nc,
+                               (const float*)h->LciT2[h->lci_cur], tb[b], tb[b ^ 1], h->xcg_nptr, h->tq_part, h->cg_gd[1], n_pq,
+                               h->xstate, k, h->xy, h->status);
+            hipLaunchKernelGGL(k_xcg_prolong_rt<D>, dim3(n_rz), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb, h->pnode, h->pw0,
+                               h->pw1, h->Bmat, h->cg_r[b], h->cg_r[b ^ 1], h->cg_w[0], pbuf[b], h->cg_xh, h->cg_gd[1], n_pq,
+                               h->xstate, k, h->xy, h->cg_s[0], h->cg_gd[0], h->status);
+        }
+        return;
+    }
+    const int n_pq = cdiv(nr, PS_XCG_ROWS);
+    h->cg_kernel_launches += 4L * count;
     for (int i = 0; i < count; ++i, ++h->cg_launched) {
         const int k = h->cg_launched, b = k & 1;
-        hipLaunchKernelGGL(k_xcg_spmv<D>, dim3(n_pq), dim3(64 * PS_XCG_ROWS), 0, h->stream, nr, h->arow_ptr, h->acol_idx,
+        hipLaunchKernelGGL((k_xcg_spmv<D, PS_XCG_ROWS, false>), dim3(n_pq), dim3(64 * PS_XCG_ROWS), 0, h->stream, nr, h->arow_ptr, h->acol_idx,
                            h->ell_wf, h->Saug, h->cg_s[0], pbuf[b ^ 1], pbuf[b], h->cg_w[0], h->cg_gd[0], n_rz, h->cg_gd[1],
-                           h->xstate, k, tol * tol, h->hist, h->status, h->scalars);
+                           h->xstate, k, tol * tol, h->hist, h->status, h->scalars, XcgRestrictArgs{});
         hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode,
                            h->pw0, h->pw1, h->Bmat, h->cg_r[b], h->cg_r[b ^ 1], h->cg_w[0], pbuf[b], h->cg_xh, h->cg_gd[1],
                            n_pq, h->xstate, k, h->tvec, h->status);

@@ -13,7 +13,17 @@
 // border of ncb blocks through every row (C2: 60 -> 11 blocks per row, 100 -> ~28 us per iteration).
 // xstate: [1] threshold, [2] r0.z0, [4 + parity] r.z of iteration k (double-buffered by parity)
 // ---------------------------------------------------------------------------
-#define PS_XCG_ROWS 4                         // rows (waves) per workgroup of the SpMV
+// Three-launch form (default when every SpMV workgroup touches at most PS_XCG_NSLOT coarse nodes): the restriction
+// is linear, so t = P^T r follows the recurrence t -= alpha P^T q, and P^T q falls out of the SpMV's epilogue:
+//   k_xcg_spmv<.., RT>   ... + per-workgroup pieces of P^T q (one record per (workgroup, node), a node's records contiguous)
+//   k_xcg_coarse_rt      alpha, t = t_old - alpha sum(records) (every workgroup, in LDS; workgroup 0 keeps it), y = A_c^-1 t
+//   k_xcg_prolong_rt     alpha, r -= alpha q, x += alpha p, z = r + P y, partials of r.z
+// t is a recurrence beside r: rounding lets it drift from P^T r by ~1e-16 |t_0| -- that perturbs only what the
+// preconditioner is applied TO (r.z and the residual test use the true r and z), not the solution.
+#define PS_XCG_ROWS 4                         // rows (waves) per workgroup of the SpMV, four-launch form
+#define PS_XCG_ROWS_RT 8                      // ... three-launch form (4 / 8 / 16 measured: C2 4.40 / 4.29 / 4.44 ms, C4 2.20 / 2.15 / 2.22)
+#define PS_XCG_NSLOT 4                        // coarse nodes one SpMV workgroup may touch in the three-launch form
+#define PS_XCG_CROWS 8                        // rows of A_c^-1 per workgroup of k_xcg_coarse_rt
 #define PS_XCG_DROWS 256                      // rows per workgroup of the prolongation
 
 PS_DEV double xcg_total(const double* __restrict__ part, int n, double* lds) {
@@ -22,16 +32,26 @@ PS_DEV double xcg_total(const double* __restrict__ part, int n, double* lds) {
     return block_sum(v, lds);
 }
 
-template <int D>
-__global__ __launch_bounds__(64 * PS_XCG_ROWS) void k_xcg_spmv(
+struct XcgRestrictArgs {                      // three-launch form only (RT)
+    const double* Bmat; const int32_t* pnode; const double* pw0; const double* pw1;
+    const int32_t* wg_out;                    // [workgroup][PS_XCG_NSLOT]: record index of node (first node of the workgroup + slot), -1 none
+    double* tq_part;                          // records of D doubles
+};
+
+// (Requesting a row's first sixteen blocks and their vector entries ahead of the workgroup-wide sum of r.z was measured:
+// 106 VGPRs instead of 58 halve the occupancy and the kernel goes from 11 to 16 us at C2 and C4 -- all 10 000 waves
+// resident at once hide the dependent loads better than a shorter chain in fewer waves.)
+template <int D, int ROWS, bool RT>
+__global__ __launch_bounds__(64 * ROWS) void k_xcg_spmv(
     int nr, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx, int wf,
     const double* __restrict__ S, const double* __restrict__ z, const double* __restrict__ p_old,
     double* __restrict__ p_new, double* __restrict__ q, const double* __restrict__ rz_part, int n_rz,
     double* __restrict__ pq_part, double* __restrict__ xstate, int k, double tol2,
-    double* __restrict__ hist, int32_t* __restrict__ status, double* __restrict__ scalars)
+    double* __restrict__ hist, int32_t* __restrict__ status, double* __restrict__ scalars, XcgRestrictArgs ra)
 {
     __shared__ double lds[16];
-    __shared__ double wpq[PS_XCG_ROWS];
+    __shared__ double wpq[ROWS];
+    __shared__ double cw[RT ? ROWS : 1][PS_XCG_NSLOT][D];
     constexpr int DD = D * D;
     const int done = status[ST_PCG_DONE];
     // r.z of the previous iteration sits in the slot of the other parity: workgroup 0 of THIS launch writes
@@ -51,12 +71,27 @@ __global__ __launch_bounds__(64 * PS_XCG_ROWS) void k_xcg_spmv(
         if (k == 0) { xstate[1] = thresh; xstate[2] = rz; scalars[SC_RR0] = rz; }
     }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * PS_XCG_ROWS + w;
+    const int row = blockIdx.x * ROWS + w;
+    const int kk = lane >> 3, r = lane & 7;
     double pq = 0.0;
+    // RT: the row's basis block (one entry per lane), hat weights, nodes -- requested here, first USED after the row's
+    // product (a difference of the two node numbers taken here would wait for them before the first matrix load)
+    double bl = 0.0, rw0 = 0.0, rw1 = 0.0;
+    int prow = 0, pfirst = 0, rout = -1;
+    constexpr bool rt = RT;
+    if (rt) {
+        if (threadIdx.x < PS_XCG_NSLOT * D) rout = ra.wg_out[blockIdx.x * PS_XCG_NSLOT + threadIdx.x / D];
+        if (lane < PS_XCG_NSLOT * D) (&cw[w][0][0])[lane] = 0.0;
+        if (row < nr) {
+            // lane 8 m + a holds B[a][m]: column m of the basis block in one aligned group of eight lanes
+            if (r < D && kk < D) bl = ra.Bmat[(size_t)row * DD + r * D + kk];
+            const int urow = __builtin_amdgcn_readfirstlane(row);      // wave-uniform: scalar loads, no VGPRs held across the row loop
+            prow = ra.pnode[urow]; pfirst = ra.pnode[blockIdx.x * ROWS]; rw0 = ra.pw0[urow]; rw1 = ra.pw1[urow];
+        }
+    }
     if (row < nr) {
         const int rbeg = wf > 0 ? row * wf : row_ptr[row];
         const int rend = wf > 0 ? rbeg + wf : row_ptr[row + 1];
-        const int kk = lane >> 3, r = lane & 7;
         double acc = 0.0;
         if (r < D) {
             for (int b = rbeg + kk; b < rend; b += 8) {
@@ -76,14 +111,34 @@ __global__ __launch_bounds__(64 * PS_XCG_ROWS) void k_xcg_spmv(
             p_new[i] = pn; q[i] = acc;
         }
         pq = wave_sum(lane < D ? pn * acc : 0.0);
+        if (rt) {                                           // c = B_i^T q_i, weighted into the row's two nodes
+            double v = bl * acc;                            // B[a][m] q[a] (after the xor-shuffles every lane 8 kk + a holds q[a]); 0 where a >= D or m >= D
+            v = dpp_shift_add<0x111, 0xf, 0xf>(v);          // row_shr:1
+            v = dpp_shift_add<0x112, 0xf, 0xf>(v);          // row_shr:2
+            v = dpp_shift_add<0x114, 0xf, 0xa>(v);          // row_shr:4 into banks 1 and 3: lane 8 m + 7 = c[m]
+            const int rslot = prow - pfirst;
+            if (r == 7 && kk < D) {
+                cw[w][rslot][kk] = rw0 * v;
+                if (rslot + 1 < PS_XCG_NSLOT) cw[w][rslot + 1][kk] = rw1 * v;
+            }
+        }
     }
     if (lane == 0) wpq[w] = pq;
     __syncthreads();
     if (threadIdx.x == 0) {
         double v = 0.0;
 #pragma unroll
-        for (int ww = 0; ww < PS_XCG_ROWS; ++ww) v += wpq[ww];
+        for (int ww = 0; ww < ROWS; ++ww) v += wpq[ww];
         pq_part[blockIdx.x] = v;
+    }
+    if (rt && threadIdx.x < PS_XCG_NSLOT * D) {
+        const int o = rout;
+        if (o >= 0) {
+            double v = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < ROWS; ++ww) v += (&cw[ww][0][0])[threadIdx.x];
+            ra.tq_part[(size_t)o * D + threadIdx.x % D] = v;
+        }
     }
 }
 
@@ -247,6 +302,149 @@ __global__ __launch_bounds__(PS_XCG_DROWS) void k_xcg_prolong(
             for (int m = 0; m < D; ++m) v += B[a * D + m] * yy[m];
             z[e] = v;
             rz += r[e] * v;
+        }
+    }
+    rz = block_sum(rz, lds);
+    if (threadIdx.x == 0) rz_part[blockIdx.x] = rz;
+}
+
+// three-launch form: alpha, t = t_old - alpha P^T q from the SpMV's records (every workgroup forms all of t in LDS --
+// a few records per entry, L2-resident), then CROWS rows of y = A_c^-1 t, one wave per row
+template <int D>
+__global__ __launch_bounds__(64 * PS_XCG_CROWS) void k_xcg_coarse_rt(
+    int nc, const float* __restrict__ Ainv, const double* __restrict__ t_old, double* __restrict__ t_new,
+    const int32_t* __restrict__ nptr, const double* __restrict__ tq_part, const double* __restrict__ pq_part, int n_pq,
+    const double* __restrict__ xstate, int k, double* __restrict__ y, const int32_t* __restrict__ status)
+{
+    constexpr int NT = 64 * PS_XCG_CROWS, NE = (256 * D + NT - 1) / NT, NA = (256 * D + 127) / 128;
+    __shared__ double lds[16];
+    __shared__ double tl[256 * D];
+    // every load that does not depend on another one is issued up front: two memory round trips, not five
+    const int done = status[ST_PCG_DONE];
+    const double rz = xstate[4 + (k & 1)];
+    double pqv = 0.0;
+    for (int i = threadIdx.x; i < n_pq; i += NT) pqv += pq_part[i];
+    const int row = blockIdx.x * PS_XCG_CROWS + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool even = (nc & 1) == 0;
+    const float* a = Ainv + (size_t)(row < nc ? row : 0) * nc;
+    float2 av[NA];
+    if (even) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int j = 2 * lane + 128 * u;
+            av[u] = (j < nc) ? *reinterpret_cast<const float2*>(a + j) : make_float2(0.f, 0.f);
+        }
+    }
+    int lo[NE], hi[NE];
+    double to[NE], sq[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int e = threadIdx.x + u * NT;
+        const int n = e / D;
+        lo[u] = hi[u] = 0; to[u] = 0.0;
+        if (e < nc) { lo[u] = nptr[n]; hi[u] = nptr[n + 1]; to[u] = t_old[e]; }
+    }
+    // a node's records in batches of four independent loads (a plain loop waits out one memory latency per record)
+#pragma unroll
+    for (int u = 0; u < NE; ++u) sq[u] = 0.0;
+    for (int base = 0;; base += 4) {
+        bool any = false;
+        double rec[NE][4];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int m = (threadIdx.x + u * NT) % D;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = lo[u] + base + c;
+                rec[u][c] = (j < hi[u]) ? tq_part[(size_t)j * D + m] : 0.0;
+            }
+            any = any || (lo[u] + base + 4 < hi[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sq[u] += rec[u][c];
+        if (!__syncthreads_or(any)) break;
+    }
+    const double pq = block_sum(pqv, lds);
+    if (done) return;
+    const double alpha = rz / pq;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int e = threadIdx.x + u * NT;
+        if (e < nc) {
+            const double tn = to[u] - alpha * sq[u];
+            tl[e] = tn;
+            if (blockIdx.x == 0) t_new[e] = tn;
+        }
+    }
+    __syncthreads();
+    if (row >= nc) return;
+    double v = 0.0;
+    if (even) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int j = 2 * lane + 128 * u;
+            if (j < nc) v += (double)av[u].x * tl[j] + (double)av[u].y * tl[j + 1];
+        }
+    } else {
+        for (int j = lane; j < nc; j += 64) v += (double)a[j] * tl[j];
+    }
+    v = wave_sum(v);
+    if (lane == 0) y[row] = v;
+}
+
+template <int D>
+__global__ __launch_bounds__(PS_XCG_DROWS) void k_xcg_prolong_rt(
+    int nr, int ncb, const int32_t* __restrict__ pnode, const double* __restrict__ pw0, const double* __restrict__ pw1,
+    const double* __restrict__ Bmat, const double* __restrict__ r_old, double* __restrict__ r_new,
+    const double* __restrict__ qv, const double* __restrict__ p, double* __restrict__ x,
+    const double* __restrict__ pq_part, int n_pq, const double* __restrict__ xstate, int k,
+    const double* __restrict__ y, double* __restrict__ z, double* __restrict__ rz_part, const int32_t* __restrict__ status)
+{
+    __shared__ double lds[16];
+    const int done = status[ST_PCG_DONE];
+    const double rzk = xstate[4 + (k & 1)];
+    double pqv = 0.0;
+    for (int i = threadIdx.x; i < n_pq; i += PS_XCG_DROWS) pqv += pq_part[i];
+    const int i = blockIdx.x * PS_XCG_DROWS + threadIdx.x;
+    const bool live = i < nr;
+    // (all of the row's inputs are loaded before the workgroup-wide sum of p.q, whose barriers would otherwise
+    // serialise them behind it)
+    double ro[D], qo[D], po[D], xo[D], B[D * D], yy[D];
+    if (live) {
+        const int n0 = pnode[i];
+        const double w0 = pw0[i], w1 = pw1[i];
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const size_t e = (size_t)i * D + a;
+            ro[a] = r_old[e]; qo[a] = qv[e]; po[a] = p[e]; xo[a] = x[e];
+        }
+#pragma unroll
+        for (int a = 0; a < D * D; ++a) B[a] = Bmat[(size_t)i * D * D + a];
+#pragma unroll
+        for (int m = 0; m < D; ++m) yy[m] = w0 * y[n0 * D + m] + ((n0 + 1 < ncb) ? w1 * y[(n0 + 1) * D + m] : 0.0);
+    }
+    const double pq = block_sum(pqv, lds);
+    if (done) return;
+    const double alpha = rzk / pq;
+    double rz = 0.0;
+    if (live) {
+        double rn[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const size_t e = (size_t)i * D + a;
+            rn[a] = ro[a] - alpha * qo[a];
+            r_new[e] = rn[a];
+            x[e] = xo[a] + alpha * po[a];
+        }
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            double v = rn[a];
+#pragma unroll
+            for (int m = 0; m < D; ++m) v += B[a * D + m] * yy[m];
+            z[(size_t)i * D + a] = v;
+            rz += rn[a] * v;
         }
     }
     rz = block_sum(rz, lds);

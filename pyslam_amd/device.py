@@ -219,6 +219,12 @@ class DeviceProblem:
         nat.check(self._lib.ps_get_info(self._h, C.byref(info)))
         return int(info.cg_restarts)
 
+    def cg_kernel_launches(self):
+        """Kernels enqueued for iterations of the reduced solve so far (ps_problem_info.cg_kernel_launches)."""
+        info = nat.ProblemInfo()
+        nat.check(self._lib.ps_get_info(self._h, C.byref(info)))
+        return int(info.cg_kernel_launches)
+
     def set_option(self, name, value):
         nat.check(self._lib.ps_set_option(self._h, name.encode(), float(value)))
 

@@ -422,3 +422,37 @@ def test_streaming_schur_kernel_builds_the_same_reduced_system(monkeypatch):
         dev.close()
     assert np.array_equal(out[0][2], out[1][2])
     assert np.abs(out[0][2] - vals).max() <= 1e-12 * np.abs(vals).max() and np.array_equal(out[0][3], g)
+
+
+@pytest.mark.parametrize('shape', ['ba', 'pg_se3', 'pg_se2'])
+def test_explicit_pcg_three_launch_form_equals_the_four_launch_form(shape):
+    """Explicit two-level PCG: the restriction folded into the SpMV epilogue + the recurrence t -= alpha P^T q (three
+    launches per iteration) against the separate restriction kernel (four): same iterations, same step; and the launch
+    counter shows which form ran."""
+    if shape == 'ba':
+        lp, _ = synthetic.stereo_ba(160, 16000, 8, 12, seed=11)
+    else:
+        lp, _ = synthetic.pose_graph(num_poses=700, num_loops=2801, dof=6 if shape == 'pg_se3' else 3, seed=12)
+    out = {}
+    for fused in (1, 0):
+        dev = device(lp)
+        dev.set_option('cg_explicit_min_rows', 0)
+        dev.set_option('cg_split_min_rows', 0)
+        if shape == 'ba':
+            dev.set_option('coarse_groups', 10)        # (the automatic 48 intervals of 3 rows are too short for the fused form)
+        dev.set_option('xcg_restrict_fused', fused)
+        n0 = dev.cg_kernel_launches()
+        res = [dev.gn_iteration(0., 1e-12, 3000, True) for _ in range(3)]
+        # launches per CG iteration of the LAST call (count = iterations of the previous call + 2 when it sufficed)
+        out[fused] = (res, dev.get_dx(), dev.get_params(), dev.cg_kernel_launches() - n0)
+    (r1, dx1, p1, n1), (r0, dx0, p0, n0) = out[1], out[0]
+    # (an iteration count may differ by one between the forms when r.z ends next to the threshold)
+    assert n1 % 3 == 0 and n0 % 4 == 0 and abs(n1 // 3 - n0 // 4) <= 6, (n1, n0)
+    for a, b in zip(r1, r0):
+        assert abs(a[2] - b[2]) <= 2 and abs(a[0] - b[0]) <= 1e-10 * abs(b[0]) and a[3] <= 1e-12, (a, b)
+    for a, b in zip(dx1, dx0):
+        if a.size:
+            assert np.linalg.norm(a - b) <= 1e-8 * np.linalg.norm(b)
+    for a, b in zip(p1, p0):
+        if a.size:
+            assert np.abs(a - b).max() <= 1e-8
