@@ -24,6 +24,9 @@
 #define PS_XCG_ROWS_RT 8                      // ... three-launch form (4 / 8 / 16 measured: C2 4.40 / 4.29 / 4.44 ms, C4 2.20 / 2.15 / 2.22)
 #define PS_XCG_NSLOT 4                        // coarse nodes one SpMV workgroup may touch in the three-launch form
 #define PS_XCG_CROWS 8                        // rows of A_c^-1 per workgroup of k_xcg_coarse_rt
+#ifndef PS_XCG_RBATCH
+#define PS_XCG_RBATCH 6                       // records of a node loaded together by k_xcg_coarse_rt
+#endif
 #define PS_XCG_DROWS 256                      // rows per workgroup of the prolongation
 
 PS_DEV double xcg_total(const double* __restrict__ part, int n, double* lds) {
@@ -344,26 +347,26 @@ __global__ __launch_bounds__(64 * PS_XCG_CROWS) void k_xcg_coarse_rt(
         lo[u] = hi[u] = 0; to[u] = 0.0;
         if (e < nc) { lo[u] = nptr[n]; hi[u] = nptr[n + 1]; to[u] = t_old[e]; }
     }
-    // a node's records in batches of four independent loads (a plain loop waits out one memory latency per record)
+    // a node's records in batches of PS_XCG_RBATCH independent loads (a plain loop waits out one memory latency per record)
 #pragma unroll
     for (int u = 0; u < NE; ++u) sq[u] = 0.0;
-    for (int base = 0;; base += 4) {
+    for (int base = 0;; base += PS_XCG_RBATCH) {
         bool any = false;
-        double rec[NE][4];
+        double rec[NE][PS_XCG_RBATCH];
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
             const int m = (threadIdx.x + u * NT) % D;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < PS_XCG_RBATCH; ++c) {
                 const int j = lo[u] + base + c;
                 rec[u][c] = (j < hi[u]) ? tq_part[(size_t)j * D + m] : 0.0;
             }
-            any = any || (lo[u] + base + 4 < hi[u]);
+            any = any || (lo[u] + base + PS_XCG_RBATCH < hi[u]);
         }
 #pragma unroll
         for (int u = 0; u < NE; ++u)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) sq[u] += rec[u][c];
+            for (int c = 0; c < PS_XCG_RBATCH; ++c) sq[u] += rec[u][c];
         if (!__syncthreads_or(any)) break;
     }
     const double pq = block_sum(pqv, lds);
