@@ -168,7 +168,7 @@ def trajectory(dev, iters=5):
                                    'ps_gn_iteration call (each call ends with its one synchronisation)'.format(iters)}
 
 
-def c4_single_gpu(stream, steps=5, warmup=2):
+def c4_single_gpu(stream, steps=10, warmup=5):
     """The unsharded C4 problem on the current GPU: steady-state ms per iteration + stage breakdown."""
     import torch
     from pyslam_amd import synthetic
