@@ -715,7 +715,7 @@ int linearize(ps_problem* h, double lambda) {
     if (h->npitems > 0) {
         StageTimer t(h, PS_ST_POSE);
         hipLaunchKernelGGL(k_pose_pass, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
-                           h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial);
+                           h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0);
         // tiled Schur: the combine launch also finalizes the poses (unless a task writes a diagonal block)
         fin_in_combine = (h->Spart || h->use_stream) && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6;
         if (!fin_in_combine)

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
         const Se3 T = se3_load(poses + 12 * pose);
         rid_of_obs = pose_rid[pose];
         variable_pose = rid_of_obs >= 0;
-        reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        reproj_eval_grp<true, true>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
         have = true;
         const double* J = ev.Jl;
 #pragma unroll
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
         if (rid < 0 || (ablate & 1)) continue;
         if (!single) {
             const Se3 T = se3_load(poses + 12 * pose);
-            reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+            reproj_eval_grp<true, true>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
         }
         lm_emit_m(ev, M00, M10, M11, M20, M21, M22, z);
         z[9] = ev.pc[0]; z[10] = ev.pc[1]; z[11] = ev.pc[2];
@@ -198,6 +198,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
 // scattered: that read alone cost 15 of this kernel's 37 us): it is recomputed in registers from
 // the Jacobians this kernel evaluates anyway and the landmark's 48-byte factor C^-1 (an L2-resident
 // table) -- lm_emit_m + zrow_expand on the same inputs, so the values are those every consumer of the stored row forms.
+// acc (upper triangle of a symmetric 6 x 6, row by row: 21 entries) += K^T E K with K = [I | -pc^] and E symmetric 3 x 3
+// (e = 00 01 02 11 12 22):  [[E, F], [F^T, H]],  F = -E pc^,  H = pc^ F
+PS_DEV void pose_sandwich(const double* __restrict__ e, const double* __restrict__ pc, double* __restrict__ acc) {
+    const double x = pc[0], y = pc[1], z = pc[2];
+    const double E[3][3] = {{e[0], e[1], e[2]}, {e[1], e[3], e[4]}, {e[2], e[4], e[5]}};
+    double F[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        F[i][0] = E[i][2] * y - E[i][1] * z;
+        F[i][1] = E[i][0] * z - E[i][2] * x;
+        F[i][2] = E[i][1] * x - E[i][0] * y;
+    }
+    acc[0] += e[0]; acc[1] += e[1]; acc[2] += e[2]; acc[3] += F[0][0]; acc[4] += F[0][1]; acc[5] += F[0][2];
+    acc[6] += e[3]; acc[7] += e[4]; acc[8] += F[1][0]; acc[9] += F[1][1]; acc[10] += F[1][2];
+    acc[11] += e[5]; acc[12] += F[2][0]; acc[13] += F[2][1]; acc[14] += F[2][2];
+    acc[15] += y * F[2][0] - z * F[1][0];
+    acc[16] += y * F[2][1] - z * F[1][1];
+    acc[17] += y * F[2][2] - z * F[1][2];
+    acc[18] += z * F[0][1] - x * F[2][1];
+    acc[19] += z * F[0][2] - x * F[2][2];
+    acc[20] += x * F[1][2] - y * F[0][2];
+}
+
 #define PS_NPOSE_ACC 33
 #ifndef PS_POSE_TRANSPOSE
 #define PS_POSE_TRANSPOSE 1
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_POSE_WAV
     const LObs* __restrict__ pobs /* observation records in pose order, landmark slot + 1 in the pose bits */,
     const double* __restrict__ poses, const double* __restrict__ points,
     const ObsGroup* __restrict__ groups, const double* __restrict__ Cinv,
-    const double* __restrict__ cvec, double* __restrict__ partial)
+    const double* __restrict__ cvec, double* __restrict__ partial, int want_diag /* lambda != 0: the six damping sums too */)
 {
     __shared__ double red[4][PS_NPOSE_ACC];
 #if PS_POSE_TRANSPOSE
@@ -237,32 +260,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_POSE_WAV
             c0 = cvec[3 * (size_t)v]; c1 = cvec[3 * (size_t)v + 1]; c2 = cvec[3 * (size_t)v + 2];
         }
         ReprojEval ev;
-        reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
-        int n = 0;
+        reproj_eval_grp<true, true>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);   // (only the translational columns of J~p = A are used below)
+        // J~p = A K with K = [I | -pc^], and Z = K^T M: the observation's contribution is the 3 x 3 sandwich
+        //   J~p^T J~p - Z Z^T = K^T (A^T A - M M^T) K,      -J~p^T r~ - Z c = -K^T (A^T r~ + M c)
+        // -- 160 multiply-adds instead of the 290 of the two 6 x 6 products formed entry by entry
+        double G[6], t3[3];                                  // G = A^T A (00 01 02 11 12 22), t = A^T r~ (+ M c)
+        {
+            const double* J = ev.Jp;
+            G[0] = J[0] * J[0] + J[6] * J[6] + J[12] * J[12];
+            G[1] = J[0] * J[1] + J[6] * J[7] + J[12] * J[13];
+            G[2] = J[0] * J[2] + J[6] * J[8] + J[12] * J[14];
+            G[3] = J[1] * J[1] + J[7] * J[7] + J[13] * J[13];
+            G[4] = J[1] * J[2] + J[7] * J[8] + J[13] * J[14];
+            G[5] = J[2] * J[2] + J[8] * J[8] + J[14] * J[14];
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+            for (int a = 0; a < 3; ++a) t3[a] = J[a] * ev.r[0] + J[6 + a] * ev.r[1] + J[12 + a] * ev.r[2];
+        }
+        if (want_diag) {                                     // diag(J~p^T J~p) for Marquardt damping: the sandwich of G alone
+            double d21[21];
 #pragma unroll
-            for (int b = a; b < 6; ++b)
-                acc[n++] += ev.Jp[a] * ev.Jp[b] + ev.Jp[6 + a] * ev.Jp[6 + b] + ev.Jp[12 + a] * ev.Jp[12 + b];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            acc[21 + a] -= ev.Jp[a] * ev.r[0] + ev.Jp[6 + a] * ev.r[1] + ev.Jp[12 + a] * ev.r[2];
-            acc[27 + a] += ev.Jp[a] * ev.Jp[a] + ev.Jp[6 + a] * ev.Jp[6 + a] + ev.Jp[12 + a] * ev.Jp[12 + a];
+            for (int k = 0; k < 21; ++k) d21[k] = 0.0;
+            pose_sandwich(G, ev.pc, d21);
+            acc[27] += d21[0]; acc[28] += d21[6]; acc[29] += d21[11]; acc[30] += d21[15]; acc[31] += d21[18]; acc[32] += d21[20];
         }
         if (v >= 0) {
-            double m9[9], z[18];
+            double m9[9];
             lm_emit_m(ev, m[0], m[1], m[2], m[3], m[4], m[5], m9);
-            zrow_expand(m9, ev.pc, z);
-            n = 0;
+            G[0] -= m9[0] * m9[0] + m9[1] * m9[1] + m9[2] * m9[2];
+            G[1] -= m9[0] * m9[3] + m9[1] * m9[4] + m9[2] * m9[5];
+            G[2] -= m9[0] * m9[6] + m9[1] * m9[7] + m9[2] * m9[8];
+            G[3] -= m9[3] * m9[3] + m9[4] * m9[4] + m9[5] * m9[5];
+            G[4] -= m9[3] * m9[6] + m9[4] * m9[7] + m9[5] * m9[8];
+            G[5] -= m9[6] * m9[6] + m9[7] * m9[7] + m9[8] * m9[8];
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b)
-                    acc[n++] -= z[3 * a] * z[3 * b] + z[3 * a + 1] * z[3 * b + 1] + z[3 * a + 2] * z[3 * b + 2];
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-                acc[21 + a] -= z[3 * a] * c0 + z[3 * a + 1] * c1 + z[3 * a + 2] * c2;
+            for (int a = 0; a < 3; ++a) t3[a] += m9[3 * a] * c0 + m9[3 * a + 1] * c1 + m9[3 * a + 2] * c2;
         }
+        pose_sandwich(G, ev.pc, acc);
+        acc[21] -= t3[0]; acc[22] -= t3[1]; acc[23] -= t3[2];
+        acc[24] -= ev.pc[1] * t3[2] - ev.pc[2] * t3[1];
+        acc[25] -= ev.pc[2] * t3[0] - ev.pc[0] * t3[2];
+        acc[26] -= ev.pc[0] * t3[1] - ev.pc[1] * t3[0];
     }
 #if PS_POSE_TRANSPOSE
     // 33 sums over the wave's 64 lanes through LDS: every lane stores its accumulators ([lane][17], two halves), lane k

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
         const LObs o = pobs[i];
         const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
         ReprojEval ev;
-        reproj_eval<true, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        reproj_eval_grp<true, false>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
         int n = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
             const LObs o = pobs[i];
             const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
             ReprojEval ev;
-            reproj_eval<false, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+            reproj_eval_grp<false, false>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
             c += ev.cost;
         }
         c = wave_sum(c);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_cost_reproj(
         const Se3 T = se3_load(poses + 12 * pose);
         const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
         ReprojEval ev;
-        reproj_eval<false, false>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+        reproj_eval_grp<false, false>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
         c += ev.cost;
     }
     c = block_sum(c, lds);
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_debug_reproj(
     const Se3 T = se3_load(poses + 12 * PS_POSE_OF(o));
     const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
     ReprojEval ev;
-    reproj_eval<true, true>(T, pw, &o.u, groups[PS_GRP_OF(o)], ev);
+    reproj_eval_grp<true, true>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
     const size_t k = (size_t)lorig[i];
     for (int a = 0; a < 3; ++a) r[3 * k + a] = ev.r[a];
     for (int a = 0; a < 18; ++a) jp[18 * k + a] = ev.Jp[a];

@@ -333,3 +333,16 @@ PS_DEV void reproj_eval(const Se3& T, const double* __restrict__ pw, const doubl
                 o.Jl[3 * i + j] = SJ[3 * i] * T.R[j] + SJ[3 * i + 1] * T.R[3 + j] + SJ[3 * i + 2] * T.R[6 + j];
     }
 }
+
+// The (camera, stiffness, loss) group of an observation is almost always the same for a whole wave: it is read through
+// a wave-uniform index -- scalar loads into SGPRs instead of 17 per-lane loads of the same 128 bytes into 34 VGPRs.
+// Mixed waves go round a waterfall loop, one pass per distinct group (the lanes of the first active lane's group
+// evaluate and leave), so there is ONE copy of the evaluation and it never holds a group in vector registers.
+template <bool WITH_JP, bool WITH_JL>
+PS_DEV void reproj_eval_grp(const Se3& T, const double* __restrict__ pw, const double* __restrict__ uvd,
+                            const ObsGroup* __restrict__ groups, int grp, ReprojEval& o) {
+    for (;;) {
+        const int g0 = __builtin_amdgcn_readfirstlane(grp);
+        if (grp == g0) { reproj_eval<WITH_JP, WITH_JL>(T, pw, uvd, groups[g0], o); break; }
+    }
+}
