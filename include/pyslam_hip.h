@@ -216,6 +216,8 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /
                               next side-stream factorisation (landmark-sharded runs whose iteration is shorter than that factorisation)
      "xcg_restrict_fused" [1] explicit two-level PCG: three launches per iteration (restriction in the SpMV epilogue, t by recurrence)
                               instead of four
+     "band_chol"          [1] explicit two-level PCG: banded factorisation + band substitutions for the coarse inverse when A_c
+                              has at most 7 block off-diagonals (chain-like problems); 0: always the dense factorisation
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual
      "cg_lds", "profile_every", "big_chol", "cg_margin", "pcg_chunk", "cg_split_min_rows", "cg_explicit_min_rows": implementation switches (see ps_set_option in csrc/ps_abi_solver.h)
      "cg_ablate", "schur_ablate", "lm_ablate": timing experiments only (results are wrong under ablation) */

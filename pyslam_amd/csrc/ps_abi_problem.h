@@ -23,7 +23,7 @@ int ps_problem_destroy(ps_problem* h) {
     if (h->h_seq) hipHostFree(h->h_seq);
     if (h->h_shard) hipHostFree(h->h_shard);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
-    if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); }
+    if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); hipEventDestroy(h->ev_acdone); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;

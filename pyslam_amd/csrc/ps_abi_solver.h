@@ -443,6 +443,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_force_restart") h->cg_force_restart = value != 0.0;
     else if (n == "xcg_restrict_fused") h->xcg_rt = value != 0;
+    else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
     else if (n == "coarse_refresh_every") { if (value < 1 || value > 16) return fail("coarse_refresh_every must be 1..16"); h->xcg_refresh_every = (int)value; }
     else if (n == "coarse_lag_x") { h->lagx = value != 0.0; h->lci_next = -1; h->side_todo = false; }
     else if (n == "cg_lds") h->cg_lds = value != 0.0;

@@ -146,7 +146,8 @@ struct ps_problem {
     bool side_pending = false;      // a side-stream factorisation is in flight: wait for ev_chol before reuse
     int coarse_lag = 1;
     hipStream_t side = nullptr;
-    hipEvent_t ev_ac = nullptr, ev_chol = nullptr;
+    hipEvent_t ev_ac = nullptr, ev_chol = nullptr, ev_acdone = nullptr;
+    bool acdone_pending = false;    // explicit PCG: the side stream may still be assembling A_c from SB / the basis (wait before they are overwritten)
     int32_t* lag_status = nullptr;  // ST_DIAG_FAIL of the side-stream factorisation
     double* Mc = nullptr;           // split mode: dense coarse-coarse block M of the lagged system
     bool mc_active = false;         // the current system was built with a lagged factor in split mode
@@ -165,6 +166,10 @@ struct ps_problem {
     int xcg_refresh_every = 1;      // option "coarse_refresh_every": lagged set-ups between two refreshes of the coarse inverse
     long xcg_lag_count = 0;
     double *xstate = nullptr, *xy = nullptr, *xp2 = nullptr;
+    // ... banded coarse matrix (ps_k_band.h): block off-diagonals of A_c (-1: not banded enough), band factor by rows / columns
+    int ac_bw = -1;
+    int band_chol = 1;              // option "band_chol"
+    double *Lrow = nullptr, *Lcol = nullptr, *rdiag = nullptr;
     // ... three-launch form (restriction folded into the SpMV epilogue + a recurrence for t)
     int xcg_rt = 1;                 // option "xcg_restrict_fused"
     bool xcg_rt_ok = false;         // every SpMV workgroup touches at most PS_XCG_NSLOT coarse nodes

@@ -297,6 +297,12 @@ int build_coarse(ps_problem* h) {
                     const int32_t at = pos[(size_t)q * ncb + eq[e]]++;
                     sent[at] = e; srow[at] = i;
                 }
+        // block off-diagonals of A_c = P^T S^ P: (q, q') is non-zero iff some row of supp(q) has a run in supp(q')
+        h->ac_bw = 0;
+        for (int q = 0; q < ncb; ++q)
+            for (int q2 = 0; q2 < ncb; ++q2)
+                if (sptr[(size_t)q * ncb + q2 + 1] > sptr[(size_t)q * ncb + q2]) h->ac_bw = std::max(h->ac_bw, std::abs(q - q2));
+        if (h->ac_bw > PS_BAND_MAXB) h->ac_bw = -1;
         if (h->upload(&h->ent_ptr, eptr) || h->upload(&h->ent_q, eq) || h->upload(&h->ent_lo, elo) ||
             h->upload(&h->ent_hi, ehi) || h->upload(&h->seg_ptr, sptr) || h->upload(&h->seg_ent, sent) ||
             h->upload(&h->seg_row, srow)) return -1;
@@ -327,6 +333,8 @@ int build_coarse(ps_problem* h) {
         h->alloc(&h->Lci2[1], (size_t)h->nc * h->nc) || h->alloc(&h->LciT2[1], (size_t)h->nc * h->nc) ||
         h->alloc(&h->tvec, (size_t)h->nc) || h->alloc(&h->chol_scratch, 2 * (size_t)h->nc * h->nc)) return -1;
     if (h->cg_explicit && (h->alloc(&h->xstate, 8) || h->alloc(&h->xy, (size_t)h->nc) || h->alloc(&h->xp2, (size_t)nr * D))) return -1;
+    if (h->cg_explicit && h->ac_bw >= 0 &&
+        (h->alloc(&h->Lrow, (size_t)h->nc * PS_BAND_W) || h->alloc(&h->Lcol, (size_t)h->nc * PS_BAND_W) || h->alloc(&h->rdiag, (size_t)h->nc))) return -1;
     h->xcg_rt_ok = false;
     if (h->cg_explicit && ncb <= 256) {
         // three-launch form: records of P^T q per (SpMV workgroup, node it touches), a node's records contiguous and in
@@ -363,9 +371,11 @@ int build_coarse(ps_problem* h) {
         HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIP_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
         HIP_OK(hipEventCreateWithFlags(&h->ev_ac, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_acdone, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&h->ev_chol, hipEventDisableTiming));
     }
     if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
+    h->acdone_pending = false;                             // (recorded before ev_chol on the same stream)
     h->lci_next = -1; h->lci_cur = 0;
     if (ensure_cg_buffers(h, h->nr_aug, h->nnzb_aug)) return -1;
     HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)h->nnzb_aug * D * D * sizeof(double), h->stream));
@@ -418,6 +428,24 @@ int coarse_factor(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
         hipLaunchKernelGGL((k_coarse_chol<D, false>), dim3(1), dim3(1024), 0, st, ncb, h->Ac, h->Lci2[buf],
                            h->LciT2[buf], stat, h->chol_scratch);
     }
+    return 0;
+}
+
+// explicit two-level PCG: A_c^-1 (fp32, symmetric) into LciT2[buf] -- banded factorisation + band substitutions when A_c
+// has at most PS_BAND_MAXB block off-diagonals, the dense factorisation and k_xcg_ainv otherwise
+template <int D>
+int xcg_coarse_inverse(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
+    const int nc = h->nc;
+    if (h->band_chol && h->ac_bw >= 0) {
+        HIP_OK(hipMemsetAsync(h->Lrow, 0, (size_t)nc * PS_BAND_W * sizeof(double), st));
+        HIP_OK(hipMemsetAsync(h->Lcol, 0, (size_t)nc * PS_BAND_W * sizeof(double), st));
+        hipLaunchKernelGGL(k_band_chol<D>, dim3(1), dim3(256), 0, st, h->ncb, h->ac_bw, h->Ac, h->Lrow, h->Lcol, h->rdiag, stat);
+        hipLaunchKernelGGL(k_band_inverse, dim3(cdiv(nc, 4)), dim3(256), 0, st, nc, h->Lrow, h->Lcol, h->rdiag,
+                           h->chol_scratch, (float*)h->LciT2[buf]);
+        return 0;
+    }
+    if (coarse_factor<D>(h, st, buf, stat)) return -1;
+    hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, st, nc, h->Lci2[buf], (float*)h->LciT2[buf]);
     return 0;
 }
 

@@ -4,10 +4,22 @@
 namespace {
 
 // ---- explicit two-level PCG (long sparse chains; kernels k_xcg_*) ---------------------------------
+// A_c = P^T S^ P from the non-empty (row, node) runs
+template <int D>
+void xcg_assemble_ac(ps_problem* h, hipStream_t st) {
+    const int nr = h->nr, ncb = h->ncb;
+    hipLaunchKernelGGL(k_xcoarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(h->max_row_ents + 1) * D * D * sizeof(double), st,
+                       nr, h->ent_ptr, h->ent_q, h->ent_lo, h->ent_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->Bmat, h->BSZ);
+    hipLaunchKernelGGL(k_xcoarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, st,
+                       ncb, h->seg_ptr, h->seg_ent, h->seg_row, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
+}
+
 template <int D>
 int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     const int nr = h->nr, ncb = h->ncb, nc = h->nc;
     if (max_iters + 2 > h->hist_cap) return fail("pcg max_iters exceeds the history buffer (4096)");
+    // (the side stream assembles A_c from SB and the basis blocks of the previous lagged set-up: both are rewritten below)
+    if (h->acdone_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_acdone, 0)); h->acdone_pending = false; }
     hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 4)), dim3(256), 0, h->stream, nr, h->diag_slot,
                        h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
                        h->poses, h->pose_of_rid, h->coarse_basis, h->Bmat, h->bgv);
@@ -15,8 +27,9 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
                        h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
     // A_c^-1 lives in LciT2[b] (the transposed factor is not used on this path).  It only PRECONDITIONS here, so any
     // symmetric positive definite stand-in keeps the CG exact: whole-iteration calls use the inverse formed from the
-    // PREVIOUS iteration's A_c and factor the current one on the side stream while the CG iterates (the factorisation,
-    // triangular inverse and product are 5.6 ms of the 12 ms iteration at C2 with 256 nodes).
+    // PREVIOUS iteration's A_c and form + factor the current one on the side stream while the CG iterates (assembly,
+    // factorisation, triangular inverse and product are 5.7 ms of the 12 ms iteration at C2 with 256 nodes; the assembly
+    // alone -- k_xcoarse_rowsums + k_xcoarse_matrix -- 59 us of C4's iteration when it ran on the solver stream).
     // "coarse_refresh_every" = k > 1 (landmark-sharded runs on many GPUs, where an iteration is shorter than the side
     // stream's factorisation -- C4 on 8 GPUs: ~1.1 ms against 1.6 ms): only every k-th lagged set-up consumes the newest
     // inverse and starts the next factorisation; the set-ups in between HOLD the inverse they have, assemble no A_c and
@@ -25,25 +38,20 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     const bool hold = lag && h->xcg_refresh_every > 1 && (h->xcg_lag_count % h->xcg_refresh_every) != 0;
     const int32_t* lagst = nullptr;
     h->xcg_side_todo = false;
-    if (!hold) {
-        if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
-        hipLaunchKernelGGL(k_xcoarse_rowsums<D>, dim3(nr), dim3(256), (size_t)(h->max_row_ents + 1) * D * D * sizeof(double), h->stream,
-                           nr, h->ent_ptr, h->ent_q, h->ent_lo, h->ent_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->Bmat, h->BSZ);
-        hipLaunchKernelGGL(k_xcoarse_matrix<D>, dim3(cdiv((long)ncb * ncb * D * D, 256)), dim3(256), 0, h->stream,
-                           ncb, h->seg_ptr, h->seg_ent, h->seg_row, h->pnode, h->pw0, h->pw1, h->BSZ, h->Ac);
-    }
+    if (!hold && h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
     if (lag) {
         if (!hold) {
             h->lci_cur = h->lci_next;
-            HIP_OK(hipEventRecord(h->ev_ac, h->stream));   // A_c complete; the side work is enqueued by xcg_side_enqueue
+            if (getenv("PS_XCG_AC_MAIN")) xcg_assemble_ac<D>(h, h->stream);
+            HIP_OK(hipEventRecord(h->ev_ac, h->stream));   // SB and the basis complete; the side work is enqueued by xcg_side_enqueue
             h->xcg_side_todo = true;
             lagst = h->lag_status;
         }
         ++h->xcg_lag_count;
     } else {
+        xcg_assemble_ac<D>(h, h->stream);
         const int buf = h->lci_cur;
-        if (coarse_factor<D>(h, h->stream, buf, h->status)) return -1;
-        hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, h->stream, nc, h->Lci2[buf], (float*)h->LciT2[buf]);
+        if (xcg_coarse_inverse<D>(h, h->stream, buf, h->status)) return -1;
         h->lci_next = buf;
         h->xcg_lag_count = 0;
     }
@@ -68,8 +76,10 @@ int xcg_side_enqueue(ps_problem* h) {
     h->xcg_side_todo = false;
     const int nc = h->nc, nb = h->lci_cur ^ 1;
     HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
-    if (coarse_factor<D>(h, h->side, nb, h->lag_status)) return -1;
-    hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, h->side, nc, h->Lci2[nb], (float*)h->LciT2[nb]);
+    if (!getenv("PS_XCG_AC_MAIN")) xcg_assemble_ac<D>(h, h->side);
+    HIP_OK(hipEventRecord(h->ev_acdone, h->side));
+    h->acdone_pending = true;
+    if (xcg_coarse_inverse<D>(h, h->side, nb, h->lag_status)) return -1;
     HIP_OK(hipEventRecord(h->ev_chol, h->side));
     h->lci_next = nb; h->side_pending = true;
     return 0;

@@ -1,0 +1,205 @@
+// ps_k_band.h -- banded coarse matrix of the explicit two-level PCG: factorisation and inverse.
+// Part of ps_kernels.h (included from there; not a stand-alone header).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// On chain-like problems (sliding-window BA, pose graphs with short loop closures) the coarse matrix A_c = P^T S^ P of
+// the explicit two-level PCG is block-banded: a hat function overlaps its neighbours only, and S^ couples a pose to a
+// window of poses -- C4: 4 block off-diagonals of 101, C2: 3 of 256.  The general path factors A_c as a dense matrix
+// (25 / 64 serial panel launches + triangular inverse + merges: 1.6 ms at C4, ~4 ms at C2, on the side stream, where
+// it slowed the CG beside it and made the next set-up wait).  With at most PS_BAND_MAXB block off-diagonals:
+//   k_band_chol      ONE workgroup walks the block columns with the active (B + 1) x (B + 1) block window in LDS:
+//                    6 x 6 diagonal factor, panel L_ik = A_ik L_kk^-T, trailing update; finished block rows leave as
+//                    the scalar band of L by rows (Lrow) and by columns (Lcol), diagonal as reciprocals
+//   k_band_inverse   one WAVE per column c of A_c^-1 = L^-T L^-1: forward then backward band substitution, the last
+//                    47 unknowns in a lane-shifted register ring (lane j = j steps back), the band row one coalesced
+//                    load, the dot product a wave sum; stores (i, c) and (c, i) with the same fp32 value
+// C4: 0.15 + 0.08 ms, C2: 0.4 + 0.2 ms.
+// ---------------------------------------------------------------------------
+#define PS_BAND_MAXB 7                        // block off-diagonals (nodes): scalar half-bandwidth <= 8 D - 1 = 47
+#define PS_BAND_W 48                          // row pitch of the band arrays
+#define PS_BAND_NB (PS_BAND_MAXB + 1)
+
+template <int D>
+__global__ __launch_bounds__(256) void k_band_chol(
+    int ncb, int B, const double* __restrict__ Ac, double* __restrict__ Lrow, double* __restrict__ Lcol,
+    double* __restrict__ rdiag, int32_t* __restrict__ status)
+{
+    constexpr int DD = D * D, NB = PS_BAND_NB, W = PS_BAND_W;
+    __shared__ double Wn[NB][NB][DD];         // block (i, c) of the window at [i % NB][c % NB]
+    __shared__ double P[PS_BAND_MAXB * D][D];
+    __shared__ double Li[DD];
+    __shared__ int bad;
+    const int nc = ncb * D, t = threadIdx.x;
+    if (t == 0) bad = 0;
+    // block row i of the band (block columns i - B .. i) <-> two values per thread: requested from global memory at the
+    // start of a step, stored into the window at its end (the slot is in use until then)
+    constexpr int NPRE = (PS_BAND_NB * DD + 255) / 256;
+    auto fetch_row = [&](int i, double* v) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int e = t + u * 256;
+            const int cb = i - B + e / DD, rr = (e % DD) / D, cc = e % D;
+            v[u] = (i < ncb && e < (B + 1) * DD && cb >= 0) ? Ac[(size_t)(i * D + rr) * nc + cb * D + cc] : 0.0;
+        }
+    };
+    auto store_row = [&](int i, const double* v) {
+        if (i >= ncb) return;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int e = t + u * 256;
+            const int cb = i - B + e / DD;
+            if (e < (B + 1) * DD && cb >= 0) Wn[i % NB][cb % NB][e % DD] = v[u];
+        }
+    };
+    for (int i = 0; i <= B; ++i) { double v[NPRE]; fetch_row(i, v); store_row(i, v); }
+    __syncthreads();
+    for (int k = 0; k < ncb; ++k) {
+        const int nrow = min(B, ncb - 1 - k) * D;            // scalar rows below the diagonal block
+        double nxt[NPRE];
+        fetch_row(k + B + 1, nxt);
+        double* Akk = Wn[k % NB][k % NB];
+        if (t == 0) {                                        // L_kk (lower) and its inverse, in registers
+            double a[DD], li[DD];
+#pragma unroll
+            for (int e = 0; e < DD; ++e) a[e] = Akk[e];
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double d = a[j * D + j];
+#pragma unroll
+                for (int m = 0; m < j; ++m) d -= a[j * D + m] * a[j * D + m];
+                if (!(d > 0.0)) { ok = false; d = 1.0; }
+                const double l = sqrt(d), rl = 1.0 / l;
+                a[j * D + j] = l;
+#pragma unroll
+                for (int i = j + 1; i < D; ++i) {
+                    double v = a[i * D + j];
+#pragma unroll
+                    for (int m = 0; m < j; ++m) v -= a[i * D + m] * a[j * D + m];
+                    a[i * D + j] = v * rl;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c)                      // column c of L^-1
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double v = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int m = c; m < i; ++m) v -= a[i * D + m] * li[m * D + c];
+                    li[i * D + c] = (i < c) ? 0.0 : v / a[i * D + i];
+                }
+#pragma unroll
+            for (int e = 0; e < DD; ++e) { Akk[e] = a[e]; Li[e] = li[e]; }
+            if (!ok) bad = 1;
+        }
+        __syncthreads();
+        if (t < nrow * D) {                                  // panel: L_ik = A_ik L_kk^-T
+            const int row = t / D, c = t % D, i = k + 1 + row / D;
+            const double* src = Wn[i % NB][k % NB] + (row % D) * D;
+            double v = 0.0;
+            for (int m = 0; m <= c; ++m) v += src[m] * Li[c * D + m];
+            P[row][c] = v;
+        }
+        __syncthreads();
+        for (int e = t; e < nrow * nrow; e += 256) {         // trailing update A_ij -= L_ik L_jk^T (block lower triangle)
+            const int r1 = e / nrow, r2 = e % nrow;
+            const int i = k + 1 + r1 / D, j = k + 1 + r2 / D;
+            if (j <= i) {
+                double v = 0.0;
+#pragma unroll
+                for (int m = 0; m < D; ++m) v += P[r1][m] * P[r2][m];
+                Wn[i % NB][j % NB][(r1 % D) * D + r2 % D] -= v;
+            }
+        }
+        if (t < nrow * D) {
+            const int row = t / D, c = t % D, i = k + 1 + row / D;
+            Wn[i % NB][k % NB][(row % D) * D + c] = P[row][c];
+        }
+        for (int e = t; e < (B + 1) * DD; e += 256) {        // block row k is final (nothing above touches it): out as scalar bands
+            const int cb = k - B + e / DD, rr = (e % DD) / D, cc = e % D;
+            if (cb < 0) continue;
+            const int row = k * D + rr, col = cb * D + cc;
+            const double v = Wn[k % NB][cb % NB][rr * D + cc];
+            if (col < row) { Lrow[(size_t)row * W + (row - 1 - col)] = v; Lcol[(size_t)col * W + (row - col - 1)] = v; }
+            else if (col == row) rdiag[row] = 1.0 / v;
+        }
+        __syncthreads();
+        store_row(k + B + 1, nxt);                           // (its slot is free or the one block row k just left)
+        __syncthreads();
+    }
+    if (t == 0 && bad) atomicAdd(&status[ST_DIAG_FAIL], 1);
+}
+
+// lane 0 <- x, lane j <- lane j - 1 (DPP wave_shr:1)
+PS_DEV double band_ring_push(double ring, double x) {
+    const unsigned long long r = __builtin_bit_cast(unsigned long long, ring), o = __builtin_bit_cast(unsigned long long, x);
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)r, 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(r >> 32), 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+__global__ __launch_bounds__(256) void k_band_inverse(
+    int nc, const double* __restrict__ Lrow, const double* __restrict__ Lcol, const double* __restrict__ rdiag,
+    double* __restrict__ Xs /* nc x nc scratch */, float* __restrict__ Ainv)
+{
+    constexpr int W = PS_BAND_W, U = 8;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= nc) return;
+    const bool in = lane < W;
+    double* xs = Xs + (size_t)c * nc;
+    // the band rows of the NEXT eight steps are requested before the dependent chain of the current eight runs
+    double a[U], rd[U], an[U], rdn[U], xv[U], xn[U];
+    auto fwd_fetch = [&](int i0, double* av, double* rv) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + u, nc - 1);
+            av[u] = in ? Lrow[(size_t)i * W + lane] : 0.0;
+            rv[u] = rdiag[i];
+        }
+    };
+    double ring = 0.0;
+    fwd_fetch(c, a, rd);
+    for (int i0 = c; i0 < nc; i0 += U) {                     // L x = e_c
+        if (i0 + U < nc) fwd_fetch(i0 + U, an, rdn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u;
+            if (i < nc) {
+                const double s = wave_sum(a[u] * ring);
+                const double x = ((i == c ? 1.0 : 0.0) - s) * rd[u];
+                if (lane == 0) xs[i] = x;
+                ring = band_ring_push(ring, x);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = an[u]; rd[u] = rdn[u]; }
+    }
+    __threadfence();                                         // (lane 0's stores of x, read back by every lane below)
+    auto bwd_fetch = [&](int i0, double* av, double* rv, double* xo) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = max(i0 - u, c);
+            av[u] = in ? Lcol[(size_t)i * W + lane] : 0.0;
+            rv[u] = rdiag[i];
+            xo[u] = xs[i];
+        }
+    };
+    ring = 0.0;
+    bwd_fetch(nc - 1, a, rd, xv);
+    for (int i0 = nc - 1; i0 >= c; i0 -= U) {                // L^T y = x, rows nc - 1 .. c
+        if (i0 - U >= c) bwd_fetch(i0 - U, an, rdn, xn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 - u;
+            if (i >= c) {
+                const double s = wave_sum(a[u] * ring);
+                const double y = (xv[u] - s) * rd[u];
+                if (lane == 0) { const float f = (float)y; Ainv[(size_t)i * nc + c] = f; Ainv[(size_t)c * nc + i] = f; }
+                ring = band_ring_push(ring, y);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = an[u]; rd[u] = rdn[u]; xv[u] = xn[u]; }
+    }
+}

@@ -17,7 +17,7 @@
 //   k_motion_only_iteration  WG / pose        : problems without landmarks / factors: the whole iteration
 // Every reduction has a fixed order: results are bitwise reproducible run to run.
 // This header holds the shared types, status words and reductions; the kernels live in the ps_k_*.h parts included at
-// the end (linearize, pcg_classic, cg_fused, xcg, coarse, tail), in pipeline order.
+// the end (linearize, pcg_classic, cg_fused, xcg, coarse, band, tail), in pipeline order.
 #pragma once
 #include "ps_math.h"
 
@@ -96,4 +96,5 @@ PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
 #include "ps_k_cg_fused.h"
 #include "ps_k_xcg.h"
 #include "ps_k_coarse.h"
+#include "ps_k_band.h"
 #include "ps_k_tail.h"

@@ -456,3 +456,43 @@ def test_explicit_pcg_three_launch_form_equals_the_four_launch_form(shape):
     for a, b in zip(p1, p0):
         if a.size:
             assert np.abs(a - b).max() <= 1e-8
+
+
+@pytest.mark.parametrize('shape', ['ba', 'pg_se3', 'pg_se2'])
+def test_banded_coarse_inverse_equals_the_dense_one(shape):
+    """Explicit two-level PCG on chain-like problems: the coarse matrix is block-banded and its fp32 inverse comes from
+    k_band_chol + k_band_inverse (option band_chol, default) instead of the dense blocked factorisation + triangular
+    inverse + product.  Same preconditioner up to rounding: same CG iteration counts (+-1), same trajectory."""
+    if shape == 'ba':
+        lp, _ = synthetic.stereo_ba(160, 16000, 8, 12, seed=21)
+    else:
+        lp, _ = synthetic.pose_graph(num_poses=900, num_loops=3601, dof=6 if shape == 'pg_se3' else 3, seed=22)
+    out = {}
+    for band in (1, 0):
+        dev = device(lp)
+        dev.set_option('cg_explicit_min_rows', 0)
+        dev.set_option('cg_split_min_rows', 0)
+        if shape == 'ba':
+            dev.set_option('coarse_groups', 10)
+        dev.set_option('band_chol', band)
+        res = [dev.gn_iteration(0., 1e-12, 3000, True) for _ in range(4)]
+        out[band] = (res, dev.get_params())
+    for a, b in zip(out[1][0], out[0][0]):
+        assert abs(a[2] - b[2]) <= 1 and abs(a[0] - b[0]) <= 1e-10 * abs(b[0]) and a[3] <= 1e-12, (a, b)
+    for a, b in zip(out[1][1], out[0][1]):
+        if a.size:
+            assert np.abs(a - b).max() <= 1e-9
+
+
+def test_wide_coarse_matrix_keeps_the_dense_factorisation():
+    """Hat intervals much shorter than the loop closures make A_c wider than the banded kernels take (more than 7 block
+    off-diagonals): the dense path runs, and the solve still matches the oracle."""
+    lp, _ = synthetic.pose_graph(num_poses=600, num_loops=1800, dof=6, seed=23)
+    dev = device(lp)
+    dev.set_option('cg_explicit_min_rows', 0)
+    dev.set_option('cg_split_min_rows', 0)
+    dev.set_option('coarse_groups', 200)                   # 3-pose intervals: loops of up to 30 poses span > 7 nodes
+    check = dev.gn_iteration(0., 1e-13, 3000, False)
+    dxo, _ = orc.gauss_newton_step(lp, points_first=False)
+    xp, xl = dev.get_dx()
+    assert np.linalg.norm(xp.ravel() - dxo) <= 1e-8 * np.linalg.norm(dxo), check

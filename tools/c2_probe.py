@@ -11,9 +11,10 @@ for G in ([int(a) for a in sys.argv[2:]] or [-1, 0]):
     dev.set_option('coarse_groups', G)
     if 'C2_SPLIT_MIN' in os.environ: dev.set_option('cg_split_min_rows', float(os.environ['C2_SPLIT_MIN']))
     if 'C2_EXPLICIT' in os.environ: dev.set_option('cg_explicit', float(os.environ['C2_EXPLICIT']))
+    if 'C2_REFRESH' in os.environ: dev.set_option('coarse_refresh_every', int(os.environ['C2_REFRESH']))
     dev.set_params(lp.poses, lp.points)
     hist = [dev.eval_cost(True)]
-    for it in range(6):
+    for it in range(int(os.environ.get('C2_ITERS', '6'))):
         dev.set_profiling(2); dev.stage_times(reset=True)
         t = time.time(); out = dev.gn_iteration(0., 1e-12, int(os.environ.get("C2_MAXIT", "4000")), True); dt = time.time() - t
         st = {k: round(v[0], 3) for k, v in dev.stage_times(reset=True).items() if v[1]}

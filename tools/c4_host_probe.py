@@ -6,6 +6,7 @@ from pyslam_amd import synthetic
 from pyslam_amd.device import DeviceProblem
 lp, _ = synthetic.stereo_ba(2000, 500000, 10, 20, seed=1)
 dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
+if 'C4_REFRESH' in os.environ: dev.set_option('coarse_refresh_every', int(os.environ['C4_REFRESH']))
 dev.snapshot()
 for _ in range(6):
     dev.restore(); dev.gn_iteration(0., 1e-12, 3000, True)
