@@ -433,7 +433,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     const std::string n(name);
     if (n == "pcg_variant") { if (value != 0 && value != 1) return fail("pcg_variant must be 0 or 1"); h->pcg_variant = (int)value; }
     else if (n == "coarse_groups") {
-        if (value < -1 || value > 255) return fail("coarse_groups out of range (-1 auto, 0 off, else number of hat intervals; above 63 only for the explicit two-level PCG)");
+        if (value < -1 || value >= PS_XCG_MAXNODES) return fail("coarse_groups out of range (-1 auto, 0 off, else number of hat intervals; above 63 only for the explicit two-level PCG, at most 1023)");
         h->coarse_req = (int)value; h->coarse_built = false;
     }
     else if (n == "cg_ablate") h->cg_ablate = (int)value;

@@ -181,16 +181,18 @@ int build_coarse(ps_problem* h) {
     // (restrict, dense coarse solve, prolong: cg_explicit) instead of folded into the matrix -- the folded form drags
     // a dense border of ncb blocks through every row (C2: 49 of 60 blocks per row).  Without a border the coarse
     // level can be much finer, and its factorisation runs beside the CG on the side stream from the second
-    // iteration on.  Pose-graph-like rows (C2: 11 blocks per row, hundreds of CG iterations): one interval per 40
-    // poses, up to 255; bundle-adjustment rows (C4: 80 blocks per row, ~20 iterations -- the factorisation must fit
+    // iteration on.  Pose-graph-like rows (C2: 11 blocks per row, hundreds of CG iterations): one interval per 25
+    // poses, up to 400 (C2, 10 000 poses: 250 / 333 / 400 / 500 intervals give 128 / 97 / 84 / 72 CG iterations and
+    // 4.4 / 3.8 / 3.7 / 3.9 ms -- beyond 400 the dense fp32 inverse and its band substitutions cost more than they
+    // save; the banded factorisation of ps_k_band.h is what makes more than 255 affordable); bundle-adjustment rows (C4: 80 blocks per row, ~20 iterations -- the factorisation must fit
     // beside a short CG): one per 20 poses, up to 112 (C4: 42 iterations / 3.7 ms folded at 48 -> 20 / 2.6 ms at 100).
     // Measured crossover against the folded single-launch CG (whose coarse level is capped at 12 intervals):
     // pose graphs 400 poses (600: 2.6 -> 1.4 ms, 1 000: 6.1 -> 1.5 ms), bundle adjustment 540 (700: 1.67 -> 1.28 ms).
     const int xmin = std::min(h->cg_split_min_rows, h->cg_explicit_min_rows >= 0 ? h->cg_explicit_min_rows : (sparse_rows ? 400 : 540));
     h->cg_explicit = h->explicit_ok && G != 0 && nr > xmin;
     if (h->cg_explicit && h->coarse_req < 0)
-        G = sparse_rows ? std::min(255, std::max(48, nr / 40)) : std::min(112, std::max(48, nr / 20));
-    G = std::min(G, h->cg_explicit ? 255 : Gmax);
+        G = sparse_rows ? std::min(400, std::max(48, nr / 25)) : std::min(112, std::max(48, nr / 20));
+    G = std::min(G, h->cg_explicit ? PS_XCG_MAXNODES - 1 : Gmax);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
     if (G < 1) G = 0;
     h->G = G; h->coarse_built = true; h->cg_split = false;
@@ -336,7 +338,7 @@ int build_coarse(ps_problem* h) {
     if (h->cg_explicit && h->ac_bw >= 0 &&
         (h->alloc(&h->Lrow, (size_t)h->nc * PS_BAND_W) || h->alloc(&h->Lcol, (size_t)h->nc * PS_BAND_W) || h->alloc(&h->rdiag, (size_t)h->nc))) return -1;
     h->xcg_rt_ok = false;
-    if (h->cg_explicit && ncb <= 256) {
+    if (h->cg_explicit && ncb <= PS_XCG_MAXNODES) {
         // three-launch form: records of P^T q per (SpMV workgroup, node it touches), a node's records contiguous and in
         // workgroup order (the order k_xcg_coarse_rt sums them in)
         if (const char* e = getenv("PS_XCG_ROWS_RT")) h->xcg_rt_rows = atoi(e);
@@ -439,7 +441,7 @@ int xcg_coarse_inverse(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
     if (h->band_chol && h->ac_bw >= 0) {
         HIP_OK(hipMemsetAsync(h->Lrow, 0, (size_t)nc * PS_BAND_W * sizeof(double), st));
         HIP_OK(hipMemsetAsync(h->Lcol, 0, (size_t)nc * PS_BAND_W * sizeof(double), st));
-        hipLaunchKernelGGL(k_band_chol<D>, dim3(1), dim3(256), 0, st, h->ncb, h->ac_bw, h->Ac, h->Lrow, h->Lcol, h->rdiag, stat);
+        hipLaunchKernelGGL(k_band_chol<D>, dim3(1), dim3(256), 0, st, h->ncb, std::max(h->ac_bw, 1), h->Ac, h->Lrow, h->Lcol, h->rdiag, stat);
         hipLaunchKernelGGL(k_band_inverse, dim3(cdiv(nc, 4)), dim3(256), 0, st, nc, h->Lrow, h->Lcol, h->rdiag,
                            h->chol_scratch, (float*)h->LciT2[buf]);
         return 0;

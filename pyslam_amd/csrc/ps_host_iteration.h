@@ -102,9 +102,14 @@ void xcg_launch(ps_problem* h, double tol, int count) {
                                h->cg_gd[0], n_rz, h->cg_gd[1], h->xstate, k, tol * tol, h->hist, h->status, h->scalars, ra)
             if (R == 4) PS_XCG_SPMV_RT(4); else if (R == 8) PS_XCG_SPMV_RT(8); else PS_XCG_SPMV_RT(16);
 #undef PS_XCG_SPMV_RT
-            hipLaunchKernelGGL(k_xcg_coarse_rt<D>, dim3(cdiv(nc, PS_XCG_CROWS)), dim3(64 * PS_XCG_CROWS), 0, h->stream, nc,
-                               (const float*)h->LciT2[h->lci_cur], tb[b], tb[b ^ 1], h->xcg_nptr, h->tq_part, h->cg_gd[1], n_pq,
-                               h->xstate, k, h->xy, h->status);
+            if (ncb <= 256)
+                hipLaunchKernelGGL(k_xcg_coarse_rt<D>, dim3(cdiv(nc, PS_XCG_CROWS)), dim3(64 * PS_XCG_CROWS), 0, h->stream, nc,
+                                   (const float*)h->LciT2[h->lci_cur], tb[b], tb[b ^ 1], h->xcg_nptr, h->tq_part, h->cg_gd[1], n_pq,
+                                   h->xstate, k, h->xy, h->status);
+            else
+                hipLaunchKernelGGL(k_xcg_coarse_rt_big<D>, dim3(cdiv(nc, PS_XCG_CROWS_BIG)), dim3(64 * PS_XCG_CROWS_BIG),
+                                   (size_t)nc * sizeof(double), h->stream, nc, (const float*)h->LciT2[h->lci_cur], tb[b], tb[b ^ 1],
+                                   h->xcg_nptr, h->tq_part, h->cg_gd[1], n_pq, h->xstate, k, h->xy, h->status);
             hipLaunchKernelGGL(k_xcg_prolong_rt<D>, dim3(n_rz), dim3(PS_XCG_DROWS), 0, h->stream, nr, ncb, h->pnode, h->pw0,
                                h->pw1, h->Bmat, h->cg_r[b], h->cg_r[b ^ 1], h->cg_w[0], pbuf[b], h->cg_xh, h->cg_gd[1], n_pq,
                                h->xstate, k, h->xy, h->cg_s[0], h->cg_gd[0], h->status);

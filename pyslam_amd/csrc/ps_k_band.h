@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_band_chol(
     constexpr int DD = D * D, NB = PS_BAND_NB, W = PS_BAND_W;
     __shared__ double Wn[NB][NB][DD];         // block (i, c) of the window at [i % NB][c % NB]
     __shared__ double P[PS_BAND_MAXB * D][D];
-    __shared__ double Li[DD];
+    __shared__ double Li2[2][DD];
     __shared__ int bad;
     const int nc = ncb * D, t = threadIdx.x;
     if (t == 0) bad = 0;
@@ -52,71 +52,61 @@ __global__ __launch_bounds__(256) void k_band_chol(
             if (e < (B + 1) * DD && cb >= 0) Wn[i % NB][cb % NB][e % DD] = v[u];
         }
     };
-    for (int i = 0; i <= B; ++i) { double v[NPRE]; fetch_row(i, v); store_row(i, v); }
-    __syncthreads();
-    for (int k = 0; k < ncb; ++k) {
-        const int nrow = min(B, ncb - 1 - k) * D;            // scalar rows below the diagonal block
-        double nxt[NPRE];
-        fetch_row(k + B + 1, nxt);
-        double* Akk = Wn[k % NB][k % NB];
-        if (t == 0) {                                        // L_kk (lower) and its inverse, in registers
-            double a[DD], li[DD];
+    // L_kk (lower, in place) and its inverse into li, from the block's 36 values in LDS; one thread, in registers
+    auto factor_diag = [&](double* Akk, double* li_out) {
+        double a[DD], li[DD], rl[D];
 #pragma unroll
-            for (int e = 0; e < DD; ++e) a[e] = Akk[e];
-            bool ok = true;
+        for (int e = 0; e < DD; ++e) a[e] = Akk[e];
+        bool ok = true;
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                double d = a[j * D + j];
+        for (int j = 0; j < D; ++j) {
+            double d = a[j * D + j];
 #pragma unroll
-                for (int m = 0; m < j; ++m) d -= a[j * D + m] * a[j * D + m];
-                if (!(d > 0.0)) { ok = false; d = 1.0; }
-                const double l = sqrt(d), rl = 1.0 / l;
-                a[j * D + j] = l;
+            for (int m = 0; m < j; ++m) d -= a[j * D + m] * a[j * D + m];
+            if (!(d > 0.0)) { ok = false; d = 1.0; }
+            rl[j] = rsqrt(d);
+            a[j * D + j] = d * rl[j];
 #pragma unroll
-                for (int i = j + 1; i < D; ++i) {
-                    double v = a[i * D + j];
+            for (int i = j + 1; i < D; ++i) {
+                double v = a[i * D + j];
 #pragma unroll
-                    for (int m = 0; m < j; ++m) v -= a[i * D + m] * a[j * D + m];
-                    a[i * D + j] = v * rl;
-                }
+                for (int m = 0; m < j; ++m) v -= a[i * D + m] * a[j * D + m];
+                a[i * D + j] = v * rl[j];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < D; ++c)                          // column c of L^-1
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double v = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int m = c; m < i; ++m) v -= a[i * D + m] * li[m * D + c];
+                li[i * D + c] = (i < c) ? 0.0 : v * rl[i];
             }
 #pragma unroll
-            for (int c = 0; c < D; ++c)                      // column c of L^-1
-#pragma unroll
-                for (int i = 0; i < D; ++i) {
-                    double v = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-                    for (int m = c; m < i; ++m) v -= a[i * D + m] * li[m * D + c];
-                    li[i * D + c] = (i < c) ? 0.0 : v / a[i * D + i];
-                }
-#pragma unroll
-            for (int e = 0; e < DD; ++e) { Akk[e] = a[e]; Li[e] = li[e]; }
-            if (!ok) bad = 1;
-        }
-        __syncthreads();
-        if (t < nrow * D) {                                  // panel: L_ik = A_ik L_kk^-T
+        for (int e = 0; e < DD; ++e) { Akk[e] = a[e]; li_out[e] = li[e]; }
+        if (!ok) bad = 1;
+    };
+    for (int i = 0; i <= B; ++i) { double v[NPRE]; fetch_row(i, v); store_row(i, v); }
+    __syncthreads();
+    if (t == 0) factor_diag(Wn[0][0], Li2[0]);
+    __syncthreads();
+    // Step k, two barriers: (A) panel L_ik = A_ik L_kk^-T and the finished block row k out to global memory;
+    // (B) wave 0 updates and factors the NEXT diagonal block (look-ahead: the serial part, ~0.5 us) while waves 1-3 do
+    // the rest of the trailing update, put the panel into the window and bring in block row k + B + 1.
+    for (int k = 0; k < ncb; ++k) {
+        const int nrow = min(B, ncb - 1 - k) * D;            // scalar rows below the diagonal block
+        const double* Li = Li2[k & 1];
+        double nxt[NPRE];
+        fetch_row(k + B + 1, nxt);
+        if (t < nrow * D) {
             const int row = t / D, c = t % D, i = k + 1 + row / D;
             const double* src = Wn[i % NB][k % NB] + (row % D) * D;
             double v = 0.0;
             for (int m = 0; m <= c; ++m) v += src[m] * Li[c * D + m];
             P[row][c] = v;
         }
-        __syncthreads();
-        for (int e = t; e < nrow * nrow; e += 256) {         // trailing update A_ij -= L_ik L_jk^T (block lower triangle)
-            const int r1 = e / nrow, r2 = e % nrow;
-            const int i = k + 1 + r1 / D, j = k + 1 + r2 / D;
-            if (j <= i) {
-                double v = 0.0;
-#pragma unroll
-                for (int m = 0; m < D; ++m) v += P[r1][m] * P[r2][m];
-                Wn[i % NB][j % NB][(r1 % D) * D + r2 % D] -= v;
-            }
-        }
-        if (t < nrow * D) {
-            const int row = t / D, c = t % D, i = k + 1 + row / D;
-            Wn[i % NB][k % NB][(row % D) * D + c] = P[row][c];
-        }
-        for (int e = t; e < (B + 1) * DD; e += 256) {        // block row k is final (nothing above touches it): out as scalar bands
+        for (int e = t; e < (B + 1) * DD; e += 256) {        // block row k is final: out as scalar bands
             const int cb = k - B + e / DD, rr = (e % DD) / D, cc = e % D;
             if (cb < 0) continue;
             const int row = k * D + rr, col = cb * D + cc;
@@ -125,7 +115,36 @@ __global__ __launch_bounds__(256) void k_band_chol(
             else if (col == row) rdiag[row] = 1.0 / v;
         }
         __syncthreads();
-        store_row(k + B + 1, nxt);                           // (its slot is free or the one block row k just left)
+        if (t < 64) {
+            if (nrow > 0) {
+                double* An = Wn[(k + 1) % NB][(k + 1) % NB];
+                if (t < DD) {
+                    const int r1 = t / D, r2 = t % D;
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < D; ++m) v += P[r1][m] * P[r2][m];
+                    An[t] -= v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (t == 0) factor_diag(An, Li2[(k + 1) & 1]);
+            }
+        } else {
+            for (int e = t - 64; e < nrow * nrow; e += 192) {    // trailing update A_ij -= L_ik L_jk^T (block lower triangle)
+                const int r1 = e / nrow, r2 = e % nrow;
+                const int i = k + 1 + r1 / D, j = k + 1 + r2 / D;
+                if (j <= i && !(i == k + 1 && j == k + 1)) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < D; ++m) v += P[r1][m] * P[r2][m];
+                    Wn[i % NB][j % NB][(r1 % D) * D + r2 % D] -= v;
+                }
+            }
+            for (int e = t - 64; e < nrow * D; e += 192) {
+                const int row = e / D, c = e % D, i = k + 1 + row / D;
+                Wn[i % NB][k % NB][(row % D) * D + c] = P[row][c];
+            }
+        }
+        store_row(k + B + 1, nxt);                           // (its slot is free, or the one block row k left in phase A)
         __syncthreads();
     }
     if (t == 0 && bad) atomicAdd(&status[ST_DIAG_FAIL], 1);

@@ -28,6 +28,7 @@
 #define PS_XCG_RBATCH 6                       // records of a node loaded together by k_xcg_coarse_rt
 #endif
 #define PS_XCG_DROWS 256                      // rows per workgroup of the prolongation
+#define PS_XCG_MAXNODES 1024                  // coarse nodes of the explicit form (t of the big coarse kernel in LDS: 48 KB)
 
 PS_DEV double xcg_total(const double* __restrict__ part, int n, double* lds) {
     double v = 0.0;
@@ -392,6 +393,58 @@ __global__ __launch_bounds__(64 * PS_XCG_CROWS) void k_xcg_coarse_rt(
         }
     } else {
         for (int j = lane; j < nc; j += 64) v += (double)a[j] * tl[j];
+    }
+    v = wave_sum(v);
+    if (lane == 0) y[row] = v;
+}
+
+// the same for coarse levels beyond 256 nodes (pose graphs with thousands of poses: the CG iteration count falls with
+// the node count, and the banded factorisation makes a fine coarse level affordable): t in dynamic LDS, 16 rows per
+// workgroup, plain loops
+#define PS_XCG_CROWS_BIG 16
+template <int D>
+__global__ __launch_bounds__(64 * PS_XCG_CROWS_BIG) void k_xcg_coarse_rt_big(
+    int nc, const float* __restrict__ Ainv, const double* __restrict__ t_old, double* __restrict__ t_new,
+    const int32_t* __restrict__ nptr, const double* __restrict__ tq_part, const double* __restrict__ pq_part, int n_pq,
+    const double* __restrict__ xstate, int k, double* __restrict__ y, const int32_t* __restrict__ status)
+{
+    constexpr int NT = 64 * PS_XCG_CROWS_BIG;
+    __shared__ double lds[16];
+    extern __shared__ double tl_dyn[];
+    const int done = status[ST_PCG_DONE];
+    const double rz = xstate[4 + (k & 1)];
+    double pqv = 0.0;
+    for (int i = threadIdx.x; i < n_pq; i += NT) pqv += pq_part[i];
+    const double pq = block_sum(pqv, lds);
+    if (done) return;
+    const double alpha = rz / pq;
+    for (int e = threadIdx.x; e < nc; e += NT) {
+        const int n = e / D, m = e - n * D;
+        const int lo = nptr[n], hi = nptr[n + 1];
+        double s = 0.0;
+        for (int j0 = lo; j0 < hi; j0 += PS_XCG_RBATCH) {
+            double rec[PS_XCG_RBATCH];
+#pragma unroll
+            for (int c = 0; c < PS_XCG_RBATCH; ++c) rec[c] = (j0 + c < hi) ? tq_part[(size_t)(j0 + c) * D + m] : 0.0;
+#pragma unroll
+            for (int c = 0; c < PS_XCG_RBATCH; ++c) s += rec[c];
+        }
+        const double tn = t_old[e] - alpha * s;
+        tl_dyn[e] = tn;
+        if (blockIdx.x == 0) t_new[e] = tn;
+    }
+    __syncthreads();
+    const int row = blockIdx.x * PS_XCG_CROWS_BIG + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nc) return;
+    const float* a = Ainv + (size_t)row * nc;
+    double v = 0.0;
+    if ((nc & 1) == 0) {
+        for (int j = 2 * lane; j < nc; j += 128) {
+            const float2 f = *reinterpret_cast<const float2*>(a + j);
+            v += (double)f.x * tl_dyn[j] + (double)f.y * tl_dyn[j + 1];
+        }
+    } else {
+        for (int j = lane; j < nc; j += 64) v += (double)a[j] * tl_dyn[j];
     }
     v = wave_sum(v);
     if (lane == 0) y[row] = v;
