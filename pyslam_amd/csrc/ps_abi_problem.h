@@ -21,6 +21,7 @@ int ps_problem_destroy(ps_problem* h) {
     if (h->h_scalars) hipHostFree(h->h_scalars);
     if (h->h_status) hipHostFree(h->h_status);
     if (h->h_seq) hipHostFree(h->h_seq);
+    if (h->h_setup) hipHostFree(h->h_setup);
     if (h->h_shard) hipHostFree(h->h_shard);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); hipEventDestroy(h->ev_acdone); }
@@ -654,6 +655,9 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     HIP_OK(hipHostGetDevicePointer((void**)&h->h_shard_dev, h->h_shard, 0));
     HIP_OK(hipHostGetDevicePointer((void**)&h->h_seq_dev, h->h_seq, 0));
     *h->h_seq = 0;
+    HIP_OK(hipHostMalloc((void**)&h->h_setup, sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostGetDevicePointer((void**)&h->h_setup_dev, h->h_setup, 0));
+    *h->h_setup = 0;
     if (h->alloc(&h->arrivals, 2)) return -1;
     HIP_OK(hipMemsetAsync(h->arrivals, 0, 2 * sizeof(int32_t), h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));

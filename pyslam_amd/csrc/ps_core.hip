@@ -203,6 +203,8 @@ struct ps_problem {
     double *h_shard = nullptr, *h_shard_dev = nullptr;   // host-mapped copy of shard_buf (sharded iteration)
     long long *h_seq = nullptr, *h_seq_dev = nullptr;   // sequence number stamped by the last k_reduce3 workgroup
     long long seq = 0;
+    long long *h_setup = nullptr, *h_setup_dev = nullptr;   // stamped by the last kernel of a lagged set-up: the side stream's inputs are complete
+    long long setup_seq = 0;
     int32_t* arrivals = nullptr;
     int ncost_obs = 0, ncost_fac = 0, nsq = 0;
     // native RCCL: function pointer + communicator handed over by the binding (ps_set_collective)

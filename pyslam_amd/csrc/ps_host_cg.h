@@ -41,9 +41,14 @@ void drain_timers(ps_problem* h) {      // call after a stream synchronisation
     h->ev_used = 0;
 }
 
+int side_kick(ps_problem* h);
+
 int sync(ps_problem* h) {
     HIP_OK(hipStreamSynchronize(h->stream));
     drain_timers(h);
+    // whatever produced the side stream's inputs has completed: start the next coarse operator NOW, while the GPU is
+    // idle between two calls (kicked from the next call's linearize() it started ~35 us into the iteration and the
+    // set-up waited ~20 us for its last kernel at C3)
     if (h->side_todo) h->side_ready = true;     // whatever produced the side stream's inputs has completed
     return 0;
 }
@@ -57,9 +62,14 @@ int wait_published(ps_problem* h) {
         ps_problem* h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         ~WaitClock() { h->host_wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); ++h->host_waits; }
     } wc{h};
+    static const int kick_mode = getenv("PS_SIDE_KICK") ? atoi(getenv("PS_SIDE_KICK")) : 2;   // 0 next linearize, 1 after the wait, 2 during the wait
+    volatile long long* ws = h->h_setup;
     for (long spins = 0; spins < 400000000L; ++spins) {
+        // the set-up kernels of this iteration have finished (stamp of k_coarse_mreduce): the side stream's inputs are
+        // complete, and the host has nothing to do but wait -- enqueue the next coarse operator now, beside the CG
+        if (kick_mode == 2 && h->side_todo && !h->side_ready && *ws == h->setup_seq) { h->side_ready = true; if (side_kick(h)) return -1; }
         if (*w == h->seq) {
-            if (h->side_todo) h->side_ready = true;
+            if (h->side_todo) { h->side_ready = true; if (kick_mode >= 1 && side_kick(h)) return -1; }
             if (h->pending.empty()) return 0;
             // stage timers: everything up to k_reduce3 has completed; an event recorded behind it may
             // need a moment more
@@ -497,7 +507,7 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
                            h->Saug, h->SB, h->Mpart, h->rows_lci_lds ? 1 : 0, getenv("PS_RS_ABLATE") ? atoi(getenv("PS_RS_ABLATE")) : 0);
         hipLaunchKernelGGL(k_coarse_mreduce<D>, dim3(cdiv((long)nc * (nc + 1) * 8, 256)), dim3(256), 0, h->stream, nr, ncb,
                            h->shi, h->Mpart, h->pnode, h->arow_ptr, h->Saug, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p,
-                           h->cg_xh, h->lag_status, h->status);
+                           h->cg_xh, h->lag_status, h->status, h->h_setup_dev, ++h->setup_seq);
         h->mc_active = false;
         h->side_todo = true; h->side_ready = false; h->side_buf = nb;
         h->cg_launched = 0;

@@ -894,11 +894,14 @@ __global__ __launch_bounds__(256) void k_coarse_mreduce(
     int nr, int ncb, const int32_t* __restrict__ shi, const double* __restrict__ Mpart,
     const int32_t* __restrict__ pnode, const int32_t* __restrict__ arow_ptr, double* __restrict__ Saug,
     double* __restrict__ r, double* __restrict__ w, double* __restrict__ s, double* __restrict__ p, double* __restrict__ x,
-    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status)
+    const int32_t* __restrict__ lag_status, int32_t* __restrict__ status, long long* __restrict__ hsetup, long long setup_seq)
 {
     constexpr int DD = D * D;
     const int nc = ncb * D, ncol = nc + 1;
     const int o = (blockIdx.x * blockDim.x + threadIdx.x) / 8, sub = threadIdx.x & 7;
+    // everything the side stream's next coarse operator reads (SB, the new basis) was written by the kernels BEFORE this
+    // one: tell the host, which is waiting for the iteration anyway and enqueues that work when it sees the stamp
+    if (hsetup && blockIdx.x == 0 && threadIdx.x == 0) { *reinterpret_cast<volatile long long*>(hsetup) = setup_seq; __threadfence_system(); }
     // a lagged factor whose (side-stream) factorisation failed poisons this solve: report it
     if (blockIdx.x == 0 && threadIdx.x == 0 && lag_status && lag_status[ST_DIAG_FAIL]) atomicAdd(&status[ST_DIAG_FAIL], 1);
     const bool live = o < nc * ncol;
