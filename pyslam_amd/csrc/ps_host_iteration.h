@@ -4,6 +4,9 @@
 namespace {
 
 // ---- explicit two-level PCG (long sparse chains; kernels k_xcg_*) ---------------------------------
+// (measurement switch: PS_XCG_AC_MAIN=1 keeps the assembly of A_c on the solver stream, as it was before it moved)
+inline bool xcg_ac_on_main() { static const bool v = getenv("PS_XCG_AC_MAIN") != nullptr; return v; }
+
 // A_c = P^T S^ P from the non-empty (row, node) runs
 template <int D>
 void xcg_assemble_ac(ps_problem* h, hipStream_t st) {
@@ -42,7 +45,7 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     if (lag) {
         if (!hold) {
             h->lci_cur = h->lci_next;
-            if (getenv("PS_XCG_AC_MAIN")) xcg_assemble_ac<D>(h, h->stream);
+            if (xcg_ac_on_main()) xcg_assemble_ac<D>(h, h->stream);
             HIP_OK(hipEventRecord(h->ev_ac, h->stream));   // SB and the basis complete; the side work is enqueued by xcg_side_enqueue
             h->xcg_side_todo = true;
             lagst = h->lag_status;
@@ -76,7 +79,7 @@ int xcg_side_enqueue(ps_problem* h) {
     h->xcg_side_todo = false;
     const int nc = h->nc, nb = h->lci_cur ^ 1;
     HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
-    if (!getenv("PS_XCG_AC_MAIN")) xcg_assemble_ac<D>(h, h->side);
+    if (!xcg_ac_on_main()) xcg_assemble_ac<D>(h, h->side);
     HIP_OK(hipEventRecord(h->ev_acdone, h->side));
     h->acdone_pending = true;
     if (xcg_coarse_inverse<D>(h, h->side, nb, h->lag_status)) return -1;

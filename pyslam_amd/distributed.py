@@ -170,12 +170,10 @@ class ShardedDeviceProblem:
                 self.dev.set_collective(0, 0)
                 self.native.close()
                 self.native = None
-        # Many ranks: the shard-local kernels shrink with 1 / world, the replicated reduced solve does not, and the
-        # side-stream factorisation of a large coarse level (C4: 1.6 ms) would then outlast the iteration (~1.1 ms on
-        # 8 GPUs) and stall the next set-up.  Refresh the lagged coarse inverse every second iteration there (a fixed
-        # schedule: same on every rank, reproducible).  Not measured on hardware: one GPU per box here.
-        if self.world >= 4 and hasattr(self.dev, 'set_option'):
-            self.dev.set_option('coarse_refresh_every', 2)
+        # (Round 2 first set "coarse_refresh_every" = 2 from 4 ranks on: the dense side-stream factorisation of C4's coarse
+        # level, 1.6 ms, would have outlasted a ~1.1 ms sharded iteration.  The banded factorisation takes 0.6 ms and
+        # finishes beside the CG and the next shard-local kernels, so every rank count refreshes every iteration; the
+        # option stays for problems whose coarse matrix is not banded.)
         self._scal = torch.zeros(2, dtype=torch.float64, device=self.dev.reduce_tensor.device)
 
     # ---- iteration -----------------------------------------------------

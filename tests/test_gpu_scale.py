@@ -364,7 +364,7 @@ def test_c4_four_landmark_shards_sum_to_the_unsharded_reduced_system(c4):
 
 
 def test_coarse_inverse_refreshed_every_second_iteration_gives_the_same_trajectory():
-    """"coarse_refresh_every" = 2 (what the sharded driver sets from 4 ranks on): the explicit two-level PCG holds its
+    """"coarse_refresh_every" = 2 (for coarse levels whose factorisation outlasts an iteration): the explicit two-level PCG holds its
     lagged coarse inverse for two iterations and assembles / factors A_c only every second one.  The preconditioner is
     staler, the solves are the same: four Gauss-Newton iterations agree with the default schedule to 1e-9."""
     lp, _ = synthetic.stereo_ba(num_kf=640, num_lm=12000, obs_per_lm=6, half_window=12, seed=31)
