@@ -50,7 +50,7 @@ def run(n_cases, seed0=0, verbose=True):
         if mode == 'explicit':
             dev.set_option('cg_explicit_min_rows', 0); dev.set_option('cg_split_min_rows', 0)
             if lp.num_reduced > 80 and rng.integers(2):      # larger coarse levels: blocked Cholesky + merged triangular inverse
-                dev.set_option('coarse_groups', int(rng.integers(30, min(255, (lp.num_reduced - 1) // 2) + 1)))
+                dev.set_option('coarse_groups', int(rng.integers(30, min(340, (lp.num_reduced - 1) // 2) + 1)))   # (beyond 256 nodes: the big coarse kernel)
         elif mode == 'nocoarse':
             dev.set_option('coarse_groups', 0)
         elif mode == 'G':
