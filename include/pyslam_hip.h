@@ -214,6 +214,8 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /
      "coarse_lag_x"       [1] ... and with the previous iteration's basis and X = P L_c^-T too: three set-up launches (k_rows_setup)
      "coarse_refresh_every" [1] explicit two-level PCG: only every k-th lagged set-up takes the newest coarse inverse and starts the
                               next side-stream factorisation (landmark-sharded runs whose iteration is shorter than that factorisation)
+     "coarse_auto_hold"   [1] explicit two-level PCG: while the solve has settled (last iteration changed the cost by < 1e-4
+                              relative) keep the lagged coarse inverse, for at most 3 set-ups in a row (no assembly, no factorisation)
      "xcg_restrict_fused" [1] explicit two-level PCG: three launches per iteration (restriction in the SpMV epilogue, t by recurrence)
                               instead of four
      "band_chol"          [1] explicit two-level PCG: banded factorisation + band substitutions for the coarse inverse when A_c

@@ -124,6 +124,7 @@ int ps_snapshot_params(ps_problem* h) {
 
 int ps_restore_params(ps_problem* h) {
     if (!h) return fail("null argument");
+    h->last_cost = h->prev_cost = -1.0;
     const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
     if (n1 + n2)
         hipLaunchKernelGGL(k_copy2, dim3((unsigned)std::min<size_t>(2048, cdiv((long)(n1 + n2), 256))), dim3(256), 0, h->stream,
@@ -140,6 +141,7 @@ int ps_get_params(ps_problem* h, double* poses, double* points) {
 
 int ps_set_params(ps_problem* h, const double* poses, const double* points) {
     if (!h) return fail("null argument");
+    h->last_cost = h->prev_cost = -1.0;
     if (poses && h->P) HIP_OK(hipMemcpyAsync(h->poses, poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (points && h->L) HIP_OK(hipMemcpyAsync(h->points, points, (size_t)h->L * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return sync(h);
@@ -283,6 +285,7 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
         }
         if (cost_out) *cost_out = sb[0];
         if (dx_norm_out) *dx_norm_out = std::sqrt(dxp2 + sb[1]);
+        h->prev_cost = h->last_cost; h->last_cost = sb[0];      // (all-reduced: the same on every rank)
         return 0;
     }
     if (h->mo_fused && h->nv == 0 && h->F == 0 && h->nr > 0 && h->D == 6 && h->N == h->Np && h->pcg_variant == 1 &&
@@ -328,6 +331,7 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
     }
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+    h->prev_cost = h->last_cost; h->last_cost = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
     // a slot whose reduction did not run (no reduced poses / no variable landmarks) is stale: count it as 0
     if (dx_norm_out) *dx_norm_out = std::sqrt((h->nr > 0 ? h->h_scalars[SC_DXP2] : 0.0) + (h->nv > 0 ? h->h_scalars[SC_DXL2] : 0.0));
     return 0;
@@ -444,6 +448,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "cg_force_restart") h->cg_force_restart = value != 0.0;
     else if (n == "xcg_restrict_fused") h->xcg_rt = value != 0;
     else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
+    else if (n == "coarse_auto_hold") h->xcg_auto_hold = value != 0;
     else if (n == "coarse_refresh_every") { if (value < 1 || value > 16) return fail("coarse_refresh_every must be 1..16"); h->xcg_refresh_every = (int)value; }
     else if (n == "coarse_lag_x") { h->lagx = value != 0.0; h->lci_next = -1; h->side_todo = false; }
     else if (n == "cg_lds") h->cg_lds = value != 0.0;

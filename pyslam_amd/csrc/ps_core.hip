@@ -165,6 +165,10 @@ struct ps_problem {
     bool cg_explicit = false;
     int xcg_refresh_every = 1;      // option "coarse_refresh_every": lagged set-ups between two refreshes of the coarse inverse
     long xcg_lag_count = 0;
+    // "coarse_auto_hold": keep the lagged coarse inverse (no assembly, no side-stream factorisation) while the solve has
+    // settled -- the last whole-iteration call changed the cost by less than 1e-4 relative -- for at most 3 set-ups in a row
+    int xcg_auto_hold = 1, xcg_held = 0;
+    double last_cost = -1.0, prev_cost = -1.0;   // costs returned by the last two ps_gn_iteration calls (-1: none / parameters replaced since)
     double *xstate = nullptr, *xy = nullptr, *xp2 = nullptr;
     // ... banded coarse matrix (ps_k_band.h): block off-diagonals of A_c (-1: not banded enough), band factor by rows / columns
     int ac_bw = -1;

@@ -38,7 +38,11 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     // inverse and starts the next factorisation; the set-ups in between HOLD the inverse they have, assemble no A_c and
     // do not wait for the side stream.  A fixed schedule, not a completion poll: results stay reproducible run to run.
     const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0;
-    const bool hold = lag && h->xcg_refresh_every > 1 && (h->xcg_lag_count % h->xcg_refresh_every) != 0;
+    const bool settled = h->xcg_auto_hold && h->prev_cost > 0.0 && h->last_cost > 0.0 &&
+                         std::fabs(h->prev_cost - h->last_cost) <= 1e-4 * h->prev_cost && h->xcg_held < 3;
+    const bool hold = lag && h->xcg_lag_count > 0 &&
+                      ((h->xcg_refresh_every > 1 && (h->xcg_lag_count % h->xcg_refresh_every) != 0) || settled);
+    h->xcg_held = (hold && settled) ? h->xcg_held + 1 : 0;
     const int32_t* lagst = nullptr;
     h->xcg_side_todo = false;
     if (!hold && h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }

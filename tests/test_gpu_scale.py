@@ -378,3 +378,26 @@ def test_coarse_inverse_refreshed_every_second_iteration_gives_the_same_trajecto
         assert abs(c1 - c2) <= 1e-9 * abs(c1) and abs(n1 - n2) <= 1e-7 * n1 + 1e-12
         assert r2 <= 1e-12 and i2 <= i1 + 25
     assert np.abs(out[1][1][0] - out[2][1][0]).max() <= 1e-8
+
+
+@pytest.mark.parametrize('shape', ['ba', 'pg'])
+def test_coarse_inverse_held_while_the_solve_has_settled_gives_the_same_trajectory(shape):
+    """"coarse_auto_hold" (default): once an iteration changes the cost by less than 1e-4 relative, the explicit two-level
+    PCG keeps its lagged coarse inverse for up to three set-ups instead of assembling and factoring A_c again.  It only
+    preconditions: eight Gauss-Newton iterations agree with the always-refresh schedule, CG counts within a few."""
+    if shape == 'ba':
+        lp, _ = synthetic.stereo_ba(num_kf=640, num_lm=12000, obs_per_lm=6, half_window=12, seed=32)
+    else:
+        lp, _ = synthetic.pose_graph(num_poses=1200, num_loops=4801, dof=6, seed=33)
+    out = {}
+    for hold in (0, 1):
+        dev = device(lp)
+        dev.set_option('coarse_auto_hold', hold)
+        out[hold] = ([dev.gn_iteration(0., 1e-12, 3000, True) for _ in range(8)], dev.get_params())
+        dev.close()
+    for (c1, n1, i1, r1), (c2, n2, i2, r2) in zip(out[0][0], out[1][0]):
+        assert abs(c1 - c2) <= 1e-9 * abs(c1) and abs(n1 - n2) <= 1e-6 * n1 + 1e-10
+        assert r2 <= 1e-12 and i2 <= i1 + 10
+    for a, b in zip(out[0][1], out[1][1]):
+        if a.size:
+            assert np.abs(a - b).max() <= 1e-8
