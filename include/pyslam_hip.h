@@ -202,6 +202,12 @@ int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx,
 int ps_get_landmark_factors(ps_problem* h, double* cinv /* (nv,6) */, double* c /* (nv,3) */);
 int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /* (N,18) */,
                            double* jpoint /* (N,9) */);  /* IRLS-scaled, original obs order */
+/* The pose-factor kernel's own blocks (IRLS-scaled, as they enter J~^T J~): r~ (F, dof), J~_1 (F, dof, dof) and
+   J~_2 (F, dof, dof), F = num_edges + num_priors in table order (edges first).  Edges: the reference's
+   PoseToPoseResidual.evaluate (pyslam/residuals/pose_to_pose_residual.py:12-32: r = S log(T_2 T_1^-1 T_obs^-1),
+   J_1 = -S Ad(T_2 T_1^-1), J_2 = S); priors: PoseResidual.evaluate (pose_residual.py:12-27: r = S log(T T_obs^-1),
+   J = S in j2, j1 = 0).  Runs the production kernel with its tap open; S and g are not touched. */
+int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
 
 /* Tuning knobs (defaults in brackets):
      "pcg_variant"        [1] fused single-launch-per-iteration CG on the block-Jacobi scaled system; 0 = classic two-launch PCG

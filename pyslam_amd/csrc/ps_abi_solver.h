@@ -432,6 +432,27 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r, double* jpose, double* jpoi
     return rc;
 }
 
+int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2) {
+    if (!h || !r || !j1 || !j2) return fail("null argument");
+    if (h->F == 0) return 0;
+    const int D = h->D, DD = D * D, ROW = D + 2 * DD;
+    double* dbg;
+    HIP_OK(hipMalloc((void**)&dbg, (size_t)h->F * ROW * sizeof(double)));
+    // the production kernel itself, with its tap open (binary factors first, then the priors: creation order)
+    const int rc0 = D == 6 ? launch_factor_pass<6>(h, 0.0, dbg) : launch_factor_pass<3>(h, 0.0, dbg);
+    std::vector<double> t((size_t)h->F * ROW);
+    hipMemcpyAsync(t.data(), dbg, t.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    const int rc = sync(h);
+    hipFree(dbg);
+    if (rc0 || rc) return -1;
+    for (long f = 0; f < h->F; ++f) {
+        std::memcpy(r + f * D, &t[(size_t)f * ROW], D * sizeof(double));
+        std::memcpy(j1 + f * DD, &t[(size_t)f * ROW + D], DD * sizeof(double));
+        std::memcpy(j2 + f * DD, &t[(size_t)f * ROW + D + DD], DD * sizeof(double));
+    }
+    return 0;
+}
+
 int ps_set_option(ps_problem* h, const char* name, double value) {
     if (!h || !name) return fail("null argument");
     const std::string n(name);

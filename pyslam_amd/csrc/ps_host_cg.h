@@ -92,10 +92,11 @@ int read_scalars(ps_problem* h) {
 struct PairRec { uint64_t key; int32_t a, b, tile; };
 
 template <int D>
-int launch_factor_pass(ps_problem* h, double lambda) {
+int launch_factor_pass(ps_problem* h, double lambda, double* dbg = nullptr) {
     if (h->F == 0) return 0;
     hipLaunchKernelGGL(k_factor_pass<D>, dim3(cdiv(h->F, PS_FP_FACTORS)), dim3(256), 0, h->stream, (int)h->F, h->f_i,
-                       h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->fscratch);
+                       h->f_j, h->f_Tinv, h->f_grp, h->fgroups, h->poses, h->fscratch, dbg);
+    if (dbg) return 0;                                        // parity tap: blocks only, S and g stay untouched
     const long threads = (long)h->nes * D * D + (long)h->nr * D;
     hipLaunchKernelGGL(k_factor_assemble<D>, dim3(cdiv(threads, 256)), dim3(256), 0, h->stream, h->nes,
                        h->eslots, h->eptr, h->eitems, h->eslot_diag, h->nr, h->gptr, h->gitems,

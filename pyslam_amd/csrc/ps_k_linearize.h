@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void k_factor_pass(
     int nf, const int32_t* __restrict__ f_i, const int32_t* __restrict__ f_j,
     const double* __restrict__ f_Tinv, const int32_t* __restrict__ f_grp,
     const FactorGroup* __restrict__ groups, const double* __restrict__ poses,
-    double* __restrict__ scratch)
+    double* __restrict__ scratch, double* __restrict__ dbg /* parity tap or nullptr: [r~ | J~1 | J~2] per factor */)
 {
     typedef PoseOps<D> G;
     constexpr int DD = D * D, ROW = 3 * DD + 2 * D, FPB = PS_FP_FACTORS;
@@ -613,6 +613,12 @@ __global__ __launch_bounds__(256) void k_factor_pass(
             sJ2[w][lane] = sk * grp.S[lane];
         }
         __builtin_amdgcn_wave_barrier();
+        if (dbg != nullptr && act) {                          // (uniform: production launches pass nullptr)
+            double* o = dbg + (size_t)f * (D + 2 * DD);
+            if (lane < D) o[lane] = sSr[fl][lane];
+            o[D + lane] = sJ1[w][lane];
+            o[D + DD + lane] = sJ2[w][lane];
+        }
         if (act) {
             double h11 = 0.0, h12 = 0.0, h22 = 0.0;
 #pragma unroll

@@ -213,6 +213,13 @@ class DeviceProblem:
         nat.check(self._lib.ps_debug_reproj_blocks(self._h, nat.f64p(r), nat.f64p(jp), nat.f64p(jl)))
         return r, jp, jl
 
+    def debug_factor_blocks(self):
+        """(r~, J~_1, J~_2) of every pose-pose edge, then every prior, from the production factor kernel."""
+        f, d = self.lp.num_edges + self.lp.num_priors, self.lp.dof
+        r, j1, j2 = np.zeros((f, d)), np.zeros((f, d, d)), np.zeros((f, d, d))
+        nat.check(self._lib.ps_debug_factor_blocks(self._h, nat.f64p(r), nat.f64p(j1), nat.f64p(j2)))
+        return r, j1, j2
+
     def cg_restarts(self):
         """Restarts of the pipelined CG so far (ps_problem_info.cg_restarts)."""
         info = nat.ProblemInfo()

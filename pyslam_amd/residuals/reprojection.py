@@ -14,6 +14,34 @@ def _jac_list(params):
     return [None] * len(params)
 
 
+
+SE3_ODOT_SHAPE = np.empty(6)
+"""Dummy second argument of ``fast_se3_odot`` (reference reprojection_motion_only_residual.py:9, 96): the reference's
+numba gufunc needs an input carrying the output's second core dimension; kept so that callers' code runs unchanged."""
+
+
+def fast_se3_odot(vec, junk=SE3_ODOT_SHAPE, out=None):
+    """``SE3.odot`` of a stack of points: (..., 3) -> (..., 3, 6), ``[I | -p^]`` per point -- the reference's
+    ``fast_se3_odot`` gufunc, layout '(n),(m)->(n,m)' (reprojection_motion_only_residual.py:12-32, also
+    photometric_residual.py:15-35).  ``junk`` only has to have 6 entries (the gufunc's way of naming the output width)."""
+    vec = np.asarray(vec, dtype=float)
+    if vec.shape[-1] != 3 or np.shape(junk)[-1] != 6:
+        raise ValueError('fast_se3_odot: vec must be (..., 3) and junk (6,)')
+    if out is None:
+        out = np.empty(vec.shape[:-1] + (3, 6))
+    out[..., :, :3] = np.identity(3)
+    out[..., 0, 3] = 0.
+    out[..., 0, 4] = vec[..., 2]
+    out[..., 0, 5] = -vec[..., 1]
+    out[..., 1, 3] = -vec[..., 2]
+    out[..., 1, 4] = 0.
+    out[..., 1, 5] = vec[..., 0]
+    out[..., 2, 3] = vec[..., 1]
+    out[..., 2, 4] = -vec[..., 0]
+    out[..., 2, 5] = 0.
+    return out
+
+
 class ReprojectionResidual:
     """r = S (project(T_cam_w p_w) - obs);  J_T = S Jc [I | -p_c^],  J_p = S Jc R."""
     KIND = "reproj"

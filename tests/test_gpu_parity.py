@@ -90,8 +90,8 @@ def test_reduced_system(name):
     dev.linearize(0.)
     S, g = dev.reduced_dense()
     So, go, _ = oracle_reduced(lp)
-    assert rel_err(S, So) < 1e-11
-    assert rel_err(g, go) < 1e-11
+    assert rel_err(S, So) < TOL_BLOCK          # measured maxima over the goldens: 2.8e-14 / 3.8e-14 (tools/parity_margins.py)
+    assert rel_err(g, go) < TOL_BLOCK
     assert np.abs(S - S.T).max() <= 1e-13 * np.abs(S).max()
 
 
@@ -146,15 +146,20 @@ def test_solve_trace_matches_reference(name):
     ref = g['cost_history']
     hist = np.array(problem._cost_history)
     assert len(hist) == len(ref), (hist, ref)
+    # cost <= 1e-10 relative, final poses / landmarks <= 1e-9.  One rounding-level absolute term, in units of
+    # the PREVIOUS cost: the first step of the Huber pose graphs takes the cost from 1e9 to 1e1, so the cost after it is
+    # resolved to eps * 1e9 by either implementation (measured there: 8e-11 .. 4e-10 relative to the new cost = 2e-17 of
+    # the old one; every other entry of every golden <= 1.2e-12, tools/parity_margins.py).
     big = ref > 1e-9 * ref[0]
-    assert np.allclose(hist[big], ref[big], rtol=1e-7)
+    prev = np.concatenate([[ref[0]], ref[:-1]])
+    assert np.all(np.abs(hist - ref)[big] <= TOL_COST * np.abs(ref[big]) + 1e-15 * prev[big]), np.abs(hist - ref) / np.abs(ref)
     if 'final_poses' in g:
         from pyslam_amd.lowering import pack_pose
         got = np.stack([pack_pose(final[k]) for k in problem._device.lp.pose_keys])
-        assert np.abs(got - g['final_poses']).max() < 1e-8
+        assert np.abs(got - g['final_poses']).max() < 1e-9           # measured <= 2.1e-11
     if 'final_points' in g:
         got = np.stack([final[k] for k in problem._device.lp.point_keys])
-        assert np.abs(got - g['final_points']).max() < 1e-7
+        assert np.abs(got - g['final_points']).max() < 1e-9          # measured <= 4.2e-12
 
 
 def test_deterministic_bitwise():
@@ -228,7 +233,7 @@ def test_every_loss_on_device_matches_oracle(loss_id, k):
         dev.linearize(0.)
         S, g = dev.reduced_dense()
         So, go, _ = oracle_reduced(prob)
-        assert rel_err(S, So) < 1e-11 and rel_err(g, go) < 1e-11
+        assert rel_err(S, So) < TOL_BLOCK and rel_err(g, go) < TOL_BLOCK
 
 
 def test_motion_only_batch_block_through_the_problem_api():
@@ -253,8 +258,8 @@ def test_motion_only_batch_block_through_the_problem_api():
     out = problem.solve()
     ref = g['cost_history']
     assert len(problem._cost_history) == len(ref)
-    assert np.allclose(problem._cost_history, ref, rtol=1e-7)
-    assert np.abs(pack_pose(out['T_2_1']) - g['final_poses'][0]).max() < 1e-8
+    assert np.allclose(problem._cost_history, ref, rtol=TOL_COST, atol=0)
+    assert np.abs(pack_pose(out['T_2_1']) - g['final_poses'][0]).max() < 1e-9
     assert problem.summary() == str(g['summary_brief'])
 
 
@@ -297,7 +302,7 @@ def test_rgbd_camera_reprojection_blocks():
     dev.linearize(0.)
     S_d, g_d = dev.reduced_dense()
     So, go, _ = oracle_reduced(lp)
-    assert rel_err(S_d, So) < 1e-11 and rel_err(g_d, go) < 1e-11
+    assert rel_err(S_d, So) < TOL_BLOCK and rel_err(g_d, go) < TOL_BLOCK
     out = problem.solve()
     for i, T in enumerate(Ts):
         assert np.linalg.norm(SE3.log(out['T{}'.format(i)].inv().dot(T))) < 1e-6

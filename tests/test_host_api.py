@@ -365,3 +365,19 @@ def test_same_tables_sees_every_edit_but_parameter_values():
     problem.residual_blocks[0], problem.residual_blocks[1] = problem.residual_blocks[1], problem.residual_blocks[0]
     problem.set_parameters_constant(a.point_keys[2])
     assert not a.same_tables(problem._lower())
+
+
+def test_fast_se3_odot_and_its_shape_constant_are_exported():
+    """reference reprojection_motion_only_residual.py:9-32 (surfaced by the residuals package's pkgutil walk):
+    fast_se3_odot(pts, SE3_ODOT_SHAPE) == SE3.odot(pts) for one point and for a stack."""
+    import pyslam.residuals as R
+    from liegroups import SE3
+    assert R.SE3_ODOT_SHAPE.shape == (6,)
+    rng = np.random.default_rng(0)
+    p = rng.standard_normal(3)
+    pts = rng.standard_normal((17, 3))
+    assert np.array_equal(R.fast_se3_odot(p, R.SE3_ODOT_SHAPE), SE3.odot(p))
+    assert np.array_equal(R.fast_se3_odot(pts, R.SE3_ODOT_SHAPE), SE3.odot(pts))
+    assert R.fast_se3_odot(pts, R.SE3_ODOT_SHAPE).shape == (17, 3, 6)
+    for name in ('stackmul', 'bilinear_interpolate', 'SE3'):
+        assert name in R.__all__ and hasattr(R, name)
