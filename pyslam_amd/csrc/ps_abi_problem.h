@@ -18,14 +18,10 @@ int ps_problem_destroy(ps_problem* h) {
     hipStreamSynchronize(h->stream);
     if (h->side) hipStreamSynchronize(h->side);
     for (void* p : h->allocs) hipFree(p);
-    if (h->h_scalars) hipHostFree(h->h_scalars);
-    if (h->h_status) hipHostFree(h->h_status);
-    if (h->h_seq) hipHostFree(h->h_seq);
-    if (h->h_setup) hipHostFree(h->h_setup);
-    if (h->h_shard) hipHostFree(h->h_shard);
+    h->arena_release();            // arena block, its pinned mirror and the pinned result words go back to the process-wide pool
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); hipEventDestroy(h->ev_acdone); }
-    if (h->own_stream) hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream && !ps_pool().give(ps_pool().streams, h->stream)) hipStreamDestroy(h->stream);
     delete h;
     return 0;
 }
@@ -52,7 +48,11 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     ps_problem* h = new ps_problem();
     struct Guard { ps_problem* h; bool ok = false; ~Guard() { if (!ok) ps_problem_destroy(h); } } guard{h};
     if (stream) h->stream = (hipStream_t)stream;
-    else { HIP_OK(hipStreamCreate(&h->stream)); h->own_stream = true; }
+    else {
+        if (!ps_pool().take(ps_pool().streams, &h->stream)) HIP_OK(hipStreamCreate(&h->stream));
+        h->own_stream = true;
+    }
+    if (h->arena_begin()) return -1;
     const int D = h->D = d->dof;
     const int PW = h->PW = (D == 6 ? 12 : 6);
     const int DD = D * D;
@@ -146,7 +146,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         h->upload(&h->lm_point, lm_point)) return -1;
     if (h->alloc(&h->Z, (size_t)Nl * PS_ZROW) || h->alloc(&h->Cinv, (size_t)nv * 6) ||
         h->alloc(&h->cvec, (size_t)nv * 3) || h->alloc(&h->dxl, (size_t)nv * 3)) return -1;
-    HIP_OK(hipMemsetAsync(h->dxl, 0, std::max<size_t>(1, (size_t)nv * 3) * sizeof(double), h->stream));
+    if (h->zero(h->dxl, (size_t)nv * 3 * sizeof(double))) return -1;
 
     lap("landmark sort + lobs");
     // ---- pose segments (observations on variable poses), chunks of 256
@@ -629,9 +629,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         if (h->upload(&h->brow_of, brow_of) || h->upload(&h->ident_slot, ident)) return -1;
         if (h->alloc(&h->Linv, (size_t)nr * DD)) return -1;
     }
-    HIP_OK(hipMemsetAsync(h->x, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
-    HIP_OK(hipMemsetAsync(h->p0, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
-    HIP_OK(hipMemsetAsync(h->p1, 0, std::max<size_t>(1, nvec) * sizeof(double), h->stream));
+    if (h->zero(h->x, nvec * sizeof(double)) || h->zero(h->p0, nvec * sizeof(double)) || h->zero(h->p1, nvec * sizeof(double))) return -1;
 
     lap("pcg workspace");
     // ---- scalars
@@ -639,27 +637,28 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     h->ncost_fac = F > 0 ? std::min(1024, cdiv(F, 256)) : 0;
     if (h->alloc(&h->cost_partials, (size_t)std::max(h->ncost_obs + h->ncost_fac, 512) + 8) ||
         h->alloc(&h->scalars, SC_NWORDS)) return -1;
-    HIP_OK(hipMemsetAsync(h->scalars, 0, SC_NWORDS * sizeof(double), h->stream));
-    HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+    if (h->zero(h->scalars, SC_NWORDS * sizeof(double)) || h->zero(h->status, ST_NWORDS * sizeof(int32_t))) return -1;
     h->nsq_l = nv > 0 ? cdiv(nv, 256 / PS_LM_GROUP) : 0;
     h->nsq_p = nr > 0 ? cdiv(P, 256) : 0;
     if (h->alloc(&h->sq_part_l, (size_t)h->nsq_l) || h->alloc(&h->sq_part_p, (size_t)h->nsq_p) ||
         h->alloc(&h->shard_buf, 2)) return -1;
-    HIP_OK(hipMemsetAsync(h->shard_buf, 0, 2 * sizeof(double), h->stream));
-    HIP_OK(hipHostMalloc((void**)&h->h_scalars, SC_NWORDS * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-    HIP_OK(hipHostMalloc((void**)&h->h_status, ST_NWORDS * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
-    HIP_OK(hipHostGetDevicePointer((void**)&h->h_scalars_dev, h->h_scalars, 0));
-    HIP_OK(hipHostGetDevicePointer((void**)&h->h_status_dev, h->h_status, 0));
-    HIP_OK(hipHostMalloc((void**)&h->h_seq, sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
-    HIP_OK(hipHostMalloc((void**)&h->h_shard, 2 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-    HIP_OK(hipHostGetDevicePointer((void**)&h->h_shard_dev, h->h_shard, 0));
-    HIP_OK(hipHostGetDevicePointer((void**)&h->h_seq_dev, h->h_seq, 0));
-    *h->h_seq = 0;
-    HIP_OK(hipHostMalloc((void**)&h->h_setup, sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
-    HIP_OK(hipHostGetDevicePointer((void**)&h->h_setup_dev, h->h_setup, 0));
-    *h->h_setup = 0;
+    if (h->zero(h->shard_buf, 2 * sizeof(double))) return -1;
+    // the pinned, host-mapped result words: one block (from the pool), five windows at 256-byte offsets
+    if (!ps_pool().take(ps_pool().host_words, &h->words_host))
+        HIP_OK(hipHostMalloc(&h->words_host, PS_WORDS_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h->words_host, 0, PS_WORDS_BYTES);
+    char* wdev = nullptr;
+    HIP_OK(hipHostGetDevicePointer((void**)&wdev, h->words_host, 0));
+    static_assert(SC_NWORDS * sizeof(double) <= 256 && ST_NWORDS * sizeof(int32_t) <= 256, "result words outgrew their windows");
+    char* whost = (char*)h->words_host;
+    h->h_scalars = (double*)(whost + 0);      h->h_scalars_dev = (double*)(wdev + 0);
+    h->h_status = (int32_t*)(whost + 256);    h->h_status_dev = (int32_t*)(wdev + 256);
+    h->h_seq = (long long*)(whost + 512);     h->h_seq_dev = (long long*)(wdev + 512);
+    h->h_shard = (double*)(whost + 768);      h->h_shard_dev = (double*)(wdev + 768);
+    h->h_setup = (long long*)(whost + 1024);  h->h_setup_dev = (long long*)(wdev + 1024);
     if (h->alloc(&h->arrivals, 2)) return -1;
-    HIP_OK(hipMemsetAsync(h->arrivals, 0, 2 * sizeof(int32_t), h->stream));
+    if (h->zero(h->arrivals, 2 * sizeof(int32_t))) return -1;
+    if (h->arena_close()) return -1;
     HIP_OK(hipStreamSynchronize(h->stream));
     lap("scalars + final sync");
     guard.ok = true;

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,34 @@ int fail(const std::string& msg) { g_err = msg; return -1; }
     } while (0)
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- process-wide cache of the fixed-cost resources of a handle -----------------------------------------------
+// A per-frame Problem (reference pipelines/sparse.py:153-161: a fresh Problem for every image pair) creates and
+// destroys a handle per solve; for a 45 us iteration the ~30 hipMalloc + hipMemcpy pairs, five hipHostMalloc and a
+// hipStreamCreate of ps_problem_create (0.65-0.70 ms) were the latency the user saw.  So:
+//   * tables of up to PS_ARENA_SMALL bytes are carved from ONE device block per handle ("arena") and staged in a pinned
+//     mirror; ps_problem_create ends with a single asynchronous copy of the used part (big tables keep hipMalloc);
+//   * the pinned, host-mapped result words of a handle live in one 4 KB block;
+//   * arena blocks, mirrors, word blocks and streams of destroyed handles are kept (up to PS_POOL_KEEP each) and handed
+//     to the next ps_problem_create.
+constexpr size_t PS_ARENA_BYTES = 2u << 20, PS_ARENA_SMALL = 192u << 10, PS_WORDS_BYTES = 4096;
+constexpr size_t PS_POOL_KEEP = 8;
+struct PsPool {
+    std::mutex mu;
+    std::vector<void*> dev_arenas, host_arenas, host_words;
+    std::vector<hipStream_t> streams;
+    template <typename T> bool take(std::vector<T>& v, T* out) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (v.empty()) return false;
+        *out = v.back(); v.pop_back(); return true;
+    }
+    template <typename T> bool give(std::vector<T>& v, T x) {      // false: the pool is full, the caller frees
+        std::lock_guard<std::mutex> lk(mu);
+        if (v.size() >= PS_POOL_KEEP) return false;
+        v.push_back(x); return true;
+    }
+};
+PsPool& ps_pool() { static PsPool* p = new PsPool(); return *p; }   // (leaked on purpose: no destructor order issues at exit)
 
 }  // namespace
 
@@ -232,10 +261,26 @@ struct ps_problem {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
 
+    // create-time arena (see PsPool): device block + pinned mirror, open only inside ps_problem_create
+    char *arena_dev = nullptr, *arena_host = nullptr;
+    void* words_host = nullptr;
+    size_t arena_used = 0;
+    bool arena_open = false;
+
     template <typename T>
     int alloc(T** out, size_t n) {
         *out = nullptr;
         const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        if (arena_open && bytes <= PS_ARENA_SMALL) {
+            const size_t off = (arena_used + 255) & ~(size_t)255;
+            if (off + bytes <= PS_ARENA_BYTES) {
+                std::memset(arena_host + off, 0, bytes);          // the closing copy writes the whole used range
+                arena_used = off + bytes;
+                dev_bytes += bytes;
+                *out = (T*)(arena_dev + off);
+                return 0;
+            }
+        }
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -244,17 +289,47 @@ struct ps_problem {
         *out = (T*)p;
         return 0;
     }
-    template <typename T>
-    int upload(T** out, const std::vector<T>& v) {
-        if (alloc(out, v.size())) return -1;
-        if (!v.empty()) HIP_OK(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-        return 0;
+    bool in_arena(const void* p) const {
+        return arena_open && (const char*)p >= arena_dev && (const char*)p < arena_dev + PS_ARENA_BYTES;
     }
     template <typename T>
     int upload(T** out, const T* src, size_t n) {
         if (alloc(out, n)) return -1;
-        if (n) HIP_OK(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice));
+        if (!n) return 0;
+        if (in_arena(*out)) std::memcpy(arena_host + ((char*)*out - arena_dev), src, n * sizeof(T));
+        else HIP_OK(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice));
         return 0;
+    }
+    template <typename T>
+    int upload(T** out, const std::vector<T>& v) { return upload(out, v.data(), v.size()); }
+    // zero-fill on the stream; arena memory is already zero in the mirror (and must not be touched before the closing copy)
+    int zero(void* p, size_t bytes) {
+        if (in_arena(p)) return 0;
+        HIP_OK(hipMemsetAsync(p, 0, std::max<size_t>(bytes, 1), stream));
+        return 0;
+    }
+    int arena_begin() {
+        PsPool& pool = ps_pool();
+        void *d = nullptr, *m = nullptr;
+        if (!pool.take(pool.dev_arenas, &d)) HIP_OK(hipMalloc(&d, PS_ARENA_BYTES));
+        arena_dev = (char*)d;
+        if (!pool.take(pool.host_arenas, &m)) HIP_OK(hipHostMalloc(&m, PS_ARENA_BYTES, hipHostMallocDefault));
+        arena_host = (char*)m;
+        arena_used = 0;
+        arena_open = true;
+        return 0;
+    }
+    int arena_close() {        // one copy of everything staged; the caller synchronises the stream afterwards
+        arena_open = false;
+        if (arena_used) HIP_OK(hipMemcpyAsync(arena_dev, arena_host, arena_used, hipMemcpyHostToDevice, stream));
+        return 0;
+    }
+    void arena_release() {     // after the handle's streams are idle
+        PsPool& pool = ps_pool();
+        if (arena_dev && !pool.give(pool.dev_arenas, (void*)arena_dev)) hipFree(arena_dev);
+        if (arena_host && !pool.give(pool.host_arenas, (void*)arena_host)) hipHostFree(arena_host);
+        if (words_host && !pool.give(pool.host_words, words_host)) hipHostFree(words_host);
+        arena_dev = arena_host = nullptr; words_host = nullptr;
     }
 };
 

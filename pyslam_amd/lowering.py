@@ -284,7 +284,7 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
     for k, i in pose_ix.items():
         poses[i] = pack_pose(param_dict[k])
     points = [np.asarray(param_dict[k], dtype=F64) for k in point_keys]
-    fixed_points = []          # motion-only points appended after the landmarks
+    fixed_points, n_fixed = [], 0   # motion-only points appended after the landmarks ((m, 3) chunks)
 
     rid, n = np.full(len(pose_keys), -1, dtype=I32), 0
     for k in pose_keys:
@@ -334,14 +334,17 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
                 o_uvd.append(np.asarray(block.obs, dtype=F64))
                 o_g.append(g)
             else:
-                pts = np.atleast_2d(block.pt_1 if kind == 'reproj_motion_only' else block.pts_1)
+                # whole block at once (the per-frame Problem of pipelines/sparse.py:153-161 is ONE batch block of
+                # ~10^3 points: a Python loop over them was 0.9 ms of a 2 ms solve)
+                pts = np.atleast_2d(np.asarray(block.pt_1 if kind == 'reproj_motion_only' else block.pts_1, dtype=F64))
                 obs2 = np.atleast_2d(np.asarray(block.obs_2, dtype=F64))
-                for p, o in zip(pts, obs2):
-                    o_pose.append(pose_ix[keys[0]])
-                    o_pt.append(L0 + len(fixed_points))
-                    fixed_points.append(np.asarray(p, dtype=F64))
-                    o_uvd.append(o)
-                    o_g.append(g)
+                m = min(len(pts), len(obs2))
+                o_pose.extend([pose_ix[keys[0]]] * m)
+                o_pt.extend(range(L0 + n_fixed, L0 + n_fixed + m))
+                fixed_points.append(pts[:m])
+                n_fixed += m
+                o_uvd.append(obs2[:m])
+                o_g.extend([g] * m)
         elif kind in ('pose_pose', 'pose_prior'):
             if any(k not in pose_ix for k in keys):
                 raise NotLowerable("pose block on a non-pose parameter")
@@ -398,10 +401,11 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
                            "hold at most {}".format(len(ogrp.rows), MAX_OBS_GROUPS))
 
     lp.poses, lp.pose_rid = poses, rid
-    lp.points = np.array(points + fixed_points).reshape(-1, 3)
-    lp.point_vid = np.array(vid + [-1] * len(fixed_points), dtype=I32)
+    lp.points = np.concatenate([np.array(points, dtype=F64).reshape(-1, 3)] + fixed_points)
+    lp.point_vid = np.array(vid + [-1] * n_fixed, dtype=I32)
     lp.obs_pose, lp.obs_point, lp.obs_grp = o_pose, o_pt, o_g
-    lp.obs_uvd = np.array(o_uvd).reshape(-1, 3)
+    lp.obs_uvd = np.concatenate([np.zeros((0, 3))] + [u.reshape(-1, 3) for u in o_uvd]) if n_fixed else \
+        np.array(o_uvd).reshape(-1, 3)
     lp.cams, lp.stiff3, lp.obs_groups = cams.table(5), st3.table(9), ogrp.table(4)
     lp.e_i, lp.e_j, lp.e_grp = e_i, e_j, e_g
     lp.e_Tobs_inv = np.array(e_T).reshape(-1, pw)
