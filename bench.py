@@ -175,6 +175,7 @@ def c4_single_gpu(stream, steps=10, warmup=5):
     from pyslam_amd.device import DeviceProblem
     lp, _ = synthetic.stereo_ba(obs_per_lm=OBS_PER_LM, half_window=HALF_WINDOW, **C4)
     dev = DeviceProblem(lp, stream=stream)
+    dev.eval_cost(True)                                      # (as Problem.solve does: the core then knows the start cost)
     dev.snapshot()
     sec, out = time_steps(dev, steps, warmup, torch.cuda.synchronize)
     dev.set_profiling(2)
@@ -244,6 +245,7 @@ def main():
         lp = lp_full
         dev = DeviceProblem(lp, stream=stream)
     info = dev.info
+    dev.eval_cost(True)                                      # Problem.solve() evaluates the start cost first (reference problem.py:133)
     dev.snapshot()                                           # the common linearisation point
 
     def step():

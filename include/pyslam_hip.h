@@ -87,6 +87,9 @@ typedef struct ps_problem_info {
                                     from the true residual                                    */
     int64_t cg_kernel_launches;  /* kernels enqueued for iterations of the reduced solve so far (1 per iteration for the
                                     folded CG, 3 or 4 for the explicit two-level PCG, 2 for the classic PCG)            */
+    int64_t ldi_solves;          /* reduced solves preconditioned with the lagged dense inverse (option "lagged_inverse")   */
+    int64_t ldi_fallbacks;       /* ... that gave the inverse up after "ldi_cap" iterations and ran the standard solver       */
+    int64_t ldi_seeds;           /* inverses seeded on the side stream (after a standard solve)                             */
 } ps_problem_info;
 
 enum { PS_NUM_STAGES = 10 };
@@ -224,6 +227,12 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
                               relative) keep the lagged coarse inverse, for at most 3 set-ups in a row (no assembly, no factorisation)
      "xcg_restrict_fused" [1] explicit two-level PCG: three launches per iteration (restriction in the SpMV epilogue, t by recurrence)
                               instead of four
+     "lagged_inverse"     [1] reduced systems of 91 .. "ldi_max_unknowns" [1536] unknowns (folded CG, one GPU, whole-iteration calls):
+                              precondition the CG with a dense fp32 inverse of the PREVIOUS iteration's S, kept current on the side
+                              stream by one Newton-Schulz step per iteration (two fp32 MFMA GEMMs) and seeded from the two-level
+                              operator of the last standard solve; tried while the last step changed the cost by at most
+                              "ldi_cost_tol" [0.05] relative, given up (standard solver + re-seed) after "ldi_cap" [12] iterations.
+                              It only preconditions: the solution is the current system's at pcg_tol either way.
      "band_chol"          [1] explicit two-level PCG: banded factorisation + band substitutions for the coarse inverse when A_c
                               has at most 7 block off-diagonals (chain-like problems); 0: always the dense factorisation
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual

@@ -41,6 +41,7 @@ class ProblemInfo(C.Structure):
         ('num_obs', C.c_int64), ('num_edges', C.c_int64), ('num_priors', C.c_int64),
         ('reduced_nnzb', C.c_int64), ('num_pairs', C.c_int64), ('reduce_count', C.c_int64),
         ('device_bytes', C.c_int64), ('cg_restarts', C.c_int64), ('cg_kernel_launches', C.c_int64),
+        ('ldi_solves', C.c_int64), ('ldi_fallbacks', C.c_int64), ('ldi_seeds', C.c_int64),
     ]
 
 

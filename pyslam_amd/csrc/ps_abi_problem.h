@@ -20,6 +20,7 @@ int ps_problem_destroy(ps_problem* h) {
     for (void* p : h->allocs) hipFree(p);
     h->arena_release();            // arena block, its pinned mirror and the pinned result words go back to the process-wide pool
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->ev_ldi) { hipEventDestroy(h->ev_ldi); hipEventDestroy(h->ev_ldi_sread); hipEventDestroy(h->ev_ldi_ritz); }
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); hipEventDestroy(h->ev_acdone); }
     if (h->own_stream && h->stream && !ps_pool().give(ps_pool().streams, h->stream)) hipStreamDestroy(h->stream);
     delete h;
@@ -656,6 +657,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     h->h_seq = (long long*)(whost + 512);     h->h_seq_dev = (long long*)(wdev + 512);
     h->h_shard = (double*)(whost + 768);      h->h_shard_dev = (double*)(wdev + 768);
     h->h_setup = (long long*)(whost + 1024);  h->h_setup_dev = (long long*)(wdev + 1024);
+    h->h_ldi_fro = (double*)(whost + 1280);   h->h_ldi_fro_dev = (double*)(wdev + 1280);
     if (h->alloc(&h->arrivals, 2)) return -1;
     if (h->zero(h->arrivals, 2 * sizeof(int32_t))) return -1;
     if (h->arena_close()) return -1;

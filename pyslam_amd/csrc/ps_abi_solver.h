@@ -10,6 +10,7 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
     info->device_bytes = (int64_t)h->dev_bytes;
     info->cg_restarts = h->cg_fallbacks;
     info->cg_kernel_launches = h->cg_kernel_launches;
+    info->ldi_solves = h->ldi_solves; info->ldi_fallbacks = h->ldi_fallbacks; info->ldi_seeds = h->ldi_seeds;
     return 0;
 }
 
@@ -18,11 +19,13 @@ int ps_eval_cost(ps_problem* h, int include_all_constant, double* cost) {
     if (cost_pass(h, include_all_constant, SC_COST)) return -1;
     if (read_scalars(h)) return -1;
     *cost = h->h_scalars[SC_COST];
-    return 0;
+    if (include_all_constant) h->last_cost = *cost;         // the cost AT the current parameters (what ps_gn_iteration's line-search
+    return 0;                                               // cost is for the parameters it leaves behind)
 }
 
 int ps_linearize(ps_problem* h, double lambda) {
     if (!h) return fail("null argument");
+    h->last_cost = h->prev_cost = -1.0;                     // staged API: the cost history of whole-iteration calls ends here
     return linearize(h, lambda);
 }
 
@@ -110,11 +113,13 @@ int ps_step_norm2(ps_problem* h, double* norm2) {
 
 int ps_apply_update(ps_problem* h, double step) {
     if (!h) return fail("null argument");
+    h->last_cost = h->prev_cost = -1.0;                     // parameters move without a cost: history unknown from here
     return apply_update(h, step);
 }
 
 int ps_snapshot_params(ps_problem* h) {
     if (!h) return fail("null argument");
+    h->snap_cost = h->last_cost;
     const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
     if (n1 + n2)
         hipLaunchKernelGGL(k_copy2, dim3((unsigned)std::min<size_t>(2048, cdiv((long)(n1 + n2), 256))), dim3(256), 0, h->stream,
@@ -124,7 +129,7 @@ int ps_snapshot_params(ps_problem* h) {
 
 int ps_restore_params(ps_problem* h) {
     if (!h) return fail("null argument");
-    h->last_cost = h->prev_cost = -1.0;
+    h->last_cost = h->snap_cost; h->prev_cost = -1.0;       // the snapshot's own cost (if it was known), no step history
     const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
     if (n1 + n2)
         hipLaunchKernelGGL(k_copy2, dim3((unsigned)std::min<size_t>(2048, cdiv((long)(n1 + n2), 256))), dim3(256), 0, h->stream,
@@ -470,6 +475,12 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "xcg_restrict_fused") h->xcg_rt = value != 0;
     else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
     else if (n == "coarse_auto_hold") h->xcg_auto_hold = value != 0;
+    else if (n == "lagged_inverse") { h->ldi_enable = value != 0; if (!h->ldi_enable) { h->ldi_cur = -1; if (h->ldi_state != 1) h->ldi_state = 0; } }
+    else if (n == "ldi_max_unknowns") { if (value < 0 || value > PS_LDI_MAXN) return fail("ldi_max_unknowns out of range (0 .. 2048)"); h->ldi_max_n = (int)value; }
+    else if (n == "ldi_cap") { if (value < 1 || value > 64) return fail("ldi_cap out of range (1 .. 64)"); h->ldi_cap = (int)value; }
+    else if (n == "ldi_cost_tol") { if (!(value >= 0)) return fail("ldi_cost_tol must be >= 0"); h->ldi_cost_tol = value; }
+    else if (n == "ldi_refresh_its") { if (value < 0 || value > 64) return fail("ldi_refresh_its out of range (0 .. 64)"); h->ldi_refresh_its = (int)value; }
+    else if (n == "ldi_seed_steps") { if (value < 1 || value > 40) return fail("ldi_seed_steps out of range (1 .. 40)"); h->ldi_seed_steps = (int)value; }
     else if (n == "coarse_refresh_every") { if (value < 1 || value > 16) return fail("coarse_refresh_every must be 1..16"); h->xcg_refresh_every = (int)value; }
     else if (n == "coarse_lag_x") { h->lagx = value != 0.0; h->lci_next = -1; h->side_todo = false; }
     else if (n == "cg_lds") h->cg_lds = value != 0.0;

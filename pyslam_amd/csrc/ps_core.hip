@@ -175,6 +175,7 @@ struct ps_problem {
     bool side_pending = false;      // a side-stream factorisation is in flight: wait for ev_chol before reuse
     int coarse_lag = 1;
     hipStream_t side = nullptr;
+    int side_cus = 0;               // > 0: the side stream is confined to this many compute units (CU mask)
     hipEvent_t ev_ac = nullptr, ev_chol = nullptr, ev_acdone = nullptr;
     bool acdone_pending = false;    // explicit PCG: the side stream may still be assembling A_c from SB / the basis (wait before they are overwritten)
     int32_t* lag_status = nullptr;  // ST_DIAG_FAIL of the side-stream factorisation
@@ -252,6 +253,37 @@ struct ps_problem {
     bool shard_out = false;         // k_reduce3 writes cost / ||dx_point||^2 there instead of into scalars
     double *sq_part_l = nullptr, *sq_part_p = nullptr;   // per-workgroup partials of ||dx_point||^2, ||dx_pose||^2
     int nsq_l = 0, nsq_p = 0;
+    // lagged dense inverse of the reduced system as the CG preconditioner (ps_k_ldi.h / ps_host_ldi.h)
+    int ldi_enable = 1;             // option "lagged_inverse"
+    int ldi_max_n = 1536;           // option "ldi_max_unknowns": reduced systems up to this many unknowns
+    int ldi_cap = 12;               // option "ldi_cap": PCG iterations before a solve gives the inverse up
+    int ldi_seed_steps = 3;         // Newton-Schulz steps of a seed
+    double ldi_cost_tol = 0.05;     // option "ldi_cost_tol": try the inverse while the last step changed the cost by at most this (relative)
+    bool ldi_ready = false;         // buffers allocated
+    int ldi_n = 0, ldi_np = 0, ldi_kp = 0;
+    float *ldi_S32 = nullptr, *ldi_X32 = nullptr, *ldi_R32 = nullptr, *ldi_T32 = nullptr, *ldi_Xt = nullptr, *ldi_XtT = nullptr;
+    float* ldi_Xu[2] = {};          // unscaled inverse, double-buffered against the side stream
+    double *ldi_x64 = nullptr, *ldi_Linv = nullptr, *ldi_r[2] = {}, *ldi_part = nullptr, *ldi_fro_part = nullptr;
+    double *h_ldi_fro = nullptr, *h_ldi_fro_dev = nullptr;   // ||R||_F^2 of the side stream's last Newton-Schulz step (pinned)
+    int ldi_state = 0;              // 0 none, 1 seed in flight, 2 valid (ldi_cur), 3 valid + update in flight
+    int ldi_cur = -1, ldi_next = -1;
+    long ldi_iter = 0, ldi_ready_at = 0;
+    double ldi_fro_limit = 0.1, ldi_last_rms = 0.0;
+    bool ldi_side_todo = false, ldi_update_ok = false, ldi_sread_pending = false, ldi_ritz_ok = false;
+    double ldi_ritz_lo = 0.0, ldi_ritz_hi = 0.0;
+    int ldi_last_its = 0, ldi_prev_its = 0;
+    int ldi_refresh_its = 7;        // option "ldi_refresh_its": solves slower than this switch the per-iteration refresh on
+    bool ldi_refreshed = false;     // the inverse in use has had a Newton-Schulz step since its seed
+    int2* ldi_krange = nullptr;
+    int ldi_rejects = 0; long ldi_no_seed_before = 0;
+    float* ldi_coef = nullptr;      // device: seed scale c and the two Ritz values (k_ldi_ritz)
+    double ldi_tag = -1.0, ldi_next_tag = -1.0, ldi_call_start_cost = -1.0;   // cost at the point the inverse in use / in flight was built at
+    hipEvent_t ev_ldi_ritz = nullptr;
+    double ldi_prev_start_cost = -2.0;   // cost the previous standard-path call started from
+    long ldi_solves = 0, ldi_fallbacks = 0, ldi_seeds = 0;
+    bool last_setup_lagx = false;   // the current folded system was built with the lagged X~ (three-launch set-up)
+    hipEvent_t ev_ldi = nullptr, ev_ldi_sread = nullptr;
+    double snap_cost = -1.0;        // last_cost at the time of ps_snapshot_params
     // profiling
     int profiling = 0;              // 0 off, 1 = iteration total + Schur kernel only, 2 = every stage
     hipEvent_t ev[2 * PS_NUM_STAGES] = {};
@@ -334,6 +366,7 @@ struct ps_problem {
 };
 
 #include "ps_host_cg.h"
+#include "ps_host_ldi.h"
 #include "ps_host_iteration.h"
 
 // ===========================================================================

@@ -42,6 +42,7 @@ void drain_timers(ps_problem* h) {      // call after a stream synchronisation
 }
 
 int side_kick(ps_problem* h);
+int ldi_side_kick(ps_problem* h);
 
 int sync(ps_problem* h) {
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -68,8 +69,11 @@ int wait_published(ps_problem* h) {
         // the set-up kernels of this iteration have finished (stamp of k_coarse_mreduce): the side stream's inputs are
         // complete, and the host has nothing to do but wait -- enqueue the next coarse operator now, beside the CG
         if (kick_mode == 2 && h->side_todo && !h->side_ready && *ws == h->setup_seq) { h->side_ready = true; if (side_kick(h)) return -1; }
+        // (lagged dense inverse: k_ldi_init has started, S is final -- the Newton-Schulz step may run beside the solve)
+        if (h->ldi_side_todo && *ws == h->setup_seq) { if (ldi_side_kick(h)) return -1; }
         if (*w == h->seq) {
             if (h->side_todo) { h->side_ready = true; if (kick_mode >= 1 && side_kick(h)) return -1; }
+            if (h->ldi_side_todo && ldi_side_kick(h)) return -1;
             if (h->pending.empty()) return 0;
             // stage timers: everything up to k_reduce3 has completed; an event recorded behind it may
             // need a moment more
@@ -175,6 +179,10 @@ int build_coarse(ps_problem* h) {
         t_last = now;
     };
     const int nr = h->nr, D = h->D;
+    if (h->ldi_ready) {                 // a rebuilt coarse level changes the sizes the lagged dense inverse was laid out for
+        if (h->side) HIP_OK(hipStreamSynchronize(h->side));
+        h->ldi_ready = false; h->ldi_state = 0; h->ldi_cur = -1; h->ldi_side_todo = false; h->ldi_last_its = 0;
+    }
     int G = h->coarse_req;
     const int Gmax = 63;                           // nc = (G + 1) D <= 384; LDS-resident factorisation up to nc = 96
     // auto: on from 16 reduced poses, ~18 poses per hat interval, at most 12 intervals while the
@@ -386,6 +394,14 @@ int build_coarse(ps_problem* h) {
     if (!h->side) {
         int prio_lo = 0, prio_hi = 0;                      // lowest priority: the side work must not delay the CG launches
         HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        // PS_SIDE_CUS=n (measurement switch): confine the side stream to n compute units (CU mask, low bits: spread evenly
+        // over the XCDs) instead of running it at low priority over the whole chip
+        const int side_cus = getenv("PS_SIDE_CUS") ? atoi(getenv("PS_SIDE_CUS")) : h->side_cus;
+        if (side_cus > 0) {
+            uint32_t mask[8] = {};
+            for (int b = 0; b < std::min(side_cus, 256); ++b) mask[b >> 5] |= 1u << (b & 31);
+            HIP_OK(hipExtStreamCreateWithCUMask(&h->side, 8, mask));
+        } else
         HIP_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
         HIP_OK(hipEventCreateWithFlags(&h->ev_ac, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&h->ev_acdone, hipEventDisableTiming));
@@ -516,8 +532,10 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
         h->mc_active = false;
         h->side_todo = true; h->side_ready = false; h->side_buf = nb;
         h->cg_launched = 0;
+        h->last_setup_lagx = true;
         return 0;
     }
+    h->last_setup_lagx = false;
     h->side_todo = false;                                   // the exact path below recomputes everything coarse
     if (G) h->Bmat = h->Bmat2[h->lagx_ok ? h->lci_cur : 0];
     // block-Jacobi factors + the start vectors of the scaled system (r = Linv g, w = s = p = x = 0)
@@ -749,6 +767,10 @@ int linearize(ps_problem* h, double lambda) {
     ++h->prof_tick;
     h->cov_ready = false;
     h->status_clean = false;
+    if (h->ldi_sread_pending) {         // the side stream's inverse update still converts the previous S (ps_host_ldi.h)
+        HIP_OK(hipStreamWaitEvent(h->stream, h->ev_ldi_sread, 0));
+        h->ldi_sread_pending = false;
+    }
     HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double) + ST_NWORDS * sizeof(int32_t), h->stream));   // [S | g | cost | status]
     if (h->nv > 0) {
         StageTimer t(h, PS_ST_LANDMARK);

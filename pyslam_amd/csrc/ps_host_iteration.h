@@ -244,6 +244,13 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         }
         return cg_report(h, iters_out, relres_out);
     }
+    ++h->ldi_iter;
+    h->ldi_call_start_cost = h->last_cost;                  // cost at this call's linearisation point (-1: unknown)
+    if (ldi_decide(h)) {                                    // a lagged dense inverse of S is at hand: 2-6 two-launch iterations
+        const int rc = ldi_solve_and_finish<D>(h, tol, max_iters, linesearch, iters_out, relres_out, &tp, total);
+        if (rc <= 0) return rc;
+        // gave up (nothing applied): the standard solve below, which also re-seeds the inverse
+    }
     if (cg_fused_setup<D>(h, max_iters, true)) return -1;
     // launches needed = iterations + 2 (the k = -1 launch and the one that detects convergence): exactly that when the
     // last two solves took the same number of iterations (0.360 -> 0.348 ms at C3), the configured margin otherwise --
@@ -273,7 +280,11 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         }
         count = std::max(8, h->cg_launched / 2);
     }
-    return cg_report(h, iters_out, relres_out);
+    if (cg_report(h, iters_out, relres_out)) return -1;
+    // a clean standard solve: its operator and CG coefficients seed the lagged dense inverse (side stream)
+    if (h->h_status[ST_PCG_DONE] == 1 &&
+        ldi_seed_enqueue<D>(h, h->h_status[ST_PCG_ITERS], linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST])) return -1;
+    return 0;
 }
 }  // namespace
 

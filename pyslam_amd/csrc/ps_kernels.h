@@ -93,6 +93,7 @@ PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
 #include "ps_k_linearize.h"
 #include "ps_k_stream.h"
 #include "ps_k_pcg_classic.h"
+#include "ps_k_ldi.h"
 #include "ps_k_cg_fused.h"
 #include "ps_k_xcg.h"
 #include "ps_k_coarse.h"

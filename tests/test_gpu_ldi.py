@@ -1,0 +1,172 @@
+"""GPU: the lagged dense inverse of the reduced system as CG preconditioner (option "lagged_inverse", csrc/ps_k_ldi.h,
+ps_host_ldi.h).  It only PRECONDITIONS -- every solve still ends at pcg_tol on the current system -- so the tests are:
+the same Gauss-Newton trajectory with and without it, steps against the oracle's direct solve while it is active,
+and every way out of it (iteration cap, rejected seeds, a problem that jumps) landing on the standard solver."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import gn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def info(dev):
+    from pyslam_amd import _native as nat
+    i = nat.ProblemInfo()
+    nat.check(dev._lib.ps_get_info(dev._h, C.byref(i)))
+    return i.ldi_solves, i.ldi_fallbacks, i.ldi_seeds
+
+
+def make(lp, on, **opts):
+    from pyslam_amd.device import DeviceProblem
+    dev = DeviceProblem(lp)
+    dev.set_option('lagged_inverse', 1 if on else 0)
+    for k, v in opts.items():
+        dev.set_option(k, v)
+    dev.eval_cost(True)          # as Problem.solve() does: the core knows the cost it starts from
+    return dev
+
+
+def device_dx(dev, lp):
+    xp, xl = dev.get_dx()
+    return np.concatenate([xp.ravel(), xl.ravel()])
+
+
+def ba(kf, lm, seed, **kw):
+    from pyslam_amd import synthetic
+    return synthetic.stereo_ba(num_kf=kf, num_lm=lm, obs_per_lm=6, half_window=8, seed=seed, **kw)[0]
+
+
+@pytest.mark.parametrize('lam', [0.0, 1e-3])
+def test_same_trajectory_with_and_without_the_lagged_inverse(lam):
+    """60 keyframes (354 reduced unknowns), 10 Gauss-Newton iterations: cost after every step to 1e-10, final parameters
+    to 1e-9; the inverse takes over once the solve has settled and needs a third of the CG iterations."""
+    lp = ba(60, 6000, 21)
+    a, b = make(lp, True), make(lp, False)
+    its_a, its_b = [], []
+    for _ in range(10):
+        ca, na, ia, ra = a.gn_iteration(lam, 1e-12, 500, True)
+        cb, nb, ib, rb = b.gn_iteration(lam, 1e-12, 500, True)
+        assert abs(ca - cb) <= 1e-10 * abs(cb)
+        assert ra <= 1e-11 and rb <= 1e-11
+        its_a.append(ia); its_b.append(ib)
+    solves, fallbacks, seeds = info(a)
+    assert solves >= 4 and seeds >= 1, (solves, fallbacks, seeds, its_a)
+    assert info(b) == (0, 0, 0)
+    assert min(its_a) * 2 <= min(its_b), (its_a, its_b)
+    pa, pb = a.get_params(), b.get_params()
+    assert np.abs(pa[0] - pb[0]).max() < 1e-9 and np.abs(pa[1] - pb[1]).max() < 1e-9
+
+
+def test_steps_match_the_oracle_while_the_inverse_is_active():
+    """Every step of a solve -- the standard ones, the ones beside a seed, the ones preconditioned with the inverse --
+    against the oracle's sparse direct solve at the same linearisation point (||dx - dx_ref|| / ||dx_ref|| <= 1e-8)."""
+    from pyslam_amd.lowering import LoweredProblem
+    lp = ba(30, 1500, 5)
+    dev = make(lp, True)
+    cur = lp.copy()
+    active, first = 0, None
+    for it in range(8):
+        before = info(dev)[0]
+        dx_ref, _ = orc.gauss_newton_step(cur, points_first=False)
+        cost, nrm, its, rel = dev.gn_iteration(0., 1e-12, 500, True)
+        dx = device_dx(dev, cur)
+        first = np.linalg.norm(dx_ref) if first is None else first
+        # (relative to the step while it is a step; once the solve has converged -- steps 1e-6 of the first one -- both
+        #  solvers resolve it to cond(S) * their residual tolerance, which is what the floor stands for)
+        assert np.linalg.norm(dx - dx_ref) <= 1e-8 * max(np.linalg.norm(dx_ref), 1e-4 * first), it
+        active += info(dev)[0] - before
+        poses, points = dev.get_params()
+        cur = cur.copy(); cur.poses, cur.points = poses, points
+    assert active >= 3
+
+
+def test_repeated_linearisation_point():
+    """The steady-state bench's pattern (and a damping retry's): the same point linearised again and again.  The inverse is
+    seeded from the second call on, takes over two calls later, and the step stays the standard solver's."""
+    lp = ba(80, 6000, 3)
+    dev = make(lp, True)
+    dev.snapshot()
+    ref = make(lp, False)
+    ref.gn_iteration(0., 1e-12, 500, True)
+    dx_ref = device_dx(ref, lp)
+    its = []
+    for _ in range(8):
+        dev.restore()
+        out = dev.gn_iteration(0., 1e-12, 500, True)
+        its.append(out[2])
+        assert np.linalg.norm(device_dx(dev, lp) - dx_ref) <= 1e-9 * np.linalg.norm(dx_ref)
+    assert info(dev)[0] >= 4 and its[-1] <= 8 < its[0], its
+
+
+def test_iteration_cap_falls_back_to_the_standard_solver():
+    """ldi_cap = 1: no solve with the inverse can finish, every attempt is given up -- nothing applied -- and the standard
+    path solves the same system; the trajectory is the standard one."""
+    lp = ba(40, 3000, 8)
+    a, b = make(lp, True, ldi_cap=1), make(lp, False)
+    for _ in range(9):
+        ca = a.gn_iteration(0., 1e-12, 500, True)
+        cb = b.gn_iteration(0., 1e-12, 500, True)
+        assert abs(ca[0] - cb[0]) <= 1e-10 * abs(cb[0])
+    solves, fallbacks, seeds = info(a)
+    assert solves == 0 and fallbacks >= 1 and seeds >= 2
+    assert np.abs(a.get_params()[0] - b.get_params()[0]).max() < 1e-9
+
+
+def test_a_jump_of_the_parameters_is_survived():
+    """Parameters replaced from outside while an inverse is valid (its cost tag no longer matches, or is unknown): the next
+    solve is either the standard one or a capped attempt followed by it -- and correct either way."""
+    lp = ba(40, 3000, 9)
+    dev = make(lp, True)
+    for _ in range(7):
+        dev.gn_iteration(0., 1e-12, 500, True)
+    assert info(dev)[0] >= 2
+    dev.set_params(lp.poses, lp.points)                      # back to the perturbed start: far from where the inverse was built
+    dx_ref, _ = orc.gauss_newton_step(lp, points_first=False)
+    dev.gn_iteration(0., 1e-12, 500, True)
+    assert np.linalg.norm(device_dx(dev, lp) - dx_ref) <= 1e-8 * np.linalg.norm(dx_ref)
+    dev.set_params(lp.poses, lp.points)
+    dev.eval_cost(True)                                      # ... and with the start cost known: no attempt at all
+    before = info(dev)
+    dev.gn_iteration(0., 1e-12, 500, True)
+    assert np.linalg.norm(device_dx(dev, lp) - dx_ref) <= 1e-8 * np.linalg.norm(dx_ref)
+    after = info(dev)
+    assert after[0] == before[0] and after[1] == before[1]
+
+
+@pytest.mark.parametrize('dof', [3, 6])
+def test_pose_graphs_keep_their_trajectory(dof):
+    """Pose graphs of 120 poses (SE(2): 357 unknowns, SE(3): 714) with Huber loss: long CG solves whose two-level operator
+    is a poor seed (seeds may be rejected and backed off) -- whatever the inverse does, the trajectory is the standard one."""
+    from pyslam_amd import synthetic, losses
+    lp, _ = synthetic.pose_graph(num_poses=120, num_loops=400, dof=dof, seed=4, loss=losses.HuberLoss(1.0))
+    a, b = make(lp, True), make(lp, False)
+    for _ in range(8):
+        ca = a.gn_iteration(0., 1e-13, 2000, True)
+        cb = b.gn_iteration(0., 1e-13, 2000, True)
+        assert abs(ca[0] - cb[0]) <= 1e-9 * abs(cb[0])
+    assert np.abs(a.get_params()[0] - b.get_params()[0]).max() < 1e-8
+
+
+def test_option_off_and_rebuilt_coarse_level():
+    """Switching the option off drops the inverse; changing the coarse level re-lays it out (sizes depend on it)."""
+    lp = ba(50, 4000, 2)
+    dev = make(lp, True)
+    dev.snapshot()
+    for _ in range(6):
+        dev.restore(); dev.gn_iteration(0., 1e-12, 500, True)
+    s0 = info(dev)[0]
+    assert s0 >= 1
+    dev.set_option('lagged_inverse', 0)
+    dev.restore(); dev.gn_iteration(0., 1e-12, 500, True)
+    assert info(dev)[0] == s0
+    dev.set_option('lagged_inverse', 1)
+    dev.set_option('coarse_groups', 5)
+    ref = make(lp, False)
+    ref.gn_iteration(0., 1e-12, 500, True)
+    for _ in range(6):
+        dev.restore(); dev.gn_iteration(0., 1e-12, 500, True)
+        assert np.linalg.norm(device_dx(dev, lp) - device_dx(ref, lp)) <= 1e-9 * np.linalg.norm(device_dx(ref, lp))
+    assert info(dev)[0] > s0
