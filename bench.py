@@ -168,6 +168,30 @@ def trajectory(dev, iters=5):
                                    'ps_gn_iteration call (each call ends with its one synchronisation)'.format(iters)}
 
 
+def problem_info(dev):
+    """ps_problem_info of a DeviceProblem as a dict (the lagged-inverse counters live there)."""
+    import ctypes as C
+    from pyslam_amd import _native as nat
+    i = nat.ProblemInfo()
+    nat.check(dev._lib.ps_get_info(dev._h, C.byref(i)))
+    return {k: getattr(i, k) for k, _ in nat.ProblemInfo._fields_}
+
+
+def c5_frames():
+    """Wall time of ONE per-frame motion-only Problem (BASELINE config 5, the way the reference's sparse VO pipeline runs it,
+    pyslam/pipelines/sparse.py:153-161): Problem(); add_residual_block(ReprojectionMotionOnlyBatchResidual, CauchyLoss);
+    initialize_params(); solve() -- split into lowering / ps_problem_create / iterations / write-back (tools/c5_frame_probe.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('c5_frame_probe', os.path.join(REPO, 'tools', 'c5_frame_probe.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for n in (256, 2048):
+        r = mod.frame(n, reps=20)
+        out[str(n)] = {k: round(v, 4) if isinstance(v, float) else v for k, v in r.items()}
+    return out
+
+
 def c4_single_gpu(stream, steps=10, warmup=5):
     """The unsharded C4 problem on the current GPU: steady-state ms per iteration + stage breakdown."""
     import torch
@@ -289,7 +313,27 @@ def main():
         elapsed = float(t.item())
     cost, dx_norm, n_pcg, relres = out
     ms_per_step = elapsed * 1e3 / args.steps
+    # reduced-solve launches per iteration (counter in ps_problem_info) and the lagged-inverse statistics
+    i0 = problem_info(core)
+    for _ in range(4):
+        step()
+    i1 = problem_info(core)
     traj = trajectory(dev) if dist is None else None         # (sharded: every rank would have to follow; single GPU only)
+    info_after = {'cg_kernel_launches_per_iter': (i1['cg_kernel_launches'] - i0['cg_kernel_launches']) / 4.0,
+                  'ldi': {k: i1[k] for k in ('ldi_solves', 'ldi_fallbacks', 'ldi_seeds')},
+                  'solver': 'lagged dense inverse PCG, 2 launches per iteration' if i1['ldi_solves'] > i0['ldi_solves']
+                  else 'two-level CG'}
+    first_iter_ms = first_iter_its = None
+    if dist is None:                                         # the moving phase of a solve: the same steps without the inverse
+        core.set_option('lagged_inverse', 0)
+        sec0, out0 = time_steps(dev, 10, 3, fence)
+        core.set_option('lagged_inverse', 1)
+        first_iter_ms, first_iter_its = sec0 * 1e3 / 10, out0[2]
+    ranks_stage = None
+    if dist is not None:                                     # every rank's stage times (incl. allreduce, pack_unpack) on rank 0
+        mine = {k: round(v[0] / max(v[1], 1), 4) for k, v in stages.items() if v[1] > 0}
+        ranks_stage = [None] * world
+        dist.all_gather_object(ranks_stage, mine)
 
     if rank == 0:
         b_iter, b_schur, b_spmv = algorithmic_bytes(info, n_pcg)
@@ -312,7 +356,7 @@ def main():
             'metric': 'ms/LM-iter (Jac build + J^T J + Schur solve), stereo BA @ 500k residuals',
             'value': round(ms_per_step, 4), 'unit': 'ms/LM-iter', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-            'higher_is_better': False, 'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'higher_is_better': False, 'scaling': 'strong' if world > 1 else 'none', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
             'config': {'workload': '{} stereo BA: {} keyframes x {} landmarks x {} obs/landmark = {} reprojection blocks '
                                    '(3 rows each), L2 loss, pose 0 constant{}'.format(
@@ -328,8 +372,10 @@ def main():
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'stage_ms_note': 'schur_pairs: hipEvent pair inside the timed region, on every 4th step; the other stages and iteration_total '
                              '(GPU time of one iteration) from 5 extra untimed steps with an event pair around every stage',
-            'value_note': 'steady state: every timed step restores the same linearisation point (repeated first iteration); '
-                          'trajectory_ms_per_iter is the same solve without the restore',
+            'value_note': 'steady state: every timed step restores the same linearisation point; with the lagged dense inverse '
+                          '(round 3) that is the SETTLED phase of a solve -- the inverse of this very S preconditions the CG; '
+                          'first_iteration_ms is the same step with the standard two-level CG (the moving phase), '
+                          'trajectory_ms_per_iter a real solve from the perturbed start (both phases and the switch between them)',
             'iteration_algorithmic_GBps': round(b_iter / (ms_per_step * 1e-3) / 1e9, 2),
             'roofline': {'bound': 'hbm', 'kernel': kern, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
@@ -337,6 +383,25 @@ def main():
                          'build_source_sha': sha, 'traffic_stale': bool(traffic is not None and traffic_sha != sha),
                          'algorithmic_bytes_per_launch': int(nbytes), 'avg_launch_ms': round(dur_ms, 5)},
         }
+        # the kernel with the largest TOTAL time per iteration next to the largest single launch: the reduced solve's launches
+        n_launch = info_after['cg_kernel_launches_per_iter']
+        pcg_ms = stage_ms.get('pcg', 0.0)
+        line['roofline_aggregate'] = {
+            'kernels': 'reduced solve (' + info_after['solver'] + ')', 'launches_per_iteration': round(n_launch, 2),
+            'total_ms_per_iteration': round(pcg_ms, 5), 'avg_launch_us': round(1e3 * pcg_ms / max(n_launch, 1), 3),
+            'algorithmic_bytes_per_launch': int(b_spmv),
+            'achieved_GBps': round(b_spmv * n_launch / max(pcg_ms * 1e-3, 1e-12) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+            'frac': round(b_spmv * n_launch / max(pcg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+            'bound': 'latency (dependent launches of ~5 us; DESIGN.md section 5), not bandwidth',
+            'note': 'bytes per launch = one pass over S (288 B per block) + three vectors; the launches of the lagged-inverse '
+                    'PCG alternate between that SpMV and a dense fp32 mat-vec of n^2 * 4 B (5.7 MB at C3)'}
+        line['lagged_inverse'] = info_after['ldi']
+        if first_iter_ms is not None:
+            line['first_iteration_ms'] = round(first_iter_ms, 4)
+            line['first_iteration_note'] = ('the same steady-state measurement with the lagged dense inverse switched off: what an '
+                                            'iteration costs while a solve is still moving (the standard two-level CG, {} iterations); '
+                                            '`value` is the settled phase, where the inverse preconditions ({} iterations)'.format(
+                                                first_iter_its, n_pcg))
         if traj is not None:
             line['trajectory_ms_per_iter'] = traj
         if not args.no_c4 and not args.kf and not args.lm:
@@ -347,6 +412,12 @@ def main():
             line['c4_single_gpu'] = c4
             if world > 1:                                    # same problem, same run, one GPU of this node: the strong-scaling base
                 line['speedup_vs_c4_single_gpu'] = round(c4['ms'] / ms_per_step, 3)
+        if ranks_stage is not None:
+            line['stage_ms_per_rank'] = ranks_stage
+            line['native_rccl'] = bool(getattr(dev, 'native', None) is not None)
+            line['native_rccl_reason'] = None if line['native_rccl'] else getattr(dev, 'native_reason', None)
+        if world == 1 and not args.kf and not args.lm:
+            line['c5_solve_wall_ms'] = c5_frames()
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(lp)
         print(json.dumps(line))

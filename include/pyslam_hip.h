@@ -92,10 +92,12 @@ typedef struct ps_problem_info {
     int64_t ldi_seeds;           /* inverses seeded on the side stream (after a standard solve)                             */
 } ps_problem_info;
 
-enum { PS_NUM_STAGES = 10 };
-/* stage ids for ps_get_stage_times */
+enum { PS_NUM_STAGES = 12 };
+/* stage ids for ps_get_stage_times (ALLREDUCE / PACK: the landmark-sharded iteration driven by the core itself,
+   ps_set_collective -- both all-reduces, and k_shard_pack + k_shard_unpack) */
 enum { PS_ST_LANDMARK = 0, PS_ST_POSE = 1, PS_ST_SCHUR = 2, PS_ST_EDGES = 3, PS_ST_PCG = 4,
-       PS_ST_BACKSUB = 5, PS_ST_UPDATE = 6, PS_ST_COST = 7, PS_ST_TOTAL = 8, PS_ST_SCHUR_KERNEL = 9 };
+       PS_ST_BACKSUB = 5, PS_ST_UPDATE = 6, PS_ST_COST = 7, PS_ST_TOTAL = 8, PS_ST_SCHUR_KERNEL = 9,
+       PS_ST_ALLREDUCE = 10, PS_ST_PACK = 11 };
 
 const char* ps_last_error(void);
 int ps_device_count(void);

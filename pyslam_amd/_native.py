@@ -14,9 +14,9 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libpyslam_hip.so')
 c_i32p = C.POINTER(C.c_int32)
 c_f64p = C.POINTER(C.c_double)
 c_u8p = C.POINTER(C.c_uint8)
-PS_NUM_STAGES = 10
+PS_NUM_STAGES = 12
 STAGE_NAMES = ['landmark_pass', 'pose_pass', 'schur_pairs', 'pose_factors', 'pcg',
-               'backsub', 'update', 'cost', 'iteration_total', 'reserved']
+               'backsub', 'update', 'cost', 'iteration_total', 'reserved', 'allreduce', 'pack_unpack']
 
 
 class ProblemDesc(C.Structure):

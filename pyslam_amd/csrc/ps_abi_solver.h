@@ -265,17 +265,23 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
         StageTimer total(h, PS_ST_TOTAL, 2);
         if (linearize(h, lambda)) return -1;
         // ONE sum over ranks of [upper(S) | g | cost | failure flag]
-        if (ps_shard_pack(h)) return -1;
-        if (h->nccl_allreduce(h->shard_pack, h->shard_pack, (size_t)h->pack_count, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
-            return fail("ncclAllReduce of the reduced system failed");
-        if (ps_shard_unpack(h)) return -1;
+        { StageTimer tpk(h, PS_ST_PACK); if (ps_shard_pack(h)) return -1; }
+        {
+            StageTimer tar(h, PS_ST_ALLREDUCE);
+            if (h->nccl_allreduce(h->shard_pack, h->shard_pack, (size_t)h->pack_count, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
+                return fail("ncclAllReduce of the reduced system failed");
+        }
+        { StageTimer tpk(h, PS_ST_PACK); if (ps_shard_unpack(h)) return -1; }
         int first = 1, done = 0;
         double sb[2] = {0.0, 0.0}, dxp2 = 0.0;
         for (;;) {
             const int last = ps_gn_solve_finish_enqueue(h, pcg_tol, pcg_max_iters, linesearch, first);
             if (last < 0) return -1;
-            if (h->nccl_allreduce(h->shard_buf, h->shard_buf, 2, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
-                return fail("ncclAllReduce of the shard scalars failed");
+            {
+                StageTimer tar(h, PS_ST_ALLREDUCE);
+                if (h->nccl_allreduce(h->shard_buf, h->shard_buf, 2, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
+                    return fail("ncclAllReduce of the shard scalars failed");
+            }
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, h->stream, h->status, h->scalars, h->shard_buf,
                                h->h_status_dev, h->h_scalars_dev, h->h_shard_dev, h->h_seq_dev, ++h->seq);
             total.stop();

@@ -275,6 +275,7 @@ struct ps_problem {
     int ldi_refresh_its = 7;        // option "ldi_refresh_its": solves slower than this switch the per-iteration refresh on
     bool ldi_refreshed = false;     // the inverse in use has had a Newton-Schulz step since its seed
     int2* ldi_krange = nullptr;
+    int ldi_seed_lag = getenv("PS_LDI_SEED_LAG") ? atoi(getenv("PS_LDI_SEED_LAG")) : 2;   // calls between a seed's start and its first use (fixed schedule)
     int ldi_rejects = 0; long ldi_no_seed_before = 0;
     float* ldi_coef = nullptr;      // device: seed scale c and the two Ritz values (k_ldi_ritz)
     double ldi_tag = -1.0, ldi_next_tag = -1.0, ldi_call_start_cost = -1.0;   // cost at the point the inverse in use / in flight was built at

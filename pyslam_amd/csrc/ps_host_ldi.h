@@ -67,7 +67,7 @@ int ldi_ensure(ps_problem* h) {
 void ldi_gemm(ps_problem* h, hipStream_t st, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
               float beta, const float* Dm, int ldd, float gamma, float* C, int ldc, double* fro_part,
               const int2* krange = nullptr, int upper_only = 0, const float* dev_scale = nullptr) {
-    hipLaunchKernelGGL(k_ldi_gemm, dim3(N / PS_GM_BN, M / PS_GM_BM), dim3(256 * PS_GM_KS), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, Dm, ldd,
+    hipLaunchKernelGGL(k_ldi_gemm, dim3(N / PS_GM_BN, M / PS_GM_BM), dim3(64 * PS_GM_KS), 0, st, M, N, K, alpha, A, lda, B, ldb, beta, Dm, ldd,
                        gamma, C, ldc, fro_part, krange, upper_only, dev_scale);
 }
 
@@ -80,9 +80,13 @@ void ldi_ns_step(ps_problem* h, hipStream_t st, float* xu, bool want_fro) {
     ldi_gemm(h, st, np, np, np, -1.f, h->ldi_S32, np, h->ldi_X32, np, 0.f, nullptr, 0, 1.f, h->ldi_R32, np,
              want_fro ? h->ldi_fro_part : nullptr, h->ldi_krange, 0);
     ldi_gemm(h, st, np, np, np, 1.f, h->ldi_X32, np, h->ldi_R32, np, 1.f, h->ldi_X32, np, 0.f, h->ldi_T32, np, nullptr, nullptr, 1);
-    const int tail = cdiv(np - h->ldi_n, 64);
-    hipLaunchKernelGGL(k_ldi_sym_unscale<D>, dim3(h->nr * h->nr + tail), dim3(64), 0, st, h->nr, np, h->ldi_T32, h->ldi_Linv,
-                       h->ldi_X32, xu);
+    // X <- mirror(T); the unscaled copy for the solver stream only when asked for (the last step of a seed, a refresh)
+    hipLaunchKernelGGL(k_ldi_mirror, dim3(np / 32, np / 32), dim3(256), 0, st, np, h->ldi_T32, h->ldi_X32);
+    if (xu) {
+        const int tail = cdiv(np - h->ldi_n, 64);
+        hipLaunchKernelGGL(k_ldi_sym_unscale<D>, dim3(h->nr * h->nr + tail), dim3(64), 0, st, h->nr, np, h->ldi_X32, h->ldi_Linv,
+                           h->ldi_T32, xu);                    // (reads the mirrored X; its symmetrised copy goes to the scratch T)
+    }
     if (want_fro)
         hipLaunchKernelGGL(k_ldi_fro_total, dim3(1), dim3(256), 0, st, (np / PS_GM_BM) * (np / PS_GM_BN), h->ldi_fro_part, h->h_ldi_fro_dev);
 }
@@ -126,7 +130,7 @@ int ldi_seed_enqueue(ps_problem* h, int its, double cost_now) {
         ldi_ns_step<D>(h, st, last ? h->ldi_Xu[wb] : nullptr, last);
     }
     HIP_OK(hipEventRecord(h->ev_ldi, st));
-    h->ldi_state = 1; h->ldi_next = wb; h->ldi_ready_at = h->ldi_iter + 2; h->ldi_fro_limit = 0.1;
+    h->ldi_state = 1; h->ldi_next = wb; h->ldi_ready_at = h->ldi_iter + h->ldi_seed_lag; h->ldi_fro_limit = 0.1;
     h->ldi_refreshed = false;
     h->ldi_next_tag = h->ldi_call_start_cost;               // the cost at the point whose S this inverse is built from
     ++h->ldi_seeds;

@@ -29,104 +29,99 @@ typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
 // B: lane l holds B[l / 32][l % 32]; D: register v of lane l is D[8 (v / 4) + 4 (l / 32) + v % 4][l % 32].
 // fro_part (optional): this workgroup's sum of squares of its C tile (fixed order) for a later ||C||_F^2.
 // ---------------------------------------------------------------------------
-#define PS_GM_BM 64
-#define PS_GM_BN 64
+#define PS_GM_BM 32
+#define PS_GM_BN 32
 #define PS_GM_BK 16
-#define PS_GM_KS 4                              // K-split groups per workgroup (256 threads each)
-// One 64 x 64 tile per workgroup is all the parallelism a 1 216^2 product has for 256 CUs (361 tiles), so the launch lasts
-// as long as ONE tile takes; with one wave per SIMD a tile ran at a third of the MFMA rate (58 us).  PS_GM_KS groups of four
-// waves walk interleaved K chunks of the same tile (own LDS double buffers, lock-step barriers) and are summed through
-// LDS at the end: four waves per SIMD hide each other's LDS / global latency.
-__global__ __launch_bounds__(256 * PS_GM_KS) void k_ldi_gemm(
+#define PS_GM_KS 4                              // waves per workgroup = K-split groups of one tile
+// Tiling for a 1 216^2 product on 256 CUs: one 32 x 32 tile per workgroup (1 444 tiles, 741 when only the upper triangle is
+// wanted), each of the workgroup's four waves owning every fourth K chunk of that tile with LDS double buffers of its OWN
+// -- a wave stages, reads and multiplies without ever meeting a workgroup barrier, so four waves per SIMD (several
+// workgroups per CU) hide each other's latencies -- and the four accumulators are summed through LDS at the end.
+// (64 x 64 tiles, one per CU, were bounded by ONE tile's MFMA time: 16 us at peak, 30-58 us measured.)
+__global__ __launch_bounds__(64 * PS_GM_KS) void k_ldi_gemm(
     int M, int N, int K, float alpha, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
     float beta, const float* __restrict__ Dm, int ldd, float gamma, float* __restrict__ C, int ldc,
     double* __restrict__ fro_part,
-    const int2* __restrict__ krange /* per row tile: [k_lo, k_hi) outside which A's rows are zero (banded A), or null */,
+    const int2* __restrict__ krange /* per 32-row tile: [k_lo, k_hi) outside which A's rows are zero (banded A), or null */,
     int upper_only /* C is symmetric: tiles below the diagonal are left untouched */,
     const float* __restrict__ dev_scale /* optional: alpha and gamma are multiplied by *dev_scale (a device-side scalar) */)
 {
     constexpr int KS = PS_GM_KS;
     struct Tiles { float As[2][PS_GM_BK][PS_GM_BM + 4]; float Bs[2][PS_GM_BK][PS_GM_BN + 4]; };
     __shared__ __attribute__((aligned(16))) Tiles tl[KS];
-    __shared__ double red[16];
+    __shared__ double red[KS];
     if (upper_only && blockIdx.x < blockIdx.y) return;
-    const int tt = threadIdx.x, grp = tt >> 8, t = tt & 255, w = t >> 6, l = t & 63;
+    const int grp = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int m0 = blockIdx.y * PS_GM_BM, n0 = blockIdx.x * PS_GM_BN;
-    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
     int k_lo = 0, k_hi = K;
     if (krange) { const int2 kr = krange[blockIdx.y]; k_lo = kr.x; k_hi = kr.y; }
-    // global -> register staging: A tile 64 x 16 (thread: row t / 4, 4 consecutive k), B tile 16 x 64 (row t / 16, 4 consecutive n)
-    const int am = t >> 2, ak = (t & 3) * 4;
-    const int bk = t >> 4, bn = (t & 15) * 4;
-    const int nchunks = (k_hi - k_lo) / PS_GM_BK;            // chunk c belongs to group c % KS
-    const int steps = (nchunks + KS - 1) / KS;               // lock-step rounds (a group without a chunk in the last round idles)
+    // staging by one wave: A tile 32 x 16 = lane (row l / 2, 8 consecutive k), B tile 16 x 32 = lane (row l / 4, 8 consecutive n)
+    const int am = l >> 1, ak = (l & 1) * 8;
+    const int bk = l >> 2, bn = (l & 3) * 8;
+    const int nchunks = (k_hi - k_lo) / PS_GM_BK;            // chunk c belongs to wave c % KS
     const float* Ap = A + (size_t)(m0 + am) * lda + k_lo + ak;
     const float* Bp = B + (size_t)(k_lo + bk) * ldb + n0 + bn;
     Tiles& T = tl[grp];
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-    if (grp < nchunks) {
-        ra = *reinterpret_cast<const float4*>(Ap + (size_t)grp * PS_GM_BK);
-        rb = *reinterpret_cast<const float4*>(Bp + (size_t)grp * PS_GM_BK * ldb);
-    }
     ps_f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-    int buf = 0;
-    T.As[0][ak + 0][am] = ra.x; T.As[0][ak + 1][am] = ra.y; T.As[0][ak + 2][am] = ra.z; T.As[0][ak + 3][am] = ra.w;
-    *reinterpret_cast<float4*>(&T.Bs[0][bk][bn]) = rb;
-    __syncthreads();
     const int fi = l & 31, fk = l >> 5;
-    for (int st = 0; st < steps; ++st) {
-        const int ch = st * KS + grp, nx = ch + KS;
-        if (nx < nchunks) {                                   // next chunk's global loads fly during this chunk's MFMAs
-            ra = *reinterpret_cast<const float4*>(Ap + (size_t)nx * PS_GM_BK);
-            rb = *reinterpret_cast<const float4*>(Bp + (size_t)nx * PS_GM_BK * ldb);
+    float4 ra0, ra1, rb0, rb1;
+    int ch = grp;
+    if (ch < nchunks) {
+        ra0 = *reinterpret_cast<const float4*>(Ap + (size_t)ch * PS_GM_BK); ra1 = *reinterpret_cast<const float4*>(Ap + (size_t)ch * PS_GM_BK + 4);
+        rb0 = *reinterpret_cast<const float4*>(Bp + (size_t)ch * PS_GM_BK * ldb); rb1 = *reinterpret_cast<const float4*>(Bp + (size_t)ch * PS_GM_BK * ldb + 4);
+    }
+    int buf = 0;
+    for (; ch < nchunks; ch += KS) {
+        // registers -> this wave's LDS buffer (A transposed to [k][m] so that a fragment read is 32 consecutive words)
+        T.As[buf][ak + 0][am] = ra0.x; T.As[buf][ak + 1][am] = ra0.y; T.As[buf][ak + 2][am] = ra0.z; T.As[buf][ak + 3][am] = ra0.w;
+        T.As[buf][ak + 4][am] = ra1.x; T.As[buf][ak + 5][am] = ra1.y; T.As[buf][ak + 6][am] = ra1.z; T.As[buf][ak + 7][am] = ra1.w;
+        *reinterpret_cast<float4*>(&T.Bs[buf][bk][bn]) = rb0;
+        *reinterpret_cast<float4*>(&T.Bs[buf][bk][bn + 4]) = rb1;
+        const int nx = ch + KS;
+        if (nx < nchunks) {                                   // the next chunk's global loads fly during this chunk's MFMAs
+            ra0 = *reinterpret_cast<const float4*>(Ap + (size_t)nx * PS_GM_BK); ra1 = *reinterpret_cast<const float4*>(Ap + (size_t)nx * PS_GM_BK + 4);
+            rb0 = *reinterpret_cast<const float4*>(Bp + (size_t)nx * PS_GM_BK * ldb); rb1 = *reinterpret_cast<const float4*>(Bp + (size_t)nx * PS_GM_BK * ldb + 4);
         }
-        if (ch < nchunks) {
+        __builtin_amdgcn_wave_barrier();                     // (one wave: LDS operations complete in order; no workgroup barrier)
 #pragma unroll
-            for (int kk = 0; kk < PS_GM_BK; kk += 2) {
-                const float a = T.As[buf][kk + fk][wm + fi];
-                const float b = T.Bs[buf][kk + fk][wn + fi];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            }
+        for (int kk = 0; kk < PS_GM_BK; kk += 2) {
+            const float a = T.As[buf][kk + fk][fi];
+            const float b = T.Bs[buf][kk + fk][fi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
-        if (nx < nchunks) {
-            const int nb = buf ^ 1;
-            T.As[nb][ak + 0][am] = ra.x; T.As[nb][ak + 1][am] = ra.y; T.As[nb][ak + 2][am] = ra.z; T.As[nb][ak + 3][am] = ra.w;
-            *reinterpret_cast<float4*>(&T.Bs[nb][bk][bn]) = rb;
-        }
-        __syncthreads();
         buf ^= 1;
     }
-    // sum the groups' accumulators through LDS (the tile buffers are free now): group g > 0 parks its 16 values per lane
-    float* park = reinterpret_cast<float*>(tl);               // [KS - 1][256 threads][16]  (<= 3 x 16 KB, the tiles hold 4 x 17 KB)
+    // sum the waves' accumulators through LDS (each wave parks into its own, now idle, tile buffers: 16 x 64 floats = 4 KB)
+    float* park = reinterpret_cast<float*>(&tl[grp]);
     if (grp > 0) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) park[((size_t)(grp - 1) * 16 + v) * 256 + t] = acc[v];
+        for (int v = 0; v < 16; ++v) park[v * 64 + l] = acc[v];
     }
     __syncthreads();
     double sq = 0.0;
     if (grp == 0) {
 #pragma unroll
-        for (int g = 0; g < KS - 1; ++g)
+        for (int g = 1; g < KS; ++g) {
+            const float* pg = reinterpret_cast<const float*>(&tl[g]);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[v] += park[((size_t)g * 16 + v) * 256 + t];
+            for (int v = 0; v < 16; ++v) acc[v] += pg[v * 64 + l];
+        }
         if (dev_scale) { const float sc = *dev_scale; alpha *= sc; gamma *= sc; }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int i = m0 + wm + 8 * (v >> 2) + 4 * fk + (v & 3), j = n0 + wn + fi;
+            const int i = m0 + 8 * (v >> 2) + 4 * fk + (v & 3), j = n0 + fi;
             float c = alpha * acc[v];
             if (beta != 0.f) c += beta * Dm[(size_t)i * ldd + j];
             if (i == j) c += gamma;
             C[(size_t)i * ldc + j] = c;
             sq += (double)c * (double)c;
         }
-    }
-    if (fro_part) {                                           // (uniform)
-        sq = wave_sum(sq);
-        if (grp == 0 && l == 0) red[w] = sq;
-        __syncthreads();
-        if (tt == 0) fro_part[blockIdx.y * gridDim.x + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        if (fro_part) {
+            sq = wave_sum(sq);
+            if (l == 0) fro_part[blockIdx.y * gridDim.x + blockIdx.x] = sq;
+        }
     }
 }
 
@@ -257,8 +252,8 @@ __global__ __launch_bounds__(64) void k_ldi_sym_unscale(
     const int bi = blockIdx.x / nr, bj = blockIdx.x % nr;
     const int r = t / D, c = t % D;
     if (t < DD) {
-        // T was computed for tiles on and above the diagonal only (64 x 64 tiles): an entry below it is its mirror image's
-        const int gi = bi * D + r, gj = bj * D + c, ti = gi >> 6, tj = gj >> 6;
+        // T was computed for tiles on and above the diagonal only (PS_GM_BM x PS_GM_BN tiles): an entry below it is its mirror image's
+        const int gi = bi * D + r, gj = bj * D + c, ti = gi / PS_GM_BM, tj = gj / PS_GM_BN;
         const double a = T[(size_t)gi * np + gj], b = T[(size_t)gj * np + gi];
         const double s = ti < tj ? a : (ti > tj ? b : 0.5 * (a + b));
         sX[t] = s;
@@ -279,6 +274,28 @@ __global__ __launch_bounds__(64) void k_ldi_sym_unscale(
 #pragma unroll
         for (int a = 0; a < D; ++a) v += sT[r * D + a] * sLj[a * D + c];
         Xu[(size_t)(bi * D + r) * np + bj * D + c] = (float)v;
+    }
+}
+
+// X32 <- T mirrored: T holds the tiles on and above the diagonal (32 x 32 tiles); tile (I, J), I < J, is copied as it is and
+// transposed into (J, I) through LDS; diagonal tiles are symmetrised.  One 256-thread workgroup per upper tile.
+__global__ __launch_bounds__(256) void k_ldi_mirror(int np, const float* __restrict__ T, float* __restrict__ X32)
+{
+    __shared__ float tile[32][33];
+    if (blockIdx.x < blockIdx.y) return;
+    const int I = blockIdx.y * 32, J = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty: 0..7
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = T[(size_t)(I + r) * np + J + tx];
+    __syncthreads();
+    if (I == J) {
+#pragma unroll
+        for (int r = ty; r < 32; r += 8) X32[(size_t)(I + r) * np + J + tx] = 0.5f * (tile[r][tx] + tile[tx][r]);
+    } else {
+#pragma unroll
+        for (int r = ty; r < 32; r += 8) {
+            X32[(size_t)(I + r) * np + J + tx] = tile[r][tx];
+            X32[(size_t)(J + r) * np + I + tx] = tile[tx][r];
+        }
     }
 }
 

@@ -103,6 +103,41 @@ class NativeRccl:
         if rc != 0:
             raise RuntimeError('ncclCommInitRank failed: {}'.format(rc))
         self.allreduce_ptr = C.cast(self.lib.ncclAllReduce, C.c_void_p).value
+        self.self_check(dist)
+
+    def self_check(self, dist, timeout_s=30.0):
+        """One 1-element sum over the new communicator, on a stream of its own, with a deadline: this second
+        communicator (beside PyTorch's) has to prove it works with all ranks before the solver's stream depends on it.
+        A wrong sum, an error code or no completion within `timeout_s` raises; the caller falls back to the
+        torch.distributed collectives on every rank (the choice is agreed with a MIN all-reduce there)."""
+        import ctypes as C
+        import time
+        import torch
+        world = dist.get_world_size()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            t = torch.ones(1, dtype=torch.float64, device='cuda')
+            self.lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            self.lib.ncclAllReduce.restype = C.c_int
+            rc = self.lib.ncclAllReduce(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), 1, 8, 0, self.comm,
+                                        C.c_void_p(side.cuda_stream))      # ncclFloat64 = 8, ncclSum = 0
+            if rc != 0:
+                raise RuntimeError('ncclAllReduce (self-check) returned {}'.format(rc))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        t0 = time.time()
+        while not ev.query():
+            if time.time() - t0 > timeout_s:
+                try:
+                    self.lib.ncclCommAbort.argtypes = [C.c_void_p]
+                    self.lib.ncclCommAbort(self.comm)
+                finally:
+                    self.comm = None
+                raise RuntimeError('self-check all-reduce over {} ranks did not complete in {:.0f} s'.format(world, timeout_s))
+            time.sleep(0.0005)
+        got = float(t.item())
+        if got != float(world):
+            raise RuntimeError('self-check all-reduce returned {} instead of {}'.format(got, world))
 
     def close(self):
         if getattr(self, 'comm', None):
@@ -153,23 +188,29 @@ class ShardedDeviceProblem:
         self.info = dict(self.dev.info)
         # GPU: let the HIP core drive RCCL itself (one ABI call + one sync per iteration)
         self.native = None
+        self.native_reason = 'not requested'
         import os
         if device_factory is None and native_rccl and os.environ.get('PYSLAM_AMD_NATIVE_RCCL', '1') != '0':
             try:
                 self.native = NativeRccl(dist)
                 self.dev.set_collective(self.native.allreduce_ptr, self.native.comm.value)
             except Exception as e:                       # fall back to torch.distributed collectives
-                print('pyslam_amd: native RCCL unavailable ({}); using torch.distributed'.format(e))
+                print('pyslam_amd[rank {}]: native RCCL unavailable ({}); using torch.distributed collectives'.format(self.rank, e),
+                      flush=True)
                 self.native = None
+                self.native_reason = str(e)
             # the choice must be the same on every rank (a rank that fell back alone would wait in a different
             # collective than its peers): native only if it came up everywhere
             flag = torch.tensor([1 if self.native is not None else 0], dtype=torch.int32,
                                 device=self.dev.reduce_tensor.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0 and self.native is not None:
+                print('pyslam_amd[rank {}]: another rank has no native RCCL; using torch.distributed collectives'.format(self.rank),
+                      flush=True)
                 self.dev.set_collective(0, 0)
                 self.native.close()
                 self.native = None
+                self.native_reason = 'a peer rank fell back'
         # (Round 2 first set "coarse_refresh_every" = 2 from 4 ranks on: the dense side-stream factorisation of C4's coarse
         # level, 1.6 ms, would have outlasted a ~1.1 ms sharded iteration.  The banded factorisation takes 0.6 ms and
         # finishes beside the CG and the next shard-local kernels, so every rank count refreshes every iteration; the
