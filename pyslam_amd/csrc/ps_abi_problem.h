@@ -41,7 +41,6 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     if (d->dof != 6 && d->dof != 3) return fail("dof must be 6 (SE3) or 3 (SE2)");
     if (d->num_obs > 0 && d->dof != 6) return fail("reprojection blocks need SE(3) poses");
     if (d->num_poses >= (1 << 24)) return fail("more than 2^24 poses");
-    if (d->num_obs_groups > 255) return fail("more than 255 observation groups");
     if (d->num_obs >= (1L << 31) / 18) return fail("too many observations for 32-bit indexing");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible");
@@ -100,20 +99,49 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     if (h->upload(&h->point_vid, point_slot)) return -1;     // device-side 'vid' = internal slot
 
     lap("parameter tables");
-    // ---- observation groups
-    std::vector<ObsGroup> og(std::max(1, d->num_obs_groups));
-    for (int gi = 0; gi < d->num_obs_groups; ++gi) {
-        const double* row = d->obs_groups + 4 * gi;
-        const int cam = (int)row[0], st = (int)row[1];
-        if (cam < 0 || cam >= d->num_cams || st < 0 || st >= d->num_stiff3) return fail("obs group index out of range");
-        const double* c = d->cams + 5 * cam;
-        ObsGroup& o = og[gi];
-        o.cu = c[0]; o.cv = c[1]; o.fu = c[2]; o.fv = c[3];
-        o.cam_type = c[4] < 0.0 ? 1 : 0;            // cams row: baseline b >= 0 = stereo, b = -1 = RGB-D
-        o.b = o.cam_type ? 0.0 : c[4];
-        for (int k = 0; k < 9; ++k) o.S[k] = d->stiff3[9 * st + k];
-        o.loss_id = (int)row[2]; o.loss_k = row[3];
+    // ---- observation groups.  Up to 255 rows (camera, stiffness, loss id, loss k): one device group per row.  More --
+    // typically one stiffness per observation -- : the device groups are the distinct (camera, loss id, loss k) CLASSES
+    // (at most 255 of those) and the stiffness travels as a per-observation index into the stiffness table ("wide").
+    const bool wide = d->num_obs_groups > 255;
+    std::vector<int32_t> class_of_row(std::max(1, d->num_obs_groups), 0);
+    std::vector<ObsGroup> og;
+    {
+        auto fill = [&](ObsGroup& o, const double* row, bool with_s) -> int {
+            const int cam = (int)row[0], st = (int)row[1];
+            if (cam < 0 || cam >= d->num_cams || st < 0 || st >= d->num_stiff3) return fail("obs group index out of range");
+            const double* c = d->cams + 5 * cam;
+            o.cu = c[0]; o.cv = c[1]; o.fu = c[2]; o.fv = c[3];
+            o.cam_type = c[4] < 0.0 ? 1 : 0;            // cams row: baseline b >= 0 = stereo, b = -1 = RGB-D
+            o.b = o.cam_type ? 0.0 : c[4];
+            for (int k = 0; k < 9; ++k) o.S[k] = with_s ? d->stiff3[9 * st + k] : (k % 4 == 0 ? 1.0 : 0.0);
+            o.loss_id = (int)row[2]; o.loss_k = row[3];
+            return 0;
+        };
+        if (!wide) {
+            og.resize(std::max(1, d->num_obs_groups));
+            for (int gi = 0; gi < d->num_obs_groups; ++gi) { if (fill(og[gi], d->obs_groups + 4 * gi, true)) return -1; class_of_row[gi] = gi; }
+        } else {
+            std::vector<std::array<double, 3>> keys;        // (camera, loss id, loss k) of the classes found so far
+            for (int gi = 0; gi < d->num_obs_groups; ++gi) {
+                const double* row = d->obs_groups + 4 * gi;
+                int c = -1;
+                for (size_t q = 0; q < keys.size(); ++q)
+                    if (keys[q][0] == row[0] && keys[q][1] == row[2] && keys[q][2] == row[3]) { c = (int)q; break; }
+                if (c < 0) {
+                    if (keys.size() == 255) return fail("more than 255 distinct (camera, loss) classes among the observation groups");
+                    keys.push_back({row[0], row[2], row[3]});
+                    og.emplace_back();
+                    if (fill(og.back(), row, false)) return -1;
+                    c = (int)keys.size() - 1;
+                }
+                class_of_row[gi] = c;
+            }
+            if (og.empty()) og.emplace_back();
+            std::vector<double> st(d->stiff3, d->stiff3 + 9 * (size_t)d->num_stiff3);
+            if (h->upload(&h->stiff_tab, st)) return -1;
+        }
     }
+    h->wide_obs = wide;
     if (h->upload(&h->ogroups, og)) return -1;
 
     lap("observation groups");
@@ -126,7 +154,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     };
     counting_sort(order, (size_t)nv + (size_t)L + 1, [&](int64_t a) { return lm_key(a); });
     std::vector<LObs> lobs(N);
-    std::vector<int32_t> lorig(N), lm_ptr(nv + 1, 0);
+    std::vector<int32_t> lorig(N), lm_ptr(nv + 1, 0), sidx_l(wide ? N : 0);
     long Nl = 0;
     for (long k = 0; k < N; ++k) {
         const long i = order[k];
@@ -135,16 +163,17 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
             return fail("observation index out of range");
         LObs& o = lobs[k];
         o.u = d->obs_uvd[3 * i]; o.v = d->obs_uvd[3 * i + 1]; o.d = d->obs_uvd[3 * i + 2];
-        o.pose_grp = (int32_t)((uint32_t)pose | ((uint32_t)grp << 24));
+        o.pose_grp = (int32_t)((uint32_t)pose | ((uint32_t)class_of_row[grp] << 24));
         o.point = pt;
         lorig[k] = (int32_t)i;
+        if (wide) sidx_l[k] = (int32_t)d->obs_groups[4 * (size_t)grp + 1];
         const int v = point_slot[pt];
         if (v >= 0) { lm_ptr[v + 1] += 1; ++Nl; }
     }
     for (int v = 0; v < nv; ++v) lm_ptr[v + 1] += lm_ptr[v];
     h->Nl = Nl;
     if (h->upload(&h->lobs, lobs) || h->upload(&h->lorig, lorig) || h->upload(&h->lm_ptr, lm_ptr) ||
-        h->upload(&h->lm_point, lm_point)) return -1;
+        h->upload(&h->lm_point, lm_point) || (wide && h->upload(&h->sidx_l, sidx_l))) return -1;
     if (h->alloc(&h->Z, (size_t)Nl * PS_ZROW) || h->alloc(&h->Cinv, (size_t)nv * 6) ||
         h->alloc(&h->cvec, (size_t)nv * 3) || h->alloc(&h->dxl, (size_t)nv * 3)) return -1;
     if (h->zero(h->dxl, (size_t)nv * 3 * sizeof(double))) return -1;
@@ -180,6 +209,11 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         pobs[k] = lobs[pidx[k]];
         const int slot = point_slot[pobs[k].point];              // -1: constant point
         pobs[k].pose_grp = (int32_t)(((uint32_t)PS_GRP_OF(pobs[k]) << 24) | (uint32_t)(slot + 1));
+    }
+    if (wide) {
+        std::vector<int32_t> sidx_p((size_t)Np);
+        for (long k = 0; k < Np; ++k) sidx_p[k] = sidx_l[pidx[k]];
+        if (h->upload(&h->sidx_p, sidx_p)) return -1;
     }
     h->npitems = (int)pitems.size();
     if (h->upload(&h->pitems, pitems) || h->upload(&h->pitem_ptr, pitem_ptr) ||

@@ -310,9 +310,16 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
             HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
             h->status_clean = true;
         }
-        hipLaunchKernelGGL(k_motion_only_iteration, dim3(h->nr), dim3(PS_MO_THREADS), 0, h->stream, h->nr, h->pitems, h->pitem_ptr,
+        const ObsWide wp{h->sidx_p, h->stiff_tab};
+        const long long seq_now = ++h->seq;
+        if (h->wide_obs)
+            hipLaunchKernelGGL(k_motion_only_iteration<true>, dim3(h->nr), dim3(PS_MO_THREADS), 0, h->stream, h->nr, h->pitems, h->pitem_ptr,
                            h->pobs, h->points, h->ogroups, h->poses, lambda, linesearch, h->x, h->mo_partials, h->status,
-                           h->scalars, h->arrivals + 1, h->h_status_dev, h->h_scalars_dev, h->h_seq_dev, ++h->seq);
+                           h->scalars, h->arrivals + 1, h->h_status_dev, h->h_scalars_dev, h->h_seq_dev, seq_now, wp);
+        else
+            hipLaunchKernelGGL(k_motion_only_iteration<false>, dim3(h->nr), dim3(PS_MO_THREADS), 0, h->stream, h->nr, h->pitems, h->pitem_ptr,
+                           h->pobs, h->points, h->ogroups, h->poses, lambda, linesearch, h->x, h->mo_partials, h->status,
+                           h->scalars, h->arrivals + 1, h->h_status_dev, h->h_scalars_dev, h->h_seq_dev, seq_now, wp);
         total.stop();
         if (wait_published(h)) return -1;
         if (pcg_iters_out) *pcg_iters_out = 0;
@@ -433,8 +440,13 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r, double* jpose, double* jpoi
     HIP_OK(hipMalloc((void**)&dr, (size_t)h->N * 3 * sizeof(double)));
     HIP_OK(hipMalloc((void**)&djp, (size_t)h->N * 18 * sizeof(double)));
     HIP_OK(hipMalloc((void**)&djl, (size_t)h->N * 9 * sizeof(double)));
-    hipLaunchKernelGGL(k_debug_reproj, dim3(cdiv(h->N, 256)), dim3(256), 0, h->stream, h->N, h->lobs, h->lorig,
-                       h->poses, h->points, h->ogroups, dr, djp, djl);
+    const ObsWide wl{h->sidx_l, h->stiff_tab};
+    if (h->wide_obs)
+        hipLaunchKernelGGL(k_debug_reproj<true>, dim3(cdiv(h->N, 256)), dim3(256), 0, h->stream, h->N, h->lobs, h->lorig,
+                       h->poses, h->points, h->ogroups, dr, djp, djl, wl);
+    else
+        hipLaunchKernelGGL(k_debug_reproj<false>, dim3(cdiv(h->N, 256)), dim3(256), 0, h->stream, h->N, h->lobs, h->lorig,
+                       h->poses, h->points, h->ogroups, dr, djp, djl, wl);
     hipMemcpyAsync(r, dr, (size_t)h->N * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     hipMemcpyAsync(jpose, djp, (size_t)h->N * 18 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     hipMemcpyAsync(jpoint, djl, (size_t)h->N * 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream);

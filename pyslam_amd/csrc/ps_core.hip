@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -87,6 +88,11 @@ struct ps_problem {
     int32_t *pose_rid = nullptr, *point_vid = nullptr;
     // reprojection
     ObsGroup* ogroups = nullptr;
+    // "wide" problems (more than 255 (camera, stiffness, loss) rows): per-observation stiffness index columns in landmark /
+    // pose order + the stiffness table; the 8-bit group field then holds the (camera, loss) class
+    bool wide_obs = false;
+    int32_t *sidx_l = nullptr, *sidx_p = nullptr;
+    double* stiff_tab = nullptr;
     LObs* lobs = nullptr;
     int32_t *lorig = nullptr, *lm_ptr = nullptr, *lm_point = nullptr;
     double *Z = nullptr, *Cinv = nullptr, *cvec = nullptr, *dxl = nullptr;

@@ -774,15 +774,23 @@ int linearize(ps_problem* h, double lambda) {
     HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double) + ST_NWORDS * sizeof(int32_t), h->stream));   // [S | g | cost | status]
     if (h->nv > 0) {
         StageTimer t(h, PS_ST_LANDMARK);
-        hipLaunchKernelGGL(k_landmark_pass, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr,
-                           h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,
-                           h->Cinv, h->cvec, h->status, h->lm_ablate);
+        const ObsWide wl{h->sidx_l, h->stiff_tab};
+#define PS_LM_LAUNCH(W) hipLaunchKernelGGL(k_landmark_pass<W>, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr, \
+                           h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,                       \
+                           h->Cinv, h->cvec, h->status, h->lm_ablate, wl)
+        if (h->wide_obs) PS_LM_LAUNCH(true); else PS_LM_LAUNCH(false);
+#undef PS_LM_LAUNCH
     }
     bool fin_in_combine = false;
     if (h->npitems > 0) {
         StageTimer t(h, PS_ST_POSE);
-        hipLaunchKernelGGL(k_pose_pass, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
-                           h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0);
+        const ObsWide wp{h->sidx_p, h->stiff_tab};
+        if (h->wide_obs)
+            hipLaunchKernelGGL(k_pose_pass<true>, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
+                               h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp);
+        else
+            hipLaunchKernelGGL(k_pose_pass<false>, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
+                               h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp);
         // tiled Schur: the combine launch also finalizes the poses (unless a task writes a diagonal block)
         fin_in_combine = (h->Spart || h->use_stream) && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6;
         if (!fin_in_combine)
@@ -821,8 +829,13 @@ int linearize(ps_problem* h, double lambda) {
 int cost_partials_pass(ps_problem* h, int include_all, const int32_t* gate) {
     int n = 0;
     if (h->N > 0) {
-        hipLaunchKernelGGL(k_cost_reproj, dim3(h->ncost_obs), dim3(256), 0, h->stream, h->N, h->lobs, h->poses,
-                           h->points, h->pose_rid, h->point_vid, h->ogroups, include_all, h->cost_partials, gate);
+        const ObsWide wl{h->sidx_l, h->stiff_tab};
+        if (h->wide_obs)
+            hipLaunchKernelGGL(k_cost_reproj<true>, dim3(h->ncost_obs), dim3(256), 0, h->stream, h->N, h->lobs, h->poses,
+                               h->points, h->pose_rid, h->point_vid, h->ogroups, include_all, h->cost_partials, gate, wl);
+        else
+            hipLaunchKernelGGL(k_cost_reproj<false>, dim3(h->ncost_obs), dim3(256), 0, h->stream, h->N, h->lobs, h->poses,
+                               h->points, h->pose_rid, h->point_vid, h->ogroups, include_all, h->cost_partials, gate, wl);
         n += h->ncost_obs;
     }
     if (h->F > 0) {

@@ -66,13 +66,14 @@ PS_DEV void zrow_expand(const double* __restrict__ m, const double* __restrict__
 #ifndef PS_LM_WAVES
 #define PS_LM_WAVES 3
 #endif
+template <bool WIDE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES, 8))) void k_landmark_pass(
     int nv, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_point,
     const LObs* __restrict__ lobs, const double* __restrict__ poses,
     const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
     const ObsGroup* __restrict__ groups, double lambda,
     double* __restrict__ Z, double* __restrict__ Cinv, double* __restrict__ cvec,
-    int32_t* __restrict__ status, int ablate)
+    int32_t* __restrict__ status, int ablate, ObsWide wide)
 {
     const int v = blockIdx.x * (blockDim.x / PS_LM_GROUP) + threadIdx.x / PS_LM_GROUP;
     const int sub = threadIdx.x & (PS_LM_GROUP - 1);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
         const Se3 T = se3_load(poses + 12 * pose);
         rid_of_obs = pose_rid[pose];
         variable_pose = rid_of_obs >= 0;
-        reproj_eval_grp<true, true>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
+        reproj_eval_obs<true, true, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
         have = true;
         const double* J = ev.Jl;
 #pragma unroll
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
         if (rid < 0 || (ablate & 1)) continue;
         if (!single) {
             const Se3 T = se3_load(poses + 12 * pose);
-            reproj_eval_grp<true, true>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
+            reproj_eval_obs<true, true, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
         }
         lm_emit_m(ev, M00, M10, M11, M20, M21, M22, z);
         z[9] = ev.pc[0]; z[10] = ev.pc[1]; z[11] = ev.pc[2];
@@ -231,12 +232,14 @@ typedef __attribute__((address_space(3))) void* ps_lptr_t;
 #ifndef PS_POSE_WAVES
 #define PS_POSE_WAVES 3
 #endif
+template <bool WIDE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_POSE_WAVES, 8))) void k_pose_pass(
     const PItem* __restrict__ items,
     const LObs* __restrict__ pobs /* observation records in pose order, landmark slot + 1 in the pose bits */,
     const double* __restrict__ poses, const double* __restrict__ points,
     const ObsGroup* __restrict__ groups, const double* __restrict__ Cinv,
-    const double* __restrict__ cvec, double* __restrict__ partial, int want_diag /* lambda != 0: the six damping sums too */)
+    const double* __restrict__ cvec, double* __restrict__ partial, int want_diag /* lambda != 0: the six damping sums too */,
+    ObsWide wide)
 {
     __shared__ double red[4][PS_NPOSE_ACC];
 #if PS_POSE_TRANSPOSE
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_POSE_WAV
             c0 = cvec[3 * (size_t)v]; c1 = cvec[3 * (size_t)v + 1]; c2 = cvec[3 * (size_t)v + 2];
         }
         ReprojEval ev;
-        reproj_eval_grp<true, true>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);   // (only the translational columns of J~p = A are used below)
+        reproj_eval_obs<true, true, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);   // (only the translational columns of J~p = A are used below)
         // J~p = A K with K = [I | -pc^], and Z = K^T M: the observation's contribution is the 3 x 3 sandwich
         //   J~p^T J~p - Z Z^T = K^T (A^T A - M M^T) K,      -J~p^T r~ - Z c = -K^T (A^T r~ + M c)
         // -- 160 multiply-adds instead of the 290 of the two 6 x 6 products formed entry by entry

@@ -10,13 +10,14 @@
 // in pose order and publishes status + scalars to pinned host memory (sequence word).
 // ---------------------------------------------------------------------------
 #define PS_MO_THREADS 512
+template <bool WIDE>
 __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
     int nr, const PItem* __restrict__ items, const int32_t* __restrict__ pitem_ptr,
     const LObs* __restrict__ pobs, const double* __restrict__ points, const ObsGroup* __restrict__ groups,
     double* __restrict__ poses, double lambda, int linesearch,
     double* __restrict__ xout /* nr x 6 */, double* __restrict__ partials /* nr x 2: cost, |dx|^2 */,
     int32_t* __restrict__ status, double* __restrict__ scalars, int32_t* __restrict__ arrivals,
-    int32_t* __restrict__ hst, double* __restrict__ hsc, long long* __restrict__ hseq, long long seq)
+    int32_t* __restrict__ hst, double* __restrict__ hsc, long long* __restrict__ hseq, long long seq, ObsWide wide)
 {
     constexpr int NWV = PS_MO_THREADS / 64;
     __shared__ double red[NWV][PS_NPOSE_ACC + 1];
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
         const LObs o = pobs[i];
         const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
         ReprojEval ev;
-        reproj_eval_grp<true, false>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
+        reproj_eval_obs<true, false, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
         int n = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
             const LObs o = pobs[i];
             const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
             ReprojEval ev;
-            reproj_eval_grp<false, false>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
+            reproj_eval_obs<false, false, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
             c += ev.cost;
         }
         c = wave_sum(c);
@@ -297,11 +298,12 @@ __global__ __launch_bounds__(256) void k_update_points(
 }
 
 // robust cost of the reprojection blocks: one partial per workgroup
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_cost_reproj(
     long n, const LObs* __restrict__ lobs, const double* __restrict__ poses,
     const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
     const int32_t* __restrict__ point_vid, const ObsGroup* __restrict__ groups,
-    int include_all, double* __restrict__ partials, const int32_t* __restrict__ gate)
+    int include_all, double* __restrict__ partials, const int32_t* __restrict__ gate, ObsWide wide)
 {
     __shared__ double lds[16];
     if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256) void k_cost_reproj(
         const Se3 T = se3_load(poses + 12 * pose);
         const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
         ReprojEval ev;
-        reproj_eval_grp<false, false>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
+        reproj_eval_obs<false, false, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
         c += ev.cost;
     }
     c = block_sum(c, lds);
@@ -457,11 +459,12 @@ __global__ __launch_bounds__(256) void k_reduce_partials(int n, const double* __
 }
 
 // debug tap: IRLS-scaled residual / Jacobian blocks in ORIGINAL observation order
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_debug_reproj(
     long n, const LObs* __restrict__ lobs, const int32_t* __restrict__ lorig,
     const double* __restrict__ poses, const double* __restrict__ points,
     const ObsGroup* __restrict__ groups, double* __restrict__ r, double* __restrict__ jp,
-    double* __restrict__ jl)
+    double* __restrict__ jl, ObsWide wide)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256) void k_debug_reproj(
     const Se3 T = se3_load(poses + 12 * PS_POSE_OF(o));
     const double pw[3] = {points[3 * o.point], points[3 * o.point + 1], points[3 * o.point + 2]};
     ReprojEval ev;
-    reproj_eval_grp<true, true>(T, pw, &o.u, groups, PS_GRP_OF(o), ev);
+    reproj_eval_obs<true, true, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
     const size_t k = (size_t)lorig[i];
     for (int a = 0; a < 3; ++a) r[3 * k + a] = ev.r[a];
     for (int a = 0; a < 18; ++a) jp[18 * k + a] = ev.Jp[a];

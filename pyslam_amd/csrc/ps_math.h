@@ -283,9 +283,11 @@ struct ReprojEval {
     double pc[3];       // the point in the camera frame, T p (J_pose = S Jc [I | -pc^])
 };
 
+// `Sv`: the 3 x 3 stiffness (row-major).  Normally the group's own (g.S: scalar registers, shared by the wave); problems
+// with one stiffness per observation (reference reprojection_residual.py:8-11 takes any) pass a per-lane copy instead.
 template <bool WITH_JP, bool WITH_JL>
-PS_DEV void reproj_eval(const Se3& T, const double* __restrict__ pw, const double* __restrict__ uvd,
-                        const ObsGroup& g, ReprojEval& o) {
+PS_DEV void reproj_eval_s(const Se3& T, const double* __restrict__ pw, const double* __restrict__ uvd,
+                          const ObsGroup& g, const double* __restrict__ Sv, ReprojEval& o) {
     double pc[3];
     se3_apply(T, pw, pc);
     o.pc[0] = pc[0]; o.pc[1] = pc[1]; o.pc[2] = pc[2];
@@ -298,7 +300,7 @@ PS_DEV void reproj_eval(const Se3& T, const double* __restrict__ pw, const doubl
     o.cost = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double ri = g.S[3 * i] * e0 + g.S[3 * i + 1] * e1 + g.S[3 * i + 2] * e2;
+        const double ri = Sv[3 * i] * e0 + Sv[3 * i + 1] * e1 + Sv[3 * i + 2] * e2;
         o.cost += ps_loss_rho(g.loss_id, g.loss_k, ri);
         s[i] = sqrt(ps_loss_weight(g.loss_id, g.loss_k, ri));
         o.r[i] = s[i] * ri;
@@ -311,9 +313,9 @@ PS_DEV void reproj_eval(const Se3& T, const double* __restrict__ pw, const doubl
     double SJ[9];                       // diag(s) * S * Jc
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        SJ[3 * i] = s[i] * (g.S[3 * i] * j00);
-        SJ[3 * i + 1] = s[i] * (g.S[3 * i + 1] * j11);
-        SJ[3 * i + 2] = s[i] * (g.S[3 * i] * j02 + g.S[3 * i + 1] * j12 + g.S[3 * i + 2] * j22);
+        SJ[3 * i] = s[i] * (Sv[3 * i] * j00);
+        SJ[3 * i + 1] = s[i] * (Sv[3 * i + 1] * j11);
+        SJ[3 * i + 2] = s[i] * (Sv[3 * i] * j02 + Sv[3 * i + 1] * j12 + Sv[3 * i + 2] * j22);
     }
     if (WITH_JP) {
 #pragma unroll
@@ -334,6 +336,12 @@ PS_DEV void reproj_eval(const Se3& T, const double* __restrict__ pw, const doubl
     }
 }
 
+template <bool WITH_JP, bool WITH_JL>
+PS_DEV void reproj_eval(const Se3& T, const double* __restrict__ pw, const double* __restrict__ uvd,
+                        const ObsGroup& g, ReprojEval& o) {
+    reproj_eval_s<WITH_JP, WITH_JL>(T, pw, uvd, g, g.S, o);
+}
+
 // The (camera, stiffness, loss) group of an observation is almost always the same for a whole wave: it is read through
 // a wave-uniform index -- scalar loads into SGPRs instead of 17 per-lane loads of the same 128 bytes into 34 VGPRs.
 // Mixed waves go round a waterfall loop, one pass per distinct group (the lanes of the first active lane's group
@@ -344,5 +352,25 @@ PS_DEV void reproj_eval_grp(const Se3& T, const double* __restrict__ pw, const d
     for (;;) {
         const int g0 = __builtin_amdgcn_readfirstlane(grp);
         if (grp == g0) { reproj_eval<WITH_JP, WITH_JL>(T, pw, uvd, groups[g0], o); break; }
+    }
+}
+
+// "Wide" problems: more than 255 distinct (camera, stiffness, loss) rows -- typically one stiffness per observation.  The
+// 8-bit group field then names the (camera, loss) CLASS (still wave-uniform, scalar registers) and the stiffness comes
+// from a table through a per-observation index (a parallel int32 column): nine per-lane loads, nine more registers --
+// in instantiations of their own (template flag WIDE), so the common path keeps its register budget.
+struct ObsWide { const int32_t* sidx; const double* stiff; };
+
+template <bool WITH_JP, bool WITH_JL, bool WIDE>
+PS_DEV void reproj_eval_obs(const Se3& T, const double* __restrict__ pw, const double* __restrict__ uvd,
+                            const ObsGroup* __restrict__ groups, int grp, const ObsWide& wide, long i, ReprojEval& o) {
+    if (!WIDE) { reproj_eval_grp<WITH_JP, WITH_JL>(T, pw, uvd, groups, grp, o); return; }
+    double Sl[9];
+    const double* sp = wide.stiff + 9 * (size_t)wide.sidx[i];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Sl[k] = sp[k];
+    for (;;) {
+        const int g0 = __builtin_amdgcn_readfirstlane(grp);
+        if (grp == g0) { reproj_eval_s<WITH_JP, WITH_JL>(T, pw, uvd, groups[g0], Sl, o); break; }
     }
 }

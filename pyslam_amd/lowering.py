@@ -242,7 +242,10 @@ class _Interner:
 _DEVICE_LOSSES = (_losses.L2Loss, _losses.L1Loss, _losses.CauchyLoss, _losses.HuberLoss,
                   _losses.TukeyLoss, _losses.TDistributionLoss)
 
-# the observation record carries the group index in 8 bits (csrc/ps_kernels.h: PS_GRP_OF)
+# the observation record carries 8 bits of group: up to 255 (camera, stiffness, loss) rows are device groups as they are;
+# beyond that (one stiffness per observation, reference reprojection_residual.py:8-11) the device groups are the
+# distinct (camera, loss) CLASSES -- at most 255 of those -- and the stiffness travels as a per-observation index
+# (csrc/ps_math.h: ObsWide; ps_problem_create splits the rows)
 MAX_OBS_GROUPS = 255
 
 
@@ -395,10 +398,10 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
         else:
             raise NotLowerable("block {} has no typed device kernel".format(type(block).__name__))
     if len(ogrp.rows) > MAX_OBS_GROUPS:
-        # e.g. a per-observation stiffness: more distinct (camera, stiffness, loss) combinations than the
-        # observation record's 8-bit group field addresses -> host-evaluated path (sparse normal equations)
-        raise NotLowerable("{} distinct (camera, stiffness, loss) observation groups; the typed device tables "
-                           "hold at most {}".format(len(ogrp.rows), MAX_OBS_GROUPS))
+        classes = {(r[0], r[2], r[3]) for r in ogrp.rows}
+        if len(classes) > MAX_OBS_GROUPS:
+            raise NotLowerable("{} distinct (camera, loss) classes among the observation groups; the typed device "
+                               "tables hold at most {}".format(len(classes), MAX_OBS_GROUPS))
 
     lp.poses, lp.pose_rid = poses, rid
     lp.points = np.concatenate([np.array(points, dtype=F64).reshape(-1, 3)] + fixed_points)

@@ -7,6 +7,7 @@ import pytest
 from oracle import gn_oracle as orc
 from pyslam_amd import synthetic
 from pyslam_amd.lowering import LoweredProblem
+from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -371,30 +372,67 @@ def test_generic_path_beyond_the_dense_limit_runs_sparse_cg_on_the_device():
     assert abs(got - cov[r0.start, r0.start]) <= 1e-8 * cov[r0.start, r0.start]
 
 
-def test_per_observation_stiffness_falls_to_the_host_evaluated_path_and_solves():
-    """More (camera, stiffness, loss) groups than the observation record's 8-bit group field: lowering says
-    NotLowerable (not an error out of ps_problem_create) and the host-evaluated path solves it -- same step as the
-    typed device path on the same problem with the stiffnesses quantised into 255 groups would give is NOT required;
-    the check is against scipy on the block protocol's own Jacobian."""
-    import scipy.sparse.linalg as spla
+def test_per_observation_stiffness_runs_the_typed_device_path():
+    """One stiffness per observation (the reference takes any: reprojection_residual.py:8-11) = more (camera, stiffness,
+    loss) rows than the observation record's 8-bit group field.  Round 2 sent such problems to the host-evaluated path;
+    now the device groups are the (camera, loss) classes and the stiffness is a per-observation index (ObsWide): the HIP
+    kernels themselves, against the oracle -- blocks 1e-12, reduced system 1e-12, step 1e-8 -- and a whole solve()."""
     from conftest import load_golden, golden_lp
     from test_host_api import build_namespace
     ns = build_namespace()
     lp = golden_lp(load_golden('ba_small'))
     problem = synthetic.to_objects(lp, ns)
     rng = np.random.default_rng(4)
-    for b in problem.residual_blocks:                         # one stiffness per observation
-        b.stiffness = b.stiffness * (1. + 0.2 * rng.random())
-    from pyslam_amd.lowering import NotLowerable
-    with pytest.raises(NotLowerable):
-        problem._lower()
-    dx, cost = problem.solve_one_iter()
-    J, e, _ = problem._host_jacobian()
-    ref = spla.spsolve((J.T @ J).tocsc(), -(J.T @ e))
-    assert np.linalg.norm(dx - ref) <= 1e-8 * np.linalg.norm(ref)
+    for b in problem.residual_blocks:                         # one stiffness per observation, not even symmetric
+        b.stiffness = b.stiffness.dot(np.eye(3) + 0.2 * rng.random((3, 3)))
+    wide = problem._lower()
+    assert wide.obs_groups.shape[0] == lp.num_obs > 255
+    dev = device(wide)
+    r, jp, jl = dev.debug_reproj_blocks()
+    ro, jpo, jlo = orc.eval_reproj(wide)
+    assert rel_err(r, ro) < 1e-12 and rel_err(jp, jpo) < 1e-12 and rel_err(jl, jlo) < 1e-12
+    c = dev.eval_cost(True)
+    assert abs(c - orc.eval_cost(wide)) <= 1e-10 * abs(c)
+    dev.linearize(0.)
+    S, g = dev.reduced_dense()
+    P, b, _ = orc.normal_equations(wide, points_first=False)
+    P = P.toarray()
+    n_p = wide.dof * wide.num_reduced
+    Hinv = np.linalg.inv(P[n_p:, n_p:])
+    assert rel_err(S, P[:n_p, :n_p] - P[:n_p, n_p:] @ Hinv @ P[n_p:, :n_p]) < 1e-12
+    assert rel_err(g, b[:n_p] - P[:n_p, n_p:] @ Hinv @ b[n_p:]) < 1e-12
+    dev.solve_reduced(1e-13, 500)
+    dev.backsub()
+    xp, xl = dev.get_dx()
+    dx_ref, _ = orc.gauss_newton_step(wide, points_first=False)
+    assert rel_err(np.concatenate([xp.ravel(), xl.ravel()]), dx_ref) < 1e-8
+    # the public API: no host-evaluated path involved (the tables device is what solve() built)
     c0 = problem.eval_cost()
     problem.solve()
+    assert problem._device is not None and problem._device.lp.obs_groups.shape[0] == lp.num_obs
     assert problem._cost_history[-1] < 0.05 * c0 and len(problem._cost_history) >= 3
+    _, ref = orc.solve(wide, dict(max_iters=100), points_first=True)
+    assert len(problem._cost_history) == len(ref['cost_history'])
+    assert np.allclose(problem._cost_history, ref['cost_history'], rtol=1e-9)
+
+
+def test_per_observation_stiffness_motion_only_and_losses():
+    """The wide path through the one-launch motion-only kernel (config 5 with a covariance per feature) and through the
+    general landmark-free path, Cauchy loss: step vs the oracle's."""
+    lp, _ = synthetic.motion_only(num_pts=400, seed=11)
+    rng = np.random.default_rng(1)
+    n = lp.num_obs
+    lp.stiff3 = np.stack([(np.eye(3) * (0.5 + rng.random(3))).ravel() for _ in range(n)])
+    lp.obs_groups = np.stack([np.array([0., i, lp.obs_groups[0, 2], lp.obs_groups[0, 3]]) for i in range(n)])
+    lp.obs_grp = np.arange(n, dtype=np.int32)
+    lp = lp.finalize()
+    dx_ref, lin = orc.gauss_newton_step(lp, points_first=False)
+    for fused in (1, 0):
+        dev = device(lp)
+        dev.set_option('fused_motion_only', fused)
+        cost, nrm, its, rel = dev.gn_iteration(0., 1e-12, 100, False)
+        assert abs(cost - lin) <= 1e-10 * abs(lin)
+        assert rel_err(dev.get_dx()[0].ravel(), dx_ref) < 1e-8
 
 
 def test_streaming_schur_kernel_builds_the_same_reduced_system(monkeypatch):

@@ -333,13 +333,16 @@ def test_loss_subclass_and_group_overflow_are_not_lowered():
     assert lowering.lower(params, [block], [['T', 'p']], [HuberLoss(1.)], []).obs_groups[0, 2] == 3
     with pytest.raises(NotLowerable):
         lowering.lower(params, [block], [['T', 'p']], [MyHuber(1.)], [])
-    # one stiffness per observation
+    # one stiffness per observation: lowerable whatever the count (the device splits rows beyond 255 into (camera, loss)
+    # classes + a per-observation stiffness index); more than 255 CLASSES are not
     blocks = [ReprojectionResidual(cam, np.array([640., 480., 25.]), (1. + 0.01 * i) * np.eye(3)) for i in range(300)]
     loss = L2Loss()
-    with pytest.raises(NotLowerable):
-        lowering.lower(params, blocks, [['T', 'p']] * 300, [loss] * 300, [])
+    wide = lowering.lower(params, blocks, [['T', 'p']] * 300, [loss] * 300, [])
+    assert wide.obs_groups.shape[0] == 300 and wide.stiff3.shape[0] == 300
     ok = lowering.lower(params, blocks[:255], [['T', 'p']] * 255, [loss] * 255, [])
     assert ok.obs_groups.shape[0] == 255
+    with pytest.raises(NotLowerable):
+        lowering.lower(params, blocks, [['T', 'p']] * 300, [HuberLoss(1. + 0.01 * i) for i in range(300)], [])
 
 
 def test_same_tables_sees_every_edit_but_parameter_values():
