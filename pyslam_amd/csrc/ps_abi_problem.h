@@ -466,7 +466,6 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
             std::vector<std::pair<int32_t, int32_t>> part_of;   // (block slot, partial index): combine lists
             std::vector<int32_t> part_slotT;
             bool ok = true;
-            std::vector<int32_t> blk_of_key_epoch(0);           // open-addressing map key -> local block, reset per tile
             struct KV { uint64_t key; int32_t val; };
             std::vector<KV> table(4096, KV{~0ULL, -1});
             std::vector<uint32_t> used;
@@ -499,10 +498,12 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
                     if (a1 - a0 >= 65536) { ok = false; break; }
                     const size_t used_before = used.size();
                     int added = 0;
-                    for (int a = a0; a < a1; ++a) {
+                    // (stop inserting as soon as the landmark overflows the accumulators: the 4 096-slot table holds at most
+                    //  PS_ST_CAP + 1 keys that way -- a landmark seen by ~90 variable poses used to fill it and spin, ADVICE)
+                    for (int a = a0; a < a1 && nblk + added <= PS_ST_CAP; ++a) {
                         const int ra = rid_of(a);
                         if (ra < 0) continue;
-                        for (int b = a + 1; b < a1; ++b) {
+                        for (int b = a + 1; b < a1 && nblk + added <= PS_ST_CAP; ++b) {
                             const int rb = rid_of(b);
                             if (rb < 0) continue;
                             const uint64_t key = ((uint64_t)std::min(ra, rb) << 32) | (uint32_t)std::max(ra, rb);

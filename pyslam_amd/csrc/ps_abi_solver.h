@@ -246,6 +246,8 @@ int ps_gn_result(ps_problem* h, int* done, double* shard2 /* [2] */, double* dx_
     if (done) *done = h->h_status[ST_PCG_DONE];
     if (shard2) { shard2[0] = sb[0]; shard2[1] = sb[1]; }
     if (dx_pose_norm2) *dx_pose_norm2 = h->h_scalars[SC_DXP2];
+    // the cost history the lagged operators' hold / try decisions read (same on every rank: the buffer was all-reduced)
+    if (h->h_status[ST_PCG_DONE]) { h->prev_cost = h->last_cost; h->last_cost = sb[0]; }
     return cg_report(h, pcg_iters_out, pcg_relres_out);
 }
 

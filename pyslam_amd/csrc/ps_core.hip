@@ -188,6 +188,7 @@ struct ps_problem {
     double* Mc = nullptr;           // split mode: dense coarse-coarse block M of the lagged system
     bool mc_active = false;         // the current system was built with a lagged factor in split mode
     bool coarse_built = false;
+    bool coarse_clamped = false;    // the automatic coarse level was cut back to 255 nodes: its matrix is not banded
     int cg_ablate = 0, schur_ablate = 0, lm_ablate = 0;
     int max_pose_obs = 0;           // most observations on one variable pose
     int mo_fused = 1;               // motion-only problems: one launch per iteration (k_motion_only_iteration)

@@ -212,6 +212,7 @@ int build_coarse(ps_problem* h) {
     if (h->cg_explicit && h->coarse_req < 0)
         G = sparse_rows ? std::min(400, std::max(48, nr / 25)) : std::min(112, std::max(48, nr / 20));
     G = std::min(G, h->cg_explicit ? PS_XCG_MAXNODES - 1 : Gmax);
+    if (h->coarse_clamped && h->coarse_req < 0) G = std::min(G, 255);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;
     if (G < 1) G = 0;
     h->G = G; h->coarse_built = true; h->cg_split = false;
@@ -328,6 +329,13 @@ int build_coarse(ps_problem* h) {
             for (int q2 = 0; q2 < ncb; ++q2)
                 if (sptr[(size_t)q * ncb + q2 + 1] > sptr[(size_t)q * ncb + q2]) h->ac_bw = std::max(h->ac_bw, std::abs(q - q2));
         if (h->ac_bw > PS_BAND_MAXB) h->ac_bw = -1;
+        // More than 255 coarse nodes are only affordable with the BANDED factorisation (round-2 ADVICE): a coarse matrix
+        // that turns out not to be banded (long loop closures) would take the dense one at ~4x the work and ~7 nc^2
+        // doubles of scratch.  The automatic choice then falls back to the old limit and the level is built again.
+        if (h->ac_bw < 0 && h->coarse_req < 0 && G > 255 && !h->coarse_clamped) {
+            h->coarse_clamped = true; h->coarse_built = false;
+            return build_coarse(h);
+        }
         if (h->upload(&h->ent_ptr, eptr) || h->upload(&h->ent_q, eq) || h->upload(&h->ent_lo, elo) ||
             h->upload(&h->ent_hi, ehi) || h->upload(&h->seg_ptr, sptr) || h->upload(&h->seg_ent, sent) ||
             h->upload(&h->seg_row, srow)) return -1;

@@ -260,9 +260,18 @@ def dense_normal_solve(J, r, want_covariance=False):
     return (dx, cov) if want_covariance else dx
 
 
-def sparse_normal_solve(J, r=None, rhs=None, tol=1e-12, max_iters=10000):
+class NotConverged(nat.NativeError):
+    """The CG of the host-evaluated path stopped at max_iters with a residual too large to use."""
+
+
+def sparse_normal_solve(J, r=None, rhs=None, tol=1e-12, max_iters=10000, accept=1e-6):
     """Host-evaluated generic path beyond the dense solver: (J^T J) dx = -J^T r (or = rhs) by CG on the device with J
-    (scipy CSR) resident in HBM.  -> (dx, iterations, relative preconditioned residual)."""
+    (scipy CSR) resident in HBM.  -> (dx, iterations, relative preconditioned residual).
+
+    The reference solves these systems with a sparse LU (pyslam/problem.py:186), which does not care about the
+    condition number; Jacobi-preconditioned CG on J^T J does (it squares it).  So the outcome is checked: a solve
+    that ran out of iterations with a relative residual above `accept` raises NotConverged (an unconverged step or
+    covariance column must not be used silently -- round-2 ADVICE), one that ended between `tol` and `accept` warns."""
     lib = nat.require_gpu()
     J = J.tocsr()
     J.sort_indices()
@@ -278,7 +287,17 @@ def sparse_normal_solve(J, r=None, rhs=None, tol=1e-12, max_iters=10000):
     nat.check(lib.ps_sparse_normal_solve(m, n, nat.i32p(a[0]), nat.i32p(a[1]), nat.f64p(a[2]), nat.i32p(a[3]), nat.i32p(a[4]),
                                          nat.f64p(a[5]), nat.f64p(rr), nat.f64p(bb), float(tol), int(max_iters), nat.f64p(dx),
                                          C.byref(its), C.byref(rel)))
-    return dx, its.value, rel.value
+    relres = float(rel.value)
+    if not (relres <= max(accept, tol)):
+        raise NotConverged('sparse normal equations ({} unknowns): CG stopped after {} iterations at a relative residual of '
+                           '{:.2e} (tolerance {:.1e}); the system is too ill-conditioned for Jacobi-preconditioned CG on '
+                           'J^T J -- rescale the parameters / stiffnesses, or hold enough parameters constant for the '
+                           'dense path (<= 2048 unknowns)'.format(n, int(its.value), relres, tol))
+    if relres > 10. * tol:
+        import warnings
+        warnings.warn('pyslam_amd: sparse normal equations solved to a relative residual of {:.2e} only (tolerance {:.1e}, '
+                      '{} iterations)'.format(relres, tol, int(its.value)), RuntimeWarning)
+    return dx, int(its.value), relres
 
 
 class PhotometricDevice:

@@ -311,7 +311,13 @@ class ShardedProblemView:
         return poses, np.concatenate(parts).reshape(-1, 3)
 
     def get_dx(self):
-        """(dx_pose, dx_point) of the last iteration in the FULL problem's device order."""
+        """(dx_pose, dx_point) of the last iteration in the FULL problem's device order.  After a staged solve
+        (solve_reduced) the step gathered there is returned: no second collective."""
+        if getattr(self, '_staged_dx', None) is not None:
+            return self._staged_dx
+        return self._gather_dx()
+
+    def _gather_dx(self):
         xp, xl = self.sharded.dev.get_dx()
         parts = [None] * self.world
         self.dist.all_gather_object(parts, xl)
@@ -328,6 +334,7 @@ class ShardedProblemView:
         return self.sharded.eval_cost(include_all_constant)
 
     def gn_iteration(self, lm_lambda=0., pcg_tol=1e-12, pcg_max_iters=1000, linesearch=True):
+        self._staged_dx = None
         return self.sharded.gn_iteration(lm_lambda, pcg_tol, pcg_max_iters, linesearch)
 
     # ---- staged calls (Problem.solve_one_iter): one sharded iteration, then the parameters go back -----------
@@ -337,7 +344,7 @@ class ShardedProblemView:
     def solve_reduced(self, tol=1e-12, max_iters=1000):
         self.sharded.snapshot()
         self._staged = self.sharded.gn_iteration(self._staged_lambda, tol, max_iters, True)
-        self._staged_dx = self.get_dx()
+        self._staged_dx = self._gather_dx()                # ONE gather of the step; get_dx() hands it out
         self.sharded.restore()
         return self._staged[2], self._staged[3]
 
@@ -349,6 +356,8 @@ class ShardedProblemView:
         self.sharded.dev.apply_update(step)
 
     # ---- covariance: a replica of the whole problem on this rank's GPU --------------------------------------
+    # (memory: the replica holds the UNSHARDED tables -- a problem sharded because it does not fit one GPU cannot have its
+    #  covariance computed this way; C4 needs 1.6 GB, far from that limit)
     def covariance_begin(self):
         from pyslam_amd.device import DeviceProblem
         poses, points = self.get_params()

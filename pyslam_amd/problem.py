@@ -526,7 +526,7 @@ class Problem:
                 cols = np.zeros((r0.stop - r0.start, r1.stop - r1.start))
                 for c, k in enumerate(range(r1.start, r1.stop)):
                     rhs = np.zeros(J.shape[1]); rhs[k] = 1.
-                    x, _, _ = sparse_normal_solve(J, rhs=rhs, tol=1e-13, max_iters=20 * J.shape[1])
+                    x, _, _ = sparse_normal_solve(J, rhs=rhs, tol=1e-13, max_iters=20 * J.shape[1], accept=1e-8)
                     cols[:, c] = x[r0.start:r0.stop]
                 return np.squeeze(cols)
             if self._covariance_matrix is None and getattr(self, '_cov_device', None) is not None:

@@ -372,6 +372,28 @@ def test_generic_path_beyond_the_dense_limit_runs_sparse_cg_on_the_device():
     assert abs(got - cov[r0.start, r0.start]) <= 1e-8 * cov[r0.start, r0.start]
 
 
+def test_generic_sparse_path_reports_a_solve_that_did_not_converge():
+    """Round-2 ADVICE: beyond 2 048 unknowns the host-evaluated path runs Jacobi-preconditioned CG on J^T J where the
+    reference runs a sparse LU; on an ill-conditioned system it used to return whatever max_iters had reached, silently.
+    A chain of 2 500 scalars tied by smoothness blocks of stiffness 1e4 and anchored at one end by a unit block has a
+    normal matrix of condition number ~1e15: the solve must raise NotConverged, not hand back a wrong step."""
+    from pyslam.problem import Options, Problem
+    from pyslam_amd.device import NotConverged, sparse_normal_solve
+    import scipy.sparse as sp
+    n = 2500
+    rows = np.arange(n - 1)
+    J = sp.vstack([sp.csr_matrix((np.concatenate([1e4 * np.ones(n - 1), -1e4 * np.ones(n - 1)]),
+                                  (np.concatenate([rows, rows]), np.concatenate([rows, rows + 1]))), shape=(n - 1, n)),
+                   sp.csr_matrix(([1.], ([0], [0])), shape=(1, n))]).tocsr()
+    r = np.ones(n)
+    with pytest.raises(NotConverged):
+        sparse_normal_solve(J, r=r, tol=1e-12, max_iters=300)
+    # ... a well-conditioned one of the same size still solves, silently
+    Jw = sp.vstack([J / 1e4, sp.identity(n, format='csr')]).tocsr()
+    dx, its, rel = sparse_normal_solve(Jw, r=np.ones(2 * n), tol=1e-12, max_iters=5000)
+    assert rel <= 1e-12 and its > 0
+
+
 def test_per_observation_stiffness_runs_the_typed_device_path():
     """One stiffness per observation (the reference takes any: reprojection_residual.py:8-11) = more (camera, stiffness,
     loss) rows than the observation record's 8-bit group field.  Round 2 sent such problems to the host-evaluated path;
