@@ -75,7 +75,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, config=None):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json:
     separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, read
     traffic corrected x2 as MI355X_MICROARCH.md prescribes for gfx950) + the source hash of the
@@ -83,10 +83,12 @@ def pmc_traffic(kernel):
     try:
         with open(os.path.join(REPO, 'profiles', 'pmc_traffic.json')) as f:
             table = json.load(f)
+        meta = table.get('_meta', {})
+        if config is not None:
+            table = table[config]
         total = table[kernel]['hbm_bytes_corrected']
         if kernel == 'k_schur_pairs' and 'k_schur_combine' in table:    # tiled mode: the pair kernel's partials are
             total += table['k_schur_combine']['hbm_bytes_corrected']    # summed by a second, small kernel (same timer)
-        meta = table.get('_meta', {})
         return total, meta.get('source_sha'), meta.get('git_head')
     except Exception:
         return None, None, None
@@ -208,7 +210,17 @@ def c4_single_gpu(stream, steps=10, warmup=5):
     st = dev.stage_times(reset=True)
     dev.set_profiling(0)
     traj = trajectory(dev, 4)
-    res = {'ms': round(sec * 1e3 / steps, 4), 'pcg_iters': out[2], 'blocks': dev.info['num_obs'],
+    stage = {k: v[0] / v[1] for k, v in st.items() if v[1] > 0}
+    _, b_schur, _ = algorithmic_bytes(dev.info, out[2])
+    sch_ms = stage.get('schur_pairs', 0.0)
+    traffic, tsha, _ = pmc_traffic('k_schur_pairs', 'C4')
+    ach = b_schur / (sch_ms * 1e-3) / 1e9 if sch_ms > 0 else 0.0
+    roof = {'bound': 'hbm', 'kernel': 'k_schur_pairs', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source_sha': tsha,
+            'traffic_stale': bool(traffic is not None and tsha != kernel_source_sha()),
+            'algorithmic_bytes_per_launch': int(b_schur), 'avg_launch_ms': round(sch_ms, 5),
+            'note': 'pair + combine kernel, hipEvent pair around both on 3 untimed steps (profiling level 2)'}
+    res = {'ms': round(sec * 1e3 / steps, 4), 'roofline': roof, 'pcg_iters': out[2], 'blocks': dev.info['num_obs'],
            'reduced_blocks': dev.info['reduced_nnzb'], 'device_bytes': dev.info['device_bytes'],
            'stage_ms': {k: round(v[0] / v[1], 4) for k, v in st.items() if v[1] > 0},
            'trajectory_ms_per_iter': traj['per_iter'], 'trajectory_pcg_iters': traj['pcg_iters']}

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_SP_WAVES
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int r = 9 * k + slot;
-            if (slot < 9 && r < 2 * PS_SP_PAIRS && zrow[k] >= 0 && !(ablate & 2))
+            if (slot < 9 && r < 2 * PS_SP_PAIRS && zrow[k] >= 0 && !(ablate & 2) && !((ablate & 4) && r < PS_SP_PAIRS))   // (4: no a-rows, timing only)
                 __builtin_amdgcn_global_load_lds((ps_gptr_t)(Z + PS_ZROW * (size_t)zrow[k] + 2 * piece),
                                                  (ps_lptr_t)(rows + 9 * PS_SP_ROWD * k), 16, 0, 0);
         }

@@ -1,0 +1,306 @@
+#!/usr/bin/env python
+"""CPU prototypes behind DESIGN.md section 3 "Lagged dense inverse" (round 3): which preconditioners remove CG iterations
+from the reduced (Schur) system, measured with numpy on the ORACLE's own Schur complements before any kernel was written.
+Test infrastructure (it drives oracle/gn_oracle.py); not collected by pytest.
+
+    python tests/proto_preconditioners.py gen  <kf> <lm> <seed> <iters> <out.npz>   trajectory of (S_k, g_k, x_k) of a stereo BA
+    python tests/proto_preconditioners.py lag  <npz>              CG iterations with fp64 / fp32 inverses of S_{k-1}, S_{k-2}
+    python tests/proto_preconditioners.py asw  <npz> <k> <G>      overlapping additive-Schwarz windows + hat coarse level
+    python tests/proto_preconditioners.py bj   <npz> <k> <G>      non-overlapping Jacobi blocks of 2..80 poses (additive / multiplicative)
+    python tests/proto_preconditioners.py band <npz> <k> <G>      decay of S^-1 and of S^-1 - P A_c^-1 P^T, band truncations
+    python tests/proto_preconditioners.py ns   <npz> <G>          fp32 Newton-Schulz: seed from the two-level operator, tracking
+    python tests/proto_preconditioners.py ns2  <npz>              fp32 vs fp64-residual Newton-Schulz fixed points
+
+(C3: gen 200 50000 0 5 c3.npz ~70 s; 600 keyframes: gen 600 150000 1 4 c600.npz ~4 min.)"""
+import os
+import sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+SRC_GEN = r'''import sys, numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla, time
+from pyslam_amd import synthetic
+from oracle import gn_oracle as orc
+kf=int(sys.argv[1]); lm=int(sys.argv[2]); seed=int(sys.argv[3]); iters=int(sys.argv[4]); out=sys.argv[5]
+lp,_=synthetic.stereo_ba(num_kf=kf,num_lm=lm,obs_per_lm=10,half_window=20,seed=seed)
+d=lp.dof
+res={}
+for k in range(iters):
+    t0=time.time()
+    P,b,cost=orc.normal_equations(lp,False)
+    pose_off,point_off,n=orc.unknown_offsets(lp,False)
+    nr,nv=lp.num_reduced,lp.num_var_points
+    ip=(np.sort(pose_off[pose_off>=0])[:,None]+np.arange(d)[None,:]).reshape(-1)
+    il=(np.sort(point_off[point_off>=0])[:,None]+np.arange(3)[None,:]).reshape(-1)
+    P=P.tocsr()
+    Hll=P[il][:,il]; blocks=np.zeros((nv,3,3)); coo=Hll.tocoo()
+    blocks[coo.row//3,coo.row%3,coo.col%3]=coo.data
+    inv=np.linalg.inv(blocks); Hll_inv=orc._bdiag(inv)
+    Hpl=P[ip][:,il]; Hpp=P[ip][:,ip]; Y=Hpl.dot(Hll_inv)
+    S=(Hpp-Y.dot(Hpl.T)).tocsr(); g=b[ip]-Y.dot(b[il])
+    dxp=spla.spsolve(S.tocsc(),g)
+    dx=np.zeros(n); dx[ip]=dxp; dx[il]=Hll_inv.dot(b[il]-Hpl.T.dot(dxp))
+    res['S%d_data'%k]=S.data; res['S%d_indices'%k]=S.indices; res['S%d_indptr'%k]=S.indptr; res['g%d'%k]=g; res['x%d'%k]=dxp
+    res['poses%d'%k]=lp.poses.copy()
+    lp=orc.apply_update(lp,dx,False)
+    print(k,cost,np.linalg.norm(dx),time.time()-t0,flush=True)
+res['n']=S.shape[0]
+np.savez(out,**res)
+'''
+
+SRC_LAG = r'''import numpy as np, scipy.sparse as sp, sys
+Z=np.load(sys.argv[1]); n=int(Z['n'])
+def getS(k): return sp.csr_matrix((Z['S%d_data'%k],Z['S%d_indices'%k],Z['S%d_indptr'%k]),shape=(n,n)).toarray()
+def pcg(S,g,Minv,tol=1e-12,maxit=200):
+    x=np.zeros_like(g); r=g.copy(); z=Minv(r); p=z.copy(); rz=r@z; rz0=rz; it=0
+    while it<maxit:
+        q=S@p; a=rz/(p@q); x+=a*p; r-=a*q; z=Minv(r); rzn=r@z; it+=1
+        if np.sqrt(abs(rzn)/rz0)<tol: break
+        p=z+(rzn/rz)*p; rz=rzn
+    return x,it
+def bj(S):
+    nb=n//6; L=np.zeros((n,n))
+    for i in range(nb):
+        s=slice(6*i,6*i+6); L[s,s]=np.linalg.inv(np.linalg.cholesky(S[s,s]))
+    return L
+Ss=[getS(k) for k in range(5)]
+for k in range(5):
+    S=Ss[k]; g=Z['g%d'%k]; xt=Z['x%d'%k]
+    Li=bj(S); Sh=Li@S@Li.T; gh=Li@g
+    x,it=pcg(Sh,gh,lambda r:r)
+    ev=np.linalg.eigvalsh(Sh)
+    print('iter',k,'block-jacobi CG its',it,'eig range',ev[0],ev[-1])
+    for lag in (1,2):
+        if k-lag<0: continue
+        Sp=Ss[k-lag]; Lp=bj(Sp); X=np.linalg.inv(Lp@Sp@Lp.T)
+        for nm,Xq in (('f64',X),('f32',X.astype(np.float32).astype(np.float64))):
+            Xq=(Xq+Xq.T)/2
+            Sh2=Lp@S@Lp.T; gh2=Lp@g
+            x,it=pcg(Sh2,gh2,lambda r:Xq@r)
+            e=np.linalg.eigvals(Xq@Sh2).real
+            err=np.linalg.norm(Lp.T@x-xt)/np.linalg.norm(xt)
+            print('   lag',lag,nm,'its',it,'eig(XS) range',e.min(),e.max(),'err vs direct',err)
+'''
+
+SRC_ASW = r'''import numpy as np, scipy.sparse as sp, sys
+Z=np.load(sys.argv[1]); n=int(Z['n']); k=int(sys.argv[2]); G=int(sys.argv[3])
+def getS(k): return sp.csr_matrix((Z['S%d_data'%k],Z['S%d_indices'%k],Z['S%d_indptr'%k]),shape=(n,n)).toarray()
+S=getS(k); nb=n//6; g=Z['g%d'%k]
+def bjL(S):
+    Li=np.zeros((n,n))
+    for i in range(nb):
+        s=slice(6*i,6*i+6); Li[s,s]=np.linalg.inv(np.linalg.cholesky(S[s,s]))
+    return Li
+Li=bjL(S); Sh=Li@S@Li.T; gh=Li@g
+poses=Z['poses%d'%k]
+def adj(row):
+    R=row[:9].reshape(3,3); t=row[9:]
+    tx=np.array([[0,-t[2],t[1]],[t[2],0,-t[0]],[-t[1],t[0],0]])
+    A=np.zeros((6,6)); A[:3,:3]=R; A[:3,3:]=tx@R; A[3:,3:]=R; return A
+nodes=np.arange(0,nb+G,G); nn=len(nodes)
+P=np.zeros((n,6*nn)); L=np.linalg.inv(Li)
+for i in range(nb):
+    Bi=L[6*i:6*i+6,6*i:6*i+6].T@adj(poses[i+1])
+    q=i//G; w1=(i-nodes[q])/G
+    P[6*i:6*i+6,6*q:6*q+6]=(1-w1)*Bi
+    if q+1<nn: P[6*i:6*i+6,6*q+6:6*q+12]=w1*Bi
+Ac=P.T@Sh@P; Aci=np.linalg.inv(Ac)
+def coarse(r): return P@(Aci@(P.T@r))
+def pcg(S,g,Minv,tol=1e-12,maxit=400):
+    x=np.zeros_like(g); r=g.copy(); z=Minv(r); p=z.copy(); rz=r@z; rz0=rz; it=0
+    while it<maxit:
+        q=S@p; a=rz/(p@q); x+=a*p; r-=a*q; z=Minv(r); rzn=r@z; it+=1
+        if np.sqrt(abs(rzn)/rz0)<tol: break
+        p=z+(rzn/rz)*p; rz=rzn
+    return x,it
+print('block-jacobi + coarse: its',pcg(Sh,gh,lambda r:r+coarse(r))[1])
+Slag=getS(k-1) if k>0 else S
+for src,name in ((Sh,'current'),(Li@Slag@Li.T,'lagged')):
+  for w,stride in ((8,4),(16,8),(16,4),(32,16),(32,8),(64,32),(64,16),(128,64)):
+    wins=[]
+    for a in range(0,nb,stride):
+        b=min(a+w,nb); sl=slice(6*a,6*b); wins.append((sl,np.linalg.inv(src[sl,sl])))
+        if b==nb: break
+    def AS(r):
+        z=np.zeros_like(r)
+        for sl,W in wins: z[sl]+=W@r[sl]
+        return z
+    x,it=pcg(Sh,gh,lambda r:AS(r)+coarse(r))
+    # scaled variant (divide by multiplicity)
+    mult=w/stride
+    x,it2=pcg(Sh,gh,lambda r:AS(r)/mult+coarse(r))
+    print(name,'AS window',w,'stride',stride,'its',it,'scaled',it2,'bytes/apply fp32 MB',len(wins)*(6*w)**2*4/1e6)
+'''
+
+SRC_BJ = r'''import numpy as np, scipy.sparse as sp, sys
+exec(SRC_ASW.split("print('block-jacobi + coarse")[0])
+print('block-jacobi + coarse: its',pcg(Sh,gh,lambda r:r+coarse(r))[1])
+for w in (2,4,8,16,40,80):
+    wins=[]
+    for a in range(0,nb,w):
+        b=min(a+w,nb); sl=slice(6*a,6*b); wins.append((sl,np.linalg.inv(Sh[sl,sl])))
+    def BJ(r):
+        z=np.zeros_like(r)
+        for sl,W in wins: z[sl]=W@r[sl]
+        return z
+    # coarse on top (additive), and also deflated/multiplicative variant
+    x,it=pcg(Sh,gh,lambda r:BJ(r)+coarse(r))
+    def mult(r):
+        y=coarse(r); r2=r-Sh@y; z=BJ(r2); r3=r2-Sh@z
+        return y+z+coarse(r3)
+    x,it2=pcg(Sh,gh,mult)
+    print('nonoverlapping blocks of',w,'poses: additive its',it,' symmetric multiplicative its',it2)
+'''
+
+SRC_BAND = r'''import numpy as np, scipy.sparse as sp, sys
+Z=np.load(sys.argv[1]); n=int(Z['n']); k=int(sys.argv[2])
+def getS(k): return sp.csr_matrix((Z['S%d_data'%k],Z['S%d_indices'%k],Z['S%d_indptr'%k]),shape=(n,n)).toarray()
+S=getS(k); nb=n//6
+Li=np.zeros((n,n))
+for i in range(nb):
+    s=slice(6*i,6*i+6); Li[s,s]=np.linalg.inv(np.linalg.cholesky(S[s,s]))
+Sh=Li@S@Li.T
+X=np.linalg.inv(Sh)
+# block norms of inverse by distance
+def bn(M):
+    return np.sqrt((M.reshape(nb,6,nb,6)**2).sum(axis=(1,3)))
+B=bn(X)
+d=np.abs(np.arange(nb)[:,None]-np.arange(nb)[None,:])
+for w in (0,10,20,40,60,80,120,200,300):
+    m=d==w
+    print('dist',w,'mean block norm',B[m].mean(), 'S block norm', bn(Sh)[m].mean() if w<=45 else 0)
+# hat coarse space: interval every G poses, basis Ad(T_i)? use simple: P = hats x I6 in scaled coords with B_i=Li^T Ad(T_i)
+poses=Z['poses%d'%k]
+# variable poses are 1..nb (pose 0 constant)
+def adj(row):
+    R=row[:9].reshape(3,3); t=row[9:]
+    tx=np.array([[0,-t[2],t[1]],[t[2],0,-t[0]],[-t[1],t[0],0]])
+    A=np.zeros((6,6)); A[:3,:3]=R; A[:3,3:]=tx@R; A[3:,3:]=R; return A
+G=int(sys.argv[3]) if len(sys.argv)>3 else 20
+nodes=np.arange(0,nb+G,G); nn=len(nodes)
+P=np.zeros((n,6*nn))
+L=np.linalg.inv(Li)  # block diag chol
+for i in range(nb):
+    Bi=L[6*i:6*i+6,6*i:6*i+6].T@adj(poses[i+1])
+    q=i//G; w1=(i-nodes[q])/G
+    P[6*i:6*i+6,6*q:6*q+6]=(1-w1)*Bi
+    if q+1<nn: P[6*i:6*i+6,6*q+6:6*q+12]=w1*Bi
+Ac=P.T@Sh@P
+C=P@np.linalg.solve(Ac,P.T)
+E=X-C
+BE=bn(E)
+for w in (0,10,20,40,60,80,120,200,300):
+    m=d==w
+    print('remainder dist',w,'mean block norm',BE[m].mean())
+mask=np.kron(d<=0,np.ones((6,6)))>0
+for w in (0,20,40,60,80,120):
+    mask=np.kron(d<=w,np.ones((6,6)))>0
+    M=np.where(mask,E,0)+C
+    ev=np.linalg.eigvals(M@Sh).real
+    M2=np.where(mask,X,0)
+    ev2=np.linalg.eigvals(M2@Sh).real
+    print('band',w,'eig(M S) [trunc remainder + coarse]',ev.min(),ev.max(),'  [trunc inverse only]',ev2.min(),ev2.max())
+'''
+
+SRC_NS = r'''import numpy as np, scipy.sparse as sp, sys
+Z=np.load(sys.argv[1]); n=int(Z['n']); G=int(sys.argv[2])
+f32=np.float32
+def getS(k): return sp.csr_matrix((Z['S%d_data'%k],Z['S%d_indices'%k],Z['S%d_indptr'%k]),shape=(n,n)).toarray()
+nb=n//6
+def bjL(S):
+    Li=np.zeros((n,n))
+    for i in range(nb):
+        s=slice(6*i,6*i+6); Li[s,s]=np.linalg.inv(np.linalg.cholesky(S[s,s]))
+    return Li
+def adj(row):
+    R=row[:9].reshape(3,3); t=row[9:]
+    tx=np.array([[0,-t[2],t[1]],[t[2],0,-t[0]],[-t[1],t[0],0]])
+    A=np.zeros((6,6)); A[:3,:3]=R; A[:3,3:]=tx@R; A[3:,3:]=R; return A
+def pcg(S,g,Minv,tol=1e-12,maxit=400):
+    x=np.zeros_like(g); r=g.copy(); z=Minv(r); p=z.copy(); rz=r@z; rz0=rz; it=0
+    while it<maxit:
+        q=S@p; a=rz/(p@q); x+=a*p; r-=a*q; z=Minv(r); rzn=r@z; it+=1
+        if np.sqrt(abs(rzn)/rz0)<tol: break
+        p=z+(rzn/rz)*p; rz=rzn
+    return x,it
+S0=getS(0); Li=bjL(S0); L=np.linalg.inv(Li)
+Sh=Li@S0@Li.T
+poses=Z['poses0']
+nodes=np.arange(0,nb+G,G); nn=len(nodes)
+P=np.zeros((n,6*nn))
+for i in range(nb):
+    Bi=L[6*i:6*i+6,6*i:6*i+6].T@adj(poses[i+1])
+    q=i//G; w1=(i-nodes[q])/G
+    P[6*i:6*i+6,6*q:6*q+6]=(1-w1)*Bi
+    if q+1<nn: P[6*i:6*i+6,6*q+6:6*q+12]=w1*Bi
+Ac=P.T@Sh@P
+M0=np.eye(n)+P@np.linalg.solve(Ac,P.T)
+ev=np.linalg.eigvals(M0@Sh).real
+print('two-level eig range',ev.min(),ev.max(), 'nn',nn)
+c=2/(ev.min()+ev.max())
+X=(c*M0).astype(f32); S32=Sh.astype(f32)
+I=np.eye(n,dtype=f32)
+for it in range(6):
+    R=I-S32@X
+    print('NS step',it,'||R||_2',np.linalg.norm(R.astype(float),2),'fro',np.linalg.norm(R))
+    X=X+X@R
+    X=(X+X.T)/2
+# now trajectory: scaling frozen at Li (from S0)
+for k in range(1,5):
+    S=getS(k); Shk=Li@S@Li.T; g=Li@Z['g%d'%k]
+    Xd=X.astype(float)
+    x,it=pcg(Shk,g,lambda r:Xd@r)
+    err=np.linalg.norm(Li.T@x-Z['x%d'%k])/np.linalg.norm(Z['x%d'%k])
+    R=I-Shk.astype(f32)@X
+    print('GN iter',k,'PCG its with X(lagged)',it,'err',err,'||I-SX||',np.linalg.norm(R.astype(float),2))
+    X=X+X@R; X=(X+X.T)/2
+    R=I-Shk.astype(f32)@X
+    print('    after 1 NS step vs S_k: ||I-SX||',np.linalg.norm(R.astype(float),2))
+'''
+
+SRC_NS2 = r'''import numpy as np, scipy.sparse as sp, sys
+Z=np.load(sys.argv[1]); n=int(Z['n'])
+f32=np.float32
+def getS(k): return sp.csr_matrix((Z['S%d_data'%k],Z['S%d_indices'%k],Z['S%d_indptr'%k]),shape=(n,n)).toarray()
+nb=n//6
+def bjL(S):
+    Li=np.zeros((n,n))
+    for i in range(nb):
+        s=slice(6*i,6*i+6); Li[s,s]=np.linalg.inv(np.linalg.cholesky(S[s,s]))
+    return Li
+def pcg(S,g,Minv,tol=1e-12,maxit=400):
+    x=np.zeros_like(g); r=g.copy(); z=Minv(r); p=z.copy(); rz=r@z; rz0=rz; it=0
+    while it<maxit:
+        q=S@p; a=rz/(p@q); x+=a*p; r-=a*q; z=Minv(r); rzn=r@z; it+=1
+        if np.sqrt(abs(rzn)/rz0)<tol: break
+        p=z+(rzn/rz)*p; rz=rzn
+    return x,it
+S1=getS(1); Li=bjL(S1); Sh=Li@S1@Li.T
+Xex=np.linalg.inv(Sh)
+print('max |X|',np.abs(Xex).max(),'cond',np.linalg.cond(Sh))
+I=np.eye(n)
+# start from slightly perturbed exact inverse (as if lagged)
+S2=getS(2); Sh2=Li@S2@Li.T; g2=Li@Z['g2']
+for mode in ('all32','R64','all64'):
+    X=Xex.astype(f32) if mode!='all64' else Xex.copy()
+    for it in range(3):
+        if mode=='all32':
+            R=(I.astype(f32)-Sh2.astype(f32)@X)
+            Xn=X+X@R
+        elif mode=='R64':
+            R=(I-Sh2@X.astype(float)).astype(f32)
+            Xn=X+X@R
+        else:
+            R=I-Sh2@X; Xn=X+X@R
+        Xn=(Xn+Xn.T)/2
+        Rn=I-Sh2@Xn.astype(float)
+        x,its=pcg(Sh2,g2,lambda r:Xn.astype(float)@r)
+        print(mode,'step',it,'||R_before||',np.linalg.norm(np.asarray(R,float),2),'||R_after||',np.linalg.norm(Rn,2),'pcg its',its)
+        X=Xn
+'''
+
+
+if __name__ == '__main__':
+    if len(sys.argv) < 2 or sys.argv[1] not in ('gen', 'lag', 'asw', 'bj', 'band', 'ns', 'ns2'):
+        print(__doc__); sys.exit(1)
+    which = sys.argv.pop(1)
+    exec(globals()['SRC_' + which.upper()])

@@ -90,7 +90,7 @@ def test_reduced_system(name):
     dev.linearize(0.)
     S, g = dev.reduced_dense()
     So, go, _ = oracle_reduced(lp)
-    assert rel_err(S, So) < TOL_BLOCK          # measured maxima over the goldens: 2.8e-14 / 3.8e-14 (tools/parity_margins.py)
+    assert rel_err(S, So) < TOL_BLOCK          # measured maxima over the goldens: 2.8e-14 / 3.8e-14 (tests/parity_margins.py)
     assert rel_err(g, go) < TOL_BLOCK
     assert np.abs(S - S.T).max() <= 1e-13 * np.abs(S).max()
 
@@ -149,7 +149,7 @@ def test_solve_trace_matches_reference(name):
     # cost <= 1e-10 relative, final poses / landmarks <= 1e-9.  One rounding-level absolute term, in units of
     # the PREVIOUS cost: the first step of the Huber pose graphs takes the cost from 1e9 to 1e1, so the cost after it is
     # resolved to eps * 1e9 by either implementation (measured there: 8e-11 .. 4e-10 relative to the new cost = 2e-17 of
-    # the old one; every other entry of every golden <= 1.2e-12, tools/parity_margins.py).
+    # the old one; every other entry of every golden <= 1.2e-12, tests/parity_margins.py).
     big = ref > 1e-9 * ref[0]
     prev = np.concatenate([[ref[0]], ref[:-1]])
     assert np.all(np.abs(hist - ref)[big] <= TOL_COST * np.abs(ref[big]) + 1e-15 * prev[big]), np.abs(hist - ref) / np.abs(ref)

@@ -4,7 +4,7 @@
 #   bench.json                     default bench run (CPU baseline, trajectory, C4 single GPU included)
 #   ktrace_kernel_stats.csv        rocprofv3 --kernel-trace --stats of the C3 bench command
 #   c4_kernel_stats.csv            the same for the C4 problem on one GPU (bench.py --kf 2000 --lm 500000)
-#   pmc_<set>.csv                  one rocprofv3 --pmc pass per counter set (no other trace domains)
+#   pmc_<set>.csv, pmc4_<set>.csv  one rocprofv3 --pmc pass per counter set (no other trace domains), C3 and C4
 #   bench_sharded_1rank.json       the multi-GPU driver (native RCCL) forced on with one rank, C3 and C4
 #   source_sha.txt                 hash of pyslam_amd/csrc/* (bench.py: kernel_source_sha) the passes were taken on
 # tools/summarize_profiles.py <tag> <round> then turns them into profiles/ (run locally).
@@ -28,5 +28,13 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_RE
     i=$((i + 1))
     (cd /tmp && rm -rf /tmp/pmc$i && rocprofv3 --pmc $SET --kernel-trace --output-format csv -d /tmp/pmc$i -o p -- $PMCB > /dev/null 2>&1)
     find /tmp/pmc$i -name '*counter_collection.csv' -exec cp {} "$OUT/pmc_$(echo $SET | tr ' ' '_').csv" \;
+done
+# the same counters at the north star's size (C4: Z = 640 MB no longer fits the 256 MiB Infinity Cache, so FETCH_SIZE is HBM traffic there)
+PMC4="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-c4 --kf 2000 --lm 500000"
+i=0
+for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+    i=$((i + 1))
+    (cd /tmp && rm -rf /tmp/pmc4_$i && rocprofv3 --pmc $SET --kernel-trace --output-format csv -d /tmp/pmc4_$i -o p -- $PMC4 > /dev/null 2>&1)
+    find /tmp/pmc4_$i -name '*counter_collection.csv' -exec cp {} "$OUT/pmc4_$(echo $SET | tr ' ' '_').csv" \;
 done
 ls -la "$OUT"

@@ -10,7 +10,7 @@ dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
 dev.snapshot()
 import sys
 OPT = sys.argv[1] if len(sys.argv) > 1 else 'schur_ablate'
-for ab in ([0, 1, 2, 3] if OPT == 'schur_ablate' else [0, 1]):
+for ab in ([0, 1, 2, 3, 4] if OPT == 'schur_ablate' else [0, 1]):
     dev.set_option(OPT, ab)
     for _ in range(3):
         dev.restore(); dev.linearize(0.0)
