@@ -90,6 +90,8 @@ typedef struct ps_problem_info {
     int64_t ldi_solves;          /* reduced solves preconditioned with the lagged dense inverse (option "lagged_inverse")   */
     int64_t ldi_fallbacks;       /* ... that gave the inverse up after "ldi_cap" iterations and ran the standard solver       */
     int64_t ldi_seeds;           /* inverses seeded on the side stream (after a standard solve)                             */
+    int64_t xcg_fused_solves;    /* explicit two-level PCG solves set up in the one-launch form (option "xcg_fused")       */
+    int64_t xcg_fused_fallbacks; /* ... repeated in the three-launch form after a breakdown of the single-reduction recurrences */
 } ps_problem_info;
 
 enum { PS_NUM_STAGES = 12 };
@@ -235,6 +237,9 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
                               operator of the last standard solve; tried while the last step changed the cost by at most
                               "ldi_cost_tol" [0.05] relative, given up (standard solver + re-seed) after "ldi_cap" [12] iterations.
                               It only preconditions: the solution is the current system's at pcg_tol either way.
+     "xcg_fused"          [1] explicit two-level PCG: ONE launch per iteration (single-reduction recurrences; the restriction, the coarse
+                              product for the nodes a workgroup needs, the prolongation and the SpMV in one kernel, the row's matrix
+                              blocks requested before the scalar phase); a breakdown repeats the solve in the three-launch form
      "band_chol"          [1] explicit two-level PCG: banded factorisation + band substitutions for the coarse inverse when A_c
                               has at most 7 block off-diagonals (chain-like problems); 0: always the dense factorisation
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual

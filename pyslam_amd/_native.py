@@ -42,6 +42,7 @@ class ProblemInfo(C.Structure):
         ('reduced_nnzb', C.c_int64), ('num_pairs', C.c_int64), ('reduce_count', C.c_int64),
         ('device_bytes', C.c_int64), ('cg_restarts', C.c_int64), ('cg_kernel_launches', C.c_int64),
         ('ldi_solves', C.c_int64), ('ldi_fallbacks', C.c_int64), ('ldi_seeds', C.c_int64),
+        ('xcg_fused_solves', C.c_int64), ('xcg_fused_fallbacks', C.c_int64),
     ]
 
 

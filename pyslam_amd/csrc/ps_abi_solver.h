@@ -11,6 +11,7 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
     info->cg_restarts = h->cg_fallbacks;
     info->cg_kernel_launches = h->cg_kernel_launches;
     info->ldi_solves = h->ldi_solves; info->ldi_fallbacks = h->ldi_fallbacks; info->ldi_seeds = h->ldi_seeds;
+    info->xcg_fused_solves = h->xf_solves; info->xcg_fused_fallbacks = h->xf_fallbacks;
     return 0;
 }
 
@@ -211,6 +212,9 @@ int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters,
     if (first) {
         HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
         if (!h->coarse_built && build_coarse(h)) return -1;
+        // (a caller that drives the collectives itself cannot repeat a solve whose single-reduction recurrences broke
+        //  down: it gets the three-launch form; the core's own sharded iteration below handles the fallback)
+        if (!(h->nccl_allreduce && h->nccl_comm) && h->xf_skip == 0) h->xf_skip = 1;
         if (h->cg_explicit) { if (h->D == 6 ? xcg_setup<6>(h, pcg_max_iters, true) : xcg_setup<3>(h, pcg_max_iters, true)) return -1; }
         else if (h->D == 6 ? cg_fused_setup<6>(h, pcg_max_iters, true) : cg_fused_setup<3>(h, pcg_max_iters, true)) return -1;
     }
@@ -290,6 +294,12 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
             if (wait_published(h)) return -1;
             if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
             done = h->h_status[ST_PCG_DONE];
+            if (h->xf_active && done == 2 && !h->h_status[ST_DIAG_FAIL]) {
+                // breakdown of the one-launch form's recurrences (the same on every rank: the solve is replicated): nothing
+                // applied; set the solve up again in the three-launch form
+                ++h->xf_fallbacks; h->xf_skip = 1; first = 1;
+                continue;
+            }
             sb[0] = h->h_shard[0]; sb[1] = h->h_shard[1];
             dxp2 = h->h_scalars[SC_DXP2];
             if (cg_report(h, pcg_iters_out, pcg_relres_out)) return -1;
@@ -495,6 +505,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "xcg_restrict_fused") h->xcg_rt = value != 0;
     else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
     else if (n == "coarse_auto_hold") h->xcg_auto_hold = value != 0;
+    else if (n == "xcg_fused") h->xcg_fused = value != 0;
     else if (n == "lagged_inverse") { h->ldi_enable = value != 0; if (!h->ldi_enable) { h->ldi_cur = -1; if (h->ldi_state != 1) h->ldi_state = 0; } }
     else if (n == "ldi_max_unknowns") { if (value < 0 || value > PS_LDI_MAXN) return fail("ldi_max_unknowns out of range (0 .. 2048)"); h->ldi_max_n = (int)value; }
     else if (n == "ldi_cap") { if (value < 1 || value > 64) return fail("ldi_cap out of range (1 .. 64)"); h->ldi_cap = (int)value; }

@@ -217,6 +217,16 @@ struct ps_problem {
     int xcg_rt_rows = PS_XCG_ROWS_RT;
     int32_t *xcg_wg_out = nullptr, *xcg_nptr = nullptr;
     double *tq_part = nullptr, *tvec2 = nullptr;
+    // ... one-launch form (k_xcg_fused1)
+    int xcg_fused = 1;              // option "xcg_fused"
+    bool xf_ok = false, xf_active = false;
+    int xf_skip = 0;                // upcoming set-ups that must not use the one-launch form (a fallback after its breakdown)
+    int32_t *xf_cptr = nullptr, *xf_cols = nullptr, *xf_nlo = nullptr, *xf_nhi = nullptr, *xf_rec = nullptr;
+    uint16_t* xf_lidx = nullptr;
+    double *xf_tq[2] = {}, *xf_ts[2] = {}, *xf_t[2] = {};
+    int xf_rmax = 1, xf_nwg = 0, xf_pf = 2;
+    size_t xf_nrec = 0;
+    long xf_solves = 0, xf_fallbacks = 0;
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     int prof_every = 1;             // profiling level 1: time the Schur kernel of every n-th linearisation only
     long prof_tick = 0;
@@ -305,7 +315,7 @@ struct ps_problem {
     char *arena_dev = nullptr, *arena_host = nullptr;
     void* words_host = nullptr;
     size_t arena_used = 0;
-    bool arena_open = false;
+    bool arena_open = false, arena_poisoned = false;
 
     template <typename T>
     int alloc(T** out, size_t n) {
@@ -355,12 +365,17 @@ struct ps_problem {
         arena_dev = (char*)d;
         if (!pool.take(pool.host_arenas, &m)) HIP_OK(hipHostMalloc(&m, PS_ARENA_BYTES, hipHostMallocDefault));
         arena_host = (char*)m;
+        // PS_ARENA_POISON=1 (debugging): the gaps between tables read as NaN, so a kernel that reads past the end of one shows
+        static const bool poison = getenv("PS_ARENA_POISON") != nullptr;
+        if (poison) std::memset(arena_host, 0xFF, PS_ARENA_BYTES);
+        arena_poisoned = poison;
         arena_used = 0;
         arena_open = true;
         return 0;
     }
     int arena_close() {        // one copy of everything staged; the caller synchronises the stream afterwards
         arena_open = false;
+        if (arena_poisoned) arena_used = PS_ARENA_BYTES;       // (the poisoned tail travels too)
         if (arena_used) HIP_OK(hipMemcpyAsync(arena_dev, arena_host, arena_used, hipMemcpyHostToDevice, stream));
         return 0;
     }

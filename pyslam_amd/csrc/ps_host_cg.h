@@ -394,6 +394,62 @@ int build_coarse(ps_problem* h) {
             h->xcg_rt_ok = true;
         }
     }
+    // one-launch form (k_xcg_fused1): per workgroup of 8 rows the distinct columns of its blocks (+ the LDS slot of every
+    // block's column), the contiguous range of coarse nodes those columns hang on, and its records of P^T w at a fixed
+    // stride per node (so that their addresses need no pointer load)
+    h->xf_ok = false;
+    // (fp32 rows of an odd-sized inverse are not 8-byte aligned: SE(2) graphs with an odd node count measured no gain)
+    if (h->cg_explicit && h->nc <= PS_XF_NEMAX * 64 * PS_XF_ROWS && nr >= 2 * PS_XF_ROWS && (h->nc & 1) == 0) {
+        const int R = PS_XF_ROWS, nwg = cdiv(nr, R);
+        std::vector<int32_t> cptr(nwg + 1, 0), cols, nlo(nwg), nhi(nwg), rec((size_t)nwg * PS_XCG_NSLOT, -1), cnt(ncb, 0);
+        std::vector<uint16_t> lidx((size_t)h->nnzb_aug, 0);
+        std::vector<int32_t> mark(nr, -1);
+        bool ok = true;
+        int rmax = 1;
+        for (int g = 0; g < nwg && ok; ++g) {
+            const int first = g * R, last = std::min(nr, first + R) - 1;
+            const size_t base = cols.size();
+            for (int i = first; i <= last; ++i)
+                for (int b = rp[i]; b < rp[i + 1]; ++b) if (mark[ci[b]] != g) { mark[ci[b]] = g; cols.push_back(ci[b]); }
+            std::sort(cols.begin() + base, cols.end());
+            const int n = (int)(cols.size() - base);
+            if (n > PS_XF_CAP || n == 0) { ok = false; break; }
+            cptr[g + 1] = (int32_t)cols.size();
+            int lo = ncb, hi = 0;
+            for (int c = 0; c < n; ++c) { const int j = cols[base + c]; lo = std::min(lo, pnode[j]); hi = std::max(hi, std::min(ncb - 1, pnode[j] + 1)); }
+            if (hi - lo + 1 > PS_XF_NODES) { ok = false; break; }
+            nlo[g] = lo; nhi[g] = hi;
+            for (int i = first; i <= last; ++i) {
+                const int a0 = arp[i];
+                for (int b = rp[i]; b < rp[i + 1]; ++b)
+                    lidx[slot[b]] = (uint16_t)(std::lower_bound(cols.begin() + base, cols.end(), ci[b]) - (cols.begin() + base));
+                (void)a0;                                   // (padding blocks of an ELL row keep slot 0: their values are zero)
+            }
+            const int span = pnode[last] + 1 - pnode[first];
+            if (span >= PS_XCG_NSLOT) { ok = false; break; }
+            for (int s2 = 0; s2 <= span; ++s2) { const int q = pnode[first] + s2; if (q < ncb) rec[(size_t)g * PS_XCG_NSLOT + s2] = cnt[q]++; }
+        }
+        if (ok) {
+            for (int q = 0; q < ncb; ++q) rmax = std::max(rmax, cnt[q]);
+            for (int g = 0; g < nwg; ++g) {
+                const int first = g * R;
+                for (int s2 = 0; s2 < PS_XCG_NSLOT; ++s2) {
+                    int32_t& o = rec[(size_t)g * PS_XCG_NSLOT + s2];
+                    if (o >= 0) o = (pnode[first] + s2) * rmax + o;
+                }
+            }
+            const size_t nrec = (size_t)ncb * rmax * D;
+            if (h->upload(&h->xf_cptr, cptr) || h->upload(&h->xf_cols, cols) || h->upload(&h->xf_lidx, lidx) ||
+                h->upload(&h->xf_nlo, nlo) || h->upload(&h->xf_nhi, nhi) || h->upload(&h->xf_rec, rec) ||
+                h->alloc(&h->xf_tq[0], nrec) || h->alloc(&h->xf_tq[1], nrec) || h->alloc(&h->xf_ts[0], (size_t)h->nc) ||
+                h->alloc(&h->xf_ts[1], (size_t)h->nc) || h->alloc(&h->xf_t[0], (size_t)h->nc) || h->alloc(&h->xf_t[1], (size_t)h->nc)) return -1;
+            HIP_OK(hipMemsetAsync(h->xf_tq[0], 0, nrec * sizeof(double), h->stream));
+            HIP_OK(hipMemsetAsync(h->xf_tq[1], 0, nrec * sizeof(double), h->stream));
+            h->xf_rmax = rmax; h->xf_nwg = nwg; h->xf_nrec = nrec;
+            h->xf_pf = maxlen <= 16 ? 2 : (maxlen <= 48 ? 6 : 8);
+            h->xf_ok = true;
+        }
+    }
     lap("allocations");
     if (!h->lag_status) {
         if (h->alloc(&h->lag_status, ST_NWORDS)) return -1;

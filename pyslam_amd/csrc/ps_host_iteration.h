@@ -18,6 +18,9 @@ void xcg_assemble_ac(ps_problem* h, hipStream_t st) {
 }
 
 template <int D>
+void xcg_launch(ps_problem* h, double tol, int count);
+
+template <int D>
 int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     const int nr = h->nr, ncb = h->ncb, nc = h->nc;
     if (max_iters + 2 > h->hist_cap) return fail("pcg max_iters exceeds the history buffer (4096)");
@@ -64,6 +67,22 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     }
     HIP_OK(hipMemsetAsync(h->xstate, 0, 8 * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->xp2, 0, (size_t)nr * D * sizeof(double), h->stream));
+    h->xf_active = h->xcg_fused && h->xf_ok && h->xf_skip == 0;
+    if (h->xf_skip > 0) --h->xf_skip;
+    if (h->xf_active) {
+        // one-launch form: t_0 = P^T r_0 (k_xcg_restrict, initialisation mode) into buffer 0, then launch -1 of the fused
+        // kernel (alpha = beta = 0): u_0 = M^-1 r_0, w_0 = S^ u_0, the partials of gamma_0 / delta_0 and the records of P^T w_0
+        HIP_OK(hipMemsetAsync(h->xf_ts[0], 0, (size_t)nc * sizeof(double), h->stream));
+        HIP_OK(hipMemsetAsync(h->xf_tq[0], 0, h->xf_nrec * sizeof(double), h->stream));
+        hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode, h->pw0,
+                           h->pw1, h->Bmat, h->cg_r[0], h->cg_r[0], h->cg_w[0], h->cg_p, h->cg_xh, h->cg_gd[1], 0, h->xstate, -1,
+                           h->xf_t[0], h->status);
+        if (lagst) hipLaunchKernelGGL(k_lag_status_check, dim3(1), dim3(64), 0, h->stream, lagst, h->status);
+        h->cg_launched = -1;
+        xcg_launch<D>(h, 0.0, 1);                          // launch -1 (cg_launched: -1 -> 0)
+        ++h->xf_solves;
+        return 0;
+    }
     // z_0 = M^-1 r_0 and r_0 . z_0
     hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode, h->pw0,
                        h->pw1, h->Bmat, h->cg_r[0], h->cg_r[0], h->cg_w[0], h->cg_p, h->cg_xh, h->cg_gd[1], 0, h->xstate, -1,
@@ -97,6 +116,29 @@ void xcg_launch(ps_problem* h, double tol, int count) {
     const int nr = h->nr, ncb = h->ncb, nc = h->nc;
     const int n_rz = cdiv(nr, PS_XCG_DROWS);
     double* pbuf[2] = {h->cg_p, h->xp2};
+    if (h->xf_active) {                                     // ONE launch per iteration (launch index n = k + 1 picks the buffers)
+        h->cg_kernel_launches += count;
+        const size_t lds = (size_t)nc * sizeof(double);
+        for (int i = 0; i < count; ++i, ++h->cg_launched) {
+            const int k = h->cg_launched, in = (k + 1) & 1, out = in ^ 1;
+            XcgFusedArgs a{};
+            a.cptr = h->xf_cptr; a.cols = h->xf_cols; a.lidx = h->xf_lidx; a.nlo = h->xf_nlo; a.nhi = h->xf_nhi;
+            a.Ainv = (const float*)h->LciT2[h->lci_cur]; a.nc = nc; a.ncb = ncb;
+            a.pnode = h->pnode; a.pw0 = h->pw0; a.pw1 = h->pw1; a.Bmat = h->Bmat;
+            a.rec_out = h->xf_rec; a.rmax = h->xf_rmax;
+            a.tq_in = h->xf_tq[in]; a.tq_out = h->xf_tq[out];
+            a.t_in = h->xf_t[in]; a.t_out = h->xf_t[out]; a.ts_in = h->xf_ts[in]; a.ts_out = h->xf_ts[out];
+            a.gd_in = h->cg_gd[in]; a.gd_out = h->cg_gd[out]; a.nwg = h->xf_nwg;
+            a.r_in = h->cg_r[in]; a.r_out = h->cg_r[out]; a.w_in = h->cg_w[in]; a.w_out = h->cg_w[out];
+            a.s_in = h->cg_s[in]; a.s_out = h->cg_s[out];
+            a.u = h->xp2; a.p = h->cg_p; a.x = h->cg_xh;
+#define PS_XF_LAUNCH(PF) hipLaunchKernelGGL((k_xcg_fused1<D, PF>), dim3(h->xf_nwg), dim3(64 * PS_XF_ROWS), lds, h->stream, nr, h->arow_ptr, \
+                               h->ell_wf, h->Saug, a, k, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate)
+            if (h->xf_pf == 2) PS_XF_LAUNCH(2); else if (h->xf_pf == 6) PS_XF_LAUNCH(6); else PS_XF_LAUNCH(8);
+#undef PS_XF_LAUNCH
+        }
+        return;
+    }
     if (h->xcg_rt && h->xcg_rt_ok) {                        // three launches per iteration
         const int R = h->xcg_rt_rows, n_pq = cdiv(nr, R);
         h->cg_kernel_launches += 3L * count;
@@ -150,6 +192,12 @@ int xcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* re
         xcg_launch<D>(h, tol, m);
         if (xcg_side_enqueue<D>(h)) return -1;
         if (read_scalars(h)) return -1;
+        if (h->xf_active && h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL] && !h->h_status[ST_LM_FAIL]) {
+            ++h->xf_fallbacks; h->xf_skip = 1;              // breakdown of the one-launch form: again, three launches per iteration
+            if (xcg_setup<D>(h, max_iters, false)) return -1;
+            chunk = std::max(32, h->last_pcg_iters + 2);
+            continue;
+        }
         done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 1;
         chunk = std::max(32, h->cg_launched / 4);
     }
@@ -233,6 +281,16 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
             if (gn_tail(h, linesearch, h->status, true)) return -1;
             if (total) total->stop();
             if (wait_published(h)) return -1;
+            if (h->xf_active && !h->h_status[ST_DIAG_FAIL] && !h->h_status[ST_LM_FAIL] &&
+                (h->h_status[ST_PCG_DONE] == 2 || (h->h_status[ST_PCG_DONE] == 0 && h->last_pcg_iters > 0 && h->cg_launched > 2 * h->last_pcg_iters + 16))) {
+                // the single-reduction recurrences of the one-launch form broke down (or stalled: far more iterations than
+                // the last solve needed) -- nothing has been applied: the same solve again with the three-launch form
+                ++h->xf_fallbacks;
+                h->xf_skip = 1;
+                if (xcg_setup<D>(h, max_iters, false)) return -1;
+                count = h->last_pcg_iters > 0 ? h->last_pcg_iters + 2 : 32;
+                continue;
+            }
             if (h->h_status[ST_PCG_DONE] != 0) break;
             if (h->cg_launched >= max_iters + 1) {          // not converged within max_iters: take the step anyway
                 hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)h->nr * D, 256)), dim3(256), 0, h->stream, h->nr, h->Linv,

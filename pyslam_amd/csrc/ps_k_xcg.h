@@ -522,3 +522,310 @@ __global__ __launch_bounds__(256) void k_cg_unscale(int nr, const double* __rest
     for (int a = 0; a < D; ++a) v += Linv[(size_t)i * D * D + a * D + c] * xh[(size_t)i * D + a];
     x[t] = v;
 }
+
+// ---------------------------------------------------------------------------
+// ONE launch per iteration (round 3; option "xcg_fused"): the same two-level PCG in the single-reduction
+// (Chronopoulos-Gear) arrangement, so that everything between two global reductions fits one kernel:
+//     u = M^-1 r,  w = S^ u,  gamma = r.u,  delta = w.u            (this launch, for the NEXT iteration)
+//     beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old)     (from the previous launch's partials)
+//     p = u + beta p,  s = w + beta s,  x += alpha p,  r -= alpha s
+// Launch k (8 rows of S^ per workgroup, one wave per row):
+//   0. totals of the gamma / delta partials of launch k-1 -> alpha_k, beta_k, convergence test on gamma_k = r_k . M^-1 r_k;
+//   1. t_{k+1} = P^T r_{k+1} by recurrence, ALL of it in every workgroup's LDS: ts_k = P^T w_k + beta ts_{k-1} (P^T w_k from the
+//      records of launch k-1's epilogue), t_{k+1} = t_k - alpha ts_k -- as in the three-launch form, one level deeper;
+//   2. y = A_c^-1 t_{k+1} for the coarse nodes this workgroup's columns hang on (a contiguous range; fp32 rows from L2);
+//   3. for every DISTINCT column j of the workgroup's rows (host list; a band: 88 at C4): s_j = w_j + beta s_j,
+//      r_j = r_j - alpha s_j, u_j = r_j + P_j y into LDS -- once per workgroup, not once per row; the owner of row j
+//      also stores r, s, u and updates p, x;
+//   4. w_i = sum_j S^_ij u_j from LDS (block index -> LDS slot through a uint16 column), partials of r.u and w.u, and
+//      this workgroup's records of P^T w.
+// r, w, s are double-buffered by launch parity (neighbours read the old ones while owners write the new), so are t, ts,
+// the records and the partials.  Launch -1 is the initialisation (alpha = beta = 0: u_0, w_0, gamma_0, delta_0).
+// The recurrences can break down (delta - beta gamma / alpha <= 0) where the classic ones cannot: status 2, and the host
+// repeats the solve with the three-launch form.
+// 24.4 us in three launches -> one launch per iteration at C4.
+// ---------------------------------------------------------------------------
+// a failed side-stream factorisation of the lagged coarse matrix reaches the solver's status words (k_xcg_coarse does this in
+// the other forms)
+__global__ void k_lag_status_check(const int32_t* __restrict__ lag_status, int32_t* __restrict__ status)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && lag_status[ST_DIAG_FAIL]) atomicAdd(&status[ST_DIAG_FAIL], 1);
+}
+
+#define PS_XF_ROWS 8
+#define PS_XF_CAP 170                         // distinct columns one workgroup may touch
+#define PS_XF_NODES 16                        // coarse nodes (contiguous) one workgroup may need y for
+#define PS_XF_NEMAX 4                         // coarse entries per thread: nc <= 4 * 512
+#define PS_XF_RB 4                            // records of a node requested together
+
+struct XcgFusedArgs {
+    const int32_t* cptr; const int32_t* cols;   // per workgroup: its distinct columns (ascending)
+    const uint16_t* lidx;                       // per matrix block: slot of its column in the workgroup's list
+    const int32_t* nlo; const int32_t* nhi;     // per workgroup: first / last coarse node needed
+    const float* Ainv; int nc, ncb;
+    const int32_t* pnode; const double* pw0; const double* pw1; const double* Bmat;
+    const int32_t* rec_out; int rmax;           // records of P^T w: node q owns slots [q rmax, (q + 1) rmax) (unused ones stay 0); per (workgroup, node slot) its record
+    const double* tq_in; double* tq_out;
+    const double* t_in; double* t_out; const double* ts_in; double* ts_out;
+    const double* gd_in; double* gd_out; int nwg;
+    const double* r_in; double* r_out; const double* w_in; double* w_out; const double* s_in; double* s_out;
+    double* u; double* p; double* x;
+};
+
+// PF: blocks per lane of the row's matrix blocks requested at kernel start (8 PF blocks per row): the matrix stream is in
+// flight during the scalar / coarse phases instead of behind them (two waves per SIMD: 256 VGPRs to spend)
+template <int D, int PF>
+__global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
+    int nr, const int32_t* __restrict__ row_ptr, int wf, const double* __restrict__ S, XcgFusedArgs a, int k, double tol2,
+    double* __restrict__ hist, int cap, int32_t* __restrict__ status, double* __restrict__ scalars, double* __restrict__ xstate)
+{
+    constexpr int NT = 64 * PS_XF_ROWS, DD = D * D;
+    constexpr int NCOL = (PS_XF_CAP * D + NT - 1) / NT;          // (column, component) items per thread
+    extern __shared__ __attribute__((aligned(16))) double tl[];   // nc: t_{k+1}
+    __shared__ double su[PS_XF_CAP * D];                          // u_{k+1} of the workgroup's columns
+    __shared__ double sr[PS_XF_ROWS * D], suo[PS_XF_ROWS * D];    // r_{k+1}, u_{k+1} of its own rows
+    __shared__ double yl[PS_XF_NODES * D];
+    __shared__ double ysum[PS_XF_NODES * D * ((PS_XF_NEMAX * 64 * PS_XF_ROWS + 63) / 64)];   // segment sums of phase 2
+    __shared__ double lds[32];
+    __shared__ double wred[PS_XF_ROWS][2];
+    __shared__ double cw[PS_XF_ROWS][PS_XCG_NSLOT][D];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, wg = blockIdx.x;
+    const int nc = a.nc;
+    // ---- 0. everything that does not depend on the scalars is requested first
+    const int done = status[ST_PCG_DONE];
+    const double g_prev = hist[k > 0 ? k - 1 : 0], a_prev = hist[cap + (k > 0 ? k - 1 : 0)], thresh_in = xstate[1];
+    const int row0 = wg * PS_XF_ROWS, row = row0 + wv;
+    const int kk = lane >> 3, r = lane & 7;
+    // the row's matrix blocks (row r of block rbeg + kk + 8 i) and their LDS slots
+    const int rbeg = row < nr ? (wf > 0 ? row * wf : row_ptr[row]) : 0;
+    const int rend = row < nr ? (wf > 0 ? rbeg + wf : row_ptr[row + 1]) : 0;
+    double gs = 0.0, ds = 0.0;
+    if (k >= 0) for (int i = tid; i < a.nwg; i += NT) { gs += a.gd_in[i]; ds += a.gd_in[a.nwg + i]; }
+    const int c0 = a.cptr[wg], ncols = a.cptr[wg + 1] - c0;
+    const int n_lo = a.nlo[wg], nrows_y = (a.nhi[wg] - n_lo + 1) * D;
+    double rj[NCOL], wj[NCOL], sj[NCOL], Bj[NCOL][D], cw0[NCOL], cw1[NCOL];
+    int jj[NCOL], nj[NCOL];
+#pragma unroll
+    for (int q = 0; q < NCOL; ++q) {
+        const int e = tid + q * NT, c = e / D, m = e - c * D;
+        jj[q] = -1; nj[q] = 0; rj[q] = wj[q] = sj[q] = cw0[q] = cw1[q] = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < D; ++mm) Bj[q][mm] = 0.0;
+        if (c < ncols) {
+            const int j = a.cols[c0 + c];
+            jj[q] = j;
+            const size_t o = (size_t)j * D + m;
+            rj[q] = a.r_in[o]; wj[q] = a.w_in[o]; sj[q] = a.s_in[o];
+            nj[q] = a.pnode[j]; cw0[q] = a.pw0[j]; cw1[q] = a.pw1[j];
+            const double* B = a.Bmat + (size_t)j * DD + m * D;
+#pragma unroll
+            for (int mm = 0; mm < D; ++mm) Bj[q][mm] = B[mm];
+        }
+    }
+    // the own rows' u, p, x (one (row, component) per thread of the first PS_XF_ROWS * D)
+    double uo = 0.0, po = 0.0, xo = 0.0;
+    const bool own_item = tid < PS_XF_ROWS * D && row0 + tid / D < nr;
+    if (own_item) { const size_t o = (size_t)row0 * D + tid; uo = a.u[o]; po = a.p[o]; xo = a.x[o]; }
+    // t_k, ts_{k-1} and the first batch of the records of P^T w_k, for this thread's coarse entries
+    double to[PS_XF_NEMAX], tso[PS_XF_NEMAX], sq[PS_XF_NEMAX];
+#pragma unroll
+    for (int u = 0; u < PS_XF_NEMAX; ++u) {
+        const int e = tid + u * NT;
+        to[u] = tso[u] = sq[u] = 0.0;
+        if (e < nc) {
+            const int n = e / D, m = e - n * D;
+            to[u] = a.t_in[e]; tso[u] = a.ts_in[e];
+            double rec[PS_XF_RB];
+#pragma unroll
+            for (int c = 0; c < PS_XF_RB; ++c) rec[c] = (c < a.rmax) ? a.tq_in[((size_t)n * a.rmax + c) * D + m] : 0.0;
+#pragma unroll
+            for (int c = 0; c < PS_XF_RB; ++c) sq[u] += rec[c];
+        }
+    }
+    for (int base = PS_XF_RB; base < a.rmax; base += PS_XF_RB) {   // (more than PS_XF_RB records per node: pose graphs)
+#pragma unroll
+        for (int u = 0; u < PS_XF_NEMAX; ++u) {
+            const int e = tid + u * NT;
+            if (e < nc) {
+                const int n = e / D, m = e - n * D;
+                double rec[PS_XF_RB];
+#pragma unroll
+                for (int c = 0; c < PS_XF_RB; ++c) rec[c] = (base + c < a.rmax) ? a.tq_in[((size_t)n * a.rmax + base + c) * D + m] : 0.0;
+#pragma unroll
+                for (int c = 0; c < PS_XF_RB; ++c) sq[u] += rec[c];
+            }
+        }
+    }
+    // (requested LAST: vmcnt retires in order, so everything above can be consumed while this stream is still in flight)
+    double sb[PF > 0 ? PF : 1][D];
+    int sl[PF > 0 ? PF : 1];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int b = rbeg + kk + 8 * i;
+        sl[i] = 0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) sb[i][c] = 0.0;
+        if (r < D && b < rend) {
+            sl[i] = (int)a.lidx[b] * D;
+            const double* sp = S + (size_t)b * DD + r * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c) sb[i][c] = sp[c];
+        }
+    }
+    block_sum2(gs, ds, lds);
+    if (done) return;
+    double alpha = 0.0, beta = 0.0;
+    if (k >= 0) {
+        const double gamma = gs, delta = ds;
+        const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
+        const bool first = wg == 0 && tid == 0;
+        if (!(gamma > thresh)) {
+            if (first) { status[ST_PCG_DONE] = (gamma != gamma) ? 2 : 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
+            return;
+        }
+        beta = (k == 0) ? 0.0 : gamma / g_prev;
+        const double denom = (k == 0) ? delta : delta - beta * gamma / a_prev;
+        if (!(denom > 0.0)) { if (first) { status[ST_PCG_DONE] = 2; scalars[SC_RRFINAL] = gamma; } return; }
+        alpha = gamma / denom;
+        if (first) {
+            hist[k] = gamma; hist[cap + k] = alpha; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = gamma;
+            if (k == 0) { xstate[1] = thresh; xstate[2] = gamma; scalars[SC_RR0] = gamma; }
+        }
+    }
+    // ---- 1. t_{k+1} (all of it) into LDS
+#pragma unroll
+    for (int u = 0; u < PS_XF_NEMAX; ++u) {
+        const int e = tid + u * NT;
+        if (e < nc) {
+            const double ts = sq[u] + beta * tso[u];
+            const double tn = to[u] - alpha * ts;
+            tl[e] = tn;
+            if (wg == 0) { a.t_out[e] = tn; a.ts_out[e] = ts; }
+        }
+    }
+    __syncthreads();
+    // ---- 2. y = A_c^-1 t_{k+1} for the nodes n_lo .. n_hi: the rows are cut into segments of 64 entries, one per thread (all
+    // of a thread's loads independent: ONE round trip for the phase), segment sums added up in LDS in a fixed order
+    {
+        const int nseg = (nc + 63) >> 6, nitems = nrows_y * nseg;
+        for (int it0 = 0; it0 < nitems; it0 += NT) {
+            const int it = it0 + tid;
+            double v = 0.0;
+            if (it < nitems) {
+                const int rr = it / nseg, sg = it - rr * nseg, j0 = sg << 6, j1 = min(nc, j0 + 64);
+                const float* ar = a.Ainv + (size_t)(n_lo * D + rr) * nc;
+                if ((nc & 1) == 0 && j1 - j0 == 64) {            // (rows of an even nc start 8-byte aligned)
+#pragma unroll 8
+                    for (int q = 0; q < 32; ++q) {
+                        const float2 f = *reinterpret_cast<const float2*>(ar + j0 + 2 * q);
+                        v += (double)f.x * tl[j0 + 2 * q] + (double)f.y * tl[j0 + 2 * q + 1];
+                    }
+                } else if ((nc & 1) == 0) {
+                    for (int j = j0; j < j1; j += 2) {
+                        const float2 f = *reinterpret_cast<const float2*>(ar + j);
+                        v += (double)f.x * tl[j] + (double)f.y * tl[j + 1];
+                    }
+                } else {
+                    for (int j = j0; j < j1; ++j) v += (double)ar[j] * tl[j];
+                }
+            }
+            if (it < nitems) ysum[it] = v;
+        }
+        __syncthreads();
+        if (tid < nrows_y) {
+            double v = 0.0;
+            for (int sg = 0; sg < nseg; ++sg) v += ysum[tid * nseg + sg];
+            yl[tid] = v;
+        }
+    }
+    __syncthreads();
+    // ---- 3. the workgroup's columns: s, r, u (+ the owner's stores and p, x)
+#pragma unroll
+    for (int q = 0; q < NCOL; ++q) {
+        const int j = jj[q];
+        if (j >= 0) {
+            const int e = tid + q * NT, c = e / D, m = e - c * D;
+            const double sn = wj[q] + beta * sj[q];
+            const double rn = rj[q] - alpha * sn;
+            const int n0 = nj[q] - n_lo;
+            const bool two = nj[q] + 1 < a.ncb;
+            double un = rn;
+#pragma unroll
+            for (int mm = 0; mm < D; ++mm) {
+                const double yy = cw0[q] * yl[n0 * D + mm] + (two ? cw1[q] * yl[(n0 + 1) * D + mm] : 0.0);
+                un += Bj[q][mm] * yy;
+            }
+            su[c * D + m] = un;
+            if (j >= row0 && j < row0 + PS_XF_ROWS) {
+                const size_t o = (size_t)j * D + m;
+                a.r_out[o] = rn; a.s_out[o] = sn; a.u[o] = un;
+                sr[(j - row0) * D + m] = rn; suo[(j - row0) * D + m] = un;
+            }
+        }
+    }
+    if (own_item) {                                          // p_k = u_k + beta p_{k-1}, x_{k+1} = x_k + alpha p_k (u_k: what this launch found in a.u)
+        const size_t o = (size_t)row0 * D + tid;
+        const double pn = uo + beta * po;
+        a.p[o] = pn; a.x[o] = xo + alpha * pn;
+    }
+    __syncthreads();
+    // ---- 4. w_{k+1} = S^ u_{k+1} for the own rows, partials, records of P^T w
+    double bl = 0.0, rw0 = 0.0, rw1 = 0.0;
+    int prow = 0, pfirst = 0, rout = -1;
+    if (tid < PS_XCG_NSLOT * D) rout = a.rec_out[wg * PS_XCG_NSLOT + tid / D];
+    if (lane < PS_XCG_NSLOT * D) (&cw[wv][0][0])[lane] = 0.0;
+    double g2 = 0.0, d2 = 0.0;
+    if (row < nr) {
+        if (r < D && kk < D) bl = a.Bmat[(size_t)row * DD + r * D + kk];
+        const int urow = __builtin_amdgcn_readfirstlane(row);
+        prow = a.pnode[urow]; pfirst = a.pnode[row0]; rw0 = a.pw0[urow]; rw1 = a.pw1[urow];
+        double acc = 0.0;
+        if (r < D) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const double* uc = su + sl[i];
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc += sb[i][c] * uc[c];
+            }
+            for (int b = rbeg + kk + 8 * PF; b < rend; b += 8) {
+                const double* uc = su + (int)a.lidx[b] * D;
+                const double* sp = S + (size_t)b * DD + r * D;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc += sp[c] * uc[c];
+            }
+        }
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        double ru = 0.0, wu = 0.0;
+        if (lane < D) {
+            a.w_out[(size_t)row * D + lane] = acc;
+            const double un = suo[wv * D + lane];
+            ru = sr[wv * D + lane] * un; wu = acc * un;
+        }
+        g2 = wave_sum(ru); d2 = wave_sum(wu);
+        double v = bl * acc;                                  // records: c = B_i^T w_i, weighted into the row's two nodes
+        v = dpp_shift_add<0x111, 0xf, 0xf>(v);
+        v = dpp_shift_add<0x112, 0xf, 0xf>(v);
+        v = dpp_shift_add<0x114, 0xf, 0xa>(v);
+        const int rslot = prow - pfirst;
+        if (r == 7 && kk < D) {
+            cw[wv][rslot][kk] = rw0 * v;
+            if (rslot + 1 < PS_XCG_NSLOT) cw[wv][rslot + 1][kk] = rw1 * v;
+        }
+    }
+    if (lane == 0) { wred[wv][0] = g2; wred[wv][1] = d2; }
+    __syncthreads();
+    if (tid == 0) {
+        double g = 0.0, d = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < PS_XF_ROWS; ++ww) { g += wred[ww][0]; d += wred[ww][1]; }
+        a.gd_out[wg] = g; a.gd_out[a.nwg + wg] = d;
+    }
+    if (tid < PS_XCG_NSLOT * D && rout >= 0) {
+        double v = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < PS_XF_ROWS; ++ww) v += (&cw[ww][0][0])[tid];
+        a.tq_out[(size_t)rout * D + tid % D] = v;
+    }
+}

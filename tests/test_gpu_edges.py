@@ -501,6 +501,7 @@ def test_explicit_pcg_three_launch_form_equals_the_four_launch_form(shape):
         if shape == 'ba':
             dev.set_option('coarse_groups', 10)        # (the automatic 48 intervals of 3 rows are too short for the fused form)
         dev.set_option('xcg_restrict_fused', fused)
+        dev.set_option('xcg_fused', 0)                 # (the one-launch form has its own test: tests/test_gpu_ldi.py)
         n0 = dev.cg_kernel_launches()
         res = [dev.gn_iteration(0., 1e-12, 3000, True) for _ in range(3)]
         # launches per CG iteration of the LAST call (count = iterations of the previous call + 2 when it sufficed)

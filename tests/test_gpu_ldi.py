@@ -170,3 +170,59 @@ def test_option_off_and_rebuilt_coarse_level():
         dev.restore(); dev.gn_iteration(0., 1e-12, 500, True)
         assert np.linalg.norm(device_dx(dev, lp) - device_dx(ref, lp)) <= 1e-9 * np.linalg.norm(device_dx(ref, lp))
     assert info(dev)[0] > s0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one-launch explicit two-level PCG (option "xcg_fused", csrc/ps_k_xcg.h: k_xcg_fused1)
+# ---------------------------------------------------------------------------------------------------------------------
+def xf_info(dev):
+    from pyslam_amd import _native as nat
+    i = nat.ProblemInfo()
+    nat.check(dev._lib.ps_get_info(dev._h, C.byref(i)))
+    return i.xcg_fused_solves, i.xcg_fused_fallbacks
+
+
+@pytest.mark.parametrize('kind', ['pose_graph', 'ba'])
+def test_one_launch_explicit_pcg_matches_the_three_launch_form(kind):
+    """The single-reduction (Chronopoulos-Gear) arrangement of the explicit two-level PCG in ONE launch per iteration against
+    the three-launch form: same preconditioner, same iteration counts (+-1), the same Gauss-Newton trajectory (cost 1e-10,
+    parameters 1e-9), and the first step against the oracle's direct solve."""
+    from pyslam_amd import synthetic, losses
+    from pyslam_amd.device import DeviceProblem
+    if kind == 'pose_graph':
+        lp, _ = synthetic.pose_graph(num_poses=600, num_loops=2401, dof=6, seed=2, loss=losses.HuberLoss(1.0))
+    else:
+        lp, _ = synthetic.stereo_ba(num_kf=700, num_lm=30000, obs_per_lm=6, half_window=8, seed=12)
+    a, b = DeviceProblem(lp), DeviceProblem(lp)
+    b.set_option('xcg_fused', 0)
+    dx_ref, _ = orc.gauss_newton_step(lp, points_first=False)
+    for it in range(5):
+        ra = a.gn_iteration(0., 1e-13, 3000, True)
+        rb = b.gn_iteration(0., 1e-13, 3000, True)
+        if it == 0:
+            for d in (a, b):
+                assert np.linalg.norm(device_dx(d, lp) - dx_ref) <= 1e-8 * np.linalg.norm(dx_ref)
+        assert abs(ra[0] - rb[0]) <= 1e-10 * abs(rb[0])
+        assert abs(ra[2] - rb[2]) <= 2 and ra[3] <= 1e-12
+    used, fell = xf_info(a)
+    assert used >= 5 and fell == 0 and xf_info(b) == (0, 0)
+    pa, pb = a.get_params(), b.get_params()
+    assert np.abs(pa[0] - pb[0]).max() < 1e-9
+    if pa[1].size:
+        assert np.abs(pa[1] - pb[1]).max() < 1e-9
+
+
+def test_one_launch_explicit_pcg_through_the_staged_api_and_covariance():
+    """ps_solve_reduced (synchronous driver) and a covariance column (unit right-hand side) through the one-launch form."""
+    from pyslam_amd import synthetic, losses
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.pose_graph(num_poses=600, num_loops=2401, dof=6, seed=5, loss=losses.HuberLoss(1.0))
+    a, b = DeviceProblem(lp), DeviceProblem(lp)
+    b.set_option('xcg_fused', 0)
+    for d in (a, b):
+        d.linearize(0.)
+        d.solve_reduced(1e-13, 3000)
+        d.backsub()
+    xa, xb = a.get_dx()[0], b.get_dx()[0]
+    assert np.linalg.norm(xa - xb) <= 1e-9 * np.linalg.norm(xb)
+    assert xf_info(a)[0] >= 1
