@@ -697,6 +697,15 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     if (h->zero(h->arrivals, 2 * sizeof(int32_t))) return -1;
     if (h->arena_close()) return -1;
     HIP_OK(hipStreamSynchronize(h->stream));
+    // The structures of the two-level preconditioner (node lists, augmented pattern, per-workgroup column lists: host work
+    // of a few milliseconds at C2 / C4) used to be built by the first solve, i.e. inside the first Gauss-Newton iteration
+    // (C2: 9-10 ms against 3 ms for the later ones).  They depend on nothing but the block pattern: built here.  An option
+    // that changes them (coarse_groups, cg_explicit, ...) rebuilds them on the next solve as before.
+    if (nr >= 16 && nr * D > h->direct_max && h->pcg_variant == 1 && !getenv("PS_LAZY_COARSE")) {
+        if (build_coarse(h)) return -1;
+        HIP_OK(hipStreamSynchronize(h->stream));
+        lap("two-level structures");
+    }
     lap("scalars + final sync");
     guard.ok = true;
     *out = h;
