@@ -260,6 +260,7 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     // and the per-task prologue/epilogue costs more than the extra L2 hits save).
     std::vector<PairRec> prs;
     int ntiles = 1;
+    bool tiles_forced = getenv("PS_SCHUR_TILE_KB") != nullptr;
     {
         const double zbytes = 8.0 * PS_ZROW * (double)lm_ptr[nv];
         double tile_kb = 9216.0, min_mb = 16.0;
@@ -277,53 +278,64 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     const long total_pairs = lm_pairs_before[nv];
     // one unit of work per tile: the tile's pairs in (block row, block column, landmark) order, written to its
     // slice of prs; tiles are independent, so they are built by a few host threads
-    auto tile_of = [&](int v) {
-        return (ntiles > 1 && total_pairs > 0)
-            ? (int)std::min<long>(ntiles - 1, (long)((double)ntiles * (double)lm_pairs_before[v] / (double)total_pairs)) : 0;
-    };
-    std::vector<int> tile_begin(ntiles + 1, nv);
-    {
-        int t_prev = -1;
-        for (int v = 0; v < nv; ++v) {
-            const int t = tile_of(v);
-            for (int q = t_prev + 1; q <= t; ++q) tile_begin[q] = v;
-            t_prev = std::max(t_prev, t);
-        }
-        tile_begin[ntiles] = nv;
-        for (int q = ntiles - 1; q >= 0; --q) tile_begin[q] = std::min(tile_begin[q], tile_begin[q + 1]);
-    }
-    prs.resize((size_t)total_pairs);
-    auto build_tile = [&](int tile) {
-        const int v0 = tile_begin[tile], v1 = tile_begin[tile + 1];
-        std::vector<PairRec> loc;
-        loc.reserve((size_t)(lm_pairs_before[v1] - lm_pairs_before[v0]));
-        for (int v = v0; v < v1; ++v)
-            for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) {
-                const int ra = d->pose_rid[PS_POSE_OF(lobs[a])];
-                if (ra < 0) continue;
-                for (int b = a + 1; b < lm_ptr[v + 1]; ++b) {
-                    const int rb = d->pose_rid[PS_POSE_OF(lobs[b])];
-                    if (rb < 0) continue;
-                    if (ra <= rb) loc.push_back({((uint64_t)ra << 32) | (uint32_t)rb, a, b, tile});
-                    else loc.push_back({((uint64_t)rb << 32) | (uint32_t)ra, b, a, tile});
-                }
+    // Tiles multiply the tasks (one per (tile, block) with pairs): when a task is left with a handful of pairs -- a landmark
+    // shard of a multi-GPU run: 36 pairs per block at C4 / 8 -- the per-task skeleton dominates and the
+    // untiled list wins (C4 / 8 shard: Schur stage 0.159 -> 0.119 ms).  Decided on the generated list: fewer than 64 pairs
+    // per task on average -> generated again without tiles.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        auto tile_of = [&](int v) {
+            return (ntiles > 1 && total_pairs > 0)
+                ? (int)std::min<long>(ntiles - 1, (long)((double)ntiles * (double)lm_pairs_before[v] / (double)total_pairs)) : 0;
+        };
+        std::vector<int> tile_begin(ntiles + 1, nv);
+        {
+            int t_prev = -1;
+            for (int v = 0; v < nv; ++v) {
+                const int t = tile_of(v);
+                for (int q = t_prev + 1; q <= t; ++q) tile_begin[q] = v;
+                t_prev = std::max(t_prev, t);
             }
-        // (block row, block column): two stable counting passes, least significant first
-        counting_sort(loc, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)x.key; });
-        counting_sort(loc, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)(x.key >> 32); });
-        std::copy(loc.begin(), loc.end(), prs.begin() + lm_pairs_before[v0]);
-    };
-    {
-        const int nthreads = std::max(1, std::min({ntiles, 16, (int)std::thread::hardware_concurrency()}));
-        if (nthreads <= 1) {
-            for (int t = 0; t < ntiles; ++t) build_tile(t);
-        } else {
-            std::atomic<int> next{0};
-            std::vector<std::thread> pool;
-            for (int k = 0; k < nthreads; ++k)
-                pool.emplace_back([&] { for (int t = next++; t < ntiles; t = next++) build_tile(t); });
-            for (auto& th : pool) th.join();
+            tile_begin[ntiles] = nv;
+            for (int q = ntiles - 1; q >= 0; --q) tile_begin[q] = std::min(tile_begin[q], tile_begin[q + 1]);
         }
+        prs.resize((size_t)total_pairs);
+        auto build_tile = [&](int tile) {
+            const int v0 = tile_begin[tile], v1 = tile_begin[tile + 1];
+            std::vector<PairRec> loc;
+            loc.reserve((size_t)(lm_pairs_before[v1] - lm_pairs_before[v0]));
+            for (int v = v0; v < v1; ++v)
+                for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) {
+                    const int ra = d->pose_rid[PS_POSE_OF(lobs[a])];
+                    if (ra < 0) continue;
+                    for (int b = a + 1; b < lm_ptr[v + 1]; ++b) {
+                        const int rb = d->pose_rid[PS_POSE_OF(lobs[b])];
+                        if (rb < 0) continue;
+                        if (ra <= rb) loc.push_back({((uint64_t)ra << 32) | (uint32_t)rb, a, b, tile});
+                        else loc.push_back({((uint64_t)rb << 32) | (uint32_t)ra, b, a, tile});
+                    }
+                }
+            // (block row, block column): two stable counting passes, least significant first
+            counting_sort(loc, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)x.key; });
+            counting_sort(loc, (size_t)std::max(nr, 1), [](const PairRec& x) { return (uint32_t)(x.key >> 32); });
+            std::copy(loc.begin(), loc.end(), prs.begin() + lm_pairs_before[v0]);
+        };
+        {
+            const int nthreads = std::max(1, std::min({ntiles, 16, (int)std::thread::hardware_concurrency()}));
+            if (nthreads <= 1) {
+                for (int t = 0; t < ntiles; ++t) build_tile(t);
+            } else {
+                std::atomic<int> next{0};
+                std::vector<std::thread> pool;
+                for (int k = 0; k < nthreads; ++k)
+                    pool.emplace_back([&] { for (int t = next++; t < ntiles; t = next++) build_tile(t); });
+                for (auto& th : pool) th.join();
+            }
+        }
+        if (ntiles == 1 || tiles_forced || prs.empty()) break;
+        size_t ntask = 0;
+        for (size_t k = 0; k < prs.size(); ++k) ntask += (k == 0 || prs[k].key != prs[k - 1].key || prs[k].tile != prs[k - 1].tile);
+        if (prs.size() >= 64 * ntask) break;
+        ntiles = 1;
     }
     h->schur_tiles = ntiles;
     h->npairs = (long)prs.size();

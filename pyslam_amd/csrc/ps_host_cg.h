@@ -875,8 +875,16 @@ int linearize(ps_problem* h, double lambda) {
                            fin_in_combine ? h->nr : 0, h->pitem_ptr, h->ppartial, h->diag_slot, lambda, h->g);
     } else if (h->npair_items > 0) {
         StageTimer t(h, PS_ST_SCHUR, 1);
-        hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (h->pair_per_xcd / 4)), dim3(256), 0, h->stream,
-                           h->pair_per_xcd, h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, h->schur_ablate);
+        // PS_SCHUR_SPLIT=1 (measurement switch): the same work as two launches over the two halves of
+        // every XCD's list -- what splitting the Schur build into two bands for an overlapped all-reduce would cost
+        static const bool split2 = getenv("PS_SCHUR_SPLIT") != nullptr;
+        const int halfp = split2 ? (h->pair_per_xcd / 2 + 3) / 4 * 4 : h->pair_per_xcd;
+        hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (halfp / 4)), dim3(256), 0, h->stream,
+                           h->pair_per_xcd, h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, h->schur_ablate, 0, halfp);
+        if (split2 && halfp < h->pair_per_xcd)
+            hipLaunchKernelGGL(k_schur_pairs, dim3(8 * ((h->pair_per_xcd - halfp + 3) / 4)), dim3(256), 0, h->stream,
+                               h->pair_per_xcd, h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, h->schur_ablate, halfp, h->pair_per_xcd);
+
         if (h->Spart)
             hipLaunchKernelGGL(k_schur_combine, dim3(cdiv(h->ncomb, 4) + (fin_in_combine ? cdiv(h->nr, 4) : 0)), dim3(256), 0,
                                h->stream, h->ncomb, h->comb_items, h->comb_tasks, h->Spart, h->S,

@@ -410,13 +410,14 @@ PS_DEV double half_sum_dpp(double v) {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_SP_WAVES, 8))) void k_schur_pairs(
     int per_xcd, const PairItem* __restrict__ xitems /* [8][per_xcd], slot < 0: padding */,
     const int2* __restrict__ pairs, const double* __restrict__ Z, double* __restrict__ S,
-    double* __restrict__ Spart /* tiled mode: one partial block per task position, else NULL */, int ablate)
+    double* __restrict__ Spart /* tiled mode: one partial block per task position, else NULL */, int ablate,
+    int first /* items [first, last) of every XCD's list: the whole list, or one half of it (PS_SCHUR_SPLIT) */, int last)
 {
     __shared__ __attribute__((aligned(16))) double smem[4 * PS_SP_LDS_PER_WAVE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double* rows = smem + wv * PS_SP_LDS_PER_WAVE;
-    const int local = (blockIdx.x >> 3) * 4 + wv;
-    if (local >= per_xcd) return;
+    const int local = first + (blockIdx.x >> 3) * 4 + wv;
+    if (local >= last) return;
     const size_t pos = (size_t)(blockIdx.x & 7) * per_xcd + local;
     const PairItem it = xitems[pos];
     if (it.slot < 0) return;

@@ -20,6 +20,18 @@ echo
 echo "# dense photometric alignment, 640 x 480 (tools/photo_bench.py)"
 python tools/photo_bench.py 2>&1 | grep -v amdgpu.ids
 echo
+echo "# lagged dense inverse on / off: steady state, two trajectories, counters (tools/ldi_probe.py)"
+python tools/ldi_probe.py c3 kf100 kf250 pg200 2>&1 | grep -v amdgpu.ids
+echo
+echo "# one-launch explicit two-level PCG on / off (tools/xf_probe.py)"
+python tools/xf_probe.py mid c4 c2 2>&1 | grep -v amdgpu.ids
+echo
+echo "# per-frame motion-only Problem through the public API (tools/c5_frame_probe.py)"
+python tools/c5_frame_probe.py 2>&1 | grep -v amdgpu.ids | tail -1
+echo
+echo "# Schur pair kernel ablation at C3 (tools/schur_ablate.py: 1 no compute, 2 no fetch, 3 neither, 4 no a-rows)"
+python tools/schur_ablate.py 2>&1 | grep ablate
+echo
 echo "# ps_problem_create stages (tools/create_time.py, PS_CREATE_TIMING=1)"
 PS_CREATE_TIMING=1 python tools/create_time.py 2>&1 | grep -v amdgpu.ids
 } > "$OUT/other_configs.txt"
