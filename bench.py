@@ -86,8 +86,11 @@ def pmc_traffic(kernel, config=None):
         meta = table.get('_meta', {})
         if config is not None:
             table = table[config]
+        schur = kernel.startswith('k_schur_pairs')
+        if schur:       # rocprof's name of the pipelined pair kernel (a template), else the round-2 kernel
+            kernel = next(k for k in ('void k_schur_pairs_db<0>', 'k_schur_pairs') if k in table)
         total = table[kernel]['hbm_bytes_corrected']
-        if kernel == 'k_schur_pairs' and 'k_schur_combine' in table:    # tiled mode: the pair kernel's partials are
+        if schur and 'k_schur_combine' in table:                        # tiled mode: the pair kernel's partials are
             total += table['k_schur_combine']['hbm_bytes_corrected']    # summed by a second, small kernel (same timer)
         return total, meta.get('source_sha'), meta.get('git_head')
     except Exception:
@@ -213,9 +216,9 @@ def c4_single_gpu(stream, steps=10, warmup=5):
     stage = {k: v[0] / v[1] for k, v in st.items() if v[1] > 0}
     _, b_schur, _ = algorithmic_bytes(dev.info, out[2])
     sch_ms = stage.get('schur_pairs', 0.0)
-    traffic, tsha, _ = pmc_traffic('k_schur_pairs', 'C4')
+    traffic, tsha, _ = pmc_traffic('k_schur_pairs_db', 'C4')
     ach = b_schur / (sch_ms * 1e-3) / 1e9 if sch_ms > 0 else 0.0
-    roof = {'bound': 'hbm', 'kernel': 'k_schur_pairs', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+    roof = {'bound': 'hbm', 'kernel': 'k_schur_pairs_db', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source_sha': tsha,
             'traffic_stale': bool(traffic is not None and tsha != kernel_source_sha()),
             'algorithmic_bytes_per_launch': int(b_schur), 'avg_launch_ms': round(sch_ms, 5),
@@ -354,7 +357,7 @@ def main():
         sch = stage_ms.get('schur_pairs', 0.0)
         pcg_per_iter = stage_ms.get('pcg', 0.0) / max(n_pcg, 1)
         if sch >= pcg_per_iter * 1.0 and sch > 0:
-            kern, dur_ms, nbytes = 'k_schur_pairs', sch, b_schur
+            kern, dur_ms, nbytes = 'k_schur_pairs_db', sch, b_schur
         else:
             kern, dur_ms, nbytes = 'void k_cg_fused<6>', pcg_per_iter, b_spmv
         achieved = nbytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0

@@ -9,9 +9,13 @@
  * pyslam_amd/_native.py.
  *
  * Conventions
- *   - plain C types only; all table pointers in ps_problem_desc are HOST
- *     pointers, copied to HBM by ps_problem_create (the handle owns its device
- *     memory; the caller keeps ownership of the host arrays);
+ *   - plain C types only; the table pointers in ps_problem_desc are HOST
+ *     pointers unless ps_problem_desc.flags says they are resident in HBM
+ *     (PS_DESC_DEVICE_PARAMS / PS_DESC_DEVICE_TABLES); either way
+ *     ps_problem_create copies them into the handle's own layout (records
+ *     sorted by landmark and by pose), the handle owns that memory and the
+ *     caller keeps ownership of its arrays.  ps_set_params / ps_get_params and
+ *     the pose part of ps_get_dx take host OR device pointers;
  *   - every function returns 0 on success, <0 on error (message through
  *     ps_last_error()); nothing throws across the ABI;
  *   - all launches go to ONE HIP stream per handle (the `stream` argument of
@@ -72,7 +76,15 @@ typedef struct ps_problem_desc {
     int64_t num_extra_pairs;
     const int32_t* extra_pair_i;
     const int32_t* extra_pair_j;
+
+    /* 0 = every pointer above is a host pointer.  PS_DESC_DEVICE_PARAMS: `poses` and `points` are device pointers (on the
+       device the handle is created on) and are copied device to device.  PS_DESC_DEVICE_TABLES: EVERY other non-NULL table
+       pointer above is a device pointer; the index and measurement tables come to the host once for the structure pass
+       (sorting by landmark / pose, pair lists), the caller needs no host copy of them. */
+    uint32_t flags;
 } ps_problem_desc;
+
+enum { PS_DESC_DEVICE_PARAMS = 1u, PS_DESC_DEVICE_TABLES = 2u };
 
 /* sizes a binding needs to allocate result buffers */
 typedef struct ps_problem_info {
@@ -153,6 +165,7 @@ int ps_apply_update(ps_problem* h, double step);
 int ps_snapshot_params(ps_problem* h);
 int ps_restore_params(ps_problem* h);
 
+/* either pointer may be NULL; each may be a host or a device pointer (a torch caller keeps its parameters resident) */
 int ps_get_params(ps_problem* h, double* poses, double* points);
 int ps_set_params(ps_problem* h, const double* poses, const double* points);
 

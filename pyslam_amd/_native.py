@@ -31,7 +31,11 @@ class ProblemDesc(C.Structure):
         ('num_priors', C.c_int64), ('u_i', c_i32p), ('u_Tobs_inv', c_f64p), ('u_grp', c_i32p),
         ('num_stiffd', C.c_int32), ('stiffd', c_f64p), ('num_edge_groups', C.c_int32), ('edge_groups', c_f64p),
         ('num_extra_pairs', C.c_int64), ('extra_pair_i', c_i32p), ('extra_pair_j', c_i32p),
+        ('flags', C.c_uint32),
     ]
+
+
+PS_DESC_DEVICE_PARAMS, PS_DESC_DEVICE_TABLES = 1, 2
 
 
 class ProblemInfo(C.Structure):
@@ -161,12 +165,27 @@ def check(rc):
         raise NativeError(load().ps_last_error().decode('utf-8', 'replace'))
 
 
+def is_resident(a):
+    """A torch tensor living in HBM (the C ABI takes its address: ps_problem_desc.flags, ps_set_params, ps_get_params)."""
+    return hasattr(a, 'data_ptr') and getattr(a, 'is_cuda', False)
+
+
+def _resident_ptr(a, ctype, dtype_name):
+    if not a.is_contiguous() or str(a.dtype) != 'torch.' + dtype_name:
+        raise TypeError('device-resident tables must be contiguous {} tensors'.format(dtype_name))
+    return C.cast(C.c_void_p(a.data_ptr()), ctype)
+
+
 def f64p(a):
-    return a.ctypes.data_as(c_f64p) if a is not None else None
+    if a is None:
+        return None
+    return _resident_ptr(a, c_f64p, 'float64') if is_resident(a) else a.ctypes.data_as(c_f64p)
 
 
 def i32p(a):
-    return a.ctypes.data_as(c_i32p) if a is not None else None
+    if a is None:
+        return None
+    return _resident_ptr(a, c_i32p, 'int32') if is_resident(a) else a.ctypes.data_as(c_i32p)
 
 
 def require_gpu():

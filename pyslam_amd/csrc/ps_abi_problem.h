@@ -27,7 +27,38 @@ int ps_problem_destroy(ps_problem* h) {
     return 0;
 }
 
-int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) {
+// ps_problem_desc::flags & PS_DESC_DEVICE_TABLES: the structure pass below walks the index tables on the host, so resident
+// tables are brought over once (one D2H copy each, no pinned staging on the caller's side); the parameter tables
+// (PS_DESC_DEVICE_PARAMS) never leave the device.
+struct DescStage {
+    ps_problem_desc d;
+    std::vector<std::vector<char>> bufs;
+    int pull_bytes(const void** field, size_t bytes) {
+        if (!bytes || !*field) return 0;
+        bufs.emplace_back(bytes);
+        if (hipMemcpy(bufs.back().data(), *field, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail("ps_problem_create: copy of a device-resident table failed (PS_DESC_DEVICE_TABLES set on a host pointer?)");
+        *field = bufs.back().data();
+        return 0;
+    }
+    int pull(const double** f, size_t n) { return pull_bytes((const void**)f, n * sizeof(double)); }
+    int pull(const int32_t** f, size_t n) { return pull_bytes((const void**)f, n * sizeof(int32_t)); }
+    int stage(const ps_problem_desc* in) {
+        d = *in;
+        if (!(d.flags & PS_DESC_DEVICE_TABLES)) return 0;
+        const size_t P = std::max(0, d.num_poses), L = std::max(0, d.num_points), N = (size_t)std::max<int64_t>(0, d.num_obs);
+        const size_t E = (size_t)std::max<int64_t>(0, d.num_edges), Q = (size_t)std::max<int64_t>(0, d.num_priors);
+        const size_t X = (size_t)std::max<int64_t>(0, d.num_extra_pairs), PW = d.dof == 6 ? 12 : 6, DD = (size_t)d.dof * d.dof;
+        return pull(&d.pose_rid, P) || pull(&d.point_vid, L) || pull(&d.obs_pose, N) || pull(&d.obs_point, N) || pull(&d.obs_uvd, 3 * N) ||
+               pull(&d.obs_grp, N) || pull(&d.cams, 5 * (size_t)std::max(0, d.num_cams)) || pull(&d.stiff3, 9 * (size_t)std::max(0, d.num_stiff3)) ||
+               pull(&d.obs_groups, 4 * (size_t)std::max(0, d.num_obs_groups)) || pull(&d.e_i, E) || pull(&d.e_j, E) ||
+               pull(&d.e_Tobs_inv, PW * E) || pull(&d.e_grp, E) || pull(&d.u_i, Q) || pull(&d.u_Tobs_inv, PW * Q) || pull(&d.u_grp, Q) ||
+               pull(&d.stiffd, DD * (size_t)std::max(0, d.num_stiffd)) || pull(&d.edge_groups, 3 * (size_t)std::max(0, d.num_edge_groups)) ||
+               pull(&d.extra_pair_i, X) || pull(&d.extra_pair_j, X);
+    }
+};
+
+int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** out) {
     const bool timing = getenv("PS_CREATE_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -36,14 +67,20 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         fprintf(stderr, "ps_problem_create: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    if (!d || !out) return fail("null argument");
+    if (!d_in || !out) return fail("null argument");
     *out = nullptr;
-    if (d->dof != 6 && d->dof != 3) return fail("dof must be 6 (SE3) or 3 (SE2)");
-    if (d->num_obs > 0 && d->dof != 6) return fail("reprojection blocks need SE(3) poses");
-    if (d->num_poses >= (1 << 24)) return fail("more than 2^24 poses");
-    if (d->num_obs >= (1L << 31) / 18) return fail("too many observations for 32-bit indexing");
+    if (d_in->flags & ~(uint32_t)(PS_DESC_DEVICE_PARAMS | PS_DESC_DEVICE_TABLES)) return fail("unknown bits in ps_problem_desc.flags");
+    if (d_in->dof != 6 && d_in->dof != 3) return fail("dof must be 6 (SE3) or 3 (SE2)");
+    if (d_in->num_obs > 0 && d_in->dof != 6) return fail("reprojection blocks need SE(3) poses");
+    if (d_in->num_poses >= (1 << 24)) return fail("more than 2^24 poses");
+    if (d_in->num_obs >= (1L << 31) / 18) return fail("too many observations for 32-bit indexing");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device visible");
+    DescStage staged;
+    if (staged.stage(d_in)) return -1;
+    const ps_problem_desc* d = &staged.d;
+    const bool params_resident = (d->flags & PS_DESC_DEVICE_PARAMS) != 0;
+    lap("device-resident tables");
 
     ps_problem* h = new ps_problem();
     struct Guard { ps_problem* h; bool ok = false; ~Guard() { if (!ok) ps_problem_destroy(h); } } guard{h};
@@ -61,8 +98,8 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     const long N = h->N;
 
     // ---- parameter tables
-    if (h->upload(&h->poses, d->poses, (size_t)P * PW)) return -1;
-    if (h->upload(&h->points, d->points, (size_t)L * 3)) return -1;
+    if (h->upload(&h->poses, d->poses, (size_t)P * PW, params_resident)) return -1;
+    if (h->upload(&h->points, d->points, (size_t)L * 3, params_resident)) return -1;
     if (h->upload(&h->pose_rid, d->pose_rid, (size_t)P)) return -1;
     if (h->alloc(&h->poses_snap, (size_t)P * PW) || h->alloc(&h->points_snap, (size_t)L * 3)) return -1;
     int nr = 0, nv = 0;
@@ -261,8 +298,8 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
     std::vector<PairRec> prs;
     int ntiles = 1;
     bool tiles_forced = getenv("PS_SCHUR_TILE_KB") != nullptr;
+    const double zbytes = 8.0 * PS_ZROW * (double)lm_ptr[nv];
     {
-        const double zbytes = 8.0 * PS_ZROW * (double)lm_ptr[nv];
         double tile_kb = 9216.0, min_mb = 16.0;
         if (const char* e = getenv("PS_SCHUR_TILE_KB")) tile_kb = atof(e);
         if (const char* e = getenv("PS_SCHUR_TILE_MIN_MB")) min_mb = atof(e);
@@ -333,8 +370,17 @@ int ps_problem_create(const ps_problem_desc* d, void* stream, ps_problem** out) 
         }
         if (ntiles == 1 || tiles_forced || prs.empty()) break;
         size_t ntask = 0;
-        for (size_t k = 0; k < prs.size(); ++k) ntask += (k == 0 || prs[k].key != prs[k - 1].key || prs[k].tile != prs[k - 1].tile);
-        if (prs.size() >= 64 * ntask) break;
+        std::vector<uint64_t> task_keys;
+        for (size_t k = 0; k < prs.size(); ++k)
+            if (k == 0 || prs[k].key != prs[k - 1].key || prs[k].tile != prs[k - 1].tile) { ++ntask; task_keys.push_back(prs[k].key); }
+        std::sort(task_keys.begin(), task_keys.end());
+        const size_t nblocks = std::unique(task_keys.begin(), task_keys.end()) - task_keys.begin();
+        // Tiles also buy parallelism (tasks) and L2 locality, and cost a combine launch, a partial per task and short tasks.
+        // When the blocks alone fill the chip twice over (2 x 256 CUs x 12 waves of the pipelined pair kernel) and all of Z
+        // stays in the 256 MiB Infinity Cache, the untiled list wins (C3: stage 56 -> 48 us); at C4 (Z = 640 MB) the tiles'
+        // locality is worth 0.53 against 0.77 ms.
+        const bool blocks_fill_chip = nblocks >= 2 * 256 * 12 && zbytes <= 128.0 * 1048576.0 && !getenv("PS_SCHUR_KEEP_TILES");
+        if (prs.size() >= 64 * ntask && !blocks_fill_chip) break;
         ntiles = 1;
     }
     h->schur_tiles = ntiles;

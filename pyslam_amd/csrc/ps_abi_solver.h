@@ -94,7 +94,7 @@ int ps_backsub(ps_problem* h) {
 int ps_get_dx(ps_problem* h, double* dx_pose, double* dx_point) {
     if (!h) return fail("null argument");
     std::vector<double> tmp;
-    if (dx_pose && h->nr) HIP_OK(hipMemcpyAsync(dx_pose, h->x, (size_t)h->nr * h->D * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (dx_pose && h->nr) HIP_OK(hipMemcpyAsync(dx_pose, h->x, (size_t)h->nr * h->D * sizeof(double), hipMemcpyDefault, h->stream));
     if (dx_point && h->nv) {
         tmp.resize((size_t)h->nv * 3);
         HIP_OK(hipMemcpyAsync(tmp.data(), h->dxl, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -140,16 +140,17 @@ int ps_restore_params(ps_problem* h) {
 
 int ps_get_params(ps_problem* h, double* poses, double* points) {
     if (!h) return fail("null argument");
-    if (poses && h->P) HIP_OK(hipMemcpyAsync(poses, h->poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (points && h->L) HIP_OK(hipMemcpyAsync(points, h->points, (size_t)h->L * 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    // hipMemcpyDefault: the destination may be host memory or the caller's own device buffer
+    if (poses && h->P) HIP_OK(hipMemcpyAsync(poses, h->poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDefault, h->stream));
+    if (points && h->L) HIP_OK(hipMemcpyAsync(points, h->points, (size_t)h->L * 3 * sizeof(double), hipMemcpyDefault, h->stream));
     return sync(h);
 }
 
 int ps_set_params(ps_problem* h, const double* poses, const double* points) {
     if (!h) return fail("null argument");
     h->last_cost = h->prev_cost = -1.0;
-    if (poses && h->P) HIP_OK(hipMemcpyAsync(h->poses, poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (points && h->L) HIP_OK(hipMemcpyAsync(h->points, points, (size_t)h->L * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (poses && h->P) HIP_OK(hipMemcpyAsync(h->poses, poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDefault, h->stream));
+    if (points && h->L) HIP_OK(hipMemcpyAsync(h->points, points, (size_t)h->L * 3 * sizeof(double), hipMemcpyDefault, h->stream));
     return sync(h);
 }
 
@@ -498,6 +499,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     }
     else if (n == "cg_ablate") h->cg_ablate = (int)value;
     else if (n == "schur_ablate") h->schur_ablate = (int)value;
+    else if (n == "schur_pipeline") h->schur_pipeline = value != 0.0;
     else if (n == "schur_stream") { if (value != 0.0 && !h->st_tiles) return fail("schur_stream: the streaming lists were not built for this problem"); h->use_stream = value != 0.0; }
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;

@@ -190,6 +190,7 @@ struct ps_problem {
     bool coarse_built = false;
     bool coarse_clamped = false;    // the automatic coarse level was cut back to 255 nodes: its matrix is not banded
     int cg_ablate = 0, schur_ablate = 0, lm_ablate = 0;
+    int schur_pipeline = 1;         // k_schur_pairs_db (two chunks per wave in flight) instead of k_schur_pairs; option "schur_pipeline"
     int max_pose_obs = 0;           // most observations on one variable pose
     int mo_fused = 1;               // motion-only problems: one launch per iteration (k_motion_only_iteration)
     double* mo_partials = nullptr;
@@ -334,6 +335,10 @@ struct ps_problem {
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
+        // PS_ARENA_POISON=1 (debugging): big tables start as NaN too -- recycled device memory is not zero, and a kernel that
+        // reads a word nothing wrote (padding of a tile, a slot past the end) then shows instead of depending on history
+        static const bool poison_all = getenv("PS_ARENA_POISON") != nullptr;
+        if (poison_all && hipMemset(p, 0xFF, bytes) != hipSuccess) return fail("hipMemset (poison) failed");
         allocs.push_back(p);
         dev_bytes += bytes;
         *out = (T*)p;
@@ -343,9 +348,15 @@ struct ps_problem {
         return arena_open && (const char*)p >= arena_dev && (const char*)p < arena_dev + PS_ARENA_BYTES;
     }
     template <typename T>
-    int upload(T** out, const T* src, size_t n) {
+    int upload(T** out, const T* src, size_t n, bool src_resident = false) {
         if (alloc(out, n)) return -1;
         if (!n) return 0;
+        if (src_resident) {     // a table the caller already holds in HBM (ps_problem_desc.flags): arena tables travel with the
+                                // mirror's closing copy, so the mirror is what gets filled; anything else is device to device
+            if (in_arena(*out)) HIP_OK(hipMemcpy(arena_host + ((char*)*out - arena_dev), src, n * sizeof(T), hipMemcpyDeviceToHost));
+            else HIP_OK(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyDeviceToDevice));
+            return 0;
+        }
         if (in_arena(*out)) std::memcpy(arena_host + ((char*)*out - arena_dev), src, n * sizeof(T));
         else HIP_OK(hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice));
         return 0;

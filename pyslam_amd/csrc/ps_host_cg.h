@@ -845,7 +845,7 @@ int linearize(ps_problem* h, double lambda) {
         if (h->wide_obs) PS_LM_LAUNCH(true); else PS_LM_LAUNCH(false);
 #undef PS_LM_LAUNCH
     }
-    bool fin_in_combine = false;
+    bool fin_in_combine = false, fin_in_pairs = false;
     if (h->npitems > 0) {
         StageTimer t(h, PS_ST_POSE);
         const ObsWide wp{h->sidx_p, h->stiff_tab};
@@ -857,7 +857,10 @@ int linearize(ps_problem* h, double lambda) {
                                h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp);
         // tiled Schur: the combine launch also finalizes the poses (unless a task writes a diagonal block)
         fin_in_combine = (h->Spart || h->use_stream) && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6;
-        if (!fin_in_combine)
+        // untiled Schur with the pipelined pair kernel: its trailing workgroups finalize the poses
+        fin_in_pairs = !h->Spart && !h->use_stream && h->schur_pipeline && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6 &&
+                       !getenv("PS_SCHUR_SPLIT");
+        if (!fin_in_combine && !fin_in_pairs)
             hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
                                h->ppartial, h->diag_slot, lambda, h->S, h->g);
     }
@@ -879,11 +882,23 @@ int linearize(ps_problem* h, double lambda) {
         // every XCD's list -- what splitting the Schur build into two bands for an overlapped all-reduce would cost
         static const bool split2 = getenv("PS_SCHUR_SPLIT") != nullptr;
         const int halfp = split2 ? (h->pair_per_xcd / 2 + 3) / 4 * 4 : h->pair_per_xcd;
-        hipLaunchKernelGGL(k_schur_pairs, dim3(8 * (halfp / 4)), dim3(256), 0, h->stream,
-                           h->pair_per_xcd, h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, h->schur_ablate, 0, halfp);
-        if (split2 && halfp < h->pair_per_xcd)
-            hipLaunchKernelGGL(k_schur_pairs, dim3(8 * ((h->pair_per_xcd - halfp + 3) / 4)), dim3(256), 0, h->stream,
-                               h->pair_per_xcd, h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, h->schur_ablate, halfp, h->pair_per_xcd);
+        // PS_SCHUR_LDS_PAD=<bytes> (measurement switch): unused dynamic LDS per workgroup, i.e. fewer resident waves per CU
+        static const int lds_pad = getenv("PS_SCHUR_LDS_PAD") ? atoi(getenv("PS_SCHUR_LDS_PAD")) : 0;
+        auto launch_pairs = [&](int nblk, int lds, int from, int to) {
+            if (!h->schur_pipeline)
+                hipLaunchKernelGGL(k_schur_pairs, dim3(nblk), dim3(256), lds, h->stream, h->pair_per_xcd, h->pair_xitems, h->pairs,
+                                   h->Z, h->S, h->Spart, h->schur_ablate, from, to);
+            else {
+                auto k = h->schur_ablate == 0 ? k_schur_pairs_db<0> : h->schur_ablate == 1 ? k_schur_pairs_db<1> :
+                         h->schur_ablate == 2 ? k_schur_pairs_db<2> : h->schur_ablate == 3 ? k_schur_pairs_db<3> :
+                         h->schur_ablate == 4 ? k_schur_pairs_db<4> : k_schur_pairs_db<5>;
+                hipLaunchKernelGGL(k, dim3(nblk + (fin_in_pairs ? cdiv(h->nr, 4) : 0)), dim3(256), lds, h->stream, h->pair_per_xcd,
+                                   h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, from, to, nblk, fin_in_pairs ? h->nr : 0,
+                                   h->pitem_ptr, h->ppartial, h->diag_slot, lambda, h->g);
+            }
+        };
+        launch_pairs(8 * (halfp / 4), lds_pad, 0, halfp);
+        if (split2 && halfp < h->pair_per_xcd) launch_pairs(8 * ((h->pair_per_xcd - halfp + 3) / 4), 0, halfp, h->pair_per_xcd);
 
         if (h->Spart)
             hipLaunchKernelGGL(k_schur_combine, dim3(cdiv(h->ncomb, 4) + (fin_in_combine ? cdiv(h->nr, 4) : 0)), dim3(256), 0,

@@ -91,6 +91,7 @@ PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
 }
 
 #include "ps_k_linearize.h"
+#include "ps_k_schur2.h"
 #include "ps_k_stream.h"
 #include "ps_k_pcg_classic.h"
 #include "ps_k_ldi.h"

@@ -19,16 +19,31 @@ class DeviceProblem:
         self.dof = lp.dof
         d = nat.ProblemDesc()
         keep = []       # host arrays must outlive the create call only
+        # tables a torch caller already holds in HBM (`resident_tables(lp)` below, or its own tensors) are handed over by
+        # address: ps_problem_desc.flags.  All-or-nothing per class, as the C ABI has it.
+        params_res = nat.is_resident(lp.poses)
+        tables_res = nat.is_resident(lp.pose_rid)
+        if params_res != nat.is_resident(lp.points):
+            raise TypeError('poses and points must both be host arrays or both device tensors')
+        d.flags = (nat.PS_DESC_DEVICE_PARAMS if params_res else 0) | (nat.PS_DESC_DEVICE_TABLES if tables_res else 0)
 
-        def F(a):
-            a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); return nat.f64p(a)
+        def conv(a, np_dtype, want_res, to_ptr):
+            if nat.is_resident(a) != want_res:
+                raise TypeError('mixed host / device tables (ps_problem_desc.flags is per class: parameters, everything else)')
+            if not want_res:
+                a = np.ascontiguousarray(a, dtype=np_dtype)
+            keep.append(a)
+            return to_ptr(a) if a.shape[0] else None
+
+        def F(a, res=None):
+            return conv(a, np.float64, tables_res if res is None else res, nat.f64p)
 
         def I(a):
-            a = np.ascontiguousarray(a, dtype=np.int32); keep.append(a); return nat.i32p(a)
+            return conv(a, np.int32, tables_res, nat.i32p)
 
         d.dof = lp.dof
-        d.num_poses, d.poses, d.pose_rid = lp.num_poses, F(lp.poses), I(lp.pose_rid)
-        d.num_points, d.points, d.point_vid = lp.num_points, F(lp.points), I(lp.point_vid)
+        d.num_poses, d.poses, d.pose_rid = lp.num_poses, F(lp.poses, params_res), I(lp.pose_rid)
+        d.num_points, d.points, d.point_vid = lp.num_points, F(lp.points, params_res), I(lp.point_vid)
         d.num_obs = lp.num_obs
         d.obs_pose, d.obs_point, d.obs_uvd, d.obs_grp = I(lp.obs_pose), I(lp.obs_point), F(lp.obs_uvd), I(lp.obs_grp)
         d.num_cams, d.cams = lp.cams.shape[0], F(lp.cams)
@@ -158,15 +173,20 @@ class DeviceProblem:
         nat.check(self._lib.ps_get_dx(self._h, nat.f64p(xp), nat.f64p(xl)))
         return xp, xl
 
-    def get_params(self):
+    def get_params(self, poses_out=None, points_out=None):
+        """Without arguments: fresh host arrays.  With torch tensors resident in HBM: filled in place, device to device."""
+        if poses_out is not None or points_out is not None:
+            nat.check(self._lib.ps_get_params(self._h, nat.f64p(poses_out), nat.f64p(points_out)))
+            return poses_out, points_out
         poses = np.zeros((self.lp.num_poses, self.lp.pose_width))
         points = np.zeros((self.lp.num_points, 3))
         nat.check(self._lib.ps_get_params(self._h, nat.f64p(poses), nat.f64p(points)))
         return poses, points
 
     def set_params(self, poses=None, points=None):
-        p = None if poses is None else np.ascontiguousarray(poses, dtype=np.float64)
-        q = None if points is None else np.ascontiguousarray(points, dtype=np.float64)
+        """Host arrays, or float64 torch tensors resident in HBM (copied device to device)."""
+        p = poses if poses is None or nat.is_resident(poses) else np.ascontiguousarray(poses, dtype=np.float64)
+        q = points if points is None or nat.is_resident(points) else np.ascontiguousarray(points, dtype=np.float64)
         nat.check(self._lib.ps_set_params(self._h, nat.f64p(p), nat.f64p(q)))
 
     def reduce_buffer(self):
@@ -383,3 +403,25 @@ class PhotometricDevice:
             raise ValueError('the photometric device path has no damping (Options.lm_lambda must be 0)')
         dx, cost = self.step(linesearch)
         return cost, float(np.linalg.norm(dx)), 0, 0.0
+
+
+_TABLES_F64 = ('obs_uvd', 'cams', 'stiff3', 'obs_groups', 'e_Tobs_inv', 'u_Tobs_inv', 'stiffd', 'edge_groups')
+_TABLES_I32 = ('pose_rid', 'point_vid', 'obs_pose', 'obs_point', 'obs_grp', 'e_i', 'e_j', 'e_grp', 'u_i', 'u_grp')
+
+
+def resident_tables(lp, device='cuda:0', params=True, tables=True):
+    """A view of a LoweredProblem whose tables are torch tensors in HBM -- what a torch caller that built its problem on the
+    device hands to DeviceProblem (ps_problem_desc.flags = PS_DESC_DEVICE_PARAMS | PS_DESC_DEVICE_TABLES): no host copy of
+    the measurement tables is needed on the caller's side."""
+    import copy
+    import torch
+    out = copy.copy(lp)
+    if params:
+        out.poses = torch.as_tensor(np.ascontiguousarray(lp.poses, dtype=np.float64)).to(device)
+        out.points = torch.as_tensor(np.ascontiguousarray(lp.points, dtype=np.float64)).to(device)
+    if tables:
+        for name in _TABLES_F64:
+            setattr(out, name, torch.as_tensor(np.ascontiguousarray(getattr(lp, name), dtype=np.float64)).to(device))
+        for name in _TABLES_I32:
+            setattr(out, name, torch.as_tensor(np.ascontiguousarray(getattr(lp, name), dtype=np.int32)).to(device))
+    return out

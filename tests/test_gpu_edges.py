@@ -557,3 +557,56 @@ def test_wide_coarse_matrix_keeps_the_dense_factorisation():
     dxo, _ = orc.gauss_newton_step(lp, points_first=False)
     xp, xl = dev.get_dx()
     assert np.linalg.norm(xp.ravel() - dxo) <= 1e-8 * np.linalg.norm(dxo), check
+
+
+@pytest.mark.parametrize('params,tables', [(True, True), (True, False), (False, True)])
+def test_tables_resident_in_hbm_give_the_same_problem(params, tables):
+    """ps_problem_desc.flags (PS_DESC_DEVICE_PARAMS / PS_DESC_DEVICE_TABLES): a caller whose tables already live in HBM
+    (torch tensors) hands over addresses.  Same records, same kernels, same order => the iterations are bit-identical to
+    those of the handle created from host arrays; set_params / get_params move parameters device to device."""
+    import torch
+    from pyslam_amd.device import DeviceProblem, resident_tables
+    lp, truth = synthetic.stereo_ba(num_kf=9, num_lm=400, obs_per_lm=5, half_window=4, seed=41)
+    lp = synthetic.with_pose_edges(lp, 6, seed=5, truth_poses=truth['poses'])
+    host = DeviceProblem(lp)
+    res_lp = resident_tables(lp, params=params, tables=tables)
+    from pyslam_amd._native import is_resident
+    assert is_resident(res_lp.poses) == params and is_resident(res_lp.obs_uvd) == tables
+    res = DeviceProblem(res_lp)
+    assert res.info == host.info or {k: v for k, v in res.info.items() if k != 'device_bytes'} == \
+        {k: v for k, v in host.info.items() if k != 'device_bytes'}
+    assert res.eval_cost(True) == host.eval_cost(True)
+    for _ in range(3):
+        a, b = host.gn_iteration(0., 1e-12, 200, True), res.gn_iteration(0., 1e-12, 200, True)
+        assert a == b
+    pa, qa = host.get_params()
+    pb, qb = res.get_params()
+    assert np.array_equal(pa, pb) and np.array_equal(qa, qb)
+    # and against the oracle, through the resident handle alone
+    fresh = DeviceProblem(resident_tables(lp, params=params, tables=tables))
+    fresh.gn_iteration(0., 1e-13, 500, False)
+    xp, xl = fresh.get_dx()
+    dxo, _ = orc.gauss_newton_step(lp, points_first=False)
+    assert rel_err(np.concatenate([xp.ravel(), xl.ravel()]), dxo) < 1e-8
+    # parameters in and out without leaving the device
+    tp = torch.empty((lp.num_poses, lp.pose_width), dtype=torch.float64, device='cuda:0')
+    tq = torch.empty((lp.num_points, 3), dtype=torch.float64, device='cuda:0')
+    res.get_params(tp, tq)
+    assert np.array_equal(tp.cpu().numpy(), pa) and np.array_equal(tq.cpu().numpy(), qa)
+    host.set_params(lp.poses, lp.points)
+    res.set_params(torch.as_tensor(lp.poses).cuda(), torch.as_tensor(lp.points).cuda())
+    assert host.gn_iteration(0., 1e-12, 200, True) == res.gn_iteration(0., 1e-12, 200, True)
+
+
+def test_resident_tables_are_all_or_nothing_per_class():
+    import torch
+    from pyslam_amd.device import DeviceProblem, resident_tables
+    lp, _ = synthetic.stereo_ba(num_kf=4, num_lm=30, obs_per_lm=3, half_window=2, seed=42)
+    mixed = resident_tables(lp)
+    mixed.obs_uvd = lp.obs_uvd                               # one host table among device ones
+    with pytest.raises(TypeError):
+        DeviceProblem(mixed)
+    wrong = resident_tables(lp)
+    wrong.obs_pose = wrong.obs_pose.to(torch.int64)          # the C ABI reads int32
+    with pytest.raises(TypeError):
+        DeviceProblem(wrong)

@@ -267,7 +267,22 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert ctypes.sizeof(_native.ProblemDesc) == 264 and ctypes.sizeof(_native.ProblemInfo) == 136  # gcc sizeof
+    assert ctypes.sizeof(_native.ProblemDesc) == 272 and ctypes.sizeof(_native.ProblemInfo) == 136  # gcc sizeof
+
+
+def test_unknown_descriptor_flags_are_rejected_before_anything_is_touched():
+    """ps_problem_desc.flags: bits other than PS_DESC_DEVICE_PARAMS | PS_DESC_DEVICE_TABLES are an error (checked first, so
+    it can be exercised without a GPU and without valid tables)."""
+    from pyslam_amd import _native
+    lib = _native.load()
+    d = _native.ProblemDesc()
+    d.dof, d.flags = 6, 4
+    h = _native.H()
+    assert lib.ps_problem_create(ctypes.byref(d), None, ctypes.byref(h)) < 0
+    assert b'flags' in lib.ps_last_error()
+    header = open(os.path.join(REPO, 'include', 'pyslam_hip.h')).read()
+    assert re.search(r'PS_DESC_DEVICE_PARAMS = 1u, PS_DESC_DEVICE_TABLES = 2u', header)
+    assert (_native.PS_DESC_DEVICE_PARAMS, _native.PS_DESC_DEVICE_TABLES) == (1, 2)
 
 
 def test_solver_fails_loudly_without_gpu():

@@ -8,9 +8,11 @@ from pyslam_amd.device import DeviceProblem
 lp, _ = synthetic.stereo_ba(num_kf=200, num_lm=50000, obs_per_lm=10, half_window=20, seed=0)
 dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
 dev.snapshot()
+if os.environ.get('SCHUR_PIPELINE') is not None:
+    dev.set_option('schur_pipeline', int(os.environ['SCHUR_PIPELINE']))
 import sys
 OPT = sys.argv[1] if len(sys.argv) > 1 else 'schur_ablate'
-for ab in ([0, 1, 2, 3, 4] if OPT == 'schur_ablate' else [0, 1]):
+for ab in ([0, 1, 2, 3, 4, 5] if OPT == 'schur_ablate' else [0, 1]):
     dev.set_option(OPT, ab)
     for _ in range(3):
         dev.restore(); dev.linearize(0.0)

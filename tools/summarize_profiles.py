@@ -63,6 +63,6 @@ traffic['_meta'] = {'source_sha': sha, 'git_head': head, 'round': rnd, 'tag': ta
 json.dump(traffic, open(os.path.join(dst, 'pmc_traffic.json'), 'w'), indent=1, sort_keys=True)
 b = json.load(open(os.path.join(src, 'bench.json')))
 print('bench', b['value'], b['stage_ms'], b['roofline'], b.get('cpu_baseline', {}).get('value'))
-for k in ('k_schur_pairs', 'k_schur_combine', 'k_landmark_pass', 'k_pose_pass', 'k_backsub'):
+for k in ('void k_schur_pairs_db<0>', 'k_schur_pairs', 'k_schur_combine', 'k_landmark_pass', 'k_pose_pass', 'k_backsub'):
     if k in traffic and k != '_meta':
         print(k, traffic[k])
