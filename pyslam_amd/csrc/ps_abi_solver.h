@@ -360,6 +360,7 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
             if (read_scalars(h)) return -1;
         }
     }
+    if (!h->guards.empty()) { hipStreamSynchronize(h->stream); if (h->side) hipStreamSynchronize(h->side); h->check_guards("after ps_gn_iteration"); }
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
     h->prev_cost = h->last_cost; h->last_cost = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];

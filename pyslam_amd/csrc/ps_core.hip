@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <array>
+#include <map>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -67,6 +68,30 @@ struct PsPool {
         v.push_back(x); return true;
     }
 };
+// Events that order the solver stream against the side stream (and back).  PS_EVENT_FLAGS=<int> overrides the creation flags
+// (debugging); see DESIGN.md section 3 "cross-stream visibility".
+inline unsigned ps_xstream_event_flags() {
+    static const unsigned f = getenv("PS_EVENT_FLAGS") ? (unsigned)strtoul(getenv("PS_EVENT_FLAGS"), nullptr, 0)
+                                                       : (unsigned)(hipEventDisableTiming | hipEventReleaseToSystem);
+    return f;
+}
+#define PS_XSTREAM_EVENT_FLAGS ps_xstream_event_flags()
+
+// Dynamic LDS beyond 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize, and that attribute belongs to the KERNEL, not to
+// a handle: with per-handle "already set" flags a second, smaller problem lowered the limit under a live bigger one, whose
+// next launch then failed without a trace.  One process-wide high-water mark per kernel instead.
+inline int ensure_dynamic_lds(const void* func, size_t bytes) {
+    static std::mutex mu;
+    static std::map<const void*, size_t> high;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = high[func];
+    if (bytes > cur) {
+        HIP_OK(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        cur = bytes;
+    }
+    return 0;
+}
+
 PsPool& ps_pool() { static PsPool* p = new PsPool(); return *p; }   // (leaked on purpose: no destructor order issues at exit)
 
 }  // namespace
@@ -82,6 +107,22 @@ struct ps_problem {
     int nnzb = 0;
     size_t dev_bytes = 0;
     std::vector<void*> allocs;
+    // PS_ALLOC_GUARD=1 (debugging): every hipMalloc'd table is followed by 4 KB of 0xA5; check_guards() names the table
+    // whose guard a kernel has written into
+    struct Guard { char* guard; size_t table_bytes; int serial; };
+    std::vector<Guard> guards;
+    int check_guards(const char* where) {
+        int bad = 0;
+        std::vector<unsigned char> g(4096);
+        for (const Guard& gd : guards) {
+            if (hipMemcpy(g.data(), gd.guard, 4096, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            for (int i = 0; i < 4096; ++i) if (g[i] != 0xA5) {
+                fprintf(stderr, "GUARD %p %s: table #%d (%zu bytes) overrun at +%d (byte %02x)\n", (void*)this, where, gd.serial, gd.table_bytes, i, g[i]);
+                ++bad; break;
+            }
+        }
+        return bad;
+    }
 
     // parameter tables
     double *poses = nullptr, *points = nullptr, *poses_snap = nullptr, *points_snap = nullptr;
@@ -333,8 +374,15 @@ struct ps_problem {
             }
         }
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, bytes);
+        static const bool guard_on = getenv("PS_ALLOC_GUARD") != nullptr;
+        const size_t padded = (bytes + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&p, guard_on ? padded + 4096 : bytes);
         if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
+        if (guard_on) {
+            if (hipMemset((char*)p + bytes, 0xA5, padded - bytes + 4096) != hipSuccess) return fail("hipMemset (guard) failed");
+            guards.push_back({(char*)p + padded, bytes, (int)guards.size()});
+            fprintf(stderr, "GUARD %p table #%d = %zu bytes (%s)\n", (void*)this, (int)guards.size() - 1, bytes, __PRETTY_FUNCTION__);
+        }
         // PS_ARENA_POISON=1 (debugging): big tables start as NaN too -- recycled device memory is not zero, and a kernel that
         // reads a word nothing wrote (padding of a tile, a slot past the end) then shows instead of depending on history
         static const bool poison_all = getenv("PS_ARENA_POISON") != nullptr;

@@ -456,8 +456,13 @@ int build_coarse(ps_problem* h) {
         HIP_OK(hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
     }
     if (!h->side) {
-        int prio_lo = 0, prio_hi = 0;                      // lowest priority: the side work must not delay the CG launches
-        HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        // An ORDINARY non-blocking stream.  Rounds 1-3 created it with the lowest priority so that the side work would not
+        // delay the CG launches; on this stack (ROCm 7.2 / gfx950) kernels of a low-priority stream that run beside
+        // normal-priority work now and then produce a different result -- same A_c in, a different inverse out, 8 of 40
+        // problems in tools/hunt_explicit_flake.py, none with an ordinary stream; a preconditioner either way, so nothing
+        // failed, but runs differed in the last bits and one in ~300 side factorisations reported a spurious failure
+        // (DESIGN.md section 4).  The priority bought nothing measurable (C3 0.210 / 0.213 ms, C4 2.00 / 1.97 ms).
+        // PS_SIDE_LOWPRIO=1 brings the old stream back (to reproduce).
         // PS_SIDE_CUS=n (measurement switch): confine the side stream to n compute units (CU mask, low bits: spread evenly
         // over the XCDs) instead of running it at low priority over the whole chip
         const int side_cus = getenv("PS_SIDE_CUS") ? atoi(getenv("PS_SIDE_CUS")) : h->side_cus;
@@ -465,11 +470,15 @@ int build_coarse(ps_problem* h) {
             uint32_t mask[8] = {};
             for (int b = 0; b < std::min(side_cus, 256); ++b) mask[b >> 5] |= 1u << (b & 31);
             HIP_OK(hipExtStreamCreateWithCUMask(&h->side, 8, mask));
+        } else if (getenv("PS_SIDE_LOWPRIO")) {
+            int prio_lo = 0, prio_hi = 0;
+            HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            HIP_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
         } else
-        HIP_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
-        HIP_OK(hipEventCreateWithFlags(&h->ev_ac, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&h->ev_acdone, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&h->ev_chol, hipEventDisableTiming));
+            HIP_OK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_ac, PS_XSTREAM_EVENT_FLAGS));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_acdone, PS_XSTREAM_EVENT_FLAGS));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_chol, PS_XSTREAM_EVENT_FLAGS));
     }
     if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
     h->acdone_pending = false;                             // (recorded before ev_chol on the same stream)
@@ -479,6 +488,14 @@ int build_coarse(ps_problem* h) {
     return 0;
 }
 
+// device-to-device copy of n doubles as a kernel on `st` (between kernels of a stream a copy kernel keeps everything on one
+// queue and one engine; the copies are small)
+inline void copy_doubles(hipStream_t st, double* dst, const double* src, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_copy2, dim3((unsigned)std::min<size_t>(2048, cdiv((long)n, 256))), dim3(256), 0, st, n, src, dst, (size_t)0,
+                       (const double*)nullptr, (double*)nullptr);
+}
+
 // factor A_c = L_c L_c^T and form L_c^-1 (+ transpose) into buffer `buf`: LDS-resident single workgroup up to 90
 // unknowns, blocked over the whole chip beyond
 template <int D>
@@ -486,15 +503,14 @@ int coarse_factor(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
     const int nc = h->nc, ncb = h->ncb;
     if (nc <= 90) {                                        // 2 nc^2 doubles of dynamic LDS (<= 130 KB)
         const size_t chol_lds = 2 * (size_t)nc * nc * sizeof(double);
-        HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)chol_lds));
+        if (ensure_dynamic_lds((const void*)k_coarse_chol<D, true>, (size_t)(chol_lds))) return -1;
         hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, st, ncb, h->Ac, h->Lci2[buf],
                            h->LciT2[buf], stat, nullptr);
     } else if (h->big_chol) {
         // blocked factorisation over the whole chip (chol_scratch: working copy of A_c, then the tiles' inverses)
         double* A = h->chol_scratch;
         double* Tinv = A + (size_t)nc * nc;
-        HIP_OK(hipMemcpyAsync(A, h->Ac, (size_t)nc * nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+        copy_doubles(st, A, h->Ac, (size_t)nc * nc);
         const int nsteps = cdiv(nc, PS_BC_W);
         for (int s2 = 0; s2 < nsteps; ++s2) {
             const int j0 = s2 * PS_BC_W, w = std::min(PS_BC_W, nc - j0), m = nc - j0 - w;
@@ -583,7 +599,7 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
                            h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
                            h->poses, h->pose_of_rid, h->coarse_basis, h->Bmat2[nb], h->bgv);
         if (!h->rows_attr_set) {
-            HIP_OK(hipFuncSetAttribute((const void*)k_rows_setup<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->rows_lds));
+            if (ensure_dynamic_lds((const void*)k_rows_setup<D>, (size_t)(h->rows_lds))) return -1;
             h->rows_attr_set = true;
         }
         hipLaunchKernelGGL(k_rows_setup<D>, dim3(nr), dim3(PS_RS_THREADS), h->rows_lds, h->stream, nr, ncb, h->row_ptr, h->col_idx,
@@ -632,7 +648,7 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
         h->mc_active = lag && h->cg_split;
         const int rpw = nc >= 192 ? 4 : 1;                 // fine block rows per border workgroup
         const int border_lds = (int)((size_t)rpw * D * nc * sizeof(double));
-        HIP_OK(hipFuncSetAttribute((const void*)k_coarse_border<D>, hipFuncAttributeMaxDynamicSharedMemorySize, border_lds));
+        if (ensure_dynamic_lds((const void*)k_coarse_border<D>, (size_t)border_lds)) return -1;
         if (lag) {
             const int use = h->lci_next;
             h->lci_cur = use;
@@ -802,11 +818,11 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
         const double rho = rr0 > 0.0 ? std::sqrt(rrf / rr0) : 1.0;
         ++h->cg_fallbacks;
         if (restarts == 3 || !(rho < 0.5)) {                // no progress to keep: start over with the classic PCG
-            if (restarts) HIP_OK(hipMemcpyAsync(h->g, gsaved, (size_t)nvec * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            if (restarts) copy_doubles(h->stream, h->g, gsaved, (size_t)nvec);
             return pcg_run<D>(h, tol, max_iters, iters_out, relres_out);
         }
         cg_fused_recover<D>(h, nullptr);                    // x of this pass
-        if (restarts == 0) HIP_OK(hipMemcpyAsync(gsaved, h->g, (size_t)nvec * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (restarts == 0) copy_doubles(h->stream, gsaved, h->g, (size_t)nvec);
         hipLaunchKernelGGL(k_vec_accumulate, dim3(cdiv(nvec, 256)), dim3(256), 0, h->stream, nvec, (const double*)h->x, xacc, restarts == 0);
         hipLaunchKernelGGL(k_bsr_residual<D>, dim3(cdiv(nvec, 256)), dim3(256), 0, h->stream, h->nr, h->row_ptr, h->col_idx, h->S,
                            (const double*)xacc, (const double*)gsaved, h->g);
@@ -817,7 +833,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
     cg_fused_recover<D>(h, nullptr);
     if (restarts) {                                         // x = (sum of the earlier passes) + this correction; g as it was
         hipLaunchKernelGGL(k_vec_accumulate, dim3(cdiv(nvec, 256)), dim3(256), 0, h->stream, nvec, (const double*)xacc, h->x, 0);
-        HIP_OK(hipMemcpyAsync(h->g, gsaved, (size_t)nvec * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        copy_doubles(h->stream, h->g, gsaved, (size_t)nvec);
     }
     int its = 0; double rel = 0.0;
     const int rc = cg_report(h, &its, &rel);
@@ -868,7 +884,7 @@ int linearize(ps_problem* h, double lambda) {
         StageTimer t(h, PS_ST_SCHUR, 1);
         const size_t lds = (size_t)PS_ST_SUBROWS * PS_ST_ROWD * sizeof(double);
         if (!h->st_attr_set) {
-            HIP_OK(hipFuncSetAttribute((const void*)k_schur_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (ensure_dynamic_lds((const void*)k_schur_stream, (size_t)(lds))) return -1;
             h->st_attr_set = true;
         }
         hipLaunchKernelGGL(k_schur_stream, dim3(h->st_ntiles), dim3(PS_ST_THREADS), lds, h->stream, h->st_tiles, h->st_subs,

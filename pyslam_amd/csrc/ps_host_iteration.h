@@ -218,7 +218,7 @@ int direct_solve_enqueue(ps_problem* h) {
         return -1;
     hipLaunchKernelGGL(k_bsr_to_dense<D>, dim3(1), dim3(256), 0, h->stream, nr, h->nnzb, h->brow_of, h->col_idx, h->S, h->dA);
     const size_t chol_lds = 2 * (size_t)n * n * sizeof(double);
-    HIP_OK(hipFuncSetAttribute((const void*)k_coarse_chol<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
+    if (ensure_dynamic_lds((const void*)k_coarse_chol<D, true>, (size_t)(chol_lds))) return -1;
     hipLaunchKernelGGL((k_coarse_chol<D, true>), dim3(1), dim3(1024), chol_lds, h->stream, nr, h->dA, h->dLi, h->dLiT,
                        h->status, nullptr);
     hipLaunchKernelGGL(k_direct_apply<D>, dim3(1), dim3(256), 0, h->stream, n, h->dLi, h->dLiT, h->g, h->x, h->status,

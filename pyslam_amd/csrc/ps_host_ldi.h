@@ -53,13 +53,13 @@ int ldi_ensure(ps_problem* h) {
     if (np > n) hipLaunchKernelGGL(k_ldi_pad_identity, dim3(cdiv(np - n, 64)), dim3(64), 0, h->stream, n, np, h->ldi_S32, 1.0f);
     HIP_OK(hipStreamSynchronize(h->stream));
     if (!h->ev_ldi) {
-        HIP_OK(hipEventCreateWithFlags(&h->ev_ldi, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&h->ev_ldi_sread, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&h->ev_ldi_ritz, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_ldi, PS_XSTREAM_EVENT_FLAGS));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_ldi_sread, PS_XSTREAM_EVENT_FLAGS));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_ldi_ritz, PS_XSTREAM_EVENT_FLAGS));
     }
     const size_t lds = (size_t)np * sizeof(double);
-    HIP_OK(hipFuncSetAttribute((const void*)k_ldi_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_OK(hipFuncSetAttribute((const void*)k_ldi_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ensure_dynamic_lds((const void*)k_ldi_init, (size_t)(lds))) return -1;
+    if (ensure_dynamic_lds((const void*)k_ldi_update, (size_t)(lds))) return -1;
     h->ldi_ready = true;
     return 0;
 }
@@ -113,7 +113,7 @@ int ldi_seed_enqueue(ps_problem* h, int its, double cost_now) {
     // c = 1.9 / (ritz_min + ritz_max) on the device (k_ldi_ritz): eig(c M0 S^) in (0, 1.9), Newton-Schulz contracts.
     // (`hist` was written by the CG on the solver stream; the host has synchronised with that stream since.)
     hipLaunchKernelGGL(k_ldi_ritz, dim3(1), dim3(64), 0, st, h->hist, h->hist_cap, h->status, h->ldi_coef);
-    HIP_OK(hipMemcpyAsync(h->ldi_Linv, h->Linv, (size_t)nr * D * D * sizeof(double), hipMemcpyDeviceToDevice, st));
+    copy_doubles(st, h->ldi_Linv, h->Linv, (size_t)nr * D * D);
     hipLaunchKernelGGL(k_ldi_scaled_dense<D>, dim3(h->nnzb), dim3(64), 0, st, h->brow_of, h->col_idx, h->S, h->ldi_Linv, h->ldi_S32, np);
     const double* Xsrc = h->ldi_x64;
     if (h->last_setup_lagx) Xsrc = h->X2[h->lci_cur];       // the system was built with the lagged X~ itself

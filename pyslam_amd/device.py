@@ -240,6 +240,13 @@ class DeviceProblem:
         nat.check(self._lib.ps_debug_factor_blocks(self._h, nat.f64p(r), nat.f64p(j1), nat.f64p(j2)))
         return r, j1, j2
 
+    def get_info(self):
+        """ps_problem_info as a dict, read now (sizes, and the solver counters: restarts, launches, lagged-inverse and
+        one-launch-PCG statistics)."""
+        info = nat.ProblemInfo()
+        nat.check(self._lib.ps_get_info(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in nat.ProblemInfo._fields_}
+
     def cg_restarts(self):
         """Restarts of the pipelined CG so far (ps_problem_info.cg_restarts)."""
         info = nat.ProblemInfo()

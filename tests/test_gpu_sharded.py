@@ -39,25 +39,18 @@ def test_one_rank_sharded_iteration_equals_the_unsharded_one(dist1, native, expl
         for d in (ref, sh.dev):
             d.set_option('cg_explicit_min_rows', 0)
             d.set_option('cg_split_min_rows', 0)
-    # Folded CG: bit for bit.  Explicit PCG (its coarse inverse is formed on the side stream by the blocked multi-workgroup
-    # factorisation at this size): bit for bit in 60 of 60 stand-alone repetitions with and without the one-launch form
-    # (tools/_flake.py, round 3), but twice a 1-ulp difference of the cost when run inside the whole suite -- cause not
-    # found (no out-of-bounds read: the suite passes with the table gaps poisoned, PS_ARENA_POISON=1; not stale memory).
-    # The explicit variant therefore allows two ulps on the cost and 1e-13 on the parameters.
-    ulp = 4e-16 if explicit else 0.
+    # Bit for bit, both variants.  (Round 3 had to allow the explicit variant two ulps: now and then its side-stream
+    # factorisation -- then on a LOW-PRIORITY stream -- returned a different inverse for the same A_c when it ran beside
+    # normal-priority kernels; tools/hunt_explicit_flake.py, DESIGN.md section 4.  The side stream is an ordinary stream now.)
     for _ in range(3):
         a = ref.gn_iteration(0., 1e-12, 1000, True)
         b = sh.gn_iteration(0., 1e-12, 1000, True)
-        assert abs(a[0] - b[0]) <= ulp * abs(a[0]) and a[2] == b[2]     # cost and CG iterations: identical
-        assert abs(a[1] - b[1]) <= 1e-15 * a[1] + (1e-12 * a[1] if explicit else 0.)   # ||dx||: summed in a different grouping
+        assert a[0] == b[0] and a[2] == b[2]                            # cost and CG iterations: identical
+        assert abs(a[1] - b[1]) <= 1e-15 * a[1]                         # ||dx||: summed in a different grouping
     pa, la = ref.get_params()
     pb, lb = sh.get_params()
-    if explicit:
-        assert np.abs(pa - pb).max() <= 1e-13 and np.abs(la - lb).max() <= 1e-12
-        assert abs(sh.eval_cost(True) - ref.eval_cost(True)) <= ulp * abs(a[0])
-    else:
-        assert np.array_equal(pa, pb) and np.array_equal(la, lb)
-        assert abs(sh.eval_cost(True) - ref.eval_cost(True)) == 0.
+    assert np.array_equal(pa, pb) and np.array_equal(la, lb)
+    assert sh.eval_cost(True) == ref.eval_cost(True)
     sh.close()
     ref.close()
 
