@@ -414,6 +414,60 @@ def case_metrics():
     print('  metrics: 80 poses, travelled %.1f m, endpoint error %.4f m' % (out['Tvw_cum_dists'][-1], out['Tvw_endpoint'][0]))
 
 
+_BILINEAR_REPAIRS = (('x = x[1]', 'x = x[0]'), ('y = y[1]', 'y = y[0]'), ('out[1] =', 'out[0] ='), ('np.int(', 'int('))
+
+
+def reference_bilinear_body():
+    """The reference's own image-lookup kernel, executed.  pyslam/utils.py:27-75 as committed cannot run: it reads
+    ``x[1]`` / ``y[1]`` and writes ``out[1]`` of the one-element arrays its '(n,m),(),()->()' layout hands it (:36-37,
+    :75), and calls ``np.int`` (:44, :47; removed from numpy 1.24).  The function's source is read from /root/reference
+    at generation time, exactly those four spellings are repaired (``_BILINEAR_REPAIRS``: the three subscripts to [0],
+    ``np.int`` to ``int``), every other token -- truncation, the four weights from the unclipped corners, the clamping,
+    the order of the final sum -- is the reference's, and the result is compiled and run here.  Nothing of it is copied
+    into the repository: the goldens hold inputs and outputs only.  Returns lookup(im2d, x, y) -> values."""
+    import ast
+    import inspect
+    src = inspect.getsource(sys.modules[ref_utils.__name__])
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == '_bilinear_interpolate')
+    body = ast.get_source_segment(src, fn)
+    body = body[body.index('def _bilinear_interpolate'):]            # without the decorator
+    for old, new in _BILINEAR_REPAIRS:
+        assert body.count(old) >= 1, old
+        body = body.replace(old, new)
+    scope = {'np': np}
+    exec(compile(body, REF + '/pyslam/utils.py (repaired subscripts)', 'exec'), scope)
+    kernel = scope['_bilinear_interpolate']
+
+    def lookup(im, x, y):
+        im = np.asarray(im, dtype=float)
+        x, y = np.atleast_1d(np.asarray(x, float)), np.atleast_1d(np.asarray(y, float))
+        out = np.zeros(len(x))
+        cell = np.zeros(1)
+        for k in range(len(x)):
+            kernel(im, x[k:k + 1], y[k:k + 1], cell)
+            out[k] = cell[0]
+        return out
+    return lookup
+
+
+def case_bilinear():
+    """Golden vectors of the image lookup itself (reference_bilinear_body): interior points, exact pixel centres, the last
+    row / column, and coordinates outside the image on every side (where the weights come from the unclipped corners and
+    the samples from the clamped ones)."""
+    lookup = reference_bilinear_body()
+    rng = np.random.default_rng(77)
+    h, w = 13, 17
+    im = rng.normal(size=(h, w)) * 50. + 100.
+    x = np.concatenate([rng.uniform(0, w - 1, 200), rng.integers(0, w, 30).astype(float), np.full(10, w - 1.),
+                        rng.uniform(w - 1, w + 2.5, 25), rng.uniform(-2.5, 0, 25), rng.uniform(0, w - 1, 30)])
+    y = np.concatenate([rng.uniform(0, h - 1, 200), rng.integers(0, h, 30).astype(float), rng.uniform(0, h - 1, 10),
+                        rng.uniform(0, h - 1, 25), rng.uniform(0, h - 1, 25), np.concatenate([rng.uniform(h - 1, h + 2, 15),
+                                                                                            rng.uniform(-2, 0, 15)])])
+    save('bilinear', im=im, x=x, y=y, out=lookup(im, x, y),
+         repairs=np.array(['%s -> %s' % r for r in _BILINEAR_REPAIRS]))
+
+
 def case_photometric():
     """PhotometricResidualSE3 (reference residuals/photometric_residual.py:38-161) on the exactly rendered plane scene
     of pyslam_amd.synthetic.photometric_scene: residual + Jacobian at two poses, and the dense pipeline's
@@ -421,17 +475,11 @@ def case_photometric():
 
     The reference's image lookup cannot run as committed (utils.py:36-37, :75 index one-element arrays at [1];
     its own test fails, and np.int is gone from numpy 2): the module-level name ``bilinear_interpolate`` the
-    residual calls is pointed at scipy.ndimage.map_coordinates(order=1, mode='nearest') -- bilinear weights with
-    the border rows / columns repeated, i.e. what the reference body computes for every pixel that passes
-    is_valid_measurement -- which is independent of this build's own restatement.  Everything else that executes
-    is the reference's code."""
-    import scipy.ndimage
+    residual calls is pointed at the reference's OWN kernel body with those four spellings repaired
+    (reference_bilinear_body above; round 2 used scipy.ndimage.map_coordinates here, which pinned nothing of the
+    reference's lookup).  Everything that executes is the reference's code."""
     import pyslam.residuals.photometric_residual as ref_photo
-
-    def lookup(im, x, y):
-        return scipy.ndimage.map_coordinates(np.asarray(im, dtype=float), [np.asarray(y, float), np.asarray(x, float)],
-                                             order=1, mode='nearest')
-    ref_photo.bilinear_interpolate = lookup
+    ref_photo.bilinear_interpolate = reference_bilinear_body()
     out = {}
     for tag, rgbd in (('stereo', False), ('rgbd', True)):
         sc = synthetic.photometric_scene(h=40, w=56, seed=5, rgbd=rgbd, noise=0.5)
@@ -498,6 +546,7 @@ def main():
     case_motion_only()
     case_ransac()
     case_metrics()
+    case_bilinear()
     case_photometric()
 
     lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=60, obs_per_lm=4, half_window=3, seed=5,

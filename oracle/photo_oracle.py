@@ -5,7 +5,9 @@ TEST INFRASTRUCTURE ONLY: imported by tests/ as the checker,
 never by the product path.  Works on plain tables (the constructor's outputs), one pixel per row, written
 with explicit per-pixel formulas rather than the product class's stacked einsum expressions.
 Pinned against tests/golden/photometric.npz, which oracle/gen_golden.py produced by running the reference
-class (its image lookup replaced by scipy.ndimage, see case_photometric there) and the reference Problem.
+class and the reference Problem, and -- the image lookup on its own -- against tests/golden/bilinear.npz: outputs of the
+reference's own kernel body with the four spellings that keep it from running repaired (x[1], y[1], out[1] -> [0],
+np.int -> int; gen_golden.py: reference_bilinear_body, which the photometric case uses too).
 """
 import numpy as np
 

@@ -103,6 +103,20 @@ def test_bilinear_lookup():
     assert out.shape == (5, 3) and np.allclose(out[:, 2], 3 * out[:, 0])
 
 
+def test_bilinear_lookup_is_the_reference_kernel_body():
+    """tests/golden/bilinear.npz: outputs of the reference's own ``_bilinear_interpolate`` (pyslam/utils.py:27-75) with the
+    four spellings that keep it from running repaired and nothing else (oracle/gen_golden.py: reference_bilinear_body; the
+    repairs are recorded in the fixture) -- 320 coordinates incl. pixel centres, the last row / column and points up to
+    2.5 pixels outside the image on every side.  Host function and oracle restate its arithmetic in its order: equal to
+    the last bit."""
+    from conftest import load_golden
+    g = load_golden('bilinear')
+    assert list(g['repairs']) == ['x = x[1] -> x = x[0]', 'y = y[1] -> y = y[0]', 'out[1] = -> out[0] =', 'np.int( -> int(']
+    assert ((g['x'] < 0) | (g['x'] > g['im'].shape[1] - 1) | (g['y'] < 0) | (g['y'] > g['im'].shape[0] - 1)).sum() >= 60
+    np.testing.assert_array_equal(bilinear_interpolate(g['im'], g['x'], g['y']), g['out'])
+    np.testing.assert_array_equal(po.bilinear(g['im'], g['x'], g['y']), g['out'])
+
+
 @pytest.mark.parametrize('tag', TAGS)
 @pytest.mark.parametrize('form', ['se3', 'split'])
 def test_oracle_gauss_newton_reproduces_the_reference_solve(gold, tag, form):
@@ -120,6 +134,48 @@ def test_oracle_gauss_newton_reproduces_the_reference_solve(gold, tag, form):
 def device_of(blk, loss, split=False):
     from pyslam_amd.device import PhotometricDevice
     return PhotometricDevice(blk, loss, split)
+
+
+@pytest.mark.gpu
+def test_device_image_lookup_against_the_reference_kernel_body():
+    """photo_bilinear (csrc/ps_photo.h) through the C ABI, one pixel at a time: a one-pixel problem at the identity pose whose
+    point projects to a golden coordinate, reference intensity 0, unit intensity variance, no depth variance, L2 loss has
+    cost = I(u, v)^2 / 2.  Every coordinate of tests/golden/bilinear.npz that is a valid measurement (strictly inside the
+    image: all the device ever looks up) must give the reference body's value; the others must be counted invalid."""
+    from conftest import load_golden
+    from pyslam_amd.device import PhotometricDevice
+    g = load_golden('bilinear')
+    im = np.ascontiguousarray(g['im'])
+    h, w = im.shape
+    cu, cv, fu, fv, b = 8.0, 6.0, 16.0, 16.0, 0.25
+
+    class OnePixel:
+        def __init__(self, x, y):
+            z = 2.0                                             # disparity fu b / z = 2: a valid stereo measurement
+            self.t = dict(pt_ref=np.array([[(x - cu) * z / fu, (y - cv) * z / fv, z]]), im_ref=np.zeros(1), im_jac=np.zeros((1, 2)),
+                          tri_jac_d=np.zeros((1, 3)), im_track=im, cam=(cu, cv, fu, fv, b), cam_type=0, cam_w=w, cam_h=h,
+                          intensity_covar=1.0, depth_covar=0.0)
+
+        def device_tables(self):
+            return self.t
+
+    checked = rejected = 0
+    for x, y, want in zip(g['x'], g['y'], g['out']):
+        dev = PhotometricDevice(OnePixel(x, y), L2Loss(), False)
+        dev.set_pose(np.eye(3), np.zeros(3))
+        cost = dev.eval_cost()
+        u, v = fu * ((x - cu) * 2.0 / fu) / 2.0 + cu, fv * ((y - cv) * 2.0 / fv) / 2.0 + cv     # what the device projects to
+        if 0 < u < w and 0 < v < h:
+            assert dev.num_valid == 1
+            look = po.bilinear(im, np.array([u]), np.array([v]))[0]                  # (u, v) can differ from (x, y) by an ulp
+            assert abs(look - want) <= 1e-11 * max(1., abs(want))
+            assert abs(np.sqrt(2. * cost) - abs(want)) <= 1e-11 * max(1., abs(want)), (x, y)
+            checked += 1
+        else:
+            assert dev.num_valid == 0 and cost == 0.
+            rejected += 1
+        dev.close()
+    assert checked >= 240 and rejected >= 40
 
 
 @pytest.mark.gpu
