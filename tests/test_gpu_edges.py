@@ -659,3 +659,48 @@ def test_handles_iterated_side_by_side_agree_bit_for_bit(seed):
     pa, qa = a.get_params()
     pb, qb = b.get_params()
     assert np.array_equal(pa, pb) and np.array_equal(qa, qb)
+
+
+@pytest.mark.parametrize('tiling', ['untiled', 'tiled'])
+def test_pipelined_schur_kernel_equals_the_one_chunk_kernel_bit_for_bit(monkeypatch, tiling):
+    """k_schur_pairs_db (two chunks of a wave in flight, rows and pair indices straight into LDS under a hand-counted
+    vmcnt, LDS read through inline assembly; csrc/ps_k_schur2.h) against round 2's k_schur_pairs (option "schur_pipeline"
+    0): the same pairs in the same order through the same accumulators, so the reduced system is equal to the last bit --
+    tasks of 1 to 40 chunks, ragged last chunks, tasks shorter than one chunk, duplicate observations of a pose (tasks
+    that write a diagonal block), with and without landmark tiles; and both equal the oracle's Schur complement."""
+    if tiling == 'tiled':
+        monkeypatch.setenv('PS_SCHUR_TILE_KB', '256')
+        monkeypatch.setenv('PS_SCHUR_TILE_MIN_MB', '0')
+    else:
+        monkeypatch.setenv('PS_SCHUR_TILE_KB', '0')
+    shapes = [dict(num_kf=70, num_lm=6000, obs_per_lm=7, half_window=10, seed=13),        # ~100 pairs per block
+              dict(num_kf=12, num_lm=9000, obs_per_lm=6, half_window=5, seed=14),         # long tasks: up to ~40 chunks
+              dict(num_kf=150, num_lm=1500, obs_per_lm=4, half_window=12, seed=15)]       # most tasks shorter than a chunk
+    for k, shape in enumerate(shapes):
+        lp, _ = synthetic.stereo_ba(**shape)
+        if k == 0:
+            dup = np.arange(0, lp.num_obs, 97)                    # a few landmarks seen twice from the same pose
+            lp.obs_pose = np.concatenate([lp.obs_pose, lp.obs_pose[dup]])
+            lp.obs_point = np.concatenate([lp.obs_point, lp.obs_point[dup]])
+            lp.obs_uvd = np.concatenate([lp.obs_uvd, lp.obs_uvd[dup] + 0.3])
+            lp.obs_grp = np.concatenate([lp.obs_grp, lp.obs_grp[dup]])
+            lp = lp.finalize()
+        dev = device(lp)
+        dev.linearize(0.)
+        rp, ci, vals, g = dev.reduced_system()
+        dev.set_option('schur_pipeline', 0)
+        dev.linearize(0.)
+        _, _, vals0, g0 = dev.reduced_system()
+        assert np.array_equal(vals, vals0) and np.array_equal(g, g0), k
+        dev.set_option('schur_pipeline', 1)
+        dev.linearize(0.)
+        assert np.array_equal(dev.reduced_system()[2], vals)       # and reproducible
+        S, gd = dev.reduced_dense()
+        import scipy.sparse.linalg as spla
+        P, b, _ = orc.normal_equations(lp, points_first=False)
+        n = S.shape[0]
+        P = P.tocsr()
+        Hpp, Hpl, Hll = P[:n, :n], P[:n, n:], P[n:, n:]
+        want = (Hpp - Hpl @ spla.spsolve(Hll.tocsc(), Hpl.T.tocsc())).toarray()
+        assert rel_err(S, want) < 1e-11, k
+        dev.close()
