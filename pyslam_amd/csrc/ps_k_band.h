@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void k_band_inverse(
 #pragma unroll
         for (int u = 0; u < U; ++u) { a[u] = an[u]; rd[u] = rdn[u]; }
     }
-    __threadfence();                                         // (lane 0's stores of x, read back by every lane below)
+    // lane 0's stores of x are read back by every lane of the SAME wave below: ordering within the compute unit is all that
+    // is needed (its L1 is coherent for its own waves).  This was __threadfence() until round 3: an agent-scope fence is an
+    // L2 write-back + invalidate on this eight-L2 part, one per column wave (2 406 at C2), beside the CG's kernels.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     auto bwd_fetch = [&](int i0, double* av, double* rv, double* xo) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
