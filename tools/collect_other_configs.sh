@@ -32,6 +32,14 @@ echo
 echo "# Schur pair kernel ablation at C3 (tools/schur_ablate.py: 1 no compute, 2 no fetch, 3 neither, 4 no a-rows)"
 python tools/schur_ablate.py 2>&1 | grep ablate
 echo
+echo "# the sharded protocol at shard size on ONE GPU (bench.py --force-sharded --kf 2000 --lm L: what rank 0 of an N-GPU run executes, 1-rank RCCL; DESIGN.md section 6)"
+for L in 500000 125000 62500; do
+  python bench.py --force-sharded --kf 2000 --lm $L --steps 10 --no-cpu-baseline --no-c4 2> /dev/null | grep '^{' | python -c "
+import json, sys
+b = json.loads(sys.stdin.read())
+print('landmarks', $L, 'iteration ms', b['value'], 'stage_ms', b.get('stage_ms'), 'native_rccl', b.get('native_rccl'))"
+done
+echo
 echo "# ps_problem_create stages (tools/create_time.py, PS_CREATE_TIMING=1)"
 PS_CREATE_TIMING=1 python tools/create_time.py 2>&1 | grep -v amdgpu.ids
 } > "$OUT/other_configs.txt"
