@@ -234,7 +234,19 @@ int ldi_solve_and_finish(ps_problem* h, double tol, int max_iters, int linesearc
         if (wait_published(h)) return -1;
         if (h->h_status[ST_LM_FAIL] || h->h_status[ST_DIAG_FAIL]) return 1;     // the standard path reports these
         if (h->h_status[ST_PCG_DONE] == 1) break;
-        if (h->h_status[ST_PCG_DONE] == 2 || step >= 2 * cap + 1) {   // NaN / not converged within the cap: X is not good enough
+        // Not converged yet.  Will it be within the cap?  The iterations so far give the rate (r.z drops by a constant factor per
+        // iteration to a good approximation): an inverse from a point the solve has left needs 20+ iterations, and finding
+        // that out by running all of ldi_cap of them costs the call ~0.13 ms plus a synchronisation per four launches.
+        bool hopeless = false;
+        {
+            const double rr0 = h->h_scalars[SC_RR0], rrf = h->h_scalars[SC_RRFINAL];
+            const int done_its = h->h_status[ST_PCG_ITERS];
+            if (done_its >= 3 && rr0 > 0.0 && rrf > 0.0 && rrf < rr0) {
+                const double per_it = std::log(rrf / rr0) / done_its;                // < 0
+                hopeless = std::log(tol2) / per_it > (double)cap + 1.0;
+            } else if (done_its >= 3 && !(rrf < rr0)) hopeless = true;               // not contracting at all
+        }
+        if (h->h_status[ST_PCG_DONE] == 2 || step >= 2 * cap + 1 || hopeless) {   // NaN / not (going to be) converged within the cap
             ++h->ldi_fallbacks;
             h->ldi_side_todo = false;
             ldi_invalidate(h);
