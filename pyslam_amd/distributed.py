@@ -216,6 +216,7 @@ class ShardedDeviceProblem:
         # finishes beside the CG and the next shard-local kernels, so every rank count refreshes every iteration; the
         # option stays for problems whose coarse matrix is not banded.)
         self._scal = torch.zeros(2, dtype=torch.float64, device=self.dev.reduce_tensor.device)
+        self._prof_level, self._pending_events, self._host_stage = 0, [], {}
 
     # ---- iteration -----------------------------------------------------
     def eval_cost(self, include_all_constant=True):
@@ -228,18 +229,22 @@ class ShardedDeviceProblem:
         if self.native is not None:
             return self.dev.gn_iteration(lm_lambda, pcg_tol, pcg_max_iters, linesearch)
         self.dev.linearize(lm_lambda)
-        if hasattr(self.dev, 'shard_pack'):
-            self.dev.shard_pack()                             # [upper(S) | g | cost | failure flag]
-        self.dist.all_reduce(self.dev.reduce_tensor)          # RCCL sum over xGMI, on the solver's stream
-        if hasattr(self.dev, 'shard_unpack'):
-            self.dev.shard_unpack()                           # mirrored back into S; a shard's failure reaches every rank
+        with self._timed('pack_unpack'):
+            if hasattr(self.dev, 'shard_pack'):
+                self.dev.shard_pack()                         # [upper(S) | g | cost | failure flag]
+        with self._timed('allreduce'):
+            self.dist.all_reduce(self.dev.reduce_tensor)      # RCCL sum over xGMI, on the solver's stream
+        with self._timed('pack_unpack'):
+            if hasattr(self.dev, 'shard_unpack'):
+                self.dev.shard_unpack()                       # mirrored back into S; a shard's failure reaches every rank
         if hasattr(self.dev, 'shard_tensor'):
             # fully asynchronous second half: the shard's {cost, ||dx_l||^2} are all-reduced on the
             # device; ONE synchronisation per iteration (gn_result)
             first = True
             while True:
                 last = self.dev.gn_solve_finish_enqueue(pcg_tol, pcg_max_iters, linesearch, first)
-                self.dist.all_reduce(self.dev.shard_tensor)
+                with self._timed('allreduce'):
+                    self.dist.all_reduce(self.dev.shard_tensor)
                 done, cost, dxl2, dxp2, its, rel = self.dev.gn_result()
                 if done or last:
                     return cost, float(np.sqrt(dxp2 + dxl2)), its, rel
@@ -261,10 +266,44 @@ class ShardedDeviceProblem:
         return self.dev.get_params()
 
     def set_profiling(self, level=2):
+        self._prof_level = level
         self.dev.set_profiling(level)
 
+    def _timed(self, stage):
+        """Event pair on the solver's stream around a collective / pack step of the torch.distributed fallback path (the
+        native path times the same stages inside the core: ps_get_stage_times 'allreduce' / 'pack_unpack')."""
+        outer = self
+
+        class _T:
+            def __enter__(self_t):
+                self_t.on = getattr(outer, '_prof_level', 0) >= 2 and outer.native is None and outer._torch.cuda.is_available() \
+                    and getattr(outer.dev, 'reduce_tensor', None) is not None and outer.dev.reduce_tensor.is_cuda
+                if self_t.on:
+                    self_t.a = outer._torch.cuda.Event(enable_timing=True); self_t.b = outer._torch.cuda.Event(enable_timing=True)
+                    self_t.a.record()
+
+            def __exit__(self_t, *exc):
+                if self_t.on:
+                    self_t.b.record()
+                    outer._pending_events.append((stage, self_t.a, self_t.b))
+                return False
+        return _T()
+
     def stage_times(self, reset=False):
-        return self.dev.stage_times(reset)
+        st = self.dev.stage_times(reset)
+        if self._pending_events or self._host_stage:
+            for stage, a, b in self._pending_events:
+                b.synchronize()
+                acc = self._host_stage.setdefault(stage, [0., 0])
+                acc[0] += a.elapsed_time(b); acc[1] += 1
+            self._pending_events = []
+            # (several events per iteration add up to one entry per iteration: divide by the iterations the core counted)
+            n_it = max([1] + [int(v[1]) for k, v in st.items() if k in ('iteration_total', 'landmark_pass', 'pose_pass')])
+            for stage, (ms, n) in self._host_stage.items():
+                st[stage] = (ms, n_it)
+            if reset:
+                self._host_stage = {}
+        return st
 
     def close(self):
         self.dev.close()
