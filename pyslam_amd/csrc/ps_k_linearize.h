@@ -119,16 +119,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
 
     const double damp = 1.0 + lambda;
     H00 *= damp; H11 *= damp; H22 *= damp;
-    // H_ll = C C^T
-    const double l00 = sqrt(H00);
-    const double l10 = H10 / l00, l20 = H20 / l00;
+    // H_ll = C C^T, M = C^-1 (lower): the reciprocal roots first, every quotient a product (ps_rsqrt: no division)
+    const double M00 = ps_rsqrt(H00);
+    const double l10 = H10 * M00, l20 = H20 * M00;
     const double d1 = H11 - l10 * l10;
-    const double l11 = sqrt(d1);
-    const double l21 = (H21 - l20 * l10) / l11;
+    const double M11 = ps_rsqrt(d1);
+    const double l21 = (H21 - l20 * l10) * M11;
     const double d2 = H22 - l20 * l20 - l21 * l21;
-    const double l22 = sqrt(d2);
-    // M = C^-1 (lower)
-    const double M00 = 1.0 / l00, M11 = 1.0 / l11, M22 = 1.0 / l22;
+    const double M22 = ps_rsqrt(d2);
     const double M10 = -l10 * M00 * M11;
     const double M21 = -l21 * M11 * M22;
     const double M20 = -(l20 * M00 + l21 * M10) * M22;

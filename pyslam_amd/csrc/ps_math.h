@@ -9,6 +9,17 @@
 #include <hip/hip_runtime.h>
 
 #define PS_DEV __device__ __forceinline__
+
+// 1 / sqrt(x) to double precision without a division: the hardware estimate (v_rsq_f64, ~2^-26 relative) and two
+// Newton steps y <- y (1.5 - 0.5 x y^2).  IEEE sqrt + IEEE division cost ~50 instructions on this target; the landmark
+// pass factors a 3 x 3 block per landmark with three roots and six quotients, a third of its instruction stream.
+__device__ __forceinline__ double ps_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * (1.5 - hx * y * y);
+    y = y * (1.5 - hx * y * y);
+    return y;
+}
 #define PS_SMALL_ANGLE 1e-8   // np.isclose(angle, 0.)
 
 // ---------------------------------------------------------------------------
