@@ -177,6 +177,22 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
                     int linesearch, double* cost_out, double* dx_norm_out,
                     int* pcg_iters_out, double* pcg_relres_out);
 
+/* The loop of Problem.solve (reference pyslam/problem.py:130-178) for a problem of ONE variable SE(3) pose observing
+   constant landmarks -- config 5, built per frame by pipelines/sparse.py:153-161 -- in ONE launch and one
+   synchronisation: the start cost, then iterations until `iterations > max_iters`, ||dx|| < min_update_norm, cost <
+   min_cost or the non-decreasing-step rules stop it (best parameters kept and restored as the reference does).
+   Options carry the reference's names; linesearch != 0: an iteration's cost is the cost after its (always full) step,
+   else the cost of its linearisation point (problem.py:188-192).  cost_history receives the reference's
+   _cost_history (at most max_iters + 2 entries), the pose is left updated.
+   Returns 0 = solved, 1 = not this kind of problem or history too long for `cap` (nothing done: iterate with
+   ps_gn_iteration), <0 = error. */
+typedef struct ps_solve_options {
+    int32_t max_iters, allow_nondecreasing_steps, max_nondecreasing_steps, linesearch;
+    double min_update_norm, min_cost, min_cost_decrease, lm_lambda;
+} ps_solve_options;
+int ps_motion_only_solve(ps_problem* h, const ps_solve_options* options, double* cost_history, int32_t cap,
+                         int32_t* n_history, int32_t* iterations, double* last_dx_norm);
+
 /* Second half of an iteration for a landmark-sharded (multi-GPU) caller, after
    ps_linearize -> all-reduce -> ps_solve_reduced: back-substitution, update, cost, ONE
    synchronisation.  Returns this shard's cost and ||dx_pose||^2, ||dx_point||^2 separately

@@ -38,6 +38,12 @@ class ProblemDesc(C.Structure):
 PS_DESC_DEVICE_PARAMS, PS_DESC_DEVICE_TABLES = 1, 2
 
 
+class SolveOptions(C.Structure):
+    _fields_ = [('max_iters', C.c_int32), ('allow_nondecreasing_steps', C.c_int32), ('max_nondecreasing_steps', C.c_int32),
+                ('linesearch', C.c_int32), ('min_update_norm', C.c_double), ('min_cost', C.c_double),
+                ('min_cost_decrease', C.c_double), ('lm_lambda', C.c_double)]
+
+
 class ProblemInfo(C.Structure):
     _fields_ = [
         ('dof', C.c_int32), ('num_poses', C.c_int32), ('num_reduced', C.c_int32),
@@ -81,6 +87,8 @@ SIGNATURES = {
     'ps_restore_params': (C.c_int, [H]),
     'ps_get_params': (C.c_int, [H, c_f64p, c_f64p]),
     'ps_set_params': (C.c_int, [H, c_f64p, c_f64p]),
+    'ps_motion_only_solve': (C.c_int, [H, C.POINTER(SolveOptions), c_f64p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_double)]),
     'ps_gn_iteration': (C.c_int, [H, C.c_double, C.c_double, C.c_int, C.c_int, c_f64p, c_f64p,
                                   C.POINTER(C.c_int), c_f64p]),
     'ps_gn_finish': (C.c_int, [H, C.c_int, c_f64p, c_f64p, c_f64p]),

@@ -369,6 +369,52 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
     return 0;
 }
 
+// Whole Problem.solve() loop of a one-pose motion-only problem in ONE launch (k_motion_only_solve)
+int ps_motion_only_solve(ps_problem* h, const ps_solve_options* o, double* cost_history, int32_t cap, int32_t* n_history,
+                         int32_t* iterations, double* last_dx_norm) {
+    if (!h || !o || !cost_history || !n_history) return fail("null argument");
+    const bool eligible = h->mo_fused && h->nv == 0 && h->F == 0 && h->nr == 1 && h->D == 6 && h->N == h->Np &&
+                          h->pcg_variant == 1 && h->max_pose_obs <= 2048;
+    const int need = o->max_iters + 2;                        // the start cost + at most max_iters + 1 iterations
+    if (!eligible || need + 4 > PS_MO_HIST_WORDS || need > cap) return 1;       // not an error: the caller iterates itself
+    h->cov_ready = false;
+    h->last_cost = h->prev_cost = -1.0;
+    if (!h->status_clean) {
+        HIP_OK(hipMemsetAsync(h->status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+        h->status_clean = true;
+    }
+    MoSolveOptions mo{};
+    mo.max_iters = o->max_iters; mo.allow_nondecreasing_steps = o->allow_nondecreasing_steps;
+    mo.max_nondecreasing_steps = o->max_nondecreasing_steps; mo.linesearch = o->linesearch;
+    mo.min_update_norm = o->min_update_norm; mo.min_cost = o->min_cost; mo.min_cost_decrease = o->min_cost_decrease;
+    mo.lambda = o->lm_lambda;
+    const ObsWide wp{h->sidx_p, h->stiff_tab};
+    const long long seq_now = ++h->seq;
+    StageTimer total(h, PS_ST_TOTAL, 2);
+    if (h->wide_obs)
+        hipLaunchKernelGGL(k_motion_only_solve<true>, dim3(1), dim3(PS_MO_THREADS), 0, h->stream, h->pitems, h->pitem_ptr, h->pobs,
+                           h->points, h->ogroups, h->poses, mo, h->x, h->status, h->scalars, h->h_mo_hist_dev, PS_MO_HIST_WORDS,
+                           h->h_status_dev, h->h_scalars_dev, h->h_seq_dev, seq_now, wp);
+    else
+        hipLaunchKernelGGL(k_motion_only_solve<false>, dim3(1), dim3(PS_MO_THREADS), 0, h->stream, h->pitems, h->pitem_ptr, h->pobs,
+                           h->points, h->ogroups, h->poses, mo, h->x, h->status, h->scalars, h->h_mo_hist_dev, PS_MO_HIST_WORDS,
+                           h->h_status_dev, h->h_scalars_dev, h->h_seq_dev, seq_now, wp);
+    total.stop();
+    if (wait_published(h)) return -1;
+    if (h->h_status[ST_DIAG_FAIL]) {
+        h->status_clean = false;
+        return fail("reduced system has a non-positive-definite diagonal block (gauge freedom? hold a pose constant or add a prior)");
+    }
+    const int n = (int)h->h_mo_hist[0];
+    if (n < 1 || n > cap) return fail("ps_motion_only_solve: cost history out of range");
+    for (int k = 0; k < n; ++k) cost_history[k] = h->h_mo_hist[3 + k];
+    *n_history = n;
+    if (iterations) *iterations = (int32_t)h->h_mo_hist[1];
+    if (last_dx_norm) *last_dx_norm = h->h_mo_hist[2];
+    h->last_cost = cost_history[n - 1];
+    return 0;
+}
+
 int ps_covariance_begin(ps_problem* h) {
     if (!h) return fail("null argument");
     if (linearize(h, 0.0)) return -1;

@@ -51,7 +51,7 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 //   * the pinned, host-mapped result words of a handle live in one 4 KB block;
 //   * arena blocks, mirrors, word blocks and streams of destroyed handles are kept (up to PS_POOL_KEEP each) and handed
 //     to the next ps_problem_create.
-constexpr size_t PS_ARENA_BYTES = 2u << 20, PS_ARENA_SMALL = 192u << 10, PS_WORDS_BYTES = 4096;
+constexpr size_t PS_ARENA_BYTES = 2u << 20, PS_ARENA_SMALL = 192u << 10, PS_WORDS_BYTES = 4096, PS_MO_HIST_WORDS = 256;
 constexpr size_t PS_POOL_KEEP = 8;
 struct PsPool {
     std::mutex mu;
@@ -299,6 +299,7 @@ struct ps_problem {
     long long *h_setup = nullptr, *h_setup_dev = nullptr;   // stamped by the last kernel of a lagged set-up: the side stream's inputs are complete
     long long setup_seq = 0;
     int32_t* arrivals = nullptr;
+    double *h_mo_hist = nullptr, *h_mo_hist_dev = nullptr;   // pinned: k_motion_only_solve's [entries, iterations, |dx|, cost history ...]
     int ncost_obs = 0, ncost_fac = 0, nsq = 0;
     // native RCCL: function pointer + communicator handed over by the binding (ps_set_collective)
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);

@@ -156,6 +156,179 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
 }
 
 // ---------------------------------------------------------------------------
+// The WHOLE solve of a one-pose motion-only problem in one launch (reference pipelines/sparse.py:153-161 builds such a
+// Problem per frame and calls solve(): config C5).  The loop of Problem.solve (reference problem.py:130-178) -- iterate,
+// record the cost, stop on max_iters / min_update_norm / min_cost / the non-decreasing-step rules, keep and restore the
+// best parameters -- needs nothing but the numbers this workgroup produces, so it runs here: one launch and one
+// synchronisation per FRAME instead of one per iteration (8.5 iterations on average at C5: 0.27-0.37 ms of launches and
+// host round trips for ~70 us of arithmetic).  Arithmetic and summation order are those of k_motion_only_iteration; the
+// cost after a step and the cost at the next linearisation point are the same sum, evaluated once.
+// ---------------------------------------------------------------------------
+struct MoSolveOptions {          // Options of the reference (problem.py:14-40) that the loop reads
+    int max_iters, allow_nondecreasing_steps, max_nondecreasing_steps, linesearch;
+    double min_update_norm, min_cost, min_cost_decrease, lambda;
+};
+
+template <bool WIDE>
+__global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_solve(
+    const PItem* __restrict__ items, const int32_t* __restrict__ pitem_ptr,
+    const LObs* __restrict__ pobs, const double* __restrict__ points, const ObsGroup* __restrict__ groups,
+    double* __restrict__ poses, MoSolveOptions opt, double* __restrict__ xout /* 6: the last step */,
+    int32_t* __restrict__ status, double* __restrict__ scalars,
+    double* __restrict__ hist /* pinned host: [0] = entries, [1] = iterations, [2] = last |dx|, [3..] cost history */, int hist_cap,
+    int32_t* __restrict__ hst, double* __restrict__ hsc, long long* __restrict__ hseq, long long seq, ObsWide wide)
+{
+    constexpr int NWV = PS_MO_THREADS / 64;
+    __shared__ double red[NWV][PS_NPOSE_ACC + 1];
+    __shared__ double tot[PS_NPOSE_ACC + 1];
+    __shared__ double sT[12], sBest[12];
+    __shared__ int s_done;
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+    const int ib = pitem_ptr[0], ie = pitem_ptr[1];
+    const int start = ib < ie ? items[ib].start : 0, end = ib < ie ? items[ie - 1].end : 0;
+    const int pose = ib < ie ? items[ib].pad : 0;
+    Se3 T = se3_load(poses + 12 * (size_t)pose);
+    // thread 0's loop state (Problem.solve's local variables)
+    double cost = 0.0, prev_cost = 0.0, last_dx = 100.0;
+    int nhist = 0, iters = 0, nondecreasing = 0;
+    for (;;) {
+        {
+            // ---- the 33 sums + the cost at T (k_motion_only_iteration's first phase, same order)
+            double acc[PS_NPOSE_ACC + 1];
+#pragma unroll
+            for (int k = 0; k <= PS_NPOSE_ACC; ++k) acc[k] = 0.0;
+            for (int i = start + t; i < end; i += PS_MO_THREADS) {
+                const LObs o = pobs[i];
+                const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
+                ReprojEval ev;
+                reproj_eval_obs<true, false, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
+                int n = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = a; b < 6; ++b)
+                        acc[n++] += ev.Jp[a] * ev.Jp[b] + ev.Jp[6 + a] * ev.Jp[6 + b] + ev.Jp[12 + a] * ev.Jp[12 + b];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    acc[21 + a] -= ev.Jp[a] * ev.r[0] + ev.Jp[6 + a] * ev.r[1] + ev.Jp[12 + a] * ev.r[2];
+                    acc[27 + a] += ev.Jp[a] * ev.Jp[a] + ev.Jp[6 + a] * ev.Jp[6 + a] + ev.Jp[12 + a] * ev.Jp[12 + a];
+                }
+                acc[PS_NPOSE_ACC] += ev.cost;
+            }
+            __syncthreads();                             // (red / tot of the previous round have been read)
+#pragma unroll
+            for (int k = 0; k <= PS_NPOSE_ACC; ++k) {
+                const double v = wave_sum(acc[k]);
+                if (lane == 0) red[w][k] = v;
+            }
+            __syncthreads();
+            if (t <= PS_NPOSE_ACC) {
+                double v = 0.0;
+#pragma unroll
+                for (int ww = 0; ww < NWV; ++ww) v += red[ww][t];
+                tot[t] = v;
+            }
+            __syncthreads();
+        }
+        // ---- thread 0: bookkeeping of the step that led here, then the next step
+        if (t == 0) {
+            int done = 0;
+            const double c_here = tot[PS_NPOSE_ACC];     // cost at the current T
+            if (nhist == 0) {                            // the start: Problem.solve's eval_cost
+                cost = c_here;
+                hist[3 + nhist++] = cost;
+            } else if (opt.linesearch) {                 // the step just taken is judged by the cost it led to
+                cost = c_here;
+                hist[3 + nhist++] = cost;
+                done = iters > opt.max_iters || last_dx < opt.min_update_norm || cost < opt.min_cost;
+                if (opt.allow_nondecreasing_steps) {
+                    if (nondecreasing == 0) se3_store(sBest, T);
+                    nondecreasing = (cost >= opt.min_cost_decrease * prev_cost) ? nondecreasing + 1 : 0;
+                    if (nondecreasing >= opt.max_nondecreasing_steps) { done = 1; T = se3_load(sBest); }
+                } else done = done || cost >= opt.min_cost_decrease * prev_cost;
+            }
+            double sq = 0.0;
+            if (!done) {
+                // H = J^T J (+ lambda diag) = L L^T ;  x = H^-1 g   (k_motion_only_iteration, verbatim)
+                double H[6][6], x[6];
+                bool ok = true;
+                int n = 0;
+                for (int a = 0; a < 6; ++a)
+                    for (int b = a; b < 6; ++b) { H[a][b] = tot[n]; H[b][a] = tot[n]; ++n; }
+                for (int a = 0; a < 6; ++a) H[a][a] += opt.lambda * tot[27 + a];
+                for (int j = 0; j < 6; ++j) {
+                    double d = H[j][j];
+                    for (int k = 0; k < j; ++k) d -= H[j][k] * H[j][k];
+                    ok = ok && (d > 0.0);
+                    const double l = sqrt(d);
+                    H[j][j] = l;
+                    for (int i = j + 1; i < 6; ++i) {
+                        double v = H[i][j];
+                        for (int k = 0; k < j; ++k) v -= H[i][k] * H[j][k];
+                        H[i][j] = v / l;
+                    }
+                }
+                for (int i = 0; i < 6; ++i) {
+                    double v = tot[21 + i];
+                    for (int k = 0; k < i; ++k) v -= H[i][k] * x[k];
+                    x[i] = v / H[i][i];
+                }
+                for (int i = 5; i >= 0; --i) {
+                    double v = x[i];
+                    for (int k = i + 1; k < 6; ++k) v -= H[k][i] * x[k];
+                    x[i] = v / H[i][i];
+                }
+                if (!ok) { atomicAdd(&status[ST_DIAG_FAIL], 1); done = 2; }
+                else {
+                    for (int k = 0; k < 6; ++k) { xout[k] = x[k]; sq += x[k] * x[k]; }
+                    prev_cost = cost;
+                    ++iters;
+                    last_dx = sqrt(sq);
+                    T = se3_mul(se3_exp(x), T);
+                    if (!opt.linesearch) {               // the step is judged by the cost of its linearisation point
+                        hist[3 + nhist++] = c_here;
+                        cost = c_here;
+                        done = iters > opt.max_iters || last_dx < opt.min_update_norm || cost < opt.min_cost;
+                        if (opt.allow_nondecreasing_steps) {
+                            if (nondecreasing == 0) se3_store(sBest, T);
+                            // (prev_cost: the cost recorded one iteration earlier -- at the first iteration the start cost,
+                            //  i.e. this very number: the reference counts that as a non-decreasing step, and so does this)
+                            nondecreasing = (cost >= opt.min_cost_decrease * prev_cost) ? nondecreasing + 1 : 0;
+                            if (nondecreasing >= opt.max_nondecreasing_steps) { done = 1; T = se3_load(sBest); }
+                        } else done = done || cost >= opt.min_cost_decrease * prev_cost;
+                    }
+                }
+            }
+            if (nhist >= hist_cap - 4 && !done) done = 3;             // (the caller sized hist for max_iters + 2 entries)
+            se3_store(sT, T);
+            s_done = done;
+        }
+        __syncthreads();
+        T = se3_load(sT);
+        if (s_done) break;
+    }
+    if (t == 0) {
+        se3_store(poses + 12 * (size_t)pose, T);
+        hist[0] = (double)nhist; hist[1] = (double)iters; hist[2] = last_dx;
+        scalars[opt.linesearch ? SC_COST : SC_LINCOST] = cost;
+        scalars[SC_DXP2] = last_dx * last_dx; scalars[SC_DXL2] = 0.0;
+        scalars[SC_RR0] = 1.0; scalars[SC_RRFINAL] = 0.0;
+        status[ST_PCG_DONE] = 1; status[ST_PCG_ITERS] = 0;
+    }
+    __syncthreads();
+    __threadfence();
+    if (hst) {
+        if (t < ST_NWORDS) hst[t] = status[t];
+        else if (t < ST_NWORDS + SC_NWORDS) hsc[t - ST_NWORDS] = scalars[t - ST_NWORDS];
+        __syncthreads();
+        if (t == 0) {
+            __threadfence_system();
+            *reinterpret_cast<volatile long long*>(hseq) = seq;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // back-substitution, retraction, cost, small reductions.
 // `gate`: when non-null the kernel returns unless the CG has flagged convergence
 // (status[ST_PCG_DONE]); ps_gn_iteration enqueues this tail right behind the CG launches

@@ -60,6 +60,10 @@ class Options:
         # VALUES instead of walking every block again (0.29 s at 500 000 blocks).  Default False = the reference's
         # semantics: everything is re-read on every call (pyslam/problem.py:338-360).
         self.static_blocks = False
+        # solve() of a one-pose motion-only Problem (the per-frame Problem of the reference's sparse pipeline) runs its
+        # whole loop -- iterations, stopping rules, best-parameter bookkeeping -- in one device launch.  False: one call
+        # per iteration, as every other problem shape.  Same decisions, same cost history either way.
+        self.fused_solve_loop = True
 
 
 class Problem:
@@ -287,6 +291,17 @@ class Problem:
             dev = None
         opt = self.options
         self.solver_stats = []
+
+        # a single pose against constant landmarks (the per-frame Problem of pipelines/sparse.py): this whole loop runs on
+        # the device in one launch; identical decisions, identical cost history
+        fused = getattr(dev, 'motion_only_solve', None) if dev is not None and opt.fused_solve_loop else None
+        if fused is not None:
+            out = fused(opt, opt.linesearch_max_iters > 0)
+            if out is not None:
+                self._cost_history, iters, _ = out
+                self.solver_stats = [(0, 0.0)] * iters
+                self._write_back(dev)
+                return self.param_dict
 
         cost = dev.eval_cost(True) if dev is not None else self._eval_cost_host()
         dx_norm = 100.
