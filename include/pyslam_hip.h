@@ -183,7 +183,8 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
    min_cost or the non-decreasing-step rules stop it (best parameters kept and restored as the reference does).
    Options carry the reference's names; linesearch != 0: an iteration's cost is the cost after its (always full) step,
    else the cost of its linearisation point (problem.py:188-192).  cost_history receives the reference's
-   _cost_history (at most max_iters + 2 entries), the pose is left updated.
+   _cost_history (at most max_iters + 2 entries), the pose is left updated and, if pose12_out is not NULL, also returned
+   ([R row-major | t]: no second copy from the device).
    Returns 0 = solved, 1 = not this kind of problem or history too long for `cap` (nothing done: iterate with
    ps_gn_iteration), <0 = error. */
 typedef struct ps_solve_options {
@@ -191,7 +192,7 @@ typedef struct ps_solve_options {
     double min_update_norm, min_cost, min_cost_decrease, lm_lambda;
 } ps_solve_options;
 int ps_motion_only_solve(ps_problem* h, const ps_solve_options* options, double* cost_history, int32_t cap,
-                         int32_t* n_history, int32_t* iterations, double* last_dx_norm);
+                         int32_t* n_history, int32_t* iterations, double* last_dx_norm, double* pose12_out);
 
 /* Second half of an iteration for a landmark-sharded (multi-GPU) caller, after
    ps_linearize -> all-reduce -> ps_solve_reduced: back-substitution, update, cost, ONE

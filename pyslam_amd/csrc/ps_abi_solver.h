@@ -371,12 +371,12 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
 
 // Whole Problem.solve() loop of a one-pose motion-only problem in ONE launch (k_motion_only_solve)
 int ps_motion_only_solve(ps_problem* h, const ps_solve_options* o, double* cost_history, int32_t cap, int32_t* n_history,
-                         int32_t* iterations, double* last_dx_norm) {
+                         int32_t* iterations, double* last_dx_norm, double* pose12_out) {
     if (!h || !o || !cost_history || !n_history) return fail("null argument");
     const bool eligible = h->mo_fused && h->nv == 0 && h->F == 0 && h->nr == 1 && h->D == 6 && h->N == h->Np &&
                           h->pcg_variant == 1 && h->max_pose_obs <= 2048;
     const int need = o->max_iters + 2;                        // the start cost + at most max_iters + 1 iterations
-    if (!eligible || need + 4 > PS_MO_HIST_WORDS || need > cap) return 1;       // not an error: the caller iterates itself
+    if (!eligible || need + 16 > PS_MO_HIST_WORDS || need > cap) return 1;       // not an error: the caller iterates itself
     h->cov_ready = false;
     h->last_cost = h->prev_cost = -1.0;
     if (!h->status_clean) {
@@ -407,7 +407,8 @@ int ps_motion_only_solve(ps_problem* h, const ps_solve_options* o, double* cost_
     }
     const int n = (int)h->h_mo_hist[0];
     if (n < 1 || n > cap) return fail("ps_motion_only_solve: cost history out of range");
-    for (int k = 0; k < n; ++k) cost_history[k] = h->h_mo_hist[3 + k];
+    for (int k = 0; k < n; ++k) cost_history[k] = h->h_mo_hist[15 + k];
+    if (pose12_out) for (int k = 0; k < 12; ++k) pose12_out[k] = h->h_mo_hist[3 + k];
     *n_history = n;
     if (iterations) *iterations = (int32_t)h->h_mo_hist[1];
     if (last_dx_norm) *last_dx_norm = h->h_mo_hist[2];

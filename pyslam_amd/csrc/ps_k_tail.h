@@ -164,6 +164,7 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
 // host round trips for ~70 us of arithmetic).  Arithmetic and summation order are those of k_motion_only_iteration; the
 // cost after a step and the cost at the next linearisation point are the same sum, evaluated once.
 // ---------------------------------------------------------------------------
+#define PS_MO_SOLVE_OBS 4                     // observations per thread: 4 x 512 = the 2 048 of the one-launch limit
 struct MoSolveOptions {          // Options of the reference (problem.py:14-40) that the loop reads
     int max_iters, allow_nondecreasing_steps, max_nondecreasing_steps, linesearch;
     double min_update_norm, min_cost, min_cost_decrease, lambda;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_solve(
     const LObs* __restrict__ pobs, const double* __restrict__ points, const ObsGroup* __restrict__ groups,
     double* __restrict__ poses, MoSolveOptions opt, double* __restrict__ xout /* 6: the last step */,
     int32_t* __restrict__ status, double* __restrict__ scalars,
-    double* __restrict__ hist /* pinned host: [0] = entries, [1] = iterations, [2] = last |dx|, [3..] cost history */, int hist_cap,
+    double* __restrict__ hist /* pinned host: [0] = entries, [1] = iterations, [2] = last |dx|, [3..14] final pose, [15..] cost history */, int hist_cap,
     int32_t* __restrict__ hst, double* __restrict__ hsc, long long* __restrict__ hseq, long long seq, ObsWide wide)
 {
     constexpr int NWV = PS_MO_THREADS / 64;
@@ -188,6 +189,16 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_solve(
     const int start = ib < ie ? items[ib].start : 0, end = ib < ie ? items[ie - 1].end : 0;
     const int pose = ib < ie ? items[ib].pad : 0;
     Se3 T = se3_load(poses + 12 * (size_t)pose);
+    // observations and their (constant) landmarks: fetched ONCE, kept in registers across the iterations (at most
+    // PS_MO_SOLVE_OBS per thread: the one-launch path stops at 2 048 observations per pose)
+    LObs obs[PS_MO_SOLVE_OBS];
+    double pwr[PS_MO_SOLVE_OBS][3];
+#pragma unroll
+    for (int q = 0; q < PS_MO_SOLVE_OBS; ++q) {
+        const int i = start + t + q * PS_MO_THREADS;
+        obs[q] = pobs[i < end ? i : (end > start ? end - 1 : 0)];
+        pwr[q][0] = points[3 * (size_t)obs[q].point]; pwr[q][1] = points[3 * (size_t)obs[q].point + 1]; pwr[q][2] = points[3 * (size_t)obs[q].point + 2];
+    }
     // thread 0's loop state (Problem.solve's local variables)
     double cost = 0.0, prev_cost = 0.0, last_dx = 100.0;
     int nhist = 0, iters = 0, nondecreasing = 0;
@@ -197,11 +208,12 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_solve(
             double acc[PS_NPOSE_ACC + 1];
 #pragma unroll
             for (int k = 0; k <= PS_NPOSE_ACC; ++k) acc[k] = 0.0;
-            for (int i = start + t; i < end; i += PS_MO_THREADS) {
-                const LObs o = pobs[i];
-                const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
+#pragma unroll
+            for (int q = 0; q < PS_MO_SOLVE_OBS; ++q) {
+                const int i = start + t + q * PS_MO_THREADS;
+                if (i >= end) break;
                 ReprojEval ev;
-                reproj_eval_obs<true, false, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
+                reproj_eval_obs<true, false, WIDE>(T, pwr[q], &obs[q].u, groups, PS_GRP_OF(obs[q]), wide, i, ev);
                 int n = 0;
 #pragma unroll
                 for (int a = 0; a < 6; ++a)
@@ -236,10 +248,10 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_solve(
             const double c_here = tot[PS_NPOSE_ACC];     // cost at the current T
             if (nhist == 0) {                            // the start: Problem.solve's eval_cost
                 cost = c_here;
-                hist[3 + nhist++] = cost;
+                hist[15 + nhist++] = cost;
             } else if (opt.linesearch) {                 // the step just taken is judged by the cost it led to
                 cost = c_here;
-                hist[3 + nhist++] = cost;
+                hist[15 + nhist++] = cost;
                 done = iters > opt.max_iters || last_dx < opt.min_update_norm || cost < opt.min_cost;
                 if (opt.allow_nondecreasing_steps) {
                     if (nondecreasing == 0) se3_store(sBest, T);
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_solve(
                     last_dx = sqrt(sq);
                     T = se3_mul(se3_exp(x), T);
                     if (!opt.linesearch) {               // the step is judged by the cost of its linearisation point
-                        hist[3 + nhist++] = c_here;
+                        hist[15 + nhist++] = c_here;
                         cost = c_here;
                         done = iters > opt.max_iters || last_dx < opt.min_update_norm || cost < opt.min_cost;
                         if (opt.allow_nondecreasing_steps) {
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_solve(
                     }
                 }
             }
-            if (nhist >= hist_cap - 4 && !done) done = 3;             // (the caller sized hist for max_iters + 2 entries)
+            if (nhist >= hist_cap - 16 && !done) done = 3;             // (the caller sized hist for max_iters + 2 entries)
             se3_store(sT, T);
             s_done = done;
         }
@@ -309,6 +321,7 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_solve(
     }
     if (t == 0) {
         se3_store(poses + 12 * (size_t)pose, T);
+        se3_store(hist + 3, T);
         hist[0] = (double)nhist; hist[1] = (double)iters; hist[2] = last_dx;
         scalars[opt.linesearch ? SC_COST : SC_LINCOST] = cost;
         scalars[SC_DXP2] = last_dx * last_dx; scalars[SC_DXL2] = 0.0;

@@ -92,22 +92,24 @@ class DeviceProblem:
 
     def motion_only_solve(self, opt, linesearch):
         """Problem.solve's whole loop in one launch (ps_motion_only_solve) for a one-pose motion-only problem.
-        -> (cost history, iterations, last ||dx||) or None when the problem is not of that kind (iterate instead)."""
+        -> (cost history, iterations, last ||dx||, final pose row) or None when the problem is not of that kind (iterate
+        instead)."""
         o = nat.SolveOptions()
         o.max_iters, o.allow_nondecreasing_steps = int(opt.max_iters), int(bool(opt.allow_nondecreasing_steps))
         o.max_nondecreasing_steps, o.linesearch = int(opt.max_nondecreasing_steps), int(bool(linesearch))
         o.min_update_norm, o.min_cost = float(opt.min_update_norm), float(opt.min_cost)
         o.min_cost_decrease, o.lm_lambda = float(opt.min_cost_decrease), float(getattr(opt, 'lm_lambda', 0.))
         cap = o.max_iters + 2
-        if cap < 2 or cap > 250:
+        if cap < 2 or cap > 238:
             return None
-        hist = np.zeros(cap)
+        hist, pose = np.zeros(cap), np.zeros(12)
         n, its, dxn = C.c_int32(), C.c_int32(), C.c_double()
-        rc = self._lib.ps_motion_only_solve(self._h, C.byref(o), nat.f64p(hist), cap, C.byref(n), C.byref(its), C.byref(dxn))
+        rc = self._lib.ps_motion_only_solve(self._h, C.byref(o), nat.f64p(hist), cap, C.byref(n), C.byref(its), C.byref(dxn),
+                                            nat.f64p(pose))
         if rc == 1:
             return None
         nat.check(rc)
-        return hist[:n.value].tolist(), its.value, dxn.value
+        return hist[:n.value].tolist(), its.value, dxn.value, pose
 
     def gn_finish(self, linesearch=True):
         """-> (shard cost, ||dx_pose||^2, ||dx_point||^2); parameters are updated."""

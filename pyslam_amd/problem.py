@@ -214,8 +214,9 @@ class Problem:
         from pyslam_amd.distributed import ShardedProblemView
         return ShardedProblemView(lp, dist)
 
-    def _write_back(self, dev):
-        """Copy the device parameter tables into the live param_dict objects."""
+    def _write_back(self, dev, poses=None):
+        """Copy the device parameter tables into the live param_dict objects (`poses`: rows the caller already holds, for
+        a problem without named landmarks)."""
         form = self._photometric_form()
         if form:
             R, t = dev.get_pose()
@@ -232,7 +233,10 @@ class Problem:
                     self.param_dict[keys[1]] = t
             return
         lp = dev.lp
-        poses, points = dev.get_params()
+        if poses is None or len(lp.point_keys):
+            poses, points = dev.get_params()
+        else:
+            points = ()
         for key, row in zip(lp.pose_keys, poses):
             R, t = lowering.unpack_pose(row, lp.dof)
             T = self.param_dict[key]
@@ -298,9 +302,9 @@ class Problem:
         if fused is not None:
             out = fused(opt, opt.linesearch_max_iters > 0)
             if out is not None:
-                self._cost_history, iters, _ = out
+                self._cost_history, iters, _, pose = out
                 self.solver_stats = [(0, 0.0)] * iters
-                self._write_back(dev)
+                self._write_back(dev, poses=pose.reshape(1, 12))      # (the call returned the pose: no second copy)
                 return self.param_dict
 
         cost = dev.eval_cost(True) if dev is not None else self._eval_cost_host()

@@ -81,5 +81,6 @@ def test_only_single_pose_motion_only_problems_take_the_one_launch_loop():
     opt.max_iters = 400                                       # history longer than the pinned block holds
     assert dev1.motion_only_solve(opt, True) is None
     opt.max_iters = 20
-    hist, its, dxn = dev1.motion_only_solve(opt, True)
+    hist, its, dxn, pose = dev1.motion_only_solve(opt, True)
     assert len(hist) == its + 1 and hist[-1] <= hist[0]
+    assert np.array_equal(pose, dev1.get_params()[0][0])
