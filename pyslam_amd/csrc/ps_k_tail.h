@@ -9,6 +9,51 @@
 // solve, retraction, post-step cost; the last workgroup to arrive sums the per-pose {cost, |dx|^2}
 // in pose order and publishes status + scalars to pinned host memory (sequence word).
 // ---------------------------------------------------------------------------
+// 6 x 6 normal equations of one pose from the 33 sums (21 upper entries, 6 gradient entries, 6 diagonal entries for the
+// damping): H = J^T J + lambda diag = L L^T, x = H^-1 g.  One thread; reciprocal roots (ps_rsqrt) and products instead
+// of 6 roots and 27 quotients.  false: a pivot was not positive.
+PS_DEV bool mo_solve6(const double* __restrict__ tot, double lambda, double* __restrict__ x) {
+    double H[6][6], il[6];
+    bool ok = true;
+    int n = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) { H[a][b] = tot[n]; H[b][a] = tot[n]; ++n; }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) H[a][a] += lambda * tot[27 + a];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = H[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= H[j][k] * H[j][k];
+        ok = ok && (d > 0.0);
+        il[j] = ps_rsqrt(d);                                 // 1 / L_jj
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double v = H[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= H[i][k] * H[j][k];
+            H[i][j] = v * il[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = tot[21 + i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= H[i][k] * x[k];
+        x[i] = v * il[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double v = x[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) v -= H[k][i] * x[k];
+        x[i] = v * il[i];
+    }
+    return ok;
+}
+
 #define PS_MO_THREADS 512
 template <bool WIDE>
 __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
@@ -66,34 +111,8 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_iteration(
     double sq = 0.0;
     if (t == 0) {
         // H = J^T J (+ lambda diag) = L L^T ;  x = H^-1 g
-        double H[6][6], x[6];
-        bool ok = true;
-        int n = 0;
-        for (int a = 0; a < 6; ++a)
-            for (int b = a; b < 6; ++b) { H[a][b] = tot[n]; H[b][a] = tot[n]; ++n; }
-        for (int a = 0; a < 6; ++a) H[a][a] += lambda * tot[27 + a];
-        for (int j = 0; j < 6; ++j) {
-            double d = H[j][j];
-            for (int k = 0; k < j; ++k) d -= H[j][k] * H[j][k];
-            ok = ok && (d > 0.0);
-            const double l = sqrt(d);
-            H[j][j] = l;
-            for (int i = j + 1; i < 6; ++i) {
-                double v = H[i][j];
-                for (int k = 0; k < j; ++k) v -= H[i][k] * H[j][k];
-                H[i][j] = v / l;
-            }
-        }
-        for (int i = 0; i < 6; ++i) {
-            double v = tot[21 + i];
-            for (int k = 0; k < i; ++k) v -= H[i][k] * x[k];
-            x[i] = v / H[i][i];
-        }
-        for (int i = 5; i >= 0; --i) {
-            double v = x[i];
-            for (int k = i + 1; k < 6; ++k) v -= H[k][i] * x[k];
-            x[i] = v / H[i][i];
-        }
+        double x[6];
+        const bool ok = mo_solve6(tot, lambda, x);
         if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
         for (int k = 0; k < 6; ++k) { xout[(size_t)rid * 6 + k] = x[k]; sq += x[k] * x[k]; }
         const Se3 Tn = se3_mul(se3_exp(x), T);
@@ -261,35 +280,9 @@ __global__ __launch_bounds__(PS_MO_THREADS) void k_motion_only_solve(
             }
             double sq = 0.0;
             if (!done) {
-                // H = J^T J (+ lambda diag) = L L^T ;  x = H^-1 g   (k_motion_only_iteration, verbatim)
-                double H[6][6], x[6];
-                bool ok = true;
-                int n = 0;
-                for (int a = 0; a < 6; ++a)
-                    for (int b = a; b < 6; ++b) { H[a][b] = tot[n]; H[b][a] = tot[n]; ++n; }
-                for (int a = 0; a < 6; ++a) H[a][a] += opt.lambda * tot[27 + a];
-                for (int j = 0; j < 6; ++j) {
-                    double d = H[j][j];
-                    for (int k = 0; k < j; ++k) d -= H[j][k] * H[j][k];
-                    ok = ok && (d > 0.0);
-                    const double l = sqrt(d);
-                    H[j][j] = l;
-                    for (int i = j + 1; i < 6; ++i) {
-                        double v = H[i][j];
-                        for (int k = 0; k < j; ++k) v -= H[i][k] * H[j][k];
-                        H[i][j] = v / l;
-                    }
-                }
-                for (int i = 0; i < 6; ++i) {
-                    double v = tot[21 + i];
-                    for (int k = 0; k < i; ++k) v -= H[i][k] * x[k];
-                    x[i] = v / H[i][i];
-                }
-                for (int i = 5; i >= 0; --i) {
-                    double v = x[i];
-                    for (int k = i + 1; k < 6; ++k) v -= H[k][i] * x[k];
-                    x[i] = v / H[i][i];
-                }
+                // H = J^T J (+ lambda diag) = L L^T ;  x = H^-1 g   (the function k_motion_only_iteration calls)
+                double x[6];
+                const bool ok = mo_solve6(tot, opt.lambda, x);
                 if (!ok) { atomicAdd(&status[ST_DIAG_FAIL], 1); done = 2; }
                 else {
                     for (int k = 0; k < 6; ++k) { xout[k] = x[k]; sq += x[k] * x[k]; }
