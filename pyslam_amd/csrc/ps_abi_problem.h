@@ -17,11 +17,13 @@ int ps_problem_destroy(ps_problem* h) {
                 h->host_calls, h->host_call_ns * 1e-3 / h->host_calls, h->host_wait_ns * 1e-3 / h->host_calls, h->host_waits);
     hipStreamSynchronize(h->stream);
     if (h->side) hipStreamSynchronize(h->side);
+    if (h->ldi_stream) hipStreamSynchronize(h->ldi_stream);
     for (void* p : h->allocs) hipFree(p);
     h->arena_release();            // arena block, its pinned mirror and the pinned result words go back to the process-wide pool
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->ev_ldi) { hipEventDestroy(h->ev_ldi); hipEventDestroy(h->ev_ldi_sread); hipEventDestroy(h->ev_ldi_ritz); }
-    if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); hipEventDestroy(h->ev_acdone); }
+    if (h->ldi_stream && !ps_pool().give(ps_pool().side_streams, h->ldi_stream)) hipStreamDestroy(h->ldi_stream);
+    if (h->side) { hipStreamSynchronize(h->side); if (!h->side_poolable || !ps_pool().give(ps_pool().side_streams, h->side)) hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); hipEventDestroy(h->ev_acdone); }
     if (h->own_stream && h->stream && !ps_pool().give(ps_pool().streams, h->stream)) hipStreamDestroy(h->stream);
     delete h;
     return 0;

@@ -360,7 +360,7 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
             if (read_scalars(h)) return -1;
         }
     }
-    if (!h->guards.empty()) { hipStreamSynchronize(h->stream); if (h->side) hipStreamSynchronize(h->side); h->check_guards("after ps_gn_iteration"); }
+    if (!h->guards.empty()) { hipStreamSynchronize(h->stream); if (h->side) hipStreamSynchronize(h->side); if (h->ldi_stream) hipStreamSynchronize(h->ldi_stream); h->check_guards("after ps_gn_iteration"); }
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
     h->prev_cost = h->last_cost; h->last_cost = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
@@ -561,6 +561,8 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "ldi_cap") { if (value < 1 || value > 64) return fail("ldi_cap out of range (1 .. 64)"); h->ldi_cap = (int)value; }
     else if (n == "ldi_cost_tol") { if (!(value >= 0)) return fail("ldi_cost_tol must be >= 0"); h->ldi_cost_tol = value; }
     else if (n == "ldi_refresh_its") { if (value < 0 || value > 64) return fail("ldi_refresh_its out of range (0 .. 64)"); h->ldi_refresh_its = (int)value; }
+    else if (n == "ldi_direct") { h->ldi_direct_ok = value != 0.0; h->ldi_direct = value > 0.0; }
+    else if (n == "ldi_seed_lag") { if (value < 1 || value > 16) return fail("ldi_seed_lag out of range (1 .. 16)"); h->ldi_seed_lag = (int)value; }
     else if (n == "ldi_seed_steps") { if (value < 1 || value > 40) return fail("ldi_seed_steps out of range (1 .. 40)"); h->ldi_seed_steps = (int)value; }
     else if (n == "coarse_refresh_every") { if (value < 1 || value > 16) return fail("coarse_refresh_every must be 1..16"); h->xcg_refresh_every = (int)value; }
     else if (n == "coarse_lag_x") { h->lagx = value != 0.0; h->lci_next = -1; h->side_todo = false; }

@@ -57,6 +57,7 @@ struct PsPool {
     std::mutex mu;
     std::vector<void*> dev_arenas, host_arenas, host_words;
     std::vector<hipStream_t> streams;
+    std::vector<hipStream_t> side_streams;     // ordinary non-blocking streams (side / lagged-inverse work)
     template <typename T> bool take(std::vector<T>& v, T* out) {
         std::lock_guard<std::mutex> lk(mu);
         if (v.empty()) return false;
@@ -337,6 +338,12 @@ struct ps_problem {
     int2* ldi_krange = nullptr;
     int ldi_seed_lag = getenv("PS_LDI_SEED_LAG") ? atoi(getenv("PS_LDI_SEED_LAG")) : 2;   // calls between a seed's start and its first use (fixed schedule)
     int ldi_rejects = 0; long ldi_no_seed_before = 0;
+    // direct seed (ps_host_ldi.h: ldi_direct_enqueue): on for pose graphs from the start, for any problem after a rejected
+    // Newton-Schulz seed; option "ldi_direct" (-1 auto, 0 never, 1 always)
+    bool ldi_direct = false, ldi_direct_ok = true;
+    bool side_poolable = false;            // `side` is an ordinary non-blocking stream (no CU mask, no priority)
+    hipStream_t ldi_stream = nullptr;      // the direct seed's own stream: ~100 launches that must not sit in front of the coarse operator on `side`
+    double *ldi_A64 = nullptr, *ldi_Li = nullptr, *ldi_LiT = nullptr, *ldi_Tinv = nullptr; int32_t* ldi_stat = nullptr;
     float* ldi_coef = nullptr;      // device: seed scale c and the two Ritz values (k_ldi_ritz)
     double ldi_tag = -1.0, ldi_next_tag = -1.0, ldi_call_start_cost = -1.0;   // cost at the point the inverse in use / in flight was built at
     hipEvent_t ev_ldi_ritz = nullptr;
@@ -377,6 +384,10 @@ struct ps_problem {
         void* p = nullptr;
         static const bool guard_on = getenv("PS_ALLOC_GUARD") != nullptr;
         const size_t padded = (bytes + 255) & ~(size_t)255;
+        if (slab_left >= padded) {                                // inside a slab_reserve()d block: no call into the runtime
+            *out = (T*)slab; slab += padded; slab_left -= padded; dev_bytes += bytes;
+            return 0;
+        }
         hipError_t e = hipMalloc(&p, guard_on ? padded + 4096 : bytes);
         if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
         if (guard_on) {
@@ -393,6 +404,21 @@ struct ps_problem {
         *out = (T*)p;
         return 0;
     }
+    // One hipMalloc for a group of tables that are created together in the middle of a solve (the lagged inverse's ~20
+    // buffers: 0.5 ms of hipMalloc calls inside one iteration of a problem whose iterations take 0.1 ms).  The tables that
+    // follow are carved from it in 256-byte steps; what does not fit falls through to hipMalloc.
+    char* slab = nullptr; size_t slab_left = 0;
+    int slab_reserve(size_t bytes) {
+        if (getenv("PS_ALLOC_GUARD")) return 0;                   // guard mode wants every table on its own
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
+        if (getenv("PS_ARENA_POISON") && hipMemset(p, 0xFF, bytes) != hipSuccess) return fail("hipMemset (poison) failed");
+        allocs.push_back(p);
+        slab = (char*)p; slab_left = bytes;
+        return 0;
+    }
+    void slab_close() { slab = nullptr; slab_left = 0; }
     bool in_arena(const void* p) const {
         return arena_open && (const char*)p >= arena_dev && (const char*)p < arena_dev + PS_ARENA_BYTES;
     }

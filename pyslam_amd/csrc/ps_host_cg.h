@@ -181,6 +181,7 @@ int build_coarse(ps_problem* h) {
     const int nr = h->nr, D = h->D;
     if (h->ldi_ready) {                 // a rebuilt coarse level changes the sizes the lagged dense inverse was laid out for
         if (h->side) HIP_OK(hipStreamSynchronize(h->side));
+        if (h->ldi_stream) HIP_OK(hipStreamSynchronize(h->ldi_stream));
         h->ldi_ready = false; h->ldi_state = 0; h->ldi_cur = -1; h->ldi_side_todo = false; h->ldi_last_its = 0;
     }
     int G = h->coarse_req;
@@ -474,8 +475,10 @@ int build_coarse(ps_problem* h) {
             int prio_lo = 0, prio_hi = 0;
             HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
             HIP_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
-        } else
-            HIP_OK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        } else {
+            if (!ps_pool().take(ps_pool().side_streams, &h->side)) HIP_OK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            h->side_poolable = true;
+        }
         HIP_OK(hipEventCreateWithFlags(&h->ev_ac, PS_XSTREAM_EVENT_FLAGS));
         HIP_OK(hipEventCreateWithFlags(&h->ev_acdone, PS_XSTREAM_EVENT_FLAGS));
         HIP_OK(hipEventCreateWithFlags(&h->ev_chol, PS_XSTREAM_EVENT_FLAGS));
@@ -558,7 +561,7 @@ int xcg_coarse_inverse(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
         return 0;
     }
     if (coarse_factor<D>(h, st, buf, stat)) return -1;
-    hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, st, nc, h->Lci2[buf], (float*)h->LciT2[buf]);
+    hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, st, nc, h->Lci2[buf], (float*)h->LciT2[buf], nc);
     return 0;
 }
 

@@ -23,6 +23,12 @@ int ldi_ensure(ps_problem* h) {
     const int n = h->nr * h->D, np = (n + 63) / 64 * 64, kp = (h->nc + 15) / 16 * 16;
     h->ldi_n = n; h->ldi_np = np; h->ldi_kp = kp;
     const size_t nn = (size_t)np * np;
+    {   // everything the inverse needs -- the direct seed's fp64 workspace included when it will be used -- in one block
+        const bool direct = h->ldi_direct || (h->ldi_direct_ok && h->N == 0 && h->F > 0);
+        size_t bytes = 6 * nn * 4 + 2 * (size_t)np * kp * 4 + ((size_t)n * h->nc + (size_t)n * h->D + 2 * np + n + nn / 64 + 64) * 8 + 64 * 256;
+        if (direct) bytes += 3 * (size_t)n * n * 8 + (size_t)(cdiv(n, PS_BC_W) * PS_BC_W * PS_BC_W) * 8 + 4096;
+        if (h->slab_reserve(bytes)) return -1;
+    }
     if (h->alloc(&h->ldi_S32, nn) || h->alloc(&h->ldi_X32, nn) || h->alloc(&h->ldi_R32, nn) || h->alloc(&h->ldi_T32, nn) ||
         h->alloc(&h->ldi_Xu[0], nn) || h->alloc(&h->ldi_Xu[1], nn) || h->alloc(&h->ldi_Xt, (size_t)np * kp) ||
         h->alloc(&h->ldi_XtT, (size_t)np * kp) || h->alloc(&h->ldi_x64, (size_t)n * h->nc) ||
@@ -60,6 +66,8 @@ int ldi_ensure(ps_problem* h) {
     const size_t lds = (size_t)np * sizeof(double);
     if (ensure_dynamic_lds((const void*)k_ldi_init, (size_t)(lds))) return -1;
     if (ensure_dynamic_lds((const void*)k_ldi_update, (size_t)(lds))) return -1;
+    // pose graphs (no landmark, pose factors only): the direct seed from the start -- their Newton-Schulz seeds never contract
+    if (h->ldi_direct_ok && h->N == 0 && h->F > 0) h->ldi_direct = true;
     h->ldi_ready = true;
     return 0;
 }
@@ -91,6 +99,62 @@ void ldi_ns_step(ps_problem* h, hipStream_t st, float* xu, bool want_fro) {
         hipLaunchKernelGGL(k_ldi_fro_total, dim3(1), dim3(256), 0, st, (np / PS_GM_BM) * (np / PS_GM_BN), h->ldi_fro_part, h->h_ldi_fro_dev);
 }
 
+// DIRECT seed: X_u = S^-1 by the blocked dense Cholesky + triangular inverse the explicit PCG uses for wide coarse
+// matrices (k_bchol_panel / k_bchol_update, k_btri_inverse / k_btri_merge: ~2 n / 24 + 10 launches) and k_xcg_ainv, on the
+// side stream, in place of X_0 + Newton-Schulz.  For systems whose two-level operator is too ill-conditioned a start for the
+// fp32 iteration -- pose graphs: their seeds never contracted (kappa ~ 50-100) and they solved with 50-80 CG iterations
+// per step for a system of a few hundred unknowns (BASELINE config 1: 100 SE(2) poses, 68 iterations, 0.57 ms).
+// `state`: 1 = seed, 3 = refresh (there is no incremental refresh here: the inverse is formed again).
+template <int D>
+int ldi_direct_enqueue(ps_problem* h, int state, int lag) {
+    const int n = h->ldi_n, np = h->ldi_np;
+    const size_t nn = (size_t)n * n;
+    const int nsteps = cdiv(n, PS_BC_W);
+    if (!h->ldi_A64) {
+        if (h->alloc(&h->ldi_A64, nn) || h->alloc(&h->ldi_Li, nn) || h->alloc(&h->ldi_LiT, nn) ||
+            h->alloc(&h->ldi_Tinv, (size_t)nsteps * PS_BC_W * PS_BC_W) || h->alloc(&h->ldi_stat, ST_NWORDS)) return -1;
+    }
+    if (!h->ldi_stream && !ps_pool().take(ps_pool().side_streams, &h->ldi_stream))
+        HIP_OK(hipStreamCreateWithFlags(&h->ldi_stream, hipStreamNonBlocking));
+    hipStream_t st = h->ldi_stream;
+    double* A = h->ldi_A64;
+    HIP_OK(hipMemsetAsync(A, 0, nn * sizeof(double), st));
+    HIP_OK(hipMemsetAsync(h->ldi_stat, 0, ST_NWORDS * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_ldi_dense64<D>, dim3(h->nnzb), dim3(64), 0, st, h->brow_of, h->col_idx, h->S, A, n);
+    HIP_OK(hipEventRecord(h->ev_ldi_sread, st));              // S has been read: the next linearisation may overwrite it
+    h->ldi_sread_pending = true;
+    for (int s2 = 0; s2 < nsteps; ++s2) {
+        const int j0 = s2 * PS_BC_W, w = std::min(PS_BC_W, n - j0), m = n - j0 - w;
+        hipLaunchKernelGGL(k_bchol_panel, dim3(std::max(1, cdiv((long)m * w, 1024))), dim3(256), 0, st, n, j0, A,
+                           h->ldi_Tinv + (size_t)s2 * PS_BC_W * PS_BC_W, h->ldi_stat);
+        if (m > 0) {
+            const int nt = cdiv(m, 32);
+            hipLaunchKernelGGL(k_bchol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, n, j0, w, A);
+        }
+    }
+    const size_t inv_lds = ((size_t)PS_BI_S0 + PS_BC_W) * PS_BI_CW * sizeof(double);
+    hipLaunchKernelGGL(k_btri_inverse, dim3(cdiv(n, PS_BI_CW)), dim3(256), inv_lds, st, n, A, h->ldi_Tinv, h->ldi_Li, h->ldi_LiT);
+    for (int s2 = PS_BI_S0; s2 < n; s2 *= 2) {
+        const int pairs = cdiv(n, 2 * s2), nt = cdiv(s2, PS_BM_T);
+        for (int stage = 0; stage < 2; ++stage)
+            hipLaunchKernelGGL(k_btri_merge, dim3(pairs * nt * nt), dim3(256), 0, st, n, s2, stage, A, h->ldi_Li, h->ldi_LiT);
+    }
+    const int wb = h->ldi_cur < 0 ? 0 : (h->ldi_cur ^ 1);
+    HIP_OK(hipMemsetAsync(h->ldi_Xu[wb], 0, (size_t)np * np * sizeof(float), st));
+    hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(n, PS_AI_T) * (cdiv(n, PS_AI_T) + 1) / 2), dim3(256), 0, st, n, h->ldi_Li, h->ldi_Xu[wb], np);
+    hipLaunchKernelGGL(k_ldi_direct_done, dim3(1), dim3(64), 0, st, h->ldi_stat, h->h_ldi_fro_dev);
+    HIP_OK(hipEventRecord(h->ev_ldi, st));
+    h->ldi_state = state; h->ldi_next = wb; h->ldi_ready_at = h->ldi_iter + lag; h->ldi_fro_limit = 0.1;
+    h->ldi_refreshed = state == 3;
+    h->ldi_next_tag = h->ldi_call_start_cost;
+    if (state == 1) ++h->ldi_seeds;
+    return 0;
+}
+
+// calls between a direct seed and its first use: the factorisation is ~2 n / 24 dependent launches (a fixed schedule by size,
+// not a completion poll: the call that first uses the inverse is the same from run to run)
+inline int ldi_direct_lag(const ps_problem* h) { return h->ldi_n <= 400 ? 2 : (h->ldi_n <= 800 ? 4 : 6); }
+
 // After a standard (folded two-level) solve of a whole-iteration call: seed the inverse on the side stream from that
 // solve's own operator.  Everything the side stream reads from the solver's buffers (S, the block-Jacobi factors, the
 // prolongation) is read by its first kernels; ev_ldi_sread marks their end and the next linearisation waits for it.
@@ -107,6 +171,7 @@ int ldi_seed_enqueue(ps_problem* h, int its, double cost_now) {
     h->ldi_prev_start_cost = h->last_cost;
     if (!settling && !same_point) return 0;
     if (ldi_ensure(h)) return -1;
+    if (h->ldi_direct) return ldi_direct_enqueue<D>(h, 1, ldi_direct_lag(h));
     if (its < 2) return 0;
     const int nr = h->nr, n = h->ldi_n, np = h->ldi_np, nc = h->nc, kp = h->ldi_kp, ncb = h->ncb;
     hipStream_t st = h->side;
@@ -143,6 +208,7 @@ template <int D>
 int ldi_update_kick(ps_problem* h) {
     if (!h->ldi_side_todo) return 0;
     h->ldi_side_todo = false;
+    if (h->ldi_direct) return ldi_direct_enqueue<D>(h, 3, ldi_direct_lag(h));
     hipStream_t st = h->side;
     hipLaunchKernelGGL(k_ldi_scaled_dense<D>, dim3(h->nnzb), dim3(64), 0, st, h->brow_of, h->col_idx, h->S, h->ldi_Linv, h->ldi_S32, h->ldi_np);
     HIP_OK(hipEventRecord(h->ev_ldi_sread, st));
@@ -178,6 +244,8 @@ bool ldi_decide(ps_problem* h) {
             // a seed that did not contract in its Newton-Schulz steps (an operator whose preconditioned condition number is
             // large: long pose graphs) is side work for nothing: wait 8, 16, 32 ... calls before the next one
             if (h->ldi_state == 1) { h->ldi_rejects = std::min(h->ldi_rejects + 1, 10); h->ldi_no_seed_before = h->ldi_iter + (4L << h->ldi_rejects); }
+            // ... unless the direct seed has not been tried on this problem yet: the next standard solve seeds with it
+            if (h->ldi_state == 1 && !h->ldi_direct && h->ldi_direct_ok) { h->ldi_direct = true; h->ldi_rejects = 0; h->ldi_no_seed_before = 0; }
             h->ldi_state = 0; h->ldi_cur = -1; h->ldi_last_its = 0;
         }
     }

@@ -439,3 +439,23 @@ __global__ __launch_bounds__(256) void k_ldi_update(
     __syncthreads();
     if (t == 0) part[blockIdx.x] = ((wpart[0] + wpart[1]) + wpart[2]) + wpart[3];
 }
+
+
+// ---------------------------------------------------------------------------
+// DIRECT seed (pose graphs): S as a dense fp64 matrix for the blocked Cholesky + triangular inverse of ps_k_coarse.h
+// (k_bchol_*, k_btri_*) and k_xcg_ainv, which leave S^-1 in fp32 where the Newton-Schulz seed leaves its X_u.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void k_ldi_dense64(
+    const int32_t* __restrict__ brow_of, const int32_t* __restrict__ col_idx, const double* __restrict__ S, double* __restrict__ A, int n)
+{
+    constexpr int DD = D * D;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < DD) A[(size_t)(brow_of[b] * D + t / D) * n + col_idx[b] * D + t % D] = S[(size_t)b * DD + t];
+}
+
+// the word ldi_decide reads as "rms of the residual": 0 = take the inverse, huge = the factorisation met a non-positive pivot
+__global__ void k_ldi_direct_done(const int32_t* __restrict__ stat, double* __restrict__ hfro)
+{
+    if (threadIdx.x == 0) { *hfro = stat[ST_DIAG_FAIL] ? 1e300 : 0.0; __threadfence_system(); }
+}

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void k_xcg_restrict(
 // store), 4 x 4 outputs per thread, rows of Lci staged through LDS 16 at a time.
 #define PS_AI_T 64
 #define PS_AI_K 16
-__global__ __launch_bounds__(256) void k_xcg_ainv(int nc, const double* __restrict__ Lci, float* __restrict__ Ainv)
+__global__ __launch_bounds__(256) void k_xcg_ainv(int nc, const double* __restrict__ Lci, float* __restrict__ Ainv,
+                                                  int ld /* leading dimension of Ainv (>= nc) */)
 {
     __shared__ double As[PS_AI_K][PS_AI_T + 4];
     __shared__ double Bs[PS_AI_K][PS_AI_T + 4];
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void k_xcg_ainv(int nc, const double* __restri
             const int i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
             if (i < nc && j < nc) {
                 const float v = (float)acc[a][b];          // (both triangles get the SAME rounded value: still symmetric)
-                if (ti != tj || i >= j) { Ainv[(size_t)i * nc + j] = v; Ainv[(size_t)j * nc + i] = v; }
+                if (ti != tj || i >= j) { Ainv[(size_t)i * ld + j] = v; Ainv[(size_t)j * ld + i] = v; }
             }
         }
 }

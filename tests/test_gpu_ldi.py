@@ -150,6 +150,61 @@ def test_pose_graphs_keep_their_trajectory(dof):
     assert np.abs(a.get_params()[0] - b.get_params()[0]).max() < 1e-8
 
 
+@pytest.mark.parametrize('dof,poses,loops', [(3, 100, 150), (3, 100, 400), (6, 50, 120), (6, 100, 300), (6, 200, 800)])
+def test_direct_seed_takes_pose_graphs_to_a_handful_of_cg_iterations(dof, poses, loops):
+    """Pose graphs get the DIRECT seed (fp64 blocked Cholesky + triangular inverse of S on its own stream, ps_host_ldi.h:
+    ldi_direct_enqueue): once it is in (a fixed number of calls after the seed, by size) the CG takes <= 8 iterations where
+    the two-level operator alone took 50-80, and the trajectory is the one of the solver without any of this."""
+    from pyslam_amd import synthetic, losses
+    lp, _ = synthetic.pose_graph(num_poses=poses, num_loops=loops, dof=dof, seed=4, loss=losses.HuberLoss(1.0))
+    a, b = make(lp, True), make(lp, False)
+    its_a, its_b = [], []
+    for _ in range(12):
+        ca = a.gn_iteration(0., 1e-13, 2000, True)
+        cb = b.gn_iteration(0., 1e-13, 2000, True)
+        its_a.append(ca[2]); its_b.append(cb[2])
+        assert abs(ca[0] - cb[0]) <= 1e-9 * abs(cb[0])
+    assert np.abs(a.get_params()[0] - b.get_params()[0]).max() < 1e-8
+    solves, fallbacks, seeds = info(a)
+    assert seeds >= 1 and solves >= 2 and fallbacks == 0
+    assert max(its_a[-2:]) <= 8 and min(its_b[-2:]) >= 5 * max(its_a[-2:]), (its_a, its_b)
+
+
+def test_direct_seed_is_deterministic_and_switchable():
+    """Same problem twice: the same CG iteration counts and bit-identical parameters (the inverse enters at a fixed call,
+    not when an event happens to have fired).  ldi_direct = 0 keeps pose graphs on the Newton-Schulz seed / standard solver."""
+    from pyslam_amd import synthetic, losses
+    lp, _ = synthetic.pose_graph(num_poses=100, num_loops=300, dof=6, seed=9, loss=losses.HuberLoss(1.0))
+    runs = []
+    for _ in range(2):
+        d = make(lp, True)
+        its = [d.gn_iteration(0., 1e-12, 2000, True)[2] for _ in range(10)]
+        runs.append((its, d.get_params()[0].copy()))
+        d.close()
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1])
+    off = make(lp, True, ldi_direct=0)
+    ref = make(lp, False)
+    for _ in range(10):
+        c0 = off.gn_iteration(0., 1e-12, 2000, True); c1 = ref.gn_iteration(0., 1e-12, 2000, True)
+        assert abs(c0[0] - c1[0]) <= 1e-9 * abs(c1[0])
+
+
+def test_direct_seed_on_a_bundle_adjustment_problem():
+    """ldi_direct = 1 on a stereo BA problem (whose Newton-Schulz seed works too): steps still match the oracle's direct
+    solve of the full system while the directly formed inverse preconditions."""
+    lp = ba(40, 3000, 6)
+    dev = make(lp, True, ldi_direct=1)
+    dev.snapshot()
+    ref, _ = orc.gauss_newton_step(lp, points_first=False)
+    for k in range(8):
+        dev.restore()
+        out = dev.gn_iteration(0., 1e-13, 500, True)
+        dx = device_dx(dev, lp)
+        assert np.linalg.norm(dx - ref) <= 1e-8 * np.linalg.norm(ref), k
+    assert info(dev)[0] >= 2 and out[2] <= 6
+
+
 def test_option_off_and_rebuilt_coarse_level():
     """Switching the option off drops the inverse; changing the coarse level re-lays it out (sizes depend on it)."""
     lp = ba(50, 4000, 2)
