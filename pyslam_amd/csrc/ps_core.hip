@@ -261,8 +261,9 @@ struct ps_problem {
     int32_t *xcg_wg_out = nullptr, *xcg_nptr = nullptr;
     double *tq_part = nullptr, *tvec2 = nullptr;
     // ... one-launch form (k_xcg_fused1)
-    int xcg_fused = 1;              // option "xcg_fused"
+    int xcg_fused = 1;              // option "xcg_fused": 0 = three launches per iteration, 1 = one (two when the coarse level is too wide), 2 = two
     bool xf_ok = false, xf_active = false;
+    bool xf_one_ok = false, xf_two = false;   // the one-launch form fits (nc <= 2 048, even) / this solve runs the two-launch form
     int xf_skip = 0;                // upcoming set-ups that must not use the one-launch form (a fallback after its breakdown)
     int32_t *xf_cptr = nullptr, *xf_cols = nullptr, *xf_nlo = nullptr, *xf_nhi = nullptr, *xf_rec = nullptr;
     uint16_t* xf_lidx = nullptr;

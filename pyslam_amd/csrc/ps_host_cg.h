@@ -400,7 +400,9 @@ int build_coarse(ps_problem* h) {
     // stride per node (so that their addresses need no pointer load)
     h->xf_ok = false;
     // (fp32 rows of an odd-sized inverse are not 8-byte aligned: SE(2) graphs with an odd node count measured no gain)
-    if (h->cg_explicit && h->nc <= PS_XF_NEMAX * 64 * PS_XF_ROWS && nr >= 2 * PS_XF_ROWS && (h->nc & 1) == 0) {
+    // (beyond that, and for odd sizes: the two-launch form, whose coarse kernel takes any nc up to PS_XF2_NEMAX * 1 024)
+    h->xf_one_ok = h->nc <= PS_XF_NEMAX * 64 * PS_XF_ROWS && (h->nc & 1) == 0;
+    if (h->cg_explicit && (h->xf_one_ok || h->nc <= PS_XF2_NEMAX * 64 * PS_XCG_CROWS_BIG) && nr >= 2 * PS_XF_ROWS) {
         const int R = PS_XF_ROWS, nwg = cdiv(nr, R);
         std::vector<int32_t> cptr(nwg + 1, 0), cols, nlo(nwg), nhi(nwg), rec((size_t)nwg * PS_XCG_NSLOT, -1), cnt(ncb, 0);
         std::vector<uint16_t> lidx((size_t)h->nnzb_aug, 0);

@@ -68,6 +68,10 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     HIP_OK(hipMemsetAsync(h->xstate, 0, 8 * sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->xp2, 0, (size_t)nr * D * sizeof(double), h->stream));
     h->xf_active = h->xcg_fused && h->xf_ok && h->xf_skip == 0;
+    // one launch while the chip holds every workgroup at once (each forms its own rows of y: cheap for a narrow coarse level and
+    // one round of workgroups); beyond that y is computed once, in a launch of its own -- 5 000 SE(3) poses: 5.95 ms with one
+    // launch, 2.26 with three, 2.11 with two; 4 000-keyframe BA 2.26 / 1.79 / 1.69 (tools/xf_forms_probe.py)
+    h->xf_two = h->xf_active && (!h->xf_one_ok || h->xcg_fused == 2 || h->xf_nwg > 256);
     if (h->xf_skip > 0) --h->xf_skip;
     if (h->xf_active) {
         // one-launch form: t_0 = P^T r_0 (k_xcg_restrict, initialisation mode) into buffer 0, then launch -1 of the fused
@@ -117,8 +121,8 @@ void xcg_launch(ps_problem* h, double tol, int count) {
     const int n_rz = cdiv(nr, PS_XCG_DROWS);
     double* pbuf[2] = {h->cg_p, h->xp2};
     if (h->xf_active) {                                     // ONE launch per iteration (launch index n = k + 1 picks the buffers)
-        h->cg_kernel_launches += count;
-        const size_t lds = (size_t)nc * sizeof(double);
+        h->cg_kernel_launches += (h->xf_two ? 2 : 1) * count;
+        const size_t lds = h->xf_two ? 0 : (size_t)nc * sizeof(double);
         for (int i = 0; i < count; ++i, ++h->cg_launched) {
             const int k = h->cg_launched, in = (k + 1) & 1, out = in ^ 1;
             XcgFusedArgs a{};
@@ -131,10 +135,18 @@ void xcg_launch(ps_problem* h, double tol, int count) {
             a.gd_in = h->cg_gd[in]; a.gd_out = h->cg_gd[out]; a.nwg = h->xf_nwg;
             a.r_in = h->cg_r[in]; a.r_out = h->cg_r[out]; a.w_in = h->cg_w[in]; a.w_out = h->cg_w[out];
             a.s_in = h->cg_s[in]; a.s_out = h->cg_s[out];
-            a.u = h->xp2; a.p = h->cg_p; a.x = h->cg_xh;
-#define PS_XF_LAUNCH(PF) hipLaunchKernelGGL((k_xcg_fused1<D, PF>), dim3(h->xf_nwg), dim3(64 * PS_XF_ROWS), lds, h->stream, nr, h->arow_ptr, \
+            a.u = h->xp2; a.p = h->cg_p; a.x = h->cg_xh; a.y = h->xy;
+#define PS_XF_LAUNCH(PF, TWO) hipLaunchKernelGGL((k_xcg_fused1<D, PF, TWO>), dim3(h->xf_nwg), dim3(64 * PS_XF_ROWS), lds, h->stream, nr, h->arow_ptr, \
                                h->ell_wf, h->Saug, a, k, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate)
-            if (h->xf_pf == 2) PS_XF_LAUNCH(2); else if (h->xf_pf == 6) PS_XF_LAUNCH(6); else PS_XF_LAUNCH(8);
+            if (h->xf_two) {
+                hipLaunchKernelGGL(k_xcg_f2_coarse<D>, dim3(cdiv(nc, PS_XCG_CROWS_BIG)), dim3(64 * PS_XCG_CROWS_BIG), (size_t)nc * sizeof(double),
+                                   h->stream, a, k, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate);
+                static const int pf_env = getenv("PS_XF2_PF") ? atoi(getenv("PS_XF2_PF")) : -1;
+                // more workgroups than the chip holds at once: the kernel's time is (rounds of workgroups) x (its dependent
+                // phases), so registers go to occupancy, not to prefetch (C2, 1 250 workgroups: 24.4 us with PF = 6)
+                const int pf = pf_env >= 0 ? pf_env : (h->xf_nwg > 512 ? 0 : h->xf_pf);
+                if (pf == 0) PS_XF_LAUNCH(0, true); else if (pf == 2) PS_XF_LAUNCH(2, true); else if (pf == 6) PS_XF_LAUNCH(6, true); else PS_XF_LAUNCH(8, true);
+            } else if (h->xf_pf == 2) PS_XF_LAUNCH(2, false); else if (h->xf_pf == 6) PS_XF_LAUNCH(6, false); else PS_XF_LAUNCH(8, false);
 #undef PS_XF_LAUNCH
         }
         return;

@@ -571,11 +571,12 @@ struct XcgFusedArgs {
     const double* gd_in; double* gd_out; int nwg;
     const double* r_in; double* r_out; const double* w_in; double* w_out; const double* s_in; double* s_out;
     double* u; double* p; double* x;
+    double* y;                                  // two-launch form: y = A_c^-1 t_{k+1}, written by k_xcg_f2_coarse
 };
 
 // PF: blocks per lane of the row's matrix blocks requested at kernel start (8 PF blocks per row): the matrix stream is in
 // flight during the scalar / coarse phases instead of behind them (two waves per SIMD: 256 VGPRs to spend)
-template <int D, int PF>
+template <int D, int PF, bool TWO>
 __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
     int nr, const int32_t* __restrict__ row_ptr, int wf, const double* __restrict__ S, XcgFusedArgs a, int k, double tol2,
     double* __restrict__ hist, int cap, int32_t* __restrict__ status, double* __restrict__ scalars, double* __restrict__ xstate)
@@ -601,9 +602,13 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
     const int rbeg = row < nr ? (wf > 0 ? row * wf : row_ptr[row]) : 0;
     const int rend = row < nr ? (wf > 0 ? rbeg + wf : row_ptr[row + 1]) : 0;
     double gs = 0.0, ds = 0.0;
-    if (k >= 0) for (int i = tid; i < a.nwg; i += NT) { gs += a.gd_in[i]; ds += a.gd_in[a.nwg + i]; }
+    if (!TWO && k >= 0) for (int i = tid; i < a.nwg; i += NT) { gs += a.gd_in[i]; ds += a.gd_in[a.nwg + i]; }
+    // two-launch form: alpha_k, beta_k and y are what k_xcg_f2_coarse left for this launch
+    const double alpha_in = (TWO && k >= 0) ? xstate[6] : 0.0, beta_in = (TWO && k >= 0) ? xstate[7] : 0.0;
     const int c0 = a.cptr[wg], ncols = a.cptr[wg + 1] - c0;
     const int n_lo = a.nlo[wg], nrows_y = (a.nhi[wg] - n_lo + 1) * D;
+    double y_in = 0.0;
+    if (TWO && tid < nrows_y) y_in = a.y[n_lo * D + tid];
     double rj[NCOL], wj[NCOL], sj[NCOL], Bj[NCOL][D], cw0[NCOL], cw1[NCOL];
     int jj[NCOL], nj[NCOL];
 #pragma unroll
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
     // t_k, ts_{k-1} and the first batch of the records of P^T w_k, for this thread's coarse entries
     double to[PS_XF_NEMAX], tso[PS_XF_NEMAX], sq[PS_XF_NEMAX];
 #pragma unroll
-    for (int u = 0; u < PS_XF_NEMAX; ++u) {
+    for (int u = 0; u < (TWO ? 0 : PS_XF_NEMAX); ++u) {
         const int e = tid + u * NT;
         to[u] = tso[u] = sq[u] = 0.0;
         if (e < nc) {
@@ -643,7 +648,7 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
             for (int c = 0; c < PS_XF_RB; ++c) sq[u] += rec[c];
         }
     }
-    for (int base = PS_XF_RB; base < a.rmax; base += PS_XF_RB) {   // (more than PS_XF_RB records per node: pose graphs)
+    for (int base = PS_XF_RB; !TWO && base < a.rmax; base += PS_XF_RB) {   // (more than PS_XF_RB records per node: pose graphs)
 #pragma unroll
         for (int u = 0; u < PS_XF_NEMAX; ++u) {
             const int e = tid + u * NT;
@@ -673,10 +678,10 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
             for (int c = 0; c < D; ++c) sb[i][c] = sp[c];
         }
     }
-    block_sum2(gs, ds, lds);
+    if (!TWO) block_sum2(gs, ds, lds);
     if (done) return;
-    double alpha = 0.0, beta = 0.0;
-    if (k >= 0) {
+    double alpha = alpha_in, beta = beta_in;
+    if (!TWO && k >= 0) {
         const double gamma = gs, delta = ds;
         const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
         const bool first = wg == 0 && tid == 0;
@@ -693,6 +698,9 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
             if (k == 0) { xstate[1] = thresh; xstate[2] = gamma; scalars[SC_RR0] = gamma; }
         }
     }
+    if (TWO) {
+        if (tid < nrows_y) yl[tid] = y_in;
+    } else {
     // ---- 1. t_{k+1} (all of it) into LDS
 #pragma unroll
     for (int u = 0; u < PS_XF_NEMAX; ++u) {
@@ -738,6 +746,7 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
             for (int sg = 0; sg < nseg; ++sg) v += ysum[tid * nseg + sg];
             yl[tid] = v;
         }
+    }
     }
     __syncthreads();
     // ---- 3. the workgroup's columns: s, r, u (+ the owner's stores and p, x)
@@ -829,4 +838,105 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
         for (int ww = 0; ww < PS_XF_ROWS; ++ww) v += (&cw[ww][0][0])[tid];
         a.tq_out[(size_t)rout * D + tid % D] = v;
     }
+}
+
+// ---------------------------------------------------------------------------
+// TWO launches per iteration: coarse levels too wide for every workgroup of k_xcg_fused1 to form its own rows of y
+// (C2: 2 406 coarse unknowns -- 16 x 6 rows of a 2 406-wide inverse per workgroup, 1 250 workgroups: 1.1 GB per iteration,
+// measured 14.5 ms against 3.0).  The scalar phase, t_{k+1} and y = A_c^-1 t_{k+1} move into this kernel, computed ONCE
+// (16 rows of the inverse per workgroup, every workgroup forming all of t in LDS as k_xcg_coarse_rt_big does), and
+// k_xcg_fused1<.., TWO = true> reads alpha, beta (xstate[6], [7]) and its nodes' y.  Same recurrences, same records.
+// ---------------------------------------------------------------------------
+#define PS_XF2_NEMAX 6                        // coarse entries per thread: nc <= 6 * 1024 (PS_XCG_MAXNODES nodes of SE(3))
+template <int D>
+__global__ __launch_bounds__(64 * PS_XCG_CROWS_BIG) void k_xcg_f2_coarse(
+    XcgFusedArgs a, int k, double tol2, double* __restrict__ hist, int cap, int32_t* __restrict__ status,
+    double* __restrict__ scalars, double* __restrict__ xstate)
+{
+    constexpr int NT = 64 * PS_XCG_CROWS_BIG;
+    extern __shared__ __attribute__((aligned(16))) double tl[];   // nc: t_{k+1}
+    __shared__ double lds[32];
+    const int tid = threadIdx.x, wg = blockIdx.x, nc = a.nc;
+    // ---- 0. everything that does not depend on the scalars is requested first
+    const int done = status[ST_PCG_DONE];
+    const double g_prev = hist[k > 0 ? k - 1 : 0], a_prev = hist[cap + (k > 0 ? k - 1 : 0)], thresh_in = xstate[1];
+    double gs = 0.0, ds = 0.0;
+    if (k >= 0) for (int i = tid; i < a.nwg; i += NT) { gs += a.gd_in[i]; ds += a.gd_in[a.nwg + i]; }
+    double to[PS_XF2_NEMAX], tso[PS_XF2_NEMAX], sq[PS_XF2_NEMAX];
+#pragma unroll
+    for (int u = 0; u < PS_XF2_NEMAX; ++u) {
+        const int e = tid + u * NT;
+        to[u] = tso[u] = sq[u] = 0.0;
+        if (e < nc) {
+            const int n = e / D, m = e - n * D;
+            to[u] = a.t_in[e]; tso[u] = a.ts_in[e];
+            double rec[PS_XF_RB];
+#pragma unroll
+            for (int c = 0; c < PS_XF_RB; ++c) rec[c] = (c < a.rmax) ? a.tq_in[((size_t)n * a.rmax + c) * D + m] : 0.0;
+#pragma unroll
+            for (int c = 0; c < PS_XF_RB; ++c) sq[u] += rec[c];
+        }
+    }
+    for (int base = PS_XF_RB; base < a.rmax; base += PS_XF_RB) {
+#pragma unroll
+        for (int u = 0; u < PS_XF2_NEMAX; ++u) {
+            const int e = tid + u * NT;
+            if (e < nc) {
+                const int n = e / D, m = e - n * D;
+                double rec[PS_XF_RB];
+#pragma unroll
+                for (int c = 0; c < PS_XF_RB; ++c) rec[c] = (base + c < a.rmax) ? a.tq_in[((size_t)n * a.rmax + base + c) * D + m] : 0.0;
+#pragma unroll
+                for (int c = 0; c < PS_XF_RB; ++c) sq[u] += rec[c];
+            }
+        }
+    }
+    block_sum2(gs, ds, lds);
+    if (done) return;
+    double alpha = 0.0, beta = 0.0;
+    if (k >= 0) {
+        const double gamma = gs, delta = ds;
+        const double thresh = (k == 0) ? tol2 * gamma : thresh_in;
+        const bool first = wg == 0 && tid == 0;
+        if (!(gamma > thresh)) {
+            if (first) { status[ST_PCG_DONE] = (gamma != gamma) ? 2 : 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
+            return;
+        }
+        beta = (k == 0) ? 0.0 : gamma / g_prev;
+        const double denom = (k == 0) ? delta : delta - beta * gamma / a_prev;
+        if (!(denom > 0.0)) { if (first) { status[ST_PCG_DONE] = 2; scalars[SC_RRFINAL] = gamma; } return; }
+        alpha = gamma / denom;
+        if (first) {
+            hist[k] = gamma; hist[cap + k] = alpha; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = gamma;
+            xstate[6] = alpha; xstate[7] = beta;
+            if (k == 0) { xstate[1] = thresh; xstate[2] = gamma; scalars[SC_RR0] = gamma; }
+        }
+    }
+    // ---- 1. t_{k+1} (all of it) into LDS
+#pragma unroll
+    for (int u = 0; u < PS_XF2_NEMAX; ++u) {
+        const int e = tid + u * NT;
+        if (e < nc) {
+            const double ts = sq[u] + beta * tso[u];
+            const double tn = to[u] - alpha * ts;
+            tl[e] = tn;
+            if (wg == 0) { a.t_out[e] = tn; a.ts_out[e] = ts; }
+        }
+    }
+    __syncthreads();
+    // ---- 2. PS_XCG_CROWS_BIG rows of y = A_c^-1 t_{k+1}, one wave per row
+    const int row = wg * PS_XCG_CROWS_BIG + (tid >> 6), lane = tid & 63;
+    if (row >= nc) return;
+    const float* ar = a.Ainv + (size_t)row * nc;
+    double v = 0.0;
+    if ((nc & 1) == 0) {
+        for (int j = 2 * lane; j < nc; j += 128) {
+            const float2 f = *reinterpret_cast<const float2*>(ar + j);
+            v += (double)f.x * tl[j] + (double)f.y * tl[j + 1];
+        }
+    } else {
+        for (int j = lane; j < nc; j += 64) v += (double)ar[j] * tl[j];
+    }
+    v = wave_sum(v);
+    if (lane == 0) a.y[row] = v;
 }

@@ -237,9 +237,11 @@ def xf_info(dev):
     return i.xcg_fused_solves, i.xcg_fused_fallbacks
 
 
+@pytest.mark.parametrize('mode', [1, 2])
 @pytest.mark.parametrize('kind', ['pose_graph', 'ba'])
-def test_one_launch_explicit_pcg_matches_the_three_launch_form(kind):
-    """The single-reduction (Chronopoulos-Gear) arrangement of the explicit two-level PCG in ONE launch per iteration against
+def test_one_launch_explicit_pcg_matches_the_three_launch_form(kind, mode):
+    """(mode 2: the TWO-launch form -- scalars, t and y = A_c^-1 t once in k_xcg_f2_coarse -- that coarse levels beyond 2 048
+    unknowns get.)  The single-reduction (Chronopoulos-Gear) arrangement of the explicit two-level PCG in ONE launch per iteration against
     the three-launch form: same preconditioner, same iteration counts (+-1), the same Gauss-Newton trajectory (cost 1e-10,
     parameters 1e-9), and the first step against the oracle's direct solve."""
     from pyslam_amd import synthetic, losses
@@ -249,6 +251,7 @@ def test_one_launch_explicit_pcg_matches_the_three_launch_form(kind):
     else:
         lp, _ = synthetic.stereo_ba(num_kf=700, num_lm=30000, obs_per_lm=6, half_window=8, seed=12)
     a, b = DeviceProblem(lp), DeviceProblem(lp)
+    a.set_option('xcg_fused', mode)
     b.set_option('xcg_fused', 0)
     dx_ref, _ = orc.gauss_newton_step(lp, points_first=False)
     for it in range(5):
@@ -281,3 +284,23 @@ def test_one_launch_explicit_pcg_through_the_staged_api_and_covariance():
     xa, xb = a.get_dx()[0], b.get_dx()[0]
     assert np.linalg.norm(xa - xb) <= 1e-9 * np.linalg.norm(xb)
     assert xf_info(a)[0] >= 1
+
+
+def test_two_launch_explicit_pcg_on_a_coarse_level_too_wide_for_one_launch():
+    """3 000 SE(3) poses with 400 coarse intervals asked for: 2 406 coarse unknowns, beyond the one-launch kernel's 2 048 --
+    the default picks the two-launch form by itself; trajectory against the three-launch form."""
+    from pyslam_amd import synthetic
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.pose_graph(num_poses=3000, num_loops=12001, dof=6, seed=3)
+    a, b = DeviceProblem(lp), DeviceProblem(lp)
+    for d in (a, b):
+        d.set_option('coarse_groups', 400)
+    b.set_option('xcg_fused', 0)
+    for it in range(4):
+        ra = a.gn_iteration(0., 1e-12, 4000, True)
+        rb = b.gn_iteration(0., 1e-12, 4000, True)
+        assert abs(ra[0] - rb[0]) <= 1e-10 * abs(rb[0])
+        assert abs(ra[2] - rb[2]) <= 3 and ra[3] <= 1e-11
+    used, fell = xf_info(a)
+    assert used >= 4 and fell == 0 and xf_info(b) == (0, 0)
+    assert np.abs(a.get_params()[0] - b.get_params()[0]).max() < 1e-9
