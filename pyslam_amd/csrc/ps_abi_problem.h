@@ -767,6 +767,11 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
         HIP_OK(hipStreamSynchronize(h->stream));
         lap("two-level structures");
     }
+    // a pose graph that will get the direct seed of the lagged inverse (ps_host_ldi.h): its stream is taken here -- the
+    // first hipStreamCreate of a process costs ~5 ms, which belongs to set-up, not into the third iteration of a 0.1 ms solve
+    if (ldi_eligible(h) && h->ldi_direct_ok && h->N == 0 && h->F > 0 && !h->ldi_stream &&
+        !ps_pool().take(ps_pool().side_streams, &h->ldi_stream))
+        HIP_OK(hipStreamCreateWithFlags(&h->ldi_stream, hipStreamNonBlocking));
     lap("scalars + final sync");
     guard.ok = true;
     *out = h;
