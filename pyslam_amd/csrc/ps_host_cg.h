@@ -487,7 +487,7 @@ int build_coarse(ps_problem* h) {
     }
     if (h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
     h->acdone_pending = false;                             // (recorded before ev_chol on the same stream)
-    h->lci_next = -1; h->lci_cur = 0;
+    h->lci_next = -1; h->lci_cur = 0; h->xcg_tag[0] = h->xcg_tag[1] = -1.0;
     if (ensure_cg_buffers(h, h->nr_aug, h->nnzb_aug)) return -1;
     HIP_OK(hipMemsetAsync(h->Saug, 0, (size_t)h->nnzb_aug * D * D * sizeof(double), h->stream));
     return 0;

@@ -43,9 +43,13 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0;
     const bool settled = h->xcg_auto_hold && h->prev_cost > 0.0 && h->last_cost > 0.0 &&
                          std::fabs(h->prev_cost - h->last_cost) <= 1e-4 * h->prev_cost && h->xcg_held < 3;
-    const bool hold = lag && h->xcg_lag_count > 0 &&
-                      ((h->xcg_refresh_every > 1 && (h->xcg_lag_count % h->xcg_refresh_every) != 0) || settled);
-    h->xcg_held = (hold && settled) ? h->xcg_held + 1 : 0;
+    // ... or the inverse in use was formed from the A_c of THIS linearisation point (the caller linearises at the same point
+    // again -- a damping retry, a repeated step: the same start cost): nothing to refresh, for as long as that lasts
+    const bool same_point = h->xcg_auto_hold && h->last_cost > 0.0 && h->last_cost == h->xcg_tag[h->lci_cur];
+    const bool hold = lag && ((h->xcg_lag_count > 0 &&
+                               ((h->xcg_refresh_every > 1 && (h->xcg_lag_count % h->xcg_refresh_every) != 0) || settled)) || same_point);
+    h->xcg_held = (hold && settled && !same_point) ? h->xcg_held + 1 : 0;
+    h->xcg_setup_cost = h->last_cost;
     const int32_t* lagst = nullptr;
     h->xcg_side_todo = false;
     if (!hold && h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
@@ -62,7 +66,7 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
         xcg_assemble_ac<D>(h, h->stream);
         const int buf = h->lci_cur;
         if (xcg_coarse_inverse<D>(h, h->stream, buf, h->status)) return -1;
-        h->lci_next = buf;
+        h->lci_next = buf; h->xcg_tag[buf] = h->last_cost;
         h->xcg_lag_count = 0;
     }
     HIP_OK(hipMemsetAsync(h->xstate, 0, 8 * sizeof(double), h->stream));
@@ -111,7 +115,7 @@ int xcg_side_enqueue(ps_problem* h) {
     h->acdone_pending = true;
     if (xcg_coarse_inverse<D>(h, h->side, nb, h->lag_status)) return -1;
     HIP_OK(hipEventRecord(h->ev_chol, h->side));
-    h->lci_next = nb; h->side_pending = true;
+    h->lci_next = nb; h->side_pending = true; h->xcg_tag[nb] = h->xcg_setup_cost;
     return 0;
 }
 
