@@ -248,7 +248,7 @@ struct ps_problem {
     // "coarse_auto_hold": keep the lagged coarse inverse (no assembly, no side-stream factorisation) while the solve has
     // settled -- the last whole-iteration call changed the cost by less than 1e-4 relative -- for at most 3 set-ups in a row
     int xcg_auto_hold = 1, xcg_held = 0;
-    double xcg_tag[2] = {-1.0, -1.0}, xcg_setup_cost = -1.0;   // start cost of the call whose A_c each inverse buffer was formed from
+    double xcg_tag[2] = {-1.0, -1.0}, xcg_setup_cost = -1.0, xcg_tag_lambda[2] = {0.0, 0.0}, xcg_setup_lambda = 0.0, lin_lambda = 0.0;   // start cost of the call whose A_c each inverse buffer was formed from
     double last_cost = -1.0, prev_cost = -1.0;   // costs returned by the last two ps_gn_iteration calls (-1: none / parameters replaced since)
     double *xstate = nullptr, *xy = nullptr, *xp2 = nullptr;
     // ... banded coarse matrix (ps_k_band.h): block off-diagonals of A_c (-1: not banded enough), band factor by rows / columns

@@ -849,6 +849,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
 }
 
 int linearize(ps_problem* h, double lambda) {
+    h->lin_lambda = lambda;                                  // (what the held coarse inverse is tagged with, beside the cost)
     ++h->prof_tick;
     h->cov_ready = false;
     h->status_clean = false;

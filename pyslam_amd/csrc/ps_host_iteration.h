@@ -40,16 +40,21 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     // stream's factorisation -- C4 on 8 GPUs: ~1.1 ms against 1.6 ms): only every k-th lagged set-up consumes the newest
     // inverse and starts the next factorisation; the set-ups in between HOLD the inverse they have, assemble no A_c and
     // do not wait for the side stream.  A fixed schedule, not a completion poll: results stay reproducible run to run.
-    const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0;
+    // (an inverse formed under another damping is a poor stand-in -- 93 CG iterations against 24 on a 600-keyframe BA when lambda
+    // goes from 0 to 1e-3: such a call factors its own A_c, on the solver stream)
+    const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && h->lin_lambda == h->xcg_tag_lambda[h->lci_next];
     const bool settled = h->xcg_auto_hold && h->prev_cost > 0.0 && h->last_cost > 0.0 &&
                          std::fabs(h->prev_cost - h->last_cost) <= 1e-4 * h->prev_cost && h->xcg_held < 3;
     // ... or the inverse in use was formed from the A_c of THIS linearisation point (the caller linearises at the same point
     // again -- a damping retry, a repeated step: the same start cost): nothing to refresh, for as long as that lasts
-    const bool same_point = h->xcg_auto_hold && h->last_cost > 0.0 && h->last_cost == h->xcg_tag[h->lci_cur];
+    // (and the same damping: the inverse of an undamped A_c against a system damped with lambda = 1e-3 took 93 iterations where
+    // the right one takes 24 -- a 600-keyframe BA, tests/test_gpu_ldi.py)
+    const bool same_point = h->xcg_auto_hold && h->last_cost > 0.0 && h->last_cost == h->xcg_tag[h->lci_cur] &&
+                            h->lin_lambda == h->xcg_tag_lambda[h->lci_cur];
     const bool hold = lag && ((h->xcg_lag_count > 0 &&
                                ((h->xcg_refresh_every > 1 && (h->xcg_lag_count % h->xcg_refresh_every) != 0) || settled)) || same_point);
     h->xcg_held = (hold && settled && !same_point) ? h->xcg_held + 1 : 0;
-    h->xcg_setup_cost = h->last_cost;
+    h->xcg_setup_cost = h->last_cost; h->xcg_setup_lambda = h->lin_lambda;
     const int32_t* lagst = nullptr;
     h->xcg_side_todo = false;
     if (!hold && h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
@@ -66,7 +71,7 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
         xcg_assemble_ac<D>(h, h->stream);
         const int buf = h->lci_cur;
         if (xcg_coarse_inverse<D>(h, h->stream, buf, h->status)) return -1;
-        h->lci_next = buf; h->xcg_tag[buf] = h->last_cost;
+        h->lci_next = buf; h->xcg_tag[buf] = h->last_cost; h->xcg_tag_lambda[buf] = h->lin_lambda;
         h->xcg_lag_count = 0;
     }
     HIP_OK(hipMemsetAsync(h->xstate, 0, 8 * sizeof(double), h->stream));
@@ -115,7 +120,7 @@ int xcg_side_enqueue(ps_problem* h) {
     h->acdone_pending = true;
     if (xcg_coarse_inverse<D>(h, h->side, nb, h->lag_status)) return -1;
     HIP_OK(hipEventRecord(h->ev_chol, h->side));
-    h->lci_next = nb; h->side_pending = true; h->xcg_tag[nb] = h->xcg_setup_cost;
+    h->lci_next = nb; h->side_pending = true; h->xcg_tag[nb] = h->xcg_setup_cost; h->xcg_tag_lambda[nb] = h->xcg_setup_lambda;
     return 0;
 }
 

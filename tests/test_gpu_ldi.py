@@ -304,3 +304,29 @@ def test_two_launch_explicit_pcg_on_a_coarse_level_too_wide_for_one_launch():
     used, fell = xf_info(a)
     assert used >= 4 and fell == 0 and xf_info(b) == (0, 0)
     assert np.abs(a.get_params()[0] - b.get_params()[0]).max() < 1e-9
+
+
+def test_coarse_inverse_is_held_at_a_repeated_linearisation_point():
+    """Explicit two-level PCG: a call that linearises where the inverse in use was formed (restore + iterate, a damping
+    retry with another lambda) holds it -- no factorisation beside the solve, same preconditioner.  Against the same calls
+    with the hold switched off (coarse_auto_hold = 0) and, for the first step, the oracle's Schur solve."""
+    lp = ba(600, 15000, 12)
+    from pyslam_amd.device import DeviceProblem
+    a, b = DeviceProblem(lp), DeviceProblem(lp)
+    b.set_option('coarse_auto_hold', 0)
+    for d in (a, b):
+        d.eval_cost(True); d.snapshot()
+    dx_ref, _ = orc.gauss_newton_step(lp, points_first=False, linear_solver='schur')
+    its = []
+    for k, lam in enumerate([0., 0., 0., 1e-3, 1e-3, 0.]):
+        outs = []
+        for d in (a, b):
+            d.restore()
+            outs.append(d.gn_iteration(lam, 1e-13, 3000, False))
+        xa, xb = device_dx(a, lp), device_dx(b, lp)
+        assert np.linalg.norm(xa - xb) <= 1e-9 * np.linalg.norm(xb), (k, lam)
+        assert outs[0][3] <= 1e-12 and abs(outs[0][2] - outs[1][2]) <= 2
+        if k == 0:
+            assert np.linalg.norm(xa - dx_ref) <= 1e-8 * np.linalg.norm(dx_ref)
+        its.append(outs[0][2])
+    assert max(its[:3]) - min(its[:3]) <= 1, its
