@@ -258,7 +258,9 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
      "coarse_refresh_every" [1] explicit two-level PCG: only every k-th lagged set-up takes the newest coarse inverse and starts the
                               next side-stream factorisation (landmark-sharded runs whose iteration is shorter than that factorisation)
      "coarse_auto_hold"   [1] explicit two-level PCG: while the solve has settled (last iteration changed the cost by < 1e-4
-                              relative) keep the lagged coarse inverse, for at most 3 set-ups in a row (no assembly, no factorisation)
+                              relative) keep the lagged coarse inverse, for at most 3 set-ups in a row (no assembly, no factorisation);
+                              and for as long as the caller linearises at the point (same start cost, same lambda) the inverse in use
+                              was formed from.  A call whose lambda differs from the newest inverse's factors its own A_c (no lag).
      "xcg_restrict_fused" [1] explicit two-level PCG: three launches per iteration (restriction in the SpMV epilogue, t by recurrence)
                               instead of four
      "lagged_inverse"     [1] reduced systems of 91 .. "ldi_max_unknowns" [1536] unknowns (folded CG, one GPU, whole-iteration calls):
@@ -267,9 +269,15 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
                               operator of the last standard solve; tried while the last step changed the cost by at most
                               "ldi_cost_tol" [0.05] relative, given up (standard solver + re-seed) after "ldi_cap" [12] iterations.
                               It only preconditions: the solution is the current system's at pcg_tol either way.
+     "ldi_direct"         [-1] ... seeded by a DIRECT fp64 factorisation of S on a stream of its own instead of Newton-Schulz
+                              (-1: pose graphs from the start, any problem after a rejected Newton-Schulz seed; 0 never; 1 always);
+                              usable a fixed 2 / 4 / 6 calls later (n <= 400 / 800 / 1 536)
+     "ldi_seed_lag" [2], "ldi_seed_steps" [3], "ldi_refresh_its" [7]: schedule of the Newton-Schulz seed / refresh
      "xcg_fused"          [1] explicit two-level PCG: ONE launch per iteration (single-reduction recurrences; the restriction, the coarse
                               product for the nodes a workgroup needs, the prolongation and the SpMV in one kernel, the row's matrix
-                              blocks requested before the scalar phase); a breakdown repeats the solve in the three-launch form
+                              blocks requested before the scalar phase) up to 2 048 poses and 2 048 coarse unknowns, TWO beyond (scalars,
+                              t and y = A_c^-1 t once, in k_xcg_f2_coarse); 2: always two; 0: three launches per iteration.
+                              A breakdown of the recurrences repeats the solve in the three-launch form
      "band_chol"          [1] explicit two-level PCG: banded factorisation + band substitutions for the coarse inverse when A_c
                               has at most 7 block off-diagonals (chain-like problems); 0: always the dense factorisation
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual

@@ -26,6 +26,12 @@ echo
 echo "# one-launch explicit two-level PCG on / off (tools/xf_probe.py)"
 python tools/xf_probe.py mid c4 c2 2>&1 | grep -v amdgpu.ids
 echo
+echo "# explicit two-level PCG, three / one (auto) / two launches per iteration over problem sizes (tools/xf_forms_probe.py)"
+python tools/xf_forms_probe.py 2>&1 | grep -v amdgpu.ids
+echo
+echo "# small pose graphs (BASELINE configuration 1): direct seed of the lagged inverse on / off (tools/c1_probe.py)"
+python tools/c1_probe.py 2>&1 | grep -v amdgpu.ids
+echo
 echo "# per-frame motion-only Problem through the public API (tools/c5_frame_probe.py)"
 python tools/c5_frame_probe.py 2>&1 | grep -v amdgpu.ids | tail -1
 echo
