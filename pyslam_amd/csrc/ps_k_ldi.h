@@ -310,10 +310,11 @@ __global__ __launch_bounds__(256) void k_ldi_fro_total(int nparts, const double*
 }
 
 // ---------------------------------------------------------------------------
-// solver stream: classic PCG with the dense preconditioner.  PS_LDI_ROWS rows of X_u per workgroup (two per wave),
+// solver stream: classic PCG with the dense preconditioner.  PS_LDI_ROWS rows of X_u per workgroup (one per wave: with
+// two, C3's 1 194 rows made 150 workgroups for 256 CUs -- reduced-solve stage 56.0 -> 54.3 us with 299),
 // the whole residual vector in LDS.
 // ---------------------------------------------------------------------------
-#define PS_LDI_ROWS 8
+#define PS_LDI_ROWS 4
 #define PS_LDI_MAXN 2048
 #define PS_LDI_RPW (PS_LDI_ROWS / 4)            // rows of X_u per wave
 #define PS_LDI_NF4 (PS_LDI_MAXN / 256)          // float4 pieces of a row per lane
