@@ -278,6 +278,7 @@ struct ps_problem {
     int prev_pcg_iters = -1;        // iteration count of the solve before the last one (launch-count prediction)
     int cg_fallbacks = 0;           // solves repeated with the classic PCG after a breakdown of the pipelined CG
     int cg_force_restart = 0;       // option (tests): end the first pass of a synchronous solve at 1e-4 and restart from the true residual
+    bool ldi_moved = false;         // this call left the lagged inverse behind (cost jump): the standard solve's launch-count prediction is stale
     int cg_margin = 4;              // CG launches enqueued beyond the previous solve's iteration count
     bool cg_two_level_reduce = false, cg_short_rows = false;
     double* cg_tot = nullptr;

@@ -334,7 +334,11 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
     // launches needed = iterations + 2 (the k = -1 launch and the one that detects convergence): exactly that when the
     // last two solves took the same number of iterations (0.360 -> 0.348 ms at C3), the configured margin otherwise --
     // one iteration too few costs a host round trip (~40 us), one launch too many ~1.5 us
-    const int margin = (h->last_pcg_iters == h->prev_pcg_iters) ? std::min(2, h->cg_margin) : h->cg_margin;
+    // (after a cost jump that left the lagged inverse behind the last standard solve is several calls old and from another
+    //  phase: C3's trajectory needs 21 iterations where it needed 18 -- six spare launches at ~1.5 us each instead of a miss)
+    const int margin = h->ldi_moved ? std::max(6, h->cg_margin)
+                                    : ((h->last_pcg_iters == h->prev_pcg_iters) ? std::min(2, h->cg_margin) : h->cg_margin);
+    h->ldi_moved = false;
     int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : 16;
     for (;;) {
         count = std::min(count, max_iters + 2 - h->cg_launched);

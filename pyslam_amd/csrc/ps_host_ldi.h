@@ -255,6 +255,7 @@ bool ldi_decide(ps_problem* h) {
     // Either unknown (parameters replaced from outside): try, ldi_cap bounds the damage.
     if (h->ldi_tag > 0.0 && h->last_cost > 0.0 && std::fabs(h->ldi_tag - h->last_cost) > h->ldi_cost_tol * h->ldi_tag) {
         ldi_invalidate(h);        // the problem has moved too far: the standard path solves and re-seeds
+        h->ldi_moved = true;      // (... with a wider launch margin: its last iteration count is from another phase of the solve)
         return false;
     }
     return true;
