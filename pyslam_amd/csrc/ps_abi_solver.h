@@ -562,6 +562,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "ldi_cost_tol") { if (!(value >= 0)) return fail("ldi_cost_tol must be >= 0"); h->ldi_cost_tol = value; }
     else if (n == "ldi_refresh_its") { if (value < 0 || value > 64) return fail("ldi_refresh_its out of range (0 .. 64)"); h->ldi_refresh_its = (int)value; }
     else if (n == "ldi_direct") { h->ldi_direct_ok = value != 0.0; h->ldi_direct = value > 0.0; }
+    else if (n == "direct_fused") h->direct_fused = value != 0.0;
     else if (n == "ldi_seed_lag") { if (value < 1 || value > 16) return fail("ldi_seed_lag out of range (1 .. 16)"); h->ldi_seed_lag = (int)value; }
     else if (n == "ldi_seed_steps") { if (value < 1 || value > 40) return fail("ldi_seed_steps out of range (1 .. 40)"); h->ldi_seed_steps = (int)value; }
     else if (n == "coarse_refresh_every") { if (value < 1 || value > 16) return fail("coarse_refresh_every must be 1..16"); h->xcg_refresh_every = (int)value; }

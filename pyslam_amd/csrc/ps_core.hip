@@ -237,6 +237,7 @@ struct ps_problem {
     int mo_fused = 1;               // motion-only problems: one launch per iteration (k_motion_only_iteration)
     double* mo_partials = nullptr;
     bool status_clean = true;       // no failure flag can be pending in the device status words
+    int direct_fused = getenv("PS_DIRECT_3LAUNCH") ? 0 : 1;   // option "direct_fused": the direct solve in one launch (k_direct_solve)
     int direct_max = 90;            // reduced systems up to this many unknowns are solved directly (0: never)
     double *dA = nullptr, *dLi = nullptr, *dLiT = nullptr;
     int big_chol = 1;               // nc > 90: multi-workgroup blocked factorisation (0: one workgroup out of L2)

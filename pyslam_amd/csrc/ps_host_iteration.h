@@ -235,6 +235,18 @@ bool use_direct(const ps_problem* h) {
 template <int D>
 int direct_solve_enqueue(ps_problem* h) {
     const int nr = h->nr, n = nr * D;
+    if (h->direct_fused) {                                  // one launch: no dense copy, no inverse (k_direct_solve)
+        const size_t lds = ((size_t)n * n + 2 * (size_t)n + (size_t)nr * D * D) * sizeof(double);
+        if (ensure_dynamic_lds((const void*)k_direct_solve<D>, lds)) return -1;
+        // (1 024 threads: the trailing update has (nr - J - 1)^2 D^2 / 2 entries per step; measured 256 / 512 / 1 024 threads:
+        //  17.8 / 16.7 / 16.6 us at 30 unknowns, 70 / 58 / 50 us at 90)
+        static const int nt_env = getenv("PS_DIRECT_THREADS") ? atoi(getenv("PS_DIRECT_THREADS")) : 0;
+        const int nthreads = nt_env > 0 ? nt_env : 1024;
+        hipLaunchKernelGGL(k_direct_solve<D>, dim3(1), dim3(nthreads), lds, h->stream, nr, h->nnzb, h->brow_of, h->col_idx, h->S, h->g, h->x,
+                           h->status, h->scalars);
+        h->cg_launched = 0;
+        return 0;
+    }
     if (!h->dA && (h->alloc(&h->dA, (size_t)n * n) || h->alloc(&h->dLi, (size_t)n * n) || h->alloc(&h->dLiT, (size_t)n * n)))
         return -1;
     hipLaunchKernelGGL(k_bsr_to_dense<D>, dim3(1), dim3(256), 0, h->stream, nr, h->nnzb, h->brow_of, h->col_idx, h->S, h->dA);

@@ -638,6 +638,147 @@ __global__ __launch_bounds__(256) void k_direct_apply(
     }
 }
 
+// The same solve in ONE launch (whole-iteration calls): S straight from its blocks into LDS, the blocked Cholesky of
+// k_coarse_chol WITHOUT forming L^-1, then block forward / backward substitution on g -- the inverse was 2/5 of the
+// factor kernel's time and the two extra launches another ~17 us (reduced-solve stage at 30 / 54 / 90 unknowns:
+// 29 / 51 / 99 -> 17 / 28 / 50 us; the panel is written by the thread that read it: three barriers per block step, not four).
+// LDS: n^2 (L) + 2 n (g -> y -> x, staging) + ncb D^2 (inverse diagonal blocks of L) doubles.
+template <int D>
+__global__ __launch_bounds__(1024) void k_direct_solve(
+    int nr, int nnzb, const int32_t* __restrict__ brow_of, const int32_t* __restrict__ col_idx,
+    const double* __restrict__ S, const double* __restrict__ g, double* __restrict__ x,
+    int32_t* __restrict__ status, double* __restrict__ scalars)
+{
+    constexpr int DD = D * D;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = nr * D, t = threadIdx.x, nt = blockDim.x;
+    double* sL = sm;                       // n x n, row-major: S, overwritten by L (lower)
+    double* sv = sL + n * n;               // n: g, then y = L^-1 g (solved entries live in sw)
+    double* sw = sv + n;                   // n: y (forward), then x (backward)
+    double* sDi = sw + n;                  // nr x D x D: inverse of every diagonal block of L
+    for (int k = t; k < n * n; k += nt) sL[k] = 0.0;
+    if (t < n) sv[t] = g[t];
+    __syncthreads();
+    for (int k = t; k < nnzb * DD; k += nt) {
+        const int b = k / DD, e = k % DD;
+        sL[(brow_of[b] * D + e / D) * n + col_idx[b] * D + e % D] = S[k];
+    }
+    for (int J = 0; J < nr; ++J) {
+        __syncthreads();
+        if (t == 0) {                      // D x D Cholesky of the diagonal block + its inverse (reciprocal roots: no division)
+            double L[D][D], Mi[D][D], il[D];
+            bool ok = true;
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < D; ++b2) { L[a][b2] = 0.0; Mi[a][b2] = 0.0; }
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double d = sL[(J * D + j) * n + J * D + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+                ok = ok && (d > 0.0);
+                il[j] = ps_rsqrt(d);
+                L[j][j] = d * il[j];
+#pragma unroll
+                for (int i = j + 1; i < D; ++i) {
+                    double v = sL[(J * D + i) * n + J * D + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+                    L[i][j] = v * il[j];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                Mi[c][c] = il[c];
+#pragma unroll
+                for (int r = c + 1; r < D; ++r) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int k = c; k < r; ++k) v -= L[r][k] * Mi[k][c];
+                    Mi[r][c] = v * il[r];
+                }
+            }
+            if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < D; ++b2) {
+                    sL[(J * D + a) * n + J * D + b2] = L[a][b2];
+                    sDi[J * DD + a * D + b2] = Mi[a][b2];
+                }
+        }
+        __syncthreads();
+        const int m = nr - J - 1;          // panel: L_IJ = A_IJ L_JJ^-T, one ROW of the block column per thread (read and
+        for (int idx = t; idx < m * D; idx += nt) {          // written by the same thread: no barrier in between)
+            double* row = sL + ((J + 1) * D + idx) * n + J * D;
+            double ar[D], lr[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) ar[k] = row[k];
+#pragma unroll
+            for (int b2 = 0; b2 < D; ++b2) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k <= b2; ++k) v += ar[k] * sDi[J * DD + b2 * D + k];
+                lr[b2] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) row[k] = lr[k];
+        }
+        __syncthreads();
+        for (int idx = t; idx < m * m * DD; idx += nt) {     // trailing update A_IK -= L_IJ L_KJ^T for J < K <= I
+            const int blk = idx / DD, e = idx % DD, a = e / D, b2 = e % D;
+            const int I = J + 1 + blk / m, K = J + 1 + blk % m;
+            if (K > I) continue;
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += sL[(I * D + a) * n + J * D + k] * sL[(K * D + b2) * n + J * D + k];
+            sL[(I * D + a) * n + K * D + b2] -= v;
+        }
+    }
+    // forward: y_J = L_JJ^-1 g_J, then g_I -= L_IJ y_J for the rows below
+    for (int J = 0; J < nr; ++J) {
+        __syncthreads();
+        if (t < D) {
+            double v = 0.0;
+            for (int k = 0; k <= t; ++k) v += sDi[J * DD + t * D + k] * sv[J * D + k];
+            sw[J * D + t] = v;
+        }
+        __syncthreads();
+        const int i = (J + 1) * D + t;
+        if (i < n) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += sL[i * n + J * D + k] * sw[J * D + k];
+            sv[i] -= v;
+        }
+    }
+    __syncthreads();
+    if (t < n) sv[t] = sw[t];              // y complete
+    // backward: x_J = L_JJ^-T y_J, then y_I -= L_JI^T x_J for the rows above
+    for (int J = nr - 1; J >= 0; --J) {
+        __syncthreads();
+        if (t < D) {
+            double v = 0.0;
+            for (int k = t; k < D; ++k) v += sDi[J * DD + k * D + t] * sv[J * D + k];
+            sw[J * D + t] = v;
+        }
+        __syncthreads();
+        if (t < J * D) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += sL[(J * D + k) * n + t] * sw[J * D + k];
+            sv[t] -= v;
+        }
+    }
+    __syncthreads();
+    if (t < n) x[t] = sw[t];
+    if (t == 0) {
+        status[ST_PCG_DONE] = 1; status[ST_PCG_ITERS] = 0;
+        scalars[SC_RR0] = 1.0; scalars[SC_RRFINAL] = 0.0;
+    }
+}
+
 // ---- restart after a breakdown of the pipelined recurrences (rare; host-driven, see cg_fused_run) ----------------
 // xacc (+)= x, then g = gsaved - S xacc: the next pass solves for the correction with the same matrix and preconditioner
 __global__ __launch_bounds__(256) void k_vec_accumulate(int n, const double* __restrict__ x, double* __restrict__ xacc, int first)

@@ -32,6 +32,9 @@ echo
 echo "# small pose graphs (BASELINE configuration 1): direct seed of the lagged inverse on / off (tools/c1_probe.py)"
 python tools/c1_probe.py 2>&1 | grep -v amdgpu.ids
 echo
+echo "# lagged dense inverse on / off over BA sizes, eight-call trajectories (tools/ldi_size_sweep.py)"
+python tools/ldi_size_sweep.py 2>&1 | grep -v amdgpu.ids
+echo
 echo "# per-frame motion-only Problem through the public API (tools/c5_frame_probe.py)"
 python tools/c5_frame_probe.py 2>&1 | grep -v amdgpu.ids | tail -1
 echo

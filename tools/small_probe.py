@@ -10,7 +10,11 @@ cases = [('C5 motion-only 256 pts', synthetic.motion_only(num_pts=256, seed=3)[0
          ('C5 motion-only 2048 pts', synthetic.motion_only(num_pts=2048, seed=3)[0]),
          ('pose graph 6 poses (C1 shape, SE3)', synthetic.pose_graph(num_poses=6, num_loops=2, dof=6, seed=1)[0]),
          ('pose graph 200 poses', synthetic.pose_graph(num_poses=200, num_loops=801, dof=6, seed=2)[0]),
-         ('BA 20 kf x 400 lm', synthetic.stereo_ba(20, 400, 5, 6, seed=0)[0])]
+         ('BA 20 kf x 400 lm', synthetic.stereo_ba(20, 400, 5, 6, seed=0)[0]),
+         # reduced systems of 30 / 54 / 90 unknowns: the one-launch direct solve (k_direct_solve)
+         ('BA 6 kf x 300 lm', synthetic.stereo_ba(num_kf=6, num_lm=300, obs_per_lm=5, half_window=12, seed=6)[0]),
+         ('BA 10 kf x 800 lm', synthetic.stereo_ba(num_kf=10, num_lm=800, obs_per_lm=8, half_window=12, seed=10)[0]),
+         ('BA 16 kf x 1500 lm', synthetic.stereo_ba(num_kf=16, num_lm=1500, obs_per_lm=8, half_window=12, seed=16)[0])]
 FUSED = float(sys.argv[1]) if len(sys.argv) > 1 else 1.
 for name, lp in cases:
     dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
