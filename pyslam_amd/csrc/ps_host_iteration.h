@@ -74,9 +74,12 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
         h->lci_next = buf; h->xcg_tag[buf] = h->last_cost; h->xcg_tag_lambda[buf] = h->lin_lambda;
         h->xcg_lag_count = 0;
     }
-    HIP_OK(hipMemsetAsync(h->xstate, 0, 8 * sizeof(double), h->stream));
-    HIP_OK(hipMemsetAsync(h->xp2, 0, (size_t)nr * D * sizeof(double), h->stream));
     h->xf_active = h->xcg_fused && h->xf_ok && h->xf_skip == 0;
+    {   // xstate, the second p buffer and (one- / two-launch form) ts_0 and the records of buffer 0: one launch
+        const size_t n0 = 8, n1 = (size_t)nr * D, n2 = h->xf_active ? (size_t)nc : 0, n3 = h->xf_active ? h->xf_nrec : 0;
+        hipLaunchKernelGGL(k_zero4, dim3((unsigned)std::min<size_t>(1024, cdiv((long)(n0 + n1 + n2 + n3), 256))), dim3(256), 0, h->stream,
+                           n0, h->xstate, n1, h->xp2, n2, h->xf_active ? h->xf_ts[0] : nullptr, n3, h->xf_active ? h->xf_tq[0] : nullptr);
+    }
     // one launch while the chip holds every workgroup at once (each forms its own rows of y: cheap for a narrow coarse level and
     // one round of workgroups); beyond that y is computed once, in a launch of its own -- 5 000 SE(3) poses: 5.95 ms with one
     // launch, 2.26 with three, 2.11 with two; 4 000-keyframe BA 2.26 / 1.79 / 1.69 (tools/xf_forms_probe.py)
@@ -85,8 +88,6 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     if (h->xf_active) {
         // one-launch form: t_0 = P^T r_0 (k_xcg_restrict, initialisation mode) into buffer 0, then launch -1 of the fused
         // kernel (alpha = beta = 0): u_0 = M^-1 r_0, w_0 = S^ u_0, the partials of gamma_0 / delta_0 and the records of P^T w_0
-        HIP_OK(hipMemsetAsync(h->xf_ts[0], 0, (size_t)nc * sizeof(double), h->stream));
-        HIP_OK(hipMemsetAsync(h->xf_tq[0], 0, h->xf_nrec * sizeof(double), h->stream));
         hipLaunchKernelGGL(k_xcg_restrict<D>, dim3(ncb), dim3(256), 0, h->stream, nr, ncb, h->slo, h->shi, h->pnode, h->pw0,
                            h->pw1, h->Bmat, h->cg_r[0], h->cg_r[0], h->cg_w[0], h->cg_p, h->cg_xh, h->cg_gd[1], 0, h->xstate, -1,
                            h->xf_t[0], h->status);

@@ -591,6 +591,20 @@ __global__ __launch_bounds__(256) void k_copy2(size_t n1, const double* __restri
     }
 }
 
+// up to four vectors zeroed in ONE launch (four hipMemsetAsync are four fill launches of ~6 us each: the explicit PCG's set-up
+// paid 23 us per solve for 100 KB of zeros)
+__global__ __launch_bounds__(256) void k_zero4(size_t n0, double* __restrict__ p0, size_t n1, double* __restrict__ p1,
+                                               size_t n2, double* __restrict__ p2, size_t n3, double* __restrict__ p3)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n = n0 + n1 + n2 + n3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (i < n0) p0[i] = 0.0;
+        else if (i < n0 + n1) p1[i - n0] = 0.0;
+        else if (i < n0 + n1 + n2) p2[i - n0 - n1] = 0.0;
+        else p3[i - n0 - n1 - n2] = 0.0;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Direct solve of SMALL reduced systems (nr * D <= 90 unknowns: the reference's own examples, sliding
 // windows, motion-only problems): BSR -> dense, the LDS-resident blocked Cholesky + inverse of the
