@@ -29,8 +29,13 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 4)), dim3(256), 0, h->stream, nr, h->diag_slot,
                        h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
                        h->poses, h->pose_of_rid, h->coarse_basis, h->Bmat, h->bgv);
-    hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
-                       h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
+    static const bool scale_pipe = !getenv("PS_SCALE_NO_PIPE");
+    if (scale_pipe)
+        hipLaunchKernelGGL(k_scale_blocks_p<D>, dim3(cdiv(h->nnzb, 4 * PS_SCB_NB)), dim3(256), 0, h->stream, h->nnzb, h->col_idx,
+                           h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
+    else
+        hipLaunchKernelGGL(k_scale_blocks<D>, dim3(h->nnzb), dim3(64), 0, h->stream, nr, h->row_ptr, h->col_idx,
+                           h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
     // A_c^-1 lives in LciT2[b] (the transposed factor is not used on this path).  It only PRECONDITIONS here, so any
     // symmetric positive definite stand-in keeps the CG exact: whole-iteration calls use the inverse formed from the
     // PREVIOUS iteration's A_c and form + factor the current one on the side stream while the CG iterates (assembly,
