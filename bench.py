@@ -155,22 +155,31 @@ def time_steps(dev, steps, warmup, fence):
     return time.perf_counter() - t0, out
 
 
-def trajectory(dev, iters=5):
+def trajectory(dev, iters=5, reps=3):
     """`iters` consecutive Gauss-Newton iterations from the perturbed start WITHOUT restoring the
-    linearisation point: what a real solve() pays (stale lagged coarse factor, CG launch-count misses)."""
+    linearisation point: what a real solve() pays (stale lagged coarse factor, CG launch-count misses).
+    A single call is 0.2-0.4 ms of host wall clock, so the trajectory is run `reps` times (each time after a few
+    steady-state steps at the start point, which is the state the first run starts from) and the per-call MEDIAN reported."""
     import torch
+    runs, its, costs = [], [], []
+    for rep in range(reps):
+        for _ in range(0 if rep == 0 else 8):
+            dev.restore(); dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)
+        dev.restore()
+        torch.cuda.synchronize()
+        per, its, costs = [], [], []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            cost, _, n, _ = dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)     # synchronises (results are read back)
+            per.append((time.perf_counter() - t0) * 1e3)
+            its.append(n); costs.append(cost)
+        runs.append(per)
     dev.restore()
-    torch.cuda.synchronize()
-    per, its, costs = [], [], []
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        cost, _, n, _ = dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)     # synchronises (results are read back)
-        per.append((time.perf_counter() - t0) * 1e3)
-        its.append(n); costs.append(cost)
-    dev.restore()
+    per = [float(np.median([r[k] for r in runs])) for k in range(iters)]
     return {'mean': round(float(np.mean(per)), 4), 'per_iter': [round(p, 4) for p in per], 'pcg_iters': its,
-            'cost': costs, 'note': '{} consecutive iterations from the perturbed start, no restore, host wall clock per '
-                                   'ps_gn_iteration call (each call ends with its one synchronisation)'.format(iters)}
+            'cost': costs, 'runs_mean': [round(float(np.mean(r)), 4) for r in runs],
+            'note': '{} consecutive iterations from the perturbed start, no restore, host wall clock per ps_gn_iteration call '
+                    '(each call ends with its one synchronisation); per-call median of {} runs'.format(iters, reps)}
 
 
 def problem_info(dev):
