@@ -263,7 +263,7 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
                               was formed from.  A call whose lambda differs from the newest inverse's factors its own A_c (no lag).
      "xcg_restrict_fused" [1] explicit two-level PCG: three launches per iteration (restriction in the SpMV epilogue, t by recurrence)
                               instead of four
-     "lagged_inverse"     [1] reduced systems of 91 .. "ldi_max_unknowns" [1536] unknowns (folded CG, one GPU, whole-iteration calls):
+     "lagged_inverse"     [1] reduced systems of 91 .. "ldi_max_unknowns" [2048; up to 3328: pays from ~7 iterations per solve on] unknowns (folded CG, one GPU, whole-iteration calls):
                               precondition the CG with a dense fp32 inverse of the PREVIOUS iteration's S, kept current on the side
                               stream by one Newton-Schulz step per iteration (two fp32 MFMA GEMMs) and seeded from the two-level
                               operator of the last standard solve; tried while the last step changed the cost by at most

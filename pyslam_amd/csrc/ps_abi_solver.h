@@ -557,7 +557,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "coarse_auto_hold") h->xcg_auto_hold = value != 0;
     else if (n == "xcg_fused") { if (value != 0 && value != 1 && value != 2) return fail("xcg_fused must be 0, 1 or 2"); h->xcg_fused = (int)value; }
     else if (n == "lagged_inverse") { h->ldi_enable = value != 0; if (!h->ldi_enable) { h->ldi_cur = -1; if (h->ldi_state != 1) h->ldi_state = 0; } }
-    else if (n == "ldi_max_unknowns") { if (value < 0 || value > PS_LDI_MAXN) return fail("ldi_max_unknowns out of range (0 .. 2048)"); h->ldi_max_n = (int)value; }
+    else if (n == "ldi_max_unknowns") { if (value < 0 || value > PS_LDI_MAXN) return fail("ldi_max_unknowns out of range (0 .. 3328)"); h->ldi_max_n = (int)value; }
     else if (n == "ldi_cap") { if (value < 1 || value > 64) return fail("ldi_cap out of range (1 .. 64)"); h->ldi_cap = (int)value; }
     else if (n == "ldi_cost_tol") { if (!(value >= 0)) return fail("ldi_cost_tol must be >= 0"); h->ldi_cost_tol = value; }
     else if (n == "ldi_refresh_its") { if (value < 0 || value > 64) return fail("ldi_refresh_its out of range (0 .. 64)"); h->ldi_refresh_its = (int)value; }

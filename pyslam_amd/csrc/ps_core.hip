@@ -320,7 +320,7 @@ struct ps_problem {
     int nsq_l = 0, nsq_p = 0;
     // lagged dense inverse of the reduced system as the CG preconditioner (ps_k_ldi.h / ps_host_ldi.h)
     int ldi_enable = 1;             // option "lagged_inverse"
-    int ldi_max_n = 1536;           // option "ldi_max_unknowns": reduced systems up to this many unknowns
+    int ldi_max_n = 2048;           // option "ldi_max_unknowns": reduced systems up to this many unknowns
     int ldi_cap = 12;               // option "ldi_cap": PCG iterations before a solve gives the inverse up
     int ldi_seed_steps = 3;         // Newton-Schulz steps of a seed
     double ldi_cost_tol = 0.05;     // option "ldi_cost_tol": try the inverse while the last step changed the cost by at most this (relative)

@@ -276,7 +276,10 @@ int ldi_solve_and_finish(ps_problem* h, double tol, int max_iters, int linesearc
     // One Newton-Schulz step beside this solve only when the previous solve with this inverse took more than
     // ldi_refresh_its iterations: a refresh costs the latency-bound launches beside it ~70 us at C3 (measured), one PCG
     // iteration ~11 us, so a settled solve runs with NO side-stream work at all and a drifting S switches the refresh on
-    const bool refresh = h->ldi_last_its > h->ldi_refresh_its;
+    // (beyond 2 048 unknowns a refresh -- two n^3 GEMMs beside the solve -- costs more than the iterations it saves: a 420-keyframe
+    //  BA, 2 514 unknowns, ran 0.39 ms per call at 7 iterations and 0.69 once 8 iterations switched the refresh on; standard
+    //  solver 0.60.  There the inverse simply ages until ldi_cap gives it up and the next standard solve re-seeds.)
+    const bool refresh = h->ldi_last_its > h->ldi_refresh_its + (n > 2048 ? 4 : 0);
     h->ldi_side_todo = refresh; h->ldi_update_ok = false;
     // launch sequence: spmv(0) update(0) spmv(1) update(1) ... ; spmv(k) is the launch that detects convergence of iteration
     // k, so a solve of m iterations needs 2 m + 1 launches and ends on an spmv -- exactly that many are enqueued when the

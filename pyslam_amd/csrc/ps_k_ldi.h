@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_ldi_fro_total(int nparts, const double*
 // the whole residual vector in LDS.
 // ---------------------------------------------------------------------------
 #define PS_LDI_ROWS 4
-#define PS_LDI_MAXN 2048
+#define PS_LDI_MAXN 3328
 #define PS_LDI_RPW (PS_LDI_ROWS / 4)            // rows of X_u per wave
 #define PS_LDI_NF4 (PS_LDI_MAXN / 256)          // float4 pieces of a row per lane
 

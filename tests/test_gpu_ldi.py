@@ -205,6 +205,28 @@ def test_direct_seed_on_a_bundle_adjustment_problem():
     assert info(dev)[0] >= 2 and out[2] <= 6
 
 
+@pytest.mark.parametrize('kf,limit', [(300, None), (400, 3328)])
+def test_lagged_inverse_on_the_largest_systems_it_takes(kf, limit):
+    """1 794 unknowns (inside the default limit of 2 048) and 2 394 (option raised to the hard limit, where the refresh is
+    off): the same trajectory as the standard solver, and the inverse does engage."""
+    from pyslam_amd import synthetic
+    lp = synthetic.stereo_ba(num_kf=kf, num_lm=100 * kf, obs_per_lm=8, half_window=12, seed=kf)[0]
+    a, b = make(lp, True), make(lp, False)
+    if limit:
+        a.set_option('ldi_max_unknowns', limit)
+    its = []
+    for _ in range(8):
+        ca = a.gn_iteration(0., 1e-12, 2000, True)
+        cb = b.gn_iteration(0., 1e-12, 2000, True)
+        assert abs(ca[0] - cb[0]) <= 1e-10 * abs(cb[0]) and ca[3] <= 1e-12
+        its.append((ca[2], cb[2]))
+    pa, pb = a.get_params(), b.get_params()
+    assert np.abs(pa[0] - pb[0]).max() < 1e-9 and np.abs(pa[1] - pb[1]).max() < 1e-9
+    solves, fallbacks, seeds = info(a)
+    assert solves >= 3 and seeds >= 1, (solves, fallbacks, seeds, its)
+    assert its[-1][0] <= 10 and its[-1][1] >= 2 * its[-1][0], its
+
+
 def test_option_off_and_rebuilt_coarse_level():
     """Switching the option off drops the inverse; changing the coarse level re-lays it out (sizes depend on it)."""
     lp = ba(50, 4000, 2)
