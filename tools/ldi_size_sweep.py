@@ -6,7 +6,7 @@ sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', os.getcwd()))
 import numpy as np, torch
 from pyslam_amd import synthetic
 from pyslam_amd.device import DeviceProblem
-for kf, lm in ((16, 1500), (24, 3000), (40, 6000), (64, 12000), (100, 25000), (150, 40000), (200, 50000), (250, 60000)):
+for kf, lm in ((16, 1500), (24, 3000), (40, 6000), (64, 12000), (100, 25000), (150, 40000), (200, 50000), (250, 60000), (300, 75000), (340, 85000)):
     lp = synthetic.stereo_ba(num_kf=kf, num_lm=lm, obs_per_lm=8, half_window=12, seed=kf)[0]
     for on in (1, 0):
         dev = DeviceProblem(lp)
