@@ -47,7 +47,11 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     // do not wait for the side stream.  A fixed schedule, not a completion poll: results stay reproducible run to run.
     // (an inverse formed under another damping is a poor stand-in -- 93 CG iterations against 24 on a 600-keyframe BA when lambda
     // goes from 0 to 1e-3: such a call factors its own A_c, on the solver stream)
-    const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && h->lin_lambda == h->xcg_tag_lambda[h->lci_next];
+    // (a damping within a factor of four of the inverse's -- an LM schedule that halves or doubles lambda -- still lags: the
+    //  coarse eigenvalues move by that factor at most, and the alternative is a factorisation on the solver stream)
+    const double lam_inv = h->lci_next >= 0 ? h->xcg_tag_lambda[h->lci_next] : 0.0, lam_now = h->lin_lambda;
+    const bool lam_ok = lam_now == lam_inv || (lam_now > 0.0 && lam_inv > 0.0 && lam_now <= 4.0 * lam_inv && lam_inv <= 4.0 * lam_now);
+    const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && lam_ok;
     const bool settled = h->xcg_auto_hold && h->prev_cost > 0.0 && h->last_cost > 0.0 &&
                          std::fabs(h->prev_cost - h->last_cost) <= 1e-4 * h->prev_cost && h->xcg_held < 3;
     // ... or the inverse in use was formed from the A_c of THIS linearisation point (the caller linearises at the same point
