@@ -260,7 +260,8 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
      "coarse_auto_hold"   [1] explicit two-level PCG: while the solve has settled (last iteration changed the cost by < 1e-4
                               relative) keep the lagged coarse inverse, for at most 3 set-ups in a row (no assembly, no factorisation);
                               and for as long as the caller linearises at the point (same start cost, same lambda) the inverse in use
-                              was formed from.  A call whose lambda differs from the newest inverse's factors its own A_c (no lag).
+                              was formed from.  A call whose lambda is more than a factor of four from the newest inverse's (or zero against non-zero)
+                              factors its own A_c (no lag).
      "xcg_restrict_fused" [1] explicit two-level PCG: three launches per iteration (restriction in the SpMV epilogue, t by recurrence)
                               instead of four
      "lagged_inverse"     [1] reduced systems of 91 .. "ldi_max_unknowns" [2048; up to 3328: pays from ~7 iterations per solve on] unknowns (folded CG, one GPU, whole-iteration calls):
