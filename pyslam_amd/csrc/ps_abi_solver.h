@@ -537,6 +537,14 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2) {
     return 0;
 }
 
+// the folded / explicit crossover depends on whether the lagged dense inverse can apply (ps_host_cg.h: build_coarse): an
+// option that changes that answer has the coarse level rebuilt by the next solve
+static void relook_path(ps_problem* h) {
+    const long n = (long)h->nr * h->D;
+    const bool possible = h->ldi_enable && n <= h->ldi_max_n && n <= PS_LDI_MAXN && n > h->direct_max;
+    if (h->coarse_built && possible != h->xmin_auto_ldi && h->cg_explicit_min_rows < 0) h->coarse_built = false;
+}
+
 int ps_set_option(ps_problem* h, const char* name, double value) {
     if (!h || !name) return fail("null argument");
     const std::string n(name);
@@ -556,8 +564,8 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
     else if (n == "coarse_auto_hold") h->xcg_auto_hold = value != 0;
     else if (n == "xcg_fused") { if (value != 0 && value != 1 && value != 2) return fail("xcg_fused must be 0, 1 or 2"); h->xcg_fused = (int)value; }
-    else if (n == "lagged_inverse") { h->ldi_enable = value != 0; if (!h->ldi_enable) { h->ldi_cur = -1; if (h->ldi_state != 1) h->ldi_state = 0; } }
-    else if (n == "ldi_max_unknowns") { if (value < 0 || value > PS_LDI_MAXN) return fail("ldi_max_unknowns out of range (0 .. 3328)"); h->ldi_max_n = (int)value; }
+    else if (n == "lagged_inverse") { h->ldi_enable = value != 0; if (!h->ldi_enable) { h->ldi_cur = -1; if (h->ldi_state != 1) h->ldi_state = 0; } relook_path(h); }
+    else if (n == "ldi_max_unknowns") { if (value < 0 || value > PS_LDI_MAXN) return fail("ldi_max_unknowns out of range (0 .. 3328)"); h->ldi_max_n = (int)value; relook_path(h); }
     else if (n == "ldi_cap") { if (value < 1 || value > 64) return fail("ldi_cap out of range (1 .. 64)"); h->ldi_cap = (int)value; }
     else if (n == "ldi_cost_tol") { if (!(value >= 0)) return fail("ldi_cost_tol must be >= 0"); h->ldi_cost_tol = value; }
     else if (n == "ldi_refresh_its") { if (value < 0 || value > 64) return fail("ldi_refresh_its out of range (0 .. 64)"); h->ldi_refresh_its = (int)value; }

@@ -286,6 +286,7 @@ struct ps_problem {
     // split mode (large systems): coarse rows are owned by k_cg_reduce_split
     bool cg_split = false;
     int cg_split_min_rows = 1024;
+    bool xmin_auto_ldi = false;     // build_coarse chose the folded / explicit crossover assuming the lagged inverse applies (re-decided when that changes)
     int cg_explicit_min_rows = -1;  // explicit two-level PCG beyond this many reduced poses (-1: 400 for pose-graph rows, 540 for BA rows)
     double *cg_U = nullptr, *cg_cgd[2] = {}, *cg_ab = nullptr;
     int cg_launched = 0;            // CG launches enqueued since the last setup

@@ -208,7 +208,15 @@ int build_coarse(ps_problem* h) {
     // beside a short CG): one per 20 poses, up to 112 (C4: 42 iterations / 3.7 ms folded at 48 -> 20 / 2.6 ms at 100).
     // Measured crossover against the folded single-launch CG (whose coarse level is capped at 12 intervals):
     // pose graphs 400 poses (600: 2.6 -> 1.4 ms, 1 000: 6.1 -> 1.5 ms), bundle adjustment 540 (700: 1.67 -> 1.28 ms).
-    const int xmin = std::min(h->cg_split_min_rows, h->cg_explicit_min_rows >= 0 ? h->cg_explicit_min_rows : (sparse_rows ? 400 : 540));
+    // ... those crossovers were measured against the three-launch explicit PCG of round 2 and are kept where the folded CG
+    // can have the lagged dense inverse (ldi_possible: it beats both).  Where it cannot -- more than ldi_max_unknowns, or
+    // switched off -- the one- / two-launch explicit PCG of round 3 wins from ~250 poses on (tools/path_threshold_probe.py,
+    // settled ms folded / explicit: BA 250 keyframes 0.435 / 0.412, 360: 0.53 / 0.45, 480: 0.71 / 0.51, 539: 0.80 / 0.53;
+    // SE(3) graphs 250 poses 0.64 / 0.60, 350: 0.82 / 0.72; at 200 keyframes / poses the folded form still leads, 0.31 / 0.40).
+    const bool ldi_possible = h->ldi_enable && (long)nr * D <= h->ldi_max_n && (long)nr * D <= PS_LDI_MAXN && nr * D > h->direct_max;
+    const int xmin_auto = ldi_possible ? (sparse_rows ? 400 : 540) : 250;
+    h->xmin_auto_ldi = ldi_possible;
+    const int xmin = std::min(h->cg_split_min_rows, h->cg_explicit_min_rows >= 0 ? h->cg_explicit_min_rows : xmin_auto);
     h->cg_explicit = h->explicit_ok && G != 0 && nr > xmin;
     if (h->cg_explicit && h->coarse_req < 0)
         G = sparse_rows ? std::min(400, std::max(48, nr / 25)) : std::min(112, std::max(48, nr / 20));

@@ -35,6 +35,9 @@ echo
 echo "# lagged dense inverse on / off over BA sizes, eight-call trajectories (tools/ldi_size_sweep.py)"
 python tools/ldi_size_sweep.py 2>&1 | grep -v amdgpu.ids
 echo
+echo "# folded CG / explicit PCG / lagged inverse around the sizes where the default switches (tools/path_threshold_probe.py)"
+python tools/path_threshold_probe.py 2>&1 | grep -v amdgpu.ids
+echo
 echo "# per-frame motion-only Problem through the public API (tools/c5_frame_probe.py)"
 python tools/c5_frame_probe.py 2>&1 | grep -v amdgpu.ids | tail -1
 echo
