@@ -704,3 +704,18 @@ def test_pipelined_schur_kernel_equals_the_one_chunk_kernel_bit_for_bit(monkeypa
         want = (Hpp - Hpl @ spla.spsolve(Hll.tocsc(), Hpl.T.tocsc())).toarray()
         assert rel_err(S, want) < 1e-11, k
         dev.close()
+
+
+def test_option_values_out_of_range_are_refused():
+    """ps_set_option: the options added in round 3 reject values outside their range (and leave the handle usable)."""
+    from pyslam_amd import synthetic, _native as nat
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=200, obs_per_lm=4, half_window=4, seed=1)
+    dev = DeviceProblem(lp)
+    for name, bad in (('xcg_fused', 3), ('ldi_seed_lag', 0), ('ldi_max_unknowns', 5000), ('ldi_seed_steps', 0), ('ldi_cap', 0)):
+        with pytest.raises(nat.NativeError):
+            dev.set_option(name, bad)
+    for name, ok in (('xcg_fused', 2), ('ldi_seed_lag', 1), ('ldi_max_unknowns', 3328), ('ldi_direct', 1), ('direct_fused', 0), ('coarse_auto_hold', 0)):
+        dev.set_option(name, ok)
+    out = dev.gn_iteration(0., 1e-12, 500, True)
+    assert np.isfinite(out[0]) and out[3] <= 1e-12
