@@ -273,7 +273,7 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
      "ldi_direct"         [-1] ... seeded by a DIRECT fp64 factorisation of S on a stream of its own instead of Newton-Schulz
                               (-1: pose graphs from the start, any problem after a rejected Newton-Schulz seed; 0 never; 1 always);
                               usable a fixed 2 / 4 / 6 calls later (n <= 400 / 800 / 1 536)
-     "ldi_seed_lag" [2], "ldi_seed_steps" [3], "ldi_refresh_its" [7]: schedule of the Newton-Schulz seed / refresh
+     "ldi_seed_lag" [1], "ldi_seed_steps" [3], "ldi_refresh_its" [7]: schedule of the Newton-Schulz seed / refresh
      "xcg_fused"          [1] explicit two-level PCG: ONE launch per iteration (single-reduction recurrences; the restriction, the coarse
                               product for the nodes a workgroup needs, the prolongation and the SpMV in one kernel, the row's matrix
                               blocks requested before the scalar phase) up to 2 048 poses and 2 048 coarse unknowns, TWO beyond (scalars,

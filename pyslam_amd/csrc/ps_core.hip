@@ -341,7 +341,10 @@ struct ps_problem {
     int ldi_refresh_its = 7;        // option "ldi_refresh_its": solves slower than this switch the per-iteration refresh on
     bool ldi_refreshed = false;     // the inverse in use has had a Newton-Schulz step since its seed
     int2* ldi_krange = nullptr;
-    int ldi_seed_lag = getenv("PS_LDI_SEED_LAG") ? atoi(getenv("PS_LDI_SEED_LAG")) : 2;   // calls between a seed's start and its first use (fixed schedule)
+    // calls between a seed's start and its first use (fixed schedule).  1: the call after the seed waits for it where the solve
+    // begins (~0.1 ms of the seed's GEMMs are then still ahead at C3, hidden behind this call's linearisation for most of it) and
+    // takes 6 iterations instead of 18-25 -- eight-call solves 3-7 % shorter at every size from 138 to 2 034 unknowns than with 2
+    int ldi_seed_lag = getenv("PS_LDI_SEED_LAG") ? atoi(getenv("PS_LDI_SEED_LAG")) : 1;
     int ldi_rejects = 0; long ldi_no_seed_before = 0;
     // direct seed (ps_host_ldi.h: ldi_direct_enqueue): on for pose graphs from the start, for any problem after a rejected
     // Newton-Schulz seed; option "ldi_direct" (-1 auto, 0 never, 1 always)
