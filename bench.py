@@ -9,20 +9,33 @@ reduced pose system (relative tolerance 1e-12, the parity setting),
 back-substitution, retraction and the post-step cost pass -- exactly what the
 reference's ``Problem.solve_one_iter`` + update does (pyslam/problem.py:145-156).
 
+``value`` is the per-iteration cost of COLD, REFERENCE-TERMINATED SOLVES: the timed
+region is whole solves from the perturbed start, each running the loop of
+``Problem.solve`` (pyslam_amd/problem.py: device_solve -- the very function Problem.solve
+calls; reference pyslam/problem.py:130-178) under the options of the reference's own
+example (examples/stereo_ba.py:38-40: allow_nondecreasing_steps, max_nondecreasing_steps
+= 3): start cost, then iterations until the reference's stopping rule ends the solve (4 at
+C3).  Before every solve the solver state is cleared (ps_reset_solver_state: no lagged
+coarse factor, no lagged inverse, no held operator, no launch-count prediction, no cost
+history) and the start parameters are uploaded again -- both outside the clock; everything
+a solve itself does (start cost, iterations, best-parameter snapshots, the final restore)
+is inside.  value = sum of solve times / sum of iterations, over exactly K iterations (the
+last solve is cut at the K-th).  The W warm-up steps are whole untimed solves (at least one).
+Extra keys keep the figures of earlier rounds: ``steady_same_point_ms`` (every step restores
+the same linearisation point; with the lagged inverse that is the settled phase no
+reference-terminated solve reaches), ``moving_same_point_ms`` (the same with the inverse off).
+
 N = 1: workload C3 of SURVEY.md section 8d (200 keyframes, 50 000 landmarks,
 500 000 reprojection blocks = 1.5 M residual rows), the configuration
-BASELINE.json's metric is quoted on.  ``value`` is the steady-state figure (every
-timed step starts from the same linearisation point: a device-side restore of the
-initial parameters, so all K steps do identical work); next to it the line carries
-``trajectory_ms_per_iter`` (5 consecutive iterations of a real solve, no restore:
-the lagged coarse factor and the CG launch-count prediction are live) and
-``c4_single_gpu_ms`` (the north star's 2 000-keyframe / 500 000-landmark problem on
-this one GPU -- the strong-scaling base).
+BASELINE.json's metric is quoted on; ``c4_single_gpu`` carries the same cold-solve
+measurement of the north star's 2 000-keyframe / 500 000-landmark problem on this one
+GPU (the strong-scaling base), ``cold_solve_wall_ms`` the wall clock of ``Problem.solve()``
+through the public API (objects -> lowering -> ps_problem_create -> iterations).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of
 the fixed C4 problem (2 000 keyframes, 500 000 landmarks, 5 M blocks; BASELINE.json
-configs[3]): every rank generates the same problem and keeps landmark shard
-``rank`` of N (``shard_landmarks``); the reduced pose system [upper(S) | g | cost | flag]
+configs[3]), the same cold solves: every rank generates the same problem and keeps landmark
+shard ``rank`` of N (``shard_landmarks``); the reduced pose system [upper(S) | g | cost | flag]
 is summed with one RCCL all-reduce per iteration (issued by the HIP core itself on
 the solver's stream) and then solved redundantly on every rank; a second small
 all-reduce sums the shards' cost and landmark step norm.  Rank 0 also times the
@@ -66,13 +79,16 @@ def algorithmic_bytes(info, n_pcg, dof=6):
 
 
 def kernel_source_sha():
-    """Hash of the HIP sources: ties a committed PMC pass to the build it was taken on."""
-    h = hashlib.sha256()
-    d = os.path.join(REPO, 'pyslam_amd', 'csrc')
-    for f in sorted(os.listdir(d)):
-        with open(os.path.join(d, f), 'rb') as fh:
-            h.update(f.encode()); h.update(fh.read())
-    return h.hexdigest()[:16]
+    """The source hash COMPILED INTO the loaded library (ps_build_sha, -DPS_BUILD_SHA of __graft_entry__.build()), after
+    checking that it equals the hash of the sources on disk: a bench line is tied to the binary that produced it."""
+    import __graft_entry__ as ge
+    from pyslam_amd import _native as nat
+    built = nat.load().ps_build_sha().decode()
+    disk = ge.source_sha()
+    if built != disk:
+        raise SystemExit('bench.py: the loaded library was built from sources {} but the files on disk hash to {}: '
+                         'rebuild (python -c "import __graft_entry__ as g; g.build()")'.format(built, disk))
+    return built
 
 
 def pmc_traffic(kernel, config=None):
@@ -139,6 +155,72 @@ def cpu_baseline(lp, repeats=5):
                                     'full 151 194-unknown C3 system; not re-run here (exceeds the time bound)'}
 
 
+def example_options():
+    """Options of the reference's stereo-BA example (examples/stereo_ba.py:38-40) + the parity tolerance of the reduced solve."""
+    from pyslam_amd.problem import Options
+    opt = Options()
+    opt.allow_nondecreasing_steps = True
+    opt.max_nondecreasing_steps = 3
+    opt.pcg_tol, opt.pcg_max_iters = PCG_TOL, PCG_MAX
+    return opt
+
+
+class TimedCalls:
+    """DeviceProblem seen through a wall clock per ps_gn_iteration call (each call ends with its one synchronisation)."""
+
+    def __init__(self, dev):
+        self._dev = dev
+        self.calls = []          # (seconds, pcg iterations, cost) per whole-iteration call
+
+    def __getattr__(self, name):
+        return getattr(self._dev, name)
+
+    def gn_iteration(self, *a):
+        t0 = time.perf_counter()
+        out = self._dev.gn_iteration(*a)
+        self.calls.append((time.perf_counter() - t0, out[2], out[0]))
+        return out
+
+
+def cold_solves(dev, start, total_iters, fence, warm_solves=1):
+    """Whole solves from the perturbed start (`start` = (poses, points) host tables), solver state cleared before each, the
+    loop of Problem.solve under the reference example's options, until exactly `total_iters` iterations have run (the last
+    solve is cut there).  Timed per solve: start cost + iterations + snapshots + final restore + the synchronisation that
+    ends it; NOT timed: ps_reset_solver_state and the upload of the start parameters.
+    -> dict(seconds, iterations, solves, per_call_ms (median by position in the solve), pcg_iters, cost_history)."""
+    from pyslam_amd.problem import device_solve
+    core = dev.dev if hasattr(dev, 'dev') else dev
+
+    def one(max_its):
+        opt = example_options()
+        if max_its is not None:
+            opt.max_iters = max_its - 1                   # (the loop stops once its counter exceeds max_iters)
+        core.reset_solver_state()
+        core.set_params(*start)
+        fence()
+        tdev = TimedCalls(dev)
+        t0 = time.perf_counter()
+        hist, stats = device_solve(tdev, opt)
+        fence()                                           # (the final restore of the best parameters is enqueue-only)
+        return time.perf_counter() - t0, hist, tdev.calls
+
+    for _ in range(max(1, warm_solves)):
+        one(None)
+    sec, its, solves, calls_by_pos, hist0, pcg0 = 0.0, 0, 0, [], None, None
+    while its < total_iters:
+        dt, hist, calls = one(total_iters - its)
+        sec += dt; its += len(calls); solves += 1
+        if hist0 is None:
+            hist0, pcg0 = hist, [c[1] for c in calls]
+        for k, c in enumerate(calls):
+            if k >= len(calls_by_pos):
+                calls_by_pos.append([])
+            calls_by_pos[k].append(c[0] * 1e3)
+    return {'seconds': sec, 'iterations': its, 'solves': solves,
+            'per_call_ms': [round(float(np.median(c)), 4) for c in calls_by_pos],      # median over the solves, by call index
+            'pcg_iters': pcg0, 'cost_history': hist0}
+
+
 def time_steps(dev, steps, warmup, fence):
     """W untimed + K timed steady-state steps (restore + iteration); -> (seconds, last result)."""
     def step():
@@ -153,33 +235,6 @@ def time_steps(dev, steps, warmup, fence):
         out = step()
     fence()
     return time.perf_counter() - t0, out
-
-
-def trajectory(dev, iters=5, reps=3):
-    """`iters` consecutive Gauss-Newton iterations from the perturbed start WITHOUT restoring the
-    linearisation point: what a real solve() pays (stale lagged coarse factor, CG launch-count misses).
-    A single call is 0.2-0.4 ms of host wall clock, so the trajectory is run `reps` times (each time after a few
-    steady-state steps at the start point, which is the state the first run starts from) and the per-call MEDIAN reported."""
-    import torch
-    runs, its, costs = [], [], []
-    for rep in range(reps):
-        for _ in range(0 if rep == 0 else 8):
-            dev.restore(); dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)
-        dev.restore()
-        torch.cuda.synchronize()
-        per, its, costs = [], [], []
-        for _ in range(iters):
-            t0 = time.perf_counter()
-            cost, _, n, _ = dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)     # synchronises (results are read back)
-            per.append((time.perf_counter() - t0) * 1e3)
-            its.append(n); costs.append(cost)
-        runs.append(per)
-    dev.restore()
-    per = [float(np.median([r[k] for r in runs])) for k in range(iters)]
-    return {'mean': round(float(np.mean(per)), 4), 'per_iter': [round(p, 4) for p in per], 'pcg_iters': its,
-            'cost': costs, 'runs_mean': [round(float(np.mean(r)), 4) for r in runs],
-            'note': '{} consecutive iterations from the perturbed start, no restore, host wall clock per ps_gn_iteration call '
-                    '(each call ends with its one synchronisation); per-call median of {} runs'.format(iters, reps)}
 
 
 def problem_info(dev):
@@ -206,38 +261,130 @@ def c5_frames():
     return out
 
 
-def c4_single_gpu(stream, steps=10, warmup=5):
-    """The unsharded C4 problem on the current GPU: steady-state ms per iteration + stage breakdown."""
+def stage_breakdown(dev, start, fence):
+    """One more (untimed) cold solve with an event pair around every stage: mean ms per stage and iteration."""
+    core = dev.dev if hasattr(dev, 'dev') else dev
+    core.set_option('profile_every', 1)
+    dev.set_profiling(2)
+    dev.stage_times(reset=True)
+    cold_solves(dev, start, 4, fence, warm_solves=0)
+    st = dev.stage_times(reset=True)
+    dev.set_profiling(0)
+    return st
+
+
+def pmc_config(cfg):
+    """Which table of profiles/pmc_traffic.json belongs to a workload: None = the top level (C3), 'C4', or no table at all."""
+    size = (cfg['num_kf'], cfg['num_lm'])
+    return None if size == (C3['num_kf'], C3['num_lm']) else ('C4' if size == (C4['num_kf'], C4['num_lm']) else 'not collected')
+
+
+def schur_roofline(info, sch_ms, config, n_pcg=0, note=None):
+    """roofline object of the dominant kernel (the Schur pair kernel, + its combine launch in tiled mode)."""
+    _, b_schur, _ = algorithmic_bytes(info, n_pcg)
+    ach = b_schur / (sch_ms * 1e-3) / 1e9 if sch_ms > 0 else 0.0
+    traffic, tsha, thead = pmc_traffic('k_schur_pairs_db', config)
+    sha = kernel_source_sha()
+    if traffic is not None and tsha != sha:
+        print('bench.py: WARNING profiles/pmc_traffic.json ({}) was collected on kernel sources {} but this build is {}: '
+              'roofline.traffic is stale (re-run tools/collect_profiles.sh)'.format(config, tsha, sha), file=sys.stderr)
+    roof = {'bound': 'hbm', 'kernel': 'k_schur_pairs_db', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source_sha': tsha, 'traffic_git_head': thead,
+            'build_source_sha': sha, 'traffic_stale': bool(traffic is not None and tsha != sha),
+            'algorithmic_bytes_per_launch': int(b_schur), 'avg_launch_ms': round(sch_ms, 5)}
+    if note:
+        roof['note'] = note
+    return roof
+
+
+def c4_single_gpu(stream, iters=8):
+    """The unsharded C4 problem on the current GPU: the same cold, reference-terminated solves + stage breakdown."""
     import torch
     from pyslam_amd import synthetic
     from pyslam_amd.device import DeviceProblem
     lp, _ = synthetic.stereo_ba(obs_per_lm=OBS_PER_LM, half_window=HALF_WINDOW, **C4)
     dev = DeviceProblem(lp, stream=stream)
-    dev.eval_cost(True)                                      # (as Problem.solve does: the core then knows the start cost)
-    dev.snapshot()
-    sec, out = time_steps(dev, steps, warmup, torch.cuda.synchronize)
-    dev.set_profiling(2)
-    for _ in range(3):
-        dev.restore(); dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)
-    st = dev.stage_times(reset=True)
-    dev.set_profiling(0)
-    traj = trajectory(dev, 4)
+    start = (lp.poses.copy(), lp.points.copy())
+    cold = cold_solves(dev, start, iters, torch.cuda.synchronize)
+    st = stage_breakdown(dev, start, torch.cuda.synchronize)
     stage = {k: v[0] / v[1] for k, v in st.items() if v[1] > 0}
-    _, b_schur, _ = algorithmic_bytes(dev.info, out[2])
-    sch_ms = stage.get('schur_pairs', 0.0)
-    traffic, tsha, _ = pmc_traffic('k_schur_pairs_db', 'C4')
-    ach = b_schur / (sch_ms * 1e-3) / 1e9 if sch_ms > 0 else 0.0
-    roof = {'bound': 'hbm', 'kernel': 'k_schur_pairs_db', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source_sha': tsha,
-            'traffic_stale': bool(traffic is not None and tsha != kernel_source_sha()),
-            'algorithmic_bytes_per_launch': int(b_schur), 'avg_launch_ms': round(sch_ms, 5),
-            'note': 'pair + combine kernel, hipEvent pair around both on 3 untimed steps (profiling level 2)'}
-    res = {'ms': round(sec * 1e3 / steps, 4), 'roofline': roof, 'pcg_iters': out[2], 'blocks': dev.info['num_obs'],
-           'reduced_blocks': dev.info['reduced_nnzb'], 'device_bytes': dev.info['device_bytes'],
-           'stage_ms': {k: round(v[0] / v[1], 4) for k, v in st.items() if v[1] > 0},
-           'trajectory_ms_per_iter': traj['per_iter'], 'trajectory_pcg_iters': traj['pcg_iters']}
+    # the figures of earlier rounds: the same linearisation point restored before every step (coarse inverse held)
+    dev.reset_solver_state(); dev.set_params(*start)
+    dev.eval_cost(True); dev.snapshot()
+    sec, out = time_steps(dev, 10, 5, torch.cuda.synchronize)
+    res = {'ms': round(cold['seconds'] * 1e3 / cold['iterations'], 4), 'iterations': cold['iterations'], 'solves': cold['solves'],
+           'per_call_ms': cold['per_call_ms'], 'pcg_iters': cold['pcg_iters'], 'cost_history': cold['cost_history'],
+           'steady_same_point_ms': round(sec * 1e3 / 10, 4), 'steady_same_point_pcg_iters': out[2],
+           'roofline': schur_roofline(dev.info, stage.get('schur_pairs', 0.0), 'C4',
+                                      note='pair + combine kernel, hipEvent pair around both on the iterations of one untimed cold solve (profiling level 2)'),
+           'blocks': dev.info['num_obs'], 'reduced_blocks': dev.info['reduced_nnzb'], 'device_bytes': dev.info['device_bytes'],
+           'stage_ms': {k: round(v, 4) for k, v in stage.items()}}
     dev.close()
     return res
+
+
+def cold_solve_wall(cfg):
+    """Wall clock of Problem.solve() through the public API on the workload `cfg`, fresh Problem, fresh handle: residual-block
+    objects -> lowering (the walk over the blocks) -> ps_problem_create (structure build + upload) -> start cost + iterations
+    -> write-back into the parameter objects; the reference's example options.  Run twice: the second run shows what the
+    process-wide one-off costs (code-object load, first allocations) were."""
+    import types
+    import torch
+    import pyslam.problem as P
+    import pyslam.residuals as R
+    import pyslam.losses as Ls
+    import pyslam.sensors as S
+    import liegroups as G
+    from pyslam_amd import synthetic
+    import pyslam_amd.problem as core_problem
+    import pyslam_amd.device as core_device
+    ns = types.SimpleNamespace(Problem=P.Problem, Options=P.Options, StereoCamera=S.StereoCamera, PoseResidual=R.PoseResidual,
+                               PoseToPoseResidual=R.PoseToPoseResidual, PoseToPoseOrientationResidual=R.PoseToPoseOrientationResidual,
+                               ReprojectionResidual=R.ReprojectionResidual, L2Loss=Ls.L2Loss, L1Loss=Ls.L1Loss, CauchyLoss=Ls.CauchyLoss,
+                               HuberLoss=Ls.HuberLoss, TukeyLoss=Ls.TukeyLoss, TDistributionLoss=Ls.TDistributionLoss,
+                               SE3=G.SE3, SO3=G.SO3, SE2=G.SE2, SO2=G.SO2)
+    lp, _ = synthetic.stereo_ba(obs_per_lm=OBS_PER_LM, half_window=HALF_WINDOW, **cfg)
+    runs = []
+    for rep in range(2):
+        t0 = time.perf_counter()
+        problem = synthetic.to_objects(lp, ns, example_options())
+        t_objects = time.perf_counter() - t0
+        marks = {}
+        # split the solve by wrapping the three phases (lowering, create, device loop) with clocks
+        orig_lower, orig_make, orig_loop = problem._lower, problem._make_device, core_problem.device_solve
+
+        def lower(*a, **k):
+            t = time.perf_counter(); out = orig_lower(*a, **k); marks['lowering'] = time.perf_counter() - t; return out
+
+        def make(*a, **k):
+            t = time.perf_counter(); out = orig_make(*a, **k); torch.cuda.synchronize()
+            marks['create'] = time.perf_counter() - t; return out
+
+        def loop(dev, opt):
+            t = time.perf_counter(); tdev = TimedCalls(dev); out = orig_loop(tdev, opt); torch.cuda.synchronize()
+            marks['device_loop'] = time.perf_counter() - t; marks['calls'] = [c[0] for c in tdev.calls]; return out
+        problem._lower, problem._make_device, core_problem.device_solve = lower, make, loop
+        try:
+            t0 = time.perf_counter()
+            problem.solve()
+            t_solve = time.perf_counter() - t0
+        finally:
+            core_problem.device_solve = orig_loop
+        calls = marks.get('calls', [])
+        runs.append({'objects_s': round(t_objects, 3), 'solve_wall_ms': round(t_solve * 1e3, 2),
+                     'lowering_ms': round(marks.get('lowering', 0.) * 1e3, 2), 'create_ms': round(marks.get('create', 0.) * 1e3, 2),
+                     'device_loop_ms': round(marks.get('device_loop', 0.) * 1e3, 3),
+                     'first_call_ms': round(calls[0] * 1e3, 3) if calls else None,
+                     'other_calls_ms': [round(c * 1e3, 3) for c in calls[1:]],
+                     'write_back_and_rest_ms': round((t_solve - marks.get('lowering', 0.) - marks.get('create', 0.) - marks.get('device_loop', 0.)) * 1e3, 2),
+                     'iterations': len(calls)})
+        if problem._device is not None:
+            problem._device.close()
+        del problem
+    return {'first_in_process': runs[0], 'second': runs[1],
+            'note': 'Problem.solve() on a fresh Problem and a fresh device handle (public API: block objects -> lowering -> '
+                    'ps_problem_create -> start cost + iterations -> write-back); objects_s = building the Python block objects, '
+                    'not part of solve()'}
 
 
 def main():
@@ -249,6 +396,7 @@ def main():
     ap.add_argument('--lm', type=int, default=None, help='override the landmark count of the workload')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-c4', action='store_true', help='skip the single-GPU C4 leg')
+    ap.add_argument('--no-wall', action='store_true', help='skip the Problem.solve() wall-clock leg (500 000 Python block objects)')
     ap.add_argument('--force-sharded', action='store_true',
                     help='use the multi-GPU driver (RCCL all-reduce) even with one rank (testing)')
     args = ap.parse_args()
@@ -267,6 +415,7 @@ def main():
         local_rank = 0
     backend = os.environ.get('PYSLAM_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
+    sha = kernel_source_sha()                                # (refuses a library that does not match the sources on disk)
     dist = None
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
@@ -293,12 +442,7 @@ def main():
         lp = lp_full
         dev = DeviceProblem(lp, stream=stream)
     info = dev.info
-    dev.eval_cost(True)                                      # Problem.solve() evaluates the start cost first (reference problem.py:133)
-    dev.snapshot()                                           # the common linearisation point
-
-    def step():
-        dev.restore()
-        return dev.gn_iteration(0.0, PCG_TOL, PCG_MAX, True)
+    start = (lp.poses.copy(), lp.points.copy())              # the perturbed start every cold solve begins at (this rank's shard)
 
     def fence():
         torch.cuda.synchronize()
@@ -307,52 +451,46 @@ def main():
         torch.cuda.synchronize()
 
     core = dev.dev if hasattr(dev, 'dev') else dev
-    for _ in range(args.warmup):
-        out = step()
-    # timed region: ONE hipEvent pair around the dominant (Schur) kernel, on every 4th iteration
-    # (an event pair costs ~8 us of pipeline bubbles: the kernel is timed on every 4th step of the timed region)
+    # timed region: cold solves (module docstring); ONE hipEvent pair around the dominant (Schur) kernel on every 4th
+    # linearisation (an event pair costs ~8 us of pipeline bubbles)
     core.set_option('profile_every', 4)
     dev.set_profiling(1)
     dev.stage_times(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    warm_solves = max(1, (args.warmup + 3) // 4)
+    # (the warm-up solves run inside cold_solves, before its clock; their Schur timings are discarded below)
+    cold = cold_solves(dev, start, args.steps, fence, warm_solves=warm_solves)
     stages = dev.stage_times(reset=True)
-    # untimed: a few more steps with an event pair around every stage, for the breakdown only
-    core.set_option('profile_every', 1)
-    dev.set_profiling(2)
-    for _ in range(5):
-        step()
-    detail = dev.stage_times(reset=True)
     dev.set_profiling(0)
-    for k, v in detail.items():
-        if k != 'schur_pairs' and v[1] > 0:
-            stages[k] = v
+    elapsed = cold['seconds']
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    cost, dx_norm, n_pcg, relres = out
-    ms_per_step = elapsed * 1e3 / args.steps
-    # reduced-solve launches per iteration (counter in ps_problem_info) and the lagged-inverse statistics
+    ms_per_step = elapsed * 1e3 / cold['iterations']
+    n_pcg_list = cold['pcg_iters']
+    n_pcg = int(round(float(np.mean(n_pcg_list)))) if n_pcg_list else 0
+    # untimed: one more cold solve with an event pair around every stage, for the breakdown only
+    detail = stage_breakdown(dev, start, fence)
+    for k, v in detail.items():
+        if k != 'schur_pairs' and v[1] > 0:
+            stages[k] = v
     i0 = problem_info(core)
-    for _ in range(4):
-        step()
+    cold_solves(dev, start, 4, fence, warm_solves=0)
     i1 = problem_info(core)
-    traj = trajectory(dev) if dist is None else None         # (sharded: every rank would have to follow; single GPU only)
-    info_after = {'cg_kernel_launches_per_iter': (i1['cg_kernel_launches'] - i0['cg_kernel_launches']) / 4.0,
-                  'ldi': {k: i1[k] for k in ('ldi_solves', 'ldi_fallbacks', 'ldi_seeds')},
-                  'solver': 'lagged dense inverse PCG, 2 launches per iteration' if i1['ldi_solves'] > i0['ldi_solves']
-                  else 'two-level CG'}
-    first_iter_ms = first_iter_its = None
-    if dist is None:                                         # the moving phase of a solve: the same steps without the inverse
+    n_launch = (i1['cg_kernel_launches'] - i0['cg_kernel_launches']) / 4.0
+
+    # the figures of rounds 1-3, kept as extra keys: the same linearisation point restored before every step
+    steady = moving = None
+    if dist is None:
+        core.reset_solver_state(); core.set_params(*start)
+        dev.eval_cost(True); dev.snapshot()
+        sec1, out1 = time_steps(dev, 20, 8, fence)
         core.set_option('lagged_inverse', 0)
+        core.reset_solver_state(); core.set_params(*start)
+        dev.eval_cost(True); dev.snapshot()
         sec0, out0 = time_steps(dev, 10, 3, fence)
         core.set_option('lagged_inverse', 1)
-        first_iter_ms, first_iter_its = sec0 * 1e3 / 10, out0[2]
+        steady = (sec1 * 1e3 / 20, out1[2]); moving = (sec0 * 1e3 / 10, out0[2])
     ranks_stage = None
     if dist is not None:                                     # every rank's stage times (incl. allreduce, pack_unpack) on rank 0
         mine = {k: round(v[0] / max(v[1], 1), 4) for k, v in stages.items() if v[1] > 0}
@@ -362,24 +500,13 @@ def main():
     if rank == 0:
         b_iter, b_schur, b_spmv = algorithmic_bytes(info, n_pcg)
         stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in stages.items() if v[1] > 0}
-        # dominant kernel: the Schur pair kernel is ONE launch per iteration; the CG is n_pcg + 2 launches
         sch = stage_ms.get('schur_pairs', 0.0)
-        pcg_per_iter = stage_ms.get('pcg', 0.0) / max(n_pcg, 1)
-        if sch >= pcg_per_iter * 1.0 and sch > 0:
-            kern, dur_ms, nbytes = 'k_schur_pairs_db', sch, b_schur
-        else:
-            kern, dur_ms, nbytes = 'void k_cg_fused<6>', pcg_per_iter, b_spmv
-        achieved = nbytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-        traffic, traffic_sha, traffic_head = pmc_traffic(kern)
-        sha = kernel_source_sha()
-        if traffic is not None and traffic_sha != sha:
-            print('bench.py: WARNING profiles/pmc_traffic.json was collected on kernel sources {} but this build is {}: '
-                  'roofline.traffic is stale (re-run tools/collect_profiles.sh)'.format(traffic_sha, sha), file=sys.stderr)
         total_blocks = lp_full.num_obs
+        hist = cold['cost_history']
         line = {
             'metric': 'ms/LM-iter (Jac build + J^T J + Schur solve), stereo BA @ 500k residuals',
             'value': round(ms_per_step, 4), 'unit': 'ms/LM-iter', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+            'steps': cold['iterations'], 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': False, 'scaling': 'strong' if world > 1 else 'none', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
             'config': {'workload': '{} stereo BA: {} keyframes x {} landmarks x {} obs/landmark = {} reprojection blocks '
@@ -389,45 +516,42 @@ def main():
                                        if world > 1 else ''),
                        'parallelism': 'landmark-sharded x{} + RCCL all-reduce of the reduced pose system (upper triangle)'.format(world)
                        if world > 1 else 'single GPU',
-                       'pcg_tol': PCG_TOL, 'pcg_iters': n_pcg, 'pcg_relres': relres,
-                       'reduced_blocks': info['reduced_nnzb'], 'schur_pairs': info['num_pairs'],
-                       'cost_after_step': cost, 'step_norm': dx_norm},
+                       'timed_region': '{} cold solves from the perturbed start = {} iterations: solver state cleared before each solve '
+                                       '(ps_reset_solver_state), the loop of Problem.solve under the options of reference '
+                                       'examples/stereo_ba.py:38-40 (allow_nondecreasing_steps, max_nondecreasing_steps = 3); '
+                                       '{} untimed warm-up solve(s)'.format(cold['solves'], cold['iterations'], warm_solves),
+                       'pcg_tol': PCG_TOL, 'pcg_iters_per_call': n_pcg_list, 'cost_history': hist,
+                       'reduced_blocks': info['reduced_nnzb'], 'schur_pairs': info['num_pairs']},
             'residual_blocks_per_s': round(total_blocks / (ms_per_step * 1e-3), 1),
+            'cold_solve': {'solves': cold['solves'], 'iterations': cold['iterations'],
+                           'ms_per_solve': round(elapsed * 1e3 / cold['solves'], 4), 'per_call_ms': cold['per_call_ms'],
+                           'per_call_note': 'host wall clock of each ps_gn_iteration call by its position in the solve (median over the '
+                                            'solves); the solve time also holds the start-cost pass, the best-parameter snapshots and '
+                                            'the final restore'},
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
-            'stage_ms_note': 'schur_pairs: hipEvent pair inside the timed region, on every 4th step; the other stages and iteration_total '
-                             '(GPU time of one iteration) from 5 extra untimed steps with an event pair around every stage',
-            'value_note': 'steady state: every timed step restores the same linearisation point; with the lagged dense inverse '
-                          '(round 3) that is the SETTLED phase of a solve -- the inverse of this very S preconditions the CG; '
-                          'first_iteration_ms is the same step with the standard two-level CG (the moving phase), '
-                          'trajectory_ms_per_iter a real solve from the perturbed start (both phases and the switch between them)',
+            'stage_ms_note': 'schur_pairs: hipEvent pair inside the timed region, on every 4th linearisation; the other stages and '
+                             'iteration_total (GPU time of one iteration) from one more untimed cold solve with an event pair around every stage',
             'iteration_algorithmic_GBps': round(b_iter / (ms_per_step * 1e-3) / 1e9, 2),
-            'roofline': {'bound': 'hbm', 'kernel': kern, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': traffic, 'traffic_source_sha': traffic_sha, 'traffic_git_head': traffic_head,
-                         'build_source_sha': sha, 'traffic_stale': bool(traffic is not None and traffic_sha != sha),
-                         'algorithmic_bytes_per_launch': int(nbytes), 'avg_launch_ms': round(dur_ms, 5)},
+            'roofline': schur_roofline(info, sch, pmc_config(cfg), n_pcg),
         }
         # the kernel with the largest TOTAL time per iteration next to the largest single launch: the reduced solve's launches
-        n_launch = info_after['cg_kernel_launches_per_iter']
         pcg_ms = stage_ms.get('pcg', 0.0)
         line['roofline_aggregate'] = {
-            'kernels': 'reduced solve (' + info_after['solver'] + ')', 'launches_per_iteration': round(n_launch, 2),
+            'kernels': 'reduced solve (two-level CG, one launch per iteration)', 'launches_per_iteration': round(n_launch, 2),
             'total_ms_per_iteration': round(pcg_ms, 5), 'avg_launch_us': round(1e3 * pcg_ms / max(n_launch, 1), 3),
             'algorithmic_bytes_per_launch': int(b_spmv),
             'achieved_GBps': round(b_spmv * n_launch / max(pcg_ms * 1e-3, 1e-12) / 1e9, 1), 'peak': HBM_PEAK_GBS,
             'frac': round(b_spmv * n_launch / max(pcg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
-            'bound': 'latency (dependent launches of ~5 us; DESIGN.md section 5), not bandwidth',
-            'note': 'bytes per launch = one pass over S (288 B per block) + three vectors; the launches of the lagged-inverse '
-                    'PCG alternate between that SpMV and a dense fp32 mat-vec of n^2 * 4 B (5.7 MB at C3)'}
-        line['lagged_inverse'] = info_after['ldi']
-        if first_iter_ms is not None:
-            line['first_iteration_ms'] = round(first_iter_ms, 4)
-            line['first_iteration_note'] = ('the same steady-state measurement with the lagged dense inverse switched off: what an '
-                                            'iteration costs while a solve is still moving (the standard two-level CG, {} iterations); '
-                                            '`value` is the settled phase, where the inverse preconditions ({} iterations)'.format(
-                                                first_iter_its, n_pcg))
-        if traj is not None:
-            line['trajectory_ms_per_iter'] = traj
+            'bound': 'latency (dependent launches; DESIGN.md section 5), not bandwidth',
+            'note': 'bytes per launch = one pass over S (288 B per block) + three vectors'}
+        line['lagged_inverse'] = {k: i1[k] for k in ('ldi_solves', 'ldi_fallbacks', 'ldi_seeds')}
+        if steady is not None:
+            line['steady_same_point_ms'] = round(steady[0], 4)
+            line['steady_same_point_note'] = ('rounds 1-3 `value`: every step restores the same linearisation point, so the lagged dense '
+                                              'inverse of this very S preconditions ({} CG iterations) -- the settled phase, which a '
+                                              'reference-terminated solve of this workload never reaches'.format(steady[1]))
+            line['moving_same_point_ms'] = round(moving[0], 4)
+            line['moving_same_point_note'] = 'the same with the lagged dense inverse off ({} CG iterations; round 3: first_iteration_ms)'.format(moving[1])
         if not args.no_c4 and not args.kf and not args.lm:
             if dist is None:
                 dev.close()                                      # free the C3 tables first
@@ -442,6 +566,8 @@ def main():
             line['native_rccl_reason'] = None if line['native_rccl'] else getattr(dev, 'native_reason', None)
         if world == 1 and not args.kf and not args.lm:
             line['c5_solve_wall_ms'] = c5_frames()
+            if not args.no_wall:
+                line['cold_solve_wall_ms'] = {'C3': cold_solve_wall(C3)}
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(lp)
         print(json.dumps(line))

@@ -194,6 +194,19 @@ typedef struct ps_solve_options {
 int ps_motion_only_solve(ps_problem* h, const ps_solve_options* options, double* cost_history, int32_t cap,
                          int32_t* n_history, int32_t* iterations, double* last_dx_norm, double* pose12_out);
 
+/* Start of a NEW solve on a live handle: drop every piece of state the solver carries from one whole-iteration call to
+   the next (lagged coarse factors / inverses and their tags, the lagged dense inverse of S, launch-count predictions, the
+   cost history), waiting for side-stream work in flight first.  Tables, parameters and options stay.  The next
+   ps_gn_iteration behaves exactly like the first one of a freshly created handle -- what Problem.solve (reference
+   pyslam/problem.py:130-141: every solve starts from scratch) calls before its first iteration, so that a solve is a
+   function of (parameters, options) and not of what the handle did before. */
+int ps_reset_solver_state(ps_problem* h);
+
+/* Hash of the HIP sources the loaded library was compiled from (first 16 hex digits of the SHA-256 over include/pyslam_hip.h
+   and pyslam_amd/csrc/, the -DPS_BUILD_SHA of __graft_entry__.build(); "unknown" for a hand build): bench.py reports THIS and
+   refuses to run on a library that does not match the sources on disk. */
+const char* ps_build_sha(void);
+
 /* Second half of an iteration for a landmark-sharded (multi-GPU) caller, after
    ps_linearize -> all-reduce -> ps_solve_reduced: back-substitution, update, cost, ONE
    synchronisation.  Returns this shard's cost and ||dx_pose||^2, ||dx_point||^2 separately
@@ -281,6 +294,9 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
                               A breakdown of the recurrences repeats the solve in the three-launch form
      "band_chol"          [1] explicit two-level PCG: banded factorisation + band substitutions for the coarse inverse when A_c
                               has at most 7 block off-diagonals (chain-like problems); 0: always the dense factorisation
+     "solve_horizon"      [-1 unknown] how many more whole-iteration calls the caller's stopping rule allows if the step about to be
+                              taken turns out non-decreasing (reference problem.py:163-178); side work that pays back only over
+                              several later calls (the lagged inverse's seed) is not started with fewer than three to come
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual
      "cg_lds", "profile_every", "big_chol", "cg_margin", "pcg_chunk", "cg_split_min_rows", "cg_explicit_min_rows": implementation switches (see ps_set_option in csrc/ps_abi_solver.h)
      "cg_ablate", "schur_ablate", "lm_ablate": timing experiments only (results are wrong under ablation) */

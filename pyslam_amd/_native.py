@@ -85,6 +85,8 @@ SIGNATURES = {
     'ps_apply_update': (C.c_int, [H, C.c_double]),
     'ps_snapshot_params': (C.c_int, [H]),
     'ps_restore_params': (C.c_int, [H]),
+    'ps_reset_solver_state': (C.c_int, [H]),
+    'ps_build_sha': (C.c_char_p, []),
     'ps_get_params': (C.c_int, [H, c_f64p, c_f64p]),
     'ps_set_params': (C.c_int, [H, c_f64p, c_f64p]),
     'ps_motion_only_solve': (C.c_int, [H, C.POINTER(SolveOptions), c_f64p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -163,6 +163,9 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
             std::vector<std::array<double, 3>> keys;        // (camera, loss id, loss k) of the classes found so far
             for (int gi = 0; gi < d->num_obs_groups; ++gi) {
                 const double* row = d->obs_groups + 4 * gi;
+                // every row's stiffness index is read on the device through the per-observation column (round-3 ADVICE: only
+                // the first row of a class used to be range-checked)
+                if ((int)row[1] < 0 || (int)row[1] >= d->num_stiff3) return fail("obs group index out of range");
                 int c = -1;
                 for (size_t q = 0; q < keys.size(); ++q)
                     if (keys[q][0] == row[0] && keys[q][1] == row[2] && keys[q][2] == row[3]) { c = (int)q; break; }

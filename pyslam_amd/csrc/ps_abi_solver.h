@@ -363,7 +363,9 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
     if (!h->guards.empty()) { hipStreamSynchronize(h->stream); if (h->side) hipStreamSynchronize(h->side); if (h->ldi_stream) hipStreamSynchronize(h->ldi_stream); h->check_guards("after ps_gn_iteration"); }
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
-    h->prev_cost = h->last_cost; h->last_cost = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+    // (without a line search the cost returned is the cost at the START point: what the parameters left behind cost is unknown,
+    //  and the tags that compare linearisation points by their cost must not take one for the other -- round-3 ADVICE)
+    h->prev_cost = h->last_cost; h->last_cost = linesearch ? h->h_scalars[SC_COST] : -1.0;
     // a slot whose reduction did not run (no reduced poses / no variable landmarks) is stale: count it as 0
     if (dx_norm_out) *dx_norm_out = std::sqrt((h->nr > 0 ? h->h_scalars[SC_DXP2] : 0.0) + (h->nv > 0 ? h->h_scalars[SC_DXL2] : 0.0));
     return 0;
@@ -373,7 +375,7 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
 int ps_motion_only_solve(ps_problem* h, const ps_solve_options* o, double* cost_history, int32_t cap, int32_t* n_history,
                          int32_t* iterations, double* last_dx_norm, double* pose12_out) {
     if (!h || !o || !cost_history || !n_history) return fail("null argument");
-    const bool eligible = h->mo_fused && h->nv == 0 && h->F == 0 && h->nr == 1 && h->D == 6 && h->N == h->Np &&
+    const bool eligible = h->mo_fused && h->nv == 0 && h->F == 0 && h->nr == 1 && h->P == 1 && h->D == 6 && h->N == h->Np &&
                           h->pcg_variant == 1 && h->max_pose_obs <= 2048;
     const int need = o->max_iters + 2;                        // the start cost + at most max_iters + 1 iterations
     if (!eligible || need + 16 > PS_MO_HIST_WORDS || need > cap) return 1;       // not an error: the caller iterates itself
@@ -585,10 +587,52 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
     else if (n == "cg_explicit_min_rows") { h->cg_explicit_min_rows = (int)value; h->coarse_built = false; }
+    else if (n == "solve_horizon") h->solve_horizon = value < 0 ? -1 : (int)std::min(value, 1e6);
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }
     else return fail("unknown option: " + n);
     return 0;
 }
+
+// Forget everything the solver carries from one whole-iteration call to the next, as if the handle had just been
+// created: the lagged coarse factor / inverse and their tags, the lagged dense inverse of S (seeds in flight are waited
+// for, then dropped), held coarse inverses, the launch-count predictions, the cost history.  Tables, parameters, options
+// and the structures built at create time stay.  The first ps_gn_iteration after this runs the exact (un-lagged) set-up,
+// exactly like the first iteration of a fresh handle.  What a caller that starts a NEW solve on a live handle calls
+// (Problem.solve; bench.py's cold solves).
+int ps_reset_solver_state(ps_problem* h) {
+    if (!h) return fail("null argument");
+    HIP_OK(hipStreamSynchronize(h->stream));
+    if (h->side) HIP_OK(hipStreamSynchronize(h->side));
+    if (h->ldi_stream) HIP_OK(hipStreamSynchronize(h->ldi_stream));
+    drain_timers(h);
+    // lagged coarse level (folded and explicit forms)
+    h->lci_next = -1; h->lci_cur = 0;
+    h->side_todo = false; h->side_ready = false; h->side_pending = false; h->acdone_pending = false;
+    h->xcg_side_todo = false; h->xcg_lag_count = 0; h->xcg_held = 0;
+    h->xcg_tag[0] = h->xcg_tag[1] = -1.0; h->xcg_tag_lambda[0] = h->xcg_tag_lambda[1] = 0.0;
+    h->xcg_setup_cost = -1.0; h->xcg_setup_lambda = 0.0;
+    h->mc_active = false; h->last_setup_lagx = false; h->xf_skip = 0;
+    if (h->lag_status) HIP_OK(hipMemsetAsync(h->lag_status, 0, ST_NWORDS * sizeof(int32_t), h->stream));
+    // lagged dense inverse
+    h->ldi_state = 0; h->ldi_cur = -1; h->ldi_next = -1; h->ldi_iter = 0; h->ldi_ready_at = 0;
+    h->ldi_side_todo = false; h->ldi_update_ok = false; h->ldi_sread_pending = false; h->ldi_refreshed = false;
+    h->ldi_last_its = h->ldi_prev_its = 0; h->ldi_rejects = 0; h->ldi_no_seed_before = 0;
+    h->ldi_tag = h->ldi_next_tag = h->ldi_call_start_cost = -1.0; h->ldi_prev_start_cost = -2.0;
+    h->ldi_moved = false; h->ldi_last_rms = 0.0;
+    if (h->ldi_ready && !(h->ldi_direct_ok && h->N == 0 && h->F > 0)) h->ldi_direct = false;   // (a rejected seed had switched the direct seed on)
+    // predictions and history
+    h->last_pcg_iters = 0; h->prev_pcg_iters = -1;
+    h->last_cost = h->prev_cost = h->snap_cost = -1.0;
+    h->solve_horizon = -1;
+    h->cov_ready = false;
+    return 0;
+}
+
+/* the hash of the HIP sources this library was compiled from (-DPS_BUILD_SHA, set by __graft_entry__.build()) */
+#ifndef PS_BUILD_SHA
+#define PS_BUILD_SHA "unknown"
+#endif
+const char* ps_build_sha(void) { return PS_BUILD_SHA; }
 
 int ps_set_profiling(ps_problem* h, int enabled) {
     if (!h) return fail("null argument");

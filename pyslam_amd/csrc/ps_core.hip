@@ -360,6 +360,11 @@ struct ps_problem {
     bool last_setup_lagx = false;   // the current folded system was built with the lagged X~ (three-launch set-up)
     hipEvent_t ev_ldi = nullptr, ev_ldi_sread = nullptr;
     double snap_cost = -1.0;        // last_cost at the time of ps_snapshot_params
+    // option "solve_horizon": how many MORE whole-iteration calls the caller's stopping rule allows if the step about to be
+    // taken does not decrease the cost enough (reference problem.py:163-178: max_nondecreasing_steps - taken - 1, or 0 without
+    // allow_nondecreasing_steps); -1 = unknown (a caller that drives ps_gn_iteration itself).  Side work that only pays back
+    // over several later calls -- the seed of the lagged dense inverse -- is not started when the solve is about to stop.
+    int solve_horizon = -1;
     // profiling
     int profiling = 0;              // 0 off, 1 = iteration total + Schur kernel only, 2 = every stage
     hipEvent_t ev[2 * PS_NUM_STAGES] = {};

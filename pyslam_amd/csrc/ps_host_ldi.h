@@ -160,7 +160,12 @@ inline int ldi_direct_lag(const ps_problem* h) { return h->ldi_n <= 400 ? 2 : (h
 // prolongation) is read by its first kernels; ev_ldi_sread marks their end and the next linearisation waits for it.
 template <int D>
 int ldi_seed_enqueue(ps_problem* h, int its, double cost_now) {
-    if (!ldi_eligible(h) || h->ldi_state == 1) return 0;       // (a seed is already in flight)
+    if (!ldi_eligible(h) || h->ldi_state == 1 || h->ldi_state == 3) return 0;       // (a seed / a re-formed inverse is already in flight)
+    // A seed costs the call that starts it ~45 us of enqueueing and the next one ~0.1 ms of GEMMs beside its kernels, and
+    // gives ~80 us back per call from then on: with fewer than three calls to come it is a loss.  The caller's stopping
+    // rule says how many can come (option "solve_horizon"; a settling step IS a non-decreasing one under the reference's
+    // rule, problem.py:177-178: cost >= 0.9 prev) -- C3 under the examples' options: calls 2-4 at 0.31 ms instead of 0.37 / 0.40 / 0.22.
+    if (h->solve_horizon >= 0 && h->solve_horizon < 3) return 0;
     if (h->ldi_iter < h->ldi_no_seed_before) return 0;         // (back-off after rejected seeds)
     // only once the solve has begun to settle: an inverse of an S that the next steps leave far behind is wasted side work
     // (last_cost: the cost the previous call left behind = where this call started; cost_now: what this call returns)
@@ -249,7 +254,8 @@ bool ldi_decide(ps_problem* h) {
             h->ldi_state = 0; h->ldi_cur = -1; h->ldi_last_its = 0;
         }
     }
-    if (h->ldi_state != 2 || h->ldi_cur < 0) return false;
+    // (state 3 before its ready_at: a re-formed inverse is in flight into the OTHER buffer; the one in use stays valid)
+    if (!(h->ldi_state == 2 || h->ldi_state == 3) || h->ldi_cur < 0) return false;
     // How far is this call's linearisation point from the one the inverse was built at?  Judged by the cost (scale-free, and
     // the host has it for nothing): the cost at the inverse's point (its tag) against the cost this call starts from.
     // Either unknown (parameters replaced from outside): try, ldi_cap bounds the damage.
@@ -279,7 +285,7 @@ int ldi_solve_and_finish(ps_problem* h, double tol, int max_iters, int linesearc
     // (beyond 2 048 unknowns a refresh -- two n^3 GEMMs beside the solve -- costs more than the iterations it saves: a 420-keyframe
     //  BA, 2 514 unknowns, ran 0.39 ms per call at 7 iterations and 0.69 once 8 iterations switched the refresh on; standard
     //  solver 0.60.  There the inverse simply ages until ldi_cap gives it up and the next standard solve re-seeds.)
-    const bool refresh = h->ldi_last_its > h->ldi_refresh_its + (n > 2048 ? 4 : 0);
+    const bool refresh = h->ldi_state == 2 && h->ldi_last_its > h->ldi_refresh_its + (n > 2048 ? 4 : 0);   // (not while one is in flight)
     h->ldi_side_todo = refresh; h->ldi_update_ok = false;
     // launch sequence: spmv(0) update(0) spmv(1) update(1) ... ; spmv(k) is the launch that detects convergence of iteration
     // k, so a solve of m iterations needs 2 m + 1 launches and ends on an spmv -- exactly that many are enqueued when the

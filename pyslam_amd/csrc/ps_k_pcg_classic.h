@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(
     const double thresh = (k == 0) ? tol2 * rz : thresh_in;
     const bool first_wave = (blockIdx.x == 0 && threadIdx.x == 0);
     if (!(rz > thresh)) {                      // converged (also catches rz == 0 and NaN)
-        if (first_wave) { status[ST_PCG_DONE] = (rz != rz) ? 2 : 1; scalars[SC_RRFINAL] = rz; if (k == 0) scalars[SC_RR0] = rz; }
+        // r^T M^-1 r < 0: the preconditioner is not positive definite (the fp32 lagged inverse can be indefinite at a tiny
+        // rms residual, round-3 ADVICE) -- a breakdown (2: the gated tail applies nothing, the caller falls back), not convergence
+        if (first_wave) { status[ST_PCG_DONE] = (rz != rz || rz < 0.0) ? 2 : 1; scalars[SC_RRFINAL] = rz; if (k == 0) scalars[SC_RR0] = rz; }
         return;
     }
     const double beta = (k == 0) ? 0.0 : rz / rz_prev;

@@ -173,6 +173,14 @@ class DeviceProblem:
     def restore(self):
         nat.check(self._lib.ps_restore_params(self._h))
 
+    def reset_solver_state(self):
+        """A new solve starts here: nothing the solver carried over from earlier calls is used (ps_reset_solver_state)."""
+        nat.check(self._lib.ps_reset_solver_state(self._h))
+
+    def set_solve_horizon(self, n):
+        """Further iterations the caller's stopping rule allows if the coming step is non-decreasing (-1: unknown)."""
+        nat.check(self._lib.ps_set_option(self._h, b'solve_horizon', float(n)))
+
     # ---- covariance by columns (reference problem.py:196-216) ------------
     def covariance_begin(self):
         """Linearise at the current parameters and prepare the reduced solver."""

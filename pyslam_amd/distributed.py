@@ -103,7 +103,18 @@ class NativeRccl:
         if rc != 0:
             raise RuntimeError('ncclCommInitRank failed: {}'.format(rc))
         self.allreduce_ptr = C.cast(self.lib.ncclAllReduce, C.c_void_p).value
-        self.self_check(dist)
+        try:
+            self.self_check(dist)
+        except Exception:
+            # a communicator that failed its check must not stay alive beside the torch.distributed fallback
+            # (self_check aborts it itself on a timeout and clears self.comm)
+            if getattr(self, 'comm', None):
+                try:
+                    self.lib.ncclCommAbort.argtypes = [C.c_void_p]
+                    self.lib.ncclCommAbort(self.comm)
+                finally:
+                    self.comm = None
+            raise
 
     def self_check(self, dist, timeout_s=30.0):
         """One 1-element sum over the new communicator, on a stream of its own, with a deadline: this second
@@ -262,6 +273,15 @@ class ShardedDeviceProblem:
     def restore(self):
         self.dev.restore()
 
+    def reset_solver_state(self):
+        """Every rank forgets its lagged solver state at the same call (the replicated solve stays identical)."""
+        if hasattr(self.dev, 'reset_solver_state'):
+            self.dev.reset_solver_state()
+
+    def set_solve_horizon(self, n):
+        if hasattr(self.dev, 'set_solve_horizon'):
+            self.dev.set_solve_horizon(n)
+
     def get_params(self):
         return self.dev.get_params()
 
@@ -367,6 +387,12 @@ class ShardedProblemView:
 
     def restore(self):
         self.sharded.restore()
+
+    def reset_solver_state(self):
+        self.sharded.reset_solver_state()
+
+    def set_solve_horizon(self, n):
+        self.sharded.set_solve_horizon(n)
 
     # ---- hot path ----------------------------------------------------------
     def eval_cost(self, include_all_constant=True):

@@ -66,6 +66,64 @@ class Options:
         self.fused_solve_loop = True
 
 
+def solve_horizon(opt, iteration, nondecreasing_steps_taken):
+    """Iterations the stopping rules of Problem.solve (reference pyslam/problem.py:159-178) still allow AFTER iteration
+    number `iteration` (1-based) if its step turns out non-decreasing (cost >= min_cost_decrease * previous cost): none
+    without allow_nondecreasing_steps, else what max_nondecreasing_steps and max_iters leave.  The device core does not
+    start side work that needs several more iterations to pay back when fewer are to come (ps_set_option "solve_horizon")."""
+    if not opt.allow_nondecreasing_steps:
+        return 0
+    left_nd = opt.max_nondecreasing_steps - (nondecreasing_steps_taken + 1)
+    left_it = opt.max_iters + 1 - iteration       # the loop stops once optimization_iters > max_iters
+    return max(0, min(left_nd, left_it))
+
+
+def device_solve(dev, opt):
+    """The loop of Problem.solve (reference pyslam/problem.py:130-178) on a problem resident on the device: start cost,
+    then whole iterations (one ps_gn_iteration call each) until the reference's stopping rules fire, with the best
+    parameters kept on the device (snapshot / restore = best_params).  -> (cost history, [(pcg iterations, relative
+    residual)] per iteration).  Problem.solve() runs exactly this; bench.py times exactly this.
+
+    `dev`: DeviceProblem, ShardedProblemView / ShardedDeviceProblem or PhotometricDevice."""
+    if hasattr(dev, 'reset_solver_state'):
+        dev.reset_solver_state()          # a solve is a function of (parameters, options), not of the handle's history
+    horizon = getattr(dev, 'set_solve_horizon', None)
+    linesearch = opt.linesearch_max_iters > 0
+    lam = getattr(opt, 'lm_lambda', 0.)
+    pcg_tol, pcg_max = getattr(opt, 'pcg_tol', 1e-12), getattr(opt, 'pcg_max_iters', 2000)
+    cost = dev.eval_cost(True)
+    history, stats = [cost], []
+    optimization_iters = 0
+    nondecreasing_steps_taken = 0
+    done_optimization = False
+    while not done_optimization:
+        optimization_iters += 1
+        prev_cost = cost
+        if horizon is not None:
+            horizon(solve_horizon(opt, optimization_iters, nondecreasing_steps_taken))
+        # one device call: linearise, solve, update, post-step cost
+        cost, dx_norm, its, rel = dev.gn_iteration(lam, pcg_tol, pcg_max, linesearch)
+        stats.append((its, rel))
+        history.append(cost)
+
+        done_optimization = optimization_iters > opt.max_iters or \
+            dx_norm < opt.min_update_norm or cost < opt.min_cost
+
+        if opt.allow_nondecreasing_steps:
+            if nondecreasing_steps_taken == 0:
+                dev.snapshot()
+            if cost >= opt.min_cost_decrease * prev_cost:
+                nondecreasing_steps_taken += 1
+            else:
+                nondecreasing_steps_taken = 0
+            if nondecreasing_steps_taken >= opt.max_nondecreasing_steps:
+                done_optimization = True
+                dev.restore()
+        else:
+            done_optimization = done_optimization or cost >= opt.min_cost_decrease * prev_cost
+    return history, stats
+
+
 class Problem:
     def __init__(self, options=Options()):
         self.options = options
@@ -307,7 +365,12 @@ class Problem:
                 self._write_back(dev, poses=pose.reshape(1, 12))      # (the call returned the pose: no second copy)
                 return self.param_dict
 
-        cost = dev.eval_cost(True) if dev is not None else self._eval_cost_host()
+        if dev is not None:
+            self._cost_history, self.solver_stats = device_solve(dev, opt)
+            self._write_back(dev)
+            return self.param_dict
+
+        cost = self._eval_cost_host()
         dx_norm = 100.
         optimization_iters = 0
         nondecreasing_steps_taken = 0
@@ -319,16 +382,10 @@ class Problem:
             optimization_iters += 1
             prev_cost = cost
 
-            if dev is not None:
-                # one device call: linearise, solve, update, post-step cost
-                cost, dx_norm, its, rel = dev.gn_iteration(
-                    opt.lm_lambda, opt.pcg_tol, opt.pcg_max_iters, opt.linesearch_max_iters > 0)
-                self.solver_stats.append((its, rel))
-            else:
-                dx, cost = self.solve_one_iter()
-                dx_norm = np.linalg.norm(dx)
-                for k, r in self._update_partition_dict.items():
-                    self._perturb_by_key(k, dx[r])
+            dx, cost = self.solve_one_iter()
+            dx_norm = np.linalg.norm(dx)
+            for k, r in self._update_partition_dict.items():
+                self._perturb_by_key(k, dx[r])
             self._cost_history.append(cost)
 
             done_optimization = optimization_iters > opt.max_iters or \
@@ -336,25 +393,17 @@ class Problem:
 
             if opt.allow_nondecreasing_steps:
                 if nondecreasing_steps_taken == 0:
-                    if dev is not None:
-                        dev.snapshot()
-                    else:
-                        best_params = copy.deepcopy(self.param_dict)
+                    best_params = copy.deepcopy(self.param_dict)
                 if cost >= opt.min_cost_decrease * prev_cost:
                     nondecreasing_steps_taken += 1
                 else:
                     nondecreasing_steps_taken = 0
                 if nondecreasing_steps_taken >= opt.max_nondecreasing_steps:
                     done_optimization = True
-                    if dev is not None:
-                        dev.restore()
-                    else:
-                        self.param_dict.update(best_params)
+                    self.param_dict.update(best_params)
             else:
                 done_optimization = done_optimization or cost >= opt.min_cost_decrease * prev_cost
 
-        if dev is not None:
-            self._write_back(dev)
         return self.param_dict
 
     def solve_one_iter(self):
