@@ -165,26 +165,10 @@ def example_options():
     return opt
 
 
-class TimedCalls:
-    """DeviceProblem seen through a wall clock per ps_gn_iteration call (each call ends with its one synchronisation)."""
-
-    def __init__(self, dev):
-        self._dev = dev
-        self.calls = []          # (seconds, pcg iterations, cost) per whole-iteration call
-
-    def __getattr__(self, name):
-        return getattr(self._dev, name)
-
-    def gn_iteration(self, *a):
-        t0 = time.perf_counter()
-        out = self._dev.gn_iteration(*a)
-        self.calls.append((time.perf_counter() - t0, out[2], out[0]))
-        return out
-
-
 def cold_solves(dev, start, total_iters, fence, warm_solves=1):
     """Whole solves from the perturbed start (`start` = (poses, points) host tables), solver state cleared before each, the
-    loop of Problem.solve under the reference example's options, until exactly `total_iters` iterations have run (the last
+    loop of Problem.solve (pyslam_amd.problem.device_solve: ps_solve on one GPU, the Python loop over ps_gn_iteration on the
+    sharded driver) under the reference example's options, until exactly `total_iters` iterations have run (the last
     solve is cut there).  Timed per solve: start cost + iterations + snapshots + final restore + the synchronisation that
     ends it; NOT timed: ps_reset_solver_state and the upload of the start parameters.
     -> dict(seconds, iterations, solves, per_call_ms (median by position in the solve), pcg_iters, cost_history)."""
@@ -198,11 +182,11 @@ def cold_solves(dev, start, total_iters, fence, warm_solves=1):
         core.reset_solver_state()
         core.set_params(*start)
         fence()
-        tdev = TimedCalls(dev)
+        call_ms = []
         t0 = time.perf_counter()
-        hist, stats = device_solve(tdev, opt)
+        hist, stats = device_solve(dev, opt, call_ms=call_ms)
         fence()                                           # (the final restore of the best parameters is enqueue-only)
-        return time.perf_counter() - t0, hist, tdev.calls
+        return time.perf_counter() - t0, hist, [(ms, st[0]) for ms, st in zip(call_ms, stats)]
 
     for _ in range(max(1, warm_solves)):
         one(None)
@@ -215,7 +199,7 @@ def cold_solves(dev, start, total_iters, fence, warm_solves=1):
         for k, c in enumerate(calls):
             if k >= len(calls_by_pos):
                 calls_by_pos.append([])
-            calls_by_pos[k].append(c[0] * 1e3)
+            calls_by_pos[k].append(c[0])
     return {'seconds': sec, 'iterations': its, 'solves': solves,
             'per_call_ms': [round(float(np.median(c)), 4) for c in calls_by_pos],      # median over the solves, by call index
             'pcg_iters': pcg0, 'cost_history': hist0}
@@ -361,8 +345,8 @@ def cold_solve_wall(cfg):
             marks['create'] = time.perf_counter() - t; return out
 
         def loop(dev, opt):
-            t = time.perf_counter(); tdev = TimedCalls(dev); out = orig_loop(tdev, opt); torch.cuda.synchronize()
-            marks['device_loop'] = time.perf_counter() - t; marks['calls'] = [c[0] for c in tdev.calls]; return out
+            t = time.perf_counter(); ms = []; out = orig_loop(dev, opt, call_ms=ms); torch.cuda.synchronize()
+            marks['device_loop'] = time.perf_counter() - t; marks['calls'] = [c * 1e-3 for c in ms]; return out
         problem._lower, problem._make_device, core_problem.device_solve = lower, make, loop
         try:
             t0 = time.perf_counter()

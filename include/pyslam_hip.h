@@ -207,6 +207,19 @@ int ps_reset_solver_state(ps_problem* h);
    refuses to run on a library that does not match the sources on disk. */
 const char* ps_build_sha(void);
 
+/* The loop of Problem.solve (reference pyslam/problem.py:130-178) on a resident problem, in one call: ps_reset_solver_state,
+   the start cost (its pass is enqueued in front of the first iteration: no call and no synchronisation of its own), then
+   whole iterations (each exactly ps_gn_iteration) until `iterations > max_iters`, ||dx|| < min_update_norm, cost < min_cost or
+   the non-decreasing-step rules stop it, the best parameters kept by ps_snapshot_params / ps_restore_params as the reference
+   keeps best_params.  cost_history receives the reference's _cost_history (at most max_iters + 2 entries); pcg_iters,
+   pcg_relres and iter_ms (host wall clock of every iteration call, ms) receive one entry per iteration, each may be NULL.
+   The same statements as pyslam_amd/problem.py: device_solve (which calls this when the device offers it), without the
+   interpreter between two iterations.  Returns 0 = solved, 1 = not offered for this handle (landmark-sharded: the caller
+   loops with ps_gn_iteration) or `cap` too small, <0 = error. */
+int ps_solve(ps_problem* h, const ps_solve_options* options, double pcg_tol, int pcg_max_iters, double* cost_history,
+             int32_t cap, int32_t* n_history, int32_t* iterations, double* last_dx_norm, int32_t* pcg_iters,
+             double* pcg_relres, double* iter_ms);
+
 /* Second half of an iteration for a landmark-sharded (multi-GPU) caller, after
    ps_linearize -> all-reduce -> ps_solve_reduced: back-substitution, update, cost, ONE
    synchronisation.  Returns this shard's cost and ||dx_pose||^2, ||dx_point||^2 separately

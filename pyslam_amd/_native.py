@@ -91,6 +91,8 @@ SIGNATURES = {
     'ps_set_params': (C.c_int, [H, c_f64p, c_f64p]),
     'ps_motion_only_solve': (C.c_int, [H, C.POINTER(SolveOptions), c_f64p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                        C.POINTER(C.c_double), c_f64p]),
+    'ps_solve': (C.c_int, [H, C.POINTER(SolveOptions), C.c_double, C.c_int, c_f64p, C.c_int32, C.POINTER(C.c_int32),
+                           C.POINTER(C.c_int32), C.POINTER(C.c_double), c_i32p, c_f64p, c_f64p]),
     'ps_gn_iteration': (C.c_int, [H, C.c_double, C.c_double, C.c_int, C.c_int, c_f64p, c_f64p,
                                   C.POINTER(C.c_int), c_f64p]),
     'ps_gn_finish': (C.c_int, [H, C.c_int, c_f64p, c_f64p, c_f64p]),

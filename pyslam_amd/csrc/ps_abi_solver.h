@@ -256,9 +256,22 @@ int ps_gn_result(ps_problem* h, int* done, double* shard2 /* [2] */, double* dx_
     return cg_report(h, pcg_iters_out, pcg_relres_out);
 }
 
-int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters, int linesearch,
-                    double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out) {
+// ps_gn_iteration; `start_cost_out` != NULL: also the cost AT the linearisation point (all blocks, ps_eval_cost's sum) --
+// the start cost of Problem.solve (reference problem.py:133), whose pass is enqueued in front of the iteration instead of
+// costing a call and a synchronisation of its own
+static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters, int linesearch,
+                             double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out,
+                             double* start_cost_out) {
     if (!h) return fail("null argument");
+    h->start_cost_pending = false;
+    if (start_cost_out) {
+        const bool published_path = !(h->nccl_allreduce && h->nccl_comm) && h->nr > 0 && h->pcg_variant == 1 &&
+                                    !(h->mo_fused && h->nv == 0 && h->F == 0 && h->D == 6 && h->N == h->Np && h->max_pose_obs <= 2048);
+        if (!published_path) {                              // paths that end otherwise: a call of its own
+            if (ps_eval_cost(h, 1, start_cost_out)) return -1;
+            start_cost_out = nullptr;
+        } else { if (cost_pass(h, 1, SC_STARTCOST)) return -1; h->start_cost_pending = true; }
+    }
     struct CallClock {
         ps_problem* h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         ~CallClock() { h->host_call_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); ++h->host_calls; }
@@ -363,11 +376,61 @@ int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_it
     if (!h->guards.empty()) { hipStreamSynchronize(h->stream); if (h->side) hipStreamSynchronize(h->side); if (h->ldi_stream) hipStreamSynchronize(h->ldi_stream); h->check_guards("after ps_gn_iteration"); }
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     if (cost_out) *cost_out = linesearch ? h->h_scalars[SC_COST] : h->h_scalars[SC_LINCOST];
+    if (start_cost_out) {                                    // (last_cost: what ps_eval_cost would have left, if no wait took it over)
+        *start_cost_out = h->h_scalars[SC_STARTCOST];
+        if (h->start_cost_pending) { h->start_cost_pending = false; h->last_cost = *start_cost_out; }
+    }
     // (without a line search the cost returned is the cost at the START point: what the parameters left behind cost is unknown,
     //  and the tags that compare linearisation points by their cost must not take one for the other -- round-3 ADVICE)
     h->prev_cost = h->last_cost; h->last_cost = linesearch ? h->h_scalars[SC_COST] : -1.0;
     // a slot whose reduction did not run (no reduced poses / no variable landmarks) is stale: count it as 0
     if (dx_norm_out) *dx_norm_out = std::sqrt((h->nr > 0 ? h->h_scalars[SC_DXP2] : 0.0) + (h->nv > 0 ? h->h_scalars[SC_DXL2] : 0.0));
+    return 0;
+}
+
+int ps_gn_iteration(ps_problem* h, double lambda, double pcg_tol, int pcg_max_iters, int linesearch,
+                    double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out) {
+    return gn_iteration_impl(h, lambda, pcg_tol, pcg_max_iters, linesearch, cost_out, dx_norm_out, pcg_iters_out, pcg_relres_out, nullptr);
+}
+
+// The loop of Problem.solve (reference pyslam/problem.py:130-178), driven from here: no interpreter between two iterations,
+// the start cost's pass rides in front of the first iteration.  Statement for statement pyslam_amd/problem.py: device_solve.
+int ps_solve(ps_problem* h, const ps_solve_options* o, double pcg_tol, int pcg_max_iters, double* cost_history, int32_t cap,
+             int32_t* n_history, int32_t* iterations, double* last_dx_norm, int32_t* pcg_iters, double* pcg_relres, double* iter_ms) {
+    if (!h || !o || !cost_history || !n_history) return fail("null argument");
+    if (h->nccl_allreduce && h->nccl_comm) return 1;          // sharded: every rank's start cost needs the all-reduce (the caller loops)
+    if (o->max_iters < 0 || (long)o->max_iters + 2 > cap) return 1;
+    if (ps_reset_solver_state(h)) return -1;
+    int n = 0, it = 0, nd = 0;
+    double cost = 0.0, dxn = 0.0;
+    bool done = false;
+    while (!done) {
+        ++it;
+        // iterations the stopping rules still allow after this one if its step is non-decreasing (option "solve_horizon")
+        h->solve_horizon = !o->allow_nondecreasing_steps ? 0
+                         : std::max(0, std::min(o->max_nondecreasing_steps - (nd + 1), o->max_iters + 1 - it));
+        const auto t0 = std::chrono::steady_clock::now();
+        double c0 = 0.0, c = 0.0, rel = 0.0;
+        int its = 0;
+        if (gn_iteration_impl(h, o->lm_lambda, pcg_tol, pcg_max_iters, o->linesearch, &c, &dxn, &its, &rel, it == 1 ? &c0 : nullptr)) return -1;
+        if (it == 1) { cost = c0; cost_history[n++] = c0; h->prev_cost = c0; }
+        const double prev = cost;
+        cost = c;
+        if (pcg_iters) pcg_iters[it - 1] = its;
+        if (pcg_relres) pcg_relres[it - 1] = rel;
+        if (iter_ms) iter_ms[it - 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        cost_history[n++] = cost;
+        done = it > o->max_iters || dxn < o->min_update_norm || cost < o->min_cost;
+        if (o->allow_nondecreasing_steps) {
+            if (nd == 0 && ps_snapshot_params(h)) return -1;
+            if (cost >= o->min_cost_decrease * prev) ++nd; else nd = 0;
+            if (nd >= o->max_nondecreasing_steps) { done = true; if (ps_restore_params(h)) return -1; }
+        } else done = done || cost >= o->min_cost_decrease * prev;
+    }
+    h->solve_horizon = -1;
+    *n_history = n;
+    if (iterations) *iterations = it;
+    if (last_dx_norm) *last_dx_norm = dxn;
     return 0;
 }
 
@@ -601,6 +664,12 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
 // (Problem.solve; bench.py's cold solves).
 int ps_reset_solver_state(ps_problem* h) {
     if (!h) return fail("null argument");
+    if (!h->solver_touched) {                               // nothing linearised since creation / the last reset: only the history
+        h->last_cost = h->prev_cost = h->snap_cost = -1.0;
+        h->solve_horizon = -1;
+        return 0;
+    }
+    h->solver_touched = false;
     HIP_OK(hipStreamSynchronize(h->stream));
     if (h->side) HIP_OK(hipStreamSynchronize(h->side));
     if (h->ldi_stream) HIP_OK(hipStreamSynchronize(h->ldi_stream));

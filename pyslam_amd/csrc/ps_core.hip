@@ -365,6 +365,8 @@ struct ps_problem {
     // allow_nondecreasing_steps); -1 = unknown (a caller that drives ps_gn_iteration itself).  Side work that only pays back
     // over several later calls -- the seed of the lagged dense inverse -- is not started when the solve is about to stop.
     int solve_horizon = -1;
+    bool start_cost_pending = false; // the running whole-iteration call also evaluates the cost at its linearisation point (SC_STARTCOST)
+    bool solver_touched = false;    // something has been linearised since creation / the last ps_reset_solver_state
     // profiling
     int profiling = 0;              // 0 off, 1 = iteration total + Schur kernel only, 2 = every stage
     hipEvent_t ev[2 * PS_NUM_STAGES] = {};

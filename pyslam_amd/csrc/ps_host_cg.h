@@ -72,6 +72,10 @@ int wait_published(ps_problem* h) {
         // (lagged dense inverse: k_ldi_init has started, S is final -- the Newton-Schulz step may run beside the solve)
         if (h->ldi_side_todo && *ws == h->setup_seq) { if (ldi_side_kick(h)) return -1; }
         if (*w == h->seq) {
+            if (h->start_cost_pending) {                     // ps_solve's first iteration: the start cost rode in front of it --
+                h->start_cost_pending = false;               // from here on the call knows it, as if ps_eval_cost had run first
+                h->last_cost = h->ldi_call_start_cost = h->h_scalars[SC_STARTCOST];
+            }
             if (h->side_todo) { h->side_ready = true; if (kick_mode >= 1 && side_kick(h)) return -1; }
             if (h->ldi_side_todo && ldi_side_kick(h)) return -1;
             if (h->pending.empty()) return 0;
@@ -857,6 +861,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
 }
 
 int linearize(ps_problem* h, double lambda) {
+    h->solver_touched = true;
     h->lin_lambda = lambda;                                  // (what the held coarse inverse is tagged with, beside the cost)
     ++h->prof_tick;
     h->cov_ready = false;

@@ -309,7 +309,9 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
     if (!h->coarse_built && build_coarse(h)) return -1;
     if (h->cg_explicit) {                                   // explicit two-level PCG, same one-synchronisation protocol
         if (xcg_setup<D>(h, max_iters, true)) return -1;
-        int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + 2 : 32;
+        // (+ 3 spare launches behind a step that changed the cost by more than 5 %: the lagged coarse inverse is from the other side of it)
+        const bool big_step_x = h->prev_cost > 0.0 && h->last_cost > 0.0 && std::fabs(h->prev_cost - h->last_cost) > 0.05 * h->prev_cost;
+        int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + 2 + (big_step_x ? 3 : 0) : 32;
         for (;;) {
             count = std::min(count, max_iters + 1 - h->cg_launched);
             // (the side-stream factorisation goes in after the first few iterations' launches: early enough to
@@ -358,7 +360,11 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
     // one iteration too few costs a host round trip (~40 us), one launch too many ~1.5 us
     // (after a cost jump that left the lagged inverse behind the last standard solve is several calls old and from another
     //  phase: C3's trajectory needs 21 iterations where it needed 18 -- six spare launches at ~1.5 us each instead of a miss)
-    const int margin = h->ldi_moved ? std::max(6, h->cg_margin)
+    // (the same after a step that changed the cost by more than 5 %: the lagged basis this set-up uses is from the other side of
+    //  it -- the second call of a cold C3 solve needs 21 iterations where the first needed 18, and 18 + 4 launches were one
+    //  short: +35 us for the second round)
+    const bool big_step = h->prev_cost > 0.0 && h->last_cost > 0.0 && std::fabs(h->prev_cost - h->last_cost) > 0.05 * h->prev_cost;
+    const int margin = (h->ldi_moved || big_step) ? std::max(6, h->cg_margin)
                                     : ((h->last_pcg_iters == h->prev_pcg_iters) ? std::min(2, h->cg_margin) : h->cg_margin);
     h->ldi_moved = false;
     int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : 16;

@@ -36,7 +36,7 @@ struct FactorGroup { double S[36]; int32_t loss_id; int32_t pad; double loss_k; 
 // status words
 enum { ST_LM_FAIL = 0, ST_DIAG_FAIL = 1, ST_PCG_DONE = 2, ST_PCG_ITERS = 3, ST_NWORDS = 8 };
 // scalar slots
-enum { SC_COST = 0, SC_DXP2 = 1, SC_LINCOST = 2, SC_RR0 = 3, SC_RRFINAL = 4, SC_THRESH = 5, SC_DXL2 = 6, SC_NWORDS = 8 };
+enum { SC_COST = 0, SC_DXP2 = 1, SC_LINCOST = 2, SC_RR0 = 3, SC_RRFINAL = 4, SC_THRESH = 5, SC_DXL2 = 6, SC_STARTCOST = 7, SC_NWORDS = 8 };
 
 // Wave-wide sum with DPP row operations instead of ds_bpermute shuffles (each __shfl_xor of a
 // double is two LDS-crossbar permutes, ~100+ cycles of latency; a DPP add is a plain VALU op).

@@ -111,6 +111,28 @@ class DeviceProblem:
         nat.check(rc)
         return hist[:n.value].tolist(), its.value, dxn.value, pose
 
+    def solve_loop(self, opt):
+        """Problem.solve's loop in one C call (ps_solve).  -> (cost history, [(pcg iterations, relative residual)], [ms per
+        iteration call]) or None when the core does not offer it for this handle (the caller loops itself)."""
+        o = nat.SolveOptions()
+        o.max_iters, o.allow_nondecreasing_steps = int(opt.max_iters), int(bool(opt.allow_nondecreasing_steps))
+        o.max_nondecreasing_steps, o.linesearch = int(opt.max_nondecreasing_steps), int(opt.linesearch_max_iters > 0)
+        o.min_update_norm, o.min_cost = float(opt.min_update_norm), float(opt.min_cost)
+        o.min_cost_decrease, o.lm_lambda = float(opt.min_cost_decrease), float(getattr(opt, 'lm_lambda', 0.))
+        cap = o.max_iters + 2
+        if cap < 2 or cap > 100000:
+            return None
+        hist, rel, ms = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        its = np.zeros(cap, dtype=np.int32)
+        n, iters, dxn = C.c_int32(), C.c_int32(), C.c_double()
+        rc = self._lib.ps_solve(self._h, C.byref(o), float(getattr(opt, 'pcg_tol', 1e-12)), int(getattr(opt, 'pcg_max_iters', 2000)),
+                                nat.f64p(hist), cap, C.byref(n), C.byref(iters), C.byref(dxn), nat.i32p(its), nat.f64p(rel), nat.f64p(ms))
+        if rc == 1:
+            return None
+        nat.check(rc)
+        k = iters.value
+        return hist[:n.value].tolist(), [(int(a), float(b)) for a, b in zip(its[:k], rel[:k])], ms[:k].tolist()
+
     def gn_finish(self, linesearch=True):
         """-> (shard cost, ||dx_pose||^2, ||dx_point||^2); parameters are updated."""
         c, a, b = C.c_double(), C.c_double(), C.c_double()

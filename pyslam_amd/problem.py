@@ -20,6 +20,7 @@ attributes the reference's tests read).  What differs is where the work runs:
 There is no CPU solver: without the HIP library or a GPU, solve() raises.
 """
 import copy
+import time
 
 import numpy as np
 
@@ -78,13 +79,23 @@ def solve_horizon(opt, iteration, nondecreasing_steps_taken):
     return max(0, min(left_nd, left_it))
 
 
-def device_solve(dev, opt):
+def device_solve(dev, opt, use_core_loop=True, call_ms=None):
     """The loop of Problem.solve (reference pyslam/problem.py:130-178) on a problem resident on the device: start cost,
     then whole iterations (one ps_gn_iteration call each) until the reference's stopping rules fire, with the best
     parameters kept on the device (snapshot / restore = best_params).  -> (cost history, [(pcg iterations, relative
     residual)] per iteration).  Problem.solve() runs exactly this; bench.py times exactly this.
 
-    `dev`: DeviceProblem, ShardedProblemView / ShardedDeviceProblem or PhotometricDevice."""
+    `dev`: DeviceProblem, ShardedProblemView / ShardedDeviceProblem or PhotometricDevice.  A DeviceProblem runs the loop in
+    the core (ps_solve: the same statements in C, no interpreter between two iterations, the start cost's pass enqueued in
+    front of the first iteration); tests/test_gpu_solve_loop.py holds the two against each other.  `call_ms`, if a list, receives
+    the wall clock of every iteration call in ms."""
+    loop = getattr(dev, 'solve_loop', None) if use_core_loop else None
+    if loop is not None:
+        out = loop(opt)
+        if out is not None:
+            if call_ms is not None:
+                call_ms.extend(out[2])
+            return out[0], out[1]
     if hasattr(dev, 'reset_solver_state'):
         dev.reset_solver_state()          # a solve is a function of (parameters, options), not of the handle's history
     horizon = getattr(dev, 'set_solve_horizon', None)
@@ -102,7 +113,10 @@ def device_solve(dev, opt):
         if horizon is not None:
             horizon(solve_horizon(opt, optimization_iters, nondecreasing_steps_taken))
         # one device call: linearise, solve, update, post-step cost
+        t0 = time.perf_counter()
         cost, dx_norm, its, rel = dev.gn_iteration(lam, pcg_tol, pcg_max, linesearch)
+        if call_ms is not None:
+            call_ms.append((time.perf_counter() - t0) * 1e3)
         stats.append((its, rel))
         history.append(cost)
 

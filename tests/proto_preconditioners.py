@@ -8,6 +8,8 @@ Test infrastructure (it drives oracle/gn_oracle.py); not collected by pytest.
     python tests/proto_preconditioners.py asw  <npz> <k> <G>      overlapping additive-Schwarz windows + hat coarse level
     python tests/proto_preconditioners.py bj   <npz> <k> <G>      non-overlapping Jacobi blocks of 2..80 poses (additive / multiplicative)
     python tests/proto_preconditioners.py band <npz> <k> <G>      decay of S^-1 and of S^-1 - P A_c^-1 P^T, band truncations
+    python tests/proto_preconditioners.py fsai <npz> <k> <G>      round 4: factorised sparse approximate inverses G^T G ~ S^-1 (G lower block-banded,
+                                                                  rows from local SPD solves) alone / + coarse additive / symmetric multiplicative
     python tests/proto_preconditioners.py ns   <npz> <G>          fp32 Newton-Schulz: seed from the two-level operator, tracking
     python tests/proto_preconditioners.py ns2  <npz>              fp32 vs fp64-residual Newton-Schulz fixed points
 
@@ -129,6 +131,66 @@ for src,name in ((Sh,'current'),(Li@Slag@Li.T,'lagged')):
     mult=w/stride
     x,it2=pcg(Sh,gh,lambda r:AS(r)/mult+coarse(r))
     print(name,'AS window',w,'stride',stride,'its',it,'scaled',it2,'bytes/apply fp32 MB',len(wins)*(6*w)**2*4/1e6)
+'''
+
+SRC_FSAI = r'''import numpy as np, scipy.sparse as sp, sys, time
+Z=np.load(sys.argv[1]); n=int(Z['n']); k=int(sys.argv[2]); G=int(sys.argv[3])
+def getS(k): return sp.csr_matrix((Z['S%d_data'%k],Z['S%d_indices'%k],Z['S%d_indptr'%k]),shape=(n,n)).toarray()
+S=getS(k); nb=n//6; g=Z['g%d'%k]
+def bjL(S):
+    Li=np.zeros((n,n))
+    for i in range(nb):
+        s=slice(6*i,6*i+6); Li[s,s]=np.linalg.inv(np.linalg.cholesky(S[s,s]))
+    return Li
+Li=bjL(S); Sh=Li@S@Li.T; gh=Li@g
+poses=Z['poses%d'%k]
+def adj(row):
+    R=row[:9].reshape(3,3); t=row[9:]
+    tx=np.array([[0,-t[2],t[1]],[t[2],0,-t[0]],[-t[1],t[0],0]])
+    A=np.zeros((6,6)); A[:3,:3]=R; A[:3,3:]=tx@R; A[3:,3:]=R; return A
+nodes=np.arange(0,nb+G,G); nn=len(nodes)
+P=np.zeros((n,6*nn)); L=np.linalg.inv(Li)
+for i in range(nb):
+    Bi=L[6*i:6*i+6,6*i:6*i+6].T@adj(poses[i+1])
+    q=i//G; w1=(i-nodes[q])/G
+    P[6*i:6*i+6,6*q:6*q+6]=(1-w1)*Bi
+    if q+1<nn: P[6*i:6*i+6,6*q+6:6*q+12]=w1*Bi
+Ac=P.T@Sh@P; Aci=np.linalg.inv(Ac)
+def coarse(r): return P@(Aci@(P.T@r))
+def pcg(S,g,Minv,tol=1e-12,maxit=400):
+    x=np.zeros_like(g); r=g.copy(); z=Minv(r); p=z.copy(); rz=r@z; rz0=rz; it=0
+    while it<maxit:
+        q=S@p; a=rz/(p@q); x+=a*p; r-=a*q; z=Minv(r); rzn=r@z; it+=1
+        if np.sqrt(abs(rzn)/rz0)<tol: break
+        p=z+(rzn/rz)*p; rz=rzn
+    return x,it
+bw=np.abs(np.nonzero(Sh)[0]-np.nonzero(Sh)[1]).max()//6
+print('n',n,'poses',nb,'block half-bandwidth',bw,'coarse nodes',nn)
+print('block-jacobi + coarse: its',pcg(Sh,gh,lambda r:r+coarse(r))[1], ' block-jacobi only:',pcg(Sh,gh,lambda r:r)[1])
+def fsai(A,w):
+    # lower block-banded G, pattern poses i-w..i (scalar-lower within the diagonal block)
+    Gm=np.zeros((n,n))
+    for i in range(nb):
+        lo=max(0,i-w)*6
+        for c in range(6):
+            row=6*i+c
+            J=np.arange(lo,row+1)
+            y=np.linalg.solve(A[np.ix_(J,J)],np.eye(len(J))[:,-1])
+            Gm[row,J]=y/np.sqrt(y[-1])
+    return Gm
+for w in (2,5,10,20,40):
+    t0=time.time(); Gm=fsai(Sh,w)
+    M=Gm.T@Gm
+    ev=np.linalg.eigvalsh(Gm@Sh@Gm.T)
+    it_f=pcg(Sh,gh,lambda r:M@r)[1]
+    it_fc=pcg(Sh,gh,lambda r:M@r+coarse(r))[1]
+    # multiplicative (deflated) combination: coarse first then FSAI on the deflated residual, symmetrised
+    def mult(r):
+        y=coarse(r); r2=r-Sh@y; z=M@r2; r3=r2-Sh@z
+        return y+z+coarse(r3)
+    it_m=pcg(Sh,gh,mult)[1]
+    # coarse space built on the FSAI-preconditioned operator: A_c' = P^T S P same P; additive with scaled FSAI
+    print('FSAI w=%d poses: eig(G S G^T) [%.3f, %.3f]  its FSAI only %d, FSAI+coarse additive %d, symmetric multiplicative %d   (%.0f s)'%(w,ev[0],ev[-1],it_f,it_fc,it_m,time.time()-t0),flush=True)
 '''
 
 SRC_BJ = r'''import numpy as np, scipy.sparse as sp, sys
@@ -300,7 +362,7 @@ for mode in ('all32','R64','all64'):
 
 
 if __name__ == '__main__':
-    if len(sys.argv) < 2 or sys.argv[1] not in ('gen', 'lag', 'asw', 'bj', 'band', 'ns', 'ns2'):
+    if len(sys.argv) < 2 or sys.argv[1] not in ('gen', 'lag', 'asw', 'bj', 'band', 'fsai', 'ns', 'ns2'):
         print(__doc__); sys.exit(1)
     which = sys.argv.pop(1)
     exec(globals()['SRC_' + which.upper()])

@@ -1,0 +1,89 @@
+"""ps_solve (the loop of Problem.solve in the core) against the Python loop over ps_gn_iteration it restates
+(pyslam_amd/problem.py: device_solve, reference pyslam/problem.py:130-178), and ps_reset_solver_state: a solve on a used
+handle equals the solve on a fresh one, bit for bit."""
+import numpy as np
+import pytest
+
+from pyslam_amd import synthetic
+from pyslam_amd.problem import Options, device_solve
+
+pytestmark = pytest.mark.gpu
+
+
+def _options(**kw):
+    opt = Options()
+    opt.pcg_tol = 1e-12
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    return opt
+
+
+CASES = [
+    dict(),                                                                   # the reference's defaults: stops at the first step that does not cut the cost by 10 %
+    dict(allow_nondecreasing_steps=True, max_nondecreasing_steps=3),          # examples/stereo_ba.py:38-40
+    dict(allow_nondecreasing_steps=True, max_nondecreasing_steps=1),
+    dict(max_iters=2, allow_nondecreasing_steps=True, max_nondecreasing_steps=5),
+    dict(max_iters=0),
+    dict(linesearch_max_iters=0, allow_nondecreasing_steps=True, max_nondecreasing_steps=2),
+    dict(min_cost=1e30),                                                      # stops on min_cost after one iteration
+    dict(min_update_norm=1e30),
+    dict(lm_lambda=1e-3, allow_nondecreasing_steps=True, max_nondecreasing_steps=2),
+]
+
+
+def _problems():
+    yield 'ba', synthetic.stereo_ba(num_kf=24, num_lm=600, obs_per_lm=6, half_window=5, seed=4)[0]
+    yield 'ba_small', synthetic.stereo_ba(num_kf=6, num_lm=80, obs_per_lm=4, half_window=3, seed=2)[0]
+    yield 'pg', synthetic.pose_graph(num_poses=60, num_loops=90, dof=6, seed=3)[0]
+    yield 'pg2', synthetic.pose_graph(num_poses=40, num_loops=50, dof=3, seed=5)[0]
+
+
+@pytest.mark.parametrize('name,lp', list(_problems()), ids=lambda v: v if isinstance(v, str) else '')
+def test_core_loop_equals_the_python_loop(name, lp):
+    from pyslam_amd.device import DeviceProblem
+    for kw in CASES:
+        opt = _options(**kw)
+        dev = DeviceProblem(lp)
+        h_c, s_c = device_solve(dev, opt, use_core_loop=True)
+        p_c = dev.get_params()
+        dev.close()
+        dev = DeviceProblem(lp)
+        h_p, s_p = device_solve(dev, opt, use_core_loop=False)
+        p_p = dev.get_params()
+        dev.close()
+        assert len(h_c) == len(h_p), (name, kw, h_c, h_p)
+        # (the start cost is the same kernel's sum in both; every iteration is the same ps_gn_iteration)
+        assert h_c == h_p, (name, kw, h_c, h_p)
+        assert [a for a, _ in s_c] == [a for a, _ in s_p]
+        assert np.array_equal(p_c[0], p_p[0]) and np.array_equal(p_c[1], p_p[1])
+
+
+def test_a_solve_on_a_used_handle_equals_the_solve_on_a_fresh_one():
+    """ps_reset_solver_state: lagged coarse operators, the lagged inverse, predictions and cost history of earlier calls leave no
+    trace in the next solve (reference problem.py:130-141: every solve starts from scratch)."""
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=1500, obs_per_lm=8, half_window=6, seed=9)
+    opt = _options(allow_nondecreasing_steps=True, max_nondecreasing_steps=3)
+    fresh = DeviceProblem(lp)
+    want_h, want_s = device_solve(fresh, opt)
+    want_p = fresh.get_params()
+    fresh.close()
+    used = DeviceProblem(lp)
+    for _ in range(7):                                       # a history: iterations that settle, seed and use the lagged operators
+        used.gn_iteration(0.0, 1e-12, 2000, True)
+    used.set_params(lp.poses, lp.points)
+    got_h, got_s = device_solve(used, opt)
+    got_p = used.get_params()
+    assert got_h == want_h and got_s == want_s
+    assert np.array_equal(got_p[0], want_p[0]) and np.array_equal(got_p[1], want_p[1])
+    # ... and once more on the same handle, through the Python loop
+    used.set_params(lp.poses, lp.points)
+    again_h, again_s = device_solve(used, opt, use_core_loop=False)
+    assert again_h == want_h and [a for a, _ in again_s] == [a for a, _ in want_s]
+    used.close()
+
+
+def test_build_sha_matches_the_sources_on_disk():
+    import __graft_entry__ as ge
+    from pyslam_amd import _native as nat
+    assert nat.load().ps_build_sha().decode() == ge.source_sha()

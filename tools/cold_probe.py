@@ -1,0 +1,33 @@
+"""Cold, reference-terminated solves (bench.py: cold_solves) of a stereo BA on one GPU: per-call wall clock, iteration counts.
+    python tools/cold_probe.py [kf lm [solves]] [--python-loop]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from pyslam_amd import synthetic
+from pyslam_amd.device import DeviceProblem
+from pyslam_amd.problem import device_solve
+
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+kf, lm = (int(args[0]), int(args[1])) if len(args) >= 2 else (200, 50000)
+solves = int(args[2]) if len(args) >= 3 else 6
+core_loop = '--python-loop' not in sys.argv
+lp, _ = synthetic.stereo_ba(num_kf=kf, num_lm=lm, obs_per_lm=10, half_window=20, seed=0 if kf == 200 else 1)
+dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
+start = (lp.poses.copy(), lp.points.copy())
+opt = bench.example_options()
+tot, its = 0.0, 0
+for s in range(solves + 1):
+    dev.reset_solver_state(); dev.set_params(*start); torch.cuda.synchronize()
+    ms = []
+    t0 = time.perf_counter()
+    hist, stats = device_solve(dev, opt, use_core_loop=core_loop, call_ms=ms)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) * 1e3
+    if s:
+        tot += dt; its += len(ms)
+    print('solve %d: %.4f ms, calls %s, pcg %s, outside the calls %.4f ms' % (s, dt, ['%.4f' % m for m in ms], [a for a, _ in stats], dt - sum(ms)))
+print('kf %d lm %d %s loop: %.4f ms per iteration over %d solves (first excluded); cost history %s' % (
+    kf, lm, 'core' if core_loop else 'python', tot / its, solves, ['%.6e' % c for c in hist]))
+dev.close()
