@@ -288,6 +288,8 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
                               and for as long as the caller linearises at the point (same start cost, same lambda) the inverse in use
                               was formed from.  A call whose lambda is more than a factor of four from the newest inverse's (or zero against non-zero)
                               factors its own A_c (no lag).
+     "coarse_adaptive_hold" [1] explicit two-level PCG: keep the lagged coarse inverse (no assembly, no side-stream factorisation) while the
+                              last solve with it took at most 3 iterations more than the first one did (at most 8 set-ups in a row)
      "xcg_restrict_fused" [1] explicit two-level PCG: three launches per iteration (restriction in the SpMV epilogue, t by recurrence)
                               instead of four
      "lagged_inverse"     [1] reduced systems of 91 .. "ldi_max_unknowns" [2048; up to 3328: pays from ~7 iterations per solve on] unknowns (folded CG, one GPU, whole-iteration calls):

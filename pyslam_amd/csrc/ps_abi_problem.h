@@ -756,6 +756,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     h->h_shard = (double*)(whost + 768);      h->h_shard_dev = (double*)(wdev + 768);
     h->h_setup = (long long*)(whost + 1024);  h->h_setup_dev = (long long*)(wdev + 1024);
     h->h_ldi_fro = (double*)(whost + 1280);   h->h_ldi_fro_dev = (double*)(wdev + 1280);
+    h->h_early = (long long*)(whost + 1536);  h->h_early_dev = (long long*)(wdev + 1536);
     h->h_mo_hist = (double*)(whost + 2048);   h->h_mo_hist_dev = (double*)(wdev + 2048);     // PS_MO_HIST_WORDS doubles
     if (h->alloc(&h->arrivals, 2)) return -1;
     if (h->zero(h->arrivals, 2 * sizeof(int32_t))) return -1;

@@ -114,6 +114,7 @@ int ps_step_norm2(ps_problem* h, double* norm2) {
 
 int ps_apply_update(ps_problem* h, double step) {
     if (!h) return fail("null argument");
+    h->prelin_valid = false;
     h->last_cost = h->prev_cost = -1.0;                     // parameters move without a cost: history unknown from here
     return apply_update(h, step);
 }
@@ -130,6 +131,7 @@ int ps_snapshot_params(ps_problem* h) {
 
 int ps_restore_params(ps_problem* h) {
     if (!h) return fail("null argument");
+    h->prelin_valid = false;
     h->last_cost = h->snap_cost; h->prev_cost = -1.0;       // the snapshot's own cost (if it was known), no step history
     const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
     if (n1 + n2)
@@ -148,6 +150,7 @@ int ps_get_params(ps_problem* h, double* poses, double* points) {
 
 int ps_set_params(ps_problem* h, const double* poses, const double* points) {
     if (!h) return fail("null argument");
+    h->prelin_valid = false;
     h->last_cost = h->prev_cost = -1.0;
     if (poses && h->P) HIP_OK(hipMemcpyAsync(h->poses, poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDefault, h->stream));
     if (points && h->L) HIP_OK(hipMemcpyAsync(h->points, points, (size_t)h->L * 3 * sizeof(double), hipMemcpyDefault, h->stream));
@@ -360,7 +363,9 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
     }
     {
         StageTimer total(h, PS_ST_TOTAL, 2);  // closed before the last synchronising read-back
-        if (linearize(h, lambda)) return -1;
+        h->spec_enqueued = false;
+        if (h->prelin_valid && h->prelin_lambda == lambda) h->prelin_valid = false;     // linearised ahead, behind the last call's tail
+        else if (linearize(h, lambda)) return -1;
         if (h->nr > 0 && h->pcg_variant == 1) {
             const int rc = h->D == 6
                 ? gn_solve_and_finish_async<6>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, &total)
@@ -372,6 +377,11 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
             total.stop();
             if (read_scalars(h)) return -1;
         }
+    }
+    if (h->spec_enqueued) {                                  // the next iteration's linearisation is in the queue: valid if this one ended well
+        h->spec_enqueued = false;
+        h->prelin_valid = h->h_status[ST_PCG_DONE] == 1 && !h->h_status[ST_LM_FAIL] && !h->h_status[ST_DIAG_FAIL];
+        h->prelin_lambda = lambda;
     }
     if (!h->guards.empty()) { hipStreamSynchronize(h->stream); if (h->side) hipStreamSynchronize(h->side); if (h->ldi_stream) hipStreamSynchronize(h->ldi_stream); h->check_guards("after ps_gn_iteration"); }
     if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
@@ -402,20 +412,29 @@ int ps_solve(ps_problem* h, const ps_solve_options* o, double pcg_tol, int pcg_m
     if (o->max_iters < 0 || (long)o->max_iters + 2 > cap) return 1;
     if (ps_reset_solver_state(h)) return -1;
     int n = 0, it = 0, nd = 0;
-    double cost = 0.0, dxn = 0.0;
+    double cost = 0.0, dxn = 0.0, last_ratio = 1.0;
     bool done = false;
     while (!done) {
         ++it;
         // iterations the stopping rules still allow after this one if its step is non-decreasing (option "solve_horizon")
         h->solve_horizon = !o->allow_nondecreasing_steps ? 0
                          : std::max(0, std::min(o->max_nondecreasing_steps - (nd + 1), o->max_iters + 1 - it));
+        // Will there be another iteration?  Surely (short of ||dx|| / min_cost stopping it) if even a non-decreasing step leaves
+        // the solve running; without allow_nondecreasing_steps, likely while the steps still cut the cost in half.  Then the next
+        // linearisation is enqueued behind this iteration's tail (wait_published).  Not while the lagged dense inverse may seed: its
+        // side stream reads S after the call.
+        h->spec_next = it <= o->max_iters && !(ldi_eligible(h) && h->solve_horizon >= 3) &&
+                       (o->allow_nondecreasing_steps ? h->solve_horizon >= 1 : (it >= 2 && last_ratio < 0.5));
         const auto t0 = std::chrono::steady_clock::now();
         double c0 = 0.0, c = 0.0, rel = 0.0;
         int its = 0;
-        if (gn_iteration_impl(h, o->lm_lambda, pcg_tol, pcg_max_iters, o->linesearch, &c, &dxn, &its, &rel, it == 1 ? &c0 : nullptr)) return -1;
+        const int rc_it = gn_iteration_impl(h, o->lm_lambda, pcg_tol, pcg_max_iters, o->linesearch, &c, &dxn, &its, &rel, it == 1 ? &c0 : nullptr);
+        h->spec_next = false;
+        if (rc_it) return -1;
         if (it == 1) { cost = c0; cost_history[n++] = c0; h->prev_cost = c0; }
         const double prev = cost;
         cost = c;
+        last_ratio = prev > 0.0 ? cost / prev : 1.0;
         if (pcg_iters) pcg_iters[it - 1] = its;
         if (pcg_relres) pcg_relres[it - 1] = rel;
         if (iter_ms) iter_ms[it - 1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -438,6 +457,7 @@ int ps_solve(ps_problem* h, const ps_solve_options* o, double pcg_tol, int pcg_m
 int ps_motion_only_solve(ps_problem* h, const ps_solve_options* o, double* cost_history, int32_t cap, int32_t* n_history,
                          int32_t* iterations, double* last_dx_norm, double* pose12_out) {
     if (!h || !o || !cost_history || !n_history) return fail("null argument");
+    h->prelin_valid = false;
     const bool eligible = h->mo_fused && h->nv == 0 && h->F == 0 && h->nr == 1 && h->P == 1 && h->D == 6 && h->N == h->Np &&
                           h->pcg_variant == 1 && h->max_pose_obs <= 2048;
     const int need = o->max_iters + 2;                        // the start cost + at most max_iters + 1 iterations
@@ -483,6 +503,7 @@ int ps_motion_only_solve(ps_problem* h, const ps_solve_options* o, double* cost_
 
 int ps_covariance_begin(ps_problem* h) {
     if (!h) return fail("null argument");
+    h->prelin_valid = false;
     if (linearize(h, 0.0)) return -1;
     if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h) && !h->coarse_built && build_coarse(h)) return -1;
     if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h) && !h->cg_explicit) {
@@ -612,6 +633,7 @@ static void relook_path(ps_problem* h) {
 
 int ps_set_option(ps_problem* h, const char* name, double value) {
     if (!h || !name) return fail("null argument");
+    h->prelin_valid = false;
     const std::string n(name);
     if (n == "pcg_variant") { if (value != 0 && value != 1) return fail("pcg_variant must be 0 or 1"); h->pcg_variant = (int)value; }
     else if (n == "coarse_groups") {
@@ -628,6 +650,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "xcg_restrict_fused") h->xcg_rt = value != 0;
     else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
     else if (n == "coarse_auto_hold") h->xcg_auto_hold = value != 0;
+    else if (n == "coarse_adaptive_hold") h->xcg_adaptive_hold = value != 0;
     else if (n == "xcg_fused") { if (value != 0 && value != 1 && value != 2) return fail("xcg_fused must be 0, 1 or 2"); h->xcg_fused = (int)value; }
     else if (n == "lagged_inverse") { h->ldi_enable = value != 0; if (!h->ldi_enable) { h->ldi_cur = -1; if (h->ldi_state != 1) h->ldi_state = 0; } relook_path(h); }
     else if (n == "ldi_max_unknowns") { if (value < 0 || value > PS_LDI_MAXN) return fail("ldi_max_unknowns out of range (0 .. 3328)"); h->ldi_max_n = (int)value; relook_path(h); }
@@ -664,6 +687,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
 // (Problem.solve; bench.py's cold solves).
 int ps_reset_solver_state(ps_problem* h) {
     if (!h) return fail("null argument");
+    h->prelin_valid = false;
     if (!h->solver_touched) {                               // nothing linearised since creation / the last reset: only the history
         h->last_cost = h->prev_cost = h->snap_cost = -1.0;
         h->solve_horizon = -1;
@@ -678,6 +702,7 @@ int ps_reset_solver_state(ps_problem* h) {
     h->lci_next = -1; h->lci_cur = 0;
     h->side_todo = false; h->side_ready = false; h->side_pending = false; h->acdone_pending = false;
     h->xcg_side_todo = false; h->xcg_lag_count = 0; h->xcg_held = 0;
+    h->xcg_its_ref = 0; h->xcg_good_held = 0; h->xcg_ref_pending = false;
     h->xcg_tag[0] = h->xcg_tag[1] = -1.0; h->xcg_tag_lambda[0] = h->xcg_tag_lambda[1] = 0.0;
     h->xcg_setup_cost = -1.0; h->xcg_setup_lambda = 0.0;
     h->mc_active = false; h->last_setup_lagx = false; h->xf_skip = 0;

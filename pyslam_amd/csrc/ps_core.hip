@@ -249,6 +249,9 @@ struct ps_problem {
     // "coarse_auto_hold": keep the lagged coarse inverse (no assembly, no side-stream factorisation) while the solve has
     // settled -- the last whole-iteration call changed the cost by less than 1e-4 relative -- for at most 3 set-ups in a row
     int xcg_auto_hold = 1, xcg_held = 0;
+    int xcg_adaptive_hold = 1;      // option "coarse_adaptive_hold": keep the lagged inverse while it still does its job (xcg_setup)
+    int xcg_its_ref = 0, xcg_good_held = 0;   // CG iterations of the first solve with the inverse in use / set-ups it has been kept for
+    bool xcg_ref_pending = false;
     double xcg_tag[2] = {-1.0, -1.0}, xcg_setup_cost = -1.0, xcg_tag_lambda[2] = {0.0, 0.0}, xcg_setup_lambda = 0.0, lin_lambda = 0.0;   // start cost of the call whose A_c each inverse buffer was formed from
     double last_cost = -1.0, prev_cost = -1.0;   // costs returned by the last two ps_gn_iteration calls (-1: none / parameters replaced since)
     double *xstate = nullptr, *xy = nullptr, *xp2 = nullptr;
@@ -365,6 +368,13 @@ struct ps_problem {
     // allow_nondecreasing_steps); -1 = unknown (a caller that drives ps_gn_iteration itself).  Side work that only pays back
     // over several later calls -- the seed of the lagged dense inverse -- is not started when the solve is about to stop.
     int solve_horizon = -1;
+    // speculative next linearisation (ps_solve): the call's tail stamps h_early when its reduced solve has converged; the host,
+    // waiting for the end of the iteration, then enqueues the linearisation of the NEXT iteration behind the tail, and the next
+    // ps_gn_iteration finds it done (prelin_valid) -- the GPU does not idle while the host ends one call and starts the next
+    long long *h_early = nullptr, *h_early_dev = nullptr;
+    long long early_seq = 0;
+    bool spec_next = false, spec_enqueued = false, early_armed = false, prelin_valid = false;
+    double prelin_lambda = 0.0;
     bool start_cost_pending = false; // the running whole-iteration call also evaluates the cost at its linearisation point (SC_STARTCOST)
     bool solver_touched = false;    // something has been linearised since creation / the last ps_reset_solver_state
     // profiling

@@ -43,6 +43,23 @@ void drain_timers(ps_problem* h) {      // call after a stream synchronisation
 
 int side_kick(ps_problem* h);
 int ldi_side_kick(ps_problem* h);
+int linearize(ps_problem* h, double lambda);
+
+// stage timers whose end event has completed (a speculative linearisation enqueued behind the iteration's end is still running
+// when the host leaves wait_published: its events stay pending)
+void drain_timers_ready(ps_problem* h) {
+    std::vector<std::pair<int, int>> keep;
+    for (auto& pr : h->pending) {
+        float ms = 0.f;
+        if (hipEventQuery(h->ev_pool[pr.second + 1]) != hipSuccess) { keep.push_back(pr); continue; }
+        if (hipEventElapsedTime(&ms, h->ev_pool[pr.second], h->ev_pool[pr.second + 1]) == hipSuccess) {
+            h->stage_ms[pr.first] += ms;
+            h->stage_n[pr.first] += 1;
+        }
+    }
+    h->pending.swap(keep);
+    if (h->pending.empty()) h->ev_used = 0;
+}
 
 int sync(ps_problem* h) {
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -71,14 +88,23 @@ int wait_published(ps_problem* h) {
         if (kick_mode == 2 && h->side_todo && !h->side_ready && *ws == h->setup_seq) { h->side_ready = true; if (side_kick(h)) return -1; }
         // (lagged dense inverse: k_ldi_init has started, S is final -- the Newton-Schulz step may run beside the solve)
         if (h->ldi_side_todo && *ws == h->setup_seq) { if (ldi_side_kick(h)) return -1; }
+        // ps_solve expects another iteration and the reduced solve has converged (the tail's first kernel says so): the next
+        // linearisation goes in behind the tail NOW, while the GPU runs the tail and the host has nothing to do but wait
+        if (h->early_armed && *reinterpret_cast<volatile long long*>(h->h_early) == h->early_seq) {
+            h->early_armed = false; h->spec_enqueued = true;
+            if (linearize(h, h->lin_lambda)) return -1;
+        }
         if (*w == h->seq) {
             if (h->start_cost_pending) {                     // ps_solve's first iteration: the start cost rode in front of it --
                 h->start_cost_pending = false;               // from here on the call knows it, as if ps_eval_cost had run first
                 h->last_cost = h->ldi_call_start_cost = h->h_scalars[SC_STARTCOST];
             }
             if (h->side_todo) { h->side_ready = true; if (kick_mode >= 1 && side_kick(h)) return -1; }
-            if (h->ldi_side_todo && ldi_side_kick(h)) return -1;
+            // (a refresh of the lagged inverse reads S on the side stream: not once the next linearisation is overwriting it)
+            if (h->ldi_side_todo) { if (h->spec_enqueued) h->ldi_side_todo = false; else if (ldi_side_kick(h)) return -1; }
+            h->early_armed = false;
             if (h->pending.empty()) return 0;
+            if (h->spec_enqueued) { drain_timers_ready(h); return 0; }     // (the next linearisation's events are still ahead)
             // stage timers: everything up to k_reduce3 has completed; an event recorded behind it may
             // need a moment more
             HIP_OK(hipEventSynchronize(h->ev_pool[h->pending.back().second + 1]));
@@ -862,6 +888,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
 
 int linearize(ps_problem* h, double lambda) {
     h->solver_touched = true;
+    h->prelin_valid = false;                                 // (whatever was linearised ahead is replaced)
     h->lin_lambda = lambda;                                  // (what the held coarse inverse is tagged with, beside the cost)
     ++h->prof_tick;
     h->cov_ready = false;
@@ -982,17 +1009,17 @@ int cost_pass(ps_problem* h, int include_all, int scalar_slot) {
     return 0;
 }
 
-int backsub(ps_problem* h, const int32_t* gate = nullptr, bool fuse_update = false) {
+int backsub(ps_problem* h, const int32_t* gate = nullptr, bool fuse_update = false, long long* hearly = nullptr, long long eseq = 0) {
     if (h->nv == 0) return 0;
     StageTimer t(h, PS_ST_BACKSUB);
     if (fuse_update)       // + full-step landmark update + SE(3) retraction of the poses in the same launch
         hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l + h->nsq_p), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
                            h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate,
-                           h->nsq_l, h->lm_point, h->points, h->P, h->poses, h->sq_part_p);
+                           h->nsq_l, h->lm_point, h->points, h->P, h->poses, h->sq_part_p, hearly, eseq);
     else
         hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
                            h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate,
-                           h->nsq_l, (const int32_t*)nullptr, (double*)nullptr, 0, (double*)nullptr, (double*)nullptr);
+                           h->nsq_l, (const int32_t*)nullptr, (double*)nullptr, 0, (double*)nullptr, (double*)nullptr, hearly, eseq);
     return 0;
 }
 
@@ -1014,14 +1041,14 @@ int step_norm(ps_problem* h) {
     return 0;
 }
 
-int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool with_norm = false) {
+int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool with_norm = false, long long* hearly = nullptr, long long eseq = 0) {
     StageTimer t(h, PS_ST_UPDATE);
     if (h->nr > 0) {
         double* sq = with_norm ? h->sq_part_p : nullptr;
         if (h->D == 6)
-            hipLaunchKernelGGL(k_update_poses<6>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses, sq, gate);
+            hipLaunchKernelGGL(k_update_poses<6>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses, sq, gate, hearly, eseq);
         else
-            hipLaunchKernelGGL(k_update_poses<3>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses, sq, gate);
+            hipLaunchKernelGGL(k_update_poses<3>, dim3(cdiv(h->P, 256)), dim3(256), 0, h->stream, h->P, h->pose_rid, h->x, step, h->poses, sq, gate, hearly, eseq);
     }
     if (h->nv > 0)
         hipLaunchKernelGGL(k_update_points, dim3(cdiv((long)h->nv * 3, 256)), dim3(256), 0, h->stream, h->nv,
@@ -1035,10 +1062,16 @@ int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = f
     // line-search order (cost AFTER the step): back-substitution, landmark update and pose retraction
     // are one launch when the problem has landmarks (then D == 6)
     const bool fused = linesearch && h->nv > 0 && h->nr > 0 && h->D == 6;
-    if (backsub(h, gate, fused)) return -1;
+    // the early word (speculative next linearisation, wait_published): stamped by the first kernel of the tail that reads the gate
+    long long* const hearly = (publish && h->spec_next && !h->spec_enqueued && gate) ? h->h_early_dev : nullptr;
+    const long long eseq = hearly ? ++h->early_seq : 0;
+    h->early_armed = hearly != nullptr;
+    const bool stamp_in_backsub = h->nv > 0;
+    if (backsub(h, gate, fused, stamp_in_backsub ? hearly : nullptr, eseq)) return -1;
     int ncost = 0;
     if (!linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 0, gate); }
-    if (!fused && apply_update(h, 1.0, gate, true)) return -1;
+    if (!fused && apply_update(h, 1.0, gate, true, stamp_in_backsub ? nullptr : hearly, eseq)) return -1;
+    if (!stamp_in_backsub && (fused || h->nr == 0)) h->early_armed = false;     // (no kernel carried the word)
     if (linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 1, gate); }
     double* o_cost = h->shard_out ? h->shard_buf : h->scalars + (linesearch ? SC_COST : SC_LINCOST);
     double* o_dxl = h->shard_out ? h->shard_buf + 1 : h->scalars + SC_DXL2;

@@ -60,19 +60,39 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     // the right one takes 24 -- a 600-keyframe BA, tests/test_gpu_ldi.py)
     const bool same_point = h->xcg_auto_hold && h->last_cost > 0.0 && h->last_cost == h->xcg_tag[h->lci_cur] &&
                             h->lin_lambda == h->xcg_tag_lambda[h->lci_cur];
+    // ... or the inverse in use still does its job (round 4): a refresh costs the latency-bound CG launches beside the side
+    // stream's factorisation ~5 us each (C4: 0.10-0.15 ms per iteration), a stale coarse inverse costs CG iterations (C4: the
+    // inverse of the start point serves the whole 4-iteration solve at 20-21 iterations against 19-20) -- so it is kept
+    // while the last solve with it took at most 3 iterations more than the first one did, for at most 8 set-ups in a row,
+    // under the damping it was formed with
+    // (not behind a step that changed the cost by more than 5 %: the point has moved, and a pose graph's coarse operator with it --
+    //  10 000 poses: 122 CG iterations in the third call with the start point's inverse against 88 with the refreshed one)
+    const bool moved = !(h->prev_cost > 0.0 && h->last_cost > 0.0 && std::fabs(h->prev_cost - h->last_cost) <= 0.05 * h->prev_cost);
+    const bool keep_ok = h->xcg_adaptive_hold && !moved && h->xcg_its_ref > 0 && h->last_pcg_iters > 0 &&
+                         h->last_pcg_iters <= h->xcg_its_ref + 3 && h->xcg_good_held < 8 && h->lci_next >= 0 &&
+                         h->lin_lambda == h->xcg_tag_lambda[h->lci_next];
+    const bool fresh_waiting = h->lci_next != h->lci_cur;    // a newer inverse has been (or is being) formed and not taken yet
+    const bool still_good = keep_ok && !fresh_waiting;       // keep the inverse in use: nothing on the side stream
+    const bool take_only = keep_ok && fresh_waiting;         // take the newer one, but do not start the next factorisation
     const bool hold = lag && ((h->xcg_lag_count > 0 &&
-                               ((h->xcg_refresh_every > 1 && (h->xcg_lag_count % h->xcg_refresh_every) != 0) || settled)) || same_point);
+                               ((h->xcg_refresh_every > 1 && (h->xcg_lag_count % h->xcg_refresh_every) != 0) || settled)) || same_point ||
+                              still_good);
     h->xcg_held = (hold && settled && !same_point) ? h->xcg_held + 1 : 0;
+    h->xcg_good_held = ((hold && still_good && !same_point && !settled) || (!hold && take_only)) ? h->xcg_good_held + 1
+                                                                                                  : (hold ? h->xcg_good_held : 0);
     h->xcg_setup_cost = h->last_cost; h->xcg_setup_lambda = h->lin_lambda;
     const int32_t* lagst = nullptr;
     h->xcg_side_todo = false;
     if (!hold && h->side_pending) { HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0)); h->side_pending = false; }
     if (lag) {
         if (!hold) {
+            if (h->lci_cur != h->lci_next) h->xcg_ref_pending = true;   // a new inverse: the solve below sets its reference iteration count
             h->lci_cur = h->lci_next;
-            if (xcg_ac_on_main()) xcg_assemble_ac<D>(h, h->stream);
-            HIP_OK(hipEventRecord(h->ev_ac, h->stream));   // SB and the basis complete; the side work is enqueued by xcg_side_enqueue
-            h->xcg_side_todo = true;
+            if (!take_only) {
+                if (xcg_ac_on_main()) xcg_assemble_ac<D>(h, h->stream);
+                HIP_OK(hipEventRecord(h->ev_ac, h->stream));   // SB and the basis complete; the side work is enqueued by xcg_side_enqueue
+                h->xcg_side_todo = true;
+            }
             lagst = h->lag_status;
         }
         ++h->xcg_lag_count;
@@ -82,6 +102,7 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
         if (xcg_coarse_inverse<D>(h, h->stream, buf, h->status)) return -1;
         h->lci_next = buf; h->xcg_tag[buf] = h->last_cost; h->xcg_tag_lambda[buf] = h->lin_lambda;
         h->xcg_lag_count = 0;
+        h->xcg_ref_pending = true;
     }
     h->xf_active = h->xcg_fused && h->xf_ok && h->xf_skip == 0;
     {   // xstate, the second p buffer and (one- / two-launch form) ts_0 and the records of buffer 0: one launch
@@ -345,7 +366,9 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
             }
             count = std::max(8, h->cg_launched / 2);
         }
-        return cg_report(h, iters_out, relres_out);
+        if (cg_report(h, iters_out, relres_out)) return -1;
+        if (h->xcg_ref_pending) { h->xcg_ref_pending = false; h->xcg_its_ref = h->last_pcg_iters; }
+        return 0;
     }
     ++h->ldi_iter;
     h->ldi_call_start_cost = h->last_cost;                  // cost at this call's linearisation point (-1: unknown)
@@ -367,7 +390,9 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
     const int margin = (h->ldi_moved || big_step) ? std::max(6, h->cg_margin)
                                     : ((h->last_pcg_iters == h->prev_pcg_iters) ? std::min(2, h->cg_margin) : h->cg_margin);
     h->ldi_moved = false;
-    int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : 16;
+    // (no prediction -- the first call of a solve: 24.  C3's first iteration needs 18 + 2; 16 meant a second round, +40 us, in every
+    //  cold solve; a launch past convergence costs ~1.5 us)
+    int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : 24;
     for (;;) {
         count = std::min(count, max_iters + 2 - h->cg_launched);
         cg_fused_launch<D>(h, tol, count);

@@ -166,6 +166,7 @@ int ldi_seed_enqueue(ps_problem* h, int its, double cost_now) {
     // rule says how many can come (option "solve_horizon"; a settling step IS a non-decreasing one under the reference's
     // rule, problem.py:177-178: cost >= 0.9 prev) -- C3 under the examples' options: calls 2-4 at 0.31 ms instead of 0.37 / 0.40 / 0.22.
     if (h->solve_horizon >= 0 && h->solve_horizon < 3) return 0;
+    if (h->spec_enqueued) return 0;                              // the next linearisation is already overwriting S
     if (h->ldi_iter < h->ldi_no_seed_before) return 0;         // (back-off after rejected seeds)
     // only once the solve has begun to settle: an inverse of an S that the next steps leave far behind is wasted side work
     // (last_cost: the cost the previous call left behind = where this call started; cost_now: what this call returns)

@@ -376,10 +376,15 @@ __global__ __launch_bounds__(256) void k_backsub(
     // fused full-step update (NULL points: back-substitution only).  Workgroups >= nblk_l retract the
     // SE(3) poses instead (nothing in the back-substitution reads `poses` or `points`).
     int nblk_l, const int32_t* __restrict__ lm_point, double* __restrict__ points,
-    int P, double* __restrict__ poses, double* __restrict__ sq_part_p)
+    int P, double* __restrict__ poses, double* __restrict__ sq_part_p,
+    // early word (pinned host memory; NULL: none): has the reduced solve in front of this tail converged?  +seq / -seq.  The
+    // host, which is only waiting for the end of the iteration, may enqueue the NEXT linearisation behind the tail on it
+    long long* __restrict__ hearly, long long eseq)
 {
     __shared__ double lds[16];
-    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
+    const bool closed = gate && gate[ST_PCG_DONE] != 1;
+    if (hearly && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<volatile long long*>(hearly) = closed ? -eseq : eseq;
+    if (closed) return;                              // (2 = CG breakdown: the host falls back, nothing is applied)
     if ((int)blockIdx.x >= nblk_l) {
         typedef PoseOps<6> G;
         const int i = (blockIdx.x - nblk_l) * blockDim.x + threadIdx.x;
@@ -442,11 +447,13 @@ template <int D>
 __global__ __launch_bounds__(256) void k_update_poses(
     int P, const int32_t* __restrict__ pose_rid, const double* __restrict__ xp,
     double step, double* __restrict__ poses, double* __restrict__ sq_part /* per workgroup, or null */,
-    const int32_t* __restrict__ gate)
+    const int32_t* __restrict__ gate, long long* __restrict__ hearly = nullptr /* as k_backsub's */, long long eseq = 0)
 {
     typedef PoseOps<D> G;
     __shared__ double lds[16];
-    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
+    const bool closed = gate && gate[ST_PCG_DONE] != 1;
+    if (hearly && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<volatile long long*>(hearly) = closed ? -eseq : eseq;
+    if (closed) return;                              // (2 = CG breakdown: the host falls back, nothing is applied)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double sq = 0.0;
     const int rid = (i < P) ? pose_rid[i] : -1;

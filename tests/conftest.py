@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A test that hangs must end as ONE failed test, not as a suite that runs into the box's limit: every test gets a
+    deadline when pytest-timeout is there (it is in this image), unless the command line set one."""
+    if not config.pluginmanager.hasplugin('timeout') or getattr(config.option, 'timeout', None):
+        return
+    for item in items:
+        if item.get_closest_marker('timeout') is None:
+            item.add_marker(pytest.mark.timeout(600))
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
 

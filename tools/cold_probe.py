@@ -1,5 +1,5 @@
 """Cold, reference-terminated solves (bench.py: cold_solves) of a stereo BA on one GPU: per-call wall clock, iteration counts.
-    python tools/cold_probe.py [kf lm [solves]] [--python-loop]"""
+    python tools/cold_probe.py [kf lm [solves]] [--python-loop] [--pg] [--opt=name:value ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,8 +13,14 @@ args = [a for a in sys.argv[1:] if not a.startswith('--')]
 kf, lm = (int(args[0]), int(args[1])) if len(args) >= 2 else (200, 50000)
 solves = int(args[2]) if len(args) >= 3 else 6
 core_loop = '--python-loop' not in sys.argv
-lp, _ = synthetic.stereo_ba(num_kf=kf, num_lm=lm, obs_per_lm=10, half_window=20, seed=0 if kf == 200 else 1)
+opts = [a for a in sys.argv[1:] if a.startswith('--opt=')]
+if '--pg' in sys.argv:       # kf = poses, lm = loop closures, SE(3), Huber (BASELINE configuration 2 at 10000 40001)
+    lp, _ = synthetic.pose_graph(num_poses=kf, num_loops=lm, dof=6, seed=2)
+else:
+    lp, _ = synthetic.stereo_ba(num_kf=kf, num_lm=lm, obs_per_lm=10, half_window=20, seed=0 if kf == 200 else 1)
 dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
+for o in opts:
+    k, v = o[6:].split(':'); dev.set_option(k, float(v))
 start = (lp.poses.copy(), lp.points.copy())
 opt = bench.example_options()
 tot, its = 0.0, 0
