@@ -115,6 +115,9 @@ enum { PS_ST_LANDMARK = 0, PS_ST_POSE = 1, PS_ST_SCHUR = 2, PS_ST_EDGES = 3, PS_
 
 const char* ps_last_error(void);
 int ps_device_count(void);
+/* Pay the process-wide one-off costs now (code-object load at the first kernel launch, allocator set-up at the first
+   hipMalloc) instead of inside the first solve.  Idempotent; the binding calls it when it first finds a device. */
+int ps_warm_up(void);
 
 /* Lower the tables to HBM and precompute the iteration-invariant structure
    (landmark / pose segment lists, Schur pair lists, block pattern).

@@ -70,6 +70,7 @@ H = C.c_void_p
 SIGNATURES = {
     'ps_last_error': (C.c_char_p, []),
     'ps_device_count': (C.c_int, []),
+    'ps_warm_up': (C.c_int, []),
     'ps_problem_create': (C.c_int, [C.POINTER(ProblemDesc), C.c_void_p, C.POINTER(H)]),
     'ps_problem_destroy': (C.c_int, [H]),
     'ps_get_info': (C.c_int, [H, C.POINTER(ProblemInfo)]),
@@ -200,8 +201,15 @@ def i32p(a):
     return _resident_ptr(a, c_i32p, 'int32') if is_resident(a) else a.ctypes.data_as(c_i32p)
 
 
+_warm = False
+
+
 def require_gpu():
+    global _warm
     lib = load()
     if lib.ps_device_count() < 1:
         raise NativeError("no HIP device visible: pyslam_amd solves only on an MI355X (no CPU fallback)")
+    if not _warm:           # the process-wide one-off costs (code-object load, allocator set-up) here, not in the first solve
+        check(lib.ps_warm_up())
+        _warm = True
     return lib

@@ -238,25 +238,54 @@ def test_c3_covariance_columns_solve_the_reference_precision(c3):
         k = (index * d + comp) if kind == 0 else (nr * d + index * 3 + comp)
         assert x[k] > 0.                                       # a variance
 
-def test_c2_full_size_first_steps_match_the_reference_algebra():
-    """BASELINE config C2 at full size: 10 000 SE(3) poses, 50 001 edges, Huber, prior on pose 0.  Two
-    Gauss-Newton steps on the device (two-level CG with the rigid-motion-aware coarse basis, relative
-    tolerance 1e-12) against the oracle's sparse direct solves of the reference's normal equations."""
+def accurate_sparse_solve(H, b):
+    """The arbiter at sizes where a dense solve is out of reach: Jacobi-scaled sparse LU + iterative refinement with
+    long-double residuals (cond(H) ~ 1e12 with the 1e-12 prior next to unit loop closures: SuperLU on the unscaled
+    matrix is itself the less accurate side)."""
+    import scipy.sparse as sp
     import scipy.sparse.linalg as spl
+    d = 1. / np.sqrt(H.diagonal())
+    Dm = sp.diags(d)
+    Hs = (Dm @ H @ Dm).tocsc()
+    bs = b * d
+    lu = spl.splu(Hs)
+    x = lu.solve(bs)
+    Hl = Hs.tocsr().astype(np.longdouble)
+    for _ in range(3):
+        res = bs.astype(np.longdouble) - Hl.dot(x.astype(np.longdouble))
+        x = x + lu.solve(np.asarray(res, dtype=float))
+    return x * d
+
+
+def test_c2_full_size_first_steps_match_the_reference_algebra():
+    """BASELINE config C2 at full size: 10 000 SE(3) poses, 50 001 edges, Huber, prior on pose 0.  Two Gauss-Newton
+    steps on the device (two-level PCG, rigid-motion-aware coarse basis) in the form of the C3 / C4 checks, SURVEY 8d's
+    tolerances: every step satisfies the oracle's normal equations at the device's own linearisation point,
+    |H dx - b| <= 1e-9 |b| (Jacobi-scaled norms: block scales differ by 1e12), equals the accurate solve to 1e-8, and the
+    post-step cost equals the oracle's to 1e-10."""
+    import copy
     lp, _ = synthetic.pose_graph(num_poses=10000, num_loops=40001, dof=6, seed=2)
     dev = device(lp)
     cur = lp
     assert abs(dev.eval_cost(True) - orc.eval_cost(cur)) <= 1e-10 * orc.eval_cost(cur)
     for _ in range(2):
-        H, b, _ = orc.normal_equations(cur, points_first=False)
-        dx = spl.spsolve(H.tocsc(), b)
-        cur = orc.apply_update(cur, dx, False)
-        cost, nrm, its, rel = dev.gn_iteration(0., 1e-12, 4000, True)
-        assert rel <= 1e-12 and its < 4000                       # the CG converges (it did not before the Ad-aware basis)
-        assert abs(nrm - np.linalg.norm(dx)) <= 1e-6 * np.linalg.norm(dx)
-        assert abs(cost - orc.eval_cost(cur)) <= 1e-6 * cost
-    poses, _ = dev.get_params()
-    assert np.abs(poses - cur.poses).max() < 1e-5
+        H, b, _ = orc.normal_equations(cur, points_first=False)       # the oracle at the DEVICE's current parameters
+        dx_ref = accurate_sparse_solve(H.tocsr(), b)
+        cost, nrm, its, rel = dev.gn_iteration(0., 1e-14, 4000, True)  # (1e-14: error <= cond(M^-1 S) x relres, as the pose-graph goldens)
+        assert rel <= 1e-14 and its < 4000                       # the CG converges (it did not before the Ad-aware basis)
+        xp, _ = dev.get_dx()
+        dx = xp.ravel()                                          # pose-first order, no landmarks: the oracle's order
+        dj = 1. / np.sqrt(H.diagonal())
+        assert np.linalg.norm((H.dot(dx) - b) * dj) <= 1e-9 * np.linalg.norm(b * dj)
+        assert np.linalg.norm(dx - dx_ref) <= 1e-8 * np.linalg.norm(dx_ref), np.linalg.norm(dx - dx_ref) / np.linalg.norm(dx_ref)
+        assert abs(nrm - np.linalg.norm(dx_ref)) <= 1e-8 * np.linalg.norm(dx_ref)
+        nxt = orc.apply_update(cur, dx_ref, False)
+        assert abs(cost - orc.eval_cost(nxt)) <= 1e-10 * cost
+        poses, _ = dev.get_params()
+        assert np.abs(poses - nxt.poses).max() < 1e-9
+        cur = copy.copy(nxt)
+        cur.poses = poses                                        # the next step is compared at the device's own point
+
 
 def test_explicit_and_folded_two_level_cg_agree_on_a_long_chain():
     """Long sparse chains run the two-level PCG with the preconditioner APPLIED (k_xcg_*: restrict, dense coarse
