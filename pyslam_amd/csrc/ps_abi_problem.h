@@ -330,6 +330,116 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     if (h->alloc(&h->fscratch, (size_t)F * FROW)) return -1;
 
     lap("pose factors");
+    // ---- pose-stationary Schur lists (round 4; kernel k_schur_pose, csrc/ps_k_schur3.h; NOT the default: slower, see below).
+    // A workgroup takes a SEGMENT of up to PS_PP_SEG rows of ONE pose i -- its Z rows on variable landmarks, in landmark
+    // order -- brings them into LDS once, and its waves work through the tasks (segment, partner pose j > i): the pairs
+    // (a = local index of pose i's row, b = the Z row of pose j on the same landmark).  Only the partner rows are gathered:
+    // 0.5 M + 2.25 M row fetches at C3 instead of 4.5 M.  One partial block per task, summed in segment order by
+    // k_schur_combine (fixed order).  Not built when a landmark is observed twice from one pose (a diagonal-block task: the
+    // gather kernels handle that) or when a Z row index does not fit 23 bits.
+    std::vector<uint64_t> pose_keys;              // upper block keys (ri < rj) that receive pairs, unsorted, with repeats
+    std::vector<PoseSeg> psegs;
+    std::vector<int32_t> pseg_rows;
+    std::vector<PairItem> ptasks;                 // slot / slotT are filled once the block pattern exists
+    std::vector<uint64_t> ptask_key;
+    std::vector<uint32_t> ppairs;
+    std::vector<long> pseg_pairs;                 // pairs per segment (XCD balancing)
+    // Measured (tools/schur_probe.py): 0.121 ms at C3 against 0.046 for the pipelined gather kernel, 1.01 ms
+    // against 0.515 at C4 -- a workgroup needs 157 KB of LDS (the segment + two chunk buffers per wave), so ONE is resident per
+    // CU and the dependent loads of its start-up (order -> segment -> row indices -> rows -> pair words -> partner rows) are
+    // covered by nothing; with products, fetches, fill and stores all removed the skeleton still takes 0.06 ms.  Kept as an
+    // independent variant (parity-tested against the gather kernels and the oracle); built with PS_SCHUR_MODE=1 (this
+    // kernel only) or 2 (both list sets: option "schur_mode" switches).
+    const int schur_mode_env = getenv("PS_SCHUR_MODE") ? atoi(getenv("PS_SCHUR_MODE")) : 0;
+    bool pose_mode = schur_mode_env != 0 && D == 6 && nv > 0 && nr > 0 && Nl > 0 && Nl < (1L << 23);
+    if (pose_mode) {
+        std::vector<int32_t> rid_row((size_t)Nl), lm_row((size_t)Nl);
+        for (int v = 0; v < nv; ++v)
+            for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) { lm_row[a] = v; rid_row[a] = d->pose_rid[PS_POSE_OF(lobs[a])]; }
+        struct Tri { int32_t rb, al, b; };
+        struct Part {                                   // what one host thread produces for its range of poses
+            std::vector<PoseSeg> segs; std::vector<int32_t> rows; std::vector<PairItem> tasks; std::vector<uint64_t> keys;
+            std::vector<uint32_t> pairs; std::vector<long> seg_pairs; bool diag = false;
+        };
+        const int nth = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, nr}));
+        std::vector<Part> parts(nth);
+        auto work = [&](int th) {
+            Part& o = parts[th];
+            const int r0 = (int)((long)nr * th / nth), r1 = (int)((long)nr * (th + 1) / nth);
+            std::vector<Tri> tri, sorted;
+            std::vector<int32_t> cnt((size_t)nr + 1, 0), touched;
+            for (int r = r0; r < r1; ++r) {
+                // pose r's Z rows (variable landmarks only), ascending
+                int s0 = pcount[r];
+                const int s_end = pcount[r + 1];
+                while (s0 < s_end) {
+                    PoseSeg sg{(int32_t)o.rows.size(), 0, (int32_t)o.tasks.size(), 0};
+                    tri.clear();
+                    int al = 0;
+                    for (; s0 < s_end && al < PS_PP_SEG - 1; ++s0) {
+                        const int k = pidx[s0];
+                        if (k >= Nl) continue;                   // an observation of a constant point: no Z row
+                        o.rows.push_back(k);
+                        const int v = lm_row[k];
+                        for (int b = lm_ptr[v]; b < lm_ptr[v + 1]; ++b) {
+                            const int rb = rid_row[b];
+                            if (rb > r) tri.push_back({rb, al, b});
+                            else if (rb == r && b != k) o.diag = true;
+                        }
+                        ++al;
+                    }
+                    sg.row_count = al;
+                    // tasks: the pairs by partner (stable counting sort: pairs of a task stay in landmark order)
+                    touched.clear();
+                    for (const Tri& t : tri) { if (cnt[t.rb]++ == 0) touched.push_back(t.rb); }
+                    std::sort(touched.begin(), touched.end());
+                    int32_t run = 0;
+                    for (int32_t rb : touched) { const int32_t c = cnt[rb]; cnt[rb] = run; run += c; }
+                    sorted.resize(tri.size());
+                    for (const Tri& t : tri) sorted[cnt[t.rb]++] = t;
+                    // every task's words are padded to a multiple of 32 (one product pass of the kernel); a padding word carries
+                    // the reserved a-row index and the task's last partner row (a harmless fetch)
+                    int32_t prev = 0;
+                    for (int32_t rb : touched) {
+                        const int32_t end = cnt[rb];
+                        const int32_t w0 = (int32_t)o.pairs.size();
+                        for (int32_t q = prev; q < end; ++q) o.pairs.push_back(((uint32_t)sorted[q].al << 23) | (uint32_t)sorted[q].b);
+                        while ((o.pairs.size() - (size_t)w0) % 32) o.pairs.push_back(((uint32_t)511u << 23) | (uint32_t)sorted[end - 1].b);
+                        o.tasks.push_back({-1, -1, w0, (int32_t)o.pairs.size()});
+                        o.keys.push_back(((uint64_t)r << 32) | (uint32_t)rb);
+                        prev = end;
+                        cnt[rb] = 0;
+                    }
+                    sg.task_end = (int32_t)o.tasks.size();
+                    if (al > 0) { o.segs.push_back(sg); o.seg_pairs.push_back((long)tri.size()); }
+                    else { o.rows.resize(sg.row_start); }
+                }
+            }
+        };
+        if (nth == 1) work(0);
+        else {
+            std::vector<std::thread> pool;
+            for (int th = 0; th < nth; ++th) pool.emplace_back(work, th);
+            for (auto& t : pool) t.join();
+        }
+        size_t tot_pairs = 0, tot_tasks = 0;
+        for (const Part& o : parts) { pose_mode = pose_mode && !o.diag; tot_pairs += o.pairs.size(); tot_tasks += o.tasks.size(); }
+        if (tot_pairs >= (1UL << 31) || tot_tasks >= (1UL << 31) / 36) pose_mode = false;
+        if (pose_mode) {
+            for (const Part& o : parts) {                   // concatenate in pose order, rebasing the offsets
+                const int32_t rb = (int32_t)pseg_rows.size(), tb = (int32_t)ptasks.size(), pb = (int32_t)ppairs.size();
+                for (PoseSeg sg : o.segs) { sg.row_start += rb; sg.task_start += tb; sg.task_end += tb; psegs.push_back(sg); }
+                for (PairItem t : o.tasks) { t.start += pb; t.end += pb; ptasks.push_back(t); }
+                pseg_rows.insert(pseg_rows.end(), o.rows.begin(), o.rows.end());
+                ptask_key.insert(ptask_key.end(), o.keys.begin(), o.keys.end());
+                ppairs.insert(ppairs.end(), o.pairs.begin(), o.pairs.end());
+                pseg_pairs.insert(pseg_pairs.end(), o.seg_pairs.begin(), o.seg_pairs.end());
+            }
+            pose_keys = ptask_key;
+        }
+    }
+    const bool gather_lists = !pose_mode || schur_mode_env == 2;      // the pair lists of the gather kernels (k_schur_pairs[_db])
+    lap("pose-stationary lists");
     // ---- Schur pairs per landmark (upper-triangle block keys)
     // Landmark tiles: when Z (144 B per row) is much larger than the eight 4 MB L2s, the pair list is
     // cut into tiles of consecutive landmarks (consecutive Z rows) and ONE XCD works through a whole
@@ -350,19 +460,19 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
             ntiles = 8 * (int)std::ceil(zbytes / (8.0 * tile_kb * 1024.0));
     }
     std::vector<long> lm_pairs_before(nv + 1, 0);
-    for (int v = 0; v < nv; ++v) {
+    for (int v = 0; v < nv && gather_lists; ++v) {
         long nvar = 0;
         for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) nvar += d->pose_rid[PS_POSE_OF(lobs[a])] >= 0;
         lm_pairs_before[v + 1] = lm_pairs_before[v] + nvar * (nvar - 1) / 2;
     }
-    const long total_pairs = lm_pairs_before[nv];
+    const long total_pairs = gather_lists ? lm_pairs_before[nv] : 0;
     // one unit of work per tile: the tile's pairs in (block row, block column, landmark) order, written to its
     // slice of prs; tiles are independent, so they are built by a few host threads
     // Tiles multiply the tasks (one per (tile, block) with pairs): when a task is left with a handful of pairs -- a landmark
     // shard of a multi-GPU run: 36 pairs per block at C4 / 8 -- the per-task skeleton dominates and the
     // untiled list wins (C4 / 8 shard: Schur stage 0.159 -> 0.119 ms).  Decided on the generated list: fewer than 64 pairs
     // per task on average -> generated again without tiles.
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 2 && gather_lists; ++attempt) {
         auto tile_of = [&](int v) {
             return (ntiles > 1 && total_pairs > 0)
                 ? (int)std::min<long>(ntiles - 1, (long)((double)ntiles * (double)lm_pairs_before[v] / (double)total_pairs)) : 0;
@@ -379,6 +489,65 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
             for (int q = ntiles - 1; q >= 0; --q) tile_begin[q] = std::min(tile_begin[q], tile_begin[q + 1]);
         }
         prs.resize((size_t)total_pairs);
+        // One tile (the untiled list: C3): pose by pose on several host threads.  The pairs of pose r -- its rows a in landmark
+        // order against the rows b of the same landmark whose pose comes later (or the same pose again, b > a: a diagonal block)
+        // -- sorted by partner (stable) ARE the (block row, block column, landmark) order the two counting passes over the whole
+        // list produce, so the threads' outputs are simply concatenated (C3: 70 ms -> 7 ms of ps_problem_create).
+        auto build_untiled_by_pose = [&]() {
+            std::vector<int32_t> rid_row((size_t)lm_ptr[nv]), lm_row((size_t)lm_ptr[nv]);
+            for (int v = 0; v < nv; ++v)
+                for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) { lm_row[a] = v; rid_row[a] = d->pose_rid[PS_POSE_OF(lobs[a])]; }
+            const long nrows = lm_ptr[nv];
+            const int nth = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, nr}));
+            std::vector<std::vector<PairRec>> outs(nth);
+            auto work = [&](int th) {
+                std::vector<PairRec>& o = outs[th];
+                const int r0 = (int)((long)nr * th / nth), r1 = (int)((long)nr * (th + 1) / nth);
+                std::vector<PairRec> tri;
+                std::vector<int32_t> cnt((size_t)nr + 1, 0), touched;
+                for (int r = r0; r < r1; ++r) {
+                    tri.clear();
+                    for (int s0 = pcount[r]; s0 < pcount[r + 1]; ++s0) {
+                        const int k = pidx[s0];
+                        if (k >= nrows) continue;                // an observation of a constant point: no Z row
+                        const int v = lm_row[k];
+                        for (int b = lm_ptr[v]; b < lm_ptr[v + 1]; ++b) {
+                            const int rb = rid_row[b];
+                            if (rb > r || (rb == r && b > k)) tri.push_back({((uint64_t)r << 32) | (uint32_t)rb, k, b, 0});
+                        }
+                    }
+                    touched.clear();
+                    for (const PairRec& t : tri) { if (cnt[(uint32_t)t.key]++ == 0) touched.push_back((int32_t)(uint32_t)t.key); }
+                    std::sort(touched.begin(), touched.end());
+                    int32_t run = 0;
+                    for (int32_t rb : touched) { const int32_t c = cnt[rb]; cnt[rb] = run; run += c; }
+                    const size_t base = o.size();
+                    o.resize(base + tri.size());
+                    for (const PairRec& t : tri) o[base + cnt[(uint32_t)t.key]++] = t;
+                    for (int32_t rb : touched) cnt[rb] = 0;
+                }
+            };
+            if (nth == 1) work(0);
+            else {
+                std::vector<std::thread> pool;
+                for (int th = 0; th < nth; ++th) pool.emplace_back(work, th);
+                for (auto& t : pool) t.join();
+            }
+            size_t at = 0;
+            for (auto& o : outs) { std::copy(o.begin(), o.end(), prs.begin() + at); at += o.size(); }
+            prs.resize(at);
+        };
+        // When all of Z stays in the Infinity Cache the untiled list is the likely winner (the rule below): build IT first and
+        // keep it if the blocks alone fill the chip -- no tiled list is generated only to be thrown away (C3: 23 -> 7 ms)
+        const bool by_pose = nr > 0 && !getenv("PS_PAIRS_BY_LANDMARK");
+        if (by_pose && attempt == 0 && ntiles > 1 && !tiles_forced && zbytes <= 128.0 * 1048576.0 && !getenv("PS_SCHUR_KEEP_TILES")) {
+            build_untiled_by_pose();
+            size_t nblocks0 = 0;
+            for (size_t k = 0; k < prs.size(); ++k) nblocks0 += (k == 0 || prs[k].key != prs[k - 1].key);
+            if (nblocks0 >= 2 * 256 * 12) { ntiles = 1; break; }
+            prs.resize((size_t)total_pairs);
+        }
+        if (ntiles == 1 && by_pose) { build_untiled_by_pose(); break; }
         auto build_tile = [&](int tile) {
             const int v0 = tile_begin[tile], v1 = tile_begin[tile + 1];
             std::vector<PairRec> loc;
@@ -426,8 +595,9 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
         if (prs.size() >= 64 * ntask && !blocks_fill_chip) break;
         ntiles = 1;
     }
+    if (!gather_lists) ntiles = 1;
     h->schur_tiles = ntiles;
-    h->npairs = (long)prs.size();
+    h->npairs = gather_lists ? (long)prs.size() : (long)ppairs.size();
     if (prs.size() >= (1UL << 31)) return fail("too many Schur pairs for 32-bit indexing");
 
     lap("pair generation + sort");
@@ -436,6 +606,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     keys.reserve(prs.size() / 8 + nr + F + d->num_extra_pairs);
     for (int r = 0; r < nr; ++r) keys.push_back(((uint64_t)r << 32) | (uint32_t)r);
     for (size_t k = 0; k < prs.size(); ++k) if (k == 0 || prs[k].key != prs[k - 1].key) keys.push_back(prs[k].key);
+    keys.insert(keys.end(), pose_keys.begin(), pose_keys.end());
     for (long f = 0; f < E; ++f) {
         const int ra = d->pose_rid[f_i[f]], rb = d->pose_rid[f_j[f]];
         if (ra >= 0 && rb >= 0 && ra != rb)
@@ -551,6 +722,66 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
         }
     }
     prs.clear(); prs.shrink_to_fit();
+    if (pose_mode && !ptasks.empty()) {
+        for (size_t t = 0; t < ptasks.size(); ++t) {
+            const int a = (int)(ptask_key[t] >> 32), b = (int)(uint32_t)ptask_key[t];
+            ptasks[t].slot = slot_of(a, b); ptasks[t].slotT = slot_of(b, a);
+        }
+        // XCD x sweeps a contiguous range of poses (its segments in pose order: neighbouring poses share landmarks, hence
+        // partner rows -- temporal locality in that XCD's L2 and in the Infinity Cache); ranges balanced by pair count
+        long total = 0;
+        for (long c : pseg_pairs) total += c + 64;           // (+ a per-segment constant: the row fill)
+        std::vector<std::vector<int32_t>> lists(8);
+        long run = 0;
+        for (size_t q = 0; q < psegs.size(); ++q) {
+            lists[std::min(7, (int)(8.0 * (double)run / (double)std::max(total, 1L)))].push_back((int32_t)q);
+            run += pseg_pairs[q] + 64;
+        }
+        size_t mx = 0;
+        for (auto& l : lists) mx = std::max(mx, l.size());
+        mx = std::max<size_t>(mx, 1);
+        std::vector<int32_t> order(8 * mx, -1);
+        for (int x = 0; x < 8; ++x) for (size_t q = 0; q < lists[x].size(); ++q) order[x * mx + q] = lists[x][q];
+        // per-block task lists in segment order (tasks are numbered pose-, segment-, partner-major)
+        std::vector<std::pair<int32_t, int32_t>> bt(ptasks.size());
+        for (size_t k = 0; k < ptasks.size(); ++k) bt[k] = {ptasks[k].slot, (int32_t)k};
+        std::stable_sort(bt.begin(), bt.end(), [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) {
+            return x.first < y.first; });
+        std::vector<PairItem> citm;
+        std::vector<int32_t> ctasks(bt.size());
+        for (size_t k = 0; k < bt.size(); ++k) {
+            ctasks[k] = bt[k].second;
+            if (k == 0 || bt[k].first != bt[k - 1].first) {
+                if (!citm.empty()) citm.back().end = (int32_t)k;
+                citm.push_back({ptasks[bt[k].second].slot, ptasks[bt[k].second].slotT, (int32_t)k, 0});
+            }
+        }
+        citm.back().end = (int32_t)bt.size();
+        // device records: a wave takes a contiguous run of the segment's tasks (their words are contiguous), runs balanced by
+        // product passes
+        std::vector<PoseSegW> psegw(psegs.size());
+        for (size_t q = 0; q < psegs.size(); ++q) {
+            const PoseSeg& sg = psegs[q];
+            PoseSegW& o = psegw[q];
+            o.row_start = sg.row_start; o.row_count = sg.row_count;
+            const long w0 = sg.task_start < sg.task_end ? ptasks[sg.task_start].start : 0;
+            const long wn = sg.task_start < sg.task_end ? ptasks[sg.task_end - 1].end - w0 : 0;
+            int tcur = sg.task_start;
+            o.wt[0] = tcur;
+            for (int w = 1; w <= PS_PP_WAVES; ++w) {
+                const long target = w0 + wn * w / PS_PP_WAVES;
+                while (tcur < sg.task_end && (w == PS_PP_WAVES || ptasks[tcur].end <= target)) ++tcur;
+                // (a task that straddles the target goes to the next wave; the last wave takes the rest)
+                o.wt[w] = tcur;
+            }
+        }
+        h->pp_per_xcd = (int)mx; h->pp_ntasks = (int)ptasks.size(); h->pp_ncomb = (int)citm.size();
+        if (h->upload(&h->pp_order, order) || h->upload(&h->pp_segs, psegw) || h->upload(&h->pp_rows, pseg_rows) ||
+            h->upload(&h->pp_tasks, ptasks) || h->upload(&h->pp_pairs, ppairs) || h->upload(&h->pp_comb_items, citm) ||
+            h->upload(&h->pp_comb_tasks, ctasks) || h->alloc(&h->pp_part, ptasks.size() * 36)) return -1;
+        h->pose_mode = true;
+    }
+    h->gather_lists = gather_lists;
 
     lap("pair items + XCD lists");
     // ---- streaming Schur kernel (k_schur_stream): landmark tiles, per-tile block tables, per-lane-pair entry lists

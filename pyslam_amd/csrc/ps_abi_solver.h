@@ -643,6 +643,11 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "cg_ablate") h->cg_ablate = (int)value;
     else if (n == "schur_ablate") h->schur_ablate = (int)value;
     else if (n == "schur_pipeline") h->schur_pipeline = value != 0.0;
+    else if (n == "schur_mode") {
+        if (value != 0.0 && value != 1.0) return fail("schur_mode must be 0 (gather kernels) or 1 (pose-stationary kernel)");
+        if (value == 0.0 && !h->gather_lists) return fail("schur_mode 0: the gather kernels' pair lists were not built for this handle (create it under PS_SCHUR_MODE=0 or 2)");
+        h->schur_mode = (int)value;
+    }
     else if (n == "schur_stream") { if (value != 0.0 && !h->st_tiles) return fail("schur_stream: the streaming lists were not built for this problem"); h->use_stream = value != 0.0; }
     else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;

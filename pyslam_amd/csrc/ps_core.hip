@@ -152,6 +152,16 @@ struct ps_problem {
     double* Spart = nullptr;
     PairItem* comb_items = nullptr;     // slot, slotT, [start, end) into comb_tasks
     int32_t* comb_tasks = nullptr;
+    // pose-stationary Schur kernel (k_schur_pose, ps_k_schur3.h): segments of a pose's Z rows, tasks (segment, partner), packed pairs
+    int schur_mode = 1;             // option "schur_mode": 1 = pose-stationary kernel when its lists exist (PS_SCHUR_MODE=1 / 2 at create), 0 = the gather kernels
+    bool gather_lists = true;       // the pair lists of the gather kernels exist (not built in pose mode unless PS_SCHUR_MODE=2)
+    bool pose_mode = false;         // the lists exist and the kernel is in use (option "schur_mode": 0 = gather kernels, if their lists exist)
+    int pp_per_xcd = 0, pp_ntasks = 0, pp_ncomb = 0;
+    int32_t *pp_order = nullptr, *pp_rows = nullptr, *pp_comb_tasks = nullptr;
+    PoseSegW* pp_segs = nullptr;
+    PairItem *pp_tasks = nullptr, *pp_comb_items = nullptr;
+    uint32_t* pp_pairs = nullptr;
+    double* pp_part = nullptr;
     // streaming Schur kernel (k_schur_stream): landmark tiles, sub-tiles, entry words, partial blocks + their combine lists
     int stream_mode = 0;            // PS_SCHUR_STREAM: 0 off (default: measured slower than the gather kernel), 1 whenever it can be built
     bool use_stream = false;

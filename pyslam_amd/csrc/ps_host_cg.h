@@ -917,16 +917,27 @@ int linearize(ps_problem* h, double lambda) {
         else
             hipLaunchKernelGGL(k_pose_pass<false>, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
                                h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp);
+        const bool pose_schur = h->pose_mode && h->schur_mode != 0;
         // tiled Schur: the combine launch also finalizes the poses (unless a task writes a diagonal block)
-        fin_in_combine = (h->Spart || h->use_stream) && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6;
+        fin_in_combine = pose_schur ? h->D == 6
+                                    : ((h->Spart || h->use_stream) && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6);
         // untiled Schur with the pipelined pair kernel: its trailing workgroups finalize the poses
-        fin_in_pairs = !h->Spart && !h->use_stream && h->schur_pipeline && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6 &&
+        fin_in_pairs = !pose_schur && !h->Spart && !h->use_stream && h->schur_pipeline && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6 &&
                        !getenv("PS_SCHUR_SPLIT");
         if (!fin_in_combine && !fin_in_pairs)
             hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
                                h->ppartial, h->diag_slot, lambda, h->S, h->g);
     }
-    if (h->npair_items > 0 && h->use_stream) {
+    if (h->pose_mode && h->schur_mode != 0) {
+        // pose-stationary pair products (ps_k_schur3.h) + the combine launch (partials in segment order; it also finalizes the poses)
+        StageTimer t(h, PS_ST_SCHUR, 1);
+        if (ensure_dynamic_lds((const void*)k_schur_pose, (size_t)PS_PP_LDS_BYTES)) return -1;
+        hipLaunchKernelGGL(k_schur_pose, dim3(8 * h->pp_per_xcd), dim3(PS_PP_THREADS), PS_PP_LDS_BYTES, h->stream, h->pp_per_xcd, h->pp_order, h->pp_segs,
+                           h->pp_rows, h->pp_tasks, h->pp_pairs, h->Z, h->pp_part, h->schur_ablate);
+        hipLaunchKernelGGL(k_schur_combine, dim3(cdiv(h->pp_ncomb, 4) + (fin_in_combine ? cdiv(h->nr, 4) : 0)), dim3(256), 0,
+                           h->stream, h->pp_ncomb, h->pp_comb_items, h->pp_comb_tasks, h->pp_part, h->S,
+                           fin_in_combine ? h->nr : 0, h->pitem_ptr, h->ppartial, h->diag_slot, lambda, h->g);
+    } else if (h->npair_items > 0 && h->use_stream) {
         StageTimer t(h, PS_ST_SCHUR, 1);
         const size_t lds = (size_t)PS_ST_SUBROWS * PS_ST_ROWD * sizeof(double);
         if (!h->st_attr_set) {

@@ -28,6 +28,9 @@ struct __attribute__((aligned(32))) LObs {   // one reprojection observation, 32
 };
 struct PItem { int32_t rid, start, end, pad; };
 struct PairItem { int32_t slot, slotT, start, end; };
+// pose-stationary Schur kernel: a segment of one pose's Z rows (row_start into the row list) and its tasks
+struct PoseSeg { int32_t row_start, row_count, task_start, task_end; };
+#define PS_PP_SEG 512                         // a-rows in LDS; a segment holds at most PS_PP_SEG - 1 (index 511 marks a padding word)
 struct FactorGroup { double S[36]; int32_t loss_id; int32_t pad; double loss_k; };
 
 #define PS_POSE_OF(o) ((o).pose_grp & 0xFFFFFF)
@@ -92,6 +95,7 @@ PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
 
 #include "ps_k_linearize.h"
 #include "ps_k_schur2.h"
+#include "ps_k_schur3.h"
 #include "ps_k_stream.h"
 #include "ps_k_pcg_classic.h"
 #include "ps_k_ldi.h"

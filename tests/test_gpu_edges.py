@@ -469,6 +469,7 @@ def test_streaming_schur_kernel_builds_the_same_reduced_system(monkeypatch):
     lp.obs_uvd = np.concatenate([lp.obs_uvd, lp.obs_uvd[dup] + 0.3])
     lp.obs_grp = np.concatenate([lp.obs_grp, lp.obs_grp[dup]])
     lp = lp.finalize()
+    monkeypatch.setenv('PS_SCHUR_MODE', '0')                  # (the gather / streaming kernels' lists; round 4's default is k_schur_pose)
     ref = device(lp)
     ref.linearize(0.)
     _, _, vals, g = ref.reduced_system()
@@ -668,6 +669,7 @@ def test_pipelined_schur_kernel_equals_the_one_chunk_kernel_bit_for_bit(monkeypa
     0): the same pairs in the same order through the same accumulators, so the reduced system is equal to the last bit --
     tasks of 1 to 40 chunks, ragged last chunks, tasks shorter than one chunk, duplicate observations of a pose (tasks
     that write a diagonal block), with and without landmark tiles; and both equal the oracle's Schur complement."""
+    monkeypatch.setenv('PS_SCHUR_MODE', '0')                  # (the gather kernels' pair lists; round 4's default is k_schur_pose)
     if tiling == 'tiled':
         monkeypatch.setenv('PS_SCHUR_TILE_KB', '256')
         monkeypatch.setenv('PS_SCHUR_TILE_MIN_MB', '0')
@@ -719,3 +721,92 @@ def test_option_values_out_of_range_are_refused():
         dev.set_option(name, ok)
     out = dev.gn_iteration(0., 1e-12, 500, True)
     assert np.isfinite(out[0]) and out[3] <= 1e-12
+
+
+@pytest.mark.parametrize('case', ['multi_segment', 'sparse', 'constants', 'duplicates'])
+def test_pose_stationary_schur_kernel_against_the_gather_kernels_and_the_oracle(monkeypatch, case):
+    """k_schur_pose (round 4, csrc/ps_k_schur3.h: a workgroup holds a segment of one pose's Z rows in LDS and gathers only the
+    partner rows; one partial per (segment, partner) task, summed in segment order) against the gather kernel on the same
+    handle (PS_SCHUR_MODE=2 builds both list sets; option "schur_mode") -- same reduced system to rounding (the sums group
+    differently), bit-reproducible run to run -- and against the oracle's Schur complement.  Poses with several segments
+    (more than 512 observations), tasks of one pair, constant landmarks and poses; a landmark seen twice from one pose
+    leaves the handle on the gather kernels (a diagonal-block task)."""
+    import scipy.sparse.linalg as spla
+    monkeypatch.setenv('PS_SCHUR_MODE', '2')
+    if case == 'multi_segment':
+        lp, _ = synthetic.stereo_ba(num_kf=14, num_lm=9000, obs_per_lm=6, half_window=5, seed=21)     # ~3 900 observations per pose
+    elif case == 'sparse':
+        lp, _ = synthetic.stereo_ba(num_kf=150, num_lm=1500, obs_per_lm=4, half_window=12, seed=15)
+    else:
+        lp, _ = synthetic.stereo_ba(num_kf=70, num_lm=6000, obs_per_lm=7, half_window=10, seed=13)
+    if case == 'constants':
+        lp.pose_rid = lp.pose_rid.copy()
+        keep = np.ones(lp.num_poses, dtype=bool); keep[[0, 7, 8, 33]] = False
+        lp.pose_rid[:] = -1
+        lp.pose_rid[keep] = np.arange(keep.sum())
+        lp.point_vid = lp.point_vid.copy()
+        fixed = np.arange(0, lp.num_points, 5)
+        vid = np.full(lp.num_points, -1, dtype=np.int32)
+        free = np.setdiff1d(np.arange(lp.num_points), fixed)
+        vid[free] = np.arange(free.size)
+        lp.point_vid = vid
+        lp = lp.finalize()
+    if case == 'duplicates':
+        dup = np.arange(0, lp.num_obs, 97)
+        lp.obs_pose = np.concatenate([lp.obs_pose, lp.obs_pose[dup]])
+        lp.obs_point = np.concatenate([lp.obs_point, lp.obs_point[dup]])
+        lp.obs_uvd = np.concatenate([lp.obs_uvd, lp.obs_uvd[dup] + 0.3])
+        lp.obs_grp = np.concatenate([lp.obs_grp, lp.obs_grp[dup]])
+        lp = lp.finalize()
+    dev = device(lp)
+    dev.linearize(0.)
+    _, _, v1, g1 = dev.reduced_system()
+    dev.linearize(0.)
+    assert np.array_equal(dev.reduced_system()[2], v1)             # reproducible
+    dev.set_option('schur_mode', 0)
+    dev.linearize(0.)
+    _, _, v0, g0 = dev.reduced_system()
+    assert np.array_equal(g0, g1)
+    if case == 'duplicates':
+        assert np.array_equal(v0, v1)                              # the pose-stationary lists were not built: the same kernel both times
+    else:
+        assert np.abs(v0 - v1).max() <= 1e-13 * np.abs(v0).max()
+    dev.set_option('schur_mode', 1)
+    dev.linearize(0.)
+    S, gd = dev.reduced_dense()
+    P, b, _ = orc.normal_equations(lp, points_first=False)
+    n = S.shape[0]
+    P = P.tocsr()
+    Hpp, Hpl, Hll = P[:n, :n], P[:n, n:], P[n:, n:]
+    want = (Hpp - Hpl @ spla.spsolve(Hll.tocsc(), Hpl.T.tocsc())).toarray()
+    assert rel_err(S, want) < 1e-12
+    out = dev.gn_iteration(0., 1e-12, 500, True)
+    assert np.isfinite(out[0]) and out[3] <= 1e-12
+    dev.close()
+
+
+def test_untiled_pair_list_built_pose_by_pose_equals_the_landmark_order_build(monkeypatch):
+    """ps_problem_create builds the untiled Schur pair list pose by pose on several host threads (round 4); the result must
+    be the list the two counting passes over the landmark-ordered pairs give: same reduced system to the last bit, duplicate
+    observations of a pose (diagonal-block tasks) and constant poses / landmarks included."""
+    monkeypatch.setenv('PS_SCHUR_TILE_KB', '0')               # untiled at this size
+    lp, _ = synthetic.stereo_ba(num_kf=70, num_lm=6000, obs_per_lm=7, half_window=10, seed=13)
+    dup = np.arange(0, lp.num_obs, 97)
+    lp.obs_pose = np.concatenate([lp.obs_pose, lp.obs_pose[dup]])
+    lp.obs_point = np.concatenate([lp.obs_point, lp.obs_point[dup]])
+    lp.obs_uvd = np.concatenate([lp.obs_uvd, lp.obs_uvd[dup] + 0.3])
+    lp.obs_grp = np.concatenate([lp.obs_grp, lp.obs_grp[dup]])
+    vid = np.full(lp.num_points, -1, dtype=np.int32)
+    free = np.setdiff1d(np.arange(lp.num_points), np.arange(0, lp.num_points, 7))
+    vid[free] = np.arange(free.size)
+    lp.point_vid = vid
+    lp = lp.finalize()
+    out = []
+    for by_landmark in (False, True):
+        if by_landmark:
+            monkeypatch.setenv('PS_PAIRS_BY_LANDMARK', '1')
+        dev = device(lp)
+        dev.linearize(0.)
+        out.append(dev.reduced_system())
+        dev.close()
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
