@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpyslam_hip.so')
+if os.environ.get('PYSLAM_AMD_MEASURE') == '1':       # tools/: the -DPS_MEASURE build (__graft_entry__.build_measure())
+    LIB_PATH = os.path.join(_HERE, 'lib', 'libpyslam_hip_measure.so')
 
 c_i32p = C.POINTER(C.c_int32)
 c_f64p = C.POINTER(C.c_double)

@@ -50,7 +50,7 @@ int ps_warm_up(void) {
 
 int ps_problem_destroy(ps_problem* h) {
     if (!h) return 0;
-    if (getenv("PS_HOST_TIMING") && h->host_calls)
+    if (ps_env("PS_HOST_TIMING") && h->host_calls)
         fprintf(stderr, "ps_gn_iteration: %ld calls, %.1f us per call on the host, of which %.1f us waiting for the GPU (%ld waits)\n",
                 h->host_calls, h->host_call_ns * 1e-3 / h->host_calls, h->host_wait_ns * 1e-3 / h->host_calls, h->host_waits);
     hipStreamSynchronize(h->stream);
@@ -99,7 +99,7 @@ struct DescStage {
 };
 
 int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** out) {
-    const bool timing = getenv("PS_CREATE_TIMING") != nullptr;
+    const bool timing = ps_env("PS_CREATE_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing) return;
@@ -276,7 +276,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // (measured with the LDS-transposed reduction of k_pose_pass: 256 / 512 / 1024 observations per workgroup give
     //  28.3 / 25.9 / 28.6 us at C3 and 0.218 / 0.192 / 0.202 ms at C4)
     int pchunk = Np >= 512L * 256 ? 512 : 256;
-    if (const char* e = getenv("PS_POSE_CHUNK")) pchunk = std::max(256, atoi(e) / 256 * 256);
+    if (const char* e = ps_env("PS_POSE_CHUNK")) pchunk = std::max(256, atoi(e) / 256 * 256);
     for (int r = 0; r < nr; ++r) {
         for (int s = pcount[r]; s < pcount[r + 1]; s += pchunk)
             pitems.push_back({r, s, std::min(s + pchunk, pcount[r + 1]), pose_of_rid[r]});
@@ -350,7 +350,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // covered by nothing; with products, fetches, fill and stores all removed the skeleton still takes 0.06 ms.  Kept as an
     // independent variant (parity-tested against the gather kernels and the oracle); built with PS_SCHUR_MODE=1 (this
     // kernel only) or 2 (both list sets: option "schur_mode" switches).
-    const int schur_mode_env = getenv("PS_SCHUR_MODE") ? atoi(getenv("PS_SCHUR_MODE")) : 0;
+    const int schur_mode_env = ps_create_env("PS_SCHUR_MODE") ? atoi(ps_create_env("PS_SCHUR_MODE")) : 0;
     bool pose_mode = schur_mode_env != 0 && D == 6 && nv > 0 && nr > 0 && Nl > 0 && Nl < (1L << 23);
     if (pose_mode) {
         std::vector<int32_t> rid_row((size_t)Nl), lm_row((size_t)Nl);
@@ -450,12 +450,12 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // and the per-task prologue/epilogue costs more than the extra L2 hits save).
     std::vector<PairRec> prs;
     int ntiles = 1;
-    bool tiles_forced = getenv("PS_SCHUR_TILE_KB") != nullptr;
+    bool tiles_forced = ps_create_env("PS_SCHUR_TILE_KB") != nullptr;
     const double zbytes = 8.0 * PS_ZROW * (double)lm_ptr[nv];
     {
         double tile_kb = 9216.0, min_mb = 16.0;
-        if (const char* e = getenv("PS_SCHUR_TILE_KB")) tile_kb = atof(e);
-        if (const char* e = getenv("PS_SCHUR_TILE_MIN_MB")) min_mb = atof(e);
+        if (const char* e = ps_create_env("PS_SCHUR_TILE_KB")) tile_kb = atof(e);
+        if (const char* e = ps_create_env("PS_SCHUR_TILE_MIN_MB")) min_mb = atof(e);
         if (tile_kb > 0 && zbytes > min_mb * 1048576.0)
             ntiles = 8 * (int)std::ceil(zbytes / (8.0 * tile_kb * 1024.0));
     }
@@ -539,8 +539,8 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
         };
         // When all of Z stays in the Infinity Cache the untiled list is the likely winner (the rule below): build IT first and
         // keep it if the blocks alone fill the chip -- no tiled list is generated only to be thrown away (C3: 23 -> 7 ms)
-        const bool by_pose = nr > 0 && !getenv("PS_PAIRS_BY_LANDMARK");
-        if (by_pose && attempt == 0 && ntiles > 1 && !tiles_forced && zbytes <= 128.0 * 1048576.0 && !getenv("PS_SCHUR_KEEP_TILES")) {
+        const bool by_pose = nr > 0 && !ps_create_env("PS_PAIRS_BY_LANDMARK");
+        if (by_pose && attempt == 0 && ntiles > 1 && !tiles_forced && zbytes <= 128.0 * 1048576.0 && !ps_env("PS_SCHUR_KEEP_TILES")) {
             build_untiled_by_pose();
             size_t nblocks0 = 0;
             for (size_t k = 0; k < prs.size(); ++k) nblocks0 += (k == 0 || prs[k].key != prs[k - 1].key);
@@ -591,7 +591,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
         // When the blocks alone fill the chip twice over (2 x 256 CUs x 12 waves of the pipelined pair kernel) and all of Z
         // stays in the 256 MiB Infinity Cache, the untiled list wins (C3: stage 56 -> 48 us); at C4 (Z = 640 MB) the tiles'
         // locality is worth 0.53 against 0.77 ms.
-        const bool blocks_fill_chip = nblocks >= 2 * 256 * 12 && zbytes <= 128.0 * 1048576.0 && !getenv("PS_SCHUR_KEEP_TILES");
+        const bool blocks_fill_chip = nblocks >= 2 * 256 * 12 && zbytes <= 128.0 * 1048576.0 && !ps_env("PS_SCHUR_KEEP_TILES");
         if (prs.size() >= 64 * ntask && !blocks_fill_chip) break;
         ntiles = 1;
     }
@@ -682,7 +682,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
             lists[x].push_back((int32_t)k);
         }
         // longest tasks first (within each tile): the short ones fill the tail of the XCD's schedule
-        if (!getenv("PS_SCHUR_NO_LPT"))
+        if (!ps_env("PS_SCHUR_NO_LPT"))
             for (auto& l : lists)
                 std::stable_sort(l.begin(), l.end(), [&](int32_t x, int32_t y) {
                     if (task_tile[x] != task_tile[y]) return task_tile[x] < task_tile[y];
@@ -789,7 +789,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
         // OFF unless PS_SCHUR_STREAM=1: measured slower than the gather kernel on MI355X (C3 0.112-0.137 ms against 0.060,
         // C4 0.79 against 0.57 ms): 57 MB of partial blocks written and read back plus 28 MB of padded entry words
         // outweigh the 9x fewer L2 requests, which L2 / Infinity Cache absorb well enough.
-        const char* env = getenv("PS_SCHUR_STREAM");
+        const char* env = ps_create_env("PS_SCHUR_STREAM");
         h->stream_mode = env ? atoi(env) : 0;                   // 0 off (default), 1 on whenever it can be built
         if (h->stream_mode != 0 && total_pairs > 0 && D == 6) {
             std::vector<StreamTile> tiles;
@@ -815,7 +815,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
             // enough workgroups: a multiple of its 256 CUs, about 5 M pairs per round of 256 tiles (C3: 256 tiles of 196
             // landmarks, C4: 1 024 of 489).  Fewer, larger tiles would write fewer partial blocks but leave CUs idle.
             long ttarget = 256L * std::max<long>(1, std::lround((double)total_pairs / 5.0e6));
-            if (const char* e2 = getenv("PS_ST_TILES")) ttarget = std::max(1L, atol(e2));
+            if (const char* e2 = ps_create_env("PS_ST_TILES")) ttarget = std::max(1L, atol(e2));
             const int tile_lm_cap = std::max(32, cdiv(nv, ttarget));
             int v = 0;
             while (v < nv && ok) {
@@ -1035,7 +1035,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // of a few milliseconds at C2 / C4) used to be built by the first solve, i.e. inside the first Gauss-Newton iteration
     // (C2: 9-10 ms against 3 ms for the later ones).  They depend on nothing but the block pattern: built here.  An option
     // that changes them (coarse_groups, cg_explicit, ...) rebuilds them on the next solve as before.
-    if (nr >= 16 && nr * D > h->direct_max && h->pcg_variant == 1 && !getenv("PS_LAZY_COARSE")) {
+    if (nr >= 16 && nr * D > h->direct_max && h->pcg_variant == 1 && !ps_env("PS_LAZY_COARSE")) {
         if (build_coarse(h)) return -1;
         HIP_OK(hipStreamSynchronize(h->stream));
         lap("two-level structures");

@@ -640,8 +640,15 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
         if (value < -1 || value >= PS_XCG_MAXNODES) return fail("coarse_groups out of range (-1 auto, 0 off, else number of hat intervals; above 63 only for the explicit two-level PCG, at most 1023)");
         h->coarse_req = (int)value; h->coarse_built = false;
     }
+#ifdef PS_MEASURE
     else if (n == "cg_ablate") h->cg_ablate = (int)value;
     else if (n == "schur_ablate") h->schur_ablate = (int)value;
+    else if (n == "lm_ablate") h->lm_ablate = (int)value;
+#else
+    else if (n == "cg_ablate" || n == "schur_ablate" || n == "lm_ablate") {
+        if (value != 0.0) return fail(n + ": timing experiments exist in the measurement build only (__graft_entry__.build_measure(), PYSLAM_AMD_MEASURE=1)");
+    }
+#endif
     else if (n == "schur_pipeline") h->schur_pipeline = value != 0.0;
     else if (n == "schur_mode") {
         if (value != 0.0 && value != 1.0) return fail("schur_mode must be 0 (gather kernels) or 1 (pose-stationary kernel)");
@@ -649,7 +656,6 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
         h->schur_mode = (int)value;
     }
     else if (n == "schur_stream") { if (value != 0.0 && !h->st_tiles) return fail("schur_stream: the streaming lists were not built for this problem"); h->use_stream = value != 0.0; }
-    else if (n == "lm_ablate") h->lm_ablate = (int)value;
     else if (n == "coarse_lag") h->coarse_lag = value != 0.0;
     else if (n == "cg_force_restart") h->cg_force_restart = value != 0.0;
     else if (n == "xcg_restrict_fused") h->xcg_rt = value != 0;

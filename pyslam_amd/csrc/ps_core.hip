@@ -29,6 +29,18 @@
 
 namespace {
 
+// Environment switches.  ps_create_env: variants chosen when a handle is CREATED (which Schur lists are built, tile sizes: the
+// parity tests hold the variants against each other) -- read once per ps_problem_create, never inside an iteration.
+// ps_env: measurement and debugging switches (timing printouts, ablations, allocation guards, launch-shape experiments);
+// compiled out of the product library -- they exist only in the -DPS_MEASURE build (__graft_entry__.build_measure(),
+// lib/libpyslam_hip_measure.so, loaded when PYSLAM_AMD_MEASURE=1), which tools/ use.
+inline const char* ps_create_env(const char* name) { return getenv(name); }
+#ifdef PS_MEASURE
+inline const char* ps_env(const char* name) { return getenv(name); }
+#else
+inline const char* ps_env(const char*) { return nullptr; }
+#endif
+
 thread_local std::string g_err;
 
 int fail(const std::string& msg) { g_err = msg; return -1; }
@@ -72,7 +84,7 @@ struct PsPool {
 // Events that order the solver stream against the side stream (and back).  PS_EVENT_FLAGS=<int> overrides the creation flags
 // (debugging); see DESIGN.md section 3 "cross-stream visibility".
 inline unsigned ps_xstream_event_flags() {
-    static const unsigned f = getenv("PS_EVENT_FLAGS") ? (unsigned)strtoul(getenv("PS_EVENT_FLAGS"), nullptr, 0)
+    static const unsigned f = ps_env("PS_EVENT_FLAGS") ? (unsigned)strtoul(ps_env("PS_EVENT_FLAGS"), nullptr, 0)
                                                        : (unsigned)(hipEventDisableTiming | hipEventReleaseToSystem);
     return f;
 }
@@ -247,7 +259,7 @@ struct ps_problem {
     int mo_fused = 1;               // motion-only problems: one launch per iteration (k_motion_only_iteration)
     double* mo_partials = nullptr;
     bool status_clean = true;       // no failure flag can be pending in the device status words
-    int direct_fused = getenv("PS_DIRECT_3LAUNCH") ? 0 : 1;   // option "direct_fused": the direct solve in one launch (k_direct_solve)
+    int direct_fused = ps_env("PS_DIRECT_3LAUNCH") ? 0 : 1;   // option "direct_fused": the direct solve in one launch (k_direct_solve)
     int direct_max = 90;            // reduced systems up to this many unknowns are solved directly (0: never)
     double *dA = nullptr, *dLi = nullptr, *dLiT = nullptr;
     int big_chol = 1;               // nc > 90: multi-workgroup blocked factorisation (0: one workgroup out of L2)
@@ -357,7 +369,7 @@ struct ps_problem {
     // calls between a seed's start and its first use (fixed schedule).  1: the call after the seed waits for it where the solve
     // begins (~0.1 ms of the seed's GEMMs are then still ahead at C3, hidden behind this call's linearisation for most of it) and
     // takes 6 iterations instead of 18-25 -- eight-call solves 3-7 % shorter at every size from 138 to 2 034 unknowns than with 2
-    int ldi_seed_lag = getenv("PS_LDI_SEED_LAG") ? atoi(getenv("PS_LDI_SEED_LAG")) : 1;
+    int ldi_seed_lag = ps_env("PS_LDI_SEED_LAG") ? atoi(ps_env("PS_LDI_SEED_LAG")) : 1;
     int ldi_rejects = 0; long ldi_no_seed_before = 0;
     // direct seed (ps_host_ldi.h: ldi_direct_enqueue): on for pose graphs from the start, for any problem after a rejected
     // Newton-Schulz seed; option "ldi_direct" (-1 auto, 0 never, 1 always)
@@ -417,7 +429,7 @@ struct ps_problem {
             }
         }
         void* p = nullptr;
-        static const bool guard_on = getenv("PS_ALLOC_GUARD") != nullptr;
+        static const bool guard_on = ps_env("PS_ALLOC_GUARD") != nullptr;
         const size_t padded = (bytes + 255) & ~(size_t)255;
         if (slab_left >= padded) {                                // inside a slab_reserve()d block: no call into the runtime
             *out = (T*)slab; slab += padded; slab_left -= padded; dev_bytes += bytes;
@@ -432,7 +444,7 @@ struct ps_problem {
         }
         // PS_ARENA_POISON=1 (debugging): big tables start as NaN too -- recycled device memory is not zero, and a kernel that
         // reads a word nothing wrote (padding of a tile, a slot past the end) then shows instead of depending on history
-        static const bool poison_all = getenv("PS_ARENA_POISON") != nullptr;
+        static const bool poison_all = ps_env("PS_ARENA_POISON") != nullptr;
         if (poison_all && hipMemset(p, 0xFF, bytes) != hipSuccess) return fail("hipMemset (poison) failed");
         allocs.push_back(p);
         dev_bytes += bytes;
@@ -444,11 +456,11 @@ struct ps_problem {
     // follow are carved from it in 256-byte steps; what does not fit falls through to hipMalloc.
     char* slab = nullptr; size_t slab_left = 0;
     int slab_reserve(size_t bytes) {
-        if (getenv("PS_ALLOC_GUARD")) return 0;                   // guard mode wants every table on its own
+        if (ps_env("PS_ALLOC_GUARD")) return 0;                   // guard mode wants every table on its own
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
-        if (getenv("PS_ARENA_POISON") && hipMemset(p, 0xFF, bytes) != hipSuccess) return fail("hipMemset (poison) failed");
+        if (ps_env("PS_ARENA_POISON") && hipMemset(p, 0xFF, bytes) != hipSuccess) return fail("hipMemset (poison) failed");
         allocs.push_back(p);
         slab = (char*)p; slab_left = bytes;
         return 0;
@@ -487,7 +499,7 @@ struct ps_problem {
         if (!pool.take(pool.host_arenas, &m)) HIP_OK(hipHostMalloc(&m, PS_ARENA_BYTES, hipHostMallocDefault));
         arena_host = (char*)m;
         // PS_ARENA_POISON=1 (debugging): the gaps between tables read as NaN, so a kernel that reads past the end of one shows
-        static const bool poison = getenv("PS_ARENA_POISON") != nullptr;
+        static const bool poison = ps_env("PS_ARENA_POISON") != nullptr;
         if (poison) std::memset(arena_host, 0xFF, PS_ARENA_BYTES);
         arena_poisoned = poison;
         arena_used = 0;

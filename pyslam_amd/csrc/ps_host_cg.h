@@ -80,7 +80,7 @@ int wait_published(ps_problem* h) {
         ps_problem* h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         ~WaitClock() { h->host_wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count(); ++h->host_waits; }
     } wc{h};
-    static const int kick_mode = getenv("PS_SIDE_KICK") ? atoi(getenv("PS_SIDE_KICK")) : 2;   // 0 next linearize, 1 after the wait, 2 during the wait
+    static const int kick_mode = ps_env("PS_SIDE_KICK") ? atoi(ps_env("PS_SIDE_KICK")) : 2;   // 0 next linearize, 1 after the wait, 2 during the wait
     volatile long long* ws = h->h_setup;
     for (long spins = 0; spins < 400000000L; ++spins) {
         // the set-up kernels of this iteration have finished (stamp of k_coarse_mreduce): the side stream's inputs are
@@ -200,7 +200,7 @@ int ensure_cg_buffers(ps_problem* h, int rows, int blocks) {
 // Coarse nodes (hat functions over the reduced-pose index) + the augmented BSR pattern
 // [[S^, K], [K^T, I]].  coarse_req = number of intervals G (ncb = G + 1 nodes).
 int build_coarse(ps_problem* h) {
-    const bool timing = getenv("PS_CREATE_TIMING") != nullptr;
+    const bool timing = ps_env("PS_CREATE_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing) return;
@@ -411,7 +411,7 @@ int build_coarse(ps_problem* h) {
     if (h->cg_explicit && ncb <= PS_XCG_MAXNODES) {
         // three-launch form: records of P^T q per (SpMV workgroup, node it touches), a node's records contiguous and in
         // workgroup order (the order k_xcg_coarse_rt sums them in)
-        if (const char* e = getenv("PS_XCG_ROWS_RT")) h->xcg_rt_rows = atoi(e);
+        if (const char* e = ps_env("PS_XCG_ROWS_RT")) h->xcg_rt_rows = atoi(e);
         const int R = h->xcg_rt_rows, nwg = cdiv(nr, R);
         std::vector<int32_t> wgo((size_t)nwg * PS_XCG_NSLOT, -1), nptr(ncb + 1, 0);
         bool ok = true;
@@ -506,12 +506,12 @@ int build_coarse(ps_problem* h) {
         // PS_SIDE_LOWPRIO=1 brings the old stream back (to reproduce).
         // PS_SIDE_CUS=n (measurement switch): confine the side stream to n compute units (CU mask, low bits: spread evenly
         // over the XCDs) instead of running it at low priority over the whole chip
-        const int side_cus = getenv("PS_SIDE_CUS") ? atoi(getenv("PS_SIDE_CUS")) : h->side_cus;
+        const int side_cus = ps_env("PS_SIDE_CUS") ? atoi(ps_env("PS_SIDE_CUS")) : h->side_cus;
         if (side_cus > 0) {
             uint32_t mask[8] = {};
             for (int b = 0; b < std::min(side_cus, 256); ++b) mask[b >> 5] |= 1u << (b & 31);
             HIP_OK(hipExtStreamCreateWithCUMask(&h->side, 8, mask));
-        } else if (getenv("PS_SIDE_LOWPRIO")) {
+        } else if (ps_env("PS_SIDE_LOWPRIO")) {
             int prio_lo = 0, prio_hi = 0;
             HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
             HIP_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo));
@@ -645,10 +645,11 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
             if (ensure_dynamic_lds((const void*)k_rows_setup<D>, (size_t)(h->rows_lds))) return -1;
             h->rows_attr_set = true;
         }
+        static const int rs_ablate = ps_env("PS_RS_ABLATE") ? atoi(ps_env("PS_RS_ABLATE")) : 0;    // (measurement build only)
         hipLaunchKernelGGL(k_rows_setup<D>, dim3(nr), dim3(PS_RS_THREADS), h->rows_lds, h->stream, nr, ncb, h->row_ptr, h->col_idx,
                            h->aug_slot, h->S, h->Linv, h->Bmat2[use], h->Bmat2[nb], h->arow_ptr, h->fine_nnz,
                            h->run_lo, h->run_hi, h->pnode, h->pw0, h->pw1, h->LciT2[use], h->X2[use], h->cg_r[0],
-                           h->Saug, h->SB, h->Mpart, h->rows_lci_lds ? 1 : 0, getenv("PS_RS_ABLATE") ? atoi(getenv("PS_RS_ABLATE")) : 0);
+                           h->Saug, h->SB, h->Mpart, h->rows_lci_lds ? 1 : 0, rs_ablate);
         hipLaunchKernelGGL(k_coarse_mreduce<D>, dim3(cdiv((long)nc * (nc + 1) * 8, 256)), dim3(256), 0, h->stream, nr, ncb,
                            h->shi, h->Mpart, h->pnode, h->arow_ptr, h->Saug, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p,
                            h->cg_xh, h->lag_status, h->status, h->h_setup_dev, ++h->setup_seq);
@@ -908,6 +909,7 @@ int linearize(ps_problem* h, double lambda) {
 #undef PS_LM_LAUNCH
     }
     bool fin_in_combine = false, fin_in_pairs = false;
+    static const bool schur_split_env = ps_env("PS_SCHUR_SPLIT") != nullptr;      // (measurement build only; read once)
     if (h->npitems > 0) {
         StageTimer t(h, PS_ST_POSE);
         const ObsWide wp{h->sidx_p, h->stiff_tab};
@@ -923,7 +925,7 @@ int linearize(ps_problem* h, double lambda) {
                                     : ((h->Spart || h->use_stream) && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6);
         // untiled Schur with the pipelined pair kernel: its trailing workgroups finalize the poses
         fin_in_pairs = !pose_schur && !h->Spart && !h->use_stream && h->schur_pipeline && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6 &&
-                       !getenv("PS_SCHUR_SPLIT");
+                       !schur_split_env;
         if (!fin_in_combine && !fin_in_pairs)
             hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
                                h->ppartial, h->diag_slot, lambda, h->S, h->g);
@@ -953,18 +955,22 @@ int linearize(ps_problem* h, double lambda) {
         StageTimer t(h, PS_ST_SCHUR, 1);
         // PS_SCHUR_SPLIT=1 (measurement switch): the same work as two launches over the two halves of
         // every XCD's list -- what splitting the Schur build into two bands for an overlapped all-reduce would cost
-        static const bool split2 = getenv("PS_SCHUR_SPLIT") != nullptr;
+        const bool split2 = schur_split_env;
         const int halfp = split2 ? (h->pair_per_xcd / 2 + 3) / 4 * 4 : h->pair_per_xcd;
         // PS_SCHUR_LDS_PAD=<bytes> (measurement switch): unused dynamic LDS per workgroup, i.e. fewer resident waves per CU
-        static const int lds_pad = getenv("PS_SCHUR_LDS_PAD") ? atoi(getenv("PS_SCHUR_LDS_PAD")) : 0;
+        static const int lds_pad = ps_env("PS_SCHUR_LDS_PAD") ? atoi(ps_env("PS_SCHUR_LDS_PAD")) : 0;
         auto launch_pairs = [&](int nblk, int lds, int from, int to) {
             if (!h->schur_pipeline)
                 hipLaunchKernelGGL(k_schur_pairs, dim3(nblk), dim3(256), lds, h->stream, h->pair_per_xcd, h->pair_xitems, h->pairs,
                                    h->Z, h->S, h->Spart, h->schur_ablate, from, to);
             else {
+#ifdef PS_MEASURE
                 auto k = h->schur_ablate == 0 ? k_schur_pairs_db<0> : h->schur_ablate == 1 ? k_schur_pairs_db<1> :
                          h->schur_ablate == 2 ? k_schur_pairs_db<2> : h->schur_ablate == 3 ? k_schur_pairs_db<3> :
                          h->schur_ablate == 4 ? k_schur_pairs_db<4> : k_schur_pairs_db<5>;
+#else
+                auto k = k_schur_pairs_db<0>;                   // (the ablation instantiations exist in the measurement build only)
+#endif
                 hipLaunchKernelGGL(k, dim3(nblk + (fin_in_pairs ? cdiv(h->nr, 4) : 0)), dim3(256), lds, h->stream, h->pair_per_xcd,
                                    h->pair_xitems, h->pairs, h->Z, h->S, h->Spart, from, to, nblk, fin_in_pairs ? h->nr : 0,
                                    h->pitem_ptr, h->ppartial, h->diag_slot, lambda, h->g);

@@ -5,7 +5,7 @@ namespace {
 
 // ---- explicit two-level PCG (long sparse chains; kernels k_xcg_*) ---------------------------------
 // (measurement switch: PS_XCG_AC_MAIN=1 keeps the assembly of A_c on the solver stream, as it was before it moved)
-inline bool xcg_ac_on_main() { static const bool v = getenv("PS_XCG_AC_MAIN") != nullptr; return v; }
+inline bool xcg_ac_on_main() { static const bool v = ps_env("PS_XCG_AC_MAIN") != nullptr; return v; }
 
 // A_c = P^T S^ P from the non-empty (row, node) runs
 template <int D>
@@ -29,7 +29,7 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     hipLaunchKernelGGL(k_block_jacobi_factor<D>, dim3(cdiv(nr, 4)), dim3(256), 0, h->stream, nr, h->diag_slot,
                        h->S, h->Linv, h->status, h->g, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, h->cg_xh,
                        h->poses, h->pose_of_rid, h->coarse_basis, h->Bmat, h->bgv);
-    static const bool scale_pipe = !getenv("PS_SCALE_NO_PIPE");
+    static const bool scale_pipe = !ps_env("PS_SCALE_NO_PIPE");
     if (scale_pipe)
         hipLaunchKernelGGL(k_scale_blocks_p<D>, dim3(cdiv(h->nnzb, 4 * PS_SCB_NB)), dim3(256), 0, h->stream, h->nnzb, h->col_idx,
                            h->brow_of, h->Linv, h->S, h->aug_slot, h->Saug, h->Bmat, h->SB);
@@ -181,7 +181,7 @@ void xcg_launch(ps_problem* h, double tol, int count) {
             if (h->xf_two) {
                 hipLaunchKernelGGL(k_xcg_f2_coarse<D>, dim3(cdiv(nc, PS_XCG_CROWS_BIG)), dim3(64 * PS_XCG_CROWS_BIG), (size_t)nc * sizeof(double),
                                    h->stream, a, k, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate);
-                static const int pf_env = getenv("PS_XF2_PF") ? atoi(getenv("PS_XF2_PF")) : -1;
+                static const int pf_env = ps_env("PS_XF2_PF") ? atoi(ps_env("PS_XF2_PF")) : -1;
                 // more workgroups than the chip holds at once: the kernel's time is (rounds of workgroups) x (its dependent
                 // phases), so registers go to occupancy, not to prefetch (C2, 1 250 workgroups: 24.4 us with PF = 6)
                 const int pf = pf_env >= 0 ? pf_env : (h->xf_nwg > 512 ? 0 : h->xf_pf);
@@ -271,7 +271,7 @@ int direct_solve_enqueue(ps_problem* h) {
         if (ensure_dynamic_lds((const void*)k_direct_solve<D>, lds)) return -1;
         // (1 024 threads: the trailing update has (nr - J - 1)^2 D^2 / 2 entries per step; measured 256 / 512 / 1 024 threads:
         //  17.8 / 16.7 / 16.6 us at 30 unknowns, 70 / 58 / 50 us at 90)
-        static const int nt_env = getenv("PS_DIRECT_THREADS") ? atoi(getenv("PS_DIRECT_THREADS")) : 0;
+        static const int nt_env = ps_env("PS_DIRECT_THREADS") ? atoi(ps_env("PS_DIRECT_THREADS")) : 0;
         const int nthreads = nt_env > 0 ? nt_env : 1024;
         hipLaunchKernelGGL(k_direct_solve<D>, dim3(1), dim3(nthreads), lds, h->stream, nr, h->nnzb, h->brow_of, h->col_idx, h->S, h->g, h->x,
                            h->status, h->scalars);

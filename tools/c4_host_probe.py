@@ -1,4 +1,11 @@
 """C4 on one GPU: where the wall time of a step goes (restore, enqueue, wait) -- run with PS_HOST_TIMING=1."""
+# (measurement build: the PS_* switches / ablation options used here exist only in lib/libpyslam_hip_measure.so)
+import os as _os, sys as _sys
+_os.environ.setdefault('PYSLAM_AMD_MEASURE', '1')
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+import __graft_entry__ as _ge
+if not _os.path.exists(_ge.OUT_MEASURE) or _os.path.getmtime(_ge.OUT_MEASURE) < _os.path.getmtime(_ge.SRC):
+    _ge.build_measure()
 import os, sys, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import torch

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (PS_* measurement switches exist only in the measurement build: python -c "import __graft_entry__ as g; g.build_measure()" first)
+export PYSLAM_AMD_MEASURE=1
 # Run ON THE GPU BOX: the non-bench configurations of SURVEY 8d (C4, C2, C5 / small problems) and the RANSAC step.
 # Output: gpurun_out/<tag>/other_configs.txt  (copied to profiles/<round>_other_configs.txt)
 TAG=${1:-r01}

@@ -1,4 +1,6 @@
 # pose pass at C3 / C4: chunk size (PS_POSE_CHUNK) x reduction form (rebuild with -DPS_POSE_TRANSPOSE=0/1)
+# (PS_* measurement switches exist only in the measurement build: python -c "import __graft_entry__ as g; g.build_measure()" first)
+export PYSLAM_AMD_MEASURE=1
 for tr in 1 0; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-value -Wno-unused-result -DPS_POSE_TRANSPOSE=$tr \
      -Iinclude pyslam_amd/csrc/ps_core.hip -o pyslam_amd/lib/libpyslam_hip.so 2>/dev/null

@@ -1,5 +1,12 @@
 """Ablation timing of k_schur_pairs at C3 (bits: 1 = no LDS reads / FMAs, 2 = no Z fetch, 4 = all
 rows from the first 64 Z rows).  Results are wrong under ablation; timing only."""
+# (measurement build: the PS_* switches / ablation options used here exist only in lib/libpyslam_hip_measure.so)
+import os as _os, sys as _sys
+_os.environ.setdefault('PYSLAM_AMD_MEASURE', '1')
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+import __graft_entry__ as _ge
+if not _os.path.exists(_ge.OUT_MEASURE) or _os.path.getmtime(_ge.OUT_MEASURE) < _os.path.getmtime(_ge.SRC):
+    _ge.build_measure()
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

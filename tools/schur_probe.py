@@ -2,9 +2,15 @@
     PS_SCHUR_MODE=2 python tools/schur_probe.py [kf lm]"""
 import os, sys, time
 os.environ.setdefault('PS_SCHUR_MODE', '2')
+if os.environ.get('ABLATE'):
+    os.environ.setdefault('PYSLAM_AMD_MEASURE', '1')      # the ablation options exist in the measurement build only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
+if os.environ.get('PYSLAM_AMD_MEASURE') == '1':
+    import __graft_entry__ as _ge
+    if not os.path.exists(_ge.OUT_MEASURE) or os.path.getmtime(_ge.OUT_MEASURE) < os.path.getmtime(_ge.SRC):
+        _ge.build_measure()
 from pyslam_amd import synthetic
 from pyslam_amd.device import DeviceProblem
 kf, lm = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) >= 3 else (200, 50000)

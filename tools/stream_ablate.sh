@@ -1,3 +1,5 @@
+# (PS_* measurement switches exist only in the measurement build: python -c "import __graft_entry__ as g; g.build_measure()" first)
+export PYSLAM_AMD_MEASURE=1
 PS_SCHUR_STREAM=1 python - <<'PY' 2>&1 | grep -v amdgpu.ids
 import sys, time
 sys.path.insert(0, '.')
