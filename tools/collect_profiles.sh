@@ -15,14 +15,14 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python -c "import bench; print(bench.kernel_source_sha())" > "$OUT/source_sha.txt"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-python bench.py --force-sharded --no-cpu-baseline --no-c4 2> /dev/null | grep '^{' > "$OUT/bench_sharded_1rank.json"
-python bench.py --force-sharded --no-cpu-baseline --no-c4 --kf 2000 --lm 500000 --steps 10 2> /dev/null | grep '^{' > "$OUT/bench_sharded_1rank_c4.json"
-BENCH="python $PWD/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-c4"
+python bench.py --force-sharded --no-cpu-baseline --no-c4 --no-wall 2> /dev/null | grep '^{' > "$OUT/bench_sharded_1rank.json"
+python bench.py --force-sharded --no-cpu-baseline --no-c4 --no-wall --kf 2000 --lm 500000 --steps 10 2> /dev/null | grep '^{' > "$OUT/bench_sharded_1rank_c4.json"
+BENCH="python $PWD/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-c4 --no-wall"
 (cd /tmp && rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- $BENCH > "$OUT/bench_under_rocprof.json" 2> /dev/null)
 find /tmp/kt -name '*kernel_stats.csv' -exec cp {} "$OUT/ktrace_kernel_stats.csv" \;
-(cd /tmp && rm -rf /tmp/kt4 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt4 -o kt -- $BENCH --kf 2000 --lm 500000 --steps 10 > "$OUT/bench_c4_under_rocprof.json" 2> /dev/null)
+(cd /tmp && rm -rf /tmp/kt4 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt4 -o kt -- $BENCH --kf 2000 --lm 500000 --steps 8 > "$OUT/bench_c4_under_rocprof.json" 2> /dev/null)
 find /tmp/kt4 -name '*kernel_stats.csv' -exec cp {} "$OUT/c4_kernel_stats.csv" \;
-PMCB="python $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-c4"
+PMCB="python $PWD/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-c4 --no-wall"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
     i=$((i + 1))
@@ -30,7 +30,7 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_RE
     find /tmp/pmc$i -name '*counter_collection.csv' -exec cp {} "$OUT/pmc_$(echo $SET | tr ' ' '_').csv" \;
 done
 # the same counters at the north star's size (C4: Z = 640 MB no longer fits the 256 MiB Infinity Cache, so FETCH_SIZE is HBM traffic there)
-PMC4="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-c4 --kf 2000 --lm 500000"
+PMC4="python $PWD/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-c4 --no-wall --kf 2000 --lm 500000"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
     i=$((i + 1))
