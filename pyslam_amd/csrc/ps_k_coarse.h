@@ -166,9 +166,16 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
 #pragma unroll
                 for (int b2 = 0; b2 < D; ++b2) { L[a][b2] = 0.0; Mi[a][b2] = 0.0; }
             double il[D];                       // 1 / L[j][j]: one division per pivot, the rest are multiplies
+            // (the block comes into registers in ONE round of independent reads: read where it is used, every element waited out
+            //  its own LDS -- or, for big coarse levels, L2 -- latency inside the serial factorisation: ~1.5 us per block step)
+            double Ab[D][D];
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 <= a; ++b2) Ab[a][b2] = sL[(J * D + a) * nc + J * D + b2];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                double d = sL[(J * D + j) * nc + J * D + j];
+                double d = Ab[j][j];
 #pragma unroll
                 for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
                 ok = ok && (d > 0.0);
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
                 il[j] = 1.0 / l;
 #pragma unroll
                 for (int i = j + 1; i < D; ++i) {
-                    double v = sL[(J * D + i) * nc + J * D + j];
+                    double v = Ab[i][j];
 #pragma unroll
                     for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
                     L[i][j] = v * il[j];
