@@ -153,15 +153,26 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // Z rows a pose (and a reduced-system block row) touches come from a compact address range and
     // stay in the 4 MB per-XCD L2, whatever order the caller numbered the landmarks in.
     std::vector<int32_t> first_pose(L, INT32_MAX);
-    for (long i = 0; i < N; ++i) {
-        const int pt = d->obs_point[i];
-        if (pt >= 0 && pt < L) first_pose[pt] = std::min(first_pose[pt], d->obs_pose[i]);
+    {
+        const int T = ps_host_threads(N, 8);
+        std::vector<std::vector<int32_t>> fp(T > 1 ? T : 0);
+        ps_parallel(T, [&](int t, int TT) {
+            std::vector<int32_t>& mine = TT > 1 ? fp[t] : first_pose;
+            if (TT > 1) mine.assign(L, INT32_MAX);
+            for (long i = N * t / TT, e = N * (t + 1) / TT; i < e; ++i) {
+                const int pt = d->obs_point[i];
+                if (pt >= 0 && pt < L) mine[pt] = std::min(mine[pt], d->obs_pose[i]);
+            }
+        });
+        for (auto& v2 : fp) for (int i = 0; i < L; ++i) first_pose[i] = std::min(first_pose[i], v2[i]);
     }
     std::vector<int32_t>& vid_of_slot = h->h_vid_of_slot;
     vid_of_slot.resize(nv);
-    for (int v = 0; v < nv; ++v) vid_of_slot[v] = v;
-    std::stable_sort(vid_of_slot.begin(), vid_of_slot.end(), [&](int32_t a, int32_t b) {
-        return first_pose[point_of_vid[a]] < first_pose[point_of_vid[b]]; });
+    {   // vids in ascending first pose, ties in vid order (what the stable sort over 500 000 landmarks gave: 40 ms at C4)
+        std::vector<int32_t> fkey(nv), cnts;
+        for (int v = 0; v < nv; ++v) { const int32_t f = first_pose[point_of_vid[v]]; fkey[v] = (f < 0 || f >= P) ? P : f; }
+        parallel_index_sort(nv, (size_t)P + 1, fkey.data(), vid_of_slot.data(), cnts);
+    }
     std::vector<int32_t> lm_point(nv), point_slot(L, -1);
     for (int s2 = 0; s2 < nv; ++s2) { lm_point[s2] = point_of_vid[vid_of_slot[s2]]; point_slot[lm_point[s2]] = s2; }
     {
@@ -226,30 +237,38 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
 
     lap("observation groups");
     // ---- observations sorted by landmark: variable points (by vid) first, then constant points
-    std::vector<int64_t> order(N);
-    for (long i = 0; i < N; ++i) order[i] = i;
-    auto lm_key = [&](long i) -> int64_t {
-        const int v = point_slot[d->obs_point[i]];
-        return v >= 0 ? (int64_t)v : (int64_t)nv + d->obs_point[i];
-    };
-    counting_sort(order, (size_t)nv + (size_t)L + 1, [&](int64_t a) { return lm_key(a); });
+    if ((long)nv + (long)L + 1 >= (1L << 31)) return fail("too many landmarks for 32-bit sort keys");
+    std::vector<int32_t> order((size_t)N), lkey((size_t)N), lcounts;
+    {   // keys (and the range checks the fill below relies on) on several threads
+        std::atomic<int> bad{0};
+        ps_parallel(ps_host_threads(N), [&](int t, int TT) {
+            for (long i = N * t / TT, e = N * (t + 1) / TT; i < e; ++i) {
+                const int pose = d->obs_pose[i], pt = d->obs_point[i], grp = d->obs_grp[i];
+                if (pose < 0 || pose >= P || pt < 0 || pt >= L || grp < 0 || grp >= d->num_obs_groups) { bad = 1; lkey[i] = 0; continue; }
+                const int v = point_slot[pt];
+                lkey[i] = v >= 0 ? v : nv + pt;
+            }
+        });
+        if (bad) return fail("observation index out of range");
+    }
+    parallel_index_sort(N, (size_t)nv + (size_t)L + 1, lkey.data(), order.data(), lcounts);
     std::vector<LObs> lobs(N);
     std::vector<int32_t> lorig(N), lm_ptr(nv + 1, 0), sidx_l(wide ? N : 0);
     long Nl = 0;
-    for (long k = 0; k < N; ++k) {
-        const long i = order[k];
-        const int pose = d->obs_pose[i], pt = d->obs_point[i], grp = d->obs_grp[i];
-        if (pose < 0 || pose >= P || pt < 0 || pt >= L || grp < 0 || grp >= d->num_obs_groups)
-            return fail("observation index out of range");
-        LObs& o = lobs[k];
-        o.u = d->obs_uvd[3 * i]; o.v = d->obs_uvd[3 * i + 1]; o.d = d->obs_uvd[3 * i + 2];
-        o.pose_grp = (int32_t)((uint32_t)pose | ((uint32_t)class_of_row[grp] << 24));
-        o.point = pt;
-        lorig[k] = (int32_t)i;
-        if (wide) sidx_l[k] = (int32_t)d->obs_groups[4 * (size_t)grp + 1];
-        const int v = point_slot[pt];
-        if (v >= 0) { lm_ptr[v + 1] += 1; ++Nl; }
-    }
+    for (int v = 0; v < nv; ++v) { lm_ptr[v + 1] = lcounts[v]; Nl += lcounts[v]; }
+    ps_parallel(ps_host_threads(N), [&](int t, int TT) {
+        for (long k = N * t / TT, e = N * (t + 1) / TT; k < e; ++k) {
+            const long i = order[k];
+            const int pose = d->obs_pose[i], pt = d->obs_point[i], grp = d->obs_grp[i];
+            LObs& o = lobs[k];
+            o.u = d->obs_uvd[3 * i]; o.v = d->obs_uvd[3 * i + 1]; o.d = d->obs_uvd[3 * i + 2];
+            o.pose_grp = (int32_t)((uint32_t)pose | ((uint32_t)class_of_row[grp] << 24));
+            o.point = pt;
+            lorig[k] = (int32_t)i;
+            if (wide) sidx_l[k] = (int32_t)d->obs_groups[4 * (size_t)grp + 1];
+        }
+    });
+    { std::vector<int32_t>().swap(lkey); std::vector<int32_t>().swap(lcounts); }
     for (int v = 0; v < nv; ++v) lm_ptr[v + 1] += lm_ptr[v];
     h->Nl = Nl;
     if (h->upload(&h->lobs, lobs) || h->upload(&h->lorig, lorig) || h->upload(&h->lm_ptr, lm_ptr) ||
@@ -261,12 +280,19 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     lap("landmark sort + lobs");
     // ---- pose segments (observations on variable poses), chunks of 256
     std::vector<int32_t> pcount(nr + 1, 0);
-    for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pcount[r + 1]++; }
-    for (int r = 0; r < nr; ++r) pcount[r + 1] += pcount[r];
+    std::vector<int32_t> pidx;
+    {   // observations by reduced pose (constant poses: key nr, cut off afterwards), stable in landmark order
+        std::vector<int32_t> pkey((size_t)N), pord((size_t)N), pcnt;
+        ps_parallel(ps_host_threads(N), [&](int t, int TT) {
+            for (long k = N * t / TT, e = N * (t + 1) / TT; k < e; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; pkey[k] = r >= 0 ? r : nr; }
+        });
+        parallel_index_sort(N, (size_t)nr + 1, pkey.data(), pord.data(), pcnt);
+        for (int r = 0; r < nr; ++r) pcount[r + 1] = pcount[r] + pcnt[r];
+        pord.resize((size_t)pcount[nr]);
+        pidx.swap(pord);
+    }
     const long Np = h->Np = pcount[nr];
     for (int r = 0; r < nr; ++r) h->max_pose_obs = std::max(h->max_pose_obs, pcount[r + 1] - pcount[r]);
-    std::vector<int32_t> pidx(Np), fill(pcount.begin(), pcount.end() - 1);
-    for (long k = 0; k < N; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; if (r >= 0) pidx[fill[r]++] = (int32_t)k; }
     std::vector<PItem> pitems;
     std::vector<int32_t> pitem_ptr(nr + 1, 0);
     std::vector<int32_t> pose_of_rid(std::max(nr, 1), 0);
@@ -285,11 +311,13 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // pose-sorted copy of the observation records; the pose bits (uniform per chunk) carry the landmark slot + 1
     if (nv >= (1 << 24) - 1) return fail("too many variable landmarks for the 24-bit slot field");
     std::vector<LObs> pobs((size_t)Np);
-    for (long k = 0; k < Np; ++k) {
-        pobs[k] = lobs[pidx[k]];
-        const int slot = point_slot[pobs[k].point];              // -1: constant point
-        pobs[k].pose_grp = (int32_t)(((uint32_t)PS_GRP_OF(pobs[k]) << 24) | (uint32_t)(slot + 1));
-    }
+    ps_parallel(ps_host_threads(Np), [&](int t, int TT) {
+        for (long k = Np * t / TT, e = Np * (t + 1) / TT; k < e; ++k) {
+            pobs[k] = lobs[pidx[k]];
+            const int slot = point_slot[pobs[k].point];          // -1: constant point
+            pobs[k].pose_grp = (int32_t)(((uint32_t)PS_GRP_OF(pobs[k]) << 24) | (uint32_t)(slot + 1));
+        }
+    });
     if (wide) {
         std::vector<int32_t> sidx_p((size_t)Np);
         for (long k = 0; k < Np; ++k) sidx_p[k] = sidx_l[pidx[k]];
@@ -658,15 +686,35 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     std::vector<int2> pairs(prs.size());
     std::vector<PairItem> pitm;
     std::vector<int32_t> task_tile;
-    for (size_t k = 0; k < prs.size(); ++k) {
-        pairs[k] = make_int2(prs[k].a, prs[k].b);
-        if (k == 0 || prs[k].key != prs[k - 1].key || prs[k].tile != prs[k - 1].tile) {
-            const int a = (int)(prs[k].key >> 32), b = (int)(uint32_t)prs[k].key;
-            if (!pitm.empty()) pitm.back().end = (int32_t)k;
-            pitm.push_back({slot_of(a, b), slot_of(b, a), (int32_t)k, 0});
-            if (a == b) h->has_diag_tasks = true;
-            task_tile.push_back(prs[k].tile);
-        }
+    {   // on several threads: every thread copies its chunk of pairs and notes where tasks begin in it; the task records are then
+        // assembled in order (22.5 M pairs at C4: 0.1 s on one core)
+        const long np = (long)prs.size();
+        const int T = ps_host_threads(np);
+        std::vector<std::vector<int32_t>> starts(T);
+        ps_parallel(T, [&](int t, int TT) {
+            for (long k = np * t / TT, e = np * (t + 1) / TT; k < e; ++k) {
+                pairs[k] = make_int2(prs[k].a, prs[k].b);
+                if (k == 0 || prs[k].key != prs[k - 1].key || prs[k].tile != prs[k - 1].tile) starts[t].push_back((int32_t)k);
+            }
+        });
+        size_t ntask = 0;
+        for (auto& v2 : starts) ntask += v2.size();
+        pitm.reserve(ntask); task_tile.reserve(ntask);
+        for (auto& v2 : starts)
+            for (int32_t k : v2) {
+                const int a = (int)(prs[k].key >> 32), b = (int)(uint32_t)prs[k].key;
+                if (!pitm.empty()) pitm.back().end = k;
+                pitm.push_back({-1, -1, k, 0});
+                if (a == b) h->has_diag_tasks = true;
+                task_tile.push_back(prs[k].tile);
+            }
+        ps_parallel(ps_host_threads((long)pitm.size() * 16), [&](int t, int TT) {
+            for (long q = (long)pitm.size() * t / TT, e = (long)pitm.size() * (t + 1) / TT; q < e; ++q) {
+                const uint64_t key = prs[pitm[q].start].key;
+                const int a = (int)(key >> 32), b = (int)(uint32_t)key;
+                pitm[q].slot = slot_of(a, b); pitm[q].slotT = slot_of(b, a);
+            }
+        });
     }
     if (!pitm.empty()) pitm.back().end = (int32_t)prs.size();
     h->npair_items = (int)pitm.size();

@@ -439,6 +439,41 @@ int need_device() {
 }  // namespace
 
 namespace {
+// ---- host threads for the structure pass of ps_problem_create (round 4: the O(N) loops over 5 M observations and 22 M pairs at
+// C4 were 0.6 s on one core) -------------------------------------------------------------------------------------------------
+inline int ps_host_threads(long items, int cap = 16) {
+    if (items < 200000) return 1;                             // (a thread start costs more than a small loop)
+    return std::max(1, std::min({(int)std::thread::hardware_concurrency(), cap, 16}));
+}
+// fn(t, T): chunk t of T; T == 1 runs inline
+template <class F>
+void ps_parallel(int T, F fn) {
+    if (T <= 1) { fn(0, 1); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t) pool.emplace_back([&fn, t, T] { fn(t, T); });
+    for (auto& th : pool) th.join();
+}
+// Stable counting sort of the INDICES 0..n-1 by key[i] in [0, nkeys) on several threads: out[position] = i, counts[k] = number
+// of items with key k.  Thread t histograms its contiguous chunk; the (key-major, thread-minor) prefix gives every thread its
+// own output range per key, so chunk order -- hence stability -- is kept.
+inline void parallel_index_sort(long n, size_t nkeys, const int32_t* key, int32_t* out, std::vector<int32_t>& counts) {
+    const int T = ps_host_threads(n, (size_t)nkeys > (1u << 18) ? 8 : 16);
+    std::vector<std::vector<int32_t>> hist(T, std::vector<int32_t>(nkeys, 0));
+    ps_parallel(T, [&](int t, int TT) {
+        std::vector<int32_t>& hh = hist[t];
+        for (long i = n * t / TT, e = n * (t + 1) / TT; i < e; ++i) hh[key[i]]++;
+    });
+    counts.assign(nkeys, 0);
+    int32_t run = 0;
+    for (size_t k = 0; k < nkeys; ++k) {
+        for (int t = 0; t < T; ++t) { const int32_t c = hist[t][k]; hist[t][k] = run; run += c; counts[k] += c; }
+    }
+    ps_parallel(T, [&](int t, int TT) {
+        std::vector<int32_t>& hh = hist[t];
+        for (long i = n * t / TT, e = n * (t + 1) / TT; i < e; ++i) out[hh[key[i]]++] = (int32_t)i;
+    });
+}
+
 // stable counting sort of `v` by an integer key in [0, nkeys): O(n + nkeys), used for the big
 // host-side orderings of ps_problem_create (std::stable_sort was most of its run time)
 template <class T, class KeyFn>
