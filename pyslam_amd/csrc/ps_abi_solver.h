@@ -224,8 +224,12 @@ int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters,
     }
     // (the explicit PCG runs iteration k in launch group k: one group less than the fused CG's launches)
     const int limit = pcg_max_iters + (h->cg_explicit ? 1 : 2);
-    const int margin = (h->cg_explicit || h->last_pcg_iters == h->prev_pcg_iters) ? std::min(2, h->cg_margin) : h->cg_margin;
-    int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : (h->cg_explicit ? 32 : 16)) : std::max(8, h->cg_launched / 2);
+    // (behind a step that changed the cost by more than 5 % the lagged operators are from the other side of it: spare launches,
+    //  as in gn_solve_and_finish_async; no prediction -- the first call of a solve -- 24 launches for the folded CG)
+    const bool big_step = h->prev_cost > 0.0 && h->last_cost > 0.0 && std::fabs(h->prev_cost - h->last_cost) > 0.05 * h->prev_cost;
+    const int margin = big_step ? (h->cg_explicit ? 5 : std::max(6, h->cg_margin))
+                                : ((h->cg_explicit || h->last_pcg_iters == h->prev_pcg_iters) ? std::min(2, h->cg_margin) : h->cg_margin);
+    int count = first ? (h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : (h->cg_explicit ? 32 : 24)) : std::max(8, h->cg_launched / 2);
     count = std::min(count, limit - h->cg_launched);
     const bool last = count <= 0;
     const int32_t* gate = last ? nullptr : h->status;
@@ -256,7 +260,9 @@ int ps_gn_result(ps_problem* h, int* done, double* shard2 /* [2] */, double* dx_
     if (dx_pose_norm2) *dx_pose_norm2 = h->h_scalars[SC_DXP2];
     // the cost history the lagged operators' hold / try decisions read (same on every rank: the buffer was all-reduced)
     if (h->h_status[ST_PCG_DONE]) { h->prev_cost = h->last_cost; h->last_cost = sb[0]; }
-    return cg_report(h, pcg_iters_out, pcg_relres_out);
+    if (cg_report(h, pcg_iters_out, pcg_relres_out)) return -1;
+    if (h->h_status[ST_PCG_DONE] && h->xcg_ref_pending) { h->xcg_ref_pending = false; h->xcg_its_ref = h->last_pcg_iters; }
+    return 0;
 }
 
 // ps_gn_iteration; `start_cost_out` != NULL: also the cost AT the linearisation point (all blocks, ps_eval_cost's sum) --
@@ -320,6 +326,7 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
             sb[0] = h->h_shard[0]; sb[1] = h->h_shard[1];
             dxp2 = h->h_scalars[SC_DXP2];
             if (cg_report(h, pcg_iters_out, pcg_relres_out)) return -1;
+            if (done && h->xcg_ref_pending) { h->xcg_ref_pending = false; h->xcg_its_ref = h->last_pcg_iters; }   // (coarse_adaptive_hold)
             if (done || last) break;
             first = 0;
         }
