@@ -596,8 +596,13 @@ int xcg_coarse_inverse(ps_problem* h, hipStream_t st, int buf, int32_t* stat) {
         HIP_OK(hipMemsetAsync(h->Lrow, 0, (size_t)nc * PS_BAND_W * sizeof(double), st));
         HIP_OK(hipMemsetAsync(h->Lcol, 0, (size_t)nc * PS_BAND_W * sizeof(double), st));
         hipLaunchKernelGGL(k_band_chol<D>, dim3(1), dim3(256), 0, st, h->ncb, std::max(h->ac_bw, 1), h->Ac, h->Lrow, h->Lcol, h->rdiag, stat);
-        hipLaunchKernelGGL(k_band_inverse, dim3(cdiv(nc, 4)), dim3(256), 0, st, nc, h->Lrow, h->Lcol, h->rdiag,
-                           h->chol_scratch, (float*)h->LciT2[buf]);
+        static const bool inv_dot = ps_env("PS_BAND_INV_DOT") != nullptr;      // (measurement build: round 2's dot-product form)
+        if (inv_dot)
+            hipLaunchKernelGGL(k_band_inverse, dim3(cdiv(nc, 4)), dim3(256), 0, st, nc, h->Lrow, h->Lcol, h->rdiag,
+                               h->chol_scratch, (float*)h->LciT2[buf]);
+        else
+            hipLaunchKernelGGL(k_band_inverse_rl, dim3(cdiv(nc, 4)), dim3(256), 0, st, nc, h->Lrow, h->Lcol, h->rdiag,
+                               h->chol_scratch, (float*)h->LciT2[buf]);
         return 0;
     }
     if (coarse_factor<D>(h, st, buf, stat)) return -1;

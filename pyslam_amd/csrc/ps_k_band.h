@@ -225,3 +225,89 @@ __global__ __launch_bounds__(256) void k_band_inverse(
         for (int u = 0; u < U; ++u) { a[u] = an[u]; rd[u] = rdn[u]; xv[u] = xn[u]; }
     }
 }
+
+
+// lane j <- lane j + 1, lane 63 <- 0 (DPP wave_shl:1)
+PS_DEV double band_shift_down(double v) {
+    const unsigned long long r = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)r, 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(r >> 32), 0x130, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+PS_DEV double band_lane0(double v) {
+    const unsigned long long r = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(r >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Round 4: the same columns by RIGHT-LOOKING substitution.  k_band_inverse forms every unknown as a 48-lane dot product of
+// the band row with a ring of the last unknowns: a wave-wide sum (six dependent DPP stages on doubles, ~450 cycles) in a
+// chain of 2 (nc - c) dependent steps -- 0.19 us per step, 0.23 ms at C4 and 0.66-1.2 ms at C2 for a few MFLOP.  Here lane j
+// carries the PENDING sum of the row j steps ahead: a step reads lane 0's (v_readfirstlane), forms the unknown, shifts the
+// pending sums down one lane (one DPP move) and adds the new unknown's column of L to them (one FMA per lane, the column a
+// coalesced load from Lcol / Lrow, eight steps prefetched): ~40 dependent cycles per step.
+__global__ __launch_bounds__(256) void k_band_inverse_rl(
+    int nc, const double* __restrict__ Lrow, const double* __restrict__ Lcol, const double* __restrict__ rdiag,
+    double* __restrict__ Xs /* nc x nc scratch */, float* __restrict__ Ainv)
+{
+    constexpr int W = PS_BAND_W, U = 8;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= nc) return;
+    const bool in = lane < W;
+    double* xs = Xs + (size_t)c * nc;
+    double a[U], rd[U], an[U], rdn[U], xv[U], xn[U];
+    // forward, L x = e_c: after x_i, row i + 1 + j is owed L[i + 1 + j][i] x_i = Lcol[i][j] x_i
+    auto fwd_fetch = [&](int i0, double* av, double* rv) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + u, nc - 1);
+            av[u] = in ? Lcol[(size_t)i * W + lane] : 0.0;
+            rv[u] = rdiag[i];
+        }
+    };
+    double pend = 0.0;
+    fwd_fetch(c, a, rd);
+    for (int i0 = c; i0 < nc; i0 += U) {
+        if (i0 + U < nc) fwd_fetch(i0 + U, an, rdn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u;
+            if (i < nc) {
+                const double x = ((i == c ? 1.0 : 0.0) - band_lane0(pend)) * rd[u];
+                if (lane == 0) xs[i] = x;
+                pend = band_shift_down(pend);
+                pend += a[u] * x;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = an[u]; rd[u] = rdn[u]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // (lane 0's x, read back by this wave below: as in k_band_inverse)
+    // backward, L^T y = x, rows nc - 1 .. c: after y_i, row i - 1 - j is owed L[i][i - 1 - j] y_i = Lrow[i][j] y_i
+    auto bwd_fetch = [&](int i0, double* av, double* rv, double* xo) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = max(i0 - u, c);
+            av[u] = in ? Lrow[(size_t)i * W + lane] : 0.0;
+            rv[u] = rdiag[i];
+            xo[u] = xs[i];
+        }
+    };
+    pend = 0.0;
+    bwd_fetch(nc - 1, a, rd, xv);
+    for (int i0 = nc - 1; i0 >= c; i0 -= U) {
+        if (i0 - U >= c) bwd_fetch(i0 - U, an, rdn, xn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 - u;
+            if (i >= c) {
+                const double y = (xv[u] - band_lane0(pend)) * rd[u];
+                if (lane == 0) { const float f = (float)y; Ainv[(size_t)i * nc + c] = f; Ainv[(size_t)c * nc + i] = f; }
+                pend = band_shift_down(pend);
+                pend += a[u] * y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = an[u]; rd[u] = rdn[u]; xv[u] = xn[u]; }
+    }
+}
