@@ -240,74 +240,125 @@ PS_DEV double band_lane0(double v) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// Round 4: the same columns by RIGHT-LOOKING substitution.  k_band_inverse forms every unknown as a 48-lane dot product of
-// the band row with a ring of the last unknowns: a wave-wide sum (six dependent DPP stages on doubles, ~450 cycles) in a
-// chain of 2 (nc - c) dependent steps -- 0.19 us per step, 0.23 ms at C4 and 0.66-1.2 ms at C2 for a few MFLOP.  Here lane j
-// carries the PENDING sum of the row j steps ahead: a step reads lane 0's (v_readfirstlane), forms the unknown, shifts the
-// pending sums down one lane (one DPP move) and adds the new unknown's column of L to them (one FMA per lane, the column a
-// coalesced load from Lcol / Lrow, eight steps prefetched): ~40 dependent cycles per step.
+PS_DEV double band_lane(double v, int idx /* wave-uniform */) {
+    const unsigned long long r = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)r, idx), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(r >> 32), idx);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// Round 4: the same columns by RIGHT-LOOKING substitution, the band streamed through LDS.
+// k_band_inverse forms every unknown as a 48-lane dot product of the band row with a ring of the last unknowns, the rows
+// requested eight steps ahead: 0.19 us per step of a chain of 2 (nc - c) dependent steps -- 0.23 ms at C4, 0.66-1.2 ms at C2,
+// for a few MFLOP.  A first rewrite only replaced the dot product (wave-wide sum, six dependent DPP stages) by pending sums --
+// lane j carries what the row j steps ahead is owed; a step reads lane 0's, forms the unknown, shifts the pending sums down
+// one lane and adds the unknown's column of L -- and gained 25 %: the chain was waiting for its LOADS (eight steps of ~40
+// cycles are far shorter than a memory latency).  So the four waves of a workgroup (four neighbouring columns: the same
+// rows) now share tiles of 64 band rows, brought into LDS by all 256 threads one tile ahead; a step costs an LDS read that
+// does not depend on the chain, two v_readlane, a DPP move and two FMAs.
+#define PS_BI2_T 64
 __global__ __launch_bounds__(256) void k_band_inverse_rl(
     int nc, const double* __restrict__ Lrow, const double* __restrict__ Lcol, const double* __restrict__ rdiag,
     double* __restrict__ Xs /* nc x nc scratch */, float* __restrict__ Ainv)
 {
-    constexpr int W = PS_BAND_W, U = 8;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= nc) return;
-    const bool in = lane < W;
-    double* xs = Xs + (size_t)c * nc;
-    double a[U], rd[U], an[U], rdn[U], xv[U], xn[U];
-    // forward, L x = e_c: after x_i, row i + 1 + j is owed L[i + 1 + j][i] x_i = Lcol[i][j] x_i
-    auto fwd_fetch = [&](int i0, double* av, double* rv) {
+    constexpr int W = PS_BAND_W, T = PS_BI2_T, NPT = T * W / 256;          // 12 doubles per thread and tile
+    __shared__ double tile[2][T][W];
+    __shared__ double rdt[2][T];
+    const int t = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int cmin = blockIdx.x * 4, c = cmin + wv;            // (wave-uniform: the per-step tests below are scalar branches)
+    const bool live = c < nc, in = lane < W;
+    double* xs = Xs + (size_t)min(c, nc - 1) * nc;
+    // tile k of a sweep: rows row0 + dir * (0 .. 63)
+    auto fetch = [&](const double* __restrict__ L, int row0, int dir, double* v, double& rv) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + u, nc - 1);
-            av[u] = in ? Lcol[(size_t)i * W + lane] : 0.0;
-            rv[u] = rdiag[i];
+        for (int q = 0; q < NPT; ++q) {
+            const int e = t + 256 * q, r = row0 + dir * (e / W);
+            v[q] = (r >= 0 && r < nc) ? L[(size_t)r * W + (e % W)] : 0.0;
         }
+        const int r = row0 + dir * t;
+        rv = (t < T && r >= 0 && r < nc) ? rdiag[r] : 0.0;
     };
+    auto stash = [&](int b, const double* v, double rv) {
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) { const int e = t + 256 * q; tile[b][e / W][e % W] = v[q]; }
+        if (t < T) rdt[b][t] = rv;
+    };
+    double v[NPT], rv;
+    // ---- forward, L x = e_c, rows cmin .. nc - 1: after x_i, row i + 1 + j is owed L[i + 1 + j][i] x_i = Lcol[i][j] x_i
     double pend = 0.0;
-    fwd_fetch(c, a, rd);
-    for (int i0 = c; i0 < nc; i0 += U) {
-        if (i0 + U < nc) fwd_fetch(i0 + U, an, rdn);
+    fetch(Lcol, cmin, 1, v, rv);
+    stash(0, v, rv);
+    __syncthreads();
+    int b = 0;
+    for (int base = cmin; base < nc; base += T, b ^= 1) {
+        const bool more = base + T < nc;
+        if (more) fetch(Lcol, base + T, 1, v, rv);
+        if (live) {
+            double xring = 0.0;                                 // the tile's unknowns, pushed in at lane 0: lane j ends up with row base + 63 - j
+            const double rdreg = rdt[b][lane];                  // (T == 64: lane u holds 1 / L[u][u] of the tile's row u)
+            // sixteen steps at a time: their band entries come out of LDS before the dependent chain of the steps runs (an LDS
+            // read inside every step cost the chain its latency: 134 us at C4 that way)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u;
-            if (i < nc) {
-                const double x = ((i == c ? 1.0 : 0.0) - band_lane0(pend)) * rd[u];
-                if (lane == 0) xs[i] = x;
-                pend = band_shift_down(pend);
-                pend += a[u] * x;
+            for (int g = 0; g < T / 16; ++g) {
+                double a[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k] = in ? tile[b][16 * g + k][lane] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int u = 16 * g + k, i = base + u;
+                    double x = 0.0;
+                    if (i >= c && i < nc) {
+                        x = ((i == c ? 1.0 : 0.0) - band_lane0(pend)) * band_lane(rdreg, u);
+                        pend = band_shift_down(pend);
+                        pend += a[k] * x;
+                    }
+                    xring = band_ring_push(xring, x);
+                }
             }
+            { const int i = base + 63 - lane; if (i >= c && i < nc) xs[i] = xring; }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { a[u] = an[u]; rd[u] = rdn[u]; }
+        if (more) stash(b ^ 1, v, rv);
+        __syncthreads();
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // (lane 0's x, read back by this wave below: as in k_band_inverse)
-    // backward, L^T y = x, rows nc - 1 .. c: after y_i, row i - 1 - j is owed L[i][i - 1 - j] y_i = Lrow[i][j] y_i
-    auto bwd_fetch = [&](int i0, double* av, double* rv, double* xo) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = max(i0 - u, c);
-            av[u] = in ? Lrow[(size_t)i * W + lane] : 0.0;
-            rv[u] = rdiag[i];
-            xo[u] = xs[i];
-        }
-    };
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // (this wave's x, read back by the same wave below: as in k_band_inverse)
+    // ---- backward, L^T y = x, rows nc - 1 .. cmin: after y_i, row i - 1 - j is owed L[i][i - 1 - j] y_i = Lrow[i][j] y_i
     pend = 0.0;
-    bwd_fetch(nc - 1, a, rd, xv);
-    for (int i0 = nc - 1; i0 >= c; i0 -= U) {
-        if (i0 - U >= c) bwd_fetch(i0 - U, an, rdn, xn);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 - u;
-            if (i >= c) {
-                const double y = (xv[u] - band_lane0(pend)) * rd[u];
-                if (lane == 0) { const float f = (float)y; Ainv[(size_t)i * nc + c] = f; Ainv[(size_t)c * nc + i] = f; }
-                pend = band_shift_down(pend);
-                pend += a[u] * y;
-            }
+    fetch(Lrow, nc - 1, -1, v, rv);
+    stash(0, v, rv);
+    double xt = 0.0, xn = 0.0;
+    if (live && nc - 1 - lane >= c) xt = xs[nc - 1 - lane];
+    __syncthreads();
+    b = 0;
+    for (int top = nc - 1; top >= cmin; top -= T, b ^= 1) {
+        const bool more = top - T >= cmin;
+        if (more) {
+            fetch(Lrow, top - T, -1, v, rv);
+            xn = (live && top - T - lane >= c) ? xs[top - T - lane] : 0.0;
         }
+        if (live) {
+            double yring = 0.0;                                 // lane j ends up with row top - 63 + j
+            const double rdreg = rdt[b][lane];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { a[u] = an[u]; rd[u] = rdn[u]; xv[u] = xn[u]; }
+            for (int g = 0; g < T / 16; ++g) {
+                double a[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k] = in ? tile[b][16 * g + k][lane] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int u = 16 * g + k, i = top - u;
+                    double y = 0.0;
+                    if (i >= c) {
+                        y = (band_lane(xt, u) - band_lane0(pend)) * band_lane(rdreg, u);
+                        pend = band_shift_down(pend);
+                        pend += a[k] * y;
+                    }
+                    yring = band_ring_push(yring, y);
+                }
+            }
+            const int i = top - 63 + lane;
+            if (i >= c && i <= top) { const float f = (float)yring; Ainv[(size_t)i * nc + c] = f; Ainv[(size_t)c * nc + i] = f; }
+        }
+        if (more) stash(b ^ 1, v, rv);
+        xt = xn;
+        __syncthreads();
     }
 }

@@ -366,7 +366,6 @@ __global__ __launch_bounds__(64) void k_cov_rhs(
     }
 }
 
-#define PS_BS_ROWS 256                        // Z rows staged per pass of k_backsub (28 KB of LDS)
 __global__ __launch_bounds__(256) void k_backsub(
     int nv, const int32_t* __restrict__ lm_ptr, const LObs* __restrict__ lobs,
     const int32_t* __restrict__ pose_rid, const double* __restrict__ Z,
@@ -401,35 +400,18 @@ __global__ __launch_bounds__(256) void k_backsub(
         if (threadIdx.x == 0) sq_part_p[blockIdx.x - nblk_l] = sq;
         return;
     }
+    // (Round 4 tried the workgroup's rows -- one contiguous range of Z -- as a dense stream through LDS instead of seven 16-byte
+    //  pieces per lane at a 128-byte stride: 173 -> 198 us at C4, the staging barrier and the lost occupancy cost more than the
+    //  scattered requests; not kept.)
     // 16 lanes per landmark, one observation per lane (same mapping as k_landmark_pass)
     const int v = blockIdx.x * (blockDim.x / PS_LM_GROUP) + threadIdx.x / PS_LM_GROUP;
     const int sub = threadIdx.x & (PS_LM_GROUP - 1);
     const bool live = v < nv;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    // The rows of the workgroup's 16 landmarks are ONE contiguous range of Z (observations are sorted by landmark).  Round 4:
-    // they come in as a dense stream -- thread q brings 16-byte piece q of the range (7 of the 8 pieces of every 128-byte row),
-    // 4 KB per load instruction of the workgroup -- and the lanes read their rows from LDS.  Before, every lane loaded its own
-    // row as seven 16-byte pieces at a 128-byte stride: 40 scattered sectors per wave instruction, 3.5 requests per sector
-    // actually needed (C3: 21 -> @@ us, C4: 0.176 -> @@ ms).  Same arithmetic in the same order: bit-identical results.
-    __shared__ __attribute__((aligned(16))) double2 srow[PS_BS_ROWS * 7];
-    const int v0 = blockIdx.x * (blockDim.x / PS_LM_GROUP);
-    const int r_begin = lm_ptr[min(v0, nv)], r_end = lm_ptr[min(v0 + (int)(blockDim.x / PS_LM_GROUP), nv)];
-    const int my_b = live ? lm_ptr[v] : 0, my_e = live ? lm_ptr[v + 1] : 0;
-    for (int base = r_begin; base < r_end; base += PS_BS_ROWS) {
-        const int n = min(PS_BS_ROWS, r_end - base);
-        if (base != r_begin) __syncthreads();
-        const double2* zsrc = reinterpret_cast<const double2*>(Z + PS_ZROW * (size_t)base);
-        for (int q = threadIdx.x; q < n * 7; q += blockDim.x) {
-            const int row = q / 7, k = q - 7 * row;
-            srow[q] = zsrc[8 * row + k];
-        }
-        __syncthreads();
-        // this lane's observations that lie in [base, base + n): i = my_b + sub + 16 m
-        int i = my_b + sub;
-        if (i < base) i += (base - i + PS_LM_GROUP - 1) / PS_LM_GROUP * PS_LM_GROUP;
-        for (; i < my_e && i < base + n; i += PS_LM_GROUP) {
-            // the whole row: M (9) | pc (3) | reduced pose index (no observation record, no pose_rid gather)
-            const double2* zq = srow + 7 * (i - base);
+    if (live) {
+        for (int i = lm_ptr[v] + sub; i < lm_ptr[v + 1]; i += PS_LM_GROUP) {
+            // the whole 128-byte row: M (9) | pc (3) | reduced pose index (no observation record, no pose_rid gather)
+            const double2* zq = reinterpret_cast<const double2*>(Z + PS_ZROW * (size_t)i);
             double z[14];
 #pragma unroll
             for (int k = 0; k < 7; ++k) { const double2 t = zq[k]; z[2 * k] = t.x; z[2 * k + 1] = t.y; }
