@@ -274,6 +274,11 @@ int ps_debug_reproj_blocks(ps_problem* h, double* r /* (N,3) */, double* jpose /
    J_1 = -S Ad(T_2 T_1^-1), J_2 = S); priors: PoseResidual.evaluate (pose_residual.py:12-27: r = S log(T T_obs^-1),
    J = S in j2, j1 = 0).  Runs the production kernel with its tap open; S and g are not touched. */
 int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2);
+/* FNV-1a (64 bit) of the structure tables ps_problem_create left in HBM, in a fixed order: point slots, lobs, lorig,
+   lm_ptr, lm_point, pose_of_rid, pitems, pitem_ptr, pobs, pairs, pair work items (XCD order), combine items, combine
+   tasks, row_ptr, col_idx, diag_slot (16 words; 0 for a table the problem does not have).  What holds the device
+   structure build against the host builder bit for bit (tests/test_gpu_create.py); no reference counterpart. */
+int ps_debug_table_checksums(ps_problem* h, uint64_t* out, int capacity, int* count);
 
 /* Tuning knobs (defaults in brackets):
      "pcg_variant"        [1] fused single-launch-per-iteration CG on the block-Jacobi scaled system; 0 = classic two-launch PCG

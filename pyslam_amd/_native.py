@@ -111,6 +111,7 @@ SIGNATURES = {
     'ps_get_landmark_factors': (C.c_int, [H, c_f64p, c_f64p]),
     'ps_debug_reproj_blocks': (C.c_int, [H, c_f64p, c_f64p, c_f64p]),
     'ps_debug_factor_blocks': (C.c_int, [H, c_f64p, c_f64p, c_f64p]),
+    'ps_debug_table_checksums': (C.c_int, [H, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
     'ps_set_option': (C.c_int, [H, C.c_char_p, C.c_double]),
     'ps_set_profiling': (C.c_int, [H, C.c_int]),
     'ps_get_stage_times': (C.c_int, [H, c_f64p, C.POINTER(C.c_int64), C.c_int]),

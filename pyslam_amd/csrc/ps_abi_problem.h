@@ -500,20 +500,54 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
         if (tile_kb > 0 && zbytes > min_mb * 1048576.0)
             ntiles = 8 * (int)std::ceil(zbytes / (8.0 * tile_kb * 1024.0));
     }
+    // Device build of the pair list (csrc/ps_host_build.h): pairs generated, sorted and left in HBM; the host receives the task
+    // starts and keys only.  PS_CREATE_DEVICE: 0 = host builder (the test oracle of the device build), 1 = device build from
+    // 200 000 observations up (default; below that the host builder is a fraction of a millisecond), 2 = always.
+    const int create_dev_env = ps_create_env("PS_CREATE_DEVICE") ? atoi(ps_create_env("PS_CREATE_DEVICE")) : 1;
+    const bool dev_pairs = gather_lists && create_dev_env != 0 && D == 6 && nr > 0 && nv > 0 && lm_ptr[nv] > 0 && !tiles_forced &&
+                           !ps_create_env("PS_PAIRS_BY_LANDMARK") && ntiles < 65536 && (create_dev_env == 2 || N >= 200000);
+    DevPairBuild devb;
     std::vector<long> lm_pairs_before(nv + 1, 0);
-    for (int v = 0; v < nv && gather_lists; ++v) {
-        long nvar = 0;
-        for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) nvar += d->pose_rid[PS_POSE_OF(lobs[a])] >= 0;
-        lm_pairs_before[v + 1] = lm_pairs_before[v] + nvar * (nvar - 1) / 2;
+    if (dev_pairs) {
+        if (h->arena_flush() || devb.prepare(h, nv, nr, (long)lm_ptr[nv])) return -1;
+    } else {
+        for (int v = 0; v < nv && gather_lists; ++v) {
+            long nvar = 0;
+            for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) nvar += d->pose_rid[PS_POSE_OF(lobs[a])] >= 0;
+            lm_pairs_before[v + 1] = lm_pairs_before[v] + nvar * (nvar - 1) / 2;
+        }
     }
-    const long total_pairs = gather_lists ? lm_pairs_before[nv] : 0;
+    const long total_pairs = dev_pairs ? (long)devb.total : (gather_lists ? lm_pairs_before[nv] : 0);
+    if (total_pairs >= (1L << 31)) return fail("too many Schur pairs for 32-bit indexing");
+    if (dev_pairs) {
+        // the same decisions as the host loop below, on lists that are never on the host
+        if (h->alloc(&h->pairs, (size_t)total_pairs, true)) return -1;
+        uint64_t* pout = reinterpret_cast<uint64_t*>(h->pairs);
+        const bool keep_env = ps_env("PS_SCHUR_KEEP_TILES") != nullptr;
+        bool done = false;
+        if (ntiles > 1 && zbytes <= 128.0 * 1048576.0 && !keep_env) {
+            if (devb.build(1, pout)) return -1;
+            if (devb.task_start.size() >= 2 * 256 * 12) { ntiles = 1; done = true; }
+        }
+        if (!done && ntiles == 1) { if (devb.build(1, pout)) return -1; done = true; }
+        if (!done) {
+            if (devb.build(ntiles, pout)) return -1;
+            if (total_pairs > 0) {
+                std::vector<uint64_t> tk(devb.task_key);
+                std::sort(tk.begin(), tk.end());
+                const size_t nblocks = std::unique(tk.begin(), tk.end()) - tk.begin(), ntask = devb.task_start.size();
+                const bool blocks_fill_chip = nblocks >= 2 * 256 * 12 && zbytes <= 128.0 * 1048576.0 && !keep_env;
+                if (!((size_t)total_pairs >= 64 * ntask && !blocks_fill_chip)) { ntiles = 1; if (devb.build(1, pout)) return -1; }
+            }
+        }
+    }
     // one unit of work per tile: the tile's pairs in (block row, block column, landmark) order, written to its
     // slice of prs; tiles are independent, so they are built by a few host threads
     // Tiles multiply the tasks (one per (tile, block) with pairs): when a task is left with a handful of pairs -- a landmark
     // shard of a multi-GPU run: 36 pairs per block at C4 / 8 -- the per-task skeleton dominates and the
     // untiled list wins (C4 / 8 shard: Schur stage 0.159 -> 0.119 ms).  Decided on the generated list: fewer than 64 pairs
     // per task on average -> generated again without tiles.
-    for (int attempt = 0; attempt < 2 && gather_lists; ++attempt) {
+    for (int attempt = 0; attempt < 2 && gather_lists && !dev_pairs; ++attempt) {
         auto tile_of = [&](int v) {
             return (ntiles > 1 && total_pairs > 0)
                 ? (int)std::min<long>(ntiles - 1, (long)((double)ntiles * (double)lm_pairs_before[v] / (double)total_pairs)) : 0;
@@ -638,15 +672,40 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     }
     if (!gather_lists) ntiles = 1;
     h->schur_tiles = ntiles;
-    h->npairs = gather_lists ? (long)prs.size() : (long)ppairs.size();
+    const long npairs_l = dev_pairs ? total_pairs : (long)prs.size();
+    h->npairs = gather_lists ? npairs_l : (long)ppairs.size();
     if (prs.size() >= (1UL << 31)) return fail("too many Schur pairs for 32-bit indexing");
 
     lap("pair generation + sort");
+    // tasks: runs of equal (tile, block) in the pair list -- start, block key, tile.  The device build has them already; the host
+    // build finds them (and copies its records into the kernels' int2 form) on several threads
+    std::vector<int32_t> task_start, task_tile;
+    std::vector<uint64_t> task_keyv;
+    std::vector<int2> pairs(dev_pairs ? 0 : prs.size());
+    if (dev_pairs) {
+        task_start.swap(devb.task_start); task_tile.swap(devb.task_tile); task_keyv.swap(devb.task_key);
+    } else {
+        const long np = (long)prs.size();
+        const int T = ps_host_threads(np);
+        std::vector<std::vector<int32_t>> starts(T);
+        ps_parallel(T, [&](int t, int TT) {
+            for (long k = np * t / TT, e = np * (t + 1) / TT; k < e; ++k) {
+                pairs[k] = make_int2(prs[k].a, prs[k].b);
+                if (k == 0 || prs[k].key != prs[k - 1].key || prs[k].tile != prs[k - 1].tile) starts[t].push_back((int32_t)k);
+            }
+        });
+        size_t ntask = 0;
+        for (auto& v2 : starts) ntask += v2.size();
+        task_start.reserve(ntask); task_tile.reserve(ntask); task_keyv.reserve(ntask);
+        for (auto& v2 : starts)
+            for (int32_t k : v2) { task_start.push_back(k); task_tile.push_back(prs[k].tile); task_keyv.push_back(prs[k].key); }
+        prs.clear(); prs.shrink_to_fit();
+    }
     // ---- block pattern of the reduced system
     std::vector<uint64_t> keys;                 // upper keys (ri <= rj)
-    keys.reserve(prs.size() / 8 + nr + F + d->num_extra_pairs);
+    keys.reserve(task_keyv.size() + nr + F + d->num_extra_pairs);
     for (int r = 0; r < nr; ++r) keys.push_back(((uint64_t)r << 32) | (uint32_t)r);
-    for (size_t k = 0; k < prs.size(); ++k) if (k == 0 || prs[k].key != prs[k - 1].key) keys.push_back(prs[k].key);
+    keys.insert(keys.end(), task_keyv.begin(), task_keyv.end());
     keys.insert(keys.end(), pose_keys.begin(), pose_keys.end());
     for (long f = 0; f < E; ++f) {
         const int ra = d->pose_rid[f_i[f]], rb = d->pose_rid[f_j[f]];
@@ -695,48 +754,28 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     h->S = h->red; h->g = h->red + (size_t)nnzb * DD; h->red_cost = h->g + (size_t)nr * D;
 
     lap("block pattern");
-    // pair list + one work item (task) per (tile, block) that has pairs
-    std::vector<int2> pairs(prs.size());
-    std::vector<PairItem> pitm;
-    std::vector<int32_t> task_tile;
-    {   // on several threads: every thread copies its chunk of pairs and notes where tasks begin in it; the task records are then
-        // assembled in order (22.5 M pairs at C4: 0.1 s on one core)
-        const long np = (long)prs.size();
-        const int T = ps_host_threads(np);
-        std::vector<std::vector<int32_t>> starts(T);
-        ps_parallel(T, [&](int t, int TT) {
-            for (long k = np * t / TT, e = np * (t + 1) / TT; k < e; ++k) {
-                pairs[k] = make_int2(prs[k].a, prs[k].b);
-                if (k == 0 || prs[k].key != prs[k - 1].key || prs[k].tile != prs[k - 1].tile) starts[t].push_back((int32_t)k);
-            }
-        });
-        size_t ntask = 0;
-        for (auto& v2 : starts) ntask += v2.size();
-        pitm.reserve(ntask); task_tile.reserve(ntask);
-        for (auto& v2 : starts)
-            for (int32_t k : v2) {
-                const int a = (int)(prs[k].key >> 32), b = (int)(uint32_t)prs[k].key;
-                if (!pitm.empty()) pitm.back().end = k;
-                pitm.push_back({-1, -1, k, 0});
-                if (a == b) h->has_diag_tasks = true;
-                task_tile.push_back(prs[k].tile);
-            }
-        ps_parallel(ps_host_threads((long)pitm.size() * 16), [&](int t, int TT) {
-            for (long q = (long)pitm.size() * t / TT, e = (long)pitm.size() * (t + 1) / TT; q < e; ++q) {
-                const uint64_t key = prs[pitm[q].start].key;
+    // one work item (task) per (tile, block) that has pairs
+    std::vector<PairItem> pitm(task_start.size());
+    {
+        const long nt = (long)pitm.size();
+        std::atomic<int> diag{0};
+        ps_parallel(ps_host_threads(nt * 16), [&](int t, int TT) {
+            for (long q = nt * t / TT, e = nt * (t + 1) / TT; q < e; ++q) {
+                const uint64_t key = task_keyv[q];
                 const int a = (int)(key >> 32), b = (int)(uint32_t)key;
-                pitm[q].slot = slot_of(a, b); pitm[q].slotT = slot_of(b, a);
+                pitm[q] = {slot_of(a, b), slot_of(b, a), task_start[q], q + 1 < nt ? task_start[q + 1] : (int32_t)npairs_l};
+                if (a == b) diag = 1;
             }
         });
+        if (diag) h->has_diag_tasks = true;
     }
-    if (!pitm.empty()) pitm.back().end = (int32_t)prs.size();
     h->npair_items = (int)pitm.size();
-    if (h->upload(&h->pairs, pairs)) return -1;
+    if (!dev_pairs && h->upload(&h->pairs, pairs)) return -1;
     {   // per-XCD work lists.  Untiled: items are sorted by block row, so equal contiguous shares of
         // the PAIRS (not of the items) give each XCD a contiguous range of block rows with balanced
         // work.  Tiled: XCD x takes tiles x, x + 8, ... (tiles hold equal pair counts).
         std::vector<std::vector<int32_t>> lists(8);
-        const double total = (double)pairs.size();
+        const double total = (double)npairs_l;
         for (size_t k = 0; k < pitm.size(); ++k) {
             const int x = ntiles > 1 ? (task_tile[k] & 7)
                                      : (total > 0 ? std::min(7, (int)(8.0 * pitm[k].start / total)) : 0);
@@ -782,7 +821,6 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
             if (h->alloc(&h->Spart, xit.size() * 36)) return -1;
         }
     }
-    prs.clear(); prs.shrink_to_fit();
     if (pose_mode && !ptasks.empty()) {
         for (size_t t = 0; t < ptasks.size(); ++t) {
             const int a = (int)(ptask_key[t] >> 32), b = (int)(uint32_t)ptask_key[t];

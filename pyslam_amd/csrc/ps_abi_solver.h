@@ -630,6 +630,36 @@ int ps_debug_factor_blocks(ps_problem* h, double* r, double* j1, double* j2) {
     return 0;
 }
 
+int ps_debug_table_checksums(ps_problem* h, uint64_t* out, int capacity, int* count) {
+    if (!h || !out || !count) return fail("null argument");
+    if (sync(h)) return -1;
+    struct Tab { const void* p; size_t bytes; };
+    const bool tiled = h->schur_tiles > 1 && h->npair_items > 0;
+    const Tab tabs[16] = {
+        {h->point_vid, (size_t)h->L * 4}, {h->lobs, (size_t)h->N * sizeof(LObs)}, {h->lorig, (size_t)h->N * 4},
+        {h->lm_ptr, ((size_t)h->nv + 1) * 4}, {h->lm_point, (size_t)h->nv * 4}, {h->pose_of_rid, (size_t)std::max(h->nr, 1) * 4},
+        {h->pitems, (size_t)h->npitems * sizeof(PItem)}, {h->pitem_ptr, ((size_t)h->nr + 1) * 4}, {h->pobs, (size_t)h->Np * sizeof(LObs)},
+        {h->gather_lists ? h->pairs : nullptr, (size_t)h->npairs * 8}, {h->pair_xitems, (size_t)8 * h->pair_per_xcd * sizeof(PairItem)},
+        {tiled ? h->comb_items : nullptr, (size_t)h->ncomb * sizeof(PairItem)}, {tiled ? h->comb_tasks : nullptr, (size_t)h->npair_items * 4},
+        {h->row_ptr, ((size_t)h->nr + 1) * 4}, {h->col_idx, (size_t)h->nnzb * 4}, {h->diag_slot, (size_t)h->nr * 4}};
+    *count = 16;
+    std::vector<unsigned char> buf;
+    for (int t = 0; t < 16 && t < capacity; ++t) {
+        uint64_t hsh = 0;
+        if (tabs[t].p && tabs[t].bytes) {
+            buf.resize(tabs[t].bytes);
+            HIP_OK(hipMemcpy(buf.data(), tabs[t].p, tabs[t].bytes, hipMemcpyDeviceToHost));
+            hsh = 1469598103934665603ull;
+            // eight bytes at a time (the tables are 4-byte multiples; a tail shorter than a word is folded byte by byte)
+            size_t i = 0;
+            for (; i + 8 <= buf.size(); i += 8) { uint64_t w; std::memcpy(&w, &buf[i], 8); hsh = (hsh ^ w) * 1099511628211ull; }
+            for (; i < buf.size(); ++i) hsh = (hsh ^ buf[i]) * 1099511628211ull;
+        }
+        out[t] = hsh;
+    }
+    return 0;
+}
+
 // the folded / explicit crossover depends on whether the lagged dense inverse can apply (ps_host_cg.h: build_coarse): an
 // option that changes that answer has the coarse level rebuilt by the next solve
 static void relook_path(ps_problem* h) {

@@ -415,10 +415,10 @@ struct ps_problem {
     bool arena_open = false, arena_poisoned = false;
 
     template <typename T>
-    int alloc(T** out, size_t n) {
+    int alloc(T** out, size_t n, bool device_written = false /* filled by a kernel of the structure build: not in the arena, whose closing copy would overwrite it */) {
         *out = nullptr;
         const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-        if (arena_open && bytes <= PS_ARENA_SMALL) {
+        if (arena_open && bytes <= PS_ARENA_SMALL && !device_written) {
             const size_t off = (arena_used + 255) & ~(size_t)255;
             if (off + bytes <= PS_ARENA_BYTES) {
                 std::memset(arena_host + off, 0, bytes);          // the closing copy writes the whole used range
@@ -506,6 +506,10 @@ struct ps_problem {
         arena_open = true;
         return 0;
     }
+    int arena_flush() {        // the tables staged so far, for a kernel of the structure build that reads them (the closing copy repeats it)
+        if (arena_open && arena_used) HIP_OK(hipMemcpyAsync(arena_dev, arena_host, arena_used, hipMemcpyHostToDevice, stream));
+        return 0;
+    }
     int arena_close() {        // one copy of everything staged; the caller synchronises the stream afterwards
         arena_open = false;
         if (arena_poisoned) arena_used = PS_ARENA_BYTES;       // (the poisoned tail travels too)
@@ -524,6 +528,7 @@ struct ps_problem {
 #include "ps_host_cg.h"
 #include "ps_host_ldi.h"
 #include "ps_host_iteration.h"
+#include "ps_host_build.h"
 
 // ===========================================================================
 // C ABI

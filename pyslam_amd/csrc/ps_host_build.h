@@ -1,0 +1,192 @@
+// ps_host_build.h -- ps_problem_create's structure build on the GPU (round 4; counterpart of the per-iteration bookkeeping of
+// reference pyslam/problem.py:294-329, which this build does once per structure).
+//
+// What moves to the device: everything whose size is the number of observations or of Schur pairs -- the pair list of the
+// gather kernels (22.5 M pairs = 180 MB at C4, the largest table of a handle: generated, sorted and left where the kernels
+// read it, never on the host).  What stays on the host: everything whose size is the number of blocks or tasks (block
+// pattern, work items, XCD lists, two-level structures: 10^4 .. 10^5 records).
+//
+// The lists are BIT-IDENTICAL to the host builder's (ps_abi_problem.h keeps it: PS_CREATE_DEVICE=0, and it is what problems
+// below the size threshold use): pairs are generated in the host builder's order (landmark by landmark, row a < row b over
+// the rows of variable poses), keyed (tile, block row, block column) and sorted with a STABLE radix sort -- the order the
+// host's two stable counting passes per tile produce.  tests/test_gpu_create.py holds the two builds against each other
+// table by table (ps_debug_table_checksums).
+#pragma once
+#include "ps_sort.h"
+
+namespace {
+
+// reduced pose index of every Z row (observation in landmark order), -1 for a constant pose
+__global__ __launch_bounds__(256) void k_build_row_rid(long n, const LObs* __restrict__ lobs, const int32_t* __restrict__ pose_rid,
+                                                        int32_t* __restrict__ rid_row)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rid_row[i] = pose_rid[PS_POSE_OF(lobs[i])];
+}
+
+// pairs per landmark: nvar (nvar - 1) / 2 over its rows on variable poses; cnt[nv] = 0 (the scan's total lands there)
+__global__ __launch_bounds__(256) void k_build_pair_counts(int nv, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ rid_row,
+                                                            long long* __restrict__ cnt)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v > nv) return;
+    long long nvar = 0;
+    if (v < nv) for (int a = lm_ptr[v]; a < lm_ptr[v + 1]; ++a) nvar += rid_row[a] >= 0;
+    cnt[v] = nvar * (nvar - 1) / 2;
+}
+
+// The pairs of landmark v at before[v] .. : (row a, row b), a < b, both on variable poses, in (a, b) order -- the host builder's
+// generation order.  Key: (tile, lower reduced pose, higher reduced pose); value: (Z row of the lower pose, Z row of the higher)
+// = the int2 the Schur kernels read.  PACKED keys ((tile nr + lo) nr + hi) fit 32 bits for every size that fits a GPU today.
+template <typename K, bool PACKED>
+__global__ __launch_bounds__(256) void k_build_pairs(int nv, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ rid_row,
+                                                      const long long* __restrict__ before, int ntiles, int nr, K* __restrict__ keys,
+                                                      uint64_t* __restrict__ vals)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    long long at = before[v];
+    const long long total = before[nv];
+    int tile = 0;
+    if (ntiles > 1 && total > 0) {
+        const long long t = (long long)((double)ntiles * (double)at / (double)total);       // (the host's tile_of, same arithmetic)
+        tile = (int)(t < (long long)(ntiles - 1) ? t : (long long)(ntiles - 1));
+    }
+    const int a0 = lm_ptr[v], a1 = lm_ptr[v + 1];
+    for (int a = a0; a < a1; ++a) {
+        const int ra = rid_row[a];
+        if (ra < 0) continue;
+        for (int b = a + 1; b < a1; ++b) {
+            const int rb = rid_row[b];
+            if (rb < 0) continue;
+            const bool ord = ra <= rb;
+            const uint32_t lo = ord ? ra : rb, hi = ord ? rb : ra, rlo = ord ? a : b, rhi = ord ? b : a;
+            keys[at] = PACKED ? (K)(((K)tile * (K)nr + lo) * (K)nr + hi) : (K)(((uint64_t)tile << 48) | ((uint64_t)lo << 24) | hi);
+            vals[at] = (uint64_t)rlo | ((uint64_t)rhi << 32);
+            ++at;
+        }
+    }
+}
+
+template <typename K>
+__global__ __launch_bounds__(256) void k_build_task_flags(long n, const K* __restrict__ keys, uint8_t* __restrict__ flags)
+{
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) flags[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1 : 0;
+}
+
+template <typename K>
+__global__ __launch_bounds__(256) void k_build_gather_keys(int n, const int32_t* __restrict__ idx, const K* __restrict__ keys,
+                                                            uint64_t* __restrict__ out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) out[k] = (uint64_t)keys[idx[k]];
+}
+
+// scratch of one device build: freed when the build ends
+struct DevScratch {
+    std::vector<void*> ptrs;
+    ~DevScratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    int get(T** out, size_t n) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) return fail(std::string("hipMalloc (structure build): ") + hipGetErrorString(e));
+        ptrs.push_back(p);
+        *out = (T*)p;
+        return 0;
+    }
+};
+
+// The gather kernels' pair list on the device.  In: the handle's lobs / lm_ptr / pose_rid tables (on the device: the caller has
+// flushed the arena).  prepare(): row rids, pair counts, their scan -> total.  build(ntiles): keys + values, stable sort, values
+// into `pairs`, task starts and keys back on the host (task = run of equal (tile, block) keys).
+struct DevPairBuild {
+    ps_problem* h = nullptr;
+    DevScratch scratch;
+    int nv = 0, nr = 0;
+    long nrows = 0;
+    long long total = 0;
+    int32_t* rid_row = nullptr;
+    long long *cnt = nullptr, *before = nullptr;
+    void* tmp = nullptr; size_t tmp_bytes = 0;
+    void *keys = nullptr, *keys_sorted = nullptr;
+    uint64_t *vals = nullptr, *task_keys_dev = nullptr;
+    uint8_t* flags = nullptr;
+    int32_t *starts_dev = nullptr, *count_dev = nullptr;
+    // result of the last build()
+    std::vector<int32_t> task_start, task_tile;
+    std::vector<uint64_t> task_key;             // (lower reduced pose << 32) | higher
+
+    int prepare(ps_problem* h_, int nv_, int nr_, long nrows_) {
+        h = h_; nv = nv_; nr = nr_; nrows = nrows_;
+        if (scratch.get(&rid_row, (size_t)nrows) || scratch.get(&cnt, (size_t)nv + 1) || scratch.get(&before, (size_t)nv + 1)) return -1;
+        tmp_bytes = ps_sort_tmp_bytes((size_t)nv + 1);
+        void* t0 = nullptr;
+        if (scratch.get((char**)&t0, tmp_bytes)) return -1;
+        hipLaunchKernelGGL(k_build_row_rid, dim3(cdiv(nrows, 256)), dim3(256), 0, h->stream, nrows, h->lobs, h->pose_rid, rid_row);
+        hipLaunchKernelGGL(k_build_pair_counts, dim3(cdiv(nv + 1, 256)), dim3(256), 0, h->stream, nv, h->lm_ptr, rid_row, cnt);
+        HIP_OK(ps_scan_exclusive_i64(t0, tmp_bytes, cnt, before, (size_t)nv + 1, h->stream));
+        HIP_OK(hipMemcpyAsync(&total, before + nv, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    // key layout for `ntiles` tiles
+    static bool packed32(int ntiles, int nr) { return (uint64_t)ntiles * (uint64_t)nr * (uint64_t)nr <= 0xFFFFFFFFull; }
+    int reserve(uint64_t* pairs_out) {
+        (void)pairs_out;
+        if (keys) return 0;
+        const size_t n = (size_t)total;
+        tmp_bytes = ps_sort_tmp_bytes(n);
+        if (scratch.get((char**)&tmp, tmp_bytes) || scratch.get((uint64_t**)&keys, n) || scratch.get((uint64_t**)&keys_sorted, n) ||
+            scratch.get(&vals, n) || scratch.get(&flags, n) || scratch.get(&starts_dev, n) || scratch.get(&count_dev, 1) ||
+            scratch.get(&task_keys_dev, n)) return -1;
+        return 0;
+    }
+    template <typename K, bool PACKED>
+    int run(int ntiles, int bits, uint64_t* pairs_out) {
+        const long n = (long)total;
+        K* k0 = (K*)keys; K* k1 = (K*)keys_sorted;
+        hipLaunchKernelGGL((k_build_pairs<K, PACKED>), dim3(cdiv(nv, 256)), dim3(256), 0, h->stream, nv, h->lm_ptr, rid_row, before, ntiles, nr, k0, vals);
+        if (sizeof(K) == 4) HIP_OK(ps_sort_pairs_k32_v64(tmp, tmp_bytes, (const uint32_t*)k0, (uint32_t*)k1, vals, pairs_out, (size_t)n, bits, h->stream));
+        else HIP_OK(ps_sort_pairs_k64_v64(tmp, tmp_bytes, (const uint64_t*)k0, (uint64_t*)k1, vals, pairs_out, (size_t)n, bits, h->stream));
+        hipLaunchKernelGGL(k_build_task_flags<K>, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, n, k1, flags);
+        HIP_OK(ps_select_flagged_indices(tmp, tmp_bytes, flags, starts_dev, count_dev, (size_t)n, h->stream));
+        int32_t ntask = 0;
+        HIP_OK(hipMemcpyAsync(&ntask, count_dev, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        hipLaunchKernelGGL(k_build_gather_keys<K>, dim3(cdiv(ntask, 256)), dim3(256), 0, h->stream, (int)ntask, starts_dev, k1, task_keys_dev);
+        task_start.resize((size_t)ntask);
+        std::vector<uint64_t> raw((size_t)ntask);
+        if (ntask) {
+            HIP_OK(hipMemcpyAsync(task_start.data(), starts_dev, (size_t)ntask * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_OK(hipMemcpyAsync(raw.data(), task_keys_dev, (size_t)ntask * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        }
+        HIP_OK(hipStreamSynchronize(h->stream));
+        task_key.resize((size_t)ntask); task_tile.resize((size_t)ntask);
+        for (int32_t q = 0; q < ntask; ++q) {
+            const uint64_t k = raw[q];
+            uint64_t tile, lo, hi;
+            if (PACKED) { hi = k % (uint64_t)nr; lo = (k / (uint64_t)nr) % (uint64_t)nr; tile = k / (uint64_t)nr / (uint64_t)nr; }
+            else { hi = k & 0xFFFFFFull; lo = (k >> 24) & 0xFFFFFFull; tile = k >> 48; }
+            task_key[q] = ((uint64_t)lo << 32) | (uint64_t)hi;
+            task_tile[q] = (int32_t)tile;
+        }
+        return 0;
+    }
+    // pairs_out: the handle's pair table (total pairs x 8 B)
+    int build(int ntiles, uint64_t* pairs_out) {
+        if (total == 0) { task_start.clear(); task_key.clear(); task_tile.clear(); return 0; }
+        if (reserve(pairs_out)) return -1;
+        if (packed32(ntiles, nr)) {
+            const uint64_t mx = (uint64_t)ntiles * (uint64_t)nr * (uint64_t)nr - 1;
+            int bits = 1;
+            while (bits < 32 && (mx >> bits)) ++bits;
+            return run<uint32_t, true>(ntiles, bits, pairs_out);
+        }
+        int tb = 1;
+        while ((ntiles - 1) >> tb) ++tb;
+        return run<uint64_t, false>(ntiles, 48 + tb, pairs_out);
+    }
+};
+}  // namespace
