@@ -165,7 +165,18 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // Internal landmark order ("slots"): by the lowest pose index that observes the landmark, so the
     // Z rows a pose (and a reduced-system block row) touches come from a compact address range and
     // stay in the 4 MB per-XCD L2, whatever order the caller numbered the landmarks in.
-    std::vector<int32_t> first_pose(L, INT32_MAX);
+    // Structure build on the device (csrc/ps_host_build.h): the observation tables and the pair list are produced by kernels
+    // from the caller's observation columns; the host builder below stays as its test oracle and for what the device build
+    // does not cover.  PS_CREATE_DEVICE: 0 = host builder, 1 = device build from 200 000 observations up (default: below
+    // that the host builder takes a fraction of a millisecond), 2 = always.
+    const bool wide = d->num_obs_groups > 255;
+    const int create_dev_env = ps_create_env("PS_CREATE_DEVICE") ? atoi(ps_create_env("PS_CREATE_DEVICE")) : 1;
+    const bool dev_build = create_dev_env != 0 && D == 6 && N > 0 && nr > 0 && nv > 0 && !wide && (create_dev_env == 2 || N >= 200000) &&
+                           !(ps_create_env("PS_SCHUR_MODE") && atoi(ps_create_env("PS_SCHUR_MODE")) != 0) &&
+                           !(ps_create_env("PS_SCHUR_STREAM") && atoi(ps_create_env("PS_SCHUR_STREAM")) != 0) &&
+                           !ps_create_env("PS_SCHUR_TILE_KB") && !ps_create_env("PS_PAIRS_BY_LANDMARK");
+    std::vector<int32_t> first_pose(dev_build ? 0 : L, INT32_MAX);
+    if (!dev_build)
     {
         const int T = ps_host_threads(N, 8);
         std::vector<std::vector<int32_t>> fp(T > 1 ? T : 0);
@@ -181,13 +192,13 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     }
     std::vector<int32_t>& vid_of_slot = h->h_vid_of_slot;
     vid_of_slot.resize(nv);
-    {   // vids in ascending first pose, ties in vid order (what the stable sort over 500 000 landmarks gave: 40 ms at C4)
+    if (!dev_build) {   // vids in ascending first pose, ties in vid order (what the stable sort over 500 000 landmarks gave: 40 ms at C4)
         std::vector<int32_t> fkey(nv), cnts;
         for (int v = 0; v < nv; ++v) { const int32_t f = first_pose[point_of_vid[v]]; fkey[v] = (f < 0 || f >= P) ? P : f; }
         parallel_index_sort(nv, (size_t)P + 1, fkey.data(), vid_of_slot.data(), cnts);
     }
-    std::vector<int32_t> lm_point(nv), point_slot(L, -1);
-    for (int s2 = 0; s2 < nv; ++s2) { lm_point[s2] = point_of_vid[vid_of_slot[s2]]; point_slot[lm_point[s2]] = s2; }
+    std::vector<int32_t> lm_point(dev_build ? 0 : nv), point_slot(dev_build ? 0 : L, -1);
+    for (int s2 = 0; s2 < nv && !dev_build; ++s2) { lm_point[s2] = point_of_vid[vid_of_slot[s2]]; point_slot[lm_point[s2]] = s2; }
     {
         std::vector<char> seen(nr, 0);
         for (int i = 0; i < P; ++i) if (d->pose_rid[i] >= 0) {
@@ -197,13 +208,12 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
         for (int i = 0; i < nr; ++i) if (!seen[i]) return fail("pose_rid is not a dense 0..nr-1 numbering");
     }
 
-    if (h->upload(&h->point_vid, point_slot)) return -1;     // device-side 'vid' = internal slot
+    if (!dev_build && h->upload(&h->point_vid, point_slot)) return -1;     // device-side 'vid' = internal slot
 
     lap("parameter tables");
     // ---- observation groups.  Up to 255 rows (camera, stiffness, loss id, loss k): one device group per row.  More --
     // typically one stiffness per observation -- : the device groups are the distinct (camera, loss id, loss k) CLASSES
     // (at most 255 of those) and the stiffness travels as a per-observation index into the stiffness table ("wide").
-    const bool wide = d->num_obs_groups > 255;
     std::vector<int32_t> class_of_row(std::max(1, d->num_obs_groups), 0);
     std::vector<ObsGroup> og;
     {
@@ -251,8 +261,11 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     lap("observation groups");
     // ---- observations sorted by landmark: variable points (by vid) first, then constant points
     if ((long)nv + (long)L + 1 >= (1L << 31)) return fail("too many landmarks for 32-bit sort keys");
-    std::vector<int32_t> order((size_t)N), lkey((size_t)N), lcounts;
-    {   // keys (and the range checks the fill below relies on) on several threads
+    DevObsBuild devo;
+    if (dev_build && (h->arena_flush() || devo.run(h, d, d_in, nr, nv, point_of_vid, vid_of_slot))) return -1;
+    const size_t NH = dev_build ? 0 : (size_t)N;       // sizes of the host builder's tables
+    std::vector<int32_t> order(NH), lkey(NH), lcounts;
+    if (!dev_build) {   // keys (and the range checks the fill below relies on) on several threads
         std::atomic<int> bad{0};
         ps_parallel(ps_host_threads(N), [&](int t, int TT) {
             for (long i = N * t / TT, e = N * (t + 1) / TT; i < e; ++i) {
@@ -264,12 +277,12 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
         });
         if (bad) return fail("observation index out of range");
     }
-    parallel_index_sort(N, (size_t)nv + (size_t)L + 1, lkey.data(), order.data(), lcounts);
-    std::vector<LObs> lobs(N);
-    std::vector<int32_t> lorig(N), lm_ptr(nv + 1, 0), sidx_l(wide ? N : 0);
-    long Nl = 0;
-    for (int v = 0; v < nv; ++v) { lm_ptr[v + 1] = lcounts[v]; Nl += lcounts[v]; }
-    ps_parallel(ps_host_threads(N), [&](int t, int TT) {
+    if (!dev_build) parallel_index_sort(N, (size_t)nv + (size_t)L + 1, lkey.data(), order.data(), lcounts);
+    std::vector<LObs> lobs(NH);
+    std::vector<int32_t> lorig(NH), lm_ptr(nv + 1, 0), sidx_l(wide ? N : 0);
+    long Nl = dev_build ? devo.Nl : 0;
+    for (int v = 0; v < nv && !dev_build; ++v) { lm_ptr[v + 1] = lcounts[v]; Nl += lcounts[v]; }
+    if (!dev_build) ps_parallel(ps_host_threads(N), [&](int t, int TT) {
         for (long k = N * t / TT, e = N * (t + 1) / TT; k < e; ++k) {
             const long i = order[k];
             const int pose = d->obs_pose[i], pt = d->obs_point[i], grp = d->obs_grp[i];
@@ -284,7 +297,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     { std::vector<int32_t>().swap(lkey); std::vector<int32_t>().swap(lcounts); }
     for (int v = 0; v < nv; ++v) lm_ptr[v + 1] += lm_ptr[v];
     h->Nl = Nl;
-    if (h->upload(&h->lobs, lobs) || h->upload(&h->lorig, lorig) || h->upload(&h->lm_ptr, lm_ptr) ||
+    if (!dev_build) if (h->upload(&h->lobs, lobs) || h->upload(&h->lorig, lorig) || h->upload(&h->lm_ptr, lm_ptr) ||
         h->upload(&h->lm_point, lm_point) || (wide && h->upload(&h->sidx_l, sidx_l))) return -1;
     if (h->alloc(&h->Z, (size_t)Nl * PS_ZROW) || h->alloc(&h->Cinv, (size_t)nv * 6) ||
         h->alloc(&h->cvec, (size_t)nv * 3) || h->alloc(&h->dxl, (size_t)nv * 3)) return -1;
@@ -294,7 +307,8 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // ---- pose segments (observations on variable poses), chunks of 256
     std::vector<int32_t> pcount(nr + 1, 0);
     std::vector<int32_t> pidx;
-    {   // observations by reduced pose (constant poses: key nr, cut off afterwards), stable in landmark order
+    if (dev_build) pcount = devo.pcount;
+    else {   // observations by reduced pose (constant poses: key nr, cut off afterwards), stable in landmark order
         std::vector<int32_t> pkey((size_t)N), pord((size_t)N), pcnt;
         ps_parallel(ps_host_threads(N), [&](int t, int TT) {
             for (long k = N * t / TT, e = N * (t + 1) / TT; k < e; ++k) { const int r = d->pose_rid[PS_POSE_OF(lobs[k])]; pkey[k] = r >= 0 ? r : nr; }
@@ -323,8 +337,8 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     }
     // pose-sorted copy of the observation records; the pose bits (uniform per chunk) carry the landmark slot + 1
     if (nv >= (1 << 24) - 1) return fail("too many variable landmarks for the 24-bit slot field");
-    std::vector<LObs> pobs((size_t)Np);
-    ps_parallel(ps_host_threads(Np), [&](int t, int TT) {
+    std::vector<LObs> pobs(dev_build ? 0 : (size_t)Np);
+    if (!dev_build) ps_parallel(ps_host_threads(Np), [&](int t, int TT) {
         for (long k = Np * t / TT, e = Np * (t + 1) / TT; k < e; ++k) {
             pobs[k] = lobs[pidx[k]];
             const int slot = point_slot[pobs[k].point];          // -1: constant point
@@ -338,7 +352,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     }
     h->npitems = (int)pitems.size();
     if (h->upload(&h->pitems, pitems) || h->upload(&h->pitem_ptr, pitem_ptr) ||
-        h->upload(&h->pobs, pobs) || h->alloc(&h->ppartial, (size_t)pitems.size() * PS_NPOSE_ACC)) return -1;
+        (!dev_build && h->upload(&h->pobs, pobs)) || h->alloc(&h->ppartial, (size_t)pitems.size() * PS_NPOSE_ACC)) return -1;
 
     lap("pose segments + pobs");
     // ---- pose factors: edges then priors
@@ -492,7 +506,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     std::vector<PairRec> prs;
     int ntiles = 1;
     bool tiles_forced = ps_create_env("PS_SCHUR_TILE_KB") != nullptr;
-    const double zbytes = 8.0 * PS_ZROW * (double)lm_ptr[nv];
+    const double zbytes = 8.0 * PS_ZROW * (double)Nl;
     {
         double tile_kb = 9216.0, min_mb = 16.0;
         if (const char* e = ps_create_env("PS_SCHUR_TILE_KB")) tile_kb = atof(e);
@@ -501,15 +515,12 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
             ntiles = 8 * (int)std::ceil(zbytes / (8.0 * tile_kb * 1024.0));
     }
     // Device build of the pair list (csrc/ps_host_build.h): pairs generated, sorted and left in HBM; the host receives the task
-    // starts and keys only.  PS_CREATE_DEVICE: 0 = host builder (the test oracle of the device build), 1 = device build from
-    // 200 000 observations up (default; below that the host builder is a fraction of a millisecond), 2 = always.
-    const int create_dev_env = ps_create_env("PS_CREATE_DEVICE") ? atoi(ps_create_env("PS_CREATE_DEVICE")) : 1;
-    const bool dev_pairs = gather_lists && create_dev_env != 0 && D == 6 && nr > 0 && nv > 0 && lm_ptr[nv] > 0 && !tiles_forced &&
-                           !ps_create_env("PS_PAIRS_BY_LANDMARK") && ntiles < 65536 && (create_dev_env == 2 || N >= 200000);
+    // starts and keys only.
+    const bool dev_pairs = gather_lists && dev_build && ntiles < 65536;
     DevPairBuild devb;
     std::vector<long> lm_pairs_before(nv + 1, 0);
     if (dev_pairs) {
-        if (h->arena_flush() || devb.prepare(h, nv, nr, (long)lm_ptr[nv])) return -1;
+        if (h->arena_flush() || devb.prepare(h, nv, nr, Nl)) return -1;
     } else {
         for (int v = 0; v < nv && gather_lists; ++v) {
             long nvar = 0;

@@ -83,6 +83,88 @@ __global__ __launch_bounds__(256) void k_build_gather_keys(int n, const int32_t*
     if (k < n) out[k] = (uint64_t)keys[idx[k]];
 }
 
+// ---- observation tables (landmark-sorted lobs / lorig / lm_ptr, landmark slots, pose-sorted pobs) -------------------------------
+// status word: 1 = an observation's pose / point / group index is out of range
+__global__ __launch_bounds__(256) void k_build_first_pose(long n, const int32_t* __restrict__ obs_pose, const int32_t* __restrict__ obs_point,
+                                                           const int32_t* __restrict__ obs_grp, int P, int L, int G, int32_t* __restrict__ first_pose,
+                                                           int32_t* __restrict__ bad)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int pose = obs_pose[i], pt = obs_point[i], grp = obs_grp[i];
+    if (pose < 0 || pose >= P || pt < 0 || pt >= L || grp < 0 || grp >= G) { *bad = 1; return; }
+    atomicMin(&first_pose[pt], pose);
+}
+// sort key of landmark (vid) v: the lowest pose that observes it (P: nobody does); value: v
+__global__ __launch_bounds__(256) void k_build_slot_keys(int nv, int P, const int32_t* __restrict__ point_of_vid, const int32_t* __restrict__ first_pose,
+                                                          uint32_t* __restrict__ key, uint32_t* __restrict__ val)
+{
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    const int32_t f = first_pose[point_of_vid[v]];
+    key[v] = (uint32_t)((f < 0 || f >= P) ? P : f);
+    val[v] = (uint32_t)v;
+}
+// slot s holds landmark vid_of_slot[s]: lm_point[s] = its point, point_slot[that point] = s (point_slot starts at -1)
+__global__ __launch_bounds__(256) void k_build_slots(int nv, const uint32_t* __restrict__ vid_of_slot, const int32_t* __restrict__ point_of_vid,
+                                                      int32_t* __restrict__ lm_point, int32_t* __restrict__ point_slot)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= nv) return;
+    const int32_t pt = point_of_vid[vid_of_slot[s]];
+    lm_point[s] = pt;
+    point_slot[pt] = s;
+}
+// landmark key of observation i: its slot, or nv + point for a constant point (behind every variable landmark); counts per slot
+__global__ __launch_bounds__(256) void k_build_obs_keys(long n, const int32_t* __restrict__ obs_point, const int32_t* __restrict__ point_slot, int nv,
+                                                         uint32_t* __restrict__ key, uint32_t* __restrict__ val, int32_t* __restrict__ lcount)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int pt = obs_point[i], s = point_slot[pt];
+    key[i] = (uint32_t)(s >= 0 ? s : nv + pt);
+    val[i] = (uint32_t)i;
+    if (s >= 0) atomicAdd(&lcount[s], 1);
+}
+// record k of the landmark order = observation order[k]; its reduced pose (nr: constant) is the key of the pose order
+__global__ __launch_bounds__(256) void k_build_lobs(long n, const uint32_t* __restrict__ order, const int32_t* __restrict__ obs_pose,
+                                                     const int32_t* __restrict__ obs_point, const int32_t* __restrict__ obs_grp,
+                                                     const double* __restrict__ obs_uvd, const int32_t* __restrict__ pose_rid, int nr,
+                                                     LObs* __restrict__ lobs, int32_t* __restrict__ lorig, uint32_t* __restrict__ pkey,
+                                                     uint32_t* __restrict__ pval, int32_t* __restrict__ pcount)
+{
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const long i = order[k];
+    const int pose = obs_pose[i];
+    LObs o;
+    o.u = obs_uvd[3 * i]; o.v = obs_uvd[3 * i + 1]; o.d = obs_uvd[3 * i + 2];
+    o.pose_grp = (int32_t)((uint32_t)pose | ((uint32_t)obs_grp[i] << 24));
+    o.point = obs_point[i];
+    lobs[k] = o;
+    lorig[k] = (int32_t)i;
+    const int r = pose_rid[pose];
+    pkey[k] = (uint32_t)(r >= 0 ? r : nr);
+    pval[k] = (uint32_t)k;
+    if (r >= 0) atomicAdd(&pcount[r], 1);
+}
+// pose-sorted copy: the pose bits (uniform per chunk) carry the landmark slot + 1
+__global__ __launch_bounds__(256) void k_build_pobs(long n, const uint32_t* __restrict__ pidx, const LObs* __restrict__ lobs,
+                                                     const int32_t* __restrict__ point_slot, LObs* __restrict__ pobs)
+{
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    LObs o = lobs[pidx[k]];
+    const int slot = point_slot[o.point];
+    o.pose_grp = (int32_t)(((uint32_t)PS_GRP_OF(o) << 24) | (uint32_t)(slot + 1));
+    pobs[k] = o;
+}
+__global__ __launch_bounds__(256) void k_build_fill_i32(long n, int32_t* __restrict__ p, int32_t v)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // scratch of one device build: freed when the build ends
 struct DevScratch {
     std::vector<void*> ptrs;
@@ -94,6 +176,85 @@ struct DevScratch {
         if (e != hipSuccess) return fail(std::string("hipMalloc (structure build): ") + hipGetErrorString(e));
         ptrs.push_back(p);
         *out = (T*)p;
+        return 0;
+    }
+};
+
+// The observation tables on the device: landmark slots (by first observing pose, ties by vid), observations in landmark order
+// (lobs / lorig / lm_ptr), in pose order (pobs), the per-pose counts back on the host.  Every ordering is a STABLE radix sort of
+// indices by the key the host builder's counting sorts use, so every table is the host builder's, bit for bit.
+struct DevObsBuild {
+    DevScratch scratch;
+    std::vector<int32_t> pcount;                // nr + 1: observations on variable poses before pose r (pose order)
+    long Nl = 0, Np = 0;
+    static int bits_for(uint64_t maxval) { int b = 1; while (b < 32 && (maxval >> b)) ++b; return b; }
+    template <typename T>
+    int input(ps_problem* h, const T* host_or_dev, bool resident, size_t n, const T** out) {
+        if (resident) { *out = host_or_dev; return 0; }
+        T* p = nullptr;
+        if (scratch.get(&p, n)) return -1;
+        if (n) HIP_OK(hipMemcpyAsync(p, host_or_dev, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+        *out = p;
+        return 0;
+    }
+    // d: the descriptor with HOST tables (staged if the caller's were resident); src: the caller's own descriptor (its obs_* are
+    // device pointers when PS_DESC_DEVICE_TABLES is set: used where they lie)
+    int run(ps_problem* h, const ps_problem_desc* d, const ps_problem_desc* src, int nr, int nv, const std::vector<int32_t>& point_of_vid,
+            std::vector<int32_t>& vid_of_slot) {
+        const long N = h->N;
+        const int P = h->P, L = h->L;
+        const bool res = (src->flags & PS_DESC_DEVICE_TABLES) != 0;
+        const int32_t *obs_pose, *obs_point, *obs_grp, *pov;
+        const double* obs_uvd;
+        if (input(h, res ? src->obs_pose : d->obs_pose, res, (size_t)N, &obs_pose) || input(h, res ? src->obs_point : d->obs_point, res, (size_t)N, &obs_point) ||
+            input(h, res ? src->obs_grp : d->obs_grp, res, (size_t)N, &obs_grp) || input(h, res ? src->obs_uvd : d->obs_uvd, res, 3 * (size_t)N, &obs_uvd) ||
+            input(h, point_of_vid.data(), false, (size_t)nv, &pov)) return -1;
+        const size_t M = (size_t)std::max<long>(N, nv);
+        int32_t *first_pose, *bad, *lcount, *pcount_dev, *pscan;
+        uint32_t *k0, *k1, *v0, *v1, *vos;
+        const size_t tmp_bytes = ps_sort_tmp_bytes(M + 1);
+        char* tmp;
+        if (scratch.get(&first_pose, (size_t)L) || scratch.get(&bad, 1) || scratch.get(&lcount, (size_t)nv + 1) || scratch.get(&pcount_dev, (size_t)nr + 1) ||
+            scratch.get(&pscan, (size_t)nr + 1) || scratch.get(&k0, M) || scratch.get(&k1, M) || scratch.get(&v0, M) || scratch.get(&v1, M) ||
+            scratch.get(&vos, (size_t)nv) || scratch.get(&tmp, tmp_bytes)) return -1;
+        if (h->alloc(&h->point_vid, (size_t)L, true) || h->alloc(&h->lm_point, (size_t)nv, true) || h->alloc(&h->lobs, (size_t)N, true) ||
+            h->alloc(&h->lorig, (size_t)N, true) || h->alloc(&h->lm_ptr, (size_t)nv + 1, true)) return -1;
+        hipStream_t st = h->stream;
+        HIP_OK(hipMemsetAsync(bad, 0, sizeof(int32_t), st));
+        HIP_OK(hipMemsetAsync(lcount, 0, ((size_t)nv + 1) * sizeof(int32_t), st));
+        HIP_OK(hipMemsetAsync(pcount_dev, 0, ((size_t)nr + 1) * sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_build_fill_i32, dim3(cdiv((long)L, 256)), dim3(256), 0, st, (long)L, first_pose, INT32_MAX);
+        hipLaunchKernelGGL(k_build_fill_i32, dim3(cdiv((long)L, 256)), dim3(256), 0, st, (long)L, h->point_vid, -1);
+        hipLaunchKernelGGL(k_build_first_pose, dim3(cdiv(N, 256)), dim3(256), 0, st, N, obs_pose, obs_point, obs_grp, P, L, d->num_obs_groups, first_pose, bad);
+        // an index out of range must be known before anything is indexed with it
+        int32_t bad_h = 0;
+        HIP_OK(hipMemcpyAsync(&bad_h, bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (bad_h) return fail("observation index out of range");
+        // landmark slots
+        hipLaunchKernelGGL(k_build_slot_keys, dim3(cdiv(nv, 256)), dim3(256), 0, st, nv, P, pov, first_pose, k0, v0);
+        HIP_OK(ps_sort_pairs_k32_v32(tmp, tmp_bytes, k0, k1, v0, vos, (size_t)nv, bits_for((uint64_t)P), st));
+        hipLaunchKernelGGL(k_build_slots, dim3(cdiv(nv, 256)), dim3(256), 0, st, nv, vos, pov, h->lm_point, h->point_vid);
+        vid_of_slot.resize((size_t)nv);
+        HIP_OK(hipMemcpyAsync(vid_of_slot.data(), vos, (size_t)nv * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        // landmark order
+        hipLaunchKernelGGL(k_build_obs_keys, dim3(cdiv(N, 256)), dim3(256), 0, st, N, obs_point, h->point_vid, nv, k0, v0, lcount);
+        HIP_OK(ps_sort_pairs_k32_v32(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)N, bits_for((uint64_t)nv + (uint64_t)L), st));
+        HIP_OK(ps_scan_exclusive_i32(tmp, tmp_bytes, lcount, h->lm_ptr, (size_t)nv + 1, st));
+        // records in landmark order + pose order
+        hipLaunchKernelGGL(k_build_lobs, dim3(cdiv(N, 256)), dim3(256), 0, st, N, v1, obs_pose, obs_point, obs_grp, obs_uvd, h->pose_rid, nr, h->lobs, h->lorig,
+                           k0, v0, pcount_dev);
+        HIP_OK(ps_sort_pairs_k32_v32(tmp, tmp_bytes, k0, k1, v0, v1, (size_t)N, bits_for((uint64_t)nr), st));
+        HIP_OK(ps_scan_exclusive_i32(tmp, tmp_bytes, pcount_dev, pscan, (size_t)nr + 1, st));
+        pcount.assign((size_t)nr + 1, 0);
+        int32_t nl = 0;
+        HIP_OK(hipMemcpyAsync(pcount.data(), pscan, ((size_t)nr + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(&nl, h->lm_ptr + nv, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        Nl = nl; Np = pcount[nr];
+        if (h->alloc(&h->pobs, (size_t)Np, true)) return -1;
+        if (Np) hipLaunchKernelGGL(k_build_pobs, dim3(cdiv(Np, 256)), dim3(256), 0, st, Np, v1, h->lobs, h->point_vid, h->pobs);
+        HIP_OK(hipStreamSynchronize(st));           // (the scratch is freed when this object goes)
         return 0;
     }
 };
@@ -124,7 +285,7 @@ struct DevPairBuild {
         tmp_bytes = ps_sort_tmp_bytes((size_t)nv + 1);
         void* t0 = nullptr;
         if (scratch.get((char**)&t0, tmp_bytes)) return -1;
-        hipLaunchKernelGGL(k_build_row_rid, dim3(cdiv(nrows, 256)), dim3(256), 0, h->stream, nrows, h->lobs, h->pose_rid, rid_row);
+        if (nrows) hipLaunchKernelGGL(k_build_row_rid, dim3(cdiv(nrows, 256)), dim3(256), 0, h->stream, nrows, h->lobs, h->pose_rid, rid_row);
         hipLaunchKernelGGL(k_build_pair_counts, dim3(cdiv(nv + 1, 256)), dim3(256), 0, h->stream, nv, h->lm_ptr, rid_row, cnt);
         HIP_OK(ps_scan_exclusive_i64(t0, tmp_bytes, cnt, before, (size_t)nv + 1, h->stream));
         HIP_OK(hipMemcpyAsync(&total, before + nv, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
