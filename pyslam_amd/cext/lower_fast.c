@@ -1,0 +1,129 @@
+/* lower_fast.c -- the walk over a Problem's reprojection blocks in C (CPython API; host code, no GPU).
+ *
+ * pyslam_amd/lowering.py: lower() turns the reference's object graph (one Python object per residual block, reference
+ * pyslam/problem.py:43-108) into flat tables once per solve.  For a bundle adjustment that is 5 x 10^5 blocks of ONE kind
+ * (ReprojectionResidual: pose key, landmark key, observation, shared camera / stiffness / loss), and the interpreter's
+ * ~0.6 us per block was what a cold Problem.solve() spent most of its wall clock in.  walk() takes a run of consecutive
+ * 'reproj' blocks straight into the column arrays; anything it does not recognise -- another kind of block, an unusual
+ * key, an observation that is not three contiguous doubles -- ends the run and is handed back to the Python loop, which
+ * treats that one block exactly as before (and raises what it raised before).  Same tables either way
+ * (tests/test_lowering_fast.py).
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+#include <string.h>
+
+static PyObject *s_KIND, *s_camera, *s_stiffness, *s_obs, *s_CAMERA_ID;
+
+typedef struct { PyObject *cam, *stiff, *loss; long g; } GroupSlot;
+
+/* walk(blocks, keys, losses, i0, param_dict, pose_ix, point_ix, group_of, o_pose, o_pt, o_uvd, o_g, count)
+ * -> (i, count): blocks i0 .. i-1 were taken; block i (if i < len) is for the caller */
+static PyObject* walk(PyObject* self, PyObject* args) {
+    PyObject *blocks, *keys, *losses, *param_dict, *pose_ix, *point_ix, *group_of, *a_pose, *a_pt, *a_uvd, *a_g;
+    Py_ssize_t i0, count;
+    if (!PyArg_ParseTuple(args, "OOOnOOOOOOOOn", &blocks, &keys, &losses, &i0, &param_dict, &pose_ix, &point_ix, &group_of,
+                          &a_pose, &a_pt, &a_uvd, &a_g, &count)) return NULL;
+    if (!PyList_Check(blocks) || !PyList_Check(keys) || !PyList_Check(losses) || !PyDict_Check(param_dict) ||
+        !PyDict_Check(pose_ix) || !PyDict_Check(point_ix))
+        return Py_BuildValue("nn", i0, count);
+    Py_buffer b_pose, b_pt, b_uvd, b_g;
+    if (PyObject_GetBuffer(a_pose, &b_pose, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS)) return NULL;
+    if (PyObject_GetBuffer(a_pt, &b_pt, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS)) { PyBuffer_Release(&b_pose); return NULL; }
+    if (PyObject_GetBuffer(a_uvd, &b_uvd, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS)) { PyBuffer_Release(&b_pose); PyBuffer_Release(&b_pt); return NULL; }
+    if (PyObject_GetBuffer(a_g, &b_g, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS)) { PyBuffer_Release(&b_pose); PyBuffer_Release(&b_pt); PyBuffer_Release(&b_uvd); return NULL; }
+    int32_t *o_pose = (int32_t*)b_pose.buf, *o_pt = (int32_t*)b_pt.buf, *o_g = (int32_t*)b_g.buf;
+    double* o_uvd = (double*)b_uvd.buf;
+    const Py_ssize_t cap = b_pose.len / 4;
+    Py_ssize_t n = PyList_GET_SIZE(blocks);
+    if (PyList_GET_SIZE(keys) < n) n = PyList_GET_SIZE(keys);
+    if (PyList_GET_SIZE(losses) < n) n = PyList_GET_SIZE(losses);
+    int failed = 0;
+    if (b_pt.len / 4 < cap || b_g.len / 4 < cap || b_uvd.len / 24 < cap) { PyErr_SetString(PyExc_ValueError, "lower_fast.walk: column arrays of different capacity"); failed = 1; }
+
+    PyTypeObject *reproj_tp = NULL, *other_tp = NULL;
+    PyObject* cam_ok = NULL;                 /* the camera whose CAMERA_ID was last found to be 0 or 1 (borrowed; compared by address only) */
+    GroupSlot slots[4];
+    int nslots = 0;
+    Py_ssize_t i = i0;
+    for (; i < n && !failed; ++i) {
+        if (count >= cap) break;
+        PyObject* block = PyList_GET_ITEM(blocks, i);
+        PyTypeObject* tp = Py_TYPE(block);
+        if (tp != reproj_tp) {
+            if (tp == other_tp) break;
+            PyObject* kind = PyObject_GetAttr(block, s_KIND);
+            if (!kind) { PyErr_Clear(); break; }
+            const int is_reproj = PyUnicode_Check(kind) && PyUnicode_CompareWithASCIIString(kind, "reproj") == 0;
+            Py_DECREF(kind);
+            if (!is_reproj) { other_tp = tp; break; }
+            reproj_tp = tp;
+        }
+        PyObject* ks = PyList_GET_ITEM(keys, i);
+        PyObject *k0, *k1;
+        if (PyList_Check(ks) && PyList_GET_SIZE(ks) == 2) { k0 = PyList_GET_ITEM(ks, 0); k1 = PyList_GET_ITEM(ks, 1); }
+        else if (PyTuple_Check(ks) && PyTuple_GET_SIZE(ks) == 2) { k0 = PyTuple_GET_ITEM(ks, 0); k1 = PyTuple_GET_ITEM(ks, 1); }
+        else break;
+        int c0 = PyDict_Contains(param_dict, k0), c1 = c0 == 1 ? PyDict_Contains(param_dict, k1) : 0;
+        if (c0 != 1 || c1 != 1) { PyErr_Clear(); break; }
+        PyObject* pi = PyDict_GetItemWithError(pose_ix, k0);       /* borrowed */
+        PyObject* qi = pi ? PyDict_GetItemWithError(point_ix, k1) : NULL;
+        if (!pi || !qi) { PyErr_Clear(); break; }
+        PyObject* cam = PyObject_GetAttr(block, s_camera);
+        if (!cam) { PyErr_Clear(); break; }
+        if (cam != cam_ok) {
+            PyObject* cid = PyObject_GetAttr(cam, s_CAMERA_ID);
+            long v = -1;
+            if (cid) { v = PyLong_Check(cid) ? PyLong_AsLong(cid) : -1; Py_DECREF(cid); }
+            PyErr_Clear();
+            if (v != 0 && v != 1) { Py_DECREF(cam); break; }
+            cam_ok = cam;
+        }
+        PyObject* stiff = PyObject_GetAttr(block, s_stiffness);
+        if (!stiff) { PyErr_Clear(); Py_DECREF(cam); break; }
+        PyObject* loss = PyList_GET_ITEM(losses, i);
+        long g = -1;
+        for (int q = 0; q < nslots; ++q)
+            if (slots[q].cam == cam && slots[q].stiff == stiff && slots[q].loss == loss) { g = slots[q].g; break; }
+        if (g < 0) {
+            /* the Python side owns the group table (and its checks): identity-keyed, so the three objects stay alive there */
+            PyObject* r = PyObject_CallFunctionObjArgs(group_of, cam, block, loss, NULL);
+            if (!r) { Py_DECREF(cam); Py_DECREF(stiff); failed = 1; break; }
+            g = PyLong_AsLong(r);
+            Py_DECREF(r);
+            if (g < 0) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "lower_fast.walk: bad group index"); Py_DECREF(cam); Py_DECREF(stiff); failed = 1; break; }
+            GroupSlot* sl = &slots[nslots < 4 ? nslots++ : (int)(i & 3)];
+            sl->cam = cam; sl->stiff = stiff; sl->loss = loss; sl->g = g;
+        }
+        Py_DECREF(cam); Py_DECREF(stiff);          /* (still referenced by the block; the slots compare addresses only) */
+        PyObject* obs = PyObject_GetAttr(block, s_obs);
+        if (!obs) { PyErr_Clear(); break; }
+        Py_buffer ov;
+        if (PyObject_GetBuffer(obs, &ov, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS)) { PyErr_Clear(); Py_DECREF(obs); break; }
+        const int good = ov.itemsize == 8 && ov.len == 24 && ov.format && (strcmp(ov.format, "d") == 0 || strcmp(ov.format, "=d") == 0 || strcmp(ov.format, "<d") == 0);
+        if (good) memcpy(o_uvd + 3 * count, ov.buf, 24);
+        PyBuffer_Release(&ov);
+        Py_DECREF(obs);
+        if (!good) break;
+        const long pv = PyLong_AsLong(pi), qv = PyLong_AsLong(qi);
+        if ((pv == -1 || qv == -1) && PyErr_Occurred()) { PyErr_Clear(); break; }
+        o_pose[count] = (int32_t)pv; o_pt[count] = (int32_t)qv; o_g[count] = (int32_t)g;
+        ++count;
+    }
+    PyBuffer_Release(&b_pose); PyBuffer_Release(&b_pt); PyBuffer_Release(&b_uvd); PyBuffer_Release(&b_g);
+    if (failed) return NULL;
+    return Py_BuildValue("nn", i, count);
+}
+
+static PyMethodDef methods[] = {
+    {"walk", walk, METH_VARARGS, "take a run of consecutive reprojection blocks into the column arrays; returns (next block, count)"},
+    {NULL, NULL, 0, NULL}};
+static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_lower_fast", NULL, -1, methods};
+
+PyMODINIT_FUNC PyInit__lower_fast(void) {
+    s_KIND = PyUnicode_InternFromString("KIND"); s_camera = PyUnicode_InternFromString("camera");
+    s_stiffness = PyUnicode_InternFromString("stiffness"); s_obs = PyUnicode_InternFromString("obs");
+    s_CAMERA_ID = PyUnicode_InternFromString("CAMERA_ID");
+    return PyModule_Create(&moddef);
+}

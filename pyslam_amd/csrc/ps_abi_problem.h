@@ -80,9 +80,10 @@ int ps_problem_destroy(ps_problem* h) {
     return 0;
 }
 
-// ps_problem_desc::flags & PS_DESC_DEVICE_TABLES: the structure pass below walks the index tables on the host, so resident
-// tables are brought over once (one D2H copy each, no pinned staging on the caller's side); the parameter tables
-// (PS_DESC_DEVICE_PARAMS) never leave the device.
+// ps_problem_desc::flags & PS_DESC_DEVICE_TABLES: the small tables (groups, factors, index maps) are walked on the host, so they are
+// brought over once (one D2H copy each, no pinned staging on the caller's side); the observation columns stay where they are when
+// the structure is built on the device (csrc/ps_host_build.h reads them in place) and come over only for the host builder; the
+// parameter tables (PS_DESC_DEVICE_PARAMS) never leave the device.
 struct DescStage {
     ps_problem_desc d;
     std::vector<std::vector<char>> bufs;
@@ -96,14 +97,21 @@ struct DescStage {
     }
     int pull(const double** f, size_t n) { return pull_bytes((const void**)f, n * sizeof(double)); }
     int pull(const int32_t** f, size_t n) { return pull_bytes((const void**)f, n * sizeof(int32_t)); }
+    bool obs_pending = false;
+    int pull_obs() {
+        if (!obs_pending) return 0;
+        obs_pending = false;
+        const size_t N = (size_t)std::max<int64_t>(0, d.num_obs);
+        return pull(&d.obs_pose, N) || pull(&d.obs_point, N) || pull(&d.obs_uvd, 3 * N) || pull(&d.obs_grp, N);
+    }
     int stage(const ps_problem_desc* in) {
         d = *in;
         if (!(d.flags & PS_DESC_DEVICE_TABLES)) return 0;
         const size_t P = std::max(0, d.num_poses), L = std::max(0, d.num_points), N = (size_t)std::max<int64_t>(0, d.num_obs);
         const size_t E = (size_t)std::max<int64_t>(0, d.num_edges), Q = (size_t)std::max<int64_t>(0, d.num_priors);
         const size_t X = (size_t)std::max<int64_t>(0, d.num_extra_pairs), PW = d.dof == 6 ? 12 : 6, DD = (size_t)d.dof * d.dof;
-        return pull(&d.pose_rid, P) || pull(&d.point_vid, L) || pull(&d.obs_pose, N) || pull(&d.obs_point, N) || pull(&d.obs_uvd, 3 * N) ||
-               pull(&d.obs_grp, N) || pull(&d.cams, 5 * (size_t)std::max(0, d.num_cams)) || pull(&d.stiff3, 9 * (size_t)std::max(0, d.num_stiff3)) ||
+        obs_pending = N > 0;       // the observation columns come over only if the HOST builder is going to walk them (pull_obs)
+        return pull(&d.pose_rid, P) || pull(&d.point_vid, L) || pull(&d.cams, 5 * (size_t)std::max(0, d.num_cams)) || pull(&d.stiff3, 9 * (size_t)std::max(0, d.num_stiff3)) ||
                pull(&d.obs_groups, 4 * (size_t)std::max(0, d.num_obs_groups)) || pull(&d.e_i, E) || pull(&d.e_j, E) ||
                pull(&d.e_Tobs_inv, PW * E) || pull(&d.e_grp, E) || pull(&d.u_i, Q) || pull(&d.u_Tobs_inv, PW * Q) || pull(&d.u_grp, Q) ||
                pull(&d.stiffd, DD * (size_t)std::max(0, d.num_stiffd)) || pull(&d.edge_groups, 3 * (size_t)std::max(0, d.num_edge_groups)) ||
@@ -175,6 +183,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
                            !(ps_create_env("PS_SCHUR_MODE") && atoi(ps_create_env("PS_SCHUR_MODE")) != 0) &&
                            !(ps_create_env("PS_SCHUR_STREAM") && atoi(ps_create_env("PS_SCHUR_STREAM")) != 0) &&
                            !ps_create_env("PS_SCHUR_TILE_KB") && !ps_create_env("PS_PAIRS_BY_LANDMARK");
+    if (!dev_build && staged.pull_obs()) return -1;
     std::vector<int32_t> first_pose(dev_build ? 0 : L, INT32_MAX);
     if (!dev_build)
     {

@@ -258,6 +258,42 @@ def _loss_id_k(loss):
     return float(loss.LOSS_ID), float(getattr(loss, 'k', 0.))
 
 
+_FAST = [False, None]        # [looked for, the C walk or None]
+
+
+def _fast_walk():
+    """pyslam_amd/cext/lower_fast.c (built by __graft_entry__.build() into pyslam_amd/lib/_lower_fast.so, or here on first use
+    when a C compiler is at hand): the walk over runs of reprojection blocks.  None -- every block through the Python loop,
+    same tables -- when it cannot be had or PYSLAM_AMD_LOWER_FAST=0."""
+    if not _FAST[0]:
+        _FAST[0] = True
+        import os
+        if os.environ.get('PYSLAM_AMD_LOWER_FAST', '1') != '0':
+            try:
+                _FAST[1] = _load_fast_walk()
+            except Exception:       # noqa: BLE001 (no compiler, no headers: the Python loop does the same job)
+                _FAST[1] = None
+    return _FAST[1]
+
+
+def _load_fast_walk(rebuild=False):
+    import importlib.machinery
+    import importlib.util
+    import os
+    import subprocess
+    import sysconfig
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, out = os.path.join(here, 'cext', 'lower_fast.c'), os.path.join(here, 'lib', '_lower_fast.so')
+    if rebuild or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run(['gcc', '-O2', '-shared', '-fPIC', '-I' + sysconfig.get_paths()['include'], src, '-o', out], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    spec = importlib.util.spec_from_file_location('_lower_fast', out, loader=importlib.machinery.ExtensionFileLoader('_lower_fast', out))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.walk
+
+
 def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
           constant_param_keys):
     """Build a LoweredProblem from the registries of a Problem."""
@@ -304,15 +340,42 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
 
     cams, st3, std = _Interner(), _Interner(), _Interner()
     ogrp, egrp = _Interner(), _Interner()
-    o_pose, o_pt, o_uvd, o_g = [], [], [], []      # single-observation blocks, one entry each
+    # single-observation blocks, one entry each: columns of capacity len(residual_blocks), `cnt` filled
+    n_blocks = min(len(residual_blocks), len(block_param_keys), len(block_loss_functions))
+    o_pose, o_pt, o_g = np.empty(n_blocks, dtype=I32), np.empty(n_blocks, dtype=I32), np.empty(n_blocks, dtype=I32)
+    o_uvd = np.empty((n_blocks, 3), dtype=F64)
+    cnt = 0
     c_pose, c_pt, c_uvd, c_g = [], [], [], []      # batch blocks, one array each (appended after the single ones)
     e_i, e_j, e_T, e_g = [], [], [], []
     u_i, u_T, u_g = [], [], []
     L0 = len(point_keys)
     ogrp_cache, egrp_cache = {}, {}   # keyed by object identity: O(1) per block
 
-    for block, keys, loss in zip(residual_blocks, block_param_keys, block_loss_functions):
+    def obs_group(cam, block, loss):
+        gkey = (id(cam), id(block.stiffness), id(loss))
+        g = ogrp_cache.get(gkey)
+        if g is None:
+            if np.size(block.stiffness) != 9:
+                raise NotLowerable("reprojection stiffness must be 3x3")
+            lid, lk = _loss_id_k(loss)
+            g = ogrp.add([cams.add(cam.intrinsics()), st3.add(block.stiffness), lid, lk])
+            ogrp_cache[gkey] = g
+        return g
+
+    walk = _fast_walk() if dof == 6 and isinstance(residual_blocks, list) else None
+    i = -1
+    while i + 1 < n_blocks:
+        i += 1
+        block, keys, loss = residual_blocks[i], block_param_keys[i], block_loss_functions[i]
         kind = getattr(block, 'KIND', 'generic')
+        if kind == 'reproj' and walk is not None:
+            # a run of consecutive reprojection blocks in C (pyslam_amd/cext/lower_fast.c); it stops at the first block it
+            # does not take, which then goes through the general path below
+            nxt, cnt = walk(residual_blocks, block_param_keys, block_loss_functions, i, param_dict, pose_ix, point_ix, obs_group,
+                            o_pose, o_pt, o_uvd, o_g, cnt)
+            if nxt > i:
+                i = nxt - 1
+                continue
         for k in keys:
             if k not in param_dict:
                 raise KeyError(k)
@@ -322,21 +385,13 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
                 raise NotLowerable("camera {} has no device restatement".format(type(cam).__name__))
             if dof != 6 or keys[0] not in pose_ix:
                 raise NotLowerable("reprojection block needs an SE(3) pose first")
-            gkey = (id(cam), id(block.stiffness), id(loss))
-            g = ogrp_cache.get(gkey)
-            if g is None:
-                if np.size(block.stiffness) != 9:
-                    raise NotLowerable("reprojection stiffness must be 3x3")
-                lid, lk = _loss_id_k(loss)
-                g = ogrp.add([cams.add(cam.intrinsics()), st3.add(block.stiffness), lid, lk])
-                ogrp_cache[gkey] = g
+            g = obs_group(cam, block, loss)
             if kind == 'reproj':
                 if keys[1] not in point_ix:
                     raise NotLowerable("reprojection block needs a 3-vector landmark second")
-                o_pose.append(pose_ix[keys[0]])
-                o_pt.append(point_ix[keys[1]])
-                o_uvd.append(np.asarray(block.obs, dtype=F64))
-                o_g.append(g)
+                o_pose[cnt], o_pt[cnt], o_g[cnt] = pose_ix[keys[0]], point_ix[keys[1]], g
+                o_uvd[cnt] = np.asarray(block.obs, dtype=F64).reshape(3)
+                cnt += 1
             else:
                 # whole block at once (the per-frame Problem of pipelines/sparse.py:153-161 is ONE batch block of
                 # ~10^3 points: a Python loop over them was 0.9 ms of a 2 ms solve)
@@ -408,14 +463,14 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
     lp.poses, lp.pose_rid = poses, rid
     lp.points = np.concatenate([np.array(points, dtype=F64).reshape(-1, 3)] + fixed_points)
     lp.point_vid = np.array(vid + [-1] * n_fixed, dtype=I32)
+    o_pose, o_pt, o_g, o_uvd = o_pose[:cnt], o_pt[:cnt], o_g[:cnt], o_uvd[:cnt]
     if c_pose:
-        one = lambda col: [np.asarray(col, dtype=I32)] if col else []
+        one = lambda col: [col] if cnt else []
         lp.obs_pose, lp.obs_point = np.concatenate(one(o_pose) + c_pose), np.concatenate(one(o_pt) + c_pt)
         lp.obs_grp = np.concatenate(one(o_g) + c_g)
-        lp.obs_uvd = np.concatenate(([np.array(o_uvd, dtype=F64).reshape(-1, 3)] if o_uvd else []) + c_uvd)
+        lp.obs_uvd = np.concatenate(one(o_uvd) + c_uvd)
     else:
-        lp.obs_pose, lp.obs_point, lp.obs_grp = o_pose, o_pt, o_g
-        lp.obs_uvd = np.array(o_uvd).reshape(-1, 3)
+        lp.obs_pose, lp.obs_point, lp.obs_grp, lp.obs_uvd = o_pose, o_pt, o_g, o_uvd
     lp.cams, lp.stiff3, lp.obs_groups = cams.table(5), st3.table(9), ogrp.table(4)
     lp.e_i, lp.e_j, lp.e_grp = e_i, e_j, e_g
     lp.e_Tobs_inv = np.array(e_T).reshape(-1, pw)

@@ -1,0 +1,140 @@
+"""The C walk over runs of reprojection blocks (pyslam_amd/cext/lower_fast.c) against the Python loop of
+pyslam_amd/lowering.py: the same LoweredProblem, table by table, on problems that mix block kinds, key containers and
+observation containers, and the same exceptions.  Host logic; no GPU.  (What the walk replaces: the reference's per-iteration
+walk over its block objects, pyslam/problem.py:279-360, done once per solve here.)"""
+import types
+
+import numpy as np
+import pytest
+
+import liegroups as G
+import pyslam.losses as Ls
+import pyslam.problem as P
+import pyslam.residuals as R
+import pyslam.sensors as S
+from pyslam_amd import lowering, synthetic
+
+NS = types.SimpleNamespace(Problem=P.Problem, Options=P.Options, StereoCamera=S.StereoCamera, PoseResidual=R.PoseResidual,
+                           PoseToPoseResidual=R.PoseToPoseResidual, PoseToPoseOrientationResidual=R.PoseToPoseOrientationResidual,
+                           ReprojectionResidual=R.ReprojectionResidual, L2Loss=Ls.L2Loss, L1Loss=Ls.L1Loss, CauchyLoss=Ls.CauchyLoss,
+                           HuberLoss=Ls.HuberLoss, TukeyLoss=Ls.TukeyLoss, TDistributionLoss=Ls.TDistributionLoss,
+                           SE3=G.SE3, SO3=G.SO3, SE2=G.SE2, SO2=G.SO2)
+TABLES = ['poses', 'pose_rid', 'points', 'point_vid', 'obs_pose', 'obs_point', 'obs_uvd', 'obs_grp', 'cams', 'stiff3', 'obs_groups',
+          'e_i', 'e_j', 'e_Tobs_inv', 'e_grp', 'u_i', 'u_Tobs_inv', 'u_grp', 'stiffd', 'edge_groups']
+
+
+def _walk_available():
+    lowering._FAST[:] = [False, None]
+    return lowering._fast_walk() is not None
+
+
+def _both(problem):
+    """(tables with the C walk, tables with the Python loop)"""
+    assert _walk_available(), 'pyslam_amd/lib/_lower_fast.so could not be built or loaded'
+    fast = problem._lower()
+    lowering._FAST[:] = [True, None]
+    try:
+        slow = problem._lower()
+    finally:
+        lowering._FAST[:] = [False, None]
+    return fast, slow
+
+
+def _same(a, b):
+    for name in TABLES:
+        x, y = getattr(a, name), getattr(b, name)
+        assert np.asarray(x).dtype == np.asarray(y).dtype and np.array_equal(np.asarray(x), np.asarray(y)), name
+    assert a.pose_keys == b.pose_keys and a.point_keys == b.point_keys
+
+
+def test_bundle_adjustment_tables_are_the_python_loops():
+    lp, _ = synthetic.stereo_ba(num_kf=12, num_lm=700, obs_per_lm=5, half_window=4, seed=3)
+    fast, slow = _both(synthetic.to_objects(lp, NS))
+    _same(fast, slow)
+    assert fast.num_obs == lp.num_obs and np.array_equal(fast.obs_uvd, lp.obs_uvd)
+
+
+def test_mixed_kinds_key_containers_and_observation_containers():
+    """Pose-graph blocks between the reprojection blocks (the run ends and starts again), keys as tuples, observations as
+    lists / float32 / non-contiguous views (handed back to the Python loop block by block), two cameras, three losses."""
+    lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=120, obs_per_lm=4, half_window=3, seed=4)
+    problem = synthetic.to_objects(lp, NS)
+    cam2 = S.StereoCamera(300., 200., 500., 510., 0.3, 1280, 960)
+    losses = [Ls.HuberLoss(1.5), Ls.CauchyLoss(2.0), problem.block_loss_functions[0]]
+    wide = np.zeros((7, 6))
+    for i, (block, keys) in enumerate(zip(problem.residual_blocks, problem.block_param_keys)):
+        if getattr(block, 'KIND', '') != 'reproj':
+            continue
+        if i % 5 == 0:
+            problem.block_param_keys[i] = tuple(keys)
+        if i % 7 == 0:
+            block.obs = list(block.obs)
+        elif i % 7 == 1:
+            block.obs = block.obs.astype(np.float32)
+        elif i % 7 == 2:
+            wide[i % 7, ::2] = block.obs
+            block.obs = wide[i % 7, ::2].copy()[::1]
+        elif i % 7 == 3:
+            block.obs = np.stack([block.obs, block.obs])[:, :][0:2][1]        # a row view: still contiguous
+        elif i % 7 == 4:
+            block.obs = np.asfortranarray(np.stack([block.obs, 2 * block.obs]).T)[:, 0]    # strided view
+        if i % 11 == 0:
+            block.camera = cam2
+        problem.block_loss_functions[i] = losses[i % 3]
+    # pose-graph blocks in the middle of the list
+    T = G.SE3.exp(0.01 * np.arange(6))
+    mid = len(problem.residual_blocks) // 2
+    problem.residual_blocks.insert(mid, R.PoseToPoseResidual(T, np.eye(6)))
+    problem.block_param_keys.insert(mid, ['T_cam1_w', 'T_cam2_w'])
+    problem.block_loss_functions.insert(mid, Ls.L2Loss())
+    problem.residual_blocks.insert(3, R.PoseResidual(T, 2 * np.eye(6)))
+    problem.block_param_keys.insert(3, ['T_cam3_w'])
+    problem.block_loss_functions.insert(3, Ls.L2Loss())
+    fast, slow = _both(problem)
+    _same(fast, slow)
+    assert fast.num_edges == 1 and fast.num_priors == 1 and len(fast.cams) == 2 and len(fast.obs_groups) >= 6
+
+
+def test_motion_only_batch_blocks_between_single_observations():
+    lp, _ = synthetic.stereo_ba(num_kf=5, num_lm=60, obs_per_lm=3, half_window=2, seed=5)
+    problem = synthetic.to_objects(lp, NS)
+    cam = problem.residual_blocks[-1].camera
+    obs1 = np.array([[640., 480., 12.], [600., 470., 9.], [500., 400., 20.]])
+    batch = R.ReprojectionMotionOnlyBatchResidual(cam, obs1, obs1 + 0.5, np.eye(3))
+    problem.residual_blocks.insert(10, batch)
+    problem.block_param_keys.insert(10, ['T_cam1_w'])
+    problem.block_loss_functions.insert(10, Ls.L2Loss())
+    fast, slow = _both(problem)
+    _same(fast, slow)
+    assert fast.num_points == lp.num_points + 3
+
+
+@pytest.mark.parametrize('what', ['unknown_key', 'camera', 'landmark_is_a_pose', 'stiffness'])
+def test_errors_are_the_python_loops(what):
+    lp, _ = synthetic.stereo_ba(num_kf=5, num_lm=40, obs_per_lm=3, half_window=2, seed=6)
+    problem = synthetic.to_objects(lp, NS)
+    k = 17
+    if what == 'unknown_key':
+        problem.block_param_keys[k] = [problem.block_param_keys[k][0], 'no such landmark']
+        exc = KeyError
+    elif what == 'camera':
+        class OtherCamera:
+            pass
+        problem.residual_blocks[k].camera = OtherCamera()
+        exc = lowering.NotLowerable
+    elif what == 'landmark_is_a_pose':
+        problem.block_param_keys[k] = ['T_cam1_w', 'T_cam2_w']
+        exc = lowering.NotLowerable
+    else:
+        problem.residual_blocks[k].stiffness = np.eye(2)
+        exc = lowering.NotLowerable
+    assert _walk_available()
+    with pytest.raises(exc) as e_fast:
+        problem._lower()
+    lowering._FAST[:] = [True, None]
+    try:
+        with pytest.raises(exc) as e_slow:
+            problem._lower()
+    finally:
+        lowering._FAST[:] = [False, None]
+    assert str(e_fast.value) == str(e_slow.value)
