@@ -234,7 +234,11 @@ int build_coarse(ps_problem* h) {
     // iteration on.  Pose-graph-like rows (C2: 11 blocks per row, hundreds of CG iterations): one interval per 25
     // poses, up to 400 (C2, 10 000 poses: 250 / 333 / 400 / 500 intervals give 128 / 97 / 84 / 72 CG iterations and
     // 4.4 / 3.8 / 3.7 / 3.9 ms -- beyond 400 the dense fp32 inverse and its band substitutions cost more than they
-    // save; the banded factorisation of ps_k_band.h is what makes more than 255 affordable); bundle-adjustment rows (C4: 80 blocks per row, ~20 iterations -- the factorisation must fit
+    // save; the banded factorisation of ps_k_band.h is what makes more than 255 affordable.  Round 4, with the right-looking
+    // band substitutions (k_band_inverse_rl: 0.4 instead of 1.0 ms at C2) and cold, reference-terminated solves as the measure: one
+    // interval per 20 poses, up to 500 -- ms per iteration at 1 500 / 3 000 / 5 000 / 10 000 poses 1.57 -> 1.23 / 2.34 -> 2.15 /
+    // 2.63 -> 2.32 / 3.90 -> 3.74; finer still (one per 12-15) costs more in the set-up of calls 1-3 than its iterations save);
+    // bundle-adjustment rows (C4: 80 blocks per row, ~20 iterations -- the factorisation must fit
     // beside a short CG): one per 20 poses, up to 112 (C4: 42 iterations / 3.7 ms folded at 48 -> 20 / 2.6 ms at 100).
     // Measured crossover against the folded single-launch CG (whose coarse level is capped at 12 intervals):
     // pose graphs 400 poses (600: 2.6 -> 1.4 ms, 1 000: 6.1 -> 1.5 ms), bundle adjustment 540 (700: 1.67 -> 1.28 ms).
@@ -249,7 +253,7 @@ int build_coarse(ps_problem* h) {
     const int xmin = std::min(h->cg_split_min_rows, h->cg_explicit_min_rows >= 0 ? h->cg_explicit_min_rows : xmin_auto);
     h->cg_explicit = h->explicit_ok && G != 0 && nr > xmin;
     if (h->cg_explicit && h->coarse_req < 0)
-        G = sparse_rows ? std::min(400, std::max(48, nr / 25)) : std::min(112, std::max(48, nr / 20));
+        G = sparse_rows ? std::min(500, std::max(48, nr / 20)) : std::min(112, std::max(48, nr / 20));
     G = std::min(G, h->cg_explicit ? PS_XCG_MAXNODES - 1 : Gmax);
     if (h->coarse_clamped && h->coarse_req < 0) G = std::min(G, 255);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;

@@ -333,6 +333,14 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
         // (+ 3 spare launches behind a step that changed the cost by more than 5 %: the lagged coarse inverse is from the other side of it)
         const bool big_step_x = h->prev_cost > 0.0 && h->last_cost > 0.0 && std::fabs(h->prev_cost - h->last_cost) > 0.05 * h->prev_cost;
         int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + 2 + (big_step_x ? 3 : 0) : 32;
+        // The call behind a big step ran with a coarse inverse from the other side of it and took far more iterations than its
+        // neighbours (10 000-pose graph, cold: 71 / 111 / 77 / 75 / 72; 1 500 poses 70 / 122 / 87 / 86; BA barely: 19 / 20 / 20):
+        // predicting the next call from THAT count enqueued ~36 iterations past convergence, and a launch that finds the solve done
+        // still costs its prefetch (12 us each at that size: 0.9 ms of the third call).  Behind such a spike the call before it is the
+        // better guide -- the third call needs up to a quarter more than the first across 600 .. 10 000 poses -- and a short second
+        // round costs one host round trip (~40 us) where an overshoot costs 25 us per iteration.
+        const bool spike = h->prev_pcg_iters > 0 && h->last_pcg_iters > h->prev_pcg_iters + 16;
+        if (spike) count = h->prev_pcg_iters + h->prev_pcg_iters / 4 + 2;
         for (;;) {
             count = std::min(count, max_iters + 1 - h->cg_launched);
             // (the side-stream factorisation goes in after the first few iterations' launches: early enough to
@@ -364,7 +372,7 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
                 if (gn_tail(h, linesearch, nullptr, true) || wait_published(h)) return -1;
                 break;
             }
-            count = std::max(8, h->cg_launched / 2);
+            count = std::max(8, h->cg_launched / (spike ? 8 : 2));
         }
         if (cg_report(h, iters_out, relres_out)) return -1;
         if (h->xcg_ref_pending) { h->xcg_ref_pending = false; h->xcg_its_ref = h->last_pcg_iters; }
