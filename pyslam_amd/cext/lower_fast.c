@@ -116,7 +116,98 @@ static PyObject* walk(PyObject* self, PyObject* args) {
     return Py_BuildValue("nn", i, count);
 }
 
+/* classify(param_dict, pose_types: tuple, ndarray_type) -> (pose_keys, point_keys, offending key or None): the dictionary's keys in
+ * its own order, split into poses (instances of pose_types) and landmarks (ndarrays of shape (3,)); stops at the first value that
+ * is neither */
+static PyObject* classify(PyObject* self, PyObject* args) {
+    PyObject *param_dict, *pose_types, *nd_type;
+    if (!PyArg_ParseTuple(args, "O!OO", &PyDict_Type, &param_dict, &pose_types, &nd_type)) return NULL;
+    PyObject *poses = PyList_New(0), *points = PyList_New(0), *badkey = Py_None;
+    if (!poses || !points) { Py_XDECREF(poses); Py_XDECREF(points); return NULL; }
+    Py_ssize_t pos = 0;
+    PyObject *key, *val;
+    PyTypeObject* last_pose_tp = NULL;
+    while (PyDict_Next(param_dict, &pos, &key, &val)) {
+        int is_pose = Py_TYPE(val) == last_pose_tp;
+        if (!is_pose && (PyObject*)Py_TYPE(val) != nd_type) {
+            is_pose = PyObject_IsInstance(val, pose_types);
+            if (is_pose < 0) { Py_DECREF(poses); Py_DECREF(points); return NULL; }
+            if (is_pose) last_pose_tp = Py_TYPE(val);
+        }
+        if (is_pose) { if (PyList_Append(poses, key)) { Py_DECREF(poses); Py_DECREF(points); return NULL; } continue; }
+        int ok = 0;
+        const int is_nd = (PyObject*)Py_TYPE(val) == nd_type ? 1 : PyObject_IsInstance(val, nd_type);
+        if (is_nd < 0) { Py_DECREF(poses); Py_DECREF(points); return NULL; }
+        if (is_nd) {
+            Py_buffer v;
+            if (PyObject_GetBuffer(val, &v, PyBUF_STRIDES) == 0) { ok = v.ndim == 1 && v.shape[0] == 3; PyBuffer_Release(&v); }
+            else PyErr_Clear();
+        }
+        if (!ok) { badkey = key; break; }
+        if (PyList_Append(points, key)) { Py_DECREF(poses); Py_DECREF(points); return NULL; }
+    }
+    return Py_BuildValue("NNO", poses, points, badkey);
+}
+
+static int is_f64x3(const Py_buffer* v) {
+    return v->itemsize == 8 && v->len == 24 && v->format && (strcmp(v->format, "d") == 0 || strcmp(v->format, "=d") == 0 || strcmp(v->format, "<d") == 0);
+}
+
+/* gather3(param_dict, keys: list, dst: (n, 3) float64) -> list of the indices NOT copied (value is not three contiguous doubles) */
+static PyObject* gather3(PyObject* self, PyObject* args) {
+    PyObject *param_dict, *keys, *dst;
+    if (!PyArg_ParseTuple(args, "O!O!O", &PyDict_Type, &param_dict, &PyList_Type, &keys, &dst)) return NULL;
+    Py_buffer b;
+    if (PyObject_GetBuffer(dst, &b, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS)) return NULL;
+    const Py_ssize_t n = PyList_GET_SIZE(keys);
+    PyObject* rest = PyList_New(0);
+    if (!rest || b.len < 24 * n) { PyBuffer_Release(&b); Py_XDECREF(rest); if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "gather3: destination too small"); return NULL; }
+    double* out = (double*)b.buf;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* val = PyDict_GetItemWithError(param_dict, PyList_GET_ITEM(keys, i));
+        int done = 0;
+        Py_buffer v;
+        if (val && PyObject_GetBuffer(val, &v, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) == 0) {
+            if (is_f64x3(&v)) { memcpy(out + 3 * i, v.buf, 24); done = 1; }
+            PyBuffer_Release(&v);
+        }
+        PyErr_Clear();
+        if (!done) { PyObject* ix = PyLong_FromSsize_t(i); if (!ix || PyList_Append(rest, ix)) { Py_XDECREF(ix); Py_DECREF(rest); PyBuffer_Release(&b); return NULL; } Py_DECREF(ix); }
+    }
+    PyBuffer_Release(&b);
+    return rest;
+}
+
+/* scatter3(param_dict, keys: list, src: (n, 3) float64) -> list of the indices NOT written (value is not a writable array of three
+ * contiguous doubles): val[...] = src[i] for the others */
+static PyObject* scatter3(PyObject* self, PyObject* args) {
+    PyObject *param_dict, *keys, *src;
+    if (!PyArg_ParseTuple(args, "O!O!O", &PyDict_Type, &param_dict, &PyList_Type, &keys, &src)) return NULL;
+    Py_buffer b;
+    if (PyObject_GetBuffer(src, &b, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT)) return NULL;
+    const Py_ssize_t n = PyList_GET_SIZE(keys);
+    PyObject* rest = PyList_New(0);
+    if (!rest || b.len < 24 * n || b.itemsize != 8) { PyBuffer_Release(&b); Py_XDECREF(rest); if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "scatter3: source too small"); return NULL; }
+    const double* in = (const double*)b.buf;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* val = PyDict_GetItemWithError(param_dict, PyList_GET_ITEM(keys, i));
+        int done = 0;
+        Py_buffer v;
+        if (val && PyObject_GetBuffer(val, &v, PyBUF_WRITABLE | PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) == 0) {
+            if (is_f64x3(&v)) { memcpy(v.buf, in + 3 * i, 24); done = 1; }
+            PyBuffer_Release(&v);
+        }
+        PyErr_Clear();
+        if (!done) { PyObject* ix = PyLong_FromSsize_t(i); if (!ix || PyList_Append(rest, ix)) { Py_XDECREF(ix); Py_DECREF(rest); PyBuffer_Release(&b); return NULL; } Py_DECREF(ix); }
+    }
+    PyBuffer_Release(&b);
+    return rest;
+}
+
 static PyMethodDef methods[] = {
+    {"classify", classify, METH_VARARGS, "split a parameter dictionary's keys into poses and 3-vector landmarks"},
+    {"gather3", gather3, METH_VARARGS, "copy 3-vector parameters into the rows of an (n, 3) array; returns the indices left to the caller"},
+    {"scatter3", scatter3, METH_VARARGS, "write the rows of an (n, 3) array into 3-vector parameters in place; returns the indices left to the caller"},
     {"walk", walk, METH_VARARGS, "take a run of consecutive reprojection blocks into the column arrays; returns (next block, count)"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_lower_fast", NULL, -1, methods};

@@ -291,7 +291,7 @@ def _load_fast_walk(rebuild=False):
     spec = importlib.util.spec_from_file_location('_lower_fast', out, loader=importlib.machinery.ExtensionFileLoader('_lower_fast', out))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.walk
+    return mod
 
 
 def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
@@ -300,20 +300,35 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
     const = set(constant_param_keys)
     pose_keys, point_keys, pose_ix, point_ix = [], [], {}, {}
     dof = None
-    for key, val in param_dict.items():
-        if isinstance(val, (SE3, SE2)):
-            d = val.dof
+    fast = _fast_walk()
+    if fast is not None and type(param_dict) is dict:
+        # the same split in C (pyslam_amd/cext/lower_fast.c: classify): the keys in the dictionary's order
+        pose_keys, point_keys, bad = fast.classify(param_dict, (SE3, SE2), np.ndarray)
+        if bad is not None:
+            raise NotLowerable("parameter {!r} is neither an SE2/SE3 pose nor a 3-vector".format(bad))
+        pose_ix = {k: i for i, k in enumerate(pose_keys)}
+        point_ix = {k: i for i, k in enumerate(point_keys)}
+        for key in pose_keys:
+            d = param_dict[key].dof
             if dof is None:
                 dof = d
             elif dof != d:
                 raise NotLowerable("mixed SE(2)/SE(3) poses")
-            pose_ix[key] = len(pose_keys)
-            pose_keys.append(key)
-        elif isinstance(val, np.ndarray) and val.shape == (3,):
-            point_ix[key] = len(point_keys)
-            point_keys.append(key)
-        else:
-            raise NotLowerable("parameter {!r} is neither an SE2/SE3 pose nor a 3-vector".format(key))
+    else:
+        for key, val in param_dict.items():
+            if isinstance(val, (SE3, SE2)):
+                d = val.dof
+                if dof is None:
+                    dof = d
+                elif dof != d:
+                    raise NotLowerable("mixed SE(2)/SE(3) poses")
+                pose_ix[key] = len(pose_keys)
+                pose_keys.append(key)
+            elif isinstance(val, np.ndarray) and val.shape == (3,):
+                point_ix[key] = len(point_keys)
+                point_keys.append(key)
+            else:
+                raise NotLowerable("parameter {!r} is neither an SE2/SE3 pose nor a 3-vector".format(key))
     if dof is None:
         dof = 6
 
@@ -322,7 +337,10 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
     poses = np.zeros((len(pose_keys), pw))
     for k, i in pose_ix.items():
         poses[i] = pack_pose(param_dict[k])
-    points = [np.asarray(param_dict[k], dtype=F64) for k in point_keys]
+    points = np.empty((len(point_keys), 3), dtype=F64)
+    rest = fast.gather3(param_dict, point_keys, points) if fast is not None and type(param_dict) is dict else range(len(point_keys))
+    for i in rest:
+        points[i] = np.asarray(param_dict[point_keys[i]], dtype=F64)
     fixed_points, n_fixed = [], 0   # motion-only points appended after the landmarks ((m, 3) chunks)
 
     rid, n = np.full(len(pose_keys), -1, dtype=I32), 0
@@ -362,7 +380,7 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
             ogrp_cache[gkey] = g
         return g
 
-    walk = _fast_walk() if dof == 6 and isinstance(residual_blocks, list) else None
+    walk = fast.walk if fast is not None and dof == 6 and isinstance(residual_blocks, list) else None
     i = -1
     while i + 1 < n_blocks:
         i += 1
@@ -461,7 +479,7 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
                                "tables hold at most {}".format(len(classes), MAX_OBS_GROUPS))
 
     lp.poses, lp.pose_rid = poses, rid
-    lp.points = np.concatenate([np.array(points, dtype=F64).reshape(-1, 3)] + fixed_points)
+    lp.points = np.concatenate([points] + fixed_points) if fixed_points else points
     lp.point_vid = np.array(vid + [-1] * n_fixed, dtype=I32)
     o_pose, o_pt, o_g, o_uvd = o_pose[:cnt], o_pt[:cnt], o_g[:cnt], o_uvd[:cnt]
     if c_pose:

@@ -314,7 +314,14 @@ class Problem:
             T = self.param_dict[key]
             T.rot.mat = R
             T.trans = t
-        for key, p in zip(lp.point_keys, points):
+        fast = lowering._fast_walk()
+        if fast is not None and len(lp.point_keys) and type(self.param_dict) is dict and isinstance(lp.point_keys, list):
+            # landmarks that are plain arrays of three doubles are written in place in C (pyslam_amd/cext/lower_fast.c: scatter3)
+            todo = fast.scatter3(self.param_dict, lp.point_keys, np.ascontiguousarray(points[:len(lp.point_keys)], dtype=np.float64))
+            todo = [(lp.point_keys[i], points[i]) for i in todo]
+        else:
+            todo = zip(lp.point_keys, points)
+        for key, p in todo:
             val = self.param_dict[key]
             if isinstance(val, np.ndarray):
                 val[...] = p

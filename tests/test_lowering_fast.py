@@ -138,3 +138,48 @@ def test_errors_are_the_python_loops(what):
     finally:
         lowering._FAST[:] = [False, None]
     assert str(e_fast.value) == str(e_slow.value)
+
+
+def test_parameter_split_gather_and_write_back_with_unusual_landmark_arrays():
+    """Landmarks that are float32 arrays, strided views or read-only arrays go through the Python statements one by one (the C
+    helpers hand their indices back); a parameter that is neither a pose nor a 3-vector raises the same error either way."""
+    lp, _ = synthetic.stereo_ba(num_kf=5, num_lm=50, obs_per_lm=3, half_window=2, seed=7)
+    problem = synthetic.to_objects(lp, NS)
+    keys = list(lp.point_keys)
+    big = np.zeros((4, 6))
+    big[1, ::2] = problem.param_dict[keys[3]]
+    problem.param_dict[keys[3]] = big[1, ::2]                        # strided view (writable)
+    problem.param_dict[keys[5]] = problem.param_dict[keys[5]].astype(np.float32)
+    ro = problem.param_dict[keys[8]].copy(); ro.setflags(write=False)
+    problem.param_dict[keys[8]] = ro
+    fast, slow = _both(problem)
+    _same(fast, slow)
+    assert np.array_equal(fast.points[3], big[1, ::2]) and fast.points.dtype == np.float64
+
+    class Dev:                                                       # what _write_back needs of a DeviceProblem
+        def __init__(self, lp):
+            self.lp = lp
+        def get_params(self):
+            return self.lp.poses.copy(), self.lp.points + 1.0
+    problem.param_dict[keys[8]] = ro.copy()                          # (a read-only landmark cannot be written back by either path)
+    for use_c in (True, False):
+        lowering._FAST[:] = [False, None] if use_c else [True, None]
+        try:
+            lpw = problem._lower()
+            problem._write_back(Dev(lpw))
+            got = np.array([np.asarray(problem.param_dict[k], dtype=np.float64) for k in lpw.point_keys])
+            assert np.allclose(got, lpw.points + 1.0, rtol=0, atol=1e-6), use_c     # (float32 landmark: rounded)
+            assert np.array_equal(big[1, ::2], lpw.points[lpw.point_keys.index(keys[3])] + 1.0)
+            for k in lpw.point_keys:                                  # back, for the second pass
+                v = problem.param_dict[k]
+                v[...] = np.asarray(v, dtype=np.float64) - 1.0
+        finally:
+            lowering._FAST[:] = [False, None]
+    problem.param_dict['odd'] = [1.0, 2.0, 3.0]
+    for use_c in (True, False):
+        lowering._FAST[:] = [False, None] if use_c else [True, None]
+        try:
+            with pytest.raises(lowering.NotLowerable, match="'odd'"):
+                problem._lower()
+        finally:
+            lowering._FAST[:] = [False, None]
