@@ -16,14 +16,21 @@ echo
 echo "# C2 (10 000 SE(3) poses, 50 001 edges, Huber) and a 1 500-pose graph, cold solves"
 python tools/cold_probe.py 10000 40001 2 --pg 2>&1 | tail -2
 python tools/cold_probe.py 10000 40001 2 --pg --opt=coarse_adaptive_hold:0 2>&1 | tail -1
+python tools/cold_probe.py 10000 40001 2 --pg --opt=coarse_groups:400 2>&1 | tail -1
 python tools/cold_probe.py 1500 6000 2 --pg 2>&1 | tail -1
+python tools/cold_probe.py 5000 20000 2 --pg 2>&1 | tail -1
+echo "# its timeline under rocprofv3 --kernel-trace (tools/cold_trace_pg.sh)"
+bash tools/cold_trace_pg.sh 2>&1 | grep -v "^solve\|^kf"
 echo
 echo "# the first whole-iteration call of a fresh process (tools/first_call_probe.py)"
 python tools/first_call_probe.py 2>&1 | tail -1
 echo
 echo "# ps_problem_create stages (tools/create_time.py; the measurement build prints the laps)"
 python -c "import __graft_entry__ as g; g.build_measure()" > /dev/null 2>&1
+echo "## structure built on the device (default from 200 000 observations; csrc/ps_host_build.h)"
 PYSLAM_AMD_MEASURE=1 PS_CREATE_TIMING=1 python tools/create_time.py 2>&1 | grep -v "amdgpu.ids\| 0.0 ms\|build_coarse"
+echo "## the host builder (PS_CREATE_DEVICE=0: the device build's test oracle)"
+PYSLAM_AMD_MEASURE=1 PS_CREATE_TIMING=1 PS_CREATE_DEVICE=0 python tools/create_time.py 2>&1 | grep "again\|synthetic"
 echo
 echo "# pose-stationary Schur kernel against the pipelined gather kernel (tools/schur_probe.py, PS_SCHUR_MODE=2) + its ablation"
 ABLATE=1 python tools/schur_probe.py 2>&1 | grep -v amdgpu.ids | tail -12
