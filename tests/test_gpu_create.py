@@ -101,3 +101,26 @@ def test_device_build_with_constant_poses_constant_points_and_repeated_observati
     lp.obs_uvd = np.concatenate([lp.obs_uvd, lp.obs_uvd[dup] + 0.25])
     assert keep.any() and lp.obs_pose.size == n + 50
     _compare(lp)
+
+
+def test_device_build_reads_resident_observation_columns_in_place():
+    """PS_DESC_DEVICE_TABLES with the device build: the observation columns are read where the caller holds them (no copy to
+    the host first); same tables as from host columns, whichever builder."""
+    from pyslam_amd import synthetic
+    from pyslam_amd.device import resident_tables
+    lp, truth = synthetic.stereo_ba(num_kf=25, num_lm=4000, obs_per_lm=7, half_window=6, seed=9)
+    lp = synthetic.with_pose_edges(lp, 5, seed=3, truth_poses=truth['poses'])
+    host = _build(lp, 0)
+    dev_host_cols = _build(lp, 2)
+    dev_res_cols = _build(resident_tables(lp, params=True, tables=True), 2)
+    host_res_cols = _build(resident_tables(lp, params=False, tables=True), 0)
+    try:
+        ref = _checksums(host)
+        for other in (dev_host_cols, dev_res_cols, host_res_cols):
+            got = _checksums(other)
+            assert [TABLES[i] for i in range(16) if ref[i] != got[i]] == []
+        a = host.gn_iteration()
+        assert dev_host_cols.gn_iteration() == a and dev_res_cols.gn_iteration() == a and host_res_cols.gn_iteration() == a
+    finally:
+        for d in (host, dev_host_cols, dev_res_cols, host_res_cols):
+            d.close()
