@@ -121,7 +121,12 @@ int ps_warm_up(void);
 
 /* Lower the tables to HBM and precompute the iteration-invariant structure
    (landmark / pose segment lists, Schur pair lists, block pattern).
-   Replaces the per-iteration Python bookkeeping of pyslam/problem.py:294-329. */
+   Replaces the per-iteration Python bookkeeping of pyslam/problem.py:294-329.
+   From 200 000 observations up the observation tables and the Schur pair list are built BY THE DEVICE from the caller's
+   columns (csrc/ps_host_build.h; with PS_DESC_DEVICE_TABLES the columns are read in place), bit-identical to the host
+   builder that smaller problems use.  Environment, read once here: PS_CREATE_DEVICE = 0 host builder / 1 by size
+   (default) / 2 always; PS_SCHUR_MODE, PS_SCHUR_TILE_KB, PS_SCHUR_TILE_MIN_MB, PS_CREATE_KEYS64: list variants the
+   parity tests hold against each other. */
 int ps_problem_create(const ps_problem_desc* desc, void* stream, ps_problem** out);
 int ps_problem_destroy(ps_problem* h);
 int ps_get_info(ps_problem* h, ps_problem_info* info);

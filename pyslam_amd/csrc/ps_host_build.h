@@ -293,7 +293,11 @@ struct DevPairBuild {
         return 0;
     }
     // key layout for `ntiles` tiles
-    static bool packed32(int ntiles, int nr) { return (uint64_t)ntiles * (uint64_t)nr * (uint64_t)nr <= 0xFFFFFFFFull; }
+    // (PS_CREATE_KEYS64=1 at create: the 64-bit keys of problems beyond tiles x poses^2 = 2^32 on any problem -- no problem that fits
+    //  a test reaches them by size: tests/test_gpu_create.py holds them against the host builder this way)
+    static bool packed32(int ntiles, int nr) {
+        return (uint64_t)ntiles * (uint64_t)nr * (uint64_t)nr <= 0xFFFFFFFFull && !ps_create_env("PS_CREATE_KEYS64");
+    }
     int reserve(uint64_t* pairs_out) {
         (void)pairs_out;
         if (keys) return 0;

@@ -124,3 +124,29 @@ def test_device_build_reads_resident_observation_columns_in_place():
     finally:
         for d in (host, dev_host_cols, dev_res_cols, host_res_cols):
             d.close()
+
+
+def test_device_build_with_64_bit_pair_keys():
+    """Problems beyond tiles x poses^2 = 2^32 sort their pairs by 64-bit (tile | row | column) keys; none that fits a test gets
+    there by size, so the switch PS_CREATE_KEYS64 puts an ordinary problem on that path: same tables, tiled and untiled."""
+    from pyslam_amd import synthetic
+    lp, _ = synthetic.stereo_ba(num_kf=60, num_lm=30000, obs_per_lm=10, half_window=10, seed=5)
+    assert _compare(lp, PS_SCHUR_TILE_MIN_MB=1, PS_CREATE_KEYS64=1)[11] != 0        # tiled
+    lp2, _ = synthetic.stereo_ba(num_kf=33, num_lm=777, obs_per_lm=12, half_window=16, seed=4)
+    assert _compare(lp2, PS_CREATE_KEYS64=1)[11] == 0
+
+
+@pytest.mark.parametrize('kf,lm', [(200, 50000), (2000, 500000)])
+def test_device_build_at_the_baseline_sizes_is_the_host_builders(kf, lm):
+    """C3 (untiled, 2.2 M pairs) and C4 (72 landmark tiles, 22.5 M pairs, 29-bit packed keys): every structure table of the default
+    (device) build against the host builder's, bit for bit."""
+    from pyslam_amd import synthetic
+    lp, _ = synthetic.stereo_ba(num_kf=kf, num_lm=lm, obs_per_lm=10, half_window=20, seed=0 if kf == 200 else 1)
+    host = _build(lp, 0)
+    dev = _build(lp, 1)
+    try:
+        a, b = _checksums(host), _checksums(dev)
+        assert [TABLES[i] for i in range(16) if a[i] != b[i]] == []
+        assert (a[11] != 0) == (kf == 2000)
+    finally:
+        host.close(); dev.close()
