@@ -399,3 +399,17 @@ def test_fast_se3_odot_and_its_shape_constant_are_exported():
     assert R.fast_se3_odot(pts, R.SE3_ODOT_SHAPE).shape == (17, 3, 6)
     for name in ('stackmul', 'bilinear_interpolate', 'SE3'):
         assert name in R.__all__ and hasattr(R, name)
+
+
+def test_update_partition_is_rebuilt_on_first_use_after_solve_invalidated_it():
+    """reference problem.py:132 rebuilds `_update_partition_dict` at the top of solve(); here solve() only invalidates it (the
+    device path never reads it: one Python statement per parameter saved) and the attribute rebuilds itself when read."""
+    import pyslam.problem as P
+    problem = P.Problem()
+    problem.initialize_params({'a': np.zeros(3), 'b': np.zeros(3), 'c': np.zeros(2)})
+    problem.set_parameters_constant('b')
+    assert problem._update_partition_dict == {}                       # as constructed (reference problem.py:60)
+    problem._partition = None                                         # what solve() does
+    assert problem._update_partition_dict == {'a': range(0, 3), 'c': range(3, 5)}
+    problem._update_partition_dict = {'x': range(0, 1)}               # assignable, as in the reference
+    assert problem._update_partition_dict == {'x': range(0, 1)}
