@@ -84,10 +84,10 @@ __global__ __launch_bounds__(256) void k_block_jacobi_factor(
         typedef PoseOps<D> G;
         double v = (r == c) ? 1.0 : 0.0;
         if (basis == 1) {
-            const typename G::T T = G::load(poses + G::W * (size_t)pose_of_rid[i]);
+            const double* Tp = poses + G::W * (size_t)pose_of_rid[i];      // (c differs per lane: entries straight from memory)
             v = 0.0;
 #pragma unroll
-            for (int m2 = 0; m2 < D; ++m2) v += (m2 >= r) ? A[m2 * D + r] * G::adj(T, m2, c) : 0.0;     // (L^T Ad)[r][c]
+            for (int m2 = 0; m2 < D; ++m2) v += (m2 >= r) ? A[m2 * D + r] * G::adj_mem(Tp, m2, c) : 0.0;     // (L^T Ad)[r][c]
         }
         Bmat[(size_t)i * DD + lane] = v;
         sB[wv][lane] = v;

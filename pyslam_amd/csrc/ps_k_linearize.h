@@ -607,9 +607,8 @@ __global__ __launch_bounds__(256) void k_factor_pass(
             const double sk = sS[fl][r];
             double j1 = 0.0;
             if (sBin[fl]) {
-                const typename G::T T21 = G::load(sT21[fl]);
 #pragma unroll
-                for (int m = 0; m < D; ++m) j1 -= grp.S[r * D + m] * G::adj(T21, m, c);
+                for (int m = 0; m < D; ++m) j1 -= grp.S[r * D + m] * G::adj_mem(sT21[fl], m, c);     // (c differs per lane: from LDS)
             }
             sJ1[w][lane] = sk * j1;
             sJ2[w][lane] = sk * grp.S[lane];

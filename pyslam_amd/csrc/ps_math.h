@@ -175,6 +175,19 @@ PS_DEV Se3 se3_exp(const double* __restrict__ xi) {
 }
 
 // Ad(T)[r][c], 6x6: [[C, t^ C], [0, C]]
+// the same entry from the packed pose in MEMORY (LDS or global: R row-major | t).  For a column index that differs from lane to
+// lane: indexing the register copy with it put the whole pose into scratch (the only scratch users of the library were the two
+// kernels that do this: k_factor_pass, k_block_jacobi_factor)
+PS_DEV double se3_adjoint_entry_mem(const double* __restrict__ p, int r, int c) {
+    if (r >= 3) return (c >= 3) ? p[3 * (r - 3) + (c - 3)] : 0.0;
+    if (c < 3) return p[3 * r + c];
+    const int j = c - 3;
+    const double* t = p + 9;
+    if (r == 0) return -t[2] * p[3 + j] + t[1] * p[6 + j];
+    if (r == 1) return t[2] * p[j] - t[0] * p[6 + j];
+    return -t[1] * p[j] + t[0] * p[3 + j];
+}
+
 PS_DEV double se3_adjoint_entry(const Se3& T, int r, int c) {
     if (r >= 3) return (c >= 3) ? T.R[3 * (r - 3) + (c - 3)] : 0.0;
     if (c < 3) return T.R[3 * r + c];
@@ -246,6 +259,12 @@ PS_DEV Se2 se2_exp(const double* __restrict__ xi) {
 }
 
 // Ad(T)[r][c], 3x3: [[C, (y, -x)^T], [0, 1]]
+PS_DEV double se2_adjoint_entry_mem(const double* __restrict__ p, int r, int c) {
+    if (r == 2) return (c == 2) ? 1.0 : 0.0;
+    if (c < 2) return p[2 * r + c];
+    return (r == 0) ? p[5] : -p[4];
+}
+
 PS_DEV double se2_adjoint_entry(const Se2& T, int r, int c) {
     if (r == 2) return (c == 2) ? 1.0 : 0.0;
     if (c < 2) return T.R[2 * r + c];
@@ -264,6 +283,7 @@ template <> struct PoseOps<6> {
     static PS_DEV void log(const T& x, double* xi) { se3_log(x, xi); }
     static PS_DEV T exp(const double* xi) { return se3_exp(xi); }
     static PS_DEV double adj(const T& x, int r, int c) { return se3_adjoint_entry(x, r, c); }
+    static PS_DEV double adj_mem(const double* p, int r, int c) { return se3_adjoint_entry_mem(p, r, c); }
 };
 template <> struct PoseOps<3> {
     typedef Se2 T;
@@ -275,6 +295,7 @@ template <> struct PoseOps<3> {
     static PS_DEV void log(const T& x, double* xi) { se2_log(x, xi); }
     static PS_DEV T exp(const double* xi) { return se2_exp(xi); }
     static PS_DEV double adj(const T& x, int r, int c) { return se2_adjoint_entry(x, r, c); }
+    static PS_DEV double adj_mem(const double* p, int r, int c) { return se2_adjoint_entry_mem(p, r, c); }
 };
 
 // ---------------------------------------------------------------------------
