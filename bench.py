@@ -190,17 +190,23 @@ def cold_solves(dev, start, total_iters, fence, warm_solves=1):
 
     for _ in range(max(1, warm_solves)):
         one(None)
-    sec, its, solves, calls_by_pos, hist0, pcg0 = 0.0, 0, 0, [], None, None
+    sec, its, solves, calls_by_pos, hist0, pcg0, per_solve = 0.0, 0, 0, [], None, None, []
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()              # (as timeit does: a collection of the interpreter inside a 1.3 ms solve is not the solver's time)
     while its < total_iters:
         dt, hist, calls = one(total_iters - its)
         sec += dt; its += len(calls); solves += 1
+        per_solve.append(round(dt * 1e3, 4))
         if hist0 is None:
             hist0, pcg0 = hist, [c[1] for c in calls]
         for k, c in enumerate(calls):
             if k >= len(calls_by_pos):
                 calls_by_pos.append([])
             calls_by_pos[k].append(c[0])
-    return {'seconds': sec, 'iterations': its, 'solves': solves,
+    if gc_was:
+        gc.enable()
+    return {'seconds': sec, 'iterations': its, 'solves': solves, 'per_solve_ms': per_solve,
             'per_call_ms': [round(float(np.median(c)), 4) for c in calls_by_pos],      # median over the solves, by call index
             'pcg_iters': pcg0, 'cost_history': hist0}
 
@@ -508,7 +514,8 @@ def main():
                        'reduced_blocks': info['reduced_nnzb'], 'schur_pairs': info['num_pairs']},
             'residual_blocks_per_s': round(total_blocks / (ms_per_step * 1e-3), 1),
             'cold_solve': {'solves': cold['solves'], 'iterations': cold['iterations'],
-                           'ms_per_solve': round(elapsed * 1e3 / cold['solves'], 4), 'per_call_ms': cold['per_call_ms'],
+                           'ms_per_solve': round(elapsed * 1e3 / cold['solves'], 4), 'per_solve_ms': cold.get('per_solve_ms'),
+                           'per_call_ms': cold['per_call_ms'],
                            'per_call_note': 'host wall clock of each ps_gn_iteration call by its position in the solve (median over the '
                                             'solves); the solve time also holds the start-cost pass, the best-parameter snapshots and '
                                             'the final restore'},

@@ -21,6 +21,8 @@ else:
 dev = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
 for o in opts:
     k, v = o[6:].split(':'); dev.set_option(k, float(v))
+if '--prof' in sys.argv:      # as bench.py's timed region: one event pair around the Schur kernel on every 4th linearisation
+    dev.set_option('profile_every', 4); dev.set_profiling(1)
 start = (lp.poses.copy(), lp.points.copy())
 opt = bench.example_options()
 tot, its = 0.0, 0
