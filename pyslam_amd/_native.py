@@ -158,6 +158,10 @@ def _share_torch_hip_runtime():
         pass
 
 
+_CREATE_ENV = {'PS_CREATE_DEVICE', 'PS_CREATE_KEYS64', 'PS_PAIRS_BY_LANDMARK', 'PS_SCHUR_MODE', 'PS_SCHUR_STREAM',
+               'PS_SCHUR_TILE_KB', 'PS_SCHUR_TILE_MIN_MB', 'PS_ST_TILES'}       # ps_create_env(): read by every build
+
+
 def load():
     """dlopen the HIP core; raise loudly if it is missing (no CPU fallback)."""
     global _lib
@@ -168,6 +172,14 @@ def load():
             "{} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). pyslam_amd has no CPU solver path.".format(LIB_PATH))
     _share_torch_hip_runtime()
+    if os.environ.get('PYSLAM_AMD_MEASURE') != '1':
+        # the product library compiles the measurement / debugging switches out (csrc/ps_core.hip: ps_env): say so once instead of
+        # silently ignoring a variable somebody set (round-4 ADVICE).  The create-time variants below ARE read by it.
+        ignored = sorted(k for k in os.environ if k.startswith('PS_') and k not in _CREATE_ENV)
+        if ignored:
+            import sys
+            sys.stderr.write('pyslam_amd: {} ignored by the product library (measurement switches exist only in the -DPS_MEASURE '
+                             'build: PYSLAM_AMD_MEASURE=1)\n'.format(', '.join(ignored)))
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

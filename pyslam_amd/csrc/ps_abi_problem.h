@@ -526,6 +526,9 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // Device build of the pair list (csrc/ps_host_build.h): pairs generated, sorted and left in HBM; the host receives the task
     // starts and keys only.
     const bool dev_pairs = gather_lists && dev_build && ntiles < 65536;
+    // (a device build leaves no observation tables on the host: the host pair loop below would see empty lists and the reduced
+    //  system would silently lose every landmark coupling -- round-4 ADVICE.  65 536 tiles = 590 GB of Z rows: not reachable)
+    if (dev_build && gather_lists && !dev_pairs) return fail("too many landmark tiles for the device pair build");
     DevPairBuild devb;
     std::vector<long> lm_pairs_before(nv + 1, 0);
     if (dev_pairs) {

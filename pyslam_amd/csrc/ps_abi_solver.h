@@ -71,6 +71,7 @@ int ps_shard_pack(ps_problem* h) {
 
 int ps_shard_unpack(ps_problem* h) {
     if (!h) return fail("null argument");
+    h->prelin_valid = false;            // S and g are overwritten with the all-reduced system
     if (ensure_shard_pack(h)) return -1;
     const long ntail = (long)h->nr * h->D + 2;
     const int nb = (int)std::min<long>(4096, cdiv(h->pack_count, 256));

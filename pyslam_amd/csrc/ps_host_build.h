@@ -303,9 +303,14 @@ struct DevPairBuild {
         if (keys) return 0;
         const size_t n = (size_t)total;
         tmp_bytes = ps_sort_tmp_bytes(n);
+        // 33 B of transient scratch per pair (+ rocPRIM's temporary): two key arrays (sized for 64-bit keys: build() may be called
+        // again with another tile count, i.e. another key width), the values, one flag byte.  The task starts and task keys reuse
+        // what is dead once the sort has run -- the unsorted keys and the unsorted values (round-4 ADVICE: they had 12 B per pair
+        // of their own).
         if (scratch.get((char**)&tmp, tmp_bytes) || scratch.get((uint64_t**)&keys, n) || scratch.get((uint64_t**)&keys_sorted, n) ||
-            scratch.get(&vals, n) || scratch.get(&flags, n) || scratch.get(&starts_dev, n) || scratch.get(&count_dev, 1) ||
-            scratch.get(&task_keys_dev, n)) return -1;
+            scratch.get(&vals, n) || scratch.get(&flags, n) || scratch.get(&count_dev, 1)) return -1;
+        starts_dev = reinterpret_cast<int32_t*>(keys);      // (n x 4 B of the n x 8 B)
+        task_keys_dev = vals;
         return 0;
     }
     template <typename K, bool PACKED>

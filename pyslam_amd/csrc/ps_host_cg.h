@@ -1068,6 +1068,8 @@ int step_norm(ps_problem* h) {
 }
 
 int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool with_norm = false, long long* hearly = nullptr, long long eseq = 0) {
+    h->prelin_valid = false;            // the parameters move: a linearisation enqueued ahead is of the old point (set again by
+                                        // gn_iteration_impl AFTER its tail, for the speculative one enqueued behind that tail)
     StageTimer t(h, PS_ST_UPDATE);
     if (h->nr > 0) {
         double* sq = with_norm ? h->sq_part_p : nullptr;
@@ -1085,6 +1087,7 @@ int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool
 // back-substitution, update, cost and ||dx||^2 with ONE final reduction launch.  `gate` (device
 // status words) makes every kernel a no-op until the CG has flagged convergence.
 int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = false) {
+    h->prelin_valid = false;            // (as apply_update: every tail moves the parameters)
     // line-search order (cost AFTER the step): back-substitution, landmark update and pose retraction
     // are one launch when the problem has landmarks (then D == 6)
     const bool fused = linesearch && h->nv > 0 && h->nr > 0 && h->D == 6;

@@ -1,5 +1,6 @@
 // pyslam_amd / HIP (gfx950): k_schur_pose -- the POSE-STATIONARY form of the Schur pair products (round 4).
-// (product kernel; the default where its lists can be built, ps_abi_problem.h "pose-stationary Schur lists")
+// (NOT the default: measured 2-2.6x slower than the gather kernel k_schur_pairs_db; its lists are built and it
+//  runs only with PS_SCHUR_MODE=1|2 at create + option "schur_mode" -- kept with its parity test as the record of that experiment)
 //
 // The gather kernels (k_schur_pairs, k_schur_pairs_db) fetch BOTH rows of every pair: 4.46 M row fetches for 0.5 M distinct
 // rows at C3, every row requested 9 times, and the pipelined kernel is bound by what a CU can ingest (its ablation: 38 us with

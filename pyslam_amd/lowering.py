@@ -262,32 +262,60 @@ _FAST = [False, None]        # [looked for, the C walk or None]
 
 
 def _fast_walk():
-    """pyslam_amd/cext/lower_fast.c (built by __graft_entry__.build() into pyslam_amd/lib/_lower_fast.so, or here on first use
-    when a C compiler is at hand): the walk over runs of reprojection blocks.  None -- every block through the Python loop,
-    same tables -- when it cannot be had or PYSLAM_AMD_LOWER_FAST=0."""
+    """pyslam_amd/cext/lower_fast.c (built by __graft_entry__.build() into pyslam_amd/lib/_lower_fast<EXT_SUFFIX>, or here on
+    first use when a C compiler is at hand): the walk over runs of reprojection blocks.  None -- every block through the
+    Python loop, same tables -- when it cannot be had (said once on stderr) or PYSLAM_AMD_LOWER_FAST=0."""
     if not _FAST[0]:
         _FAST[0] = True
         import os
         if os.environ.get('PYSLAM_AMD_LOWER_FAST', '1') != '0':
             try:
                 _FAST[1] = _load_fast_walk()
-            except Exception:       # noqa: BLE001 (no compiler, no headers: the Python loop does the same job)
+            except Exception as e:       # noqa: BLE001 (no compiler, no headers: the Python loop does the same job)
+                import sys
+                sys.stderr.write('pyslam_amd: the C lowering walk is unavailable ({}: {}); using the Python loop\n'.format(
+                    type(e).__name__, e))
                 _FAST[1] = None
     return _FAST[1]
 
 
 def _load_fast_walk(rebuild=False):
+    """Build (if the source's hash differs from the one the library was built from) and import the C walk.  The library's name
+    carries the interpreter's ABI tag; it is compiled to a temporary file and renamed into place, so that ranks starting
+    together (torchrun) never import a half-written file (round-4 ADVICE)."""
+    import hashlib
     import importlib.machinery
     import importlib.util
     import os
     import subprocess
     import sysconfig
+    import tempfile
     here = os.path.dirname(os.path.abspath(__file__))
-    src, out = os.path.join(here, 'cext', 'lower_fast.c'), os.path.join(here, 'lib', '_lower_fast.so')
-    if rebuild or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+    src = os.path.join(here, 'cext', 'lower_fast.c')
+    suffix = sysconfig.get_config_var('EXT_SUFFIX') or '.so'
+    out = os.path.join(here, 'lib', '_lower_fast' + suffix)
+    with open(src, 'rb') as fh:
+        sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+    stamp = out + '.sha'
+    built = None
+    if os.path.exists(out) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            built = fh.read().strip()
+    if rebuild or built != sha:
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.run(['gcc', '-O2', '-shared', '-fPIC', '-I' + sysconfig.get_paths()['include'], src, '-o', out], check=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        fd, tmp = tempfile.mkstemp(suffix=suffix, dir=os.path.dirname(out))
+        os.close(fd)
+        try:
+            subprocess.run(['gcc', '-O2', '-shared', '-fPIC', '-I' + sysconfig.get_paths()['include'], src, '-o', tmp], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            os.replace(tmp, out)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        fd, tmp = tempfile.mkstemp(dir=os.path.dirname(out))
+        with os.fdopen(fd, 'w') as fh:
+            fh.write(sha)
+        os.replace(tmp, stamp)
     spec = importlib.util.spec_from_file_location('_lower_fast', out, loader=importlib.machinery.ExtensionFileLoader('_lower_fast', out))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -83,6 +83,29 @@ def test_a_solve_on_a_used_handle_equals_the_solve_on_a_fresh_one():
     used.close()
 
 
+def test_a_linearisation_enqueued_ahead_does_not_survive_a_staged_tail():
+    """ps_solve may leave the NEXT linearisation in the queue (enqueued behind a converged tail while the host waited).  Anything
+    that moves the parameters afterwards -- here the staged tail ps_gn_finish, which applies the last step once more -- must
+    invalidate it, or the next ps_gn_iteration at the same damping solves a stale system (round-4 ADVICE).  Held against a
+    handle on which set_params forces the fresh linearisation."""
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=1500, obs_per_lm=8, half_window=6, seed=9)
+    opt = _options(max_iters=2, allow_nondecreasing_steps=True, max_nondecreasing_steps=5)
+    outs = []
+    for force in (False, True):
+        dev = DeviceProblem(lp)
+        device_solve(dev, opt)
+        dev.eval_cost(True)
+        dev.gn_finish(True)                                  # moves the parameters (the last dx again), no linearize in front
+        if force:
+            dev.set_params(*dev.get_params())                # the same values: clears whatever was linearised ahead
+        outs.append((dev.gn_iteration(0.0, 1e-12, 2000, True), dev.get_params()))
+        dev.close()
+    (a, pa), (b, pb) = outs
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+
+
 def test_build_sha_matches_the_sources_on_disk():
     import __graft_entry__ as ge
     from pyslam_amd import _native as nat

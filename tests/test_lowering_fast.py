@@ -30,7 +30,7 @@ def _walk_available():
 
 def _both(problem):
     """(tables with the C walk, tables with the Python loop)"""
-    assert _walk_available(), 'pyslam_amd/lib/_lower_fast.so could not be built or loaded'
+    assert _walk_available(), 'pyslam_amd/lib/_lower_fast<EXT_SUFFIX> could not be built or loaded'
     fast = problem._lower()
     lowering._FAST[:] = [True, None]
     try:
