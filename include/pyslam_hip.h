@@ -351,6 +351,15 @@ int ps_sparse_normal_solve(int32_t m, int32_t n, const int32_t* j_row_ptr, const
                            const double* r, const double* rhs, double tol, int32_t max_iters,
                            double* dx, int32_t* iters_out, double* relres_out);
 
+/* The banded factorisation kernels of the explicit two-level PCG's coarse level on their own (csrc/ps_k_band.h: one workgroup
+ * walking the block columns; csrc/ps_k_bandpart.h: the partitioned, parallel form): inverse of a symmetric positive definite
+ * matrix with `bw` (1..7) block off-diagonals of dof x dof blocks.  `a`: dense, row-major, (ncb dof)^2 doubles on the host, lower
+ * triangle read.  chunk_nodes < 0: serial walk; 0: partitioned, automatic chunk size; > 0: interior nodes per chunk (partitioned
+ * needs 2 bw - 1 <= 7).  ainv_out: fp32, what the preconditioner keeps.  elapsed_us (or NULL): GPU time of the launches.
+ * Stands in for the coarse-level part of scipy.sparse.linalg.spsolve (reference pyslam/problem.py:186); test and measurement entry. */
+int ps_debug_band_inverse(const double* a, int32_t ncb, int32_t dof, int32_t bw, int32_t chunk_nodes, float* ainv_out,
+                          double* elapsed_us);
+
 /* Frame-to-frame RANSAC, the step before the motion-only solve in the reference's sparse VO pipeline
    (pyslam/pipelines/sparse.py:148-150).  Stateless; host pointers in, host pointers out.
    ps_ransac_transforms   -- compute_transform_fast (pyslam/pipelines/ransac.py:13-67): `batch` rigid

@@ -258,3 +258,63 @@ int ps_sparse_normal_solve(int32_t m, int32_t n, const int32_t* j_row_ptr, const
     if (sc[SPS_DONE] == 2.0) return fail("sparse normal-equation CG broke down (J^T J is not positive semi-definite to rounding, or a NaN in J)");
     return 0;
 }
+
+// ---- the band factorisation kernels on their own (csrc/ps_k_band.h, ps_k_bandpart.h): inverse of a symmetric positive definite
+// matrix with `bw` block off-diagonals of D x D blocks, A given dense on the host (row-major, nc = ncb D; the lower triangle is
+// read).  chunk_nodes < 0: the one-workgroup column walk (k_band_chol + k_band_inverse_rl); 0: the partitioned form with its
+// automatic chunk size; > 0: that many interior nodes per chunk.  ainv_out: nc x nc fp32 (what the explicit two-level PCG
+// keeps).  elapsed_us (may be NULL): GPU time of the factorisation + inverse launches, measured with events.
+int ps_debug_band_inverse(const double* a, int32_t ncb, int32_t dof, int32_t bw, int32_t chunk_nodes, float* ainv_out, double* elapsed_us) {
+    if (!a || !ainv_out || ncb <= 0 || (dof != 3 && dof != 6) || bw < 1 || bw > PS_BAND_MAXB) return fail("bad argument");
+    if (need_device()) return -1;
+    const int nc = ncb * dof;
+    DevBuf bA, bInv, bLr, bLc, brd, bXs, bst;
+    if (bA.get((size_t)nc * nc * 8) || bInv.get((size_t)nc * nc * 4) || bst.get(ST_NWORDS * 4)) return -1;
+    HIP_OK(hipMemcpy(bA.p, a, (size_t)nc * nc * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(bst.p, 0, ST_NWORDS * 4));
+    HIP_OK(hipMemset(bInv.p, 0, (size_t)nc * nc * 4));
+    hipStream_t st = 0;
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    struct Ev { hipEvent_t a, b; ~Ev() { hipEventDestroy(a); hipEventDestroy(b); } } evs{e0, e1};
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {                       // (the second run is the one timed: the first loads the kernels)
+        if (chunk_nodes < 0) {
+            if (rep == 0 && (bLr.get((size_t)nc * PS_BAND_W * 8) || bLc.get((size_t)nc * PS_BAND_W * 8) || brd.get((size_t)nc * 8) ||
+                             bXs.get((size_t)nc * nc * 8))) return -1;
+            HIP_OK(hipMemsetAsync(bLr.p, 0, (size_t)nc * PS_BAND_W * 8, st));
+            HIP_OK(hipMemsetAsync(bLc.p, 0, (size_t)nc * PS_BAND_W * 8, st));
+            HIP_OK(hipEventRecord(e0, st));
+            if (dof == 6) hipLaunchKernelGGL(k_band_chol<6>, dim3(1), dim3(256), 0, st, ncb, bw, bA.as<double>(), bLr.as<double>(), bLc.as<double>(),
+                                             brd.as<double>(), bst.as<int32_t>(), nc, (const int2*)nullptr);
+            else hipLaunchKernelGGL(k_band_chol<3>, dim3(1), dim3(256), 0, st, ncb, bw, bA.as<double>(), bLr.as<double>(), bLc.as<double>(),
+                                    brd.as<double>(), bst.as<int32_t>(), nc, (const int2*)nullptr);
+            hipLaunchKernelGGL(k_band_inverse_rl<false>, dim3(cdiv(nc, 4)), dim3(256), 0, st, nc, (const double*)bLr.as<double>(),
+                               (const double*)bLc.as<double>(), (const double*)brd.as<double>(), bXs.as<double>(), bInv.as<float>(),
+                               (const BandInvItem*)nullptr, (double*)nullptr, nc);
+            HIP_OK(hipEventRecord(e1, st));
+        } else {
+            static thread_local std::unique_ptr<BandPart> bp;
+            const int m = chunk_nodes > 0 ? chunk_nodes : BandPart::auto_m(ncb, bw);
+            if (rep == 0) {
+                if (2 * bw - 1 > PS_BAND_MAXB || m < bw) return fail("partitioned band factorisation: needs 2 bw - 1 <= 7 and chunks of at least bw nodes");
+                bp.reset(new BandPart());
+                if (bp->build(ncb, dof, bw, m, st)) { bp.reset(); return -1; }
+            }
+            HIP_OK(hipEventRecord(e0, st));
+            const int rc = dof == 6 ? bp->run<6>(st, bA.as<double>(), nc, bInv.as<float>(), nc, bst.as<int32_t>())
+                                    : bp->run<3>(st, bA.as<double>(), nc, bInv.as<float>(), nc, bst.as<int32_t>());
+            HIP_OK(hipEventRecord(e1, st));
+            if (rc) { bp.reset(); return -1; }
+            if (rep == 1) { HIP_OK(hipStreamSynchronize(st)); bp.reset(); }
+        }
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    if (elapsed_us) *elapsed_us = 1e3 * ms;
+    int32_t stw[ST_NWORDS];
+    HIP_OK(hipMemcpy(stw, bst.p, sizeof(stw), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(ainv_out, bInv.p, (size_t)nc * nc * 4, hipMemcpyDeviceToHost));
+    if (stw[ST_DIAG_FAIL]) return fail("band factorisation: the matrix is not positive definite");
+    return 0;
+}

@@ -109,6 +109,8 @@ PsPool& ps_pool() { static PsPool* p = new PsPool(); return *p; }   // (leaked o
 
 }  // namespace
 
+#include "ps_host_bandpart.h"
+
 struct ps_problem {
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -280,6 +282,9 @@ struct ps_problem {
     // ... banded coarse matrix (ps_k_band.h): block off-diagonals of A_c (-1: not banded enough), band factor by rows / columns
     int ac_bw = -1;
     int band_chol = 1;              // option "band_chol"
+    int band_part = 1;              // option "band_part": the banded coarse matrix by the PARTITIONED factorisation (ps_k_bandpart.h) where it applies
+    int band_part_m = 0;            // option "band_part_chunk": interior nodes per chunk (0: automatic, ~ sqrt(B ncb) - B)
+    std::unique_ptr<BandPart> bpart;
     double *Lrow = nullptr, *Lcol = nullptr, *rdiag = nullptr;
     // ... three-launch form (restriction folded into the SpMV epilogue + a recurrence for t)
     int xcg_rt = 1;                 // option "xcg_restrict_fused"

@@ -20,17 +20,26 @@
 #define PS_BAND_W 48                          // row pitch of the band arrays
 #define PS_BAND_NB (PS_BAND_MAXB + 1)
 
+// Batched form (round 5, ps_k_bandpart.h): `part` != NULL -- workgroup b factors the diagonal sub-matrix of the nodes
+// part[b].x .. part[b].x + part[b].y - 1 (the interior of one chunk of the partitioned factorisation); the band arrays are
+// indexed by global row, so the chunks' factors sit side by side in the same Lrow / Lcol / rdiag.  `lda`: row pitch of Ac.
 template <int D>
 __global__ __launch_bounds__(256) void k_band_chol(
     int ncb, int B, const double* __restrict__ Ac, double* __restrict__ Lrow, double* __restrict__ Lcol,
-    double* __restrict__ rdiag, int32_t* __restrict__ status)
+    double* __restrict__ rdiag, int32_t* __restrict__ status, int lda, const int2* __restrict__ part)
 {
     constexpr int DD = D * D, NB = PS_BAND_NB, W = PS_BAND_W;
     __shared__ double Wn[NB][NB][DD];         // block (i, c) of the window at [i % NB][c % NB]
     __shared__ double P[PS_BAND_MAXB * D][D];
     __shared__ double Li2[2][DD];
     __shared__ int bad;
-    const int nc = ncb * D, t = threadIdx.x;
+    if (part) {
+        const int2 pr = part[blockIdx.x];
+        ncb = pr.y;
+        Ac += (size_t)pr.x * D * lda + (size_t)pr.x * D;
+        Lrow += (size_t)pr.x * D * W; Lcol += (size_t)pr.x * D * W; rdiag += (size_t)pr.x * D;
+    }
+    const int nc = lda, t = threadIdx.x;
     if (t == 0) bad = 0;
     // block row i of the band (block columns i - B .. i) <-> two values per thread: requested from global memory at the
     // start of a step, stored into the window at its end (the slot is in use until then)
@@ -256,17 +265,32 @@ PS_DEV double band_lane(double v, int idx /* wave-uniform */) {
 // rows) now share tiles of 64 band rows, brought into LDS by all 256 threads one tile ahead; a step costs an LDS read that
 // does not depend on the chain, two v_readlane, a DPP move and two FMAs.
 #define PS_BI2_T 64
+// PART (round 5, ps_k_bandpart.h): the batched form -- workgroup b takes four columns of the diagonal sub-matrix its table
+// entry names (rows row0 .. row0 + n - 1 of the band arrays: one chunk of the partitioned factorisation, or the whole
+// separator system) and writes them as DOUBLES into that sub-matrix's own dense n x n block of Gout.
+struct BandInvItem { int32_t row0, n, cmin, pad; int64_t goff; };
+template <bool PART>
 __global__ __launch_bounds__(256) void k_band_inverse_rl(
     int nc, const double* __restrict__ Lrow, const double* __restrict__ Lcol, const double* __restrict__ rdiag,
-    double* __restrict__ Xs /* nc x nc scratch */, float* __restrict__ Ainv)
+    double* __restrict__ Xs /* nc x nc scratch */, float* __restrict__ Ainv,
+    const BandInvItem* __restrict__ items, double* __restrict__ Gout, int ldx)
 {
     constexpr int W = PS_BAND_W, T = PS_BI2_T, NPT = T * W / 256;          // 12 doubles per thread and tile
     __shared__ double tile[2][T][W];
     __shared__ double rdt[2][T];
     const int t = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int cmin = blockIdx.x * 4, c = cmin + wv;            // (wave-uniform: the per-step tests below are scalar branches)
+    int cmin = blockIdx.x * 4;
+    size_t xoff = 0;
+    if (PART) {
+        const BandInvItem it = items[blockIdx.x];
+        nc = it.n; cmin = it.cmin;
+        Lrow += (size_t)it.row0 * W; Lcol += (size_t)it.row0 * W; rdiag += it.row0;
+        Gout += it.goff;
+        xoff = (size_t)it.row0 * ldx;
+    } else ldx = nc;
+    const int c = cmin + wv;                                   // (wave-uniform: the per-step tests below are scalar branches)
     const bool live = c < nc, in = lane < W;
-    double* xs = Xs + (size_t)min(c, nc - 1) * nc;
+    double* xs = Xs + xoff + (size_t)min(c, nc - 1) * ldx;
     // tile k of a sweep: rows row0 + dir * (0 .. 63)
     auto fetch = [&](const double* __restrict__ L, int row0, int dir, double* v, double& rv) {
 #pragma unroll
@@ -355,7 +379,10 @@ __global__ __launch_bounds__(256) void k_band_inverse_rl(
                 }
             }
             const int i = top - 63 + lane;
-            if (i >= c && i <= top) { const float f = (float)yring; Ainv[(size_t)i * nc + c] = f; Ainv[(size_t)c * nc + i] = f; }
+            if (i >= c && i <= top) {
+                if (PART) { Gout[(size_t)i * nc + c] = yring; Gout[(size_t)c * nc + i] = yring; }
+                else { const float f = (float)yring; Ainv[(size_t)i * nc + c] = f; Ainv[(size_t)c * nc + i] = f; }
+            }
         }
         if (more) stash(b ^ 1, v, rv);
         xt = xn;

@@ -338,6 +338,21 @@ def dense_normal_solve(J, r, want_covariance=False):
     return (dx, cov) if want_covariance else dx
 
 
+def band_inverse(A, ncb, dof, bw, chunk_nodes=0):
+    """Inverse (fp32) of a symmetric positive definite block-banded matrix by the coarse level's factorisation kernels
+    (include/pyslam_hip.h: ps_debug_band_inverse): chunk_nodes < 0 the serial column walk, 0 / > 0 the partitioned form.
+    -> (inverse, GPU microseconds of the launches)."""
+    lib = nat.require_gpu()
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = ncb * dof
+    assert A.shape == (n, n)
+    out = np.zeros((n, n), dtype=np.float32)
+    us = C.c_double(0.0)
+    nat.check(lib.ps_debug_band_inverse(nat.f64p(A), ncb, dof, bw, chunk_nodes, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                        C.cast(C.byref(us), nat.c_f64p)))
+    return out, us.value
+
+
 class NotConverged(nat.NativeError):
     """The CG of the host-evaluated path stopped at max_iters with a residual too large to use."""
 

@@ -546,6 +546,34 @@ def test_banded_coarse_inverse_equals_the_dense_one(shape):
             assert np.abs(a - b).max() <= 1e-9
 
 
+@pytest.mark.parametrize('shape', ['ba', 'pg_se3', 'pg_se2'])
+def test_partitioned_band_factorisation_equals_the_serial_walk(shape):
+    """Round 5: the banded coarse matrix is factored and inverted in independent chunks + a separator system
+    (csrc/ps_k_bandpart.h, option band_part, default) instead of one workgroup walking its block columns (band_part 0).  The
+    same fp32 inverse to rounding: the same CG iteration counts (+-1) and the same trajectory, also with a forced chunk size."""
+    if shape == 'ba':
+        lp, _ = synthetic.stereo_ba(160, 16000, 8, 12, seed=21)
+    else:
+        lp, _ = synthetic.pose_graph(num_poses=900, num_loops=3601, dof=6 if shape == 'pg_se3' else 3, seed=22)
+    out = {}
+    for part, chunk in ((1, 0), (0, 0), (1, 5)):
+        dev = device(lp)
+        dev.set_option('cg_explicit_min_rows', 0)
+        dev.set_option('cg_split_min_rows', 0)
+        if shape == 'ba':
+            dev.set_option('coarse_groups', 40)
+        dev.set_option('band_part', part)
+        dev.set_option('band_part_chunk', chunk)
+        res = [dev.gn_iteration(0., 1e-12, 3000, True) for _ in range(4)]
+        out[(part, chunk)] = (res, dev.get_params())
+    for key in ((1, 0), (1, 5)):
+        for a, b in zip(out[key][0], out[(0, 0)][0]):
+            assert abs(a[2] - b[2]) <= 1 and abs(a[0] - b[0]) <= 1e-10 * abs(b[0]) and a[3] <= 1e-12, (key, a, b)
+        for a, b in zip(out[key][1], out[(0, 0)][1]):
+            if a.size:
+                assert np.abs(a - b).max() <= 1e-9
+
+
 def test_wide_coarse_matrix_keeps_the_dense_factorisation():
     """Hat intervals much shorter than the loop closures make A_c wider than the banded kernels take (more than 7 block
     off-diagonals): the dense path runs, and the solve still matches the oracle."""
