@@ -44,7 +44,7 @@ int ps_warm_up(void) {
         PS_TOUCH(k_cg_fused<6, 8>); PS_TOUCH(k_cg_unscale<6>); PS_TOUCH(k_update_poses<6>); PS_TOUCH(k_update_points);
         PS_TOUCH(k_xcoarse_rowsums<6>); PS_TOUCH(k_xcoarse_matrix<6>); PS_TOUCH(k_band_chol<6>); PS_TOUCH(k_band_inverse); PS_TOUCH(k_band_inverse_rl<false>);
         PS_TOUCH(k_band_inverse_rl<true>); PS_TOUCH(k_bp_v); PS_TOUCH(k_bp_t); PS_TOUCH(k_bp_w); PS_TOUCH(k_bp_dense_sep); PS_TOUCH(k_bp_dense);
-        PS_TOUCH(k_xcg_restrict<6>); PS_TOUCH(k_xcg_f2_coarse<6>); PS_TOUCH(k_xcg_fused1<6, 8, false>); PS_TOUCH(k_xcg_fused1<6, 0, true>);
+        PS_TOUCH(k_xcg_restrict<6>); PS_TOUCH(k_xcg_f2_coarse<6, 3>); PS_TOUCH(k_xcg_fused1<6, 8, false>); PS_TOUCH(k_xcg_fused1<6, 0, true>);
         PS_TOUCH(k_xcg_fused1<6, 2, false>); PS_TOUCH(k_xcg_fused1<6, 6, false>);
         PS_TOUCH(k_factor_pass<6>); PS_TOUCH(k_factor_assemble<6>); PS_TOUCH(k_cost_factors<6>);
         PS_TOUCH(k_factor_pass<3>); PS_TOUCH(k_factor_assemble<3>); PS_TOUCH(k_cost_factors<3>); PS_TOUCH(k_block_jacobi_factor<3>);

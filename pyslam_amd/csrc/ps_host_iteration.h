@@ -179,8 +179,15 @@ void xcg_launch(ps_problem* h, double tol, int count) {
 #define PS_XF_LAUNCH(PF, TWO) hipLaunchKernelGGL((k_xcg_fused1<D, PF, TWO>), dim3(h->xf_nwg), dim3(64 * PS_XF_ROWS), lds, h->stream, nr, h->arow_ptr, \
                                h->ell_wf, h->Saug, a, k, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate)
             if (h->xf_two) {
-                hipLaunchKernelGGL(k_xcg_f2_coarse<D>, dim3(cdiv(nc, PS_XCG_CROWS_BIG)), dim3(64 * PS_XCG_CROWS_BIG), (size_t)nc * sizeof(double),
-                                   h->stream, a, k, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate);
+                // (one workgroup per compute unit, all in one round: ceil(nc / 256) rows each, at most one per wave)
+                static const int f2_rows_env = ps_env("PS_F2_ROWS") ? atoi(ps_env("PS_F2_ROWS")) : 0, f2_ablate = ps_env("PS_F2_ABLATE") ? atoi(ps_env("PS_F2_ABLATE")) : 0;
+                const int f2_rows = f2_rows_env > 0 ? f2_rows_env : std::min(PS_XCG_CROWS_BIG, std::max(1, cdiv(nc, 256)));
+                if (nc <= 3 * 64 * PS_XCG_CROWS_BIG)
+                    hipLaunchKernelGGL((k_xcg_f2_coarse<D, 3>), dim3(cdiv(nc, f2_rows)), dim3(64 * PS_XCG_CROWS_BIG), (size_t)nc * sizeof(double),
+                                       h->stream, a, k, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate, f2_rows, f2_ablate);
+                else
+                    hipLaunchKernelGGL((k_xcg_f2_coarse<D, PS_XF2_NEMAX>), dim3(cdiv(nc, f2_rows)), dim3(64 * PS_XCG_CROWS_BIG), (size_t)nc * sizeof(double),
+                                       h->stream, a, k, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate, f2_rows, f2_ablate);
                 static const int pf_env = ps_env("PS_XF2_PF") ? atoi(ps_env("PS_XF2_PF")) : -1;
                 // more workgroups than the chip holds at once: the kernel's time is (rounds of workgroups) x (its dependent
                 // phases), so registers go to occupancy, not to prefetch (C2, 1 250 workgroups: 24.4 us with PF = 6)

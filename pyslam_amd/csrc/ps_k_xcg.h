@@ -848,10 +848,11 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
 // k_xcg_fused1<.., TWO = true> reads alpha, beta (xstate[6], [7]) and its nodes' y.  Same recurrences, same records.
 // ---------------------------------------------------------------------------
 #define PS_XF2_NEMAX 6                        // coarse entries per thread: nc <= 6 * 1024 (PS_XCG_MAXNODES nodes of SE(3))
-template <int D>
+// NE: coarse entries per thread (3: nc <= 3 072 -- C2 -- leaves the registers for 16 row loads in flight per lane; 6: up to 6 144, 8 in flight)
+template <int D, int NE>
 __global__ __launch_bounds__(64 * PS_XCG_CROWS_BIG) void k_xcg_f2_coarse(
     XcgFusedArgs a, int k, double tol2, double* __restrict__ hist, int cap, int32_t* __restrict__ status,
-    double* __restrict__ scalars, double* __restrict__ xstate)
+    double* __restrict__ scalars, double* __restrict__ xstate, int rows_per_wg, int ablate /* measurement build: 1 no rows, 2 no records */)
 {
     constexpr int NT = 64 * PS_XCG_CROWS_BIG;
     extern __shared__ __attribute__((aligned(16))) double tl[];   // nc: t_{k+1}
@@ -862,9 +863,9 @@ __global__ __launch_bounds__(64 * PS_XCG_CROWS_BIG) void k_xcg_f2_coarse(
     const double g_prev = hist[k > 0 ? k - 1 : 0], a_prev = hist[cap + (k > 0 ? k - 1 : 0)], thresh_in = xstate[1];
     double gs = 0.0, ds = 0.0;
     if (k >= 0) for (int i = tid; i < a.nwg; i += NT) { gs += a.gd_in[i]; ds += a.gd_in[a.nwg + i]; }
-    double to[PS_XF2_NEMAX], tso[PS_XF2_NEMAX], sq[PS_XF2_NEMAX];
+    double to[NE], tso[NE], sq[NE];
 #pragma unroll
-    for (int u = 0; u < PS_XF2_NEMAX; ++u) {
+    for (int u = 0; u < NE; ++u) {
         const int e = tid + u * NT;
         to[u] = tso[u] = sq[u] = 0.0;
         if (e < nc) {
@@ -872,14 +873,14 @@ __global__ __launch_bounds__(64 * PS_XCG_CROWS_BIG) void k_xcg_f2_coarse(
             to[u] = a.t_in[e]; tso[u] = a.ts_in[e];
             double rec[PS_XF_RB];
 #pragma unroll
-            for (int c = 0; c < PS_XF_RB; ++c) rec[c] = (c < a.rmax) ? a.tq_in[((size_t)n * a.rmax + c) * D + m] : 0.0;
+            for (int c = 0; c < PS_XF_RB; ++c) rec[c] = (c < a.rmax && !(ablate & 2)) ? a.tq_in[((size_t)n * a.rmax + c) * D + m] : 0.0;
 #pragma unroll
             for (int c = 0; c < PS_XF_RB; ++c) sq[u] += rec[c];
         }
     }
-    for (int base = PS_XF_RB; base < a.rmax; base += PS_XF_RB) {
+    for (int base = PS_XF_RB; base < a.rmax && !(ablate & 2); base += PS_XF_RB) {
 #pragma unroll
-        for (int u = 0; u < PS_XF2_NEMAX; ++u) {
+        for (int u = 0; u < NE; ++u) {
             const int e = tid + u * NT;
             if (e < nc) {
                 const int n = e / D, m = e - n * D;
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(64 * PS_XCG_CROWS_BIG) void k_xcg_f2_coarse(
     }
     // ---- 1. t_{k+1} (all of it) into LDS
 #pragma unroll
-    for (int u = 0; u < PS_XF2_NEMAX; ++u) {
+    for (int u = 0; u < NE; ++u) {
         const int e = tid + u * NT;
         if (e < nc) {
             const double ts = sq[u] + beta * tso[u];
@@ -924,16 +925,38 @@ __global__ __launch_bounds__(64 * PS_XCG_CROWS_BIG) void k_xcg_f2_coarse(
         }
     }
     __syncthreads();
-    // ---- 2. PS_XCG_CROWS_BIG rows of y = A_c^-1 t_{k+1}, one wave per row
-    const int row = wg * PS_XCG_CROWS_BIG + (tid >> 6), lane = tid & 63;
-    if (row >= nc) return;
+    // ---- 2. y = A_c^-1 t_{k+1}, one wave per row, rows_per_wg = ceil(nc / 256) rows per workgroup: every compute unit has one
+    // workgroup and all of them run in ONE round (the skeleton in front of this point costs 8.4 us per round at C2 -- measured with
+    // the rows switched off -- so more, smaller workgroups lose: 8 rows each 31 us).  Round 3 read a row 128 columns at a time with
+    // 8-byte loads, 3.7 TB/s out of the Infinity Cache; 16-byte loads, all of a lane's share of the row requested before the first
+    // multiply: the rows start on 16 bytes or 8 bytes past (nc even), so a row is [head pair] + float4 body + [tail pair].
+    const int wv = tid >> 6, lane = tid & 63;
+    const int row = wg * rows_per_wg + wv;
+    if (wv >= rows_per_wg || row >= nc || (ablate & 1)) return;
     const float* ar = a.Ainv + (size_t)row * nc;
     double v = 0.0;
     if ((nc & 1) == 0) {
-        for (int j = 2 * lane; j < nc; j += 128) {
-            const float2 f = *reinterpret_cast<const float2*>(ar + j);
-            v += (double)f.x * tl[j] + (double)f.y * tl[j + 1];
+        const int head = (int)(((size_t)row * nc) & 3);          // 0 or 2 floats in front of the first 16-byte boundary
+        const int nq = (nc - head) >> 2, tail0 = head + 4 * nq;  // float4 body, then 0 or 2 floats
+        const float4* ab = reinterpret_cast<const float4*>(ar + head);
+        constexpr int U = 12;                                    // 12 x 64 float4 = 3 072 columns per pass
+        float2 hp = make_float2(0.f, 0.f);
+        if (lane == 0 && head) hp = *reinterpret_cast<const float2*>(ar);
+        if (lane == 1 && tail0 < nc) hp = *reinterpret_cast<const float2*>(ar + tail0);
+        for (int q0 = lane; q0 < nq; q0 += 64 * U) {
+            float4 f[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int q = q0 + 64 * u; f[u] = q < nq ? ab[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = min(q0 + 64 * u, nq - 1);          // (beyond the row: f = 0)
+                const double2 t0 = *reinterpret_cast<const double2*>(tl + head + 4 * q);
+                const double2 t1 = *reinterpret_cast<const double2*>(tl + head + 4 * q + 2);
+                v += ((double)f[u].x * t0.x + (double)f[u].y * t0.y) + ((double)f[u].z * t1.x + (double)f[u].w * t1.y);
+            }
         }
+        if (lane == 0 && head) v += (double)hp.x * tl[0] + (double)hp.y * tl[1];
+        if (lane == 1 && tail0 < nc) v += (double)hp.x * tl[tail0] + (double)hp.y * tl[tail0 + 1];
     } else {
         for (int j = lane; j < nc; j += 64) v += (double)ar[j] * tl[j];
     }
