@@ -57,6 +57,14 @@ PS_DEV double ps_loss_weight(int id, double k, double x) {
     }
 }
 
+// sqrt(w(x)): the IRLS scale of a residual component (reference pyslam/problem.py:351-360).  The loss id is wave-uniform (scalar
+// branch), and the L2 case -- every observation of the BASELINE stereo BA -- returns its 1 without a double-precision square
+// root of a run-time 1.0 (three of them per observation and pass: sqrt(1.0) == 1.0 exactly, so the results are the same bits)
+PS_DEV double ps_loss_sqrt_weight(int id, double k, double x) {
+    if (id == PS_LOSS_L2) return 1.0;
+    return sqrt(ps_loss_weight(id, k, x));
+}
+
 // ---------------------------------------------------------------------------
 // SE(3): R row-major (9) | t (3)
 // ---------------------------------------------------------------------------
@@ -334,7 +342,7 @@ PS_DEV void reproj_eval_s(const Se3& T, const double* __restrict__ pw, const dou
     for (int i = 0; i < 3; ++i) {
         const double ri = Sv[3 * i] * e0 + Sv[3 * i + 1] * e1 + Sv[3 * i + 2] * e2;
         o.cost += ps_loss_rho(g.loss_id, g.loss_k, ri);
-        s[i] = sqrt(ps_loss_weight(g.loss_id, g.loss_k, ri));
+        s[i] = ps_loss_sqrt_weight(g.loss_id, g.loss_k, ri);
         o.r[i] = s[i] * ri;
     }
     if (!WITH_JP && !WITH_JL) return;
