@@ -389,6 +389,9 @@ def main():
     ap.add_argument('--no-wall', action='store_true', help='skip the Problem.solve() wall-clock leg (500 000 Python block objects)')
     ap.add_argument('--force-sharded', action='store_true',
                     help='use the multi-GPU driver (RCCL all-reduce) even with one rank (testing)')
+    ap.add_argument('--shard-order', default='first_pose', choices=['first_pose', 'index'],
+                    help="how landmarks are cut into shards (pyslam_amd/distributed.py: landmark_owner_lists)")
+    ap.add_argument('--exchange', default=None, choices=['allreduce', 'segments'])
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -425,8 +428,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     if dist is not None:
         from pyslam_amd.distributed import ShardedDeviceProblem, shard_landmarks
-        lp = shard_landmarks(lp_full, rank, world)               # the FIXED problem, split N ways (strong scaling)
-        dev = ShardedDeviceProblem(lp, dist)
+        lp = shard_landmarks(lp_full, rank, world, order=args.shard_order)       # the FIXED problem, split N ways (strong scaling)
+        dev = ShardedDeviceProblem(lp, dist, exchange=args.exchange)
     else:
         from pyslam_amd.device import DeviceProblem
         lp = lp_full

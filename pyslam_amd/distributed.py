@@ -22,25 +22,53 @@ import numpy as np
 from pyslam_amd.lowering import LoweredProblem
 
 
-def shard_landmarks(lp, rank, world):
-    """Contiguous landmark range balanced by observation count; factors on rank 0."""
+def landmark_owner_lists(lp, world, order='first_pose'):
+    """Which landmarks (the caller's numbering, ascending) every rank owns.
+
+    ``order='first_pose'`` (default, round 5): landmarks are put in the order of the LOWEST POSE INDEX THAT OBSERVES them --
+    the order the device gives its landmark slots (csrc/ps_abi_problem.h "internal landmark order") -- and that order is
+    cut into ``world`` contiguous runs balanced by observation count.  On a trajectory a landmark is seen from a window of
+    poses, so a rank's landmarks touch one SEGMENT of the pose chain: its partial reduced system is a band segment of S
+    (plus a halo of one co-visibility window on either side), its Schur task list is 1/world of the whole one, and what it
+    has to contribute to the exchange is that segment only (``ShardedDeviceProblem``: segment all-gather).
+    ``order='index'`` (rounds 1-4): contiguous ranges of the caller's landmark index -- with landmarks numbered in no
+    particular order every shard touches every block of S."""
+    L = lp.num_points
+    if world == 1:
+        return [np.arange(L, dtype=np.int64)]
+    counts = np.bincount(lp.obs_point, minlength=L).astype(np.int64)
+    if order == 'first_pose':
+        first = np.full(L, lp.num_poses, dtype=np.int64)          # (a landmark nobody observes sorts last)
+        np.minimum.at(first, lp.obs_point, lp.obs_pose)
+        perm = np.lexsort((np.arange(L), first))
+    elif order == 'index':
+        perm = np.arange(L, dtype=np.int64)
+    else:
+        raise ValueError("order must be 'first_pose' or 'index'")
+    cum = np.concatenate([[0], np.cumsum(counts[perm])])
+    total = cum[-1]
+    cuts = [int(np.searchsorted(cum, total * r / world, side='left')) for r in range(world)] + [L]
+    return [np.sort(perm[cuts[r]:cuts[r + 1]]) for r in range(world)]
+
+
+def shard_landmarks(lp, rank, world, order='first_pose', owners=None):
+    """This rank's landmark shard (``landmark_owner_lists``), balanced by observation count; factors on rank 0."""
     if world == 1:
         return lp
+    idx = (owners if owners is not None else landmark_owner_lists(lp, world, order))[rank]
     L = lp.num_points
-    counts = np.bincount(lp.obs_point, minlength=L).astype(np.int64)
-    cum = np.concatenate([[0], np.cumsum(counts)])
-    total = cum[-1]
-    bounds = [int(np.searchsorted(cum, total * r / world, side='left')) for r in range(world)] + [L]
-    lo, hi = bounds[rank], bounds[rank + 1]
-    keep = (lp.obs_point >= lo) & (lp.obs_point < hi)
+    remap = np.full(L, -1, dtype=np.int64)
+    remap[idx] = np.arange(idx.size)
+    new_point = remap[lp.obs_point]
+    keep = new_point >= 0
     out = lp.copy()
-    out.points = lp.points[lo:hi]
-    vid = lp.point_vid[lo:hi].copy()
+    out.points = lp.points[idx]
+    vid = lp.point_vid[idx].copy()
     var = vid >= 0
     vid[var] = np.arange(int(var.sum()))
     out.point_vid = vid
-    out.point_keys = list(lp.point_keys[lo:hi])
-    out.obs_pose, out.obs_point = lp.obs_pose[keep], lp.obs_point[keep] - lo
+    out.point_keys = [lp.point_keys[i] for i in idx]
+    out.obs_pose, out.obs_point = lp.obs_pose[keep], new_point[keep].astype(lp.obs_point.dtype)
     out.obs_uvd, out.obs_grp = lp.obs_uvd[keep], lp.obs_grp[keep]
     if rank != 0:
         pw = lp.pose_width
@@ -73,6 +101,98 @@ def pose_pair_keys(lp):
         ok = (a >= 0) & (b >= 0) & (a != b)
         keys.append(np.unique((np.minimum(a, b)[ok] << 32) | np.maximum(a, b)[ok]))
     return np.unique(np.concatenate(keys)) if keys else np.zeros(0, np.int64)
+
+
+def shard_touch(lp):
+    """(upper block keys incl. diagonals, reduced poses) this shard's partial reduced system can be non-zero in: blocks
+    (ri<<32|rj, ri <= rj) coupled through its landmarks / factors, the diagonal block and gradient rows of every variable
+    pose it observes or has a factor on."""
+    rid = lp.pose_rid.astype(np.int64)
+    touched = [rid[lp.obs_pose]] if lp.num_obs else []
+    if lp.num_edges:
+        touched += [rid[lp.e_i], rid[lp.e_j]]
+    if getattr(lp, 'num_priors', 0):
+        touched.append(rid[lp.u_i])
+    poses = np.unique(np.concatenate(touched)) if touched else np.zeros(0, np.int64)
+    poses = poses[poses >= 0]
+    blocks = np.unique(np.concatenate([pose_pair_keys(lp), (poses << 32) | poses]))
+    return blocks, poses
+
+
+def packed_layout(pattern_keys, nr, dof):
+    """Element indices inside the core's exchange buffer [upper(S) | g | cost (2) | flag] (csrc/ps_k_tail.h: k_shard_pack; the
+    upper blocks in (row, column) order = ascending key order, diagonals included).  -> (indices(blocks, poses), tail indices)."""
+    all_keys = np.unique(np.concatenate([pattern_keys, (np.arange(nr, dtype=np.int64) << 32) | np.arange(nr, dtype=np.int64)]))
+    dd, nup = dof * dof, all_keys.size
+
+    def indices(blocks, poses):
+        slot = np.searchsorted(all_keys, blocks)
+        if blocks.size and (slot.max() >= nup or not np.array_equal(all_keys[slot], blocks)):
+            raise ValueError('a shard touches a block outside the common pattern')
+        blk = (slot[:, None] * dd + np.arange(dd)[None, :]).ravel()
+        grad = nup * dd + (poses[:, None] * dof + np.arange(dof)[None, :]).ravel()
+        return np.concatenate([blk, grad]).astype(np.int64)
+    tail = nup * dd + nr * dof + np.arange(3, dtype=np.int64)
+    return indices, tail
+
+
+class SegmentExchange:
+    """Round 5: the exchange of the partial reduced systems as an ALL-GATHER OF SEGMENTS instead of a sum all-reduce of
+    the whole buffer.  With landmarks sharded by first observing pose (landmark_owner_lists) a rank's partial system is
+    non-zero on one band segment of S (+ a halo of one co-visibility window) -- C4 on 8 ranks: 3.4 MB of the 23.5 MB
+    buffer -- so every rank sends its segment once, receives the others', and adds them up itself in a FIXED order (the
+    same on every rank: the replicated reduced solve stays bit-identical across ranks).  A ring all-reduce moves
+    2 (N-1)/N x 23.5 MB per link, the segment all-gather (N-1) x 3.4 MB; with neighbours overlapping only pairwise the
+    sum is two scatter-adds (even ranks, then odd ranks: no index twice inside one of them, hence no atomics race).
+    Buffer per rank: [tail words (cost, flag: summed over ranks) | its elements], padded to the longest.
+    Unmeasured on hardware (one GPU per lease): opt-in (ShardedDeviceProblem(exchange='segments') /
+    PYSLAM_AMD_EXCHANGE=segments); the sum all-reduce stays the default."""
+
+    def __init__(self, dist, torch, reduce_tensor, idx_lists, tail_idx):
+        self.dist, self.torch = dist, torch
+        self.buf = reduce_tensor
+        dev = reduce_tensor.device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.T = int(tail_idx.size)
+        self.lens = [int(i.size) for i in idx_lists]
+        self.maxlen = self.T + max(self.lens)
+        self.tail = torch.as_tensor(tail_idx, device=dev)
+        self.mine = torch.as_tensor(idx_lists[self.rank], device=dev)
+        self.seg_in = torch.zeros(self.maxlen, dtype=reduce_tensor.dtype, device=dev)
+        self.seg_all = torch.zeros(self.world, self.maxlen, dtype=reduce_tensor.dtype, device=dev)
+        # passes: ranks whose index sets are pairwise disjoint are added in ONE scatter-add (greedy colouring in rank
+        # order; a chain of windows gives two passes, anything gives at most `world`)
+        passes, sets = [], []
+        for r, idx in enumerate(idx_lists):
+            for k, members in enumerate(passes):
+                if not np.intersect1d(sets[k], idx, assume_unique=True).size:
+                    members.append(r); sets[k] = np.union1d(sets[k], idx)
+                    break
+            else:
+                passes.append([r]); sets.append(idx)
+        self.passes = []
+        for members in passes:
+            dst = np.concatenate([idx_lists[r] for r in members])
+            src = np.concatenate([r * self.maxlen + self.T + np.arange(self.lens[r], dtype=np.int64) for r in members])
+            self.passes.append((torch.as_tensor(dst, device=dev), torch.as_tensor(src, device=dev)))
+        self.bytes_sent = 8 * (self.T + self.lens[self.rank])
+        self.bytes_allreduce = 8 * int(reduce_tensor.numel())
+
+    def run(self):
+        """reduce_tensor (this rank's partial system, packed) -> the sum over ranks, in place."""
+        t = self.torch
+        n = self.lens[self.rank]
+        self.seg_in[:self.T] = self.buf[self.tail]
+        t.index_select(self.buf, 0, self.mine, out=self.seg_in[self.T:self.T + n])
+        if self.dist.get_backend() == 'nccl':
+            self.dist.all_gather_into_tensor(self.seg_all, self.seg_in)
+        else:
+            self.dist.all_gather(list(self.seg_all.unbind(0)), self.seg_in)
+        self.buf.zero_()
+        flat = self.seg_all.view(-1)
+        for dst, src in self.passes:
+            self.buf.index_add_(0, dst, flat.index_select(0, src))
+        self.buf[self.tail] = self.seg_all[:, :self.T].sum(0)
 
 
 class NativeRccl:
@@ -182,14 +302,25 @@ def _default_device_factory(lp, extra_pairs):
 class ShardedDeviceProblem:
     """Same surface as DeviceProblem for the pieces Problem.solve / bench.py use."""
 
-    def __init__(self, lp_shard, dist, device_factory=None, native_rccl=True):
+    def __init__(self, lp_shard, dist, device_factory=None, native_rccl=True, exchange=None, pattern_keys=None):
+        """exchange: 'allreduce' (default: one sum all-reduce of the whole packed system, driven by the core itself when the
+        native RCCL communicator is up) or 'segments' (SegmentExchange; torch.distributed collectives).  pattern_keys: more
+        block keys for the common pattern (bench.py --emulate-shard: one rank of N on one GPU with all N ranks' pattern)."""
+        import os
         import torch
         self._torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.exchange = exchange or os.environ.get('PYSLAM_AMD_EXCHANGE', 'allreduce')
+        if self.exchange not in ('allreduce', 'segments'):
+            raise ValueError("exchange must be 'allreduce' or 'segments'")
+        if self.exchange == 'segments':
+            native_rccl = False                              # (the core's own iteration knows the sum all-reduce only)
         mine = pose_pair_keys(lp_shard)
         gathered = [None] * self.world
         dist.all_gather_object(gathered, mine)
         union = np.unique(np.concatenate(gathered)) if gathered else mine
+        if pattern_keys is not None:
+            union = np.union1d(union, np.asarray(pattern_keys, dtype=np.int64))
         extra = np.setdiff1d(union, mine)
         pairs = ((extra >> 32).astype(np.int32), (extra & 0xFFFFFFFF).astype(np.int32))
         self.pattern_keys = union
@@ -228,6 +359,15 @@ class ShardedDeviceProblem:
         # option stays for problems whose coarse matrix is not banded.)
         self._scal = torch.zeros(2, dtype=torch.float64, device=self.dev.reduce_tensor.device)
         self._prof_level, self._pending_events, self._host_stage = 0, [], {}
+        self.segments = None
+        if self.exchange == 'segments':
+            touch = [None] * self.world
+            dist.all_gather_object(touch, shard_touch(lp_shard))
+            if hasattr(self.dev, 'segment_layout'):          # (the CPU stand-in of the tests has its own buffer layout)
+                indices, tail = self.dev.segment_layout()
+            else:
+                indices, tail = packed_layout(union, lp_shard.num_reduced, lp_shard.dof)
+            self.segments = SegmentExchange(dist, torch, self.dev.reduce_tensor, [indices(b, p) for b, p in touch], tail)
 
     # ---- iteration -----------------------------------------------------
     def eval_cost(self, include_all_constant=True):
@@ -244,7 +384,10 @@ class ShardedDeviceProblem:
             if hasattr(self.dev, 'shard_pack'):
                 self.dev.shard_pack()                         # [upper(S) | g | cost | failure flag]
         with self._timed('allreduce'):
-            self.dist.all_reduce(self.dev.reduce_tensor)      # RCCL sum over xGMI, on the solver's stream
+            if self.segments is not None:
+                self.segments.run()                           # all-gather of the ranks' band segments + fixed-order sum
+            else:
+                self.dist.all_reduce(self.dev.reduce_tensor)  # RCCL sum over xGMI, on the solver's stream
         with self._timed('pack_unpack'):
             if hasattr(self.dev, 'shard_unpack'):
                 self.dev.shard_unpack()                       # mirrored back into S; a shard's failure reaches every rank
@@ -332,7 +475,7 @@ class ShardedDeviceProblem:
 
 
 def landmark_bounds(lp, world):
-    """The contiguous landmark ranges shard_landmarks cuts (len world + 1)."""
+    """The contiguous landmark ranges ``order='index'`` cuts (len world + 1) -- rounds 1-4's split, kept for comparison."""
     L = lp.num_points
     if world == 1:
         return [0, L]
@@ -351,8 +494,8 @@ class ShardedProblemView:
     def __init__(self, lp, dist, device_factory=None, native_rccl=True):
         self.lp, self.dist = lp, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.bounds = landmark_bounds(lp, self.world)
-        self.sharded = ShardedDeviceProblem(shard_landmarks(lp, self.rank, self.world), dist,
+        self.owners = landmark_owner_lists(lp, self.world)   # every rank computes every rank's list: no exchange needed
+        self.sharded = ShardedDeviceProblem(shard_landmarks(lp, self.rank, self.world, owners=self.owners), dist,
                                             device_factory=device_factory, native_rccl=native_rccl)
         self.dof = lp.dof
         self.info = dict(self.sharded.info)
@@ -360,14 +503,16 @@ class ShardedProblemView:
 
     # ---- parameters: full tables <-> this rank's shard ---------------------
     def set_params(self, poses=None, points=None):
-        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
-        self.sharded.dev.set_params(poses, None if points is None else np.ascontiguousarray(points[lo:hi]))
+        self.sharded.dev.set_params(poses, None if points is None else np.ascontiguousarray(np.asarray(points)[self.owners[self.rank]]))
 
     def get_params(self):
         poses, mine = self.sharded.get_params()
         parts = [None] * self.world
         self.dist.all_gather_object(parts, mine)
-        return poses, np.concatenate(parts).reshape(-1, 3)
+        points = np.empty((self.lp.num_points, 3))
+        for r in range(self.world):                          # every landmark row back to the caller's numbering
+            points[self.owners[r]] = np.asarray(parts[r]).reshape(-1, 3)
+        return poses, points
 
     def get_dx(self):
         """(dx_pose, dx_point) of the last iteration in the FULL problem's device order.  After a staged solve
@@ -380,7 +525,11 @@ class ShardedProblemView:
         xp, xl = self.sharded.dev.get_dx()
         parts = [None] * self.world
         self.dist.all_gather_object(parts, xl)
-        return xp, np.concatenate(parts).reshape(-1, 3)
+        full = np.empty((self.lp.num_var_points, 3))
+        for r in range(self.world):                          # a shard's variable landmarks keep their relative order: its vid k
+            vids = self.lp.point_vid[self.owners[r]]         # is the k-th variable landmark of its (ascending) index list
+            full[vids[vids >= 0]] = np.asarray(parts[r]).reshape(-1, 3)
+        return xp, full
 
     def snapshot(self):
         self.sharded.snapshot()

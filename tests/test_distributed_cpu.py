@@ -67,6 +67,19 @@ class OracleShardDevice:
         return cost, float(self.dxp @ self.dxp), float(dxl @ dxl)
 
 
+    def segment_layout(self):
+        """(indices(blocks, poses), tail) of this stand-in's buffer [dense S | g | cost] for SegmentExchange."""
+        n, d = self.n, self.lp.dof
+
+        def indices(blocks, poses):
+            ri, rj = (blocks >> 32).astype(np.int64), (blocks & 0xFFFFFFFF).astype(np.int64)
+            e = np.arange(d)
+            rows = (ri[:, None, None] * d + e[None, :, None]) * n + rj[:, None, None] * d + e[None, None, :]
+            rowsT = (rj[:, None, None] * d + e[None, :, None]) * n + ri[:, None, None] * d + e[None, None, :]
+            grad = n * n + (poses[:, None] * d + e[None, :]).ravel()
+            return np.unique(np.concatenate([rows.ravel(), rowsT.ravel(), grad])).astype(np.int64)
+        return indices, np.array([n * n + n], dtype=np.int64)
+
     # parameter tables in and out (what Problem.solve drives through ShardedProblemView)
     def get_params(self):
         return self.lp.poses.copy(), self.lp.points.copy()
@@ -96,13 +109,15 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, exchange='allreduce', kf=8, lm=90):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    lp, _ = synthetic.stereo_ba(num_kf=8, num_lm=90, obs_per_lm=4, half_window=3, seed=11)
+    lp, _ = synthetic.stereo_ba(num_kf=kf, num_lm=lm, obs_per_lm=4, half_window=3, seed=11)
     # an odometry edge + prior so factors exist (rank 0 only after sharding)
     shard = shard_landmarks(lp, rank, world)
-    sp = ShardedDeviceProblem(shard, dist, device_factory=lambda l, e: OracleShardDevice(l, e))
+    sp = ShardedDeviceProblem(shard, dist, device_factory=lambda l, e: OracleShardDevice(l, e), exchange=exchange)
+    if exchange == 'segments':
+        assert sp.segments is not None and sp.segments.bytes_sent < sp.segments.bytes_allreduce
     c0 = sp.eval_cost(True)
     cost, nrm, _, _ = sp.gn_iteration(0., 1e-12, 100, True)
     poses, _ = sp.dev.lp.poses, None
@@ -133,6 +148,47 @@ def test_two_rank_iteration_matches_single_process():
     assert abs(nrm - np.linalg.norm(dx)) <= 1e-9 * nrm
     assert np.abs(poses - new.poses).max() < 1e-9
     assert np.array_equal(keys, pose_pair_keys(lp))          # union of shard patterns == global pattern
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_segment_all_gather_gives_the_all_reduced_system(world):
+    """Round 5: landmarks sharded by first observing pose + the exchange as an all-gather of band segments summed in a fixed order
+    (pyslam_amd/distributed.py: SegmentExchange) -- the same Gauss-Newton step as the single-process oracle, on a chain long
+    enough (24 keyframes, windows of 7) that a rank's segment is a proper part of the system."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, 'segments', 24, 300)) for r in range(world)]
+    for p in procs:
+        p.start()
+    c0, cost, nrm, keys, poses = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lp, _ = synthetic.stereo_ba(num_kf=24, num_lm=300, obs_per_lm=4, half_window=3, seed=11)
+    assert abs(c0 - orc.eval_cost(lp)) <= 1e-12 * c0
+    dx, _ = orc.gauss_newton_step(lp, points_first=False)
+    new = orc.apply_update(lp, dx, points_first=False)
+    assert abs(cost - orc.eval_cost(new)) <= 1e-9 * cost
+    assert abs(nrm - np.linalg.norm(dx)) <= 1e-9 * nrm
+    assert np.abs(poses - new.poses).max() < 1e-9
+
+
+def test_locality_shards_touch_band_segments():
+    """landmark_owner_lists(order='first_pose'): a rank's landmarks see a contiguous stretch of the trajectory, so its blocks
+    of S are a fraction of the pattern; the caller-index split of rounds 1-4 touches (nearly) all of it on every rank."""
+    from pyslam_amd.distributed import landmark_owner_lists, shard_touch
+    lp, _ = synthetic.stereo_ba(num_kf=80, num_lm=2000, obs_per_lm=5, half_window=4, seed=5)
+    total = pose_pair_keys(lp).size + lp.num_reduced
+    for order, bound in (('first_pose', 0.45), ('index', 1.01)):
+        owners = landmark_owner_lists(lp, 4, order)
+        assert np.array_equal(np.sort(np.concatenate(owners)), np.arange(lp.num_points))
+        frac = [shard_touch(shard_landmarks(lp, r, 4, owners=owners))[0].size / total for r in range(4)]
+        assert max(frac) <= bound, (order, frac)
+        if order == 'index':
+            assert min(frac) > 0.9, frac
+        obs = [shard_landmarks(lp, r, 4, owners=owners).num_obs for r in range(4)]
+        assert max(obs) - min(obs) <= 0.1 * lp.num_obs / 4 + 10
 
 
 def test_shards_partition_the_problem():

@@ -59,7 +59,30 @@ def test_one_rank_sharded_iteration_equals_the_unsharded_one(dist1, native, expl
     ref.close()
 
 
-def _two_rank_worker(rank, world, port, out, native):
+def test_one_rank_segment_exchange_is_the_identity(dist1):
+    """exchange='segments' (round 5) with one rank: the element list built on the host (packed_layout: the upper blocks in key
+    order, gradient rows, tail words) must cover everything the core's pack kernel leaves non-zero -- gather, all-gather over
+    one rank and the scatter-add then reproduce the buffer, and the iterations are the unsharded ones bit for bit."""
+    import torch
+    from pyslam_amd.device import DeviceProblem
+    from pyslam_amd.distributed import ShardedDeviceProblem
+    lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=4000, obs_per_lm=6, half_window=8, seed=3)
+    ref = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
+    ref.set_option('lagged_inverse', 0)
+    sh = ShardedDeviceProblem(lp, dist1, exchange='segments')
+    assert sh.native is None and sh.segments is not None
+    for _ in range(3):
+        a = ref.gn_iteration(0., 1e-12, 1000, True)
+        b = sh.gn_iteration(0., 1e-12, 1000, True)
+        assert a[0] == b[0] and a[2] == b[2]
+    pa, la = ref.get_params()
+    pb, lb = sh.get_params()
+    assert np.array_equal(pa, pb) and np.array_equal(la, lb)
+    sh.close()
+    ref.close()
+
+
+def _two_rank_worker(rank, world, port, out, native, exchange='allreduce'):
     """One of two processes sharing cuda:0: the REAL device code on a landmark shard, the collectives over
     gloo (RCCL refuses two ranks on one device; the arithmetic of the exchange is the same)."""
     import torch
@@ -69,7 +92,9 @@ def _two_rank_worker(rank, world, port, out, native):
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=4000, obs_per_lm=6, half_window=8, seed=3)
-    sp = ShardedDeviceProblem(shard_landmarks(lp, rank, world), dist, native_rccl=False)
+    sp = ShardedDeviceProblem(shard_landmarks(lp, rank, world), dist, native_rccl=False, exchange=exchange)
+    if exchange == 'segments':
+        assert sp.segments.bytes_sent < 0.8 * sp.segments.bytes_allreduce      # a band segment, not the whole system
     if native:
         # drive the core's OWN collective path (ps_set_collective: ps_gn_iteration issues both all-reduces
         # itself) with a stand-in for ncclAllReduce that sums over gloo -- same signature, in place
@@ -93,8 +118,8 @@ def _two_rank_worker(rank, world, port, out, native):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('native', [False, True])
-def test_two_ranks_on_one_gpu_reproduce_the_unsharded_iterations(native):
+@pytest.mark.parametrize('native,exchange', [(False, 'allreduce'), (True, 'allreduce'), (False, 'segments')])
+def test_two_ranks_on_one_gpu_reproduce_the_unsharded_iterations(native, exchange):
     """world_size 2 with the real HIP core in both ranks (one GPU, gloo collectives): sharded linearisation,
     all-reduce of [S | g | cost], replicated reduced solve, shard-local tail, all-reduce of the shard scalars."""
     import socket
@@ -104,7 +129,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_unsharded_iterations(native):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, native)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, native, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     trace, poses = q.get(timeout=300)
