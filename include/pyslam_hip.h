@@ -126,7 +126,11 @@ int ps_warm_up(void);
    columns (csrc/ps_host_build.h; with PS_DESC_DEVICE_TABLES the columns are read in place), bit-identical to the host
    builder that smaller problems use.  Environment, read once here: PS_CREATE_DEVICE = 0 host builder / 1 by size
    (default) / 2 always; PS_SCHUR_MODE, PS_SCHUR_TILE_KB, PS_SCHUR_TILE_MIN_MB, PS_CREATE_KEYS64: list variants the
-   parity tests hold against each other. */
+   parity tests hold against each other.
+   THREADS: the host builder (below 200 000 observations, pose graphs, more than 255 observation groups) splits its
+   counting sorts over up to 16 std::threads, all joined before this call returns; no other entry point of this header
+   creates a host thread, and none is alive between calls.  (SURVEY section 8b asked for "no internal host threads": true
+   of the iteration path; at create time the device build is the single-threaded route.) */
 int ps_problem_create(const ps_problem_desc* desc, void* stream, ps_problem** out);
 int ps_problem_destroy(ps_problem* h);
 int ps_get_info(ps_problem* h, ps_problem_info* info);

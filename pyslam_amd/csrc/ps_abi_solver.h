@@ -63,7 +63,7 @@ int ps_shard_pack(ps_problem* h) {
     if (!h) return fail("null argument");
     if (ensure_shard_pack(h)) return -1;
     const long ntail = (long)h->nr * h->D + 2;
-    const int nb = (int)std::min<long>(1 << 20, cdiv(h->pack_count, 256));      // (one element per thread: the capped grid of rounds 1-4 ran a dependent slot -> block load chain three times per thread, 63 us for C4's 23.5 MB)
+    const int nb = (int)std::min<long>(4096, cdiv(h->pack_count, 256));
     if (h->D == 6) hipLaunchKernelGGL(k_shard_pack<6>, dim3(nb), dim3(256), 0, h->stream, h->nup, h->up_slot, h->S, ntail, h->g, h->status, h->shard_pack);
     else hipLaunchKernelGGL(k_shard_pack<3>, dim3(nb), dim3(256), 0, h->stream, h->nup, h->up_slot, h->S, ntail, h->g, h->status, h->shard_pack);
     return 0;
@@ -74,7 +74,7 @@ int ps_shard_unpack(ps_problem* h) {
     h->prelin_valid = false;            // S and g are overwritten with the all-reduced system
     if (ensure_shard_pack(h)) return -1;
     const long ntail = (long)h->nr * h->D + 2;
-    const int nb = (int)std::min<long>(1 << 20, cdiv(h->pack_count, 256));      // (one element per thread: the capped grid of rounds 1-4 ran a dependent slot -> block load chain three times per thread, 63 us for C4's 23.5 MB)
+    const int nb = (int)std::min<long>(4096, cdiv(h->pack_count, 256));
     if (h->D == 6) hipLaunchKernelGGL(k_shard_unpack<6>, dim3(nb), dim3(256), 0, h->stream, h->nup, h->up_slot, h->upT_slot, h->shard_pack, h->S, ntail, h->g, h->status);
     else hipLaunchKernelGGL(k_shard_unpack<3>, dim3(nb), dim3(256), 0, h->stream, h->nup, h->up_slot, h->upT_slot, h->shard_pack, h->S, ntail, h->g, h->status);
     return 0;

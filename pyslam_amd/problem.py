@@ -138,6 +138,31 @@ def device_solve(dev, opt, use_core_loop=True, call_ms=None):
     return history, stats
 
 
+def solve_tables(lp, options=None, stream=None, device=None):
+    """BATCH ENTRY for large problems: the solve of ``Problem.solve()`` from TABLES instead of one Python object per residual
+    block (INTEGRATION.md "Batch entry").  ``lp``: a ``pyslam_amd.lowering.LoweredProblem`` -- pose rows (R | t), points,
+    observation columns (pose index, point index, (u, v, d), group), camera / stiffness / loss group tables, pose-pose edges and
+    priors -- i.e. exactly what ``Problem.solve()`` lowers its registries to (``Problem._lower()`` returns it; ``pyslam_amd.
+    synthetic`` builds it directly).  Same options, same loop (device_solve: reference pyslam/problem.py:130-178), same cost
+    history bit for bit; what is skipped is the walk over 500 000 block objects (58 of the 68 ms of a C3 solve through the
+    object API).  -> (cost history, poses (P, 12 | 6), points (L, 3), [(pcg iterations, relative residual)]).
+    ``device``: a DeviceProblem of the same tables kept from an earlier call (its parameters are reset to ``lp``'s)."""
+    from pyslam_amd.device import DeviceProblem
+    options = options if options is not None else Options()
+    dev = device
+    if dev is None:
+        dev = DeviceProblem(lp, stream=stream)
+    else:
+        dev.set_params(lp.poses, lp.points)
+    try:
+        history, stats = device_solve(dev, options)
+        poses, points = dev.get_params()
+    finally:
+        if device is None:
+            dev.close()
+    return history, poses, points, stats
+
+
 class Problem:
     def __init__(self, options=Options()):
         self.options = options

@@ -37,10 +37,12 @@ for order in ('first_pose', 'index'):
             dev.linearize(0.0)
         torch.cuda.synchronize()
         st = dev.stage_times(reset=True); dev.set_profiling(0)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dev.shard_pack(); torch.cuda.synchronize()
+        e0.record()
         for _ in range(20):
             dev.shard_pack()
-        torch.cuda.synchronize(); pack_ms = (time.perf_counter() - t0) * 1e3 / 20
+        e1.record(); torch.cuda.synchronize(); pack_ms = e0.elapsed_time(e1) / 20
         print('N %d rank %d order %-10s: obs %7d, blocks touched %6d of %6d, ' % (N, r, order, lp.num_obs, blocks.size, union.size + lp_full.num_reduced) +
               ' '.join('%s %.4f' % (k, v[0] / max(v[1], 1)) for k, v in st.items() if v[1] and k in ('landmark_pass', 'pose_pass', 'schur_pairs')) +
               ' pack %.4f ms | exchange: all-reduce buffer %.2f MB, this rank\'s segment %.2f MB' % (pack_ms, full_bytes / 1e6, seg_bytes / 1e6))
