@@ -355,6 +355,14 @@ int ps_sparse_normal_solve(int32_t m, int32_t n, const int32_t* j_row_ptr, const
                            const double* r, const double* rhs, double tol, int32_t max_iters,
                            double* dx, int32_t* iters_out, double* relres_out);
 
+/* The same system solved DIRECTLY (round 5): J^T J formed dense on the device, blocked multi-workgroup Cholesky, block
+ * substitutions, `refine_steps` refinement steps on the residual of the original system.  n <= 8192.  What the host-evaluated path
+ * uses between the single-workgroup dense solve (n <= 2048) and the CG above; stands in for scipy.sparse.linalg.spsolve
+ * (reference pyslam/problem.py:186).  relres_out: ||rhs - J^T J dx|| / ||rhs||. */
+int ps_sparse_normal_direct(int32_t m, int32_t n, const int32_t* j_row_ptr, const int32_t* j_col, const double* j_val,
+                            const int32_t* jt_row_ptr, const int32_t* jt_col, const double* jt_val,
+                            const double* r, const double* rhs, int32_t refine_steps, double* dx, double* relres_out);
+
 /* The banded factorisation kernels of the explicit two-level PCG's coarse level on their own (csrc/ps_k_band.h: one workgroup
  * walking the block columns; csrc/ps_k_bandpart.h: the partitioned, parallel form): inverse of a symmetric positive definite
  * matrix with `bw` (1..7) block off-diagonals of dof x dof blocks.  `a`: dense, row-major, (ncb dof)^2 doubles on the host, lower

@@ -129,6 +129,8 @@ SIGNATURES = {
     'ps_dense_normal_solve': (C.c_int, [c_f64p, c_f64p, C.c_int32, C.c_int32, c_f64p, c_f64p]),
     'ps_sparse_normal_solve': (C.c_int, [C.c_int32, C.c_int32, c_i32p, c_i32p, c_f64p, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p,
                                          C.c_double, C.c_int32, c_f64p, c_i32p, c_f64p]),
+    'ps_sparse_normal_direct': (C.c_int, [C.c_int32, C.c_int32, c_i32p, c_i32p, c_f64p, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p,
+                                          C.c_int32, c_f64p, c_f64p]),
     'ps_debug_band_inverse': (C.c_int, [c_f64p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), c_f64p]),
 }
 

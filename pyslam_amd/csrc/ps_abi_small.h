@@ -259,6 +259,78 @@ int ps_sparse_normal_solve(int32_t m, int32_t n, const int32_t* j_row_ptr, const
     return 0;
 }
 
+// ---- host-evaluated generic path, DIRECT: (J^T J) dx = -J^T r (or = rhs) by a dense blocked Cholesky on the device, n <= 8 192
+// (csrc/ps_sparse.h "Round 5").  relres_out: ||rhs - J^T J dx|| / ||rhs|| of the ORIGINAL system after the refinement steps.
+int ps_sparse_normal_direct(int32_t m, int32_t n, const int32_t* j_row_ptr, const int32_t* j_col, const double* j_val,
+                            const int32_t* jt_row_ptr, const int32_t* jt_col, const double* jt_val,
+                            const double* r, const double* rhs, int32_t refine_steps, double* dx, double* relres_out) {
+    if (!j_row_ptr || !j_col || !j_val || !jt_row_ptr || !jt_col || !jt_val || !dx || m <= 0 || n <= 0 || (!r && !rhs))
+        return fail("bad argument");
+    if (n > PS_SPD_MAXN) return fail("ps_sparse_normal_direct: more unknowns than the dense direct solve takes (8192)");
+    if (need_device()) return -1;
+    const size_t nnz = (size_t)j_row_ptr[m];
+    if ((size_t)jt_row_ptr[n] != nnz) return fail("J and its transpose have different numbers of non-zeros");
+    const int nsteps = cdiv(n, PS_BC_W), nb = cdiv(n, 4);
+    DevBuf bJr, bJc, bJv, bTr, bTc, bTv, be, bb, bH, bA, bTi, bx, bd, bres, bpart, bst;
+    if (bJr.get((size_t)(m + 1) * 4) || bJc.get(nnz * 4) || bJv.get(nnz * 8) || bTr.get((size_t)(n + 1) * 4) || bTc.get(nnz * 4) ||
+        bTv.get(nnz * 8) || be.get((size_t)m * 8) || bb.get((size_t)n * 8) || bH.get((size_t)n * n * 8) || bA.get((size_t)n * n * 8) ||
+        bTi.get((size_t)nsteps * PS_BC_W * PS_BC_W * 8) || bx.get((size_t)n * 8) || bd.get((size_t)n * 8) || bres.get((size_t)n * 8) ||
+        bpart.get((size_t)2 * nb * 8) || bst.get(ST_NWORDS * 4)) return -1;
+    HIP_OK(hipMemcpy(bJr.p, j_row_ptr, (size_t)(m + 1) * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bJc.p, j_col, nnz * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bJv.p, j_val, nnz * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bTr.p, jt_row_ptr, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bTc.p, jt_col, nnz * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(bTv.p, jt_val, nnz * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(bst.p, 0, ST_NWORDS * 4));
+    hipStream_t st = 0;
+    if (rhs) HIP_OK(hipMemcpy(bb.p, rhs, (size_t)n * 8, hipMemcpyHostToDevice));
+    else {
+        HIP_OK(hipMemcpy(be.p, r, (size_t)m * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_sp_spmv, dim3(cdiv(n, 256)), dim3(256), 0, st, n, bTr.as<int32_t>(), bTc.as<int32_t>(), bTv.as<double>(),
+                           be.as<double>(), bb.as<double>(), -1.0);
+    }
+    double* H = bH.as<double>();
+    double* A = bA.as<double>();
+    hipLaunchKernelGGL(k_spd_normal, dim3(cdiv((long)n * n, 256)), dim3(256), 0, st, n, bJr.as<int32_t>(), bJc.as<int32_t>(), bJv.as<double>(),
+                       bTr.as<int32_t>(), bTc.as<int32_t>(), bTv.as<double>(), H);
+    HIP_OK(hipMemcpyAsync(A, H, (size_t)n * n * 8, hipMemcpyDeviceToDevice, st));
+    for (int s2 = 0; s2 < nsteps; ++s2) {                      // blocked right-looking Cholesky over the whole chip
+        const int j0 = s2 * PS_BC_W, w = std::min(PS_BC_W, n - j0), mrem = n - j0 - w;
+        hipLaunchKernelGGL(k_bchol_panel, dim3(std::max(1, cdiv((long)mrem * w, 1024))), dim3(256), 0, st, n, j0, A,
+                           bTi.as<double>() + (size_t)s2 * PS_BC_W * PS_BC_W, bst.as<int32_t>());
+        if (mrem > 0) {
+            const int nt = cdiv(mrem, 32);
+            hipLaunchKernelGGL(k_bchol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, n, j0, w, A);
+        }
+    }
+    auto solve_into = [&](double* v) {                         // v <- (L L^T)^-1 v
+        hipLaunchKernelGGL(k_spd_subst, dim3(1), dim3(512), 0, st, n, (const double*)A, (const double*)bTi.as<double>(), v, 0);
+        hipLaunchKernelGGL(k_spd_subst, dim3(1), dim3(512), 0, st, n, (const double*)A, (const double*)bTi.as<double>(), v, 1);
+    };
+    HIP_OK(hipMemcpyAsync(bx.p, bb.p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    solve_into(bx.as<double>());
+    std::vector<double> part((size_t)2 * nb);
+    double rel = 0.0;
+    for (int it = 0;; ++it) {                                  // residual of the original system; refine through the factor
+        hipLaunchKernelGGL(k_spd_residual, dim3(nb), dim3(256), 0, st, n, (const double*)H, (const double*)bb.as<double>(),
+                           (const double*)bx.as<double>(), bres.as<double>(), bpart.as<double>());
+        HIP_OK(hipMemcpy(part.data(), bpart.p, part.size() * 8, hipMemcpyDeviceToHost));
+        double rr = 0.0, bbn = 0.0;
+        for (int k = 0; k < nb; ++k) { rr += part[2 * k]; bbn += part[2 * k + 1]; }
+        rel = bbn > 0.0 ? std::sqrt(rr / bbn) : 0.0;
+        if (it >= refine_steps || !(rel > 1e-15)) break;
+        solve_into(bres.as<double>());
+        hipLaunchKernelGGL(k_spd_axpy, dim3(cdiv(n, 256)), dim3(256), 0, st, n, (const double*)bres.as<double>(), bx.as<double>());
+    }
+    int32_t stw[ST_NWORDS];
+    HIP_OK(hipMemcpy(stw, bst.p, sizeof(stw), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(dx, bx.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (relres_out) *relres_out = rel;
+    if (stw[ST_DIAG_FAIL]) return fail("normal matrix is not positive definite to rounding (dense direct solve)");
+    return 0;
+}
+
 // ---- the band factorisation kernels on their own (csrc/ps_k_band.h, ps_k_bandpart.h): inverse of a symmetric positive definite
 // matrix with `bw` block off-diagonals of D x D blocks, A given dense on the host (row-major, nc = ncb D; the lower triangle is
 // read).  chunk_nodes < 0: the one-workgroup column walk (k_band_chol + k_band_inverse_rl); 0: the partitioned form with its

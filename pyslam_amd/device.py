@@ -393,6 +393,37 @@ def sparse_normal_solve(J, r=None, rhs=None, tol=1e-12, max_iters=10000, accept=
     return dx, int(its.value), relres
 
 
+DIRECT_GENERIC_LIMIT = 8192       # csrc/ps_sparse.h: PS_SPD_MAXN
+
+
+def sparse_normal_direct(J, r=None, rhs=None, refine_steps=3, accept=1e-8):
+    """Host-evaluated generic path, 2 049 .. 8 192 unknowns (round 5): (J^T J) dx = -J^T r (or = rhs) by a dense blocked
+    Cholesky on the device + refinement on the residual of the original system (include/pyslam_hip.h:
+    ps_sparse_normal_direct) -- what the reference's sparse LU (pyslam/problem.py:186) is replaced by where the CG of
+    sparse_normal_solve would not converge.  -> (dx, refinement steps allowed, ||rhs - J^T J dx|| / ||rhs||).
+    Raises NotConverged if the residual stays above `accept` (a normal matrix singular to rounding)."""
+    lib = nat.require_gpu()
+    J = J.tocsr()
+    J.sort_indices()
+    Jt = J.T.tocsr()
+    Jt.sort_indices()
+    m, n = J.shape
+    a = [np.ascontiguousarray(x, dtype=t) for x, t in ((J.indptr, np.int32), (J.indices, np.int32), (J.data, np.float64),
+                                                        (Jt.indptr, np.int32), (Jt.indices, np.int32), (Jt.data, np.float64))]
+    rr = None if r is None else np.ascontiguousarray(r, dtype=np.float64).reshape(-1)
+    bb = None if rhs is None else np.ascontiguousarray(rhs, dtype=np.float64).reshape(-1)
+    dx = np.zeros(n)
+    rel = C.c_double()
+    nat.check(lib.ps_sparse_normal_direct(m, n, nat.i32p(a[0]), nat.i32p(a[1]), nat.f64p(a[2]), nat.i32p(a[3]), nat.i32p(a[4]),
+                                          nat.f64p(a[5]), nat.f64p(rr), nat.f64p(bb), int(refine_steps), nat.f64p(dx),
+                                          C.cast(C.byref(rel), nat.c_f64p)))
+    relres = float(rel.value)
+    if not (relres <= accept):
+        raise NotConverged('dense direct solve of the normal equations ({} unknowns): relative residual {:.2e} after {} refinement '
+                           'steps -- J^T J is singular to rounding'.format(n, relres, refine_steps))
+    return dx, int(refine_steps), relres
+
+
 class PhotometricDevice:
     """Device side of a Problem whose only block is a PhotometricResidualSE3 (include/pyslam_hip.h:
     ps_photometric_*): the pixel tables live in HBM, one call runs a whole Gauss-Newton iteration.

@@ -494,8 +494,9 @@ class Problem:
 
     # ---- generic (host-evaluated) path ---------------------------------
     # Unknowns up to which the host-evaluated path forms J dense and solves by Cholesky on the device
-    # (ps_dense_normal_solve); beyond it J travels as CSR and the device runs CG on the normal equations
-    # (ps_sparse_normal_solve) -- the reference's sparse LU has no such limit (pyslam/problem.py:186).
+    # (ps_dense_normal_solve); up to 8 192 J travels as CSR and the device forms J^T J dense and factors it with the blocked
+    # multi-workgroup Cholesky (ps_sparse_normal_direct, round 5); beyond that it runs CG on the normal equations
+    # (ps_sparse_normal_solve) -- the reference's sparse LU has no such limits (pyslam/problem.py:186).
     DENSE_GENERIC_LIMIT = 2048
 
     def _host_jacobian(self):
@@ -530,9 +531,14 @@ class Problem:
         return J, np.concatenate(es), cost
 
     def _generic_step(self, J, e):
-        from pyslam_amd.device import dense_normal_solve, sparse_normal_solve
+        from pyslam_amd.device import dense_normal_solve, sparse_normal_solve, sparse_normal_direct, DIRECT_GENERIC_LIMIT
         if J.shape[1] <= self.DENSE_GENERIC_LIMIT:
             return dense_normal_solve(J.toarray(), e)
+        if J.shape[1] <= DIRECT_GENERIC_LIMIT:
+            # a direct solve, as the reference's (pyslam/problem.py:186): dense blocked Cholesky on the device + refinement
+            dx, its, rel = sparse_normal_direct(J, r=e)
+            self.solver_stats.append((its, rel))
+            return dx
         dx, its, rel = sparse_normal_solve(J, r=e, tol=self.options.pcg_tol, max_iters=max(self.options.pcg_max_iters, 10 * J.shape[1]))
         self.solver_stats.append((its, rel))
         return dx

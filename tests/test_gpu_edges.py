@@ -394,6 +394,69 @@ def test_generic_sparse_path_reports_a_solve_that_did_not_converge():
     assert rel <= 1e-12 and its > 0
 
 
+def test_generic_path_solves_the_stiff_chain_directly():
+    """Round 5: between 2 049 and 8 192 unknowns the host-evaluated path solves the normal equations DIRECTLY on the device (J^T J
+    dense, blocked multi-workgroup Cholesky, refinement: ps_sparse_normal_direct) as the reference's sparse LU does
+    (pyslam/problem.py:186).  The chain the CG of the test above gives up on (condition number ~1e15) solves: the residual of the
+    normal equations at rounding level, the step equal to the one an accurate solve of the least-squares problem gives."""
+    from pyslam_amd.device import sparse_normal_direct
+    import scipy.sparse as sp
+    n = 2500
+    rows = np.arange(n - 1)
+    J = sp.vstack([sp.csr_matrix((np.concatenate([1e4 * np.ones(n - 1), -1e4 * np.ones(n - 1)]),
+                                  (np.concatenate([rows, rows]), np.concatenate([rows, rows + 1]))), shape=(n - 1, n)),
+                   sp.csr_matrix(([1.], ([0], [0])), shape=(1, n))]).tocsr()
+    r = np.ones(n)
+    dx, _, rel = sparse_normal_direct(J, r=r)
+    assert rel <= 1e-10
+    # the least-squares solution of J dx = -r, by a method that does not square the condition number
+    ref = np.linalg.lstsq(J.toarray(), -r, rcond=None)[0]     # (SVD: cond(J) ~ 3e7, not its square)
+    assert np.linalg.norm(dx - ref) <= 1e-6 * np.linalg.norm(ref)
+    # a well-conditioned system of 6 000 unknowns: against numpy, 1e-12
+    rng = np.random.default_rng(3)
+    n2 = 6000
+    Jw = (sp.random(n2 + 500, n2, density=3.0 / n2, random_state=5, format='csr') + sp.vstack([sp.identity(n2), sp.csr_matrix((500, n2))])).tocsr()
+    e2 = rng.standard_normal(n2 + 500)
+    dx2, _, rel2 = sparse_normal_direct(Jw, r=e2)
+    H = (Jw.T @ Jw).toarray()
+    want = np.linalg.solve(H, -(Jw.T @ e2))
+    assert rel2 <= 1e-13 and np.linalg.norm(dx2 - want) <= 1e-11 * np.linalg.norm(want)
+
+
+def test_generic_problem_of_3000_unknowns_through_the_public_api():
+    """User-defined blocks (host-evaluated) with more unknowns than the single-workgroup dense solve takes: Problem.solve() goes
+    through the direct device solve and reaches the minimum the reference's sparse LU reaches (a linear problem: one step)."""
+    from pyslam.problem import Options, Problem
+    from pyslam.residuals import QuadraticResidual  # noqa: F401  (the package's user-block protocol is the reference's)
+
+    class Diff:                                               # r = s (a - b): a user block the typed kernels do not know
+        def __init__(self, s): self.s = s
+        def evaluate(self, params, compute_jacobians=None):
+            r = np.array([self.s * (params[0] - params[1])])
+            if compute_jacobians:
+                return r, [np.array([[self.s]]) if compute_jacobians[0] else None, np.array([[-self.s]]) if compute_jacobians[1] else None]
+            return r
+
+    class Anchor:
+        def __init__(self, v): self.v = v
+        def evaluate(self, params, compute_jacobians=None):
+            r = np.array([params[0] - self.v])
+            return (r, [np.array([[1.0]])]) if compute_jacobians else r
+
+    n = 3000
+    rng = np.random.default_rng(11)
+    problem = Problem(Options())
+    init = {'x%d' % i: float(rng.standard_normal()) for i in range(n)}
+    for i in range(n - 1):
+        problem.add_residual_block(Diff(30.0), ['x%d' % i, 'x%d' % (i + 1)])
+    problem.add_residual_block(Anchor(2.5), ['x0'])
+    problem.initialize_params(init)
+    out = problem.solve()
+    got = np.array([out['x%d' % i] for i in range(n)])
+    assert np.abs(got - 2.5).max() <= 1e-8                    # every difference zero, the anchor met
+    assert problem._cost_history[-1] <= 1e-16 * max(problem._cost_history[0], 1.0)
+
+
 def test_per_observation_stiffness_runs_the_typed_device_path():
     """One stiffness per observation (the reference takes any: reprojection_residual.py:8-11) = more (camera, stiffness,
     loss) rows than the observation record's 8-bit group field.  Round 2 sent such problems to the host-evaluated path;
