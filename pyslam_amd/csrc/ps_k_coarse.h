@@ -153,125 +153,149 @@ __global__ __launch_bounds__(1024) void k_coarse_chol(int ncb, const double* __r
     // addressing for every access and the LDS path loses ~40 %)
     double* sL = IN_LDS ? sm : gscratch;                    // nc x nc: A, overwritten by L (lower)
     double* sX = sL + nc * nc;                              // nc x nc: L^-1
-    __shared__ double sDi[64 * 36];     // inverse of every diagonal block of L
+    __shared__ double sRl[64 * 6];      // reciprocal diagonal of L
     const int t = threadIdx.x, nt = blockDim.x;
     for (int k = t; k < nc * nc; k += nt) { sL[k] = A[k]; sX[k] = 0.0; }
+    // Round 5: the serial part of a block step is the D x D Cholesky ALONE (reciprocal square roots, no division, ~150
+    // instructions of one thread); the panel below it is solved row by row against L_JJ^T (one thread per row, in place: no
+    // staging pass), and the inverses of the diagonal blocks -- which rounds 1-4 formed inside the serial part, 126 more
+    // dependent multiply-adds per step -- are formed for all blocks at once after the loop.  Three barriers per step, were four.
+    // ... and it runs AHEAD: wave 0 updates and factors the next diagonal block while the other waves do the rest of the trailing
+    // update (as k_band_chol does), so a step is two barriers: panel | trailing update + next diagonal factor.
+    auto factor_diag = [&](int J) {                         // one thread: L_JJ in place (upper part zeroed), 1 / diag into sRl
+        double a[D][D], rl[D];
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < D; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) a[r][c] = sL[(J * D + r) * nc + J * D + c];
+#pragma unroll
+        for (int jj = 0; jj < D; ++jj) {
+            double d = a[jj][jj];
+#pragma unroll
+            for (int k = 0; k < jj; ++k) d -= a[jj][k] * a[jj][k];
+            if (!(d > 0.0)) { ok = false; d = 1.0; }
+            rl[jj] = ps_rsqrt(d);
+            a[jj][jj] = d * rl[jj];
+#pragma unroll
+            for (int r = jj + 1; r < D; ++r) {
+                double v = a[r][jj];
+#pragma unroll
+                for (int k = 0; k < jj; ++k) v -= a[r][k] * a[jj][k];
+                a[r][jj] = v * rl[jj];
+            }
+        }
+        if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            sRl[J * D + r] = rl[r];
+#pragma unroll
+            for (int c = 0; c < D; ++c) sL[(J * D + r) * nc + J * D + c] = c <= r ? a[r][c] : 0.0;
+        }
+    };
+    __syncthreads();
+    if (t == 0) factor_diag(0);
     for (int J = 0; J < ncb; ++J) {
         __syncthreads();
-        if (t == 0) {                   // D x D Cholesky of the diagonal block + its inverse
-            double L[D][D], Mi[D][D];
-            bool ok = true;
-#pragma unroll
-            for (int a = 0; a < D; ++a)
-#pragma unroll
-                for (int b2 = 0; b2 < D; ++b2) { L[a][b2] = 0.0; Mi[a][b2] = 0.0; }
-            double il[D];                       // 1 / L[j][j]: one division per pivot, the rest are multiplies
-            // (the block comes into registers in ONE round of independent reads: read where it is used, every element waited out
-            //  its own LDS -- or, for big coarse levels, L2 -- latency inside the serial factorisation: ~1.5 us per block step)
-            double Ab[D][D];
-#pragma unroll
-            for (int a = 0; a < D; ++a)
-#pragma unroll
-                for (int b2 = 0; b2 <= a; ++b2) Ab[a][b2] = sL[(J * D + a) * nc + J * D + b2];
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                double d = Ab[j][j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-                ok = ok && (d > 0.0);
-                const double l = sqrt(d);
-                L[j][j] = l;
-                il[j] = 1.0 / l;
-#pragma unroll
-                for (int i = j + 1; i < D; ++i) {
-                    double v = Ab[i][j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
-                    L[i][j] = v * il[j];
-                }
-            }
+        // panel: row x of L_IJ solves x L_JJ^T = (row of A_IJ) -- forward substitution, one thread per row, in place
+        const int m = ncb - J - 1;
+        for (int row = t; row < m * D; row += nt) {
+            double* ar = sL + ((J + 1) * D + row) * nc + J * D;
+            double x[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) {
-                Mi[c][c] = il[c];
+                double v = ar[c];
 #pragma unroll
-                for (int r = c + 1; r < D; ++r) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int k = c; k < r; ++k) v -= L[r][k] * Mi[k][c];
-                    Mi[r][c] = v * il[r];
-                }
+                for (int k = 0; k < c; ++k) v -= x[k] * sL[(J * D + c) * nc + J * D + k];
+                x[c] = v * sRl[J * D + c];
             }
-            if (!ok) atomicAdd(&status[ST_DIAG_FAIL], 1);
 #pragma unroll
-            for (int a = 0; a < D; ++a)
-#pragma unroll
-                for (int b2 = 0; b2 < D; ++b2) {
-                    sL[(J * D + a) * nc + J * D + b2] = L[a][b2];
-                    sDi[J * DD + a * D + b2] = Mi[a][b2];
-                }
+            for (int c = 0; c < D; ++c) ar[c] = x[c];
         }
         __syncthreads();
-        // panel: L_IJ = A_IJ L_JJ^-T   (entry (a,b) = sum_{k<=b} A_IJ[a][k] Mi[b][k])
-        const int m = ncb - J - 1;
-        double pv[4];                         // <= 15*36 (D=6) or 31*9 (D=3) entries over 256 threads
-        int np = 0;
-        for (int idx = t; idx < m * DD; idx += nt, ++np) {
-            const int I = J + 1 + idx / DD, e = idx % DD, a = e / D, b2 = e % D;
-            double v = 0.0;
-            for (int k = 0; k <= b2; ++k) v += sL[(I * D + a) * nc + J * D + k] * sDi[J * DD + b2 * D + k];
-            pv[np] = v;
-        }
-        __syncthreads();
-        np = 0;
-        for (int idx = t; idx < m * DD; idx += nt, ++np) {
-            const int I = J + 1 + idx / DD, e = idx % DD;
-            sL[(I * D + e / D) * nc + J * D + e % D] = pv[np];
-        }
-        __syncthreads();
-        // trailing update A_IK -= L_IJ L_KJ^T for J < K <= I
-        for (int idx = t; idx < m * m * DD; idx += nt) {
-            const int blk = idx / DD, e = idx % DD, a = e / D, b2 = e % D;
-            const int I = J + 1 + blk / m, K = J + 1 + blk % m;
-            if (K > I) continue;
-            double v = 0.0;
+        if (m == 0) break;
+        if (t < 64) {                                       // wave 0: the next diagonal block, updated and factored
+            if (t < DD) {
+                const int a = t / D, b2 = t % D;
+                double v = 0.0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) v += sL[(I * D + a) * nc + J * D + k] * sL[(K * D + b2) * nc + J * D + k];
-            sL[(I * D + a) * nc + K * D + b2] -= v;
+                for (int k = 0; k < D; ++k) v += sL[((J + 1) * D + a) * nc + J * D + k] * sL[((J + 1) * D + b2) * nc + J * D + k];
+                sL[((J + 1) * D + a) * nc + (J + 1) * D + b2] -= v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (t == 0) factor_diag(J + 1);
+        } else {
+            // trailing update A_IK -= L_IJ L_KJ^T for J < K <= I, without the block wave 0 has taken
+            for (int idx = t - 64; idx < m * m * DD; idx += nt - 64) {
+                const int blk = idx / DD, e = idx % DD, a = e / D, b2 = e % D;
+                const int I = J + 1 + blk / m, K = J + 1 + blk % m;
+                if (K > I || (I == J + 1 && K == J + 1)) continue;
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v += sL[(I * D + a) * nc + J * D + k] * sL[(K * D + b2) * nc + J * D + k];
+                sL[(I * D + a) * nc + K * D + b2] -= v;
+            }
         }
     }
-    // X = L^-1 by block rows: X_RC = Mi_R (delta_RC I - sum_{K=C}^{R-1} L_RK X_KC), all C <= R in parallel
-    for (int R = 0; R < ncb; ++R) {
-        __syncthreads();
-        double tv[4];                         // <= 16*36 entries over 256 threads
-        int np = 0;
-        for (int idx = t; idx < (R + 1) * DD; idx += nt, ++np) {
-            const int C = idx / DD, e = idx % DD, a = e / D, b2 = e % D;
-            double v = (C == R && a == b2) ? 1.0 : 0.0;
-            for (int K = C; K < R; ++K)
+    // X = L^-1 by RECURSIVE DOUBLING (round 5).  The diagonal blocks first -- column c of L_RR^-1 by forward substitution, one
+    // thread per (block, column), all blocks at once --, then groups of s = 1, 2, 4, ... block rows are merged pairwise,
+    // [[X11, 0], [X21, X22]] with X21 = -X22 (L21 X11): two small matrix products per level, every entry of every pair at once,
+    // two barriers per level -- 8 barriers for 13 block rows.  (Rounds 1-4 went block row by block row, four barriers each.)  The
+    // intermediate T = L21 X11 of a pair is kept TRANSPOSED in that pair's (still unused) upper-right block of sX; the upper
+    // triangle is dropped on the way out.
+    __syncthreads();
+    for (int k = t; k < ncb * D; k += nt) {
+        const int R = k / D, c = k % D;
+        double col[D];
 #pragma unroll
-                for (int k = 0; k < D; ++k) v -= sL[(R * D + a) * nc + K * D + k] * sX[(K * D + k) * nc + C * D + b2];
-            tv[np] = v;
+        for (int r = 0; r < D; ++r) {
+            double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < r; ++q) v -= (q >= c) ? sL[(R * D + r) * nc + R * D + q] * col[q] : 0.0;
+            col[r] = (r >= c) ? v * sRl[R * D + r] : 0.0;
+            sX[(R * D + r) * nc + R * D + c] = col[r];
         }
+    }
+    // (a thread's entries of the nc x nc array are the same on every level: in the LDS variant -- nc <= 96, at most nine entries
+    //  per thread -- their row / column indices are worked out once (divisions by the run-time nc) and kept in registers; a level
+    //  only tests bits of the block indices, sg being a power of two.  The out-of-L2 variant for bigger matrices recomputes them.)
+    constexpr int NEX = IN_LDS ? 9 : 1;                     // ceil(96^2 / 1024)
+    short ei[NEX], ej[NEX];
+    if (IN_LDS) {
+#pragma unroll
+        for (int u = 0; u < NEX; ++u) {
+            const int idx = t + u * nt;
+            ei[u] = idx < nc * nc ? (short)(idx / nc) : (short)-1;
+            ej[u] = idx < nc * nc ? (short)(idx % nc) : (short)0;
+        }
+    }
+    auto t_entry = [&](int i, int jj, int sg, int lg) {      // T[i][j] = sum_{k >= j, k in group 1} L[i][k] X11[k][j], kept transposed
+        const int bi = i / D, bj = jj / D;
+        if (((bi ^ bj) >> lg) != 0 || !(bi & sg) || (bj & sg)) return;
+        const int k1 = (((bj >> lg) << lg) + sg) * D;        // end of group 1 (scalar)
+        double v = 0.0;
+        for (int k = jj; k < k1; ++k) v += sL[i * nc + k] * sX[k * nc + jj];
+        sX[jj * nc + i] = v;
+    };
+    auto x_entry = [&](int i, int jj, int sg, int lg) {      // X21[i][j] = -sum_{k <= i, k in group 2} X22[i][k] T[k][j]
+        const int bi = i / D, bj = jj / D;
+        if (((bi ^ bj) >> lg) != 0 || !(bi & sg) || (bj & sg)) return;
+        const int k0 = (((bj >> lg) << lg) + sg) * D;        // start of group 2
+        double v = 0.0;
+        for (int k = k0; k <= i; ++k) v -= sX[i * nc + k] * sX[jj * nc + k];
+        sX[i * nc + jj] = v;
+    };
+    for (int sg = 1, lg = 1; sg < ncb; sg *= 2, ++lg) {    // lg = log2(2 sg)
         __syncthreads();
-        np = 0;
-        for (int idx = t; idx < (R + 1) * DD; idx += nt, ++np) {          // stage T in the X_RC slots
-            const int C = idx / DD, e = idx % DD;
-            sX[(R * D + e / D) * nc + C * D + e % D] = tv[np];
-        }
+        if (IN_LDS) {
+#pragma unroll
+            for (int u = 0; u < NEX; ++u) if (ei[u] >= 0) t_entry(ei[u], ej[u], sg, lg);
+        } else for (int idx = t; idx < nc * nc; idx += nt) t_entry(idx / nc, idx % nc, sg, lg);
         __syncthreads();
-        np = 0;
-        for (int idx = t; idx < (R + 1) * DD; idx += nt, ++np) {
-            const int C = idx / DD, e = idx % DD, a = e / D, b2 = e % D;
-            double v = 0.0;
-            for (int k = 0; k <= a; ++k) v += sDi[R * DD + a * D + k] * sX[(R * D + k) * nc + C * D + b2];
-            tv[np] = v;
-        }
-        __syncthreads();
-        np = 0;
-        for (int idx = t; idx < (R + 1) * DD; idx += nt, ++np) {
-            const int C = idx / DD, e = idx % DD;
-            sX[(R * D + e / D) * nc + C * D + e % D] = tv[np];
-        }
+        if (IN_LDS) {
+#pragma unroll
+            for (int u = 0; u < NEX; ++u) if (ei[u] >= 0) x_entry(ei[u], ej[u], sg, lg);
+        } else for (int idx = t; idx < nc * nc; idx += nt) x_entry(idx / nc, idx % nc, sg, lg);
     }
     __syncthreads();
     for (int k = t; k < nc * nc; k += nt) {
