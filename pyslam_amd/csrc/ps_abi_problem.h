@@ -35,7 +35,7 @@ int ps_warm_up(void) {
         // when it loads).  Asking for the attributes of the kernels of the whole-iteration paths resolves them here.
         hipFuncAttributes a;
 #define PS_TOUCH(...) (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&__VA_ARGS__))
-        PS_TOUCH(k_landmark_pass<false>); PS_TOUCH(k_pose_pass<false>); PS_TOUCH(k_pose_finalize); PS_TOUCH(k_schur_pairs_db<0>);
+        PS_TOUCH(k_landmark_pass<false>); PS_TOUCH(k_landmark_pass_packed<false>); PS_TOUCH(k_backsub_packed); PS_TOUCH(k_pose_pass<false>); PS_TOUCH(k_pose_finalize); PS_TOUCH(k_schur_pairs_db<0>);
         PS_TOUCH(k_schur_combine); PS_TOUCH(k_backsub); PS_TOUCH(k_cost_reproj<false>); PS_TOUCH(k_reduce3); PS_TOUCH(k_reduce_partials);
         PS_TOUCH(k_copy2); PS_TOUCH(k_zero4); PS_TOUCH(k_lag_status_check);
         PS_TOUCH(k_block_jacobi_factor<6>); PS_TOUCH(k_scale_blocks<6>); PS_TOUCH(k_scale_blocks_p<6>); PS_TOUCH(k_rows_setup<6>);
@@ -1129,7 +1129,36 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     if (h->alloc(&h->cost_partials, (size_t)std::max(h->ncost_obs + h->ncost_fac, 512) + 8) ||
         h->alloc(&h->scalars, SC_NWORDS)) return -1;
     if (h->zero(h->scalars, SC_NWORDS * sizeof(double)) || h->zero(h->status, ST_NWORDS * sizeof(int32_t))) return -1;
-    h->nsq_l = nv > 0 ? cdiv(nv, 256 / PS_LM_GROUP) : 0;
+    h->nsq_l = h->nsq_l16 = nv > 0 ? cdiv(nv, 256 / PS_LM_GROUP) : 0;
+    // ---- runs of landmarks per wave for the packed landmark pass / back-substitution (ps_k_packed.h)
+    h->lmw_nwaves = 0;
+    if (nv > 0 && Nl > 0 && D == 6) {
+        int mx = 0, mn = INT_MAX;
+        if (!dev_build) {
+            for (int v = 0; v < nv; ++v) { const int n = lm_ptr[v + 1] - lm_ptr[v]; mx = std::max(mx, n); mn = std::min(mn, n); }
+        } else {
+            int32_t init[2] = {0, INT_MAX}, *d_mm = nullptr;
+            if (h->alloc(&d_mm, 2, true)) return -1;
+            HIP_OK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_lmw_maxobs, dim3(cdiv(nv, 256)), dim3(256), 0, h->stream, nv, h->lm_ptr, d_mm);
+            HIP_OK(hipMemcpyAsync(init, d_mm, sizeof(init), hipMemcpyDeviceToHost, h->stream));
+            HIP_OK(hipStreamSynchronize(h->stream));
+            mx = init[0]; mn = init[1];
+        }
+        if (mx <= PS_LMW_MAXOBS && mn >= 1) {
+            const int W = 64 - (mx - 1), nw = cdiv(Nl, W);
+            if (!dev_build) {
+                std::vector<int32_t> first((size_t)nw + 1, nv);
+                for (int w = 0, v = 0; w < nw; ++w) { while (v < nv && lm_ptr[v] < W * w) ++v; first[w] = v; }
+                if (h->upload(&h->lmw_first, first)) return -1;
+            } else {
+                if (h->alloc(&h->lmw_first, (size_t)nw + 1, true)) return -1;
+                hipLaunchKernelGGL(k_lmw_items, dim3(cdiv(nw + 1, 256)), dim3(256), 0, h->stream, nv, nw, W, h->lm_ptr, h->lmw_first);
+            }
+            h->lmw_nwaves = nw;
+            h->nsq_l = std::max(h->nsq_l, cdiv(nw, 4));
+        }
+    }
     h->nsq_p = nr > 0 ? cdiv(P, 256) : 0;
     if (h->alloc(&h->sq_part_l, (size_t)h->nsq_l) || h->alloc(&h->sq_part_p, (size_t)h->nsq_p) ||
         h->alloc(&h->shard_buf, 2)) return -1;

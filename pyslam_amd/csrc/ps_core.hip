@@ -348,7 +348,12 @@ struct ps_problem {
     double* shard_buf = nullptr;    // {cost, ||dx_point||^2} of this landmark shard, for the caller's all-reduce
     bool shard_out = false;         // k_reduce3 writes cost / ||dx_point||^2 there instead of into scalars
     double *sq_part_l = nullptr, *sq_part_p = nullptr;   // per-workgroup partials of ||dx_point||^2, ||dx_pose||^2
-    int nsq_l = 0, nsq_p = 0;
+    int nsq_l = 0 /* partials allocated */, nsq_l16 = 0 /* workgroups of the 16-lane back-substitution */, nsq_p = 0;
+    // landmark pass / back-substitution with the lanes packed by observation (ps_k_packed.h): the first landmark of every wave's run
+    // (lmw_nwaves + 1 entries; 0 waves: the 16-lane kernels -- a track longer than 16 observations, or an unobserved landmark)
+    int32_t* lmw_first = nullptr;
+    int lmw_nwaves = 0;
+    int lm_packed = 1;              // option "lm_packed" 
     // lagged dense inverse of the reduced system as the CG preconditioner (ps_k_ldi.h / ps_host_ldi.h)
     int ldi_enable = 1;             // option "lagged_inverse"
     int ldi_max_n = 2048;           // option "ldi_max_unknowns": reduced systems up to this many unknowns

@@ -929,7 +929,12 @@ int linearize(ps_problem* h, double lambda) {
 #define PS_LM_LAUNCH(W) hipLaunchKernelGGL(k_landmark_pass<W>, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr, \
                            h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,                       \
                            h->Cinv, h->cvec, h->status, h->lm_ablate, wl)
-        if (h->wide_obs) PS_LM_LAUNCH(true); else PS_LM_LAUNCH(false);
+#define PS_LMP_LAUNCH(W) hipLaunchKernelGGL(k_landmark_pass_packed<W>, dim3(cdiv(h->lmw_nwaves, 4)), dim3(256), 0, h->stream, h->lmw_nwaves, \
+                           h->lmw_first, h->lm_ptr, h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,      \
+                           h->Cinv, h->cvec, h->status, wl)
+        if (h->lm_packed && h->lmw_nwaves > 0 && !h->lm_ablate) { if (h->wide_obs) PS_LMP_LAUNCH(true); else PS_LMP_LAUNCH(false); }
+        else if (h->wide_obs) PS_LM_LAUNCH(true); else PS_LM_LAUNCH(false);
+#undef PS_LMP_LAUNCH
 #undef PS_LM_LAUNCH
     }
     bool fin_in_combine = false, fin_in_pairs = false;
@@ -1050,17 +1055,32 @@ int cost_pass(ps_problem* h, int include_all, int scalar_slot) {
     return 0;
 }
 
+// workgroups (= partials of ||dx_l||^2) of the back-substitution as it is launched now
+inline int nsq_l_now(const ps_problem* h) { return (h->lm_packed && h->lmw_nwaves > 0) ? cdiv(h->lmw_nwaves, 4) : h->nsq_l16; }
+
 int backsub(ps_problem* h, const int32_t* gate = nullptr, bool fuse_update = false, long long* hearly = nullptr, long long eseq = 0) {
     if (h->nv == 0) return 0;
     StageTimer t(h, PS_ST_BACKSUB);
+    if (h->lm_packed && h->lmw_nwaves > 0) {                // lanes packed by observation (ps_k_packed.h)
+        const int nbl = cdiv(h->lmw_nwaves, 4);               // (= nsq_l_now(h): the partials of ||dx_l||^2 k_reduce3 sums)
+        if (fuse_update)
+            hipLaunchKernelGGL(k_backsub_packed, dim3(nbl + h->nsq_p), dim3(256), 0, h->stream, h->lmw_nwaves, h->lmw_first, h->lm_ptr, h->Z,
+                               h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate, nbl, h->lm_point, h->points, h->P, h->pose_rid, h->poses,
+                               h->sq_part_p, hearly, eseq);
+        else
+            hipLaunchKernelGGL(k_backsub_packed, dim3(nbl), dim3(256), 0, h->stream, h->lmw_nwaves, h->lmw_first, h->lm_ptr, h->Z,
+                               h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate, nbl, (const int32_t*)nullptr, (double*)nullptr, 0,
+                               (const int32_t*)nullptr, (double*)nullptr, (double*)nullptr, hearly, eseq);
+        return 0;
+    }
     if (fuse_update)       // + full-step landmark update + SE(3) retraction of the poses in the same launch
-        hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l + h->nsq_p), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
+        hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l16 + h->nsq_p), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
                            h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate,
-                           h->nsq_l, h->lm_point, h->points, h->P, h->poses, h->sq_part_p, hearly, eseq);
+                           h->nsq_l16, h->lm_point, h->points, h->P, h->poses, h->sq_part_p, hearly, eseq);
     else
-        hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
+        hipLaunchKernelGGL(k_backsub, dim3(h->nsq_l16), dim3(256), 0, h->stream, h->nv, h->lm_ptr, h->lobs,
                            h->pose_rid, h->Z, h->Cinv, h->cvec, h->x, h->dxl, h->sq_part_l, gate,
-                           h->nsq_l, (const int32_t*)nullptr, (double*)nullptr, 0, (double*)nullptr, (double*)nullptr, hearly, eseq);
+                           h->nsq_l16, (const int32_t*)nullptr, (double*)nullptr, 0, (double*)nullptr, (double*)nullptr, hearly, eseq);
     return 0;
 }
 
@@ -1122,7 +1142,7 @@ int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = f
     hipLaunchKernelGGL(k_reduce3, dim3(3), dim3(256), 0, h->stream,
                        ncost, h->cost_partials, o_cost,
                        h->nsq_p, h->sq_part_p, h->nr > 0 ? h->scalars + SC_DXP2 : nullptr,
-                       h->nsq_l, h->sq_part_l, (h->nv > 0 || h->shard_out) ? o_dxl : nullptr, gate,
+                       nsq_l_now(h), h->sq_part_l, (h->nv > 0 || h->shard_out) ? o_dxl : nullptr, gate,
                        h->status, h->scalars, publish ? h->h_status_dev : nullptr, publish ? h->h_scalars_dev : nullptr,
                        h->arrivals, publish ? h->h_seq_dev : nullptr, publish ? ++h->seq : 0LL);
     return 0;

@@ -105,3 +105,4 @@ PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
 #include "ps_k_band.h"
 #include "ps_k_bandpart.h"
 #include "ps_k_tail.h"
+#include "ps_k_packed.h"

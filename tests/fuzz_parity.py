@@ -57,6 +57,13 @@ def run(n_cases, seed0=0, verbose=True):
             dev.set_option('coarse_groups', int(rng.integers(1, 20)))
         if rng.integers(4) == 0:
             dev.set_option('direct_max_unknowns', 0)
+        # round 5: the kernels that replaced others keep their predecessors as variants -- both sides of each switch are swept
+        if rng.integers(4) == 0:
+            dev.set_option('lm_packed', 0)                    # 16 lanes per landmark instead of lanes packed by observation
+        if rng.integers(4) == 0:
+            dev.set_option('band_part', 0)                    # serial band factorisation of the coarse matrix
+        elif rng.integers(3) == 0:
+            dev.set_option('band_part_chunk', int(rng.integers(2, 12)))
         linesearch = bool(rng.integers(2))
         try:
             c0 = dev.eval_cost(True)
