@@ -111,12 +111,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
 #pragma unroll
     for (int k = 0; k < 9; ++k) sm[9 * lane + k] = hb[k];
     __builtin_amdgcn_wave_barrier();
-    if (sg.head) {
-        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int l = lane; l < sg.lane1; ++l) {              // the landmark's observations in order: a fixed summation order
+    // the nine sums of a landmark, spread over its lanes: lane j of an n-lane segment forms quantities j, j + n, ... (each over the
+    // landmark's observations IN ORDER: a fixed summation order) -- ten dependent LDS reads per lane at ten observations instead of
+    // ninety by the head lane alone; the results go to the head's own nine slots once every lane has read
+    {
+        const int jpos = lane - sg.lane0, nseg = sg.lane1 - sg.lane0;
+        double part[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) a[k] += sm[9 * l + k];
+        for (int it = 0; it < 9; ++it) {
+            const int q = jpos + it * nseg;
+            part[it] = 0.0;
+            if (sg.valid && q < 9) {
+                double acc = 0.0;
+                for (int l = sg.lane0; l < sg.lane1; ++l) acc += sm[9 * l + q];
+                part[it] = acc;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {
+            const int q = jpos + it * nseg;
+            if (sg.valid && q < 9) sm[9 * sg.lane0 + q] = part[it];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (sg.head) {
+        double a[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a[k] = sm[9 * lane + k];
         const double damp = 1.0 + lambda;
         const double H00 = a[0] * damp, H10 = a[1], H11 = a[2] * damp, H20 = a[3], H21 = a[4], H22 = a[5] * damp;
         // H_ll = C C^T, M = C^-1 (lower): the reciprocal roots first, every quotient a product (as k_landmark_pass)

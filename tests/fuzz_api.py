@@ -103,6 +103,12 @@ def run(n_cases, seed0=0, verbose=True):
             # a landmark whose 3 x 3 block is singular to rounding (rays nearly parallel after an update): the device
             # refuses it, the reference's LU silently produces a huge step; nothing to compare
             try:
+                # (round 5, case 940269: the reference's own trajectory diverges -- cost 2e3 -> 1e11 -> NaN -- and the device stops at
+                #  the first landmark block that is no longer positive definite, which is the documented difference in error behaviour,
+                #  a NaN history is nothing to compare against)
+                if not np.all(np.isfinite(np.asarray(ref['cost_history'], dtype=float))):
+                    ok, msg = True, 'the reference trajectory itself ends in NaN, skipped'
+                    raise StopIteration
                 Pc, _, _ = orc.normal_equations(ref_lp, points_first=False)
                 nn = ref_lp.num_reduced * ref_lp.dof
                 Hd = Pc[nn:, nn:].toarray()
