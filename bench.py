@@ -526,7 +526,10 @@ def main():
                                        name, cfg['num_kf'], cfg['num_lm'], OBS_PER_LM, total_blocks,
                                        '; FIXED problem, landmark shard 1/{} per GPU ({} blocks on rank 0)'.format(world, info['num_obs'])
                                        if world > 1 else ''),
-                       'parallelism': 'landmark-sharded x{} + RCCL all-reduce of the reduced pose system (upper triangle)'.format(world)
+                       'parallelism': ('landmark-sharded x{} (landmarks cut by first observing pose) + '.format(world) +
+                                       ('all-gather of the ranks\' band segments of the reduced pose system, summed in a fixed order'
+                                        if getattr(dev, 'segments', None) is not None else
+                                        'RCCL all-reduce of the reduced pose system (upper triangle)'))
                        if world > 1 else 'single GPU',
                        'timed_region': '{} cold solves from the perturbed start = {} iterations: solver state cleared before each solve '
                                        '(ps_reset_solver_state), the loop of Problem.solve under the options of reference '
