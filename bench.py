@@ -487,9 +487,12 @@ def main():
         if k != 'schur_pairs' and v[1] > 0:
             stages[k] = v
     i0 = problem_info(core)
-    cold_solves(dev, start, 4, fence, warm_solves=0)
+    counted = cold_solves(dev, start, 4, fence, warm_solves=1)
     i1 = problem_info(core)
-    n_launch = (i1['cg_kernel_launches'] - i0['cg_kernel_launches']) / 4.0
+    # launches of the reduced solve per iteration, spare (gated, no-op) launches past convergence included.  cold_solves always runs
+    # one untimed solve in front of the counted one: both are between the two counter reads.  (Rounds 3-4 divided by the counted
+    # solve's iterations only and reported twice the launches -- 47.5 for 23.8 -- hence half the time per launch.)
+    n_launch = (i1['cg_kernel_launches'] - i0['cg_kernel_launches']) / float(2 * max(counted['iterations'], 1))
 
     # the figures of rounds 1-3, kept as extra keys: the same linearisation point restored before every step
     steady = moving = None
