@@ -278,7 +278,10 @@ def name_stage_totals(stage):
     out = dict(stage)
     if 'iteration_total' in out:
         out['call_event_pair'] = out.pop('iteration_total')
-    out['stages_sum'] = sum(v for k, v in stage.items() if k in STAGE_KEYS)
+    # (the sharded driver's reduced solve has no event pair of its own: its stages do not add up to an iteration, so the sum is named
+    #  for what it is)
+    out['stages_sum' if 'pcg' in stage or 'schur_pairs' not in stage else 'stages_sum_without_reduced_solve'] = \
+        sum(v for k, v in stage.items() if k in STAGE_KEYS)
     return out
 
 

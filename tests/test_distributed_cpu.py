@@ -191,6 +191,43 @@ def test_locality_shards_touch_band_segments():
         assert max(obs) - min(obs) <= 0.1 * lp.num_obs / 4 + 10
 
 
+def test_owner_lists_and_packed_layout_edge_cases():
+    """landmark_owner_lists: a partition for any world size (also more ranks than landmarks with observations), unobserved
+    landmarks sort last; packed_layout: positions inside [upper(S) | g | cost (2) | flag] in ascending key order, diagonals
+    included, a block outside the pattern refused."""
+    from pyslam_amd.distributed import landmark_owner_lists, packed_layout, shard_touch
+    lp, _ = synthetic.stereo_ba(num_kf=10, num_lm=30, obs_per_lm=3, half_window=3, seed=1)
+    # two landmarks nobody observes (appended): they must end up with the LAST rank
+    lp2 = lp.copy()
+    lp2.points = np.vstack([lp.points, np.zeros((2, 3))])
+    lp2.point_vid = np.concatenate([lp.point_vid, [-1, -1]]).astype(lp.point_vid.dtype)
+    lp2.point_keys = list(lp.point_keys) + ['x0', 'x1']
+    lp2 = lp2.finalize()
+    for world in (1, 2, 3, 8, 40):
+        owners = landmark_owner_lists(lp2, world)
+        assert len(owners) == world
+        assert np.array_equal(np.sort(np.concatenate(owners)), np.arange(lp2.num_points))
+        if world > 1:
+            assert {30, 31} <= set(owners[-1].tolist())
+        for r in range(world):
+            sh = shard_landmarks(lp2, r, world, owners=owners)
+            assert sh.num_points == owners[r].size and sh.num_obs == int(np.isin(lp2.obs_point, owners[r]).sum())
+    # packed_layout
+    keys = pose_pair_keys(lp)
+    nr, d = lp.num_reduced, lp.dof
+    indices, tail = packed_layout(keys, nr, d)
+    allk = np.unique(np.concatenate([keys, (np.arange(nr, dtype=np.int64) << 32) | np.arange(nr, dtype=np.int64)]))
+    nup = allk.size
+    assert np.array_equal(tail, nup * d * d + nr * d + np.arange(3))
+    blocks, poses = shard_touch(lp)
+    idx = indices(blocks, poses)
+    assert np.array_equal(np.sort(idx), np.arange(nup * d * d + nr * d))      # the whole problem touches everything but the tail
+    one = indices(allk[5:6], np.array([2], dtype=np.int64))
+    assert np.array_equal(one, np.concatenate([5 * d * d + np.arange(d * d), nup * d * d + 2 * d + np.arange(d)]))
+    with pytest.raises(ValueError):
+        indices(np.array([(np.int64(nr + 3) << 32) | np.int64(nr + 4)]), np.zeros(0, np.int64))
+
+
 def test_shards_partition_the_problem():
     lp, _ = synthetic.stereo_ba(num_kf=10, num_lm=200, obs_per_lm=5, half_window=4, seed=3,
                                 const_point_fraction=0.1)
