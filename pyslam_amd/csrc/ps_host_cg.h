@@ -253,7 +253,11 @@ int build_coarse(ps_problem* h) {
     const int xmin = std::min(h->cg_split_min_rows, h->cg_explicit_min_rows >= 0 ? h->cg_explicit_min_rows : xmin_auto);
     h->cg_explicit = h->explicit_ok && G != 0 && nr > xmin;
     if (h->cg_explicit && h->coarse_req < 0)
-        G = sparse_rows ? std::min(500, std::max(48, nr / 20)) : std::min(112, std::max(48, nr / 20));
+        // (round 5: beyond 2 048 poses -- the two-launch form, whose coarse kernel reads the inverse once per iteration -- one
+        //  interval per 10 poses: 3 000 poses 150 -> 300 intervals 1.72 -> 1.66 ms, 5 000 poses 250 -> 500 1.95 -> 1.86 ms; below,
+        //  where every workgroup of the one-launch form reads its own rows of the inverse, finer levels lose: 1 500 poses 75 -> 150
+        //  intervals 1.10 -> 1.53 ms)
+        G = sparse_rows ? std::min(500, std::max(48, nr > 2048 ? nr / 10 : nr / 20)) : std::min(112, std::max(48, nr / 20));
     G = std::min(G, h->cg_explicit ? PS_XCG_MAXNODES - 1 : Gmax);
     if (h->coarse_clamped && h->coarse_req < 0) G = std::min(G, 255);
     if (G > 0 && nr < 2 * G + 1) G = (nr - 1) / 2;

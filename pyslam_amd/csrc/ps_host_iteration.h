@@ -51,7 +51,17 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     //  coarse eigenvalues move by that factor at most, and the alternative is a factorisation on the solver stream)
     const double lam_inv = h->lci_next >= 0 ? h->xcg_tag_lambda[h->lci_next] : 0.0, lam_now = h->lin_lambda;
     const bool lam_ok = lam_now == lam_inv || (lam_now > 0.0 && lam_inv > 0.0 && lam_now <= 4.0 * lam_inv && lam_inv <= 4.0 * lam_now);
-    const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && lam_ok;
+    // (round 5) ... and not behind a step that at least HALVED the cost on pose-graph-like rows when the factorisation is the cheap
+    // partitioned one: the inverse of the start point's A_c is a poor stand-in on the other side of such a step -- C2's second call
+    // took 111 CG iterations with it against 71-77 with a current one, 34 x 31 us -- while forming the current one on the solver
+    // stream costs 0.33 + 0.06 ms there.  Bundle-adjustment rows lose nothing by lagging (C4: 20 iterations either way) and keep it.
+    const bool sparse_rows = (long)h->nnzb <= 24L * nr;
+    const bool big_drop = h->prev_cost > 0.0 && h->last_cost >= 0.0 && h->last_cost < 0.5 * h->prev_cost;
+    const int bw_now = std::max(h->ac_bw, 1);
+    const bool cheap_factor = h->band_chol && h->ac_bw >= 0 && h->band_part &&
+                              BandPart::eligible(ncb, bw_now, h->band_part_m > 0 ? h->band_part_m : BandPart::auto_m(ncb, bw_now));
+    const bool refactor_now = h->sync_refactor && sparse_rows && big_drop && cheap_factor;
+    const bool lag = allow_lag && h->coarse_lag && h->lci_next >= 0 && lam_ok && !refactor_now;
     const bool settled = h->xcg_auto_hold && h->prev_cost > 0.0 && h->last_cost > 0.0 &&
                          std::fabs(h->prev_cost - h->last_cost) <= 1e-4 * h->prev_cost && h->xcg_held < 3;
     // ... or the inverse in use was formed from the A_c of THIS linearisation point (the caller linearises at the same point
