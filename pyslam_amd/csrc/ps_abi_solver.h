@@ -700,6 +700,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
     else if (n == "lm_packed") h->lm_packed = value != 0;
     else if (n == "sync_refactor") h->sync_refactor = value != 0;
+    else if (n == "hold_across_steps") h->hold_across_steps = value != 0;
     else if (n == "band_part") { h->band_part = value != 0; h->lci_next = -1; }
     else if (n == "band_part_chunk") { if (value < 0 || value > 4096) return fail("band_part_chunk must be 0 (automatic) .. 4096 nodes"); h->band_part_m = (int)value; h->lci_next = -1; }
     else if (n == "coarse_auto_hold") h->xcg_auto_hold = value != 0;

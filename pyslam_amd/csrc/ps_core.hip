@@ -283,6 +283,7 @@ struct ps_problem {
     int ac_bw = -1;
     int band_chol = 1;              // option "band_chol"
     int band_part = 1;              // option "band_part": the banded coarse matrix by the PARTITIONED factorisation (ps_k_bandpart.h) where it applies
+    int hold_across_steps = 1;      // option "hold_across_steps": BA rows keep a coarse inverse that still converges as fast, also behind a big step
     int sync_refactor = 1;          // option "sync_refactor": pose graphs factor the CURRENT coarse matrix on the solver stream behind a step that halved the cost
     int band_part_m = 0;            // option "band_part_chunk": interior nodes per chunk (0: automatic, ~ sqrt(B ncb) - B)
     std::unique_ptr<BandPart> bpart;

@@ -49,13 +49,13 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     // goes from 0 to 1e-3: such a call factors its own A_c, on the solver stream)
     // (a damping within a factor of four of the inverse's -- an LM schedule that halves or doubles lambda -- still lags: the
     //  coarse eigenvalues move by that factor at most, and the alternative is a factorisation on the solver stream)
+    const bool sparse_rows = (long)h->nnzb <= 24L * nr;
     const double lam_inv = h->lci_next >= 0 ? h->xcg_tag_lambda[h->lci_next] : 0.0, lam_now = h->lin_lambda;
     const bool lam_ok = lam_now == lam_inv || (lam_now > 0.0 && lam_inv > 0.0 && lam_now <= 4.0 * lam_inv && lam_inv <= 4.0 * lam_now);
     // (round 5) ... and not behind a step that at least HALVED the cost on pose-graph-like rows when the factorisation is the cheap
     // partitioned one: the inverse of the start point's A_c is a poor stand-in on the other side of such a step -- C2's second call
     // took 111 CG iterations with it against 71-77 with a current one, 34 x 31 us -- while forming the current one on the solver
     // stream costs 0.33 + 0.06 ms there.  Bundle-adjustment rows lose nothing by lagging (C4: 20 iterations either way) and keep it.
-    const bool sparse_rows = (long)h->nnzb <= 24L * nr;
     const bool big_drop = h->prev_cost > 0.0 && h->last_cost >= 0.0 && h->last_cost < 0.5 * h->prev_cost;
     const int bw_now = std::max(h->ac_bw, 1);
     const bool cheap_factor = h->band_chol && h->ac_bw >= 0 && h->band_part &&
@@ -78,7 +78,11 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
     // (not behind a step that changed the cost by more than 5 %: the point has moved, and a pose graph's coarse operator with it --
     //  10 000 poses: 122 CG iterations in the third call with the start point's inverse against 88 with the refreshed one)
     const bool moved = !(h->prev_cost > 0.0 && h->last_cost > 0.0 && std::fabs(h->prev_cost - h->last_cost) <= 0.05 * h->prev_cost);
-    const bool keep_ok = h->xcg_adaptive_hold && !moved && h->xcg_its_ref > 0 && h->last_pcg_iters > 0 &&
+    // (round 5: on bundle-adjustment rows the big first step does not spoil the inverse either -- C4's second call takes 20 iterations
+    //  with the start point's inverse against 19-20 with a fresh one -- so there the iteration count alone decides; option
+    //  "hold_across_steps" 0 restores round 4's rule)
+    const bool moved_matters = moved && (sparse_rows || !h->hold_across_steps);
+    const bool keep_ok = h->xcg_adaptive_hold && !moved_matters && h->xcg_its_ref > 0 && h->last_pcg_iters > 0 &&
                          h->last_pcg_iters <= h->xcg_its_ref + 3 && h->xcg_good_held < 8 && h->lci_next >= 0 &&
                          h->lin_lambda == h->xcg_tag_lambda[h->lci_next];
     const bool fresh_waiting = h->lci_next != h->lci_cur;    // a newer inverse has been (or is being) formed and not taken yet
