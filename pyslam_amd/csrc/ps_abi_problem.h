@@ -35,8 +35,8 @@ int ps_warm_up(void) {
         // when it loads).  Asking for the attributes of the kernels of the whole-iteration paths resolves them here.
         hipFuncAttributes a;
 #define PS_TOUCH(...) (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&__VA_ARGS__))
-        PS_TOUCH(k_landmark_pass<false>); PS_TOUCH(k_landmark_pass_packed<false>); PS_TOUCH(k_backsub_packed); PS_TOUCH(k_pose_pass<false>); PS_TOUCH(k_pose_finalize); PS_TOUCH(k_schur_pairs_db<0>);
-        PS_TOUCH(k_schur_combine); PS_TOUCH(k_backsub); PS_TOUCH(k_cost_reproj<false>); PS_TOUCH(k_reduce3); PS_TOUCH(k_reduce_partials);
+        PS_TOUCH(k_landmark_pass<false>); PS_TOUCH(k_landmark_pass_packed<false, false>); PS_TOUCH(k_landmark_pass_packed<false, true>); PS_TOUCH(k_backsub_packed); PS_TOUCH(k_pose_pass<false>); PS_TOUCH(k_pose_finalize); PS_TOUCH(k_schur_pairs_db<0>);
+        PS_TOUCH(k_schur_combine); PS_TOUCH(k_backsub); PS_TOUCH(k_cost_reproj<false>); PS_TOUCH(k_cost_packed<false>); PS_TOUCH(k_reduce3); PS_TOUCH(k_reduce_partials);
         PS_TOUCH(k_copy2); PS_TOUCH(k_zero4); PS_TOUCH(k_lag_status_check);
         PS_TOUCH(k_block_jacobi_factor<6>); PS_TOUCH(k_scale_blocks<6>); PS_TOUCH(k_scale_blocks_p<6>); PS_TOUCH(k_rows_setup<6>);
         PS_TOUCH(k_coarse_rowsums<6>); PS_TOUCH(k_coarse_matrix<6>); PS_TOUCH(k_coarse_chol<6, true>); PS_TOUCH(k_coarse_border<6>);
@@ -1126,8 +1126,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     // ---- scalars
     h->ncost_obs = N > 0 ? std::min(2048, cdiv(N, 256)) : 0;
     h->ncost_fac = F > 0 ? std::min(1024, cdiv(F, 256)) : 0;
-    if (h->alloc(&h->cost_partials, (size_t)std::max(h->ncost_obs + h->ncost_fac, 512) + 8) ||
-        h->alloc(&h->scalars, SC_NWORDS)) return -1;
+    if (h->alloc(&h->scalars, SC_NWORDS)) return -1;
     if (h->zero(h->scalars, SC_NWORDS * sizeof(double)) || h->zero(h->status, ST_NWORDS * sizeof(int32_t))) return -1;
     h->nsq_l = h->nsq_l16 = nv > 0 ? cdiv(nv, 256 / PS_LM_GROUP) : 0;
     // ---- runs of landmarks per wave for the packed landmark pass / back-substitution (ps_k_packed.h)
@@ -1162,6 +1161,8 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     h->nsq_p = nr > 0 ? cdiv(P, 256) : 0;
     if (h->alloc(&h->sq_part_l, (size_t)h->nsq_l) || h->alloc(&h->sq_part_p, (size_t)h->nsq_p) ||
         h->alloc(&h->shard_buf, 2)) return -1;
+    // (cost partials: one per workgroup of the cost pass, or of the packed landmark pass when that sums the cost; + the factors')
+    if (h->alloc(&h->cost_partials, (size_t)std::max({h->ncost_obs + h->ncost_fac, cdiv(h->lmw_nwaves, 4) + h->ncost_fac, 512}) + 8)) return -1;
     if (h->zero(h->shard_buf, 2 * sizeof(double))) return -1;
     // the pinned, host-mapped result words: one block (from the pool), five windows at 256-byte offsets
     if (!ps_pool().take(ps_pool().host_words, &h->words_host))
@@ -1178,6 +1179,7 @@ int ps_problem_create(const ps_problem_desc* d_in, void* stream, ps_problem** ou
     h->h_setup = (long long*)(whost + 1024);  h->h_setup_dev = (long long*)(wdev + 1024);
     h->h_ldi_fro = (double*)(whost + 1280);   h->h_ldi_fro_dev = (double*)(wdev + 1280);
     h->h_early = (long long*)(whost + 1536);  h->h_early_dev = (long long*)(wdev + 1536);
+    h->h_lmfail = (long long*)(whost + 1792); h->h_lmfail_dev = (long long*)(wdev + 1792);
     h->h_mo_hist = (double*)(whost + 2048);   h->h_mo_hist_dev = (double*)(wdev + 2048);     // PS_MO_HIST_WORDS doubles
     if (h->alloc(&h->arrivals, 2)) return -1;
     if (h->zero(h->arrivals, 2 * sizeof(int32_t))) return -1;

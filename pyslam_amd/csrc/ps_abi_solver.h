@@ -17,7 +17,11 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
 
 int ps_eval_cost(ps_problem* h, int include_all_constant, double* cost) {
     if (!h || !cost) return fail("null argument");
-    if (cost_pass(h, include_all_constant, SC_COST)) return -1;
+    // (all blocks, every observation in the packed landmark pass's runs: that pass sums the cost -- the same sum, bit for bit, as
+    //  the tail of a whole-iteration call that expects a successor forms, ps_host_cg.h: gn_tail -- and leaves this point's
+    //  landmark pass done for a linearisation that follows)
+    if (include_all_constant && h->fuse_cost == 1 && lm_cost_possible(h)) { if (lm_cost_pass(h, h->lin_lambda, SC_COST)) return -1; }
+    else if (cost_pass(h, include_all_constant, SC_COST)) return -1;
     if (read_scalars(h)) return -1;
     *cost = h->h_scalars[SC_COST];
     if (include_all_constant) h->last_cost = *cost;         // the cost AT the current parameters (what ps_gn_iteration's line-search
@@ -71,7 +75,7 @@ int ps_shard_pack(ps_problem* h) {
 
 int ps_shard_unpack(ps_problem* h) {
     if (!h) return fail("null argument");
-    h->prelin_valid = false;            // S and g are overwritten with the all-reduced system
+    h->prelin_valid = h->prelm_valid = false;            // S and g are overwritten with the all-reduced system
     if (ensure_shard_pack(h)) return -1;
     const long ntail = (long)h->nr * h->D + 2;
     const int nb = (int)std::min<long>(4096, cdiv(h->pack_count, 256));
@@ -115,7 +119,7 @@ int ps_step_norm2(ps_problem* h, double* norm2) {
 
 int ps_apply_update(ps_problem* h, double step) {
     if (!h) return fail("null argument");
-    h->prelin_valid = false;
+    h->prelin_valid = h->prelm_valid = false;
     h->last_cost = h->prev_cost = -1.0;                     // parameters move without a cost: history unknown from here
     return apply_update(h, step);
 }
@@ -132,7 +136,7 @@ int ps_snapshot_params(ps_problem* h) {
 
 int ps_restore_params(ps_problem* h) {
     if (!h) return fail("null argument");
-    h->prelin_valid = false;
+    h->prelin_valid = h->prelm_valid = false;
     h->last_cost = h->snap_cost; h->prev_cost = -1.0;       // the snapshot's own cost (if it was known), no step history
     const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
     if (n1 + n2)
@@ -151,7 +155,7 @@ int ps_get_params(ps_problem* h, double* poses, double* points) {
 
 int ps_set_params(ps_problem* h, const double* poses, const double* points) {
     if (!h) return fail("null argument");
-    h->prelin_valid = false;
+    h->prelin_valid = h->prelm_valid = false;
     h->last_cost = h->prev_cost = -1.0;
     if (poses && h->P) HIP_OK(hipMemcpyAsync(h->poses, poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDefault, h->stream));
     if (points && h->L) HIP_OK(hipMemcpyAsync(h->points, points, (size_t)h->L * 3 * sizeof(double), hipMemcpyDefault, h->stream));
@@ -274,13 +278,19 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
                              double* start_cost_out) {
     if (!h) return fail("null argument");
     h->start_cost_pending = false;
+    h->lmfail_check = 0;
     if (start_cost_out) {
         const bool published_path = !(h->nccl_allreduce && h->nccl_comm) && h->nr > 0 && h->pcg_variant == 1 &&
                                     !(h->mo_fused && h->nv == 0 && h->F == 0 && h->D == 6 && h->N == h->Np && h->max_pose_obs <= 2048);
         if (!published_path) {                              // paths that end otherwise: a call of its own
             if (ps_eval_cost(h, 1, start_cost_out)) return -1;
             start_cost_out = nullptr;
-        } else { if (cost_pass(h, 1, SC_STARTCOST)) return -1; h->start_cost_pending = true; }
+        } else {
+            const bool ahead = h->prelin_valid && h->prelin_lambda == lambda;       // (this point is linearised already)
+            if (!ahead && h->fuse_cost == 1 && lm_cost_possible(h)) { if (lm_cost_pass(h, lambda, SC_STARTCOST)) return -1; }
+            else if (cost_pass(h, 1, SC_STARTCOST)) return -1;
+            h->start_cost_pending = true;
+        }
     }
     struct CallClock {
         ps_problem* h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -373,7 +383,8 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
         StageTimer total(h, PS_ST_TOTAL, 2);  // closed before the last synchronising read-back
         h->spec_enqueued = false;
         if (h->prelin_valid && h->prelin_lambda == lambda) h->prelin_valid = false;     // linearised ahead, behind the last call's tail
-        else if (linearize(h, lambda)) return -1;
+        else if (linearize(h, lambda, true)) return -1;
+        h->lmfail_check = h->lin_lmfail_tag;   // (its landmark pass may have run in the previous call's tail: wait_published)
         if (h->nr > 0 && h->pcg_variant == 1) {
             const int rc = h->D == 6
                 ? gn_solve_and_finish_async<6>(h, pcg_tol, pcg_max_iters, linesearch, pcg_iters_out, pcg_relres_out, &total)
@@ -385,6 +396,10 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
             total.stop();
             if (read_scalars(h)) return -1;
         }
+    }
+    if (h->prelm_pending) {                                  // the tail ran the next linearisation's landmark pass in place of the cost pass
+        h->prelm_pending = false;
+        h->prelm_valid = h->h_status[ST_PCG_DONE] == 1 && !h->h_status[ST_LM_FAIL] && !h->h_status[ST_DIAG_FAIL];
     }
     if (h->spec_enqueued) {                                  // the next iteration's linearisation is in the queue: valid if this one ended well
         h->spec_enqueued = false;
@@ -431,13 +446,13 @@ int ps_solve(ps_problem* h, const ps_solve_options* o, double pcg_tol, int pcg_m
         // the solve running; without allow_nondecreasing_steps, likely while the steps still cut the cost in half.  Then the next
         // linearisation is enqueued behind this iteration's tail (wait_published).  Not while the lagged dense inverse may seed: its
         // side stream reads S after the call.
-        h->spec_next = it <= o->max_iters && !(ldi_eligible(h) && h->solve_horizon >= 3) &&
-                       (o->allow_nondecreasing_steps ? h->solve_horizon >= 1 : (it >= 2 && last_ratio < 0.5));
+        h->expect_next = it <= o->max_iters && (o->allow_nondecreasing_steps ? h->solve_horizon >= 1 : (it >= 2 && last_ratio < 0.5));
+        h->spec_next = h->expect_next && !(ldi_eligible(h) && h->solve_horizon >= 3);
         const auto t0 = std::chrono::steady_clock::now();
         double c0 = 0.0, c = 0.0, rel = 0.0;
         int its = 0;
         const int rc_it = gn_iteration_impl(h, o->lm_lambda, pcg_tol, pcg_max_iters, o->linesearch, &c, &dxn, &its, &rel, it == 1 ? &c0 : nullptr);
-        h->spec_next = false;
+        h->spec_next = false; h->expect_next = 0;
         if (rc_it) return -1;
         if (it == 1) { cost = c0; cost_history[n++] = c0; h->prev_cost = c0; }
         const double prev = cost;
@@ -465,7 +480,7 @@ int ps_solve(ps_problem* h, const ps_solve_options* o, double pcg_tol, int pcg_m
 int ps_motion_only_solve(ps_problem* h, const ps_solve_options* o, double* cost_history, int32_t cap, int32_t* n_history,
                          int32_t* iterations, double* last_dx_norm, double* pose12_out) {
     if (!h || !o || !cost_history || !n_history) return fail("null argument");
-    h->prelin_valid = false;
+    h->prelin_valid = h->prelm_valid = false;
     const bool eligible = h->mo_fused && h->nv == 0 && h->F == 0 && h->nr == 1 && h->P == 1 && h->D == 6 && h->N == h->Np &&
                           h->pcg_variant == 1 && h->max_pose_obs <= 2048;
     const int need = o->max_iters + 2;                        // the start cost + at most max_iters + 1 iterations
@@ -511,7 +526,7 @@ int ps_motion_only_solve(ps_problem* h, const ps_solve_options* o, double* cost_
 
 int ps_covariance_begin(ps_problem* h) {
     if (!h) return fail("null argument");
-    h->prelin_valid = false;
+    h->prelin_valid = h->prelm_valid = false;
     if (linearize(h, 0.0)) return -1;
     if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h) && !h->coarse_built && build_coarse(h)) return -1;
     if (h->nr > 0 && h->pcg_variant == 1 && !use_direct(h) && !h->cg_explicit) {
@@ -671,8 +686,11 @@ static void relook_path(ps_problem* h) {
 
 int ps_set_option(ps_problem* h, const char* name, double value) {
     if (!h || !name) return fail("null argument");
-    h->prelin_valid = false;
     const std::string n(name);
+    // what a caller's own loop says about its next call leaves what was computed ahead in place
+    if (n == "expect_next") { h->expect_next = value != 0; return 0; }
+    if (n == "solve_horizon") { h->solve_horizon = value < 0 ? -1 : (int)std::min(value, 1e6); return 0; }
+    h->prelin_valid = h->prelm_valid = false;
     if (n == "pcg_variant") { if (value != 0 && value != 1) return fail("pcg_variant must be 0 or 1"); h->pcg_variant = (int)value; }
     else if (n == "coarse_groups") {
         if (value < -1 || value >= PS_XCG_MAXNODES) return fail("coarse_groups out of range (-1 auto, 0 off, else number of hat intervals; above 63 only for the explicit two-level PCG, at most 1023)");
@@ -699,6 +717,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "xcg_restrict_fused") h->xcg_rt = value != 0;
     else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
     else if (n == "lm_packed") h->lm_packed = value != 0;
+    else if (n == "fuse_cost") h->fuse_cost = (int)value;       // 0 off, 1 on, 2 = in the tails only (not the start cost / ps_eval_cost)
     else if (n == "sync_refactor") h->sync_refactor = value != 0;
     else if (n == "hold_across_steps") h->hold_across_steps = value != 0;
     else if (n == "band_part") { h->band_part = value != 0; h->lci_next = -1; }
@@ -727,7 +746,6 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "cg_margin") { if (value < 0 || value > 64) return fail("cg_margin out of range"); h->cg_margin = (int)value; }
     else if (n == "cg_split_min_rows") { h->cg_split_min_rows = (int)value; h->coarse_built = false; }
     else if (n == "cg_explicit_min_rows") { h->cg_explicit_min_rows = (int)value; h->coarse_built = false; }
-    else if (n == "solve_horizon") h->solve_horizon = value < 0 ? -1 : (int)std::min(value, 1e6);
     else if (n == "pcg_chunk") { if (value < 1 || value > 4096) return fail("pcg_chunk out of range"); h->pcg_chunk = (int)value; }
     else return fail("unknown option: " + n);
     return 0;
@@ -741,7 +759,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
 // (Problem.solve; bench.py's cold solves).
 int ps_reset_solver_state(ps_problem* h) {
     if (!h) return fail("null argument");
-    h->prelin_valid = false;
+    h->prelin_valid = h->prelm_valid = false;
     if (!h->solver_touched) {                               // nothing linearised since creation / the last reset: only the history
         h->last_cost = h->prev_cost = h->snap_cost = -1.0;
         h->solve_horizon = -1;

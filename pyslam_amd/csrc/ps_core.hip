@@ -409,6 +409,17 @@ struct ps_problem {
     long long early_seq = 0;
     bool spec_next = false, spec_enqueued = false, early_armed = false, prelin_valid = false;
     double prelin_lambda = 0.0;
+    // The landmark pass of the NEXT linearisation in place of this iteration's cost pass (k_landmark_pass_packed<.., COST>,
+    // gn_tail): option "expect_next" (ps_solve sets it per iteration; a caller's own loop may) says a successor is expected.
+    // prelm_pending: the running tail carries such a pass (tag prelm_tag); prelm_valid: it ran (the tail was open) and the
+    // parameters have not moved since -- linearize() then skips its landmark pass.  A landmark block that was not positive
+    // definite there stamps h_lmfail with the tag; the call whose linearisation consumed the pass reports it (lmfail_check).
+    int expect_next = 0, fuse_cost = 1;
+    bool prelm_pending = false, prelm_valid = false;
+    double prelm_lambda = 0.0;
+    long long prelm_tag = 0, prelm_seq = 0, lmfail_check = 0, lin_lmfail_tag = 0;
+    long long *h_lmfail = nullptr, *h_lmfail_dev = nullptr;
+    long prelm_used = 0;            // linearisations that skipped their landmark pass (ps_get_counters-style diagnostics)
     bool start_cost_pending = false; // the running whole-iteration call also evaluates the cost at its linearisation point (SC_STARTCOST)
     bool solver_touched = false;    // something has been linearised since creation / the last ps_reset_solver_state
     // profiling

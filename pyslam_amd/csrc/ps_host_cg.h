@@ -43,7 +43,7 @@ void drain_timers(ps_problem* h) {      // call after a stream synchronisation
 
 int side_kick(ps_problem* h);
 int ldi_side_kick(ps_problem* h);
-int linearize(ps_problem* h, double lambda);
+int linearize(ps_problem* h, double lambda, bool allow_prelm = false);
 
 // stage timers whose end event has completed (a speculative linearisation enqueued behind the iteration's end is still running
 // when the host leaves wait_published: its events stay pending)
@@ -92,9 +92,14 @@ int wait_published(ps_problem* h) {
         // linearisation goes in behind the tail NOW, while the GPU runs the tail and the host has nothing to do but wait
         if (h->early_armed && *reinterpret_cast<volatile long long*>(h->h_early) == h->early_seq) {
             h->early_armed = false; h->spec_enqueued = true;
-            if (linearize(h, h->lin_lambda)) return -1;
+            // (the tail is open: the landmark pass it carries in place of the cost pass runs, at the point this linearises)
+            if (h->prelm_pending) { h->prelm_pending = false; h->prelm_valid = true; }
+            if (linearize(h, h->lin_lambda, true)) return -1;
         }
         if (*w == h->seq) {
+            // a landmark block that was not positive definite in the landmark pass the previous tail ran for THIS call's
+            // linearisation (k_landmark_pass_packed<.., COST> reports through a word of its own)
+            if (h->lmfail_check && *reinterpret_cast<volatile long long*>(h->h_lmfail) == h->lmfail_check) h->h_status[ST_LM_FAIL] += 1;
             if (h->start_cost_pending) {                     // ps_solve's first iteration: the start cost rode in front of it --
                 h->start_cost_pending = false;               // from here on the call knows it, as if ps_eval_cost had run first
                 h->last_cost = h->ldi_call_start_cost = h->h_scalars[SC_STARTCOST];
@@ -915,9 +920,16 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
     return rc;
 }
 
-int linearize(ps_problem* h, double lambda) {
+int linearize(ps_problem* h, double lambda, bool allow_prelm) {
     h->solver_touched = true;
     h->prelin_valid = false;                                 // (whatever was linearised ahead is replaced)
+    // the landmark pass of THIS point already ran in the previous iteration's tail (in place of its cost pass) and nothing has
+    // moved since: Z, C^-1, c are in place; a failure it found is reported by this call (lmfail_check, wait_published)
+    // (only the whole-iteration calls take it over: they are the ones that look at h_lmfail)
+    const bool lm_done = allow_prelm && h->prelm_valid && h->prelm_lambda == lambda && h->nv > 0;
+    h->prelm_valid = false;
+    h->lin_lmfail_tag = lm_done ? h->prelm_tag : 0;
+    if (lm_done) ++h->prelm_used;
     h->lin_lambda = lambda;                                  // (what the held coarse inverse is tagged with, beside the cost)
     ++h->prof_tick;
     h->cov_ready = false;
@@ -927,15 +939,15 @@ int linearize(ps_problem* h, double lambda) {
         h->ldi_sread_pending = false;
     }
     HIP_OK(hipMemsetAsync(h->red, 0, h->red_count * sizeof(double) + ST_NWORDS * sizeof(int32_t), h->stream));   // [S | g | cost | status]
-    if (h->nv > 0) {
+    if (h->nv > 0 && !lm_done) {
         StageTimer t(h, PS_ST_LANDMARK);
         const ObsWide wl{h->sidx_l, h->stiff_tab};
 #define PS_LM_LAUNCH(W) hipLaunchKernelGGL(k_landmark_pass<W>, dim3(cdiv(h->nv, 256 / PS_LM_GROUP)), dim3(256), 0, h->stream, h->nv, h->lm_ptr, \
                            h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,                       \
                            h->Cinv, h->cvec, h->status, h->lm_ablate, wl)
-#define PS_LMP_LAUNCH(W) hipLaunchKernelGGL(k_landmark_pass_packed<W>, dim3(cdiv(h->lmw_nwaves, 4)), dim3(256), 0, h->stream, h->lmw_nwaves, \
+#define PS_LMP_LAUNCH(W) hipLaunchKernelGGL((k_landmark_pass_packed<W, false>), dim3(cdiv(h->lmw_nwaves, 4)), dim3(256), 0, h->stream, h->lmw_nwaves, \
                            h->lmw_first, h->lm_ptr, h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z,      \
-                           h->Cinv, h->cvec, h->status, wl)
+                           h->Cinv, h->cvec, h->status, wl, (const int32_t*)nullptr, (double*)nullptr, (long long*)nullptr, 0LL)
         if (h->lm_packed && h->lmw_nwaves > 0 && !h->lm_ablate) { if (h->wide_obs) PS_LMP_LAUNCH(true); else PS_LMP_LAUNCH(false); }
         else if (h->wide_obs) PS_LM_LAUNCH(true); else PS_LM_LAUNCH(false);
 #undef PS_LMP_LAUNCH
@@ -1025,9 +1037,26 @@ int linearize(ps_problem* h, double lambda) {
 }
 
 // cost partials into cost_partials[0..n); returns n.  The caller reduces them.
+// every observation is in the packed landmark pass's runs (no observation of a constant point): costs are summed in that pass's
+// structure, by k_cost_packed or by the pass itself
+inline bool cost_packed_possible(const ps_problem* h) {
+    return h->fuse_cost != 0 && h->lm_packed && h->lmw_nwaves > 0 && !h->lm_ablate && h->Nl == h->N && h->nv > 0 && h->D == 6;
+}
 int cost_partials_pass(ps_problem* h, int include_all, const int32_t* gate) {
     int n = 0;
-    if (h->N > 0) {
+    if (h->N > 0 && include_all && cost_packed_possible(h)) {
+        // the partial sums of the packed landmark pass (ps_k_packed.h): a cost is the same number, bit for bit, whether that pass
+        // summed it on its way (the tail of an iteration that expects a successor, the start cost) or this one did
+        const ObsWide wl{h->sidx_l, h->stiff_tab};
+        const int nbl = cdiv(h->lmw_nwaves, 4);
+        if (h->wide_obs)
+            hipLaunchKernelGGL(k_cost_packed<true>, dim3(nbl), dim3(256), 0, h->stream, h->lmw_nwaves, h->lmw_first, h->lm_ptr, h->lm_point,
+                               h->lobs, h->poses, h->points, h->ogroups, h->cost_partials, gate, wl);
+        else
+            hipLaunchKernelGGL(k_cost_packed<false>, dim3(nbl), dim3(256), 0, h->stream, h->lmw_nwaves, h->lmw_first, h->lm_ptr, h->lm_point,
+                               h->lobs, h->poses, h->points, h->ogroups, h->cost_partials, gate, wl);
+        n += nbl;
+    } else if (h->N > 0) {
         const ObsWide wl{h->sidx_l, h->stiff_tab};
         if (h->wide_obs)
             hipLaunchKernelGGL(k_cost_reproj<true>, dim3(h->ncost_obs), dim3(256), 0, h->stream, h->N, h->lobs, h->poses,
@@ -1107,7 +1136,7 @@ int step_norm(ps_problem* h) {
 }
 
 int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool with_norm = false, long long* hearly = nullptr, long long eseq = 0) {
-    h->prelin_valid = false;            // the parameters move: a linearisation enqueued ahead is of the old point (set again by
+    h->prelin_valid = h->prelm_valid = false;   // the parameters move: a linearisation enqueued ahead is of the old point (set again by
                                         // gn_iteration_impl AFTER its tail, for the speculative one enqueued behind that tail)
     StageTimer t(h, PS_ST_UPDATE);
     if (h->nr > 0) {
@@ -1123,10 +1152,50 @@ int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool
     return 0;
 }
 
+// ---- the robust cost summed by the landmark pass itself (k_landmark_pass_packed<.., COST>, ps_k_packed.h) --------------------
+// every observation must be in the packed pass's runs (no observation of a constant point); factors add their own partials
+inline bool lm_cost_possible(const ps_problem* h) {
+    return cost_packed_possible(h) && !h->shard_out && !(h->nccl_allreduce && h->nccl_comm);
+}
+// enqueue it at the current parameters; -> number of partials in cost_partials.  Leaves Z, C^-1, c of this point behind:
+// the caller decides whether that makes prelm_valid (an ungated launch) or prelm_pending (a gated tail).
+int lm_cost_enqueue(ps_problem* h, double lambda, const int32_t* gate) {
+    const int nbl = cdiv(h->lmw_nwaves, 4);
+    h->prelm_tag = ++h->prelm_seq;
+    {
+        StageTimer t(h, PS_ST_LANDMARK);
+        const ObsWide wl{h->sidx_l, h->stiff_tab};
+#define PS_LMC_LAUNCH(W) hipLaunchKernelGGL((k_landmark_pass_packed<W, true>), dim3(nbl), dim3(256), 0, h->stream, h->lmw_nwaves, h->lmw_first,    \
+                           h->lm_ptr, h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z, h->Cinv, h->cvec,        \
+                           h->status, wl, gate, h->cost_partials, h->h_lmfail_dev, h->prelm_tag)
+        if (h->wide_obs) PS_LMC_LAUNCH(true); else PS_LMC_LAUNCH(false);
+#undef PS_LMC_LAUNCH
+    }
+    int n = nbl;
+    if (h->F > 0) {
+        StageTimer t(h, PS_ST_COST);
+        hipLaunchKernelGGL(k_cost_factors<6>, dim3(h->ncost_fac), dim3(256), 0, h->stream, (int)h->F, h->f_i, h->f_j, h->f_Tinv, h->f_grp,
+                           h->fgroups, h->poses, h->pose_rid, 1, h->cost_partials + nbl, gate);
+        n += h->ncost_fac;
+    }
+    h->prelm_lambda = lambda;
+    return n;
+}
+// the cost at the current parameters (all blocks) into scalars[scalar_slot], by the landmark pass: the next linearisation at
+// this point and this lambda finds its landmark pass done
+int lm_cost_pass(ps_problem* h, double lambda, int scalar_slot) {
+    h->prelin_valid = false;                                 // (Z, C^-1, c are rewritten -- with the same values if nothing moved)
+    const int n = lm_cost_enqueue(h, lambda, nullptr);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, h->stream, n, h->cost_partials, h->scalars + scalar_slot);
+    h->prelm_pending = false; h->prelm_valid = true;
+    return 0;
+}
+
 // back-substitution, update, cost and ||dx||^2 with ONE final reduction launch.  `gate` (device
 // status words) makes every kernel a no-op until the CG has flagged convergence.
 int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = false) {
-    h->prelin_valid = false;            // (as apply_update: every tail moves the parameters)
+    h->prelin_valid = h->prelm_valid = false;   // (as apply_update: every tail moves the parameters)
+    h->prelm_pending = false;
     // line-search order (cost AFTER the step): back-substitution, landmark update and pose retraction
     // are one launch when the problem has landmarks (then D == 6)
     const bool fused = linesearch && h->nv > 0 && h->nr > 0 && h->D == 6;
@@ -1140,7 +1209,15 @@ int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = f
     if (!linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 0, gate); }
     if (!fused && apply_update(h, 1.0, gate, true, stamp_in_backsub ? nullptr : hearly, eseq)) return -1;
     if (!stamp_in_backsub && (fused || h->nr == 0)) h->early_armed = false;     // (no kernel carried the word)
-    if (linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 1, gate); }
+    // The cost after the step IS the cost at the next linearisation point: when a successor is expected (option "expect_next")
+    // its landmark pass runs here, gated like the rest of the tail, and sums the cost as it goes -- every observation is
+    // evaluated once instead of twice (C3: the 11-14 us of the cost pass; C4: 75).  Needs every observation in the packed
+    // landmark pass's runs (no observation of a constant point) and the published end of the iteration.
+    const bool lm_cost = fused && publish && h->expect_next && lm_cost_possible(h);
+    if (lm_cost) {
+        ncost = lm_cost_enqueue(h, h->lin_lambda, gate);
+        h->prelm_pending = true;
+    } else if (linesearch) { StageTimer t(h, PS_ST_COST); ncost = cost_partials_pass(h, 1, gate); }
     double* o_cost = h->shard_out ? h->shard_buf : h->scalars + (linesearch ? SC_COST : SC_LINCOST);
     double* o_dxl = h->shard_out ? h->shard_buf + 1 : h->scalars + SC_DXL2;
     hipLaunchKernelGGL(k_reduce3, dim3(3), dim3(256), 0, h->stream,

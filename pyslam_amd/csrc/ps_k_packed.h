@@ -62,21 +62,32 @@ PS_DEV LmwSeg lmw_segment(int v0, int v1, const int32_t* __restrict__ lm_ptr, in
     return s;
 }
 
-template <bool WIDE>
+// COST (round 5): the pass ALSO sums the robust cost of its observations at this linearisation point (ReprojEval::cost, which
+// the evaluation forms anyway) into one partial per workgroup -- the "cost after the step" of an iteration IS the cost at the
+// next iteration's linearisation point, so the tail of an iteration that expects a successor runs the successor's landmark pass
+// in place of its cost pass (gn_tail, ps_host_cg.h): one evaluation of every observation instead of two.  Such a launch is
+// gated like the rest of the tail (`gate`: a no-op until the reduced solve has converged), and a landmark block that is not
+// positive definite is reported through `fail_word` (pinned host memory, stamped with `fail_tag`) instead of the status words:
+// it belongs to the NEXT call's linearisation, whose status the host folds it into (wait_published).
+template <bool WIDE, bool COST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES, 8))) void k_landmark_pass_packed(
     int nwaves, const int32_t* __restrict__ lmw_first, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_point,
     const LObs* __restrict__ lobs, const double* __restrict__ poses,
     const double* __restrict__ points, const int32_t* __restrict__ pose_rid,
     const ObsGroup* __restrict__ groups, double lambda,
     double* __restrict__ Z, double* __restrict__ Cinv, double* __restrict__ cvec,
-    int32_t* __restrict__ status, ObsWide wide)
+    int32_t* __restrict__ status, ObsWide wide,
+    const int32_t* __restrict__ gate = nullptr, double* __restrict__ cost_part = nullptr,
+    long long* __restrict__ fail_word = nullptr, long long fail_tag = 0)
 {
     __shared__ __attribute__((aligned(16))) double zst[4][64 * PS_ZROW];    // sums (64 x 9), then C^-1 per segment, then the Z rows
     __shared__ int32_t flags[4][64];
+    __shared__ double csum[16];
+    if (COST && gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = blockIdx.x * 4 + wv;
-    if (gw >= nwaves) return;
-    const int v0 = lmw_first[gw], v1 = lmw_first[gw + 1];
-    if (v1 <= v0) return;
+    double obs_cost = 0.0;
+    const int v0 = gw < nwaves ? lmw_first[gw] : 0, v1 = gw < nwaves ? lmw_first[gw + 1] : 0;
+    if (v1 > v0) {                                            // (wave-uniform)
     const LmwSeg sg = lmw_segment(v0, v1, lm_ptr, lane, flags[wv]);
     double* sm = zst[wv];
     const int i = sg.row0 + lane;
@@ -93,6 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
         rid_of_obs = pose_rid[pose];
         variable_pose = rid_of_obs >= 0;
         reproj_eval_obs<true, true, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
+        if (COST) obs_cost = ev.cost;
         const double* J = ev.Jl;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -152,7 +164,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
         const double M10 = -l10 * M00 * M11;
         const double M21 = -l21 * M11 * M22;
         const double M20 = -(l20 * M00 + l21 * M10) * M22;
-        if (!(H00 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) atomicAdd(&status[ST_LM_FAIL], 1);
+        if (!(H00 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0)) {
+            if (COST && fail_word) *reinterpret_cast<volatile long long*>(fail_word) = fail_tag;
+            else atomicAdd(&status[ST_LM_FAIL], 1);
+        }
         double* ci = Cinv + 6 * (size_t)sg.v;
         ci[0] = M00; ci[1] = M10; ci[2] = M11; ci[3] = M20; ci[4] = M21; ci[5] = M22;
         double* cv = cvec + 3 * (size_t)sg.v;
@@ -187,6 +202,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_LM_WAVES
     const double2* src = reinterpret_cast<const double2*>(sm);
     double2* out = reinterpret_cast<double2*>(Z + PS_ZROW * (size_t)sg.row0);
     for (int k = lane; k < sg.nrows * (PS_ZROW / 2); k += 64) out[k] = src[k];
+    }
+    if (COST) {                                               // one partial per workgroup, fixed order (lanes, then waves)
+        obs_cost = block_sum(obs_cost, csum);
+        if (threadIdx.x == 0) cost_part[blockIdx.x] = obs_cost;
+    }
+}
+
+// The robust cost alone, in the landmark pass's structure: wave w evaluates the rows of run w, one per lane, a workgroup writes
+// one partial -- the SAME partial sums, bit for bit, as k_landmark_pass_packed<.., true> forms (the cost of an observation is
+// a function of its inputs alone: ps_math.h), so a cost is the same number whichever of the two produced it.
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_cost_packed(
+    int nwaves, const int32_t* __restrict__ lmw_first, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_point,
+    const LObs* __restrict__ lobs, const double* __restrict__ poses, const double* __restrict__ points,
+    const ObsGroup* __restrict__ groups, double* __restrict__ cost_part, const int32_t* __restrict__ gate, ObsWide wide)
+{
+    __shared__ double csum[16];
+    if (gate && gate[ST_PCG_DONE] != 1) return;      // (2 = CG breakdown: the host falls back, nothing is applied)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gw = blockIdx.x * 4 + wv;
+    double c = 0.0;
+    const int v0 = gw < nwaves ? lmw_first[gw] : 0, v1 = gw < nwaves ? lmw_first[gw + 1] : 0;
+    if (v1 > v0) {
+        const int row0 = lm_ptr[v0], nrows = lm_ptr[v1] - row0;
+        if (lane < nrows) {
+            const int i = row0 + lane;
+            const LObs o = lobs[i];
+            const Se3 T = se3_load(poses + 12 * PS_POSE_OF(o));
+            const double pw[3] = {points[3 * (size_t)o.point], points[3 * (size_t)o.point + 1], points[3 * (size_t)o.point + 2]};
+            ReprojEval ev;
+            reproj_eval_obs<false, false, WIDE>(T, pw, &o.u, groups, PS_GRP_OF(o), wide, i, ev);
+            c = ev.cost;
+        }
+    }
+    c = block_sum(c, csum);
+    if (threadIdx.x == 0) cost_part[blockIdx.x] = c;
 }
 
 // back-substitution, the same packing: one Z row per lane, the landmark's three sums by its head lane

@@ -28,7 +28,11 @@ __device__ __forceinline__ double ps_rsqrt(double x) {
 enum { PS_LOSS_L2 = 0, PS_LOSS_L1 = 1, PS_LOSS_CAUCHY = 2, PS_LOSS_HUBER = 3,
        PS_LOSS_TUKEY = 4, PS_LOSS_TDIST = 5 };
 
+// (no contraction into fused multiply-adds here or in the residual chain of reproj_eval_s: the cost of an observation is then a
+//  function of its inputs alone, whichever kernel the compiler inlines it into -- the landmark pass that sums the cost as it
+//  goes and the cost-only pass give the same bits, ps_k_packed.h)
 PS_DEV double ps_loss_rho(int id, double k, double x) {
+#pragma clang fp contract(off)
     const double a = fabs(x);
     switch (id) {
     case PS_LOSS_L2: return 0.5 * x * x;
@@ -328,20 +332,28 @@ struct ReprojEval {
 template <bool WITH_JP, bool WITH_JL>
 PS_DEV void reproj_eval_s(const Se3& T, const double* __restrict__ pw, const double* __restrict__ uvd,
                           const ObsGroup& g, const double* __restrict__ Sv, ReprojEval& o) {
-    double pc[3];
-    se3_apply(T, pw, pc);
-    o.pc[0] = pc[0]; o.pc[1] = pc[1]; o.pc[2] = pc[2];
-    const double iz = 1.0 / pc[2];
-    const double e0 = g.fu * pc[0] * iz + g.cu - uvd[0];
-    const double e1 = g.fv * pc[1] * iz + g.cv - uvd[1];
+    double pc[3], rr[3], iz;
     const bool rgbd = g.cam_type == 1;
-    const double e2 = (rgbd ? pc[2] : g.fu * g.b * iz) - uvd[2];
+    {   // the chain the cost depends on: explicit fused multiply-adds, no contraction left to the compiler (see ps_loss_rho)
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            pc[i] = __builtin_fma(T.R[3 * i + 2], pw[2], __builtin_fma(T.R[3 * i + 1], pw[1], __builtin_fma(T.R[3 * i], pw[0], T.t[i])));
+        iz = 1.0 / pc[2];
+        const double e0 = __builtin_fma(g.fu * pc[0], iz, g.cu - uvd[0]);
+        const double e1 = __builtin_fma(g.fv * pc[1], iz, g.cv - uvd[1]);
+        const double e2 = rgbd ? pc[2] - uvd[2] : __builtin_fma(g.fu * g.b, iz, -uvd[2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rr[i] = __builtin_fma(Sv[3 * i + 2], e2, __builtin_fma(Sv[3 * i + 1], e1, Sv[3 * i] * e0));
+        o.cost = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.cost += ps_loss_rho(g.loss_id, g.loss_k, rr[i]);
+    }
+    o.pc[0] = pc[0]; o.pc[1] = pc[1]; o.pc[2] = pc[2];
     double s[3];
-    o.cost = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double ri = Sv[3 * i] * e0 + Sv[3 * i + 1] * e1 + Sv[3 * i + 2] * e2;
-        o.cost += ps_loss_rho(g.loss_id, g.loss_k, ri);
+        const double ri = rr[i];
         s[i] = ps_loss_sqrt_weight(g.loss_id, g.loss_k, ri);
         o.r[i] = s[i] * ri;
     }

@@ -203,6 +203,12 @@ class DeviceProblem:
         """Further iterations the caller's stopping rule allows if the coming step is non-decreasing (-1: unknown)."""
         nat.check(self._lib.ps_set_option(self._h, b'solve_horizon', float(n)))
 
+    def set_expect_next(self, flag):
+        """The caller's loop will call gn_iteration again after the coming call unless a stopping rule on ||dx|| or the cost
+        fires (what ps_solve tells the core about its own loop): the coming call's tail then runs the NEXT linearisation's
+        landmark pass in place of its cost pass -- one evaluation of every observation instead of two."""
+        nat.check(self._lib.ps_set_option(self._h, b'expect_next', 1.0 if flag else 0.0))
+
     # ---- covariance by columns (reference problem.py:196-216) ------------
     def covariance_begin(self):
         """Linearise at the current parameters and prepare the reduced solver."""

@@ -99,6 +99,8 @@ def device_solve(dev, opt, use_core_loop=True, call_ms=None):
     if hasattr(dev, 'reset_solver_state'):
         dev.reset_solver_state()          # a solve is a function of (parameters, options), not of the handle's history
     horizon = getattr(dev, 'set_solve_horizon', None)
+    expect = getattr(dev, 'set_expect_next', None)
+    last_ratio = 1.
     linesearch = opt.linesearch_max_iters > 0
     lam = getattr(opt, 'lm_lambda', 0.)
     pcg_tol, pcg_max = getattr(opt, 'pcg_tol', 1e-12), getattr(opt, 'pcg_max_iters', 2000)
@@ -112,6 +114,10 @@ def device_solve(dev, opt, use_core_loop=True, call_ms=None):
         prev_cost = cost
         if horizon is not None:
             horizon(solve_horizon(opt, optimization_iters, nondecreasing_steps_taken))
+        if expect is not None:            # the rule ps_solve applies (csrc/ps_abi_solver.h): will another iteration follow?
+            expect(optimization_iters <= opt.max_iters and
+                   (solve_horizon(opt, optimization_iters, nondecreasing_steps_taken) >= 1 if opt.allow_nondecreasing_steps
+                    else (optimization_iters >= 2 and last_ratio < 0.5)))
         # one device call: linearise, solve, update, post-step cost
         t0 = time.perf_counter()
         cost, dx_norm, its, rel = dev.gn_iteration(lam, pcg_tol, pcg_max, linesearch)
@@ -119,6 +125,7 @@ def device_solve(dev, opt, use_core_loop=True, call_ms=None):
             call_ms.append((time.perf_counter() - t0) * 1e3)
         stats.append((its, rel))
         history.append(cost)
+        last_ratio = cost / prev_cost if prev_cost > 0. else 1.
 
         done_optimization = optimization_iters > opt.max_iters or \
             dx_norm < opt.min_update_norm or cost < opt.min_cost
@@ -135,6 +142,8 @@ def device_solve(dev, opt, use_core_loop=True, call_ms=None):
                 dev.restore()
         else:
             done_optimization = done_optimization or cost >= opt.min_cost_decrease * prev_cost
+    if expect is not None:
+        expect(False)
     return history, stats
 
 

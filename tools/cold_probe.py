@@ -23,9 +23,12 @@ for o in opts:
     k, v = o[6:].split(':'); dev.set_option(k, float(v))
 if '--prof' in sys.argv:      # as bench.py's timed region: one event pair around the Schur kernel on every 4th linearisation
     dev.set_option('profile_every', 4); dev.set_profiling(1)
+if '--stages' in sys.argv:    # an event pair around every stage: per solve, the GPU time of each stage summed over its calls
+    dev.set_profiling(2)
 start = (lp.poses.copy(), lp.points.copy())
 opt = bench.example_options()
 tot, its = 0.0, 0
+all_ms, all_dt = [], []
 for s in range(solves + 1):
     dev.reset_solver_state(); dev.set_params(*start); torch.cuda.synchronize()
     ms = []
@@ -34,8 +37,13 @@ for s in range(solves + 1):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) * 1e3
     if s:
-        tot += dt; its += len(ms)
+        tot += dt; its += len(ms); all_ms.append(ms); all_dt.append(dt)
     print('solve %d: %.4f ms, calls %s, pcg %s, outside the calls %.4f ms' % (s, dt, ['%.4f' % m for m in ms], [a for a, _ in stats], dt - sum(ms)))
+    if '--stages' in sys.argv:
+        st = dev.stage_times(reset=True)
+        print('   stages (ms summed over the solve, launches): ' + ', '.join('%s %.4f/%d' % (k, v[0], v[1]) for k, v in st.items() if v[1]))
 print('kf %d lm %d %s loop: %.4f ms per iteration over %d solves (first excluded); cost history %s' % (
     kf, lm, 'core' if core_loop else 'python', tot / its, solves, ['%.6e' % c for c in hist]))
+n_calls = min(len(m) for m in all_ms)
+print('median over the solves: solve %.4f ms, calls %s' % (float(np.median(all_dt)), ['%.4f' % float(np.median([m[k] for m in all_ms])) for k in range(n_calls)]))
 dev.close()

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 CMD="python $PWD/tools/cold_probe.py ${1:-200} ${2:-50000} 4 $3"
 (cd /tmp && rm -rf /tmp/ct && rocprofv3 --kernel-trace --output-format csv -d /tmp/ct -o kt -- $CMD 2> /dev/null | tail -3)
 python - <<'PY'
-import csv, glob
+import csv, glob, os
 f = glob.glob('/tmp/ct/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -34,6 +34,6 @@ for k in range(4):
         gap = (s - prev) / 1e3 if prev else 0.0
         prev = e
         name = r['Kernel_Name'].split('(')[0].replace('void ', '')[:36]
-        if gap > 3.0 or (e - s) > 15000:
+        if gap > 3.0 or (e - s) > 15000 or (k == 0 and os.environ.get('COLD_TRACE_ALL')):
             print('      +%8.1f  gap %5.1f  dur %6.1f  %s' % ((s - s0) / 1e3, gap, (e - s) / 1e3, name))
 PY
