@@ -485,10 +485,13 @@ def main():
     n_pcg_list = cold['pcg_iters']
     n_pcg = int(round(float(np.mean(n_pcg_list)))) if n_pcg_list else 0
     # untimed: one more cold solve with an event pair around every stage, for the breakdown only
+    # (per ITERATION of that solve: a stage that does not run in every iteration -- the cost-only pass since round 5: the cost
+    #  after a step is summed by the next iteration's landmark pass, run in the tail -- is spread over the solve's iterations)
     detail = stage_breakdown(dev, start, fence)
+    n_detail_its = detail.get('iteration_total', (0.0, 0))[1]
     for k, v in detail.items():
         if k != 'schur_pairs' and v[1] > 0:
-            stages[k] = v
+            stages[k] = (v[0], n_detail_its if (n_detail_its > 0 and k != 'iteration_total') else v[1])
     i0 = problem_info(core)
     counted = cold_solves(dev, start, 4, fence, warm_solves=1)
     i1 = problem_info(core)
@@ -552,7 +555,10 @@ def main():
                                             'the final restore'},
             'stage_ms': {k: round(v, 4) for k, v in name_stage_totals(stage_ms).items()},
             'stage_ms_note': 'schur_pairs: hipEvent pair inside the timed region, on every 4th linearisation; the other stages from one '
-                             'more untimed cold solve with an event pair around every stage. stages_sum = GPU time of an iteration (sum of '
+                             'more untimed cold solve with an event pair around every stage, per iteration of that solve. landmark_pass: '
+                             'since round 5 the pass of the NEXT iteration runs in the tail and sums the cost after the step on its way '
+                             '(one evaluation of every observation per iteration); cost = what is left of the cost-only pass (the last '
+                             'iteration of a solve), spread over the iterations. stages_sum = GPU time of an iteration (sum of '
                              'the stage pairs); call_event_pair = the pair around one ps_gn_iteration call, which EXCLUDES a linearisation '
                              'enqueued speculatively behind the previous call (every iteration of a solve but the first)',
             'metric_definition': {'version': 2, 'since_round': 4,

@@ -64,6 +64,9 @@ def run(n_cases, seed0=0, verbose=True):
             dev.set_option('band_part', 0)                    # serial band factorisation of the coarse matrix
         elif rng.integers(3) == 0:
             dev.set_option('band_part_chunk', int(rng.integers(2, 12)))
+        if rng.integers(3) == 0:
+            dev.set_option('fuse_cost', int(rng.integers(0, 3)))   # cost summed by the landmark pass: off / everywhere / tails only
+        dev.set_expect_next(bool(rng.integers(2)))              # the first call's tail runs the second call's landmark pass
         linesearch = bool(rng.integers(2))
         try:
             c0 = dev.eval_cost(True)
