@@ -104,6 +104,9 @@ typedef struct ps_problem_info {
     int64_t ldi_seeds;           /* inverses seeded on the side stream (after a standard solve)                             */
     int64_t xcg_fused_solves;    /* explicit two-level PCG solves set up in the one-launch form (option "xcg_fused")       */
     int64_t xcg_fused_fallbacks; /* ... repeated in the three-launch form after a breakdown of the single-reduction recurrences */
+    int64_t cg_persist_solves;   /* folded CG solves run in ONE launch (option "cg_persist", csrc/ps_k_cg_persist.h)          */
+    int64_t cg_persist_failures; /* ... whose in-launch exchange timed out: solved again with the launch-per-iteration kernels,
+                                    and the one-launch form is not used on the handle any more                              */
 } ps_problem_info;
 
 enum { PS_NUM_STAGES = 12 };

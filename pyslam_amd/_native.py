@@ -55,6 +55,7 @@ class ProblemInfo(C.Structure):
         ('device_bytes', C.c_int64), ('cg_restarts', C.c_int64), ('cg_kernel_launches', C.c_int64),
         ('ldi_solves', C.c_int64), ('ldi_fallbacks', C.c_int64), ('ldi_seeds', C.c_int64),
         ('xcg_fused_solves', C.c_int64), ('xcg_fused_fallbacks', C.c_int64),
+        ('cg_persist_solves', C.c_int64), ('cg_persist_failures', C.c_int64),
     ]
 
 

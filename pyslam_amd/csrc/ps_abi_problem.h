@@ -64,6 +64,15 @@ int ps_warm_up(void) {
 
 int ps_problem_destroy(ps_problem* h) {
     if (!h) return 0;
+    if (h->cp_dbg) {
+        long long c[8]; hipMemcpy(c, h->cp_dbg, 64, hipMemcpyDeviceToHost);
+        int khz = 100000; hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+        fprintf(stderr, "k_cg_persist, workgroup 0, %ld launches, us per launch: recurrences %.2f | sync %.2f | products + publish %.2f | gather %.2f "
+                "(%.1f failed passes) | sync %.2f | dots + sync %.2f\n", h->cp_launches, c[0] * 1e3 / khz / h->cp_launches, c[1] * 1e3 / khz / h->cp_launches,
+                c[2] * 1e3 / khz / h->cp_launches, c[3] * 1e3 / khz / h->cp_launches, (double)c[7] / h->cp_launches, c[4] * 1e3 / khz / h->cp_launches,
+                c[5] * 1e3 / khz / h->cp_launches);
+        hipFree(h->cp_dbg);
+    }
     if (ps_env("PS_HOST_TIMING") && h->host_calls)
         fprintf(stderr, "ps_gn_iteration: %ld calls, %.1f us per call on the host, of which %.1f us waiting for the GPU (%ld waits)\n",
                 h->host_calls, h->host_call_ns * 1e-3 / h->host_calls, h->host_wait_ns * 1e-3 / h->host_calls, h->host_waits);

@@ -12,6 +12,7 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
     info->cg_kernel_launches = h->cg_kernel_launches;
     info->ldi_solves = h->ldi_solves; info->ldi_fallbacks = h->ldi_fallbacks; info->ldi_seeds = h->ldi_seeds;
     info->xcg_fused_solves = h->xf_solves; info->xcg_fused_fallbacks = h->xf_fallbacks;
+    info->cg_persist_solves = h->cp_launches; info->cg_persist_failures = h->cp_failures;
     return 0;
 }
 
@@ -737,6 +738,8 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "coarse_refresh_every") { if (value < 1 || value > 16) return fail("coarse_refresh_every must be 1..16"); h->xcg_refresh_every = (int)value; }
     else if (n == "coarse_lag_x") { h->lagx = value != 0.0; h->lci_next = -1; h->side_todo = false; }
     else if (n == "cg_lds") h->cg_lds = value != 0.0;
+    else if (n == "cg_persist") h->cg_persist = value != 0.0;
+    else if (n == "cg_persist_spin") { if (value < 0 || value > 1e7) return fail("cg_persist_spin out of range"); h->cp_spin = (unsigned)value; }
     else if (n == "cg_explicit") { h->explicit_ok = value != 0.0; h->coarse_built = false; }
     else if (n == "big_chol") h->big_chol = value != 0.0;
     else if (n == "fused_motion_only") h->mo_fused = value != 0.0;

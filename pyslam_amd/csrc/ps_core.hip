@@ -306,6 +306,16 @@ struct ps_problem {
     size_t xf_nrec = 0;
     long xf_solves = 0, xf_fallbacks = 0;
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
+    // the folded CG in ONE launch (ps_k_cg_persist.h): option "cg_persist"; task table built with the coarse level
+    int cg_persist = 1;
+    bool cp_ok = false;             // the augmented system fits the kernel's layout
+    int cp_ntasks = 0, cg_max_launches = 0;
+    void* cp_tasks = nullptr;       // CpTask[cp_ntasks]
+    int32_t* cp_row_task0 = nullptr;
+    unsigned long long* cp_exch = nullptr;
+    unsigned cp_salt = 0, cp_spin = 200000;   // option "cg_persist_spin": passes over the exchange before a workgroup gives up
+    long cp_launches = 0, cp_failures = 0;
+    long long* cp_dbg = nullptr;    // measurement build, PS_CP_CLOCKS: phase clocks of the kernel's first workgroup
     int prof_every = 1;             // profiling level 1: time the Schur kernel of every n-th linearisation only
     long prof_tick = 0;
     int prev_pcg_iters = -1;        // iteration count of the solve before the last one (launch-count prediction)

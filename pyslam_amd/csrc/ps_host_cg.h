@@ -100,6 +100,9 @@ int wait_published(ps_problem* h) {
             // a landmark block that was not positive definite in the landmark pass the previous tail ran for THIS call's
             // linearisation (k_landmark_pass_packed<.., COST> reports through a word of its own)
             if (h->lmfail_check && *reinterpret_cast<volatile long long*>(h->h_lmfail) == h->lmfail_check) h->h_status[ST_LM_FAIL] += 1;
+            // an exchange of the one-launch CG timed out (a breakdown as far as the caller is concerned: it solves again with the
+            // launch-per-iteration kernels): not used on this handle any more
+            if (h->h_status[ST_PERSIST_FAIL] && h->cg_persist) { h->cg_persist = 0; ++h->cp_failures; }
             if (h->start_cost_pending) {                     // ps_solve's first iteration: the start cost rode in front of it --
                 h->start_cost_pending = false;               // from here on the call knows it, as if ps_eval_cost had run first
                 h->last_cost = h->ldi_call_start_cost = h->h_scalars[SC_STARTCOST];
@@ -399,6 +402,29 @@ int build_coarse(ps_problem* h) {
         h->upload(&h->run_hi, rhi))) || h->upload(&h->arow_ptr, arp) || h->upload(&h->acol_idx, aci) ||
         h->upload(&h->aug_slot, slot) || h->upload(&h->fine_nnz, fnz)) return -1;
     lap("uploads");
+    // one-launch folded CG (ps_k_cg_persist.h): every block row of the augmented matrix cut into tasks of at most PS_CP_TASKB
+    // blocks, one wave each; the vectors replicated in every workgroup (n <= PS_CP_MAXN)
+    h->cp_ok = false;
+    if (D == 6 && !h->cg_explicit && !split && (long)(nr + ncb) * D <= PS_CP_MAXN) {
+        const int rows = nr + ncb;
+        std::vector<CpTask> tasks;
+        std::vector<int32_t> rt0(rows + 1, 0);
+        for (int i = 0; i < rows; ++i) {
+            rt0[i] = (int32_t)tasks.size();
+            const int w = arp[i + 1] - arp[i], nt = std::max(1, cdiv(w, PS_CP_TASKB)), per = cdiv(w, nt);
+            for (int k = 0; k < nt; ++k) tasks.push_back(CpTask{i, arp[i] + k * per, std::min(arp[i + 1], arp[i] + (k + 1) * per), 0});
+        }
+        rt0[rows] = (int32_t)tasks.size();
+        // (all workgroups must be resident at once: a quarter of the chip at most)
+        if ((int)tasks.size() <= 64 * (PS_CP_NT / 64) && (long)tasks.size() * D <= (long)PS_CP_NE * PS_CP_NT) {
+            CpTask* dt = nullptr;
+            if (h->upload(&dt, tasks) || h->upload(&h->cp_row_task0, rt0) ||
+                h->alloc(&h->cp_exch, (size_t)4 * tasks.size() * D)) return -1;
+            h->cp_tasks = dt;
+            HIP_OK(hipMemsetAsync(h->cp_exch, 0, (size_t)4 * tasks.size() * D * sizeof(unsigned long long), h->stream));
+            h->cp_ntasks = (int)tasks.size(); h->cp_salt = 0; h->cp_ok = true;
+        }
+    }
     if (h->alloc(&h->BSZ, (h->cg_explicit ? eq.size() : (size_t)nr * ncb) * D * D) || h->alloc(&h->Bmat2[0], (size_t)nr * D * D) ||
         h->alloc(&h->bgv, (size_t)nr * D) || h->alloc(&h->SB, (size_t)aci.size() * D * D)) return -1;
     h->Bmat = h->Bmat2[0];
@@ -643,6 +669,7 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
     const int nr = h->nr, cap = h->hist_cap;
     if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
     if (!h->coarse_built && build_coarse(h)) return -1;
+    h->cg_max_launches = max_iters + 2;
     h->cg_two_level_reduce = h->nr_aug > 2048 || h->cg_split;
     h->cg_short_rows = (long)h->nnzb_aug <= 24L * h->nr_aug;       // pose-graph-like rows: one wave per row
     const int G = h->G, rows = h->nr_aug;
@@ -791,6 +818,24 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
     const int rows = h->cg_split ? h->nr : h->nr_aug;      // matrix rows handled by k_cg_fused
     const int ncbs = h->cg_split ? h->ncb : 0;
     const double tol2 = tol * tol;
+    // the whole solve in ONE launch (ps_k_cg_persist.h) when the system fits its layout: every launch the budget still allows
+    // (it stops at convergence by itself), from a fresh set-up only
+#ifdef PS_MEASURE
+    if (ps_env("PS_CP_CLOCKS") && !h->cp_dbg) { hipMalloc(&h->cp_dbg, 64); hipMemset(h->cp_dbg, 0, 64); }
+#endif
+    if (h->cg_persist && h->cp_ok && h->G > 0 && h->cg_lds && !h->cg_short_rows && !h->cg_split && !h->cg_two_level_reduce &&
+        !h->cg_ablate && h->cg_launched == 0 && h->cg_max_launches > 0 && h->cg_max_launches <= 4090) {
+        const int nl = h->cg_max_launches;
+        if (++h->cp_salt >= (1u << 20)) {                    // (tags are salt * 4096 + iteration: start over on a cleared buffer)
+            hipMemsetAsync(h->cp_exch, 0, (size_t)4 * h->cp_ntasks * D * sizeof(unsigned long long), h->stream);
+            h->cp_salt = 1;
+        }
+        hipLaunchKernelGGL(k_cg_persist<D>, dim3(cdiv(h->cp_ntasks, PS_CP_NT / 64)), dim3(PS_CP_NT), 0, h->stream, h->nr_aug * D, h->cp_ntasks,
+                           (const CpTask*)h->cp_tasks, h->cp_row_task0, h->acol_idx, h->Saug, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p,
+                           h->cg_xh, h->hist, cap, nl, tol2, h->status, h->scalars, h->cp_exch, h->cp_salt, h->cp_spin, h->cp_dbg);
+        h->cg_launched = nl; h->cg_kernel_launches += 1; ++h->cp_launches;
+        return;
+    }
     h->cg_kernel_launches += count;
     for (int i = 0; i < count; ++i, ++h->cg_launched) {
         const int n = h->cg_launched, o = n & 1, nw = o ^ 1;
@@ -885,6 +930,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
             HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_OK(hipStreamSynchronize(h->stream));
+            if (h->h_status[ST_PERSIST_FAIL] && h->cg_persist) { h->cg_persist = 0; ++h->cp_failures; }
             done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 2;
             chunk = h->pcg_chunk;
         }

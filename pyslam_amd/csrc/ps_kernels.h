@@ -37,7 +37,7 @@ struct FactorGroup { double S[36]; int32_t loss_id; int32_t pad; double loss_k; 
 #define PS_GRP_OF(o) (((uint32_t)(o).pose_grp) >> 24)
 
 // status words
-enum { ST_LM_FAIL = 0, ST_DIAG_FAIL = 1, ST_PCG_DONE = 2, ST_PCG_ITERS = 3, ST_NWORDS = 8 };
+enum { ST_LM_FAIL = 0, ST_DIAG_FAIL = 1, ST_PCG_DONE = 2, ST_PCG_ITERS = 3, ST_PERSIST_FAIL = 4 /* k_cg_persist: an exchange timed out */, ST_NWORDS = 8 };
 // scalar slots
 enum { SC_COST = 0, SC_DXP2 = 1, SC_LINCOST = 2, SC_RR0 = 3, SC_RRFINAL = 4, SC_THRESH = 5, SC_DXL2 = 6, SC_STARTCOST = 7, SC_NWORDS = 8 };
 
@@ -100,6 +100,7 @@ PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
 #include "ps_k_pcg_classic.h"
 #include "ps_k_ldi.h"
 #include "ps_k_cg_fused.h"
+#include "ps_k_cg_persist.h"
 #include "ps_k_xcg.h"
 #include "ps_k_coarse.h"
 #include "ps_k_band.h"

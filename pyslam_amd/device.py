@@ -316,6 +316,13 @@ class DeviceProblem:
         nat.check(self._lib.ps_get_info(self._h, C.byref(info)))
         return int(info.cg_kernel_launches)
 
+    def cg_persist_counts(self):
+        """(folded CG solves run in one launch, of which timed out and were solved again launch by launch) --
+        ps_problem_info.cg_persist_solves / cg_persist_failures (csrc/ps_k_cg_persist.h)."""
+        info = nat.ProblemInfo()
+        nat.check(self._lib.ps_get_info(self._h, C.byref(info)))
+        return int(info.cg_persist_solves), int(info.cg_persist_failures)
+
     def set_option(self, name, value):
         nat.check(self._lib.ps_set_option(self._h, name.encode(), float(value)))
 
