@@ -568,24 +568,49 @@ def main():
             'iteration_algorithmic_GBps': round(b_iter / (ms_per_step * 1e-3) / 1e9, 2),
             'roofline': schur_roofline(info, sch, pmc_config(cfg), n_pcg),
         }
-        # the kernel with the largest TOTAL time per iteration next to the largest single launch: the reduced solve's launches
+        # the kernel with the largest TOTAL time per iteration next to the largest single launch: the reduced solve
         pcg_ms = stage_ms.get('pcg', 0.0)
-        line['roofline_aggregate'] = {
-            'kernels': 'reduced solve (two-level CG, one launch per iteration)', 'launches_per_iteration': round(n_launch, 2),
-            'total_ms_per_iteration': round(pcg_ms, 5), 'avg_launch_us': round(1e3 * pcg_ms / max(n_launch, 1), 3),
-            'algorithmic_bytes_per_launch': int(b_spmv),
-            'achieved_GBps': round(b_spmv * n_launch / max(pcg_ms * 1e-3, 1e-12) / 1e9, 1), 'peak': HBM_PEAK_GBS,
-            'frac': round(b_spmv * n_launch / max(pcg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
-            'bound': 'latency (dependent launches; DESIGN.md section 5), not bandwidth',
-            'note': 'bytes per launch = one pass over S (288 B per block) + three vectors'}
-        # the same figure in the shape of `roofline`: the kernel with the largest TOTAL time per iteration (the single-launch CG)
-        cg_traffic, cg_sha, _ = pmc_traffic('k_cg_fused_lds', pmc_config(cfg))
-        line['roofline_largest_total'] = {
-            'bound': 'hbm', 'kernel': 'k_cg_fused_lds (x {:.1f} launches per iteration)'.format(n_launch),
-            'achieved': line['roofline_aggregate']['achieved_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': line['roofline_aggregate']['frac'], 'traffic': cg_traffic, 'traffic_source_sha': cg_sha,
-            'algorithmic_bytes_per_launch': int(b_spmv), 'avg_launch_ms': round(pcg_ms / max(n_launch, 1), 6),
-            'note': 'latency-bound (one dependent memory round trip per launch), not bandwidth-bound: DESIGN.md section 5'}
+        persist = i1.get('cg_persist_solves', 0) > i0.get('cg_persist_solves', 0)
+        if persist:
+            # round 5: the folded CG runs in ONE launch (csrc/ps_k_cg_persist.h): the matrix is read once into registers, every
+            # CG iteration inside costs one exchange over the fabric -- bytes per launch = the augmented matrix once + the
+            # exchanged sums of every iteration as every workgroup reads them
+            passes = n_pcg + 1
+            line['roofline_aggregate'] = {
+                'kernels': 'reduced solve: set-up kernels + the two-level CG in ONE launch (k_cg_persist) + recovery',
+                'launches_per_iteration': round(n_launch, 2), 'cg_iterations_per_launch': passes,
+                'total_ms_per_iteration': round(pcg_ms, 5),
+                'bound': 'latency: one exchange over the fabric per CG iteration (write-through store + load, 2.0-2.7 us: '
+                         'tools/probes/allgather_probe.hip), not bandwidth',
+                'note': 'the stage pair spans the set-up kernels, the CG launch and the recovery'}
+            cg_traffic, cg_sha, _ = pmc_traffic('k_cg_persist', pmc_config(cfg))
+            line['roofline_largest_total'] = {
+                'bound': 'hbm', 'kernel': 'k_cg_persist (one launch per Gauss-Newton iteration, {} CG iterations inside)'.format(passes),
+                'achieved': round(b_spmv / max(pcg_ms * 1e-3, 1e-12) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(b_spmv / max(pcg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                'traffic': cg_traffic, 'traffic_source_sha': cg_sha, 'algorithmic_bytes_per_launch': int(b_spmv),
+                'avg_launch_ms': round(pcg_ms, 6),
+                'avg_launch_ms_note': 'the event pair of the whole reduced-solve stage (set-up kernels + this launch + recovery); the '
+                                      'kernel alone: profiles/ kernel stats',
+                'note': 'latency-bound: the matrix is read ONCE into registers (the algorithmic bytes), then every CG iteration waits for '
+                        'one exchange of its sums between the workgroups over the fabric. DESIGN.md section 5'}
+        else:
+            line['roofline_aggregate'] = {
+                'kernels': 'reduced solve (two-level CG, one launch per iteration)', 'launches_per_iteration': round(n_launch, 2),
+                'total_ms_per_iteration': round(pcg_ms, 5), 'avg_launch_us': round(1e3 * pcg_ms / max(n_launch, 1), 3),
+                'algorithmic_bytes_per_launch': int(b_spmv),
+                'achieved_GBps': round(b_spmv * n_launch / max(pcg_ms * 1e-3, 1e-12) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                'frac': round(b_spmv * n_launch / max(pcg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                'bound': 'latency (dependent launches; DESIGN.md section 5), not bandwidth',
+                'note': 'bytes per launch = one pass over S (288 B per block) + three vectors'}
+            # the same figure in the shape of `roofline`: the kernel with the largest TOTAL time per iteration (the single-launch CG)
+            cg_traffic, cg_sha, _ = pmc_traffic('k_cg_fused_lds', pmc_config(cfg))
+            line['roofline_largest_total'] = {
+                'bound': 'hbm', 'kernel': 'k_cg_fused_lds (x {:.1f} launches per iteration)'.format(n_launch),
+                'achieved': line['roofline_aggregate']['achieved_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': line['roofline_aggregate']['frac'], 'traffic': cg_traffic, 'traffic_source_sha': cg_sha,
+                'algorithmic_bytes_per_launch': int(b_spmv), 'avg_launch_ms': round(pcg_ms / max(n_launch, 1), 6),
+                'note': 'latency-bound (one dependent memory round trip per launch), not bandwidth-bound: DESIGN.md section 5'}
         line['lagged_inverse'] = {k: i1[k] for k in ('ldi_solves', 'ldi_fallbacks', 'ldi_seeds')}
         if steady is not None:
             line['steady_same_point_ms'] = round(steady[0], 4)

@@ -309,6 +309,7 @@ struct ps_problem {
     // the folded CG in ONE launch (ps_k_cg_persist.h): option "cg_persist"; task table built with the coarse level
     int cg_persist = 1;
     bool cp_ok = false;             // the augmented system fits the kernel's layout
+    bool cp_recovered = false;      // the launch just enqueued recovers x itself when it converges
     int cp_ntasks = 0, cg_max_launches = 0;
     void* cp_tasks = nullptr;       // CpTask[cp_ntasks]
     int32_t* cp_row_task0 = nullptr;

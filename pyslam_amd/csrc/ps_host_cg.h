@@ -670,6 +670,7 @@ int cg_fused_setup(ps_problem* h, int max_iters, bool allow_lag = false, bool rh
     if (max_iters + 2 > cap) return fail("pcg max_iters exceeds the history buffer (4096)");
     if (!h->coarse_built && build_coarse(h)) return -1;
     h->cg_max_launches = max_iters + 2;
+    h->cp_recovered = false;
     h->cg_two_level_reduce = h->nr_aug > 2048 || h->cg_split;
     h->cg_short_rows = (long)h->nnzb_aug <= 24L * h->nr_aug;       // pose-graph-like rows: one wave per row
     const int G = h->G, rows = h->nr_aug;
@@ -832,8 +833,10 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
         }
         hipLaunchKernelGGL(k_cg_persist<D>, dim3(cdiv(h->cp_ntasks, PS_CP_NT / 64)), dim3(PS_CP_NT), 0, h->stream, h->nr_aug * D, h->cp_ntasks,
                            (const CpTask*)h->cp_tasks, h->cp_row_task0, h->acol_idx, h->Saug, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p,
-                           h->cg_xh, h->hist, cap, nl, tol2, h->status, h->scalars, h->cp_exch, h->cp_salt, h->cp_spin, h->cp_dbg);
+                           h->cg_xh, h->hist, cap, nl, tol2, h->status, h->scalars, h->cp_exch, h->cp_salt, h->cp_spin, h->cp_dbg,
+                           CpRecover{h->nr, h->ncb, h->pnode, h->pw0, h->pw1, h->Linv, h->Lci2[h->lci_cur], h->Bmat, h->x});
         h->cg_launched = nl; h->cg_kernel_launches += 1; ++h->cp_launches;
+        h->cp_recovered = true;                               // (a converged solve leaves x behind: the gated k_coarse_recover is not needed)
         return;
     }
     h->cg_kernel_launches += count;
@@ -873,6 +876,10 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
 template <int D>
 void cg_fused_recover(ps_problem* h, const int32_t* gate) {
     const int nr = h->nr;
+    // the one-launch CG recovers x itself when it converges -- exactly when a GATED recovery would run; an ungated one (the
+    // step taken at max_iters, a restart's partial iterate) still runs here
+    if (gate && h->cp_recovered) { h->cp_recovered = false; return; }
+    h->cp_recovered = false;
     if (h->G)
         hipLaunchKernelGGL(k_coarse_recover<D>, dim3(cdiv((long)nr * D, 256)), dim3(256), 0, h->stream, nr, h->ncb,
                            h->pnode, h->pw0, h->pw1, h->Linv, h->Lci2[h->lci_cur], h->cg_xh, h->x, gate, h->Bmat);

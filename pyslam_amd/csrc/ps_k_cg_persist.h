@@ -31,6 +31,9 @@
 #define PS_CP_MAXN (PS_CP_NV * PS_CP_NT)
 
 struct CpTask { int32_t row, b0, b1, pad; };
+// what k_coarse_recover needs: x = L^-T (x^_f + P y), y = L_c^-T x^_c -- done by the kernel's first workgroup once the solve has
+// converged (x == NULL: not done here)
+struct CpRecover { int nr, ncb; const int32_t* pnode; const double *pw0, *pw1, *Linv, *Lci, *Bmat; double* x; };
 
 typedef unsigned long long ps_u64;
 typedef __attribute__((address_space(1))) ps_u64 ps_gu64;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
     double* __restrict__ hist, int cap, int nlaunch /* iterations k = -1 .. nlaunch - 2 at most */, double tol2,
     int32_t* __restrict__ status, double* __restrict__ scalars,
     ps_u64* __restrict__ exch /* 2 x (ntasks * D) doubles as two granules each */, unsigned salt, unsigned spin_limit,
-    long long* __restrict__ dbg /* measurement build: phase clocks of workgroup 0 (8 words), else NULL */)
+    long long* __restrict__ dbg /* measurement build: phase clocks of workgroup 0 (8 words), else NULL */, CpRecover rec)
 {
     constexpr int DD = D * D;
     __shared__ double rn[PS_CP_MAXN];
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
     // (1 / gamma_prev and 1 / alpha_prev are formed while the exchange is in flight: ONE division between an iteration's dot
     //  products and its recurrences -- the per-launch kernels do three, which changes the last bits of alpha and beta, not more)
     double gamma = 0.0, delta = 0.0, inv_gprev = 0.0, inv_aprev = 0.0, thresh = 0.0;
+    bool converged = false;
     long long ck[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PS_CP_CLK(i) do { if (dbg) { const long long now_ = wall_clock64(); ck[i] += now_ - last_; last_ = now_; } } while (0)
     long long last_ = dbg ? wall_clock64() : 0;
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
             if (k == 0) thresh = tol2 * gamma;
             if (!(gamma > thresh)) {                         // converged (gamma == 0 too); NaN = breakdown
                 if (chief) { status[ST_PCG_DONE] = (gamma != gamma) ? 2 : 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
+                converged = !(gamma != gamma);
                 break;
             }
             beta = (k == 0) ? 0.0 : gamma * inv_gprev;
@@ -217,6 +222,38 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
 #undef PS_CP_CLK
     // ---- what the recovery reads (x^) and what a caller that looks at the state finds: written by the first workgroup
     if (blockIdx.x == 0) {
+        if (converged && rec.x) {                            // the recovery of k_coarse_recover, on x^ as this workgroup holds it
+            const int nc = rec.ncb * D, nf = rec.nr * D;
+            __syncthreads();                                 // (every wave has left the loop: rn, wex are free)
+#pragma unroll
+            for (int v = 0; v < PS_CP_NV; ++v) { const int i = t + v * PS_CP_NT; if (i < n) rn[i] = vx[v]; }
+            __syncthreads();
+            const double* xc = rn + nf;
+            for (int base = 0; base < nc; base += PS_CP_NT / 8) {
+                const int kq = base + t / 8, sub = t & 7;
+                double v = 0.0;
+                if (kq < nc) for (int m = kq + sub; m < nc; m += 8) v += rec.Lci[(size_t)m * nc + kq] * xc[m];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                if (kq < nc && sub == 0) wex[kq] = v;
+            }
+            __syncthreads();
+            for (int e = t; e < nf; e += PS_CP_NT) {
+                const int i = e / D, c = e - i * D, q = rec.pnode[i];
+                const double w0 = rec.pw0[i], w1 = rec.pw1[i];
+                double z[D];
+#pragma unroll
+                for (int m = 0; m < D; ++m) z[m] = w0 * wex[q * D + m] + ((q + 1 < rec.ncb) ? w1 * wex[(q + 1) * D + m] : 0.0);
+                double v = 0.0;
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    double xhat = rn[i * D + a];
+#pragma unroll
+                    for (int m = 0; m < D; ++m) xhat += rec.Bmat[(size_t)i * DD + a * D + m] * z[m];
+                    v += rec.Linv[(size_t)i * DD + a * D + c] * xhat;
+                }
+                rec.x[e] = v;
+            }
+        }
 #pragma unroll
         for (int v = 0; v < PS_CP_NV; ++v) {
             const int i = t + v * PS_CP_NT;
