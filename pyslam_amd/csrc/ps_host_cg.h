@@ -405,7 +405,7 @@ int build_coarse(ps_problem* h) {
     // one-launch folded CG (ps_k_cg_persist.h): every block row of the augmented matrix cut into tasks of at most PS_CP_TASKB
     // blocks, one wave each; the vectors replicated in every workgroup (n <= PS_CP_MAXN)
     h->cp_ok = false;
-    if (D == 6 && !h->cg_explicit && !split && (long)(nr + ncb) * D <= PS_CP_MAXN) {
+    if (!h->cg_explicit && !split && (long)(nr + ncb) * D <= PS_CP_MAXN) {
         const int rows = nr + ncb;
         std::vector<CpTask> tasks;
         std::vector<int32_t> rt0(rows + 1, 0);
@@ -824,7 +824,7 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
 #ifdef PS_MEASURE
     if (ps_env("PS_CP_CLOCKS") && !h->cp_dbg) { hipMalloc(&h->cp_dbg, 64); hipMemset(h->cp_dbg, 0, 64); }
 #endif
-    if (h->cg_persist && h->cp_ok && h->G > 0 && h->cg_lds && !h->cg_short_rows && !h->cg_split && !h->cg_two_level_reduce &&
+    if (h->cg_persist && h->cp_ok && h->G > 0 && h->cg_lds && !h->cg_split && !h->cg_two_level_reduce &&
         !h->cg_ablate && h->cg_launched == 0 && h->cg_max_launches > 0 && h->cg_max_launches <= 4090) {
         const int nl = h->cg_max_launches;
         if (++h->cp_salt >= (1u << 20)) {                    // (tags are salt * 4096 + iteration: start over on a cleared buffer)

@@ -26,7 +26,7 @@
 #define PS_CP_NT 512                    // threads per workgroup (8 waves = 8 tasks)
 #define PS_CP_NQ 6                      // blocks per lane slot: a task has at most 8 * PS_CP_NQ blocks
 #define PS_CP_TASKB (8 * PS_CP_NQ)
-#define PS_CP_NV 3                      // vector entries per thread: n <= PS_CP_NV * PS_CP_NT
+#define PS_CP_NV 4                      // vector entries per thread: n <= PS_CP_NV * PS_CP_NT
 #define PS_CP_NE 6                      // exchanged sums per thread: tasks * D <= PS_CP_NE * PS_CP_NT
 #define PS_CP_MAXN (PS_CP_NV * PS_CP_NT)
 
