@@ -332,6 +332,21 @@ int ps_debug_table_checksums(ps_problem* h, uint64_t* out, int capacity, int* co
      "solve_horizon"      [-1 unknown] how many more whole-iteration calls the caller's stopping rule allows if the step about to be
                               taken turns out non-decreasing (reference problem.py:163-178); side work that pays back only over
                               several later calls (the lagged inverse's seed) is not started with fewer than three to come
+     "expect_next"        [0] the caller will ask for another whole iteration after the coming one unless a stopping rule on ||dx|| or
+                              the cost fires (ps_solve sets it for its own loop): with "fuse_cost" the coming call's tail runs the NEXT
+                              iteration's landmark pass in place of its cost pass -- every observation evaluated once per iteration;
+                              the next call's linearisation takes the pass over if the parameters have not moved since.  Does not
+                              invalidate what was computed ahead (every other option does)
+     "fuse_cost"          [1] the cost of all blocks summed by the packed landmark pass itself (tails that expect a successor, the start
+                              cost of ps_solve, ps_eval_cost) or by a cost-only pass in the same structure: the same number bit for bit;
+                              2: in the tails only; 0: the grid-stride cost pass of rounds 1-4 everywhere (another summation order).
+                              Needs every observation on a variable landmark with at most 16 observations, else 0 is what runs
+     "cg_persist"         [1] the folded two-level CG in ONE launch (csrc/ps_k_cg_persist.h) where the augmented system fits (<= 2 048
+                              unknowns, <= 512 tasks); 0: one launch per CG iteration.  "cg_persist_spin" [200000]: passes over the
+                              in-launch exchange before a workgroup gives up (then the solve is repeated launch by launch and the
+                              form is not used on the handle any more: ps_problem_info.cg_persist_failures)
+     "lm_packed" [1], "band_part" [1], "band_part_chunk" [0 auto], "sync_refactor" [1], "hold_across_steps" [1]: round-5 kernels and
+                              schedules against their predecessors (DESIGN.md sections 0 and 3)
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual
      "cg_lds", "profile_every", "big_chol", "cg_margin", "pcg_chunk", "cg_split_min_rows", "cg_explicit_min_rows": implementation switches (see ps_set_option in csrc/ps_abi_solver.h)
      "cg_ablate", "schur_ablate", "lm_ablate": timing experiments only (results are wrong under ablation) */

@@ -29,6 +29,9 @@
 #define PS_CP_NV 4                      // vector entries per thread: n <= PS_CP_NV * PS_CP_NT
 #define PS_CP_NE 6                      // exchanged sums per thread: tasks * D <= PS_CP_NE * PS_CP_NT
 #define PS_CP_MAXN (PS_CP_NV * PS_CP_NT)
+#ifndef PS_CP_SLEEP
+#define PS_CP_SLEEP 1                   // s_sleep argument between two unsuccessful passes over the exchange (0: none)
+#endif
 
 struct CpTask { int32_t row, b0, b1, pad; };
 // what k_coarse_recover needs: x = L^-T (x^_f + P y), y = L_c^-T x^_c -- done by the kernel's first workgroup once the solve has
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
                 ok = __all(ok);
                 if (!ok) {
                     if (spins > spin_limit) { bad = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    if (PS_CP_SLEEP) __builtin_amdgcn_s_sleep(PS_CP_SLEEP);
                     ck[7] += 1;
                 }
             }
