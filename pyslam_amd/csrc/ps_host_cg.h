@@ -416,7 +416,7 @@ int build_coarse(ps_problem* h) {
         }
         rt0[rows] = (int32_t)tasks.size();
         // (all workgroups must be resident at once: a quarter of the chip at most)
-        if ((int)tasks.size() <= 64 * (PS_CP_NT / 64) && (long)tasks.size() * D <= (long)PS_CP_NE * PS_CP_NT) {
+        if ((int)tasks.size() <= 128 * (PS_CP_NT / 64) && (long)tasks.size() * D <= (long)PS_CP_NE_MAX * PS_CP_NT) {
             CpTask* dt = nullptr;
             if (h->upload(&dt, tasks) || h->upload(&h->cp_row_task0, rt0) ||
                 h->alloc(&h->cp_exch, (size_t)4 * tasks.size() * D)) return -1;
@@ -831,10 +831,13 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
             hipMemsetAsync(h->cp_exch, 0, (size_t)4 * h->cp_ntasks * D * sizeof(unsigned long long), h->stream);
             h->cp_salt = 1;
         }
-        hipLaunchKernelGGL(k_cg_persist<D>, dim3(cdiv(h->cp_ntasks, PS_CP_NT / 64)), dim3(PS_CP_NT), 0, h->stream, h->nr_aug * D, h->cp_ntasks,
-                           (const CpTask*)h->cp_tasks, h->cp_row_task0, h->acol_idx, h->Saug, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p,
-                           h->cg_xh, h->hist, cap, nl, tol2, h->status, h->scalars, h->cp_exch, h->cp_salt, h->cp_spin, h->cp_dbg,
-                           CpRecover{h->nr, h->ncb, h->pnode, h->pw0, h->pw1, h->Linv, h->Lci2[h->lci_cur], h->Bmat, h->x});
+#define PS_CP_LAUNCH(NE) hipLaunchKernelGGL((k_cg_persist<D, NE>), dim3(cdiv(h->cp_ntasks, PS_CP_NT / 64)), dim3(PS_CP_NT), 0, h->stream, h->nr_aug * D, \
+                           h->cp_ntasks, (const CpTask*)h->cp_tasks, h->cp_row_task0, h->acol_idx, h->Saug, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, \
+                           h->cg_xh, h->hist, cap, nl, tol2, h->status, h->scalars, h->cp_exch, h->cp_salt, h->cp_spin, h->cp_dbg,                  \
+                           CpRecover{h->nr, h->ncb, h->pnode, h->pw0, h->pw1, h->Linv, h->Lci2[h->lci_cur], h->Bmat, h->x})
+        // (two instantiations by the number of exchanged sums per thread: the small one keeps 40 registers and 24 KB of LDS free)
+        if ((long)h->cp_ntasks * D <= 6L * PS_CP_NT) PS_CP_LAUNCH(6); else PS_CP_LAUNCH(12);
+#undef PS_CP_LAUNCH
         h->cg_launched = nl; h->cg_kernel_launches += 1; ++h->cp_launches;
         h->cp_recovered = true;                               // (a converged solve leaves x behind: the gated k_coarse_recover is not needed)
         return;

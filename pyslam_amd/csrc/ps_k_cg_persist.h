@@ -27,7 +27,7 @@
 #define PS_CP_NQ 6                      // blocks per lane slot: a task has at most 8 * PS_CP_NQ blocks
 #define PS_CP_TASKB (8 * PS_CP_NQ)
 #define PS_CP_NV 4                      // vector entries per thread: n <= PS_CP_NV * PS_CP_NT
-#define PS_CP_NE 6                      // exchanged sums per thread: tasks * D <= PS_CP_NE * PS_CP_NT
+#define PS_CP_NE_MAX 12                 // exchanged sums per thread (template NE: 6 or 12): tasks * D <= NE * PS_CP_NT
 #define PS_CP_MAXN (PS_CP_NV * PS_CP_NT)
 #ifndef PS_CP_SLEEP
 #define PS_CP_SLEEP 1                   // s_sleep argument between two unsuccessful passes over the exchange (0: none)
@@ -47,7 +47,7 @@ PS_DEV void cp_put(ps_u64* g, unsigned tag, double v) {
     __hip_atomic_store((ps_gu64*)(g + 1), ((ps_u64)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int D>
+template <int D, int NE>
 __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
     int n /* augmented unknowns */, int ntasks, const CpTask* __restrict__ tasks,
     const int32_t* __restrict__ row_task0 /* first task of every block row; [rows] = ntasks */,
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
 {
     constexpr int DD = D * D;
     __shared__ double rn[PS_CP_MAXN];
-    __shared__ double wex[PS_CP_NE * PS_CP_NT];              // the exchanged sums of one iteration
+    __shared__ double wex[NE * PS_CP_NT];              // the exchanged sums of one iteration
     __shared__ double red[2][2][PS_CP_NT / 64];
     __shared__ int bad;
     const int t = threadIdx.x, wv = t >> 6, lane = t & 63, kk = lane >> 3, r = lane & 7;
@@ -170,12 +170,12 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
         // ---- gather every published sum (flat: the loads of a pass are independent, one round trip), then w_new of every entry
         // = the sum of its row's tasks, in task order, from LDS
         {
-            double gv[PS_CP_NE];
+            double gv[NE];
             bool ok = false;
             for (unsigned spins = 0; !ok; ++spins) {
                 ok = true;
 #pragma unroll
-                for (int v = 0; v < PS_CP_NE; ++v) {
+                for (int v = 0; v < NE; ++v) {
                     const int j = t + v * PS_CP_NT;
                     gv[v] = 0.0;
                     if (j < (int)nex) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
                 }
             }
 #pragma unroll
-            for (int v = 0; v < PS_CP_NE; ++v) { const int j = t + v * PS_CP_NT; if (j < (int)nex) wex[j] = gv[v]; }
+            for (int v = 0; v < NE; ++v) { const int j = t + v * PS_CP_NT; if (j < (int)nex) wex[j] = gv[v]; }
         }
         PS_CP_CLK(3);
         __syncthreads();

@@ -22,6 +22,11 @@ CASES = [
     ('ba120_huber', lambda: synthetic.stereo_ba(num_kf=120, num_lm=9000, obs_per_lm=8, half_window=14, seed=5, loss=losses.HuberLoss(2.0))[0]),
     ('ba200', lambda: synthetic.stereo_ba(num_kf=200, num_lm=12000, obs_per_lm=10, half_window=20, seed=0)[0]),
     ('ba_with_edges', lambda: synthetic.with_pose_edges(synthetic.stereo_ba(num_kf=60, num_lm=4000, obs_per_lm=6, half_window=9, seed=8)[0], 40, 9)),
+    # pose graphs: short rows, dense coarse rows cut into many tasks (300 poses: 517 tasks -> the instantiation with 12 sums per thread)
+    ('se3_graph_120', lambda: synthetic.pose_graph(num_poses=120, num_loops=90, dof=6, seed=3)[0]),
+    ('se3_graph_300', lambda: synthetic.pose_graph(num_poses=300, num_loops=200, dof=6, seed=2)[0]),
+    ('se2_graph_200', lambda: synthetic.pose_graph(num_poses=200, num_loops=150, dof=3, seed=4)[0]),
+    ('ba260', lambda: synthetic.stereo_ba(num_kf=260, num_lm=8000, obs_per_lm=10, half_window=20, seed=1)[0]),
 ]
 
 
@@ -34,20 +39,24 @@ def test_one_launch_cg_equals_the_launch_per_iteration_kernels(name, make):
         dev = DeviceProblem(lp)
         dev.set_option('cg_persist', persist)
         dev.set_option('lagged_inverse', 0)
+        if lp.num_reduced > 250:                                     # (without the lagged inverse the explicit PCG takes over from 250 poses)
+            dev.set_option('cg_explicit_min_rows', 100000)
         dev.linearize(0.0)
         its, relres = dev.solve_reduced(1e-13, 4000)
         dev.backsub()
         xp, xl = dev.get_dx()
         trace = [dev.gn_iteration(0.0, 1e-12, 4000, True) for _ in range(3)]
+        if lp.num_obs == 0:
+            xl = np.zeros((0, 3))
         out[persist] = (its, relres, xp, xl, trace, dev.get_params(), dev.cg_persist_counts())
         dev.close()
     a, b = out[1], out[0]
     assert a[6][0] >= 4 and a[6][1] == 0 and b[6][0] == 0            # the one-launch form ran (staged solve + three iterations), never failed
-    assert abs(a[0] - b[0]) <= 1 and a[1] <= 1e-13 * 1.001
-    assert rel(a[2], b[2]) <= 1e-9 and rel(a[3], b[3]) <= 1e-9
+    assert abs(a[0] - b[0]) <= max(1, a[0] // 50) and a[1] <= 1e-13 * 1.001
+    assert rel(a[2], b[2]) <= 1e-9 and (a[3].size == 0 or rel(a[3], b[3]) <= 1e-9)
     for ta, tb in zip(a[4], b[4]):
-        assert abs(ta[0] - tb[0]) <= 1e-10 * abs(tb[0]) and abs(ta[2] - tb[2]) <= 1
-    assert np.abs(a[5][0] - b[5][0]).max() <= 1e-9 and np.abs(a[5][1] - b[5][1]).max() <= 1e-8
+        assert abs(ta[0] - tb[0]) <= 1e-10 * abs(tb[0]) + 1e-18 and abs(ta[2] - tb[2]) <= max(1, tb[2] // 50)
+    assert np.abs(a[5][0] - b[5][0]).max() <= 1e-9 and (a[5][1].size == 0 or np.abs(a[5][1] - b[5][1]).max() <= 1e-8)
     if lp.num_reduced <= 60:                                         # (the sparse direct solve of the larger ones takes minutes on the host)
         dxo, _ = orc.gauss_newton_step(lp, points_first=False)
         assert rel(np.concatenate([a[2].ravel(), a[3].ravel()]), dxo) <= 1e-8
