@@ -45,5 +45,8 @@ for s in range(solves + 1):
 print('kf %d lm %d %s loop: %.4f ms per iteration over %d solves (first excluded); cost history %s' % (
     kf, lm, 'core' if core_loop else 'python', tot / its, solves, ['%.6e' % c for c in hist]))
 n_calls = min(len(m) for m in all_ms)
-print('median over the solves: solve %.4f ms, calls %s' % (float(np.median(all_dt)), ['%.4f' % float(np.median([m[k] for m in all_ms])) for k in range(n_calls)]))
+print('%s %d %d%s %s loop, median over %d solves: solve %.4f ms = %.4f ms per iteration, calls %s, pcg %s' % (
+    'graph' if '--pg' in sys.argv else 'BA', kf, lm, (' [' + ' '.join(o[6:] for o in opts) + ']') if opts else '', 'core' if core_loop else 'python',
+    solves, float(np.median(all_dt)), float(np.median(all_dt)) / n_calls, ['%.4f' % float(np.median([m[k] for m in all_ms])) for k in range(n_calls)],
+    [a for a, _ in stats]))
 dev.close()

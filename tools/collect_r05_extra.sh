@@ -49,9 +49,9 @@ echo "# SQ counters of the observation passes and the Schur kernel, C3 (tools/pm
 bash tools/pmc_sq.sh ${TAG}_sq 2>&1 | $F
 echo
 echo "# second half of round 5 -- the cost summed by the next landmark pass (fuse_cost) and the folded CG in one launch (cg_persist): medians over cold solves"
-for o in "" "--opt=fuse_cost:0" "--opt=cg_persist:0" "--opt=fuse_cost:0 --opt=cg_persist:0"; do echo "C3 [$o] $(python tools/cold_probe.py 200 50000 30 $o 2>&1 | grep median)"; done
-for o in "" "--opt=fuse_cost:0"; do echo "C4 [$o] $(python tools/cold_probe.py 2000 500000 8 $o 2>&1 | grep median)"; done
-for cfg in "100 60" "200 150" "240 300"; do for o in "" "--opt=cg_persist:0"; do echo "SE(3) graph $cfg [$o] $(python tools/cold_probe.py $cfg 12 --pg $o 2>&1 | grep median)"; done; done
+for o in "" "--opt=fuse_cost:0" "--opt=cg_persist:0" "--opt=fuse_cost:0 --opt=cg_persist:0"; do echo "C3 [$o] $(python tools/cold_probe.py 200 50000 30 $o 2>&1 | grep "median over")"; done
+for o in "" "--opt=fuse_cost:0"; do echo "C4 [$o] $(python tools/cold_probe.py 2000 500000 8 $o 2>&1 | grep "median over")"; done
+for cfg in "100 60" "200 150" "240 300"; do for o in "" "--opt=cg_persist:0"; do echo "SE(3) graph $cfg [$o] $(python tools/cold_probe.py $cfg 12 --pg $o 2>&1 | grep "median over")"; done; done
 echo "## phase clocks of the one-launch CG's first workgroup, C3 (measurement build, PS_CP_CLOCKS; the clock reads themselves cost ~0.1 us each)"
 python -c "import __graft_entry__ as g; g.build_measure()" > /dev/null 2>&1
 PYSLAM_AMD_MEASURE=1 PS_CP_CLOCKS=1 python tools/cold_probe.py 200 50000 12 2>&1 | grep "k_cg_persist"
