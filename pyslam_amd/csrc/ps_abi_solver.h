@@ -127,6 +127,7 @@ int ps_apply_update(ps_problem* h, double step) {
 
 int ps_snapshot_params(ps_problem* h) {
     if (!h) return fail("null argument");
+    h->snap_valid = true;
     h->snap_cost = h->last_cost;
     const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
     if (n1 + n2)
@@ -135,8 +136,21 @@ int ps_snapshot_params(ps_problem* h) {
     return 0;
 }
 
+// the end of ps_solve: the best parameters become the current ones by exchanging the two sets of tables -- no copy, nothing for
+// the caller's final synchronisation to wait for.  The snapshot is consumed (its tables now hold the iterate that was given up)
+static int restore_params_by_exchange(ps_problem* h) {
+    if (!h->snap_valid) return fail("ps_solve: no snapshot to restore");
+    h->prelin_valid = h->prelm_valid = false;
+    h->last_cost = h->snap_cost; h->prev_cost = -1.0;
+    std::swap(h->poses, h->poses_snap);
+    std::swap(h->points, h->points_snap);
+    h->snap_valid = false;
+    return 0;
+}
+
 int ps_restore_params(ps_problem* h) {
     if (!h) return fail("null argument");
+    if (!h->snap_valid) return fail("ps_restore_params: no snapshot (none taken, or ps_solve has consumed it)");
     h->prelin_valid = h->prelm_valid = false;
     h->last_cost = h->snap_cost; h->prev_cost = -1.0;       // the snapshot's own cost (if it was known), no step history
     const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
@@ -467,7 +481,7 @@ int ps_solve(ps_problem* h, const ps_solve_options* o, double pcg_tol, int pcg_m
         if (o->allow_nondecreasing_steps) {
             if (nd == 0 && ps_snapshot_params(h)) return -1;
             if (cost >= o->min_cost_decrease * prev) ++nd; else nd = 0;
-            if (nd >= o->max_nondecreasing_steps) { done = true; if (ps_restore_params(h)) return -1; }
+            if (nd >= o->max_nondecreasing_steps) { done = true; if (restore_params_by_exchange(h)) return -1; }
         } else done = done || cost >= o->min_cost_decrease * prev;
     }
     h->solve_horizon = -1;

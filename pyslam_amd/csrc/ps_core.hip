@@ -408,6 +408,7 @@ struct ps_problem {
     bool last_setup_lagx = false;   // the current folded system was built with the lagged X~ (three-launch set-up)
     hipEvent_t ev_ldi = nullptr, ev_ldi_sread = nullptr;
     double snap_cost = -1.0;        // last_cost at the time of ps_snapshot_params
+    bool snap_valid = false;        // a snapshot has been taken and not consumed (ps_solve's final restore exchanges the tables)
     // option "solve_horizon": how many MORE whole-iteration calls the caller's stopping rule allows if the step about to be
     // taken does not decrease the cost enough (reference problem.py:163-178: max_nondecreasing_steps - taken - 1, or 0 without
     // allow_nondecreasing_steps); -1 = unknown (a caller that drives ps_gn_iteration itself).  Side work that only pays back

@@ -110,3 +110,27 @@ def test_build_sha_matches_the_sources_on_disk():
     import __graft_entry__ as ge
     from pyslam_amd import _native as nat
     assert nat.load().ps_build_sha().decode() == ge.source_sha()
+
+
+def test_the_solves_final_restore_consumes_the_snapshot():
+    """ps_solve hands the best parameters back by exchanging the parameter tables with the snapshot's (no copy: nothing is left
+    for the caller's synchronisation to wait for).  The result equals the Python loop's copy-restore (the parametrised test above);
+    here: the snapshot is gone afterwards -- a restore without a new snapshot fails loudly instead of bringing back the iterate
+    that was given up -- and a snapshot taken after the solve works as before."""
+    from pyslam_amd._native import NativeError
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.stereo_ba(num_kf=30, num_lm=1500, obs_per_lm=6, half_window=6, seed=5)
+    dev = DeviceProblem(lp)
+    hist, _ = device_solve(dev, _options(allow_nondecreasing_steps=True, max_nondecreasing_steps=3))
+    assert len(hist) >= 4                                    # (ended on max_nondecreasing_steps: the restore ran)
+    best = dev.get_params()
+    with pytest.raises(NativeError, match='no snapshot'):
+        dev.restore()
+    assert np.array_equal(dev.get_params()[0], best[0]) and np.array_equal(dev.get_params()[1], best[1])
+    dev.snapshot()
+    dev.gn_iteration(0., 1e-12, 500, True)
+    dev.restore()
+    after = dev.get_params()
+    assert np.array_equal(after[0], best[0]) and np.array_equal(after[1], best[1])
+    assert abs(dev.eval_cost(True) - min(hist)) <= 1e-9 * min(hist)
+    dev.close()
