@@ -411,8 +411,10 @@ int build_coarse(ps_problem* h) {
         std::vector<int32_t> rt0(rows + 1, 0);
         for (int i = 0; i < rows; ++i) {
             rt0[i] = (int32_t)tasks.size();
-            const int w = arp[i + 1] - arp[i], nt = std::max(1, cdiv(w, PS_CP_TASKB)), per = cdiv(w, nt);
-            for (int k = 0; k < nt; ++k) tasks.push_back(CpTask{i, arp[i] + k * per, std::min(arp[i + 1], arp[i] + (k + 1) * per), 0});
+            // (a padded fine row: its own blocks and the ncb border blocks come first, the zero padding behind them is left out)
+            const int w = i < nr ? std::min(arp[i + 1] - arp[i], fnz[i] + ncb) : arp[i + 1] - arp[i];
+            const int nt = std::max(1, cdiv(w, PS_CP_TASKB)), per = cdiv(w, nt);
+            for (int k = 0; k < nt; ++k) tasks.push_back(CpTask{i, arp[i] + k * per, std::min(arp[i] + w, arp[i] + (k + 1) * per), 0});
         }
         rt0[rows] = (int32_t)tasks.size();
         // (all workgroups must be resident at once: a quarter of the chip at most)

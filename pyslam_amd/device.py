@@ -122,11 +122,15 @@ class DeviceProblem:
         cap = o.max_iters + 2
         if cap < 2 or cap > 100000:
             return None
-        hist, rel, ms = np.zeros(cap), np.zeros(cap), np.zeros(cap)
-        its = np.zeros(cap, dtype=np.int32)
+        buf = getattr(self, '_solve_buf', None)              # (result buffers kept on the object: four allocations less per solve)
+        if buf is None or buf[0].size < cap:
+            buf = self._solve_buf = (np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap, dtype=np.int32))
+            self._solve_ptr = (nat.f64p(buf[0]), nat.f64p(buf[1]), nat.f64p(buf[2]), nat.i32p(buf[3]))
+        hist, rel, ms, its = buf
+        p_hist, p_rel, p_ms, p_its = self._solve_ptr
         n, iters, dxn = C.c_int32(), C.c_int32(), C.c_double()
         rc = self._lib.ps_solve(self._h, C.byref(o), float(getattr(opt, 'pcg_tol', 1e-12)), int(getattr(opt, 'pcg_max_iters', 2000)),
-                                nat.f64p(hist), cap, C.byref(n), C.byref(iters), C.byref(dxn), nat.i32p(its), nat.f64p(rel), nat.f64p(ms))
+                                p_hist, cap, C.byref(n), C.byref(iters), C.byref(dxn), p_its, p_rel, p_ms)
         if rc == 1:
             return None
         nat.check(rc)

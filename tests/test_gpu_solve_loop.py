@@ -132,5 +132,9 @@ def test_the_solves_final_restore_consumes_the_snapshot():
     dev.restore()
     after = dev.get_params()
     assert np.array_equal(after[0], best[0]) and np.array_equal(after[1], best[1])
-    assert abs(dev.eval_cost(True) - min(hist)) <= 1e-9 * min(hist)
+    # (what the reference keeps as best_params, problem.py:163-178: the parameters of the iteration at whose end the count of
+    #  non-decreasing steps was still zero -- i.e. after the FIRST step that failed to cut the cost by min_cost_decrease; not
+    #  the lowest cost seen)
+    k_last_good = max(i for i in range(1, len(hist)) if hist[i] < 0.9 * hist[i - 1])
+    assert dev.eval_cost(True) == hist[k_last_good + 1]
     dev.close()

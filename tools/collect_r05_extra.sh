@@ -59,6 +59,9 @@ echo "## the exchange on its own (tools/probes/allgather_probe.hip: nwg, threads
 hipcc --offload-arch=gfx950 -O3 -o /tmp/agp tools/probes/allgather_probe.hip 2> /dev/null
 for cfg in "32 512 1280 40 0 0" "64 512 1280 40 0 0" "32 512 128 40 0 0" "32 512 4096 40 0 0" "32 512 1280 40 0 1"; do echo "[$cfg] $(timeout 60 /tmp/agp $cfg 2>&1 | tail -2 | head -1)"; done
 echo
+echo "# small pose graphs (BASELINE configuration 1 and neighbours; tools/c1_probe.py: ten whole-iteration calls, lagged inverse on / off)"
+python tools/c1_probe.py 2>&1 | $F
+echo
 echo "# batch entry: C3 from tables end to end (tests/test_gpu_batch_entry.py)"
 python -m pytest tests/test_gpu_batch_entry.py -q -s -k c3 2>&1 | grep "solve_tables\|passed\|failed"
 echo
