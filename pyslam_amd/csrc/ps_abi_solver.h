@@ -753,6 +753,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "coarse_lag_x") { h->lagx = value != 0.0; h->lci_next = -1; h->side_todo = false; }
     else if (n == "cg_lds") h->cg_lds = value != 0.0;
     else if (n == "cg_persist") h->cg_persist = value != 0.0;
+    else if (n == "xcg_persist") h->xcg_persist = value != 0.0;
     else if (n == "cg_persist_spin") { if (value < 0 || value > 1e7) return fail("cg_persist_spin out of range"); h->cp_spin = (unsigned)value; }
     else if (n == "cg_explicit") { h->explicit_ok = value != 0.0; h->coarse_built = false; }
     else if (n == "big_chol") h->big_chol = value != 0.0;

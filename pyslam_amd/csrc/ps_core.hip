@@ -316,6 +316,15 @@ struct ps_problem {
     unsigned long long* cp_exch = nullptr;
     unsigned cp_salt = 0, cp_spin = 200000;   // option "cg_persist_spin": passes over the exchange before a workgroup gives up
     long cp_launches = 0, cp_failures = 0;
+    // the explicit two-level PCG's one-launch-per-iteration form as one launch per solve (ps_k_xcg_persist.h): option "xcg_persist"
+    int xcg_persist = 1;
+    bool xp_ok = false;             // every workgroup resident at once, at most PS_XP_RB records per node
+    int32_t* xf_cnt = nullptr;      // live records per coarse node
+    unsigned long long* xp_exch = nullptr;
+    size_t xp_words = 0;
+    unsigned xp_salt = 0;
+    long xp_launches = 0;
+    bool xp_defer = false;          // xcg_setup left launch -1 to the one launch that runs them all
     long long* cp_dbg = nullptr;    // measurement build, PS_CP_CLOCKS: phase clocks of the kernel's first workgroup
     int prof_every = 1;             // profiling level 1: time the Schur kernel of every n-th linearisation only
     long prof_tick = 0;

@@ -102,7 +102,7 @@ int wait_published(ps_problem* h) {
             if (h->lmfail_check && *reinterpret_cast<volatile long long*>(h->h_lmfail) == h->lmfail_check) h->h_status[ST_LM_FAIL] += 1;
             // an exchange of the one-launch CG timed out (a breakdown as far as the caller is concerned: it solves again with the
             // launch-per-iteration kernels): not used on this handle any more
-            if (h->h_status[ST_PERSIST_FAIL] && h->cg_persist) { h->cg_persist = 0; ++h->cp_failures; }
+            if (h->h_status[ST_PERSIST_FAIL] && (h->cg_persist || h->xcg_persist)) { h->cg_persist = 0; h->xcg_persist = 0; ++h->cp_failures; }
             if (h->start_cost_pending) {                     // ps_solve's first iteration: the start cost rode in front of it --
                 h->start_cost_pending = false;               // from here on the call knows it, as if ps_eval_cost had run first
                 h->last_cost = h->ldi_call_start_cost = h->h_scalars[SC_STARTCOST];
@@ -530,6 +530,15 @@ int build_coarse(ps_problem* h) {
             h->xf_rmax = rmax; h->xf_nwg = nwg; h->xf_nrec = nrec;
             h->xf_pf = maxlen <= 16 ? 2 : (maxlen <= 48 ? 6 : 8);
             h->xf_ok = true;
+            // one launch per SOLVE (ps_k_xcg_persist.h): all workgroups at once (one per compute unit), the records of a node
+            // gathered together, the exchange buffer = [w | partials | records] twice (iteration parity), two granules per double
+            h->xp_ok = false;
+            if (h->xf_one_ok && nwg <= 256 && nrec <= (size_t)PS_XP_NR * 64 * PS_XF_ROWS) {
+                const size_t words = 4 * ((size_t)nr * D + 2 * (size_t)nwg + nrec);
+                if (h->upload(&h->xf_cnt, cnt) || h->alloc(&h->xp_exch, words)) return -1;
+                HIP_OK(hipMemsetAsync(h->xp_exch, 0, words * sizeof(unsigned long long), h->stream));
+                h->xp_words = words; h->xp_salt = 0; h->xp_ok = true;
+            }
         }
     }
     lap("allocations");

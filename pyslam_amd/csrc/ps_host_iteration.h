@@ -119,6 +119,7 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
         h->xcg_ref_pending = true;
     }
     h->xf_active = h->xcg_fused && h->xf_ok && h->xf_skip == 0;
+    h->xp_defer = false;
     {   // xstate, the second p buffer and (one- / two-launch form) ts_0 and the records of buffer 0: one launch
         const size_t n0 = 8, n1 = (size_t)nr * D, n2 = h->xf_active ? (size_t)nc : 0, n3 = h->xf_active ? h->xf_nrec : 0;
         hipLaunchKernelGGL(k_zero4, dim3((unsigned)std::min<size_t>(1024, cdiv((long)(n0 + n1 + n2 + n3), 256))), dim3(256), 0, h->stream,
@@ -137,7 +138,12 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
                            h->xf_t[0], h->status);
         if (lagst) hipLaunchKernelGGL(k_lag_status_check, dim3(1), dim3(64), 0, h->stream, lagst, h->status);
         h->cg_launched = -1;
-        xcg_launch<D>(h, 0.0, 1);                          // launch -1 (cg_launched: -1 -> 0)
+        // one launch per SOLVE (ps_k_xcg_persist.h): launch -1 is the first pass of the launch that runs them all (xcg_launch)
+        // (long rows only -- bundle adjustment: what the launch saves is the matrix stream of every iteration; with the short rows
+        //  of a pose graph there is little to save and the exchange between up to 256 workgroups costs more: 1 500 poses 5.48 -> 5.94 ms)
+        h->xp_defer = h->xcg_persist && h->xp_ok && !h->xf_two && h->xf_pf >= 6 && max_iters + 1 <= 4090;
+        h->cg_max_launches = max_iters + 1;
+        if (!h->xp_defer) xcg_launch<D>(h, 0.0, 1);        // launch -1 (cg_launched: -1 -> 0)
         ++h->xf_solves;
         return 0;
     }
@@ -174,6 +180,52 @@ void xcg_launch(ps_problem* h, double tol, int count) {
     const int nr = h->nr, ncb = h->ncb, nc = h->nc;
     const int n_rz = cdiv(nr, PS_XCG_DROWS);
     double* pbuf[2] = {h->cg_p, h->xp2};
+    if (h->xf_active && h->xp_defer && h->cg_launched >= h->cg_max_launches) return;      // (the one launch has run them all)
+    if (h->xf_active && h->xp_defer && h->cg_launched == -1) {
+        // every iteration of the solve in ONE launch: k = -1 .. max_iters - 1 at most, stops at convergence by itself
+        if (count <= 0) return;
+        XcgFusedArgs a{};
+        a.cptr = h->xf_cptr; a.cols = h->xf_cols; a.lidx = h->xf_lidx; a.nlo = h->xf_nlo; a.nhi = h->xf_nhi;
+        a.Ainv = (const float*)h->LciT2[h->lci_cur]; a.nc = nc; a.ncb = ncb;
+        a.pnode = h->pnode; a.pw0 = h->pw0; a.pw1 = h->pw1; a.Bmat = h->Bmat;
+        a.rec_out = h->xf_rec; a.rmax = h->xf_rmax; a.nwg = h->xf_nwg;
+        a.t_in = h->xf_t[0]; a.ts_in = h->xf_ts[0];
+        a.r_in = h->cg_r[0]; a.w_in = h->cg_w[0]; a.s_in = h->cg_s[0];
+        a.u = h->xp2; a.p = h->cg_p; a.x = h->cg_xh;
+        if (++h->xp_salt >= (1u << 20)) {
+            hipMemsetAsync(h->xp_exch, 0, h->xp_words * sizeof(unsigned long long), h->stream);
+            h->xp_salt = 1;
+        }
+        const int nl = h->cg_max_launches + 1;               // passes: k = -1 .. max_iters - 1
+        // (the matrix: PF blocks per lane in registers, PL in LDS behind t and the records; a row wider than 8 (PF + PL) blocks reads
+        //  the rest from L2 in every iteration)
+        const size_t lds0 = ((size_t)((nc + 1) & ~1) + ((h->xf_nrec + 1) & ~(size_t)1)) * sizeof(double);
+#define PS_XP_LAUNCH(PF, PL, NE) do {                                                                                                         \
+            const size_t lds = lds0 + (size_t)(PL) * 64 * PS_XF_ROWS * (D * sizeof(double) + sizeof(int32_t));                                 \
+            if (ensure_dynamic_lds((const void*)k_xcg_persist<D, PF, PL, NE>, lds)) { launched = false; break; }                              \
+            hipLaunchKernelGGL((k_xcg_persist<D, PF, PL, NE>), dim3(h->xf_nwg), dim3(64 * PS_XF_ROWS), lds, h->stream, nr, h->arow_ptr,        \
+                               h->ell_wf, h->Saug, a, h->xf_cnt, nl, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate,        \
+                               h->xp_exch, h->xp_salt, h->cp_spin); } while (0)
+        const bool ne2 = nc <= 2 * 64 * PS_XF_ROWS;
+        // (LDS: ~36 KB of static arrays + t + the records + PL blocks per lane of the matrix: as many as fit 160 KB)
+        const size_t per_pl = (size_t)64 * PS_XF_ROWS * (D * sizeof(double) + sizeof(int32_t));
+        const size_t room = 160 * 1024 - 38 * 1024 - std::min<size_t>(lds0, 120 * 1024);
+        const int pl = h->xf_pf == 8 ? (room >= 4 * per_pl ? 4 : (room >= 2 * per_pl ? 2 : 0)) : 0;
+        bool launched = true;
+        if (h->xf_pf == 2) { if (ne2) PS_XP_LAUNCH(2, 0, 2); else PS_XP_LAUNCH(2, 0, 4); }
+        else if (pl == 4) { if (ne2) PS_XP_LAUNCH(6, 4, 2); else PS_XP_LAUNCH(6, 4, 4); }
+        else if (pl == 2) { if (ne2) PS_XP_LAUNCH(6, 2, 2); else PS_XP_LAUNCH(6, 2, 4); }
+        else { if (ne2) PS_XP_LAUNCH(6, 0, 2); else PS_XP_LAUNCH(6, 0, 4); }
+        if (!launched) {                                     // (cannot be configured: the launch-per-iteration form from launch -1 on)
+            (void)hipGetLastError();
+            h->xp_defer = false;
+            xcg_launch<D>(h, tol, count);
+            return;
+        }
+#undef PS_XP_LAUNCH
+        h->cg_launched = h->cg_max_launches; h->cg_kernel_launches += 1; ++h->xp_launches; ++h->cp_launches;
+        return;
+    }
     if (h->xf_active) {                                     // ONE launch per iteration (launch index n = k + 1 picks the buffers)
         h->cg_kernel_launches += (h->xf_two ? 2 : 1) * count;
         const size_t lds = h->xf_two ? 0 : (size_t)nc * sizeof(double);
@@ -265,6 +317,7 @@ int xcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* re
         xcg_launch<D>(h, tol, m);
         if (xcg_side_enqueue<D>(h)) return -1;
         if (read_scalars(h)) return -1;
+        if (h->h_status[ST_PERSIST_FAIL] && h->xcg_persist) { h->xcg_persist = 0; ++h->cp_failures; }
         if (h->xf_active && h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL] && !h->h_status[ST_LM_FAIL]) {
             ++h->xf_fallbacks; h->xf_skip = 1;              // breakdown of the one-launch form: again, three launches per iteration
             if (xcg_setup<D>(h, max_iters, false)) return -1;

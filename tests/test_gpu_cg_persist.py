@@ -121,3 +121,36 @@ def test_covariance_columns_through_the_one_launch_cg():
         dev.close()
     for a, b in zip(cols[1], cols[0]):
         assert rel(a[0], b[0]) <= 1e-8 and rel(a[1], b[1]) <= 1e-8
+
+
+XCASES = [
+    ('ba600', lambda: synthetic.stereo_ba(num_kf=600, num_lm=9000, obs_per_lm=10, half_window=20, seed=3)[0]),
+    ('ba1000_huber', lambda: synthetic.stereo_ba(num_kf=1000, num_lm=12000, obs_per_lm=8, half_window=14, seed=4, loss=losses.HuberLoss(2.0))[0]),
+]
+
+
+@pytest.mark.parametrize('name,make', XCASES, ids=[c[0] for c in XCASES])
+def test_one_launch_explicit_pcg_equals_the_launch_per_iteration_form(name, make):
+    """The explicit two-level PCG of larger bundle adjustments (csrc/ps_k_xcg_persist.h, option xcg_persist): every iteration of
+    a solve in one launch, the matrix in registers / LDS, one in-launch exchange per iteration -- against k_xcg_fused1 launched
+    once per iteration (xcg_persist 0): same recurrences, same order of the sums, so the same iteration counts and the same step
+    to the solver's tolerance; then with the exchange made to time out: repeated launch by launch, counted, not used again."""
+    from pyslam_amd.device import DeviceProblem
+    lp = make()
+    out = {}
+    for mode in ('persist', 'per_iteration', 'timeout'):
+        dev = DeviceProblem(lp)
+        dev.set_option('xcg_persist', 0 if mode == 'per_iteration' else 1)
+        if mode == 'timeout':
+            dev.set_option('cg_persist_spin', 0)
+        trace = [dev.gn_iteration(0.0, 1e-12, 2000, True) for _ in range(3)]
+        out[mode] = (trace, dev.get_params(), dev.cg_persist_counts())
+        dev.close()
+    a, b, c = out['persist'], out['per_iteration'], out['timeout']
+    assert a[2][0] == 3 and a[2][1] == 0 and b[2] == (0, 0)
+    assert c[2][1] <= 1 and (c[2][1] == 0 or c[2][0] == 1)   # (a pass over the exchange may succeed at once: then nothing times out)
+    for ta, tb, tc in zip(a[0], b[0], c[0]):
+        assert abs(ta[0] - tb[0]) <= 1e-10 * abs(tb[0]) and abs(ta[2] - tb[2]) <= 1
+        assert abs(tc[0] - tb[0]) <= 1e-10 * abs(tb[0])
+    for other in (b, c):
+        assert np.abs(a[1][0] - other[1][0]).max() <= 1e-9 and np.abs(a[1][1] - other[1][1]).max() <= 1e-8
