@@ -345,6 +345,9 @@ int ps_debug_table_checksums(ps_problem* h, uint64_t* out, int capacity, int* co
                               unknowns, <= 512 tasks); 0: one launch per CG iteration.  "cg_persist_spin" [200000]: passes over the
                               in-launch exchange before a workgroup gives up (then the solve is repeated launch by launch and the
                               form is not used on the handle any more: ps_problem_info.cg_persist_failures)
+     "xcg_persist"        [1] the explicit two-level PCG of bundle adjustments (long rows, at most 256 workgroups: up to 2 048 poses) in ONE
+                              launch per solve (csrc/ps_k_xcg_persist.h): matrix in registers / LDS, w, partials and records exchanged
+                              in-launch; 0: one launch per iteration (k_xcg_fused1).  Time-outs as "cg_persist"
      "lm_packed" [1], "band_part" [1], "band_part_chunk" [0 auto], "sync_refactor" [1], "hold_across_steps" [1]: round-5 kernels and
                               schedules against their predecessors (DESIGN.md sections 0 and 3)
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual

@@ -209,7 +209,8 @@ void xcg_launch(ps_problem* h, double tol, int count) {
         const bool ne2 = nc <= 2 * 64 * PS_XF_ROWS;
         // (LDS: ~36 KB of static arrays + t + the records + PL blocks per lane of the matrix: as many as fit 160 KB)
         const size_t per_pl = (size_t)64 * PS_XF_ROWS * (D * sizeof(double) + sizeof(int32_t));
-        const size_t room = 160 * 1024 - 38 * 1024 - std::min<size_t>(lds0, 120 * 1024);
+        const size_t fixed = (ne2 ? 23920 : 36208) + 1024;   // (the kernel's static arrays by its NE, -Rpass-analysis=kernel-resource-usage)
+        const size_t room = 160 * 1024 - fixed - std::min<size_t>(lds0, 120 * 1024);
         const int pl = h->xf_pf == 8 ? (room >= 4 * per_pl ? 4 : (room >= 2 * per_pl ? 2 : 0)) : 0;
         bool launched = true;
         if (h->xf_pf == 2) { if (ne2) PS_XP_LAUNCH(2, 0, 2); else PS_XP_LAUNCH(2, 0, 4); }

@@ -48,9 +48,10 @@ echo
 echo "# SQ counters of the observation passes and the Schur kernel, C3 (tools/pmc_sq.sh; one --pmc pass per set)"
 bash tools/pmc_sq.sh ${TAG}_sq 2>&1 | $F
 echo
-echo "# second half of round 5 -- the cost summed by the next landmark pass (fuse_cost) and the folded CG in one launch (cg_persist): medians over cold solves"
+echo "# second half of round 5 -- the cost summed by the next landmark pass (fuse_cost), the folded CG in one launch (cg_persist), the explicit PCG of bundle adjustments in one launch (xcg_persist): medians over cold solves"
 for o in "" "--opt=fuse_cost:0" "--opt=cg_persist:0" "--opt=fuse_cost:0 --opt=cg_persist:0"; do echo "C3 [$o] $(python tools/cold_probe.py 200 50000 30 $o 2>&1 | grep "median over")"; done
 for o in "" "--opt=fuse_cost:0"; do echo "C4 [$o] $(python tools/cold_probe.py 2000 500000 8 $o 2>&1 | grep "median over")"; done
+for cfg in "2000 500000 6" "1500 400000 4" "1000 60000 6" "600 150000 6"; do for o in "" "--opt=xcg_persist:0"; do echo "BA $cfg [$o] $(python tools/cold_probe.py $cfg $o 2>&1 | grep "median over")"; done; done
 for cfg in "100 60" "200 150" "240 300"; do for o in "" "--opt=cg_persist:0"; do echo "SE(3) graph $cfg [$o] $(python tools/cold_probe.py $cfg 12 --pg $o 2>&1 | grep "median over")"; done; done
 echo "## phase clocks of the one-launch CG's first workgroup, C3 (measurement build, PS_CP_CLOCKS; the clock reads themselves cost ~0.1 us each)"
 python -c "import __graft_entry__ as g; g.build_measure()" > /dev/null 2>&1
