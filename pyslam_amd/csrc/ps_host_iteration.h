@@ -199,17 +199,18 @@ void xcg_launch(ps_problem* h, double tol, int count) {
         const int nl = h->cg_max_launches + 1;               // passes: k = -1 .. max_iters - 1
         // (the matrix: PF blocks per lane in registers, PL in LDS behind t and the records; a row wider than 8 (PF + PL) blocks reads
         //  the rest from L2 in every iteration)
-        const size_t lds0 = ((size_t)((nc + 1) & ~1) + ((h->xf_nrec + 1) & ~(size_t)1)) * sizeof(double);
+        const bool ne2 = nc <= 2 * 64 * PS_XF_ROWS;
+        const size_t ysum_doubles = (size_t)PS_XF_NODES * D * (((ne2 ? 2 : 4) * 64 * PS_XF_ROWS + 63) / 64);      // (phase 2's segment sums share the records' place)
+        const size_t lds0 = ((size_t)((nc + 1) & ~1) + ((std::max(h->xf_nrec, ysum_doubles) + 1) & ~(size_t)1)) * sizeof(double);
 #define PS_XP_LAUNCH(PF, PL, NE) do {                                                                                                         \
             const size_t lds = lds0 + (size_t)(PL) * 64 * PS_XF_ROWS * (D * sizeof(double) + sizeof(int32_t));                                 \
             if (ensure_dynamic_lds((const void*)k_xcg_persist<D, PF, PL, NE>, lds)) { launched = false; break; }                              \
             hipLaunchKernelGGL((k_xcg_persist<D, PF, PL, NE>), dim3(h->xf_nwg), dim3(64 * PS_XF_ROWS), lds, h->stream, nr, h->arow_ptr,        \
                                h->ell_wf, h->Saug, a, h->xf_cnt, nl, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate,        \
                                h->xp_exch, h->xp_salt, h->cp_spin); } while (0)
-        const bool ne2 = nc <= 2 * 64 * PS_XF_ROWS;
-        // (LDS: ~36 KB of static arrays + t + the records + PL blocks per lane of the matrix: as many as fit 160 KB)
+        // (LDS: the static arrays + t + the records + PL blocks per lane of the matrix: as many as fit 160 KB)
         const size_t per_pl = (size_t)64 * PS_XF_ROWS * (D * sizeof(double) + sizeof(int32_t));
-        const size_t fixed = (ne2 ? 23920 : 36208) + 1024;   // (the kernel's static arrays by its NE, -Rpass-analysis=kernel-resource-usage)
+        const size_t fixed = 11700 + 1024;                   // (the kernel's static arrays, -Rpass-analysis=kernel-resource-usage)
         const size_t room = 160 * 1024 - fixed - std::min<size_t>(lds0, 120 * 1024);
         const int pl = h->xf_pf == 8 ? (room >= 4 * per_pl ? 4 : (room >= 2 * per_pl ? 2 : 0)) : 0;
         bool launched = true;

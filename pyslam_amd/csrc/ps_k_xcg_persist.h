@@ -39,7 +39,6 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
     __shared__ double su[PS_XF_CAP * D];
     __shared__ double sr[PS_XF_ROWS * D], suo[PS_XF_ROWS * D];
     __shared__ double yl[PS_XF_NODES * D];
-    __shared__ double ysum[PS_XF_NODES * D * ((NE * 64 * PS_XF_ROWS + 63) / 64)];
     __shared__ double lds[32];
     __shared__ double wred[PS_XF_ROWS][2];
     __shared__ double cw[PS_XF_ROWS][PS_XCG_NSLOT][D];
@@ -50,7 +49,10 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
     const bool chief = wg == 0 && tid == 0;
     const int nrec = a.ncb * a.rmax * D;
     double* trec = tl + ((nc + 1) & ~1);
-    double* sml = trec + ((nrec + 1) & ~1);                  // PL blocks per lane of the matrix: [(i D + c) NT + tid]
+    // (the segment sums of phase 2 live where the records of phase 5 do: never at the same time, and 12 KB more for the matrix)
+    double* ysum = trec;
+    constexpr int YS = PS_XF_NODES * D * ((NE * 64 * PS_XF_ROWS + 63) / 64);
+    double* sml = trec + ((max(nrec, YS) + 1) & ~1);         // PL blocks per lane of the matrix: [(i D + c) NT + tid]
     int32_t* sll = reinterpret_cast<int32_t*>(sml + (size_t)PL * D * NT);     // their LDS slots: [i NT + tid]
     if (tid == 0) bad = 0;
     if (status[ST_PCG_DONE]) return;
