@@ -342,7 +342,7 @@ int ps_debug_table_checksums(ps_problem* h, uint64_t* out, int capacity, int* co
                               2: in the tails only; 0: the grid-stride cost pass of rounds 1-4 everywhere (another summation order).
                               Needs every observation on a variable landmark with at most 16 observations, else 0 is what runs
      "cg_persist"         [1] the folded two-level CG in ONE launch (csrc/ps_k_cg_persist.h) where the augmented system fits (<= 2 048
-                              unknowns, <= 512 tasks); 0: one launch per CG iteration.  "cg_persist_spin" [200000]: passes over the
+                              unknowns, <= 1 024 tasks); 0: one launch per CG iteration.  "cg_persist_spin" [200000]: passes over the
                               in-launch exchange before a workgroup gives up (then the solve is repeated launch by launch and the
                               form is not used on the handle any more: ps_problem_info.cg_persist_failures)
      "xcg_persist"        [1] the explicit two-level PCG of bundle adjustments (long rows, at most 256 workgroups: up to 2 048 poses) in ONE

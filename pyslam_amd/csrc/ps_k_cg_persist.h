@@ -6,9 +6,10 @@
 // k_cg_fused_lds runs one CG iteration per launch: 5.0-5.4 us each at C3 (a kernel boundary, one memory round trip for the
 // 5.7 MB matrix out of the Infinity Cache, one block reduction), 18-21 of them per Gauss-Newton iteration = 40 % of it.
 // Nothing in an iteration needs a kernel boundary except that every workgroup needs all of w = S^ r of the others.  Here
-//   * the augmented matrix stays IN REGISTERS for the whole solve: a wave owns one "task" = one block row (or a third of a
-//     dense coarse row), at most 88 blocks, lane (slot, r) holds row r of 11 of them (66 doubles);
-//   * the vectors r, s, p, x are REPLICATED: every workgroup keeps all n entries (three per thread) and applies the same
+//   * the augmented matrix stays IN REGISTERS for the whole solve: a wave owns one "task" = at most 48 blocks of one block row
+//     (half a fine row at C3, a fifth of a dense coarse row; the zero padding of an ELL row is left out), lane (slot, r) holds
+//     row r of 6 of them (36 doubles);
+//   * the vectors r, s, p, x are REPLICATED: every workgroup keeps all n entries (four per thread) and applies the same
 //     recurrences with the same alpha / beta -- bitwise the same everywhere, so nobody has to agree on anything;
 //   * per iteration ONE exchange: a wave publishes the six sums of its task as self-tagged 8-byte granules {tag | half of the
 //     double} with write-through stores, every workgroup gathers all of them with relaxed agent-scope loads (no flags, no
@@ -16,7 +17,8 @@
 //     double-buffered by the parity of the iteration (a workgroup can only be one exchange ahead of the slowest);
 //   * gamma = r.r and delta = w.r are summed by every workgroup itself, in the same order.
 // Measured on the chip before it was built (tools/probes/allgather_probe.hip): 2.0-2.7 us per exchange for 32 workgroups of 512
-// threads, whatever their number -- against 5.4 us per launch.
+// threads, whatever their number -- against 5.4 us per launch.  In the kernel: ~4.5 us per CG iteration at C3 (58 workgroups),
+// 3.6 on a 100-pose graph; two instantiations by the number of exchanged sums per thread (6: up to 512 tasks, 12: up to 1 024).
 // Every spin is bounded: a workgroup that does not see its granules within `spin_limit` passes reports a breakdown
 // (ST_PCG_DONE = 2, ST_PERSIST_FAIL) and leaves; the host then solves with the launch-per-iteration kernels and stops using
 // this one on the handle.

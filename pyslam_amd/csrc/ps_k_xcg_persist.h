@@ -8,14 +8,18 @@
 // through memory in ONE step (w of the rows, the partials of gamma / delta, the records of P^T w); here that step is an in-launch
 // exchange of self-tagged granules (ps_k_cg_persist.h: two 8-byte {tag | half} granules per double, write-through stores, relaxed
 // agent-scope loads, two buffers by iteration parity, bounded spins) and the launch stays:
-//   * a workgroup keeps its 8 rows of the matrix in registers (PF blocks per lane; rows wider than 8 PF blocks read the rest from L2
-//     as before), r and s of ITS COLUMNS (it recomputes them every iteration anyway), t and ts of all coarse entries, u / p / x of
-//     its own rows;
+//   * a workgroup keeps its 8 rows of the matrix in registers (PF blocks per lane) and in LDS (PL more: as many as fit 160 KB
+//     beside t, the records and the static arrays -- C4: 6 + 4 = the whole row; a row wider than 8 (PF + PL) blocks reads the rest
+//     from L2 as before), r and s of ITS COLUMNS (it recomputes them every iteration anyway), t and ts of all coarse entries,
+//     u / p / x of its own rows;
 //   * per iteration it publishes w of its rows (48 sums), its two partials and its records, and gathers w of its columns (<= 170
 //     x 6), all partials (2 per workgroup) and all live records (cnt[node] per node) -- one round trip.
 // Same recurrences, same order of the sums as k_xcg_fused1 (launches k = -1, 0, 1, ...), same status / history / scalars.
 // Needs every workgroup resident at once: the one-launch form's own condition (<= 256 workgroups) with one workgroup per compute
-// unit.  A time-out reports a breakdown + ST_PERSIST_FAIL: the host repeats the solve launch by launch.
+// unit.  A time-out (spin_limit passes, or 20 ms) reports a breakdown + ST_PERSIST_FAIL: the host repeats the solve launch by
+// launch.  Used for long (bundle-adjustment) rows only: on pose graphs there is no matrix stream worth keeping and the exchange
+// between up to 256 workgroups costs more than it saves (1 500 poses: 5.48 -> 5.94 ms per solve).  C4: 355 us per launch for 20-21
+// iterations against 21 launches of 18.7 us.
 // ---------------------------------------------------------------------------
 #define PS_XP_NR 8                      // record slots per thread: ncb * rmax * D <= PS_XP_NR * 512
 
