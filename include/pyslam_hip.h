@@ -107,13 +107,22 @@ typedef struct ps_problem_info {
     int64_t cg_persist_solves;   /* folded CG solves run in ONE launch (option "cg_persist", csrc/ps_k_cg_persist.h)          */
     int64_t cg_persist_failures; /* ... whose in-launch exchange timed out: solved again with the launch-per-iteration kernels,
                                     and the one-launch form is not used on the handle any more                              */
+    int64_t cg_persist_refused;  /* solves that wanted a one-launch form and ran launch by launch instead because its grid
+                                    could not be resident at that moment: one-launch solves of OTHER handles of this process
+                                    held the compute units (a form that can never be resident on the handle's stream -- device
+                                    size, CU mask, occupancy -- is not even tried and does not count)                        */
+    int32_t persist_cus;         /* compute units the solver's stream may use as the core found them (device count, the stream's
+                                    CU mask, ROC_GLOBAL_CU_MASK; 0: unknown, e.g. HSA_CU_MASK is set: no one-launch form)     */
+    int32_t persist_cus_needed;  /* units the one-launch form of this handle needs resident (0: the system does not fit the form) */
 } ps_problem_info;
 
 enum { PS_NUM_STAGES = 12 };
 /* stage ids for ps_get_stage_times (ALLREDUCE / PACK: the landmark-sharded iteration driven by the core itself,
-   ps_set_collective -- both all-reduces, and k_shard_pack + k_shard_unpack) */
+   ps_set_collective -- both all-reduces, and k_shard_pack + k_shard_unpack; CG_KERNEL: the launch(es) that run the CG
+   iterations of the reduced solve alone -- k_cg_persist / k_xcg_persist or the per-iteration kernels -- without the set-up
+   kernels and the recovery that PCG also spans; recorded at profiling level 1 like SCHUR) */
 enum { PS_ST_LANDMARK = 0, PS_ST_POSE = 1, PS_ST_SCHUR = 2, PS_ST_EDGES = 3, PS_ST_PCG = 4,
-       PS_ST_BACKSUB = 5, PS_ST_UPDATE = 6, PS_ST_COST = 7, PS_ST_TOTAL = 8, PS_ST_SCHUR_KERNEL = 9,
+       PS_ST_BACKSUB = 5, PS_ST_UPDATE = 6, PS_ST_COST = 7, PS_ST_TOTAL = 8, PS_ST_CG_KERNEL = 9,
        PS_ST_ALLREDUCE = 10, PS_ST_PACK = 11 };
 
 const char* ps_last_error(void);
@@ -140,7 +149,14 @@ int ps_get_info(ps_problem* h, ps_problem_info* info);
 
 /* sum_blocks sum_i rho(r_i) at the current parameters -- pyslam/problem.py:110-128
    (include_all_constant=1) or the cost term of problem.py:334,358
-   (include_all_constant=0: blocks whose parameters are all constant are skipped). */
+   (include_all_constant=0: blocks whose parameters are all constant are skipped).
+   SIDE EFFECT (option "fuse_cost" = 1, the default, include_all_constant = 1, every observation on a variable landmark with
+   at most 16 observations): the cost is summed by the landmark pass itself, which REWRITES Z, C^-1 and c at the current
+   parameters (a linearisation that follows at this point finds its landmark pass done).  If the parameters have moved since the
+   last ps_linearize those buffers then belong to the new point, and the staged entry points that read them -- ps_backsub,
+   ps_gn_finish, ps_gn_solve_finish[_enqueue], ps_get_landmark_factors -- fail with "no longer belong to the last ps_linearize"
+   until ps_linearize is called again.  The same holds after a whole-iteration call (ps_gn_iteration, ps_solve) that expected a
+   successor: its tail has run the successor's landmark pass. */
 int ps_eval_cost(ps_problem* h, int include_all_constant, double* cost);
 
 /* Residuals + Jacobians + IRLS weights + J^T J assembly + landmark elimination:
@@ -162,7 +178,12 @@ int ps_shard_unpack(ps_problem* h);
 
 /* Block-Jacobi PCG on the reduced system; replaces the splinalg.spsolve call of
    pyslam/problem.py:186 together with ps_backsub.  Stops when the preconditioned residual
-   norm sqrt(r^T M^-1 r) has dropped by `tol` (scale-invariant; relres_out reports it). */
+   norm sqrt(r^T M^-1 r) has dropped by `tol` (scale-invariant; relres_out reports it).
+   tol <= 0 (here and wherever this header takes a `pcg_tol` / `tol` of the reduced solve): the DEFAULT -- 1e-12 where the
+   reduced system is the Schur complement of a bundle adjustment (variable landmarks), 1e-14 for pose graphs (no landmarks:
+   priors of stiffness ~1e6 beside loop closures of ~1 leave cond(M^-1 S) at 1e4-1e5 after the two-level preconditioner, and
+   error <= cond x relative residual): what meets |dx - dx_spsolve| <= 1e-8 |dx| without the caller knowing the
+   condition number.  pyslam_amd.Options.pcg_tol = None passes 0. */
 int ps_solve_reduced(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out);
 
 /* Landmark back-substitution dx_l = Hll^-1 (b_l - W^T dx_p). */
@@ -343,9 +364,13 @@ int ps_debug_table_checksums(ps_problem* h, uint64_t* out, int capacity, int* co
                               Needs every observation on a variable landmark with at most 16 observations, else 0 is what runs
      "cg_persist"         [1] the folded two-level CG in ONE launch (csrc/ps_k_cg_persist.h) where the augmented system fits (<= 2 048
                               unknowns, <= 1 024 tasks); 0: one launch per CG iteration.  "cg_persist_spin" [200000]: passes over the
-                              in-launch exchange before a workgroup gives up (then the solve is repeated launch by launch and the
-                              form is not used on the handle any more: ps_problem_info.cg_persist_failures)
-     "xcg_persist"        [1] the explicit two-level PCG of bundle adjustments (long rows, at most 256 workgroups: up to 2 048 poses) in ONE
+                              in-launch exchange before a workgroup gives up -- or 20 ms, whichever comes first -- (then the solve is
+                              repeated launch by launch and the form is not used on the handle any more:
+                              ps_problem_info.cg_persist_failures).  The form is only used when its whole grid can be resident on the
+                              compute units the handle's stream may use (device count, stream CU mask, occupancy of the kernel:
+                              ps_problem_info.persist_cus / persist_cus_needed) and while one-launch solves of other handles of the
+                              process leave them free (cg_persist_refused)
+     "xcg_persist"        [1] the explicit two-level PCG of bundle adjustments (long rows, one workgroup per compute unit of the stream: up to 2 048 poses on a whole MI355X) in ONE
                               launch per solve (csrc/ps_k_xcg_persist.h): matrix in registers / LDS, w, partials and records exchanged
                               in-launch; 0: one launch per iteration (k_xcg_fused1).  Time-outs as "cg_persist"
      "lm_packed" [1], "band_part" [1], "band_part_chunk" [0 auto], "sync_refactor" [1], "hold_across_steps" [1]: round-5 kernels and

@@ -18,7 +18,7 @@ c_f64p = C.POINTER(C.c_double)
 c_u8p = C.POINTER(C.c_uint8)
 PS_NUM_STAGES = 12
 STAGE_NAMES = ['landmark_pass', 'pose_pass', 'schur_pairs', 'pose_factors', 'pcg',
-               'backsub', 'update', 'cost', 'iteration_total', 'reserved', 'allreduce', 'pack_unpack']
+               'backsub', 'update', 'cost', 'iteration_total', 'cg_kernel', 'allreduce', 'pack_unpack']
 
 
 class ProblemDesc(C.Structure):
@@ -55,7 +55,8 @@ class ProblemInfo(C.Structure):
         ('device_bytes', C.c_int64), ('cg_restarts', C.c_int64), ('cg_kernel_launches', C.c_int64),
         ('ldi_solves', C.c_int64), ('ldi_fallbacks', C.c_int64), ('ldi_seeds', C.c_int64),
         ('xcg_fused_solves', C.c_int64), ('xcg_fused_fallbacks', C.c_int64),
-        ('cg_persist_solves', C.c_int64), ('cg_persist_failures', C.c_int64),
+        ('cg_persist_solves', C.c_int64), ('cg_persist_failures', C.c_int64), ('cg_persist_refused', C.c_int64),
+        ('persist_cus', C.c_int32), ('persist_cus_needed', C.c_int32),
     ]
 
 
@@ -166,6 +167,13 @@ _CREATE_ENV = {'PS_CREATE_DEVICE', 'PS_CREATE_KEYS64', 'PS_PAIRS_BY_LANDMARK', '
                'PS_SCHUR_TILE_KB', 'PS_SCHUR_TILE_MIN_MB', 'PS_ST_TILES'}       # ps_create_env(): read by every build
 
 
+# ps_env(): the measurement / debugging switches of the -DPS_MEASURE build (tests/test_host_api.py holds this list against the sources)
+_MEASURE_ENV = {'PS_ALLOC_GUARD', 'PS_ARENA_POISON', 'PS_BAND_INV_DOT', 'PS_CP_CLOCKS', 'PS_CREATE_TIMING', 'PS_DIRECT_3LAUNCH',
+                'PS_DIRECT_THREADS', 'PS_EVENT_FLAGS', 'PS_F2_ABLATE', 'PS_F2_ROWS', 'PS_HOST_TIMING', 'PS_LAZY_COARSE', 'PS_LDI_SEED_LAG',
+                'PS_POSE_CHUNK', 'PS_RS_ABLATE', 'PS_SCALE_NO_PIPE', 'PS_SCHUR_KEEP_TILES', 'PS_SCHUR_LDS_PAD', 'PS_SCHUR_NO_LPT',
+                'PS_SCHUR_SPLIT', 'PS_SIDE_CUS', 'PS_SIDE_KICK', 'PS_SIDE_LOWPRIO', 'PS_XCG_AC_MAIN', 'PS_XCG_ROWS_RT', 'PS_XF2_PF'}
+
+
 def load():
     """dlopen the HIP core; raise loudly if it is missing (no CPU fallback)."""
     global _lib
@@ -179,7 +187,8 @@ def load():
     if os.environ.get('PYSLAM_AMD_MEASURE') != '1':
         # the product library compiles the measurement / debugging switches out (csrc/ps_core.hip: ps_env): say so once instead of
         # silently ignoring a variable somebody set (round-4 ADVICE).  The create-time variants below ARE read by it.
-        ignored = sorted(k for k in os.environ if k.startswith('PS_') and k not in _CREATE_ENV)
+        # (only the switches the sources know: procps' PS_FORMAT / PS_PERSONALITY and the like are none of our business)
+        ignored = sorted(k for k in os.environ if k in _MEASURE_ENV)
         if ignored:
             import sys
             sys.stderr.write('pyslam_amd: {} ignored by the product library (measurement switches exist only in the -DPS_MEASURE '

@@ -77,6 +77,7 @@ int ps_problem_destroy(ps_problem* h) {
         fprintf(stderr, "ps_gn_iteration: %ld calls, %.1f us per call on the host, of which %.1f us waiting for the GPU (%ld waits)\n",
                 h->host_calls, h->host_call_ns * 1e-3 / h->host_calls, h->host_wait_ns * 1e-3 / h->host_calls, h->host_waits);
     hipStreamSynchronize(h->stream);
+    h->persist_release();
     if (h->side) hipStreamSynchronize(h->side);
     if (h->ldi_stream) hipStreamSynchronize(h->ldi_stream);
     for (void* p : h->allocs) hipFree(p);

@@ -13,6 +13,8 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
     info->ldi_solves = h->ldi_solves; info->ldi_fallbacks = h->ldi_fallbacks; info->ldi_seeds = h->ldi_seeds;
     info->xcg_fused_solves = h->xf_solves; info->xcg_fused_fallbacks = h->xf_fallbacks;
     info->cg_persist_solves = h->cp_launches; info->cg_persist_failures = h->cp_failures;
+    info->cg_persist_refused = h->cp_refused; info->persist_cus = h->persist_cus;
+    info->persist_cus_needed = h->cp_ok ? h->cp_cus_needed : (h->xp_ok ? h->xp_cus_needed : 0);
     return 0;
 }
 
@@ -85,15 +87,33 @@ int ps_shard_unpack(ps_problem* h) {
     return 0;
 }
 
+// A tolerance <= 0 asks for the DEFAULT (include/pyslam_hip.h: ps_solve_reduced): what meets SURVEY 8d's bar on the step
+// (|dx - dx_spsolve| <= 1e-8 |dx|) without the caller knowing cond(M^-1 S) -- error <= cond x relative residual
+static inline double resolve_pcg_tol(const ps_problem* h, double tol) {
+    if (tol > 0.0) return tol;
+    return h->nv > 0 ? 1e-12 : 1e-14;      // Schur complements of a bundle adjustment / pose graphs (priors ~1e6 beside loops ~1)
+}
+
 int ps_solve_reduced(ps_problem* h, double tol, int max_iters, int* iters_out, double* relres_out) {
     if (!h) return fail("null argument");
+    tol = resolve_pcg_tol(h, tol);
     const int rc = solve_reduced(h, tol, max_iters, iters_out, relres_out);
     if (rc == 0 && h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
     return rc;
 }
 
+// the staged entry points that read Z, C^-1, c of the last ps_linearize (include/pyslam_hip.h: ps_eval_cost)
+static int z_of_last_linearize(ps_problem* h, const char* who) {
+    if (!h->z_foreign || h->nv == 0) return 0;
+    char buf[320];
+    snprintf(buf, sizeof buf, "%s: Z, C^-1 and c no longer belong to the last ps_linearize -- a landmark pass has since run at another point "
+             "(ps_eval_cost after the parameters moved, or a whole-iteration call that expected a successor): call ps_linearize again", who);
+    return fail(buf);
+}
+
 int ps_backsub(ps_problem* h) {
     if (!h) return fail("null argument");
+    if (z_of_last_linearize(h, "ps_backsub")) return -1;
     return backsub(h);
 }
 
@@ -140,6 +160,7 @@ int ps_snapshot_params(ps_problem* h) {
 // the caller's final synchronisation to wait for.  The snapshot is consumed (its tables now hold the iterate that was given up)
 static int restore_params_by_exchange(ps_problem* h) {
     if (!h->snap_valid) return fail("ps_solve: no snapshot to restore");
+    h->params_moved_since_lin = true;
     h->prelin_valid = h->prelm_valid = false;
     h->last_cost = h->snap_cost; h->prev_cost = -1.0;
     std::swap(h->poses, h->poses_snap);
@@ -151,6 +172,7 @@ static int restore_params_by_exchange(ps_problem* h) {
 int ps_restore_params(ps_problem* h) {
     if (!h) return fail("null argument");
     if (!h->snap_valid) return fail("ps_restore_params: no snapshot (none taken, or ps_solve has consumed it)");
+    h->params_moved_since_lin = true;
     h->prelin_valid = h->prelm_valid = false;
     h->last_cost = h->snap_cost; h->prev_cost = -1.0;       // the snapshot's own cost (if it was known), no step history
     const size_t n1 = (size_t)h->P * h->PW, n2 = (size_t)h->L * 3;
@@ -170,6 +192,7 @@ int ps_get_params(ps_problem* h, double* poses, double* points) {
 
 int ps_set_params(ps_problem* h, const double* poses, const double* points) {
     if (!h) return fail("null argument");
+    h->params_moved_since_lin = true;
     h->prelin_valid = h->prelm_valid = false;
     h->last_cost = h->prev_cost = -1.0;
     if (poses && h->P) HIP_OK(hipMemcpyAsync(h->poses, poses, (size_t)h->P * h->PW * sizeof(double), hipMemcpyDefault, h->stream));
@@ -179,6 +202,7 @@ int ps_set_params(ps_problem* h, const double* poses, const double* points) {
 
 int ps_gn_finish(ps_problem* h, int linesearch, double* cost_out, double* dx_pose_norm2, double* dx_point_norm2) {
     if (!h) return fail("null argument");
+    if (z_of_last_linearize(h, "ps_gn_finish")) return -1;
     HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
     if (gn_tail(h, linesearch, nullptr)) return -1;
@@ -193,6 +217,8 @@ int ps_gn_finish(ps_problem* h, int linesearch, double* cost_out, double* dx_pos
 int ps_gn_solve_finish(ps_problem* h, double pcg_tol, int pcg_max_iters, int linesearch, double* cost_out,
                        double* dx_pose_norm2, double* dx_point_norm2, int* pcg_iters_out, double* pcg_relres_out) {
     if (!h) return fail("null argument");
+    pcg_tol = resolve_pcg_tol(h, pcg_tol);
+    if (z_of_last_linearize(h, "ps_gn_solve_finish")) return -1;
     HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
     HIP_OK(hipMemsetAsync(h->scalars + SC_DXL2, 0, sizeof(double), h->stream));
     if (h->nr > 0 && h->pcg_variant == 1) {
@@ -231,6 +257,8 @@ int ps_shard_buffer(ps_problem* h, void** dev_ptr) {
 int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters, int linesearch, int first) {
     if (!h) return fail("null argument");
     if (h->nr == 0 || h->pcg_variant != 1) return fail("ps_gn_solve_finish_enqueue needs the fused CG and a reduced system");
+    pcg_tol = resolve_pcg_tol(h, pcg_tol);
+    if (first && z_of_last_linearize(h, "ps_gn_solve_finish_enqueue")) return -1;
     h->shard_out = true;
     struct Reset { ps_problem* h; ~Reset() { h->shard_out = false; } } reset{h};
     if (first) {
@@ -292,6 +320,7 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
                              double* cost_out, double* dx_norm_out, int* pcg_iters_out, double* pcg_relres_out,
                              double* start_cost_out) {
     if (!h) return fail("null argument");
+    pcg_tol = resolve_pcg_tol(h, pcg_tol);
     h->start_cost_pending = false;
     h->lmfail_check = 0;
     if (start_cost_out) {
@@ -562,6 +591,7 @@ int ps_covariance_begin(ps_problem* h) {
 int ps_covariance_column(ps_problem* h, int kind, int index, int comp, double tol, int max_iters,
                          int* iters_out, double* relres_out) {
     if (!h) return fail("null argument");
+    tol = resolve_pcg_tol(h, tol);
     if (!h->cov_ready) return fail("ps_covariance_column: call ps_covariance_begin first (any linearisation invalidates it)");
     if (kind == 0 ? (index < 0 || index >= h->nr || comp < 0 || comp >= h->D)
                   : (kind != 1 || index < 0 || index >= h->nv || comp < 0 || comp >= 3))
@@ -604,6 +634,7 @@ int ps_get_reduced_system(ps_problem* h, int32_t* row_ptr, int32_t* col_idx, dou
 
 int ps_get_landmark_factors(ps_problem* h, double* cinv, double* c) {
     if (!h) return fail("null argument");
+    if (z_of_last_linearize(h, "ps_get_landmark_factors")) return -1;
     std::vector<double> t6((size_t)h->nv * 6), t3((size_t)h->nv * 3);
     if (h->nv) {
         HIP_OK(hipMemcpyAsync(t6.data(), h->Cinv, t6.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));

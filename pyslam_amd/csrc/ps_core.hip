@@ -107,6 +107,47 @@ inline int ensure_dynamic_lds(const void* func, size_t bytes) {
 
 PsPool& ps_pool() { static PsPool* p = new PsPool(); return *p; }   // (leaked on purpose: no destructor order issues at exit)
 
+// ---- co-residency of the one-launch solvers (k_cg_persist, k_xcg_persist) ------------------------------------------------
+// Their workgroups wait for one another INSIDE the launch, in an ordinary (non-cooperative) launch: the whole grid must be
+// resident at once or the first arrivals spin until the time-out.  Nothing may be left to a literal there (round-5 verdict,
+// ADVICE): the compute units the solver's stream may use come from the device (hipDeviceAttributeMultiprocessorCount: a CPX /
+// DPX partition reports its own count) and from the stream's CU mask (hipExtStreamCreateWithCUMask; without one
+// hipExtStreamGetCUMask returns ROC_GLOBAL_CU_MASK or all units); workgroups per unit from
+// hipOccupancyMaxActiveBlocksPerMultiprocessor of the very instantiation; and the units that launches of OTHER handles of this
+// process hold at the same time come off a process-wide ledger per device (reserved when a solve is enqueued, released when
+// the host has seen its end).  A form that cannot be resident is refused up front -- the launch-per-iteration kernels run --
+// instead of being found out by a 20 ms stall.  What the ledger cannot see (another PROCESS on the same device, HSA_CU_MASK
+// applied below HIP) is still answered by the bounded spins.
+struct CuBudget { int cus = 0; bool masked = false; };
+inline CuBudget ps_stream_cus(hipStream_t st) {
+    CuBudget b;
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return b; }
+    b.cus = ncu;
+    uint32_t mask[64] = {};
+    const uint32_t words = (uint32_t)std::min(64, (ncu + 31) / 32);
+    if (hipExtStreamGetCUMask(st, words, mask) == hipSuccess) {
+        int c = 0;
+        for (int i = 0; i < ncu && i < 64 * 32; ++i) c += (mask[i >> 5] >> (i & 31)) & 1u;
+        if (c > 0 && c < ncu) { b.cus = c; b.masked = true; }
+    } else (void)hipGetLastError();
+    // a mask applied below HIP (ROCr) is invisible here: nothing can be promised
+    if (const char* e = getenv("HSA_CU_MASK")) { if (*e) { b.cus = 0; b.masked = true; } }
+    return b;
+}
+struct PersistLedger {
+    std::mutex mu;
+    int held[64] = {};             // compute units held by one-launch solves in flight, per device
+    bool reserve(int dev, int need, int capacity) {
+        if (dev < 0 || dev >= 64) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (held[dev] + need > capacity) return false;
+        held[dev] += need; return true;
+    }
+    void release(int dev, int n) { if (dev < 0 || dev >= 64 || n <= 0) return; std::lock_guard<std::mutex> lk(mu); held[dev] = std::max(0, held[dev] - n); }
+};
+PersistLedger& ps_persist_ledger() { static PersistLedger* p = new PersistLedger(); return *p; }
+
 }  // namespace
 
 #include "ps_host_bandpart.h"
@@ -316,6 +357,27 @@ struct ps_problem {
     unsigned long long* cp_exch = nullptr;
     unsigned cp_salt = 0, cp_spin = 200000;   // option "cg_persist_spin": passes over the exchange before a workgroup gives up
     long cp_launches = 0, cp_failures = 0;
+    // co-residency (ps_stream_cus / PersistLedger above): what build_coarse found, what a solve in flight holds
+    int persist_dev = 0, persist_cus = 0;       // device of the handle; compute units its stream may use (0: unknown -> no one-launch form)
+    bool persist_masked = false;                // ... fewer than the device has (a CU mask)
+    int cp_cus_needed = 0, xp_cus_needed = 0;   // compute units the one-launch folded CG / explicit PCG need resident
+    int persist_held = 0;                       // units this handle holds on the ledger (released when the host has seen the solve's end)
+    // Z, C^-1, c are rewritten by every landmark pass -- also by the one a tail runs AHEAD for its successor and by the pass that
+    // sums ps_eval_cost's cost (fuse_cost): the staged entry points that read them (ps_backsub, ps_gn_finish, ps_gn_solve_finish*,
+    // ps_get_landmark_factors) belong to the last ps_linearize and refuse when the buffers have since been rewritten at another point
+    bool params_moved_since_lin = false;        // a tail / update / upload / restore since the last linearize()
+    bool z_foreign = false;                     // ... and a landmark pass ran at the moved point (or under another damping)
+    long cp_refused = 0;                        // solves that wanted a one-launch form and ran launch by launch instead (not resident)
+    void persist_release() { if (persist_held) { ps_persist_ledger().release(persist_dev, persist_held); persist_held = 0; } }
+    // compute units a one-launch solve may count on: all of the stream's when it has the whole device; half of a masked stream's
+    // (workgroups go to the XCDs round-robin whatever the mask leaves of each: an uneven mask fills one XCD first)
+    int persist_capacity() const { return persist_masked ? persist_cus / 2 : persist_cus; }
+    bool persist_reserve(int need) {
+        if (need <= 0 || persist_cus <= 0) return false;
+        if (persist_held) return true;          // (a second round of launches of the same solve: already held)
+        if (!ps_persist_ledger().reserve(persist_dev, need, persist_capacity())) { ++cp_refused; return false; }
+        persist_held = need; return true;
+    }
     // the explicit two-level PCG's one-launch-per-iteration form as one launch per solve (ps_k_xcg_persist.h): option "xcg_persist"
     int xcg_persist = 1;
     bool xp_ok = false;             // every workgroup resident at once, at most PS_XP_RB records per node
@@ -434,7 +496,8 @@ struct ps_problem {
     // gn_tail): option "expect_next" (ps_solve sets it per iteration; a caller's own loop may) says a successor is expected.
     // prelm_pending: the running tail carries such a pass (tag prelm_tag); prelm_valid: it ran (the tail was open) and the
     // parameters have not moved since -- linearize() then skips its landmark pass.  A landmark block that was not positive
-    // definite there stamps h_lmfail with the tag; the call whose linearisation consumed the pass reports it (lmfail_check).
+    // definite there stamps h_lmfail[tag & 1] with the tag (two pinned words: consecutive passes cannot overwrite one another's
+    // report before it is read); the call whose linearisation consumed the pass reports it (lmfail_check).
     int expect_next = 0, fuse_cost = 1;
     bool prelm_pending = false, prelm_valid = false;
     double prelm_lambda = 0.0;

@@ -63,6 +63,7 @@ void drain_timers_ready(ps_problem* h) {
 
 int sync(ps_problem* h) {
     HIP_OK(hipStreamSynchronize(h->stream));
+    h->persist_release();               // (whatever one-launch solve was in flight has ended)
     drain_timers(h);
     // whatever produced the side stream's inputs has completed: start the next coarse operator NOW, while the GPU is
     // idle between two calls (kicked from the next call's linearize() it started ~35 us into the iteration and the
@@ -97,9 +98,14 @@ int wait_published(ps_problem* h) {
             if (linearize(h, h->lin_lambda, true)) return -1;
         }
         if (*w == h->seq) {
+            // (the tail is behind the reduced solve on the stream: a one-launch solve has ended, its compute units are free --
+            //  unless the next linearisation was enqueued behind it, which is not a one-launch solver)
+            h->persist_release();
             // a landmark block that was not positive definite in the landmark pass the previous tail ran for THIS call's
             // linearisation (k_landmark_pass_packed<.., COST> reports through a word of its own)
-            if (h->lmfail_check && *reinterpret_cast<volatile long long*>(h->h_lmfail) == h->lmfail_check) h->h_status[ST_LM_FAIL] += 1;
+            // (two words, by the parity of the tag: this call's own tail may already have run the pass of the NEXT point, whose
+            //  failure -- tag + 1 -- goes to the other word and cannot overwrite this one before it has been looked at: round-5 ADVICE)
+            if (h->lmfail_check && *reinterpret_cast<volatile long long*>(h->h_lmfail + (h->lmfail_check & 1)) == h->lmfail_check) h->h_status[ST_LM_FAIL] += 1;
             // an exchange of the one-launch CG timed out (a breakdown as far as the caller is concerned: it solves again with the
             // launch-per-iteration kernels): not used on this handle any more
             if (h->h_status[ST_PERSIST_FAIL] && (h->cg_persist || h->xcg_persist)) { h->cg_persist = 0; h->xcg_persist = 0; ++h->cp_failures; }
@@ -217,6 +223,11 @@ int build_coarse(ps_problem* h) {
         t_last = now;
     };
     const int nr = h->nr, D = h->D;
+    {   // compute units the solver's stream may use (the one-launch solvers need their whole grid resident)
+        const CuBudget cb = ps_stream_cus(h->stream);
+        int dev = 0; if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        h->persist_dev = dev; h->persist_cus = cb.cus; h->persist_masked = cb.masked;
+    }
     if (h->ldi_ready) {                 // a rebuilt coarse level changes the sizes the lagged dense inverse was laid out for
         if (h->side) HIP_OK(hipStreamSynchronize(h->side));
         if (h->ldi_stream) HIP_OK(hipStreamSynchronize(h->ldi_stream));
@@ -417,8 +428,18 @@ int build_coarse(ps_problem* h) {
             for (int k = 0; k < nt; ++k) tasks.push_back(CpTask{i, arp[i] + k * per, std::min(arp[i] + w, arp[i] + (k + 1) * per), 0});
         }
         rt0[rows] = (int32_t)tasks.size();
-        // (all workgroups must be resident at once: a quarter of the chip at most)
-        if ((int)tasks.size() <= 128 * (PS_CP_NT / 64) && (long)tasks.size() * D <= (long)PS_CP_NE_MAX * PS_CP_NT) {
+        // all workgroups must be resident at once: what the DEVICE says this stream can hold (occupancy of the instantiation x
+        // the compute units the stream may use, ps_core.hip: ps_stream_cus), not a literal; at most PS_CP_NE_MAX sums per thread
+        const int cp_nwg = cdiv((int)tasks.size(), PS_CP_NT / 64);
+        const bool cp_ne6 = (long)tasks.size() * D <= 6L * PS_CP_NT;
+        int cp_per_cu = 0;
+        {
+            const void* kfn = D == 6 ? (cp_ne6 ? (const void*)k_cg_persist<6, 6> : (const void*)k_cg_persist<6, 12>)
+                                     : (cp_ne6 ? (const void*)k_cg_persist<3, 6> : (const void*)k_cg_persist<3, 12>);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&cp_per_cu, kfn, PS_CP_NT, 0) != hipSuccess) { (void)hipGetLastError(); cp_per_cu = 0; }
+        }
+        h->cp_cus_needed = cp_per_cu > 0 ? cdiv(cp_nwg, cp_per_cu) : 0;
+        if ((long)tasks.size() * D <= (long)PS_CP_NE_MAX * PS_CP_NT && h->cp_cus_needed > 0 && h->cp_cus_needed <= h->persist_capacity()) {
             CpTask* dt = nullptr;
             if (h->upload(&dt, tasks) || h->upload(&h->cp_row_task0, rt0) ||
                 h->alloc(&h->cp_exch, (size_t)4 * tasks.size() * D)) return -1;
@@ -533,7 +554,10 @@ int build_coarse(ps_problem* h) {
             // one launch per SOLVE (ps_k_xcg_persist.h): all workgroups at once (one per compute unit), the records of a node
             // gathered together, the exchange buffer = [w | partials | records] twice (iteration parity), two granules per double
             h->xp_ok = false;
-            if (h->xf_one_ok && nwg <= 256 && nrec <= (size_t)PS_XP_NR * 64 * PS_XF_ROWS) {
+            // (all workgroups resident at once, one per compute unit -- 256 VGPRs, ~150 KB of LDS: as many as the stream's compute
+            //  units, ps_core.hip: ps_stream_cus; the exact instantiation's occupancy is checked again where it is launched)
+            h->xp_cus_needed = nwg;
+            if (h->xf_one_ok && nwg <= h->persist_capacity() && nrec <= (size_t)PS_XP_NR * 64 * PS_XF_ROWS) {
                 const size_t words = 4 * ((size_t)nr * D + 2 * (size_t)nwg + nrec);
                 if (h->upload(&h->xf_cnt, cnt) || h->alloc(&h->xp_exch, words)) return -1;
                 HIP_OK(hipMemsetAsync(h->xp_exch, 0, words * sizeof(unsigned long long), h->stream));
@@ -836,7 +860,8 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
     if (ps_env("PS_CP_CLOCKS") && !h->cp_dbg) { hipMalloc(&h->cp_dbg, 64); hipMemset(h->cp_dbg, 0, 64); }
 #endif
     if (h->cg_persist && h->cp_ok && h->G > 0 && h->cg_lds && !h->cg_split && !h->cg_two_level_reduce &&
-        !h->cg_ablate && h->cg_launched == 0 && h->cg_max_launches > 0 && h->cg_max_launches <= 4090) {
+        !h->cg_ablate && h->cg_launched == 0 && h->cg_max_launches > 0 && h->cg_max_launches <= 4090 &&
+        h->persist_reserve(h->cp_cus_needed)) {          // (refused while launches of other handles hold the units: launch by launch)
         const int nl = h->cg_max_launches;
         if (++h->cp_salt >= (1u << 20)) {                    // (tags are salt * 4096 + iteration: start over on a cleared buffer)
             hipMemsetAsync(h->cp_exch, 0, (size_t)4 * h->cp_ntasks * D * sizeof(unsigned long long), h->stream);
@@ -951,6 +976,7 @@ int cg_fused_run(ps_problem* h, double tol, int max_iters, int* iters_out, doubl
             HIP_OK(hipMemcpyAsync(h->h_status, h->status, ST_NWORDS * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
             HIP_OK(hipMemcpyAsync(h->h_scalars, h->scalars, SC_NWORDS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_OK(hipStreamSynchronize(h->stream));
+            h->persist_release();
             if (h->h_status[ST_PERSIST_FAIL] && h->cg_persist) { h->cg_persist = 0; ++h->cp_failures; }
             done = h->h_status[ST_PCG_DONE] != 0 || h->cg_launched >= max_iters + 2;
             chunk = h->pcg_chunk;
@@ -998,6 +1024,7 @@ int linearize(ps_problem* h, double lambda, bool allow_prelm) {
     h->lin_lmfail_tag = lm_done ? h->prelm_tag : 0;
     if (lm_done) ++h->prelm_used;
     h->lin_lambda = lambda;                                  // (what the held coarse inverse is tagged with, beside the cost)
+    h->params_moved_since_lin = false; h->z_foreign = false; // (Z, C^-1, c of THIS point: run below, or taken over from the pass run ahead here)
     ++h->prof_tick;
     h->cov_ready = false;
     h->status_clean = false;
@@ -1203,6 +1230,7 @@ int step_norm(ps_problem* h) {
 }
 
 int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool with_norm = false, long long* hearly = nullptr, long long eseq = 0) {
+    h->params_moved_since_lin = true;
     h->prelin_valid = h->prelm_valid = false;   // the parameters move: a linearisation enqueued ahead is of the old point (set again by
                                         // gn_iteration_impl AFTER its tail, for the speculative one enqueued behind that tail)
     StageTimer t(h, PS_ST_UPDATE);
@@ -1228,13 +1256,14 @@ inline bool lm_cost_possible(const ps_problem* h) {
 // the caller decides whether that makes prelm_valid (an ungated launch) or prelm_pending (a gated tail).
 int lm_cost_enqueue(ps_problem* h, double lambda, const int32_t* gate) {
     const int nbl = cdiv(h->lmw_nwaves, 4);
+    if (h->params_moved_since_lin || lambda != h->lin_lambda) h->z_foreign = true;      // (Z, C^-1, c leave the last linearisation's point)
     h->prelm_tag = ++h->prelm_seq;
     {
         StageTimer t(h, PS_ST_LANDMARK);
         const ObsWide wl{h->sidx_l, h->stiff_tab};
 #define PS_LMC_LAUNCH(W) hipLaunchKernelGGL((k_landmark_pass_packed<W, true>), dim3(nbl), dim3(256), 0, h->stream, h->lmw_nwaves, h->lmw_first,    \
                            h->lm_ptr, h->lm_point, h->lobs, h->poses, h->points, h->pose_rid, h->ogroups, lambda, h->Z, h->Cinv, h->cvec,        \
-                           h->status, wl, gate, h->cost_partials, h->h_lmfail_dev, h->prelm_tag)
+                           h->status, wl, gate, h->cost_partials, h->h_lmfail_dev + (h->prelm_tag & 1), h->prelm_tag)
         if (h->wide_obs) PS_LMC_LAUNCH(true); else PS_LMC_LAUNCH(false);
 #undef PS_LMC_LAUNCH
     }
@@ -1261,6 +1290,7 @@ int lm_cost_pass(ps_problem* h, double lambda, int scalar_slot) {
 // back-substitution, update, cost and ||dx||^2 with ONE final reduction launch.  `gate` (device
 // status words) makes every kernel a no-op until the CG has flagged convergence.
 int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = false) {
+    h->params_moved_since_lin = true;
     h->prelin_valid = h->prelm_valid = false;   // (as apply_update: every tail moves the parameters)
     h->prelm_pending = false;
     // line-search order (cost AFTER the step): back-substitution, landmark update and pose retraction

@@ -141,7 +141,8 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
         // one launch per SOLVE (ps_k_xcg_persist.h): launch -1 is the first pass of the launch that runs them all (xcg_launch)
         // (long rows only -- bundle adjustment: what the launch saves is the matrix stream of every iteration; with the short rows
         //  of a pose graph there is little to save and the exchange between up to 256 workgroups costs more: 1 500 poses 5.48 -> 5.94 ms)
-        h->xp_defer = h->xcg_persist && h->xp_ok && !h->xf_two && h->xf_pf >= 6 && max_iters + 1 <= 4090;
+        h->xp_defer = h->xcg_persist && h->xp_ok && !h->xf_two && h->xf_pf >= 6 && max_iters + 1 <= 4090 &&
+                      h->persist_reserve(h->xp_cus_needed);  // (its grid must be resident at once: ps_core.hip, PersistLedger)
         h->cg_max_launches = max_iters + 1;
         if (!h->xp_defer) xcg_launch<D>(h, 0.0, 1);        // launch -1 (cg_launched: -1 -> 0)
         ++h->xf_solves;
@@ -205,6 +206,9 @@ void xcg_launch(ps_problem* h, double tol, int count) {
 #define PS_XP_LAUNCH(PF, PL, NE) do {                                                                                                         \
             const size_t lds = lds0 + (size_t)(PL) * 64 * PS_XF_ROWS * (D * sizeof(double) + sizeof(int32_t));                                 \
             if (ensure_dynamic_lds((const void*)k_xcg_persist<D, PF, PL, NE>, lds)) { launched = false; break; }                              \
+            int per_cu_ = 0;                                                                                                                   \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, (const void*)k_xcg_persist<D, PF, PL, NE>, 64 * PS_XF_ROWS, lds) != hipSuccess || \
+                per_cu_ < 1 || cdiv(h->xf_nwg, per_cu_) > h->persist_capacity()) { launched = false; break; }                                 \
             hipLaunchKernelGGL((k_xcg_persist<D, PF, PL, NE>), dim3(h->xf_nwg), dim3(64 * PS_XF_ROWS), lds, h->stream, nr, h->arow_ptr,        \
                                h->ell_wf, h->Saug, a, h->xf_cnt, nl, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate,        \
                                h->xp_exch, h->xp_salt, h->cp_spin); } while (0)
@@ -218,8 +222,9 @@ void xcg_launch(ps_problem* h, double tol, int count) {
         else if (pl == 4) { if (ne2) PS_XP_LAUNCH(6, 4, 2); else PS_XP_LAUNCH(6, 4, 4); }
         else if (pl == 2) { if (ne2) PS_XP_LAUNCH(6, 2, 2); else PS_XP_LAUNCH(6, 2, 4); }
         else { if (ne2) PS_XP_LAUNCH(6, 0, 2); else PS_XP_LAUNCH(6, 0, 4); }
-        if (!launched) {                                     // (cannot be configured: the launch-per-iteration form from launch -1 on)
+        if (!launched) {                                     // (cannot be configured or not resident: the launch-per-iteration form from launch -1 on)
             (void)hipGetLastError();
+            h->persist_release(); ++h->cp_refused;
             h->xp_defer = false;
             xcg_launch<D>(h, tol, count);
             return;
@@ -318,7 +323,7 @@ int xcg_run(ps_problem* h, double tol, int max_iters, int* iters_out, double* re
         const int m = std::min(chunk, max_iters + 1 - h->cg_launched);
         xcg_launch<D>(h, tol, m);
         if (xcg_side_enqueue<D>(h)) return -1;
-        if (read_scalars(h)) return -1;
+        if (read_scalars(h)) return -1;                     // (synchronises: sync() releases the ledger)
         if (h->h_status[ST_PERSIST_FAIL] && h->xcg_persist) { h->xcg_persist = 0; ++h->cp_failures; }
         if (h->xf_active && h->h_status[ST_PCG_DONE] == 2 && !h->h_status[ST_DIAG_FAIL] && !h->h_status[ST_LM_FAIL]) {
             ++h->xf_fallbacks; h->xf_skip = 1;              // breakdown of the one-launch form: again, three launches per iteration
@@ -422,9 +427,12 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
             // (the side-stream factorisation goes in after the first few iterations' launches: early enough to
             // finish beside the CG, late enough not to delay its start on the host)
             const int head = std::min(count, 12);
-            xcg_launch<D>(h, tol, head);
-            if (xcg_side_enqueue<D>(h)) return -1;
-            xcg_launch<D>(h, tol, count - head);
+            {
+                StageTimer tk(h, PS_ST_CG_KERNEL, 1);       // the CG launches alone (the side work goes to another stream)
+                xcg_launch<D>(h, tol, head);
+                if (xcg_side_enqueue<D>(h)) return -1;
+                xcg_launch<D>(h, tol, count - head);
+            }
             hipLaunchKernelGGL(k_cg_unscale<D>, dim3(cdiv((long)h->nr * D, 256)), dim3(256), 0, h->stream, h->nr, h->Linv,
                                h->cg_xh, h->x, (const int32_t*)h->status);
             tp.stop();
@@ -479,7 +487,7 @@ int gn_solve_and_finish_async(ps_problem* h, double tol, int max_iters, int line
     int count = h->last_pcg_iters > 0 ? h->last_pcg_iters + margin : 24;
     for (;;) {
         count = std::min(count, max_iters + 2 - h->cg_launched);
-        cg_fused_launch<D>(h, tol, count);
+        { StageTimer tk(h, PS_ST_CG_KERNEL, 1); cg_fused_launch<D>(h, tol, count); }
         cg_fused_recover<D>(h, h->status);
         tp.stop();
         if (gn_tail(h, linesearch, h->status, true)) return -1;

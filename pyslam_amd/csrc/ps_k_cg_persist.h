@@ -19,7 +19,7 @@
 // Measured on the chip before it was built (tools/probes/allgather_probe.hip): 2.0-2.7 us per exchange for 32 workgroups of 512
 // threads, whatever their number -- against 5.4 us per launch.  In the kernel: ~4.5 us per CG iteration at C3 (58 workgroups),
 // 3.6 on a 100-pose graph; two instantiations by the number of exchanged sums per thread (6: up to 512 tasks, 12: up to 1 024).
-// Every spin is bounded: a workgroup that does not see its granules within `spin_limit` passes reports a breakdown
+// Every spin is bounded: a workgroup that does not see its granules within `spin_limit` passes or 20 ms reports a breakdown
 // (ST_PCG_DONE = 2, ST_PERSIST_FAIL) and leaves; the host then solves with the launch-per-iteration kernels and stops using
 // this one on the handle.
 // Semantics = the launches k = -1, 0, 1, ... of k_cg_fused_lds: same recurrences (Chronopoulos-Gear), same convergence test,
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
         {
             double gv[NE];
             bool ok = false;
+            const long long t_enter = (long long)wall_clock64();        // (100 MHz: 2 000 000 ticks = 20 ms, as k_xcg_persist)
             for (unsigned spins = 0; !ok; ++spins) {
                 ok = true;
 #pragma unroll
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
                 }
                 ok = __all(ok);
                 if (!ok) {
-                    if (spins > spin_limit) { bad = 1; break; }
+                    if (spins > spin_limit || (long long)wall_clock64() - t_enter > 2000000LL) { bad = 1; break; }
                     if (PS_CP_SLEEP) __builtin_amdgcn_s_sleep(PS_CP_SLEEP);
                     ck[7] += 1;
                 }

@@ -129,7 +129,7 @@ class DeviceProblem:
         hist, rel, ms, its = buf
         p_hist, p_rel, p_ms, p_its = self._solve_ptr
         n, iters, dxn = C.c_int32(), C.c_int32(), C.c_double()
-        rc = self._lib.ps_solve(self._h, C.byref(o), float(getattr(opt, 'pcg_tol', 1e-12)), int(getattr(opt, 'pcg_max_iters', 2000)),
+        rc = self._lib.ps_solve(self._h, C.byref(o), float(getattr(opt, 'pcg_tol', None) or 0.), int(getattr(opt, 'pcg_max_iters', 2000)),
                                 p_hist, cap, C.byref(n), C.byref(iters), C.byref(dxn), p_its, p_rel, p_ms)
         if rc == 1:
             return None
@@ -420,7 +420,8 @@ def sparse_normal_direct(J, r=None, rhs=None, refine_steps=3, accept=1e-8):
     sparse_normal_solve would not converge.  -> (dx, refinement steps allowed, ||rhs - J^T J dx|| / ||rhs||).
     Raises NotConverged if the residual stays above `accept` (a normal matrix singular to rounding)."""
     lib = nat.require_gpu()
-    J = J.tocsr()
+    J = J.tocsr(copy=True)
+    J.sum_duplicates()                # (the device looks entries up by binary search: one entry per (row, column))
     J.sort_indices()
     Jt = J.T.tocsr()
     Jt.sort_indices()

@@ -39,7 +39,11 @@ def landmark_owner_lists(lp, world, order='first_pose'):
     counts = np.bincount(lp.obs_point, minlength=L).astype(np.int64)
     if order == 'first_pose':
         first = np.full(L, lp.num_poses, dtype=np.int64)          # (a landmark nobody observes sorts last)
-        np.minimum.at(first, lp.obs_point, lp.obs_pose)
+        if lp.num_obs:                                            # lowest observing pose per landmark: sort + reduceat (np.minimum.at
+            o = np.argsort(lp.obs_point, kind='stable')           # walks 5 M observations one by one at C4 on older numpy: ADVICE)
+            pts = np.asarray(lp.obs_point)[o]
+            starts = np.flatnonzero(np.concatenate([[True], pts[1:] != pts[:-1]]))
+            first[pts[starts]] = np.minimum.reduceat(np.asarray(lp.obs_pose, dtype=np.int64)[o], starts)
         perm = np.lexsort((np.arange(L), first))
     elif order == 'index':
         perm = np.arange(L, dtype=np.int64)
@@ -154,6 +158,15 @@ class SegmentExchange:
         dev = reduce_tensor.device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.T = int(tail_idx.size)
+        # the element lists come from packed_layout, a HOST restatement of k_shard_pack's layout: hold it against the real buffer
+        # (ps_reduce_buffer's count) -- a pattern the device packs differently would scatter into the wrong slots, silently (ADVICE)
+        if int(tail_idx.max()) + 1 != int(reduce_tensor.numel()):
+            raise ValueError('SegmentExchange: the packed layout ends at element {} but the core\'s exchange buffer holds {} '
+                             '(the device pattern differs from the one the shards agreed on)'.format(int(tail_idx.max()) + 1,
+                                                                                                   int(reduce_tensor.numel())))
+        for i in idx_lists:
+            if i.size and (int(i.min()) < 0 or int(i.max()) >= int(tail_idx.min())):
+                raise ValueError('SegmentExchange: a segment element lies outside [upper(S) | g]')
         self.lens = [int(i.size) for i in idx_lists]
         self.maxlen = self.T + max(self.lens)
         self.tail = torch.as_tensor(tail_idx, device=dev)

@@ -50,7 +50,8 @@ class Options:
 
         # build-only
         self.lm_lambda = 0.             # Marquardt damping lambda * diag(J^T J); 0 = Gauss-Newton
-        self.pcg_tol = 1e-12            # relative residual of the reduced (Schur) solve
+        self.pcg_tol = None             # relative (preconditioned) residual of the reduced solve; None: the core's default -- 1e-12
+                                        # for bundle adjustments, 1e-14 for pose graphs (include/pyslam_hip.h: ps_solve_reduced)
         self.pcg_max_iters = 2000
         # None / 1: this process's GPU.  'auto': landmark-sharded over the torch.distributed process group when one
         # with more than one rank exists (every rank runs the same script on the same Problem: one process per GPU).
@@ -89,6 +90,26 @@ def device_solve(dev, opt, use_core_loop=True, call_ms=None):
     the core (ps_solve: the same statements in C, no interpreter between two iterations, the start cost's pass enqueued in
     front of the first iteration); tests/test_gpu_solve_loop.py holds the two against each other.  `call_ms`, if a list, receives
     the wall clock of every iteration call in ms."""
+    counts = getattr(dev, 'cg_persist_counts', None)
+    failures_before = counts()[1] if counts is not None else 0
+    try:
+        return _device_solve_loop(dev, opt, use_core_loop, call_ms)
+    finally:
+        if counts is not None:
+            try:
+                failed = counts()[1] - failures_before
+            except Exception:       # noqa: BLE001  (a closed handle: nothing to report)
+                failed = 0
+            if failed > 0:
+                import warnings
+                warnings.warn('pyslam_amd: {} reduced solve(s) of this handle ran the one-launch CG into its time-out (its workgroups were '
+                              'not resident together: another process on the device, a CU mask below HIP?) and were solved again launch '
+                              'by launch; the handle keeps the launch-per-iteration kernels from here on (slower, same results) -- '
+                              'ps_problem_info.cg_persist_failures'.format(failed), RuntimeWarning, stacklevel=3)
+
+
+def _device_solve_loop(dev, opt, use_core_loop, call_ms):
+    """device_solve's body (the wrapper reports a one-launch CG that timed out)."""
     loop = getattr(dev, 'solve_loop', None) if use_core_loop else None
     if loop is not None:
         out = loop(opt)
@@ -100,15 +121,24 @@ def device_solve(dev, opt, use_core_loop=True, call_ms=None):
         dev.reset_solver_state()          # a solve is a function of (parameters, options), not of the handle's history
     horizon = getattr(dev, 'set_solve_horizon', None)
     expect = getattr(dev, 'set_expect_next', None)
-    last_ratio = 1.
     linesearch = opt.linesearch_max_iters > 0
     lam = getattr(opt, 'lm_lambda', 0.)
-    pcg_tol, pcg_max = getattr(opt, 'pcg_tol', 1e-12), getattr(opt, 'pcg_max_iters', 2000)
+    pcg_tol, pcg_max = (getattr(opt, 'pcg_tol', None) or 0.), getattr(opt, 'pcg_max_iters', 2000)      # (0: the core's default)
     cost = dev.eval_cost(True)
+    try:
+        return _reference_loop(dev, opt, expect, horizon, cost, lam, pcg_tol, pcg_max, linesearch, call_ms)
+    finally:
+        if expect is not None:
+            expect(False)        # (also when an iteration raises: the handle must not keep "a successor follows" for later callers)
+
+
+def _reference_loop(dev, opt, expect, horizon, cost, lam, pcg_tol, pcg_max, linesearch, call_ms):
+    """The statements of reference pyslam/problem.py:141-178 on device calls."""
     history, stats = [cost], []
     optimization_iters = 0
     nondecreasing_steps_taken = 0
     done_optimization = False
+    last_ratio = 1.
     while not done_optimization:
         optimization_iters += 1
         prev_cost = cost
@@ -142,8 +172,6 @@ def device_solve(dev, opt, use_core_loop=True, call_ms=None):
                 dev.restore()
         else:
             done_optimization = done_optimization or cost >= opt.min_cost_decrease * prev_cost
-    if expect is not None:
-        expect(False)
     return history, stats
 
 
@@ -489,7 +517,7 @@ class Problem:
             return dx, cost
         saved = dev.get_params()
         dev.linearize(opt.lm_lambda)
-        its, rel = dev.solve_reduced(opt.pcg_tol, opt.pcg_max_iters)
+        its, rel = dev.solve_reduced(opt.pcg_tol or 0., opt.pcg_max_iters)
         dev.backsub()
         dx = self._dx_in_reference_order(dev)
         if opt.linesearch_max_iters > 0:
@@ -544,11 +572,19 @@ class Problem:
         if J.shape[1] <= self.DENSE_GENERIC_LIMIT:
             return dense_normal_solve(J.toarray(), e)
         if J.shape[1] <= DIRECT_GENERIC_LIMIT:
-            # a direct solve, as the reference's (pyslam/problem.py:186): dense blocked Cholesky on the device + refinement
-            dx, its, rel = sparse_normal_direct(J, r=e)
-            self.solver_stats.append((its, rel))
-            return dx
-        dx, its, rel = sparse_normal_solve(J, r=e, tol=self.options.pcg_tol, max_iters=max(self.options.pcg_max_iters, 10 * J.shape[1]))
+            # a direct solve, as the reference's (pyslam/problem.py:186): dense blocked Cholesky on the device + refinement.
+            # Where it cannot answer -- a rank-deficient but consistent J^T J (gauge freedom, an unobserved parameter: "not positive
+            # definite" / NotConverged), or 2 n^2 doubles that the device cannot allocate -- the CG on the normal equations below,
+            # which converges on consistent singular systems, takes over (still on the device; round-5 ADVICE)
+            from pyslam_amd.device import NotConverged
+            from pyslam_amd._native import NativeError
+            try:
+                dx, its, rel = sparse_normal_direct(J, r=e)
+                self.solver_stats.append((its, rel))
+                return dx
+            except (NotConverged, NativeError):
+                pass
+        dx, its, rel = sparse_normal_solve(J, r=e, tol=self.options.pcg_tol or 1e-12, max_iters=max(self.options.pcg_max_iters, 10 * J.shape[1]))
         self.solver_stats.append((its, rel))
         return dx
 

@@ -54,3 +54,62 @@ def test_committed_bench_line_has_the_contract_fields():
     assert line['higher_is_better'] is False and line['dtype'] == 'f64' and 'workload' in line['config']
     cs = line['cold_solve']
     assert cs['iterations'] == line['steps'] and abs(np.sum(cs['per_solve_ms']) / cs['iterations'] - line['value']) < 2e-3
+
+
+def test_roofline_names_the_candidate_with_the_largest_time():
+    """`roofline.kernel` is chosen by measurement (round-5 verdict): the event pair with the largest time per iteration."""
+    import bench
+    c3 = {'schur_pairs': 0.047, 'cg_kernel': 0.115, 'landmark_pass': 0.030, 'pose_pass': 0.027, 'backsub': 0.022, 'pcg': 0.167}
+    assert bench.pick_dominant(c3) == ('cg_kernel', 0.115)
+    c4 = {'schur_pairs': 0.529, 'cg_kernel': 0.354, 'landmark_pass': 0.249, 'pose_pass': 0.184, 'backsub': 0.173}
+    assert bench.pick_dominant(c4)[0] == 'schur_pairs'
+    assert bench.pick_dominant({'backsub': 0.5, 'schur_pairs': 0.1})[0] == 'backsub'
+    assert bench.cg_kernel_name(True, False) == 'k_cg_persist' and bench.cg_kernel_name(True, True) == 'k_xcg_persist'
+    assert bench.cg_kernel_name(False, True) == 'k_xcg_fused1' and bench.cg_kernel_name(False, False) == 'k_cg_fused_lds'
+    info = dict(num_obs=500000, num_var_points=50000, num_reduced=199, reduced_nnzb=14479)
+    r = bench.roofline_objects(info, c3, None, 19, True, False)
+    assert r['roofline']['kernel'] == 'k_cg_persist' and r['roofline']['bound'] == 'latency'
+    assert r['roofline']['algorithmic_bytes_per_launch'] == 288 * 14479 * 19          # SURVEY 8d's PCG term
+    assert abs(r['roofline']['frac'] - r['roofline']['achieved'] / 8000.) < 1e-3
+    assert abs(r['roofline']['achieved'] - 288 * 14479 * 19 / 0.115e-3 / 1e9) < 1.0
+    assert r['roofline']['latency_ceiling']['floor_ms'] == round(19 * 2.0e-3, 5)
+    assert r['roofline_schur']['kernel'] == 'k_schur_pairs_db' and r['roofline_schur']['algorithmic_bytes_per_launch'] == 76112640
+    assert bench.roofline_objects(info, c4, 'C4', 20, True, True)['roofline']['kernel'] == 'k_schur_pairs_db'
+
+
+ITERATION_KERNELS = {'k_schur_pairs_db': 'k_schur_pairs_db', 'k_schur_combine': 'k_schur_pairs_db', 'k_cg_persist': 'k_cg_persist',
+                     'k_xcg_persist': 'k_xcg_persist', 'k_cg_fused_lds': 'k_cg_fused_lds', 'k_xcg_fused1': 'k_xcg_fused1',
+                     'k_landmark_pass_packed': 'k_landmark_pass_packed', 'k_pose_pass': 'k_pose_pass', 'k_backsub_packed': 'k_backsub_packed'}
+
+
+def _largest_iteration_kernel(csv_path):
+    """From a `rocprofv3 --kernel-trace --stats` summary of the bench command: the kernel of the Gauss-Newton iteration with the
+    largest TOTAL time (per-iteration kernels of the CG summed over their launches; pair + combine kernel together, as the bench
+    line times them).  Kernels of the other legs of the command (C5 frames, create-time sorts) are not in the table above."""
+    import csv
+    total = {}
+    with open(csv_path) as f:
+        for row in csv.DictReader(f):
+            name = row['Name'].replace('void ', '')
+            for prefix, group in ITERATION_KERNELS.items():
+                if name.startswith(prefix):
+                    total[group] = total.get(group, 0.0) + float(row['TotalDurationNs'])
+                    break
+    return max(total, key=total.get), total
+
+
+def test_committed_line_names_the_top_kernel_of_the_committed_kernel_stats():
+    """The round-6 line's `roofline.kernel` (chosen live from event pairs) against the rocprofv3 summary committed beside it:
+    they must name the same kernel, at C3 (the bench line) and at C4 (its c4_single_gpu leg, stats of its own)."""
+    import pytest
+    path = os.path.join(REPO, 'profiles', 'r06_c3_bench.json')
+    if not os.path.exists(path):
+        pytest.skip('round-6 profiles not collected yet')
+    with open(path) as f:
+        line = json.load(f)
+    top, total = _largest_iteration_kernel(os.path.join(REPO, 'profiles', 'r06_c3_kernel_stats.csv'))
+    assert line['roofline']['kernel'] == top, (line['roofline']['kernel'], total)
+    assert line['roofline_candidates_ms'] and line['roofline_schur']['kernel'] == 'k_schur_pairs_db'
+    assert 'value_median' in line and line['value_median']['ms_per_iteration_median_of_solves'] > 0
+    top4, total4 = _largest_iteration_kernel(os.path.join(REPO, 'profiles', 'r06_c4_kernel_stats.csv'))
+    assert line['c4_single_gpu']['roofline']['kernel'] == top4, (line['c4_single_gpu']['roofline']['kernel'], total4)

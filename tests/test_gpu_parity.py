@@ -112,11 +112,14 @@ def test_first_step_matches_reference_spsolve(name, variant):
         if variant.endswith('split'):                      # the large-system mode, forced on small problems
             dev.set_option('cg_split_min_rows', 0)
     dev.linearize(0.)
-    # PCG tolerance (preconditioned relative residual).  1e-12 everywhere except the
-    # pose graphs: stiffness 1e6 (prior) / 31.6 (odometry) / 1 (loop), long chains => 
-    # cond(M^-1 S) ~ 1e4..1e5 after block-Jacobi scaling, and error <= cond * relres.
-    tol = 1e-14 if name.startswith(('posegraph', 'pg')) else 1e-12
-    its, rel = dev.solve_reduced(tol, 2000)
+    # PCG tolerance (preconditioned relative residual): the core's DEFAULT (tolerance 0 = what Options().pcg_tol = None passes,
+    # include/pyslam_hip.h: ps_solve_reduced) -- no per-case choice here.  It is 1e-12 except on pose graphs: stiffness 1e6
+    # (prior) / 31.6 (odometry) / 1 (loop), long chains => cond(M^-1 S) ~ 1e4..1e5 after block-Jacobi scaling, and
+    # error <= cond * relres: 1e-14 there.
+    from pyslam_amd.problem import Options
+    assert Options().pcg_tol is None
+    tol = 1e-14 if lp.num_var_points == 0 else 1e-12       # (what the default resolves to; only the assertion below uses it)
+    its, rel = dev.solve_reduced(Options().pcg_tol or 0., 2000)
     dev.backsub()
     dx = device_dx(dev, lp, pf)
     assert rel <= 10 * tol

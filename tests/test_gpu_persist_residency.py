@@ -1,0 +1,158 @@
+"""Co-residency of the one-launch solvers (k_cg_persist, k_xcg_persist: csrc/ps_core.hip "co-residency", round 6).
+
+Their workgroups wait for one another inside an ordinary launch, so the whole grid must be resident at once.  The core decides
+that from the DEVICE -- compute units the handle's stream may use (device count, the stream's CU mask), occupancy of the very
+instantiation, units held by one-launch solves of other handles of the process (a ledger) -- instead of from a literal, and
+refuses the form up front where it cannot hold: no 20 ms time-out, no silent change of the handle's performance class.
+Reference behaviour at stake: none (the reference has one direct solve, pyslam/problem.py:186); results must not depend on
+which form ran beyond the solver's tolerance."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from pyslam_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    import torch  # noqa: F401  (loads libamdhip64 into the process)
+    for name in ('libamdhip64.so', 'libamdhip64.so.7', 'libamdhip64.so.6'):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            continue
+    pytest.skip('libamdhip64 not loadable through ctypes')
+
+
+def _masked_stream(n_cus):
+    """A stream confined to the `n_cus` lowest compute-unit bits (hipExtStreamCreateWithCUMask)."""
+    hip = _hip()
+    words = (C.c_uint32 * 8)()
+    for b in range(n_cus):
+        words[b >> 5] |= 1 << (b & 31)
+    st = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(8), words)
+    if rc != 0:
+        pytest.skip('hipExtStreamCreateWithCUMask failed ({})'.format(rc))
+    return hip, st
+
+
+def _cold_solve(dev, lp, iters=3):
+    dev.reset_solver_state(); dev.set_params(lp.poses.copy(), lp.points.copy())
+    return [dev.gn_iteration(0.0, 1e-12, 2000, True) for _ in range(iters)]
+
+
+def _same(a, b, tol=1e-10):
+    for x, y in zip(a, b):
+        assert abs(x[0] - y[0]) <= tol * abs(y[0]) and abs(x[2] - y[2]) <= max(1, y[2] // 20), (x, y)
+
+
+def test_the_device_decides_residency_not_a_literal():
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.stereo_ba(num_kf=200, num_lm=12000, obs_per_lm=10, half_window=20, seed=0)
+    dev = DeviceProblem(lp)
+    _cold_solve(dev, lp, 2)
+    info = dev.get_info()
+    import torch
+    assert info['persist_cus'] == torch.cuda.get_device_properties(0).multi_processor_count
+    assert 0 < info['persist_cus_needed'] <= info['persist_cus']
+    assert info['cg_persist_solves'] >= 2 and info['cg_persist_failures'] == 0 and info['cg_persist_refused'] == 0
+    dev.close()
+
+
+def test_under_a_128_cu_mask_c3_keeps_the_one_launch_cg_and_a_1000_keyframe_ba_runs_launch_by_launch_without_a_timeout():
+    """Verdict item 5: C3's shape (58 workgroups, 2-3 per compute unit) is resident on half the chip and keeps the one-launch form;
+    the explicit PCG of a 1 000-keyframe BA needs one compute unit per workgroup (125) -- more than the 64 a masked stream is
+    counted for -- and is refused UP FRONT: zero time-outs, the launch-per-iteration kernels, the same trajectory."""
+    from pyslam_amd.device import DeviceProblem
+    hip, st = _masked_stream(128)
+    try:
+        lp3, _ = synthetic.stereo_ba(num_kf=200, num_lm=50000, obs_per_lm=10, half_window=20, seed=0)      # C3
+        ref = DeviceProblem(lp3); want = _cold_solve(ref, lp3); ref.close()
+        dev = DeviceProblem(lp3, stream=st.value)
+        got = _cold_solve(dev, lp3)
+        info = dev.get_info()
+        assert info['persist_cus'] == 128 and 0 < info['persist_cus_needed'] <= 64
+        assert info['cg_persist_solves'] >= 3 and info['cg_persist_failures'] == 0
+        _same(got, want)
+        dev.close()
+
+        lp1, _ = synthetic.stereo_ba(num_kf=1000, num_lm=60000, obs_per_lm=10, half_window=20, seed=3)
+        ref = DeviceProblem(lp1); want = _cold_solve(ref, lp1); ri = ref.get_info(); ref.close()
+        assert ri['cg_persist_solves'] >= 3 and ri['cg_persist_failures'] == 0          # (the whole chip: one launch per solve)
+        dev = DeviceProblem(lp1, stream=st.value)
+        got = _cold_solve(dev, lp1)
+        info = dev.get_info()
+        assert info['persist_cus'] == 128
+        assert info['cg_persist_solves'] == 0 and info['cg_persist_failures'] == 0      # refused up front, never timed out
+        assert info['cg_kernel_launches'] > 3 * 10                                       # one launch per CG iteration
+        _same(got, want)
+        dev.close()
+    finally:
+        hip.hipStreamDestroy(st)
+
+
+def test_two_handles_solving_at_once_on_two_streams():
+    """Two live handles, two streams, two host threads inside ps_gn_iteration at the same time.  1 500 keyframes each: 188
+    workgroups of the one-launch explicit PCG, one compute unit apiece -- two of them do not fit 256 units together.  The ledger
+    lets one launch hold the units and sends the other solve launch by launch for that call: no time-out on either handle, both
+    trajectories those of the handles solving alone."""
+    import torch
+    from pyslam_amd.device import DeviceProblem
+    lps = [synthetic.stereo_ba(num_kf=1500, num_lm=45000, obs_per_lm=10, half_window=20, seed=s)[0] for s in (11, 12)]
+    alone = []
+    for lp in lps:
+        d = DeviceProblem(lp); alone.append(_cold_solve(d, lp, 4)); d.close()
+    streams = [torch.cuda.Stream() for _ in lps]
+    devs = [DeviceProblem(lp, stream=s.cuda_stream) for lp, s in zip(lps, streams)]
+    out, errs = [None, None], []
+
+    def run(k):
+        try:
+            res = []
+            for rep in range(3):
+                res.append(_cold_solve(devs[k], lps[k], 4))
+            out[k] = res
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    infos = [d.get_info() for d in devs]
+    for k in range(2):
+        assert infos[k]['cg_persist_failures'] == 0, infos[k]
+        for res in out[k]:
+            _same(res, alone[k])
+    # every solve ran one way or the other
+    for k in range(2):
+        assert infos[k]['cg_persist_solves'] + infos[k]['cg_persist_refused'] >= 12
+    for d in devs: d.close()
+
+
+def test_staged_entry_points_refuse_buffers_of_another_point():
+    """round-5 ADVICE: ps_eval_cost (cost summed by the landmark pass) rewrites Z, C^-1, c at the CURRENT parameters; after the
+    parameters moved the staged entry points of the last ps_linearize must not read them silently."""
+    from pyslam_amd.device import DeviceProblem
+    from pyslam_amd._native import NativeError
+    lp, _ = synthetic.stereo_ba(num_kf=12, num_lm=300, obs_per_lm=5, half_window=4, seed=2)
+    dev = DeviceProblem(lp)
+    dev.linearize(0.0)
+    dev.solve_reduced(1e-12, 500)
+    dev.eval_cost(True)                       # same point: the same values are rewritten, nothing stale
+    dev.backsub()
+    c0, _ = dev.landmark_factors()
+    dev.set_params(lp.poses * 1.0, lp.points + 0.01)
+    dev.eval_cost(True)                       # the landmark pass runs at the moved point
+    with pytest.raises(NativeError, match='no longer belong'):
+        dev.backsub()
+    with pytest.raises(NativeError, match='no longer belong'):
+        dev.landmark_factors()
+    dev.linearize(0.0)                        # ... until the point is linearised again
+    dev.solve_reduced(1e-12, 500); dev.backsub()
+    c1, _ = dev.landmark_factors()
+    assert np.abs(c1 - c0).max() > 0
+    dev.close()

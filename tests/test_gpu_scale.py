@@ -271,7 +271,7 @@ def test_c2_full_size_first_steps_match_the_reference_algebra():
     for _ in range(2):
         H, b, _ = orc.normal_equations(cur, points_first=False)       # the oracle at the DEVICE's current parameters
         dx_ref = accurate_sparse_solve(H.tocsr(), b)
-        cost, nrm, its, rel = dev.gn_iteration(0., 1e-14, 4000, True)  # (1e-14: error <= cond(M^-1 S) x relres, as the pose-graph goldens)
+        cost, nrm, its, rel = dev.gn_iteration(0., 0., 4000, True)     # (tolerance 0 = Options().pcg_tol = None: the core's default, 1e-14 on pose graphs)
         assert rel <= 1e-14 and its < 4000                       # the CG converges (it did not before the Ad-aware basis)
         xp, _ = dev.get_dx()
         dx = xp.ravel()                                          # pose-first order, no landmarks: the oracle's order

@@ -267,7 +267,19 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert ctypes.sizeof(_native.ProblemDesc) == 272 and ctypes.sizeof(_native.ProblemInfo) == 152  # gcc sizeof
+    assert ctypes.sizeof(_native.ProblemDesc) == 272 and ctypes.sizeof(_native.ProblemInfo) == 168  # gcc sizeof
+
+
+def test_the_list_of_measurement_switches_is_the_sources_list():
+    """_native.load() warns about measurement switches the product library ignores -- about those the sources read through
+    ps_env(), not about every PS_* variable of the environment (procps' PS_FORMAT ...: round-5 ADVICE)."""
+    from pyslam_amd import _native
+    src = os.path.join(REPO, 'pyslam_amd', 'csrc')
+    found = set()
+    for f in os.listdir(src):
+        found |= set(re.findall(r'ps_env\("(PS_[A-Z0-9_]+)"\)', open(os.path.join(src, f)).read()))
+    assert found == _native._MEASURE_ENV, found ^ _native._MEASURE_ENV
+    assert not (_native._MEASURE_ENV & _native._CREATE_ENV) and 'PS_FORMAT' not in _native._MEASURE_ENV
 
 
 def test_unknown_descriptor_flags_are_rejected_before_anything_is_touched():
