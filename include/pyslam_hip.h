@@ -364,7 +364,7 @@ int ps_debug_table_checksums(ps_problem* h, uint64_t* out, int capacity, int* co
                               Needs every observation on a variable landmark with at most 16 observations, else 0 is what runs
      "cg_persist"         [1] the folded two-level CG in ONE launch (csrc/ps_k_cg_persist.h) where the augmented system fits (<= 2 048
                               unknowns, <= 1 024 tasks); 0: one launch per CG iteration.  "cg_persist_spin" [200000]: passes over the
-                              in-launch exchange before a workgroup gives up -- or 20 ms, whichever comes first -- (then the solve is
+                              in-launch exchange before a workgroup gives up -- or one second, whichever comes first -- (then the solve is
                               repeated launch by launch and the form is not used on the handle any more:
                               ps_problem_info.cg_persist_failures).  The form is only used when its whole grid can be resident on the
                               compute units the handle's stream may use (device count, stream CU mask, occupancy of the kernel:

@@ -84,6 +84,7 @@ int ps_problem_destroy(ps_problem* h) {
     h->arena_release();            // arena block, its pinned mirror and the pinned result words go back to the process-wide pool
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->ev_ldi) { hipEventDestroy(h->ev_ldi); hipEventDestroy(h->ev_ldi_sread); hipEventDestroy(h->ev_ldi_ritz); }
+    if (h->aux) { hipStreamSynchronize(h->aux); if (!ps_pool().give(ps_pool().side_streams, h->aux)) hipStreamDestroy(h->aux); hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); }
     if (h->ldi_stream && !ps_pool().give(ps_pool().side_streams, h->ldi_stream)) hipStreamDestroy(h->ldi_stream);
     if (h->side) { hipStreamSynchronize(h->side); if (!h->side_poolable || !ps_pool().give(ps_pool().side_streams, h->side)) hipStreamDestroy(h->side); hipEventDestroy(h->ev_ac); hipEventDestroy(h->ev_chol); hipEventDestroy(h->ev_acdone); }
     if (h->own_stream && h->stream && !ps_pool().give(ps_pool().streams, h->stream)) hipStreamDestroy(h->stream);

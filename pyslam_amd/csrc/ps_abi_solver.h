@@ -260,7 +260,11 @@ int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters,
     pcg_tol = resolve_pcg_tol(h, pcg_tol);
     if (first && z_of_last_linearize(h, "ps_gn_solve_finish_enqueue")) return -1;
     h->shard_out = true;
-    struct Reset { ps_problem* h; ~Reset() { h->shard_out = false; } } reset{h};
+    // (a caller that drives the collectives itself cannot repeat a solve on ONE rank -- the others have applied their tails and
+    //  wait in the next collective: it gets neither the explicit PCG's one-launch-per-iteration form, whose recurrences may break
+    //  down, nor the one-launch-per-SOLVE forms, whose exchange may time out under a foreign load on the device)
+    h->no_repeat = !(h->nccl_allreduce && h->nccl_comm);
+    struct Reset { ps_problem* h; ~Reset() { h->shard_out = false; h->no_repeat = false; } } reset{h};
     if (first) {
         HIP_OK(hipMemsetAsync(h->scalars + SC_DXP2, 0, sizeof(double), h->stream));
         if (!h->coarse_built && build_coarse(h)) return -1;
@@ -372,6 +376,12 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
             if (wait_published(h)) return -1;
             if (h->h_status[ST_LM_FAIL]) return fail("a landmark block H_ll is not positive definite");
             done = h->h_status[ST_PCG_DONE];
+            if (h->h_status[ST_PERSIST_FAIL])
+                // not a numerical event (those are the same on every rank): THIS rank's one-launch solver did not get its workgroups
+                // resident together within a second.  Solving again here alone would leave the other ranks waiting in a collective
+                return fail("the one-launch CG timed out on this rank (its workgroups were not resident together: is another process using "
+                            "this GPU?); a landmark-sharded iteration cannot be repeated on one rank alone -- run with the options "
+                            "cg_persist 0 and xcg_persist 0 on a shared device");
             if (h->xf_active && done == 2 && !h->h_status[ST_DIAG_FAIL]) {
                 // breakdown of the one-launch form's recurrences (the same on every rank: the solve is replicated): nothing
                 // applied; set the solve up again in the three-launch form
@@ -763,6 +773,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "xcg_restrict_fused") h->xcg_rt = value != 0;
     else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
     else if (n == "lm_packed") h->lm_packed = value != 0;
+    else if (n == "pose_async") h->pose_async = (int)value;
     else if (n == "fuse_cost") h->fuse_cost = (int)value;       // 0 off, 1 on, 2 = in the tails only (not the start cost / ps_eval_cost)
     else if (n == "sync_refactor") h->sync_refactor = value != 0;
     else if (n == "hold_across_steps") h->hold_across_steps = value != 0;

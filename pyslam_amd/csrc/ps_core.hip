@@ -367,6 +367,7 @@ struct ps_problem {
     // ps_get_landmark_factors) belong to the last ps_linearize and refuse when the buffers have since been rewritten at another point
     bool params_moved_since_lin = false;        // a tail / update / upload / restore since the last linearize()
     bool z_foreign = false;                     // ... and a landmark pass ran at the moved point (or under another damping)
+    bool no_repeat = false;                     // the caller drives the collectives itself and cannot repeat a solve: no form that may time out
     long cp_refused = 0;                        // solves that wanted a one-launch form and ran launch by launch instead (not resident)
     void persist_release() { if (persist_held) { ps_persist_ledger().release(persist_dev, persist_held); persist_held = 0; } }
     // compute units a one-launch solve may count on: all of the stream's when it has the whole device; half of a masked stream's
@@ -437,7 +438,11 @@ struct ps_problem {
     // (lmw_nwaves + 1 entries; 0 waves: the 16-lane kernels -- a track longer than 16 observations, or an unobserved landmark)
     int32_t* lmw_first = nullptr;
     int lmw_nwaves = 0;
-    int lm_packed = 1;              // option "lm_packed" 
+    int lm_packed = 1;              // option "lm_packed"
+    // option "pose_async": the pose pass beside the Schur pair kernel (both read what the landmark pass left: nothing of each
+    // other's) -- 1: on a second stream, joined by events in front of the finalisation
+    int pose_async = 0;
+    hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; 
     // lagged dense inverse of the reduced system as the CG preconditioner (ps_k_ldi.h / ps_host_ldi.h)
     int ldi_enable = 1;             // option "lagged_inverse"
     int ldi_max_n = 2048;           // option "ldi_max_unknowns": reduced systems up to this many unknowns

@@ -860,7 +860,7 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
     if (ps_env("PS_CP_CLOCKS") && !h->cp_dbg) { hipMalloc(&h->cp_dbg, 64); hipMemset(h->cp_dbg, 0, 64); }
 #endif
     if (h->cg_persist && h->cp_ok && h->G > 0 && h->cg_lds && !h->cg_split && !h->cg_two_level_reduce &&
-        !h->cg_ablate && h->cg_launched == 0 && h->cg_max_launches > 0 && h->cg_max_launches <= 4090 &&
+        !h->cg_ablate && h->cg_launched == 0 && h->cg_max_launches > 0 && h->cg_max_launches <= 4090 && !h->no_repeat &&
         h->persist_reserve(h->cp_cus_needed)) {          // (refused while launches of other handles hold the units: launch by launch)
         const int nl = h->cg_max_launches;
         if (++h->cp_salt >= (1u << 20)) {                    // (tags are salt * 4096 + iteration: start over on a cleared buffer)
@@ -1049,23 +1049,38 @@ int linearize(ps_problem* h, double lambda, bool allow_prelm) {
     }
     bool fin_in_combine = false, fin_in_pairs = false;
     static const bool schur_split_env = ps_env("PS_SCHUR_SPLIT") != nullptr;      // (measurement build only; read once)
+    // option "pose_async" = 1: the pose pass on a second stream beside the pair kernel, joined in front of the finalisation
+    const bool pose_side = h->pose_async == 1 && h->npitems > 0 && h->npair_items > 0 && h->D == 6 && !(h->pose_mode && h->schur_mode != 0) &&
+                           !h->use_stream && !h->has_diag_tasks && h->schur_pipeline;
+    if (pose_side && !h->aux) {
+        if (!ps_pool().take(ps_pool().side_streams, &h->aux)) HIP_OK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
     if (h->npitems > 0) {
         StageTimer t(h, PS_ST_POSE);
         const ObsWide wp{h->sidx_p, h->stiff_tab};
+        hipStream_t pst = h->stream;
+        if (pose_side) {
+            HIP_OK(hipEventRecord(h->ev_fork, h->stream));       // (the landmark pass -- here or in the previous tail -- is in front of it)
+            HIP_OK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+            pst = h->aux;
+        }
         if (h->wide_obs)
-            hipLaunchKernelGGL(k_pose_pass<true>, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
+            hipLaunchKernelGGL(k_pose_pass<true>, dim3(h->npitems), dim3(256), 0, pst, h->pitems, h->pobs,
                                h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp);
         else
-            hipLaunchKernelGGL(k_pose_pass<false>, dim3(h->npitems), dim3(256), 0, h->stream, h->pitems, h->pobs,
+            hipLaunchKernelGGL(k_pose_pass<false>, dim3(h->npitems), dim3(256), 0, pst, h->pitems, h->pobs,
                                h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp);
+        if (pose_side) HIP_OK(hipEventRecord(h->ev_join, h->aux));
         const bool pose_schur = h->pose_mode && h->schur_mode != 0;
         // tiled Schur: the combine launch also finalizes the poses (unless a task writes a diagonal block)
         fin_in_combine = pose_schur ? h->D == 6
                                     : ((h->Spart || h->use_stream) && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6);
         // untiled Schur with the pipelined pair kernel: its trailing workgroups finalize the poses
         fin_in_pairs = !pose_schur && !h->Spart && !h->use_stream && h->schur_pipeline && h->npair_items > 0 && !h->has_diag_tasks && h->D == 6 &&
-                       !schur_split_env;
-        if (!fin_in_combine && !fin_in_pairs)
+                       !schur_split_env && !pose_side;
+        if (!fin_in_combine && !fin_in_pairs && !pose_side)
             hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
                                h->ppartial, h->diag_slot, lambda, h->S, h->g);
     }
@@ -1117,6 +1132,12 @@ int linearize(ps_problem* h, double lambda, bool allow_prelm) {
         };
         launch_pairs(8 * (halfp / 4), lds_pad, 0, halfp);
         if (split2 && halfp < h->pair_per_xcd) launch_pairs(8 * ((h->pair_per_xcd - halfp + 3) / 4), 0, halfp, h->pair_per_xcd);
+        if (pose_side) {                                     // the pose pass ran beside the pair kernel: its partials are needed from here
+            HIP_OK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            if (!fin_in_combine)
+                hipLaunchKernelGGL(k_pose_finalize, dim3(h->nr), dim3(64), 0, h->stream, h->nr, h->pitem_ptr,
+                                   h->ppartial, h->diag_slot, lambda, h->S, h->g);
+        }
 
         if (h->Spart)
             hipLaunchKernelGGL(k_schur_combine, dim3(cdiv(h->ncomb, 4) + (fin_in_combine ? cdiv(h->nr, 4) : 0)), dim3(256), 0,

@@ -141,7 +141,7 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
         // one launch per SOLVE (ps_k_xcg_persist.h): launch -1 is the first pass of the launch that runs them all (xcg_launch)
         // (long rows only -- bundle adjustment: what the launch saves is the matrix stream of every iteration; with the short rows
         //  of a pose graph there is little to save and the exchange between up to 256 workgroups costs more: 1 500 poses 5.48 -> 5.94 ms)
-        h->xp_defer = h->xcg_persist && h->xp_ok && !h->xf_two && h->xf_pf >= 6 && max_iters + 1 <= 4090 &&
+        h->xp_defer = h->xcg_persist && h->xp_ok && !h->xf_two && h->xf_pf >= 6 && max_iters + 1 <= 4090 && !h->no_repeat &&
                       h->persist_reserve(h->xp_cus_needed);  // (its grid must be resident at once: ps_core.hip, PersistLedger)
         h->cg_max_launches = max_iters + 1;
         if (!h->xp_defer) xcg_launch<D>(h, 0.0, 1);        // launch -1 (cg_launched: -1 -> 0)

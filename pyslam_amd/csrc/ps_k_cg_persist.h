@@ -19,7 +19,7 @@
 // Measured on the chip before it was built (tools/probes/allgather_probe.hip): 2.0-2.7 us per exchange for 32 workgroups of 512
 // threads, whatever their number -- against 5.4 us per launch.  In the kernel: ~4.5 us per CG iteration at C3 (58 workgroups),
 // 3.6 on a 100-pose graph; two instantiations by the number of exchanged sums per thread (6: up to 512 tasks, 12: up to 1 024).
-// Every spin is bounded: a workgroup that does not see its granules within `spin_limit` passes or 20 ms reports a breakdown
+// Every spin is bounded: a workgroup that does not see its granules within `spin_limit` passes or one second reports a breakdown
 // (ST_PCG_DONE = 2, ST_PERSIST_FAIL) and leaves; the host then solves with the launch-per-iteration kernels and stops using
 // this one on the handle.
 // Semantics = the launches k = -1, 0, 1, ... of k_cg_fused_lds: same recurrences (Chronopoulos-Gear), same convergence test,
@@ -31,6 +31,12 @@
 #define PS_CP_NV 4                      // vector entries per thread: n <= PS_CP_NV * PS_CP_NT
 #define PS_CP_NE_MAX 12                 // exchanged sums per thread (template NE: 6 or 12): tasks * D <= NE * PS_CP_NT
 #define PS_CP_MAXN (PS_CP_NV * PS_CP_NT)
+// Wall-clock bound of a spin (wall_clock64: 100 MHz), beside the bound in passes: ONE SECOND.  Round 6 first took the 20 ms
+// k_xcg_persist had: with two PROCESSES on one device (tests/test_gpu_sharded.py: two ranks on one GPU) the scheduler suspends a
+// process's queues for whole time slices, a spin that straddles a slice sees the clock jump by more than that, and one solve in
+// ~5 reported a time-out although every workgroup was resident.  The bound exists so that a grid that can never be resident
+// does not hang the stream, not to police latency: residency is decided up front from the device (ps_core.hip: PersistLedger).
+#define PS_PERSIST_TIMEOUT_TICKS 100000000LL
 #ifndef PS_CP_SLEEP
 #define PS_CP_SLEEP 1                   // s_sleep argument between two unsuccessful passes over the exchange (0: none)
 #endif
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
         {
             double gv[NE];
             bool ok = false;
-            const long long t_enter = (long long)wall_clock64();        // (100 MHz: 2 000 000 ticks = 20 ms, as k_xcg_persist)
+            const long long t_enter = (long long)wall_clock64();        // (bounded in wall-clock time too: PS_PERSIST_TIMEOUT_TICKS)
             for (unsigned spins = 0; !ok; ++spins) {
                 ok = true;
 #pragma unroll
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
                 }
                 ok = __all(ok);
                 if (!ok) {
-                    if (spins > spin_limit || (long long)wall_clock64() - t_enter > 2000000LL) { bad = 1; break; }
+                    if (spins > spin_limit || (long long)wall_clock64() - t_enter > PS_PERSIST_TIMEOUT_TICKS) { bad = 1; break; }
                     if (PS_CP_SLEEP) __builtin_amdgcn_s_sleep(PS_CP_SLEEP);
                     ck[7] += 1;
                 }

@@ -16,7 +16,7 @@
 //     x 6), all partials (2 per workgroup) and all live records (cnt[node] per node) -- one round trip.
 // Same recurrences, same order of the sums as k_xcg_fused1 (launches k = -1, 0, 1, ...), same status / history / scalars.
 // Needs every workgroup resident at once: the one-launch form's own condition (<= 256 workgroups) with one workgroup per compute
-// unit.  A time-out (spin_limit passes, or 20 ms) reports a breakdown + ST_PERSIST_FAIL: the host repeats the solve launch by
+// unit.  A time-out (spin_limit passes, or one second) reports a breakdown + ST_PERSIST_FAIL: the host repeats the solve launch by
 // launch.  Used for long (bundle-adjustment) rows only: on pose graphs there is no matrix stream worth keeping and the exchange
 // between up to 256 workgroups costs more than it saves (1 500 poses: 5.48 -> 5.94 ms per solve).  C4: 355 us per launch for 20-21
 // iterations against 21 launches of 18.7 us.
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
         // ---- 5. gather what the next iteration needs: w of the columns, every workgroup's partials, every live record
         double gs = 0.0, ds = 0.0;
         {
-            const long long t_enter = (long long)wall_clock64();       // (100 MHz: 2 000 000 ticks = 20 ms)
+            const long long t_enter = (long long)wall_clock64();       // (bounded in wall-clock time too: PS_PERSIST_TIMEOUT_TICKS, ps_k_cg_persist.h)
             double rv[PS_XP_NR];
             bool ok = false;
             for (unsigned spins = 0; !ok; ++spins) {
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
                 ok = __all(ok);
                 if (!ok) {
                     // (bounded by TIME as well: with 250 workgroups polling, a pass that fails can take far longer than one that succeeds)
-                    if (spins > spin_limit || (long long)wall_clock64() - t_enter > 2000000LL) { bad = 1; break; }
+                    if (spins > spin_limit || (long long)wall_clock64() - t_enter > PS_PERSIST_TIMEOUT_TICKS) { bad = 1; break; }
                     __builtin_amdgcn_s_sleep(PS_CP_SLEEP);
                 }
             }

@@ -86,7 +86,7 @@ class DeviceProblem:
     def gn_iteration(self, lm_lambda=0., pcg_tol=1e-12, pcg_max_iters=1000, linesearch=True):
         """-> (cost, ||dx||, pcg iterations, pcg relative residual); parameters are updated."""
         cost, nrm, rel, it = C.c_double(), C.c_double(), C.c_double(), C.c_int()
-        nat.check(self._lib.ps_gn_iteration(self._h, lm_lambda, pcg_tol, pcg_max_iters, int(linesearch),
+        nat.check(self._lib.ps_gn_iteration(self._h, lm_lambda, pcg_tol or 0., pcg_max_iters, int(linesearch),
                                             C.byref(cost), C.byref(nrm), C.byref(it), C.byref(rel)))
         return cost.value, nrm.value, it.value, rel.value
 
@@ -147,7 +147,7 @@ class DeviceProblem:
         """Reduced solve + back-substitution + update + cost with one sync.
         -> (shard cost, ||dx_pose||^2, ||dx_point||^2, pcg iterations, relative residual)."""
         c, a, b, rel, it = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int()
-        nat.check(self._lib.ps_gn_solve_finish(self._h, pcg_tol, pcg_max_iters, int(linesearch), C.byref(c),
+        nat.check(self._lib.ps_gn_solve_finish(self._h, pcg_tol or 0., pcg_max_iters, int(linesearch), C.byref(c),
                                                C.byref(a), C.byref(b), C.byref(it), C.byref(rel)))
         return c.value, a.value, b.value, it.value, rel.value
 
@@ -162,7 +162,7 @@ class DeviceProblem:
 
     def gn_solve_finish_enqueue(self, pcg_tol, pcg_max_iters, linesearch, first):
         """No host sync.  Returns True on the final (ungated) pass."""
-        rc = self._lib.ps_gn_solve_finish_enqueue(self._h, pcg_tol, pcg_max_iters, int(linesearch), int(first))
+        rc = self._lib.ps_gn_solve_finish_enqueue(self._h, pcg_tol or 0., pcg_max_iters, int(linesearch), int(first))
         if rc < 0:
             nat.check(rc)
         return rc == 1
@@ -179,7 +179,7 @@ class DeviceProblem:
 
     def solve_reduced(self, tol=1e-12, max_iters=1000):
         rel, it = C.c_double(), C.c_int()
-        nat.check(self._lib.ps_solve_reduced(self._h, tol, max_iters, C.byref(it), C.byref(rel)))
+        nat.check(self._lib.ps_solve_reduced(self._h, tol or 0., max_iters, C.byref(it), C.byref(rel)))
         return it.value, rel.value
 
     def backsub(self):

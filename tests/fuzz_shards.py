@@ -93,6 +93,8 @@ def run_one_rank(n_cases, seed0=0, verbose=True):
             #  round 3's library does the same on those seeds)
             ref.set_option('lagged_inverse', 0)
             sh = ShardedDeviceProblem(lp, dist, native_rccl=native)
+            if sh.native is None:       # a caller that drives the collectives itself cannot repeat a solve on one rank: it never gets
+                ref.set_option('cg_persist', 0); ref.set_option('xcg_persist', 0)      # the one-launch solvers (round 6): same kernels
             for d in (ref, sh.dev):
                 if mode == 'explicit':
                     d.set_option('cg_explicit_min_rows', 0); d.set_option('cg_split_min_rows', 0)

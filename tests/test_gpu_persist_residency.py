@@ -71,18 +71,19 @@ def test_under_a_128_cu_mask_c3_keeps_the_one_launch_cg_and_a_1000_keyframe_ba_r
     hip, st = _masked_stream(128)
     try:
         lp3, _ = synthetic.stereo_ba(num_kf=200, num_lm=50000, obs_per_lm=10, half_window=20, seed=0)      # C3
-        ref = DeviceProblem(lp3); want = _cold_solve(ref, lp3); ref.close()
+        ref = DeviceProblem(lp3); want = _cold_solve(ref, lp3); ri = ref.get_info(); ref.close()
         dev = DeviceProblem(lp3, stream=st.value)
         got = _cold_solve(dev, lp3)
         info = dev.get_info()
         assert info['persist_cus'] == 128 and 0 < info['persist_cus_needed'] <= 64
-        assert info['cg_persist_solves'] >= 3 and info['cg_persist_failures'] == 0
+        # (as many one-launch solves as on the whole chip: a settled third call may take the lagged dense inverse instead)
+        assert info['cg_persist_solves'] == ri['cg_persist_solves'] >= 2 and info['cg_persist_failures'] == 0 and info['cg_persist_refused'] == 0
         _same(got, want)
         dev.close()
 
         lp1, _ = synthetic.stereo_ba(num_kf=1000, num_lm=60000, obs_per_lm=10, half_window=20, seed=3)
         ref = DeviceProblem(lp1); want = _cold_solve(ref, lp1); ri = ref.get_info(); ref.close()
-        assert ri['cg_persist_solves'] >= 3 and ri['cg_persist_failures'] == 0          # (the whole chip: one launch per solve)
+        assert ri['cg_persist_solves'] >= 2 and ri['cg_persist_failures'] == 0          # (the whole chip: one launch per solve)
         dev = DeviceProblem(lp1, stream=st.value)
         got = _cold_solve(dev, lp1)
         info = dev.get_info()
