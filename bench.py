@@ -632,7 +632,7 @@ def main():
                                        if world > 1 else ''),
                        'parallelism': ('landmark-sharded x{} (landmarks cut by first observing pose) + '.format(world) +
                                        ('all-gather of the ranks\' band segments of the reduced pose system, summed in a fixed order'
-                                        if getattr(dev, 'segments', None) is not None else
+                                        if (getattr(dev, 'segments', None) is not None or getattr(dev, 'core_segments', False)) else
                                         'RCCL all-reduce of the reduced pose system (upper triangle)'))
                        if world > 1 else 'single GPU',
                        'timed_region': '{} cold solves from the perturbed start = {} iterations: solver state cleared before each solve '

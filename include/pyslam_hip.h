@@ -114,6 +114,8 @@ typedef struct ps_problem_info {
     int32_t persist_cus;         /* compute units the solver's stream may use as the core found them (device count, the stream's
                                     CU mask, ROC_GLOBAL_CU_MASK; 0: unknown, e.g. HSA_CU_MASK is set: no one-launch form)     */
     int32_t persist_cus_needed;  /* units the one-launch form of this handle needs resident (0: the system does not fit the form) */
+    int64_t landmark_passes_taken_over; /* linearisations that found their landmark pass done: it ran in the previous call's tail
+                                    (or in ps_eval_cost) and summed that cost on its way -- options "expect_next", "fuse_cost"   */
 } ps_problem_info;
 
 enum { PS_NUM_STAGES = 12 };
@@ -280,6 +282,19 @@ int ps_shard_buffer(ps_problem* h, void** dev_ptr);
    the binding, one rank per GPU).  ps_gn_iteration then runs the whole landmark-sharded iteration
    -- both all-reduces included -- on the handle's stream with a single host synchronisation. */
 int ps_set_collective(ps_problem* h, void* nccl_all_reduce_fn, void* nccl_comm);
+/* The exchange of the partial reduced systems as an ALL-GATHER OF SEGMENTS inside the core's one-call sharded iteration (round 6;
+   needs ps_set_collective first -- the second, two-scalar exchange stays an all-reduce).  With landmarks sharded by first observing
+   pose a rank's partial system is non-zero on one band segment of S (C4 on 8 ranks: 3.2 of 23.5 MB): every rank sends
+   [tail words | its elements of the packed buffer of ps_reduce_buffer] once (ncclAllGather, `maxlen` doubles per rank) and adds up
+   what it receives itself -- every destination element over its contributing ranks in RANK ORDER, the same on every rank, so the
+   replicated solve stays bit-identical across ranks.  The plan is the caller's (pyslam_amd/distributed.py: segment_plan, held
+   against a dense sum by the CPU tests): `mine` = this rank's element positions (n_mine); `dst` (n_dst) = every position some
+   rank touches, `src_ptr` (n_dst + 1) / `src_off` = for each of them the offsets rank * maxlen + 3 + k into the gathered buffer,
+   ascending rank.  The three tail words (cost (2), failure flag) are summed over all ranks.  Arrays are copied.
+   nccl_all_gather_fn == NULL: back to the sum all-reduce. */
+int ps_set_segment_exchange(ps_problem* h, void* nccl_all_gather_fn, int32_t world, int32_t rank, int64_t maxlen,
+                            int64_t n_mine, const int64_t* mine, int64_t n_dst, const int64_t* dst, const int64_t* src_ptr,
+                            const int64_t* src_off);
 int ps_gn_solve_finish_enqueue(ps_problem* h, double pcg_tol, int pcg_max_iters, int linesearch, int first);
 int ps_gn_result(ps_problem* h, int* done, double* shard2, double* dx_pose_norm2,
                  int* pcg_iters_out, double* pcg_relres_out);

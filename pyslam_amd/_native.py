@@ -56,7 +56,7 @@ class ProblemInfo(C.Structure):
         ('ldi_solves', C.c_int64), ('ldi_fallbacks', C.c_int64), ('ldi_seeds', C.c_int64),
         ('xcg_fused_solves', C.c_int64), ('xcg_fused_fallbacks', C.c_int64),
         ('cg_persist_solves', C.c_int64), ('cg_persist_failures', C.c_int64), ('cg_persist_refused', C.c_int64),
-        ('persist_cus', C.c_int32), ('persist_cus_needed', C.c_int32),
+        ('persist_cus', C.c_int32), ('persist_cus_needed', C.c_int32), ('landmark_passes_taken_over', C.c_int64),
     ]
 
 
@@ -104,6 +104,8 @@ SIGNATURES = {
     'ps_gn_solve_finish': (C.c_int, [H, C.c_double, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p,
                                      C.POINTER(C.c_int), c_f64p]),
     'ps_set_collective': (C.c_int, [H, C.c_void_p, C.c_void_p]),
+    'ps_set_segment_exchange': (C.c_int, [H, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_int64,
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'ps_shard_buffer': (C.c_int, [H, C.POINTER(C.c_void_p)]),
     'ps_gn_solve_finish_enqueue': (C.c_int, [H, C.c_double, C.c_int, C.c_int, C.c_int]),
     'ps_gn_result': (C.c_int, [H, C.POINTER(C.c_int), c_f64p, c_f64p, C.POINTER(C.c_int), c_f64p]),

@@ -15,6 +15,7 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
     info->cg_persist_solves = h->cp_launches; info->cg_persist_failures = h->cp_failures;
     info->cg_persist_refused = h->cp_refused; info->persist_cus = h->persist_cus;
     info->persist_cus_needed = h->cp_ok ? h->cp_cus_needed : (h->xp_ok ? h->xp_cus_needed : 0);
+    info->landmark_passes_taken_over = h->prelm_used;
     return 0;
 }
 
@@ -238,6 +239,72 @@ int ps_gn_solve_finish(ps_problem* h, double pcg_tol, int pcg_max_iters, int lin
     return 0;
 }
 
+int ps_set_segment_exchange(ps_problem* h, void* nccl_all_gather_fn, int32_t world, int32_t rank, int64_t maxlen,
+                            int64_t n_mine, const int64_t* mine, int64_t n_dst, const int64_t* dst, const int64_t* src_ptr,
+                            const int64_t* src_off) {
+    if (!h) return fail("null argument");
+    if (!nccl_all_gather_fn) { h->seg_allgather = nullptr; return 0; }
+    if (!(h->nccl_allreduce && h->nccl_comm)) return fail("ps_set_segment_exchange: call ps_set_collective first");
+    if (ensure_shard_pack(h)) return -1;
+    const int64_t T = 3, body = h->pack_count - T;
+    if (world < 1 || rank < 0 || rank >= world || n_mine < 0 || n_dst < 0 || maxlen < T + n_mine || (n_mine && !mine) ||
+        (n_dst && (!dst || !src_ptr || !src_off)))
+        return fail("ps_set_segment_exchange: inconsistent plan");
+    // every index is checked here, once: a plan made for another block pattern would scatter into the wrong slots silently
+    for (int64_t k = 0; k < n_mine; ++k) if (mine[k] < 0 || mine[k] >= body) return fail("ps_set_segment_exchange: an element of this rank lies outside [upper(S) | g]");
+    for (int64_t k = 0; k < n_dst; ++k) {
+        if (dst[k] < 0 || dst[k] >= body || src_ptr[k + 1] < src_ptr[k]) return fail("ps_set_segment_exchange: bad destination table");
+        for (int64_t q = src_ptr[k]; q < src_ptr[k + 1]; ++q) {
+            const int64_t r = src_off[q] / maxlen, o = src_off[q] % maxlen;
+            if (src_off[q] < 0 || r >= world || o < T || (q > src_ptr[k] && src_off[q] / maxlen <= src_off[q - 1] / maxlen))
+                return fail("ps_set_segment_exchange: bad source table (offsets must be rank * maxlen + 3 + k, ascending rank)");
+        }
+    }
+    if (n_dst && src_ptr[0] != 0) return fail("ps_set_segment_exchange: src_ptr must start at 0");
+    const std::vector<int64_t> vm(mine, mine + n_mine), vd(dst, dst + n_dst), vp(src_ptr, src_ptr + (n_dst ? n_dst + 1 : 0)),
+                               vo(src_off, src_off + (n_dst ? src_ptr[n_dst] : 0));
+    if (h->upload(&h->seg_mine, vm) || h->upload(&h->seg_dst, vd) || h->upload(&h->seg_src_ptr, vp) || h->upload(&h->seg_src_off, vo) ||
+        h->alloc(&h->seg_in, (size_t)maxlen) || h->alloc(&h->seg_all, (size_t)maxlen * world)) return -1;
+    h->seg_world = world; h->seg_rank = rank; h->seg_maxlen = maxlen; h->seg_nmine = n_mine; h->seg_ndst = n_dst;
+    h->seg_allgather = (ps_problem::allgather_fn)nccl_all_gather_fn;
+    return 0;
+}
+
+// [upper(S) | g | cost | flag] summed over the ranks: one all-reduce of the whole packed buffer between k_shard_pack and
+// k_shard_unpack, or (round 6) the all-gather of the ranks' segments, read from and summed into S / g / cost / status directly
+static int exchange_reduced_system(ps_problem* h) {
+    enum { NCCL_F64 = 8, NCCL_SUM = 0 };
+    if (!h->seg_allgather) {
+        { StageTimer tpk(h, PS_ST_PACK); if (ps_shard_pack(h)) return -1; }
+        {
+            StageTimer tar(h, PS_ST_ALLREDUCE);
+            if (h->nccl_allreduce(h->shard_pack, h->shard_pack, (size_t)h->pack_count, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
+                return fail("ncclAllReduce of the reduced system failed");
+        }
+        { StageTimer tpk(h, PS_ST_PACK); if (ps_shard_unpack(h)) return -1; }
+        return 0;
+    }
+    h->prelin_valid = h->prelm_valid = false;            // (as ps_shard_unpack: S and g are overwritten with the summed system)
+    const long T = 3, ntail = (long)h->nr * h->D + 2;
+    const unsigned nb1 = (unsigned)std::min<long>(2048, cdiv(h->seg_maxlen, 256)), nb2 = (unsigned)std::min<long>(4096, cdiv(h->seg_ndst + T, 256));
+    {
+        StageTimer tpk(h, PS_ST_PACK);
+        if (h->D == 6) hipLaunchKernelGGL(k_seg_pack<6>, dim3(nb1), dim3(256), 0, h->stream, h->nup, h->up_slot, h->S, ntail, h->g, h->status, T, h->seg_nmine, h->seg_mine, h->seg_in, h->seg_maxlen);
+        else hipLaunchKernelGGL(k_seg_pack<3>, dim3(nb1), dim3(256), 0, h->stream, h->nup, h->up_slot, h->S, ntail, h->g, h->status, T, h->seg_nmine, h->seg_mine, h->seg_in, h->seg_maxlen);
+    }
+    {
+        StageTimer tar(h, PS_ST_ALLREDUCE);
+        if (h->seg_allgather(h->seg_in, h->seg_all, (size_t)h->seg_maxlen, NCCL_F64, h->nccl_comm, h->stream))
+            return fail("ncclAllGather of the reduced system's segments failed");
+    }
+    {
+        StageTimer tpk(h, PS_ST_PACK);
+        if (h->D == 6) hipLaunchKernelGGL(k_seg_sum<6>, dim3(nb2), dim3(256), 0, h->stream, h->seg_ndst, h->seg_dst, h->seg_src_ptr, h->seg_src_off, h->seg_all, T, h->seg_world, h->seg_maxlen, h->nup, h->up_slot, h->upT_slot, h->S, ntail, h->g, h->status);
+        else hipLaunchKernelGGL(k_seg_sum<3>, dim3(nb2), dim3(256), 0, h->stream, h->seg_ndst, h->seg_dst, h->seg_src_ptr, h->seg_src_off, h->seg_all, T, h->seg_world, h->seg_maxlen, h->nup, h->up_slot, h->upT_slot, h->S, ntail, h->g, h->status);
+    }
+    return 0;
+}
+
 int ps_set_collective(ps_problem* h, void* nccl_all_reduce_fn, void* nccl_comm) {
     if (!h) return fail("null argument");
     h->nccl_allreduce = (ps_problem::allreduce_fn)nccl_all_reduce_fn;
@@ -351,15 +418,18 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
         if (h->nr == 0 || h->pcg_variant != 1) return fail("the sharded iteration needs the fused CG and a reduced system");
         enum { NCCL_F64 = 8, NCCL_SUM = 0 };
         StageTimer total(h, PS_ST_TOTAL, 2);
-        if (linearize(h, lambda)) return -1;
-        // ONE sum over ranks of [upper(S) | g | cost | failure flag]
-        { StageTimer tpk(h, PS_ST_PACK); if (ps_shard_pack(h)) return -1; }
-        {
-            StageTimer tar(h, PS_ST_ALLREDUCE);
-            if (h->nccl_allreduce(h->shard_pack, h->shard_pack, (size_t)h->pack_count, NCCL_F64, NCCL_SUM, h->nccl_comm, h->stream))
-                return fail("ncclAllReduce of the reduced system failed");
+        // (round 6: as on one GPU, the landmark pass of this point may have run in the previous call's tail, summing that call's
+        //  cost on its way -- every observation evaluated once per iteration on the shards too)
+        if (linearize(h, lambda, true)) return -1;
+        h->lmfail_check = h->lin_lmfail_tag;
+        if (h->lin_lmfail_tag && *reinterpret_cast<volatile long long*>(h->h_lmfail + (h->lin_lmfail_tag & 1)) == h->lin_lmfail_tag) {
+            // a landmark block that was not positive definite in the pass run ahead (the host has seen its word: the previous call
+            // waited behind it): into the device status word NOW, so that the flag travels with the exchange and EVERY rank fails
+            // this call -- a rank that gave up alone would leave the others waiting in the next collective
+            HIP_OK(hipMemsetD32Async((hipDeviceptr_t)(h->status + ST_LM_FAIL), 1, 1, h->stream));
         }
-        { StageTimer tpk(h, PS_ST_PACK); if (ps_shard_unpack(h)) return -1; }
+        // ONE exchange over ranks of [upper(S) | g | cost | failure flag]
+        if (exchange_reduced_system(h)) return -1;
         int first = 1, done = 0;
         double sb[2] = {0.0, 0.0}, dxp2 = 0.0;
         for (;;) {
@@ -394,6 +464,10 @@ static int gn_iteration_impl(ps_problem* h, double lambda, double pcg_tol, int p
             if (done && h->xcg_ref_pending) { h->xcg_ref_pending = false; h->xcg_its_ref = h->last_pcg_iters; }   // (coarse_adaptive_hold)
             if (done || last) break;
             first = 0;
+        }
+        if (h->prelm_pending) {                              // the tail ran the next linearisation's landmark pass in place of the cost pass
+            h->prelm_pending = false;
+            h->prelm_valid = h->h_status[ST_PCG_DONE] == 1 && !h->h_status[ST_LM_FAIL] && !h->h_status[ST_DIAG_FAIL];
         }
         if (cost_out) *cost_out = sb[0];
         if (dx_norm_out) *dx_norm_out = std::sqrt(dxp2 + sb[1]);

@@ -426,6 +426,14 @@ struct ps_problem {
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     allreduce_fn nccl_allreduce = nullptr;
     void* nccl_comm = nullptr;
+    // segment exchange inside the core (round 6, ps_set_segment_exchange): ncclAllGather of [tail | this rank's elements of the packed
+    // system], then every destination element summed over its contributors in RANK order (the same on every rank)
+    typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+    allgather_fn seg_allgather = nullptr;
+    int seg_world = 0, seg_rank = 0;
+    long seg_maxlen = 0, seg_nmine = 0, seg_ndst = 0;
+    int64_t *seg_mine = nullptr, *seg_dst = nullptr, *seg_src_off = nullptr, *seg_src_ptr = nullptr;
+    double *seg_in = nullptr, *seg_all = nullptr;
     // sharded exchange buffer [upper(S) | g | cost | flag] (k_shard_pack / k_shard_unpack), built on first use
     double* shard_pack = nullptr;
     int32_t *up_slot = nullptr, *upT_slot = nullptr;

@@ -1270,8 +1270,11 @@ int apply_update(ps_problem* h, double step, const int32_t* gate = nullptr, bool
 
 // ---- the robust cost summed by the landmark pass itself (k_landmark_pass_packed<.., COST>, ps_k_packed.h) --------------------
 // every observation must be in the packed pass's runs (no observation of a constant point); factors add their own partials
+// (a landmark shard: only in the core's own sharded iteration -- ps_set_collective --, which takes the pass over in its next
+//  linearisation and carries a failure found ahead through the exchange; a caller that drives the collectives itself keeps the
+//  cost-only pass)
 inline bool lm_cost_possible(const ps_problem* h) {
-    return cost_packed_possible(h) && !h->shard_out && !(h->nccl_allreduce && h->nccl_comm);
+    return cost_packed_possible(h) && (!h->shard_out || (h->nccl_allreduce && h->nccl_comm));
 }
 // enqueue it at the current parameters; -> number of partials in cost_partials.  Leaves Z, C^-1, c of this point behind:
 // the caller decides whether that makes prelm_valid (an ungated launch) or prelm_pending (a gated tail).
@@ -1331,7 +1334,7 @@ int gn_tail(ps_problem* h, int linesearch, const int32_t* gate, bool publish = f
     // its landmark pass runs here, gated like the rest of the tail, and sums the cost as it goes -- every observation is
     // evaluated once instead of twice (C3: the 11-14 us of the cost pass; C4: 75).  Needs every observation in the packed
     // landmark pass's runs (no observation of a constant point) and the published end of the iteration.
-    const bool lm_cost = fused && publish && h->expect_next && lm_cost_possible(h);
+    const bool lm_cost = fused && (publish || (h->shard_out && h->nccl_allreduce && h->nccl_comm)) && h->expect_next && lm_cost_possible(h);
     if (lm_cost) {
         ncost = lm_cost_enqueue(h, h->lin_lambda, gate);
         h->prelm_pending = true;

@@ -748,6 +748,57 @@ __global__ __launch_bounds__(256) void k_shard_pack(
     }
 }
 
+// ---- segment exchange (ps_set_segment_exchange): [tail words | this rank's elements of the packed system], read straight from
+// S / g / cost / status at the packed positions (k_shard_pack's layout: the upper blocks in up_slot order, then g, cost (2), the flag)
+// -- no pass over the whole 23.5 MB buffer when a rank owns an eighth of it ...
+template <int D>
+__global__ __launch_bounds__(256) void k_seg_pack(long nup, const int32_t* __restrict__ up_slot, const double* __restrict__ S,
+                                                  long ntail, const double* __restrict__ tail /* g | cost */, const int32_t* __restrict__ status,
+                                                  long T, long nmine, const int64_t* __restrict__ mine, double* __restrict__ seg_in, long maxlen)
+{
+    constexpr int DD = D * D;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < maxlen; t += (long)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (t < T) v = t < 2 ? tail[ntail - 2 + t] : (status[ST_LM_FAIL] != 0 ? 1.0 : 0.0);
+        else if (t - T < nmine) {
+            const long p = mine[t - T];
+            v = p < nup * DD ? S[(size_t)up_slot[p / DD] * DD + p % DD] : tail[p - nup * DD];
+        }
+        seg_in[t] = v;
+    }
+}
+// ... and the sum of what the ranks sent, written where k_shard_unpack would put it (both triangles of S, g, cost, the flag): every
+// destination element over its contributors in rank order (no atomics: one thread per destination, a fixed order -- the same number
+// on every rank), the tail words over all ranks
+template <int D>
+__global__ __launch_bounds__(256) void k_seg_sum(long ndst, const int64_t* __restrict__ dst, const int64_t* __restrict__ src_ptr,
+                                                 const int64_t* __restrict__ src_off, const double* __restrict__ seg_all,
+                                                 long T, int world, long maxlen, long nup, const int32_t* __restrict__ up_slot,
+                                                 const int32_t* __restrict__ upT_slot, double* __restrict__ S, long ntail,
+                                                 double* __restrict__ tail, int32_t* __restrict__ status)
+{
+    constexpr int DD = D * D;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ndst + T; t += (long)gridDim.x * blockDim.x) {
+        double v = 0.0;
+        if (t < ndst) {
+            for (int64_t k = src_ptr[t]; k < src_ptr[t + 1]; ++k) v += seg_all[src_off[k]];
+            const long p = dst[t];
+            if (p < nup * DD) {
+                const long b = p / DD;
+                const int e = (int)(p % DD), r = e / D, c = e % D;
+                const int s1 = up_slot[b], s2 = upT_slot[b];
+                S[(size_t)s1 * DD + e] = v;
+                if (s2 != s1) S[(size_t)s2 * DD + c * D + r] = v;
+            } else tail[p - nup * DD] = v;
+        } else {
+            const long w = t - ndst;
+            for (int r = 0; r < world; ++r) v += seg_all[(size_t)r * maxlen + w];
+            if (w < 2) tail[ntail - 2 + w] = v;
+            else if (v != 0.0) status[ST_LM_FAIL] = 1;          // some shard's H_ll was not positive definite
+        }
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void k_shard_unpack(
     long nup, const int32_t* __restrict__ up_slot, const int32_t* __restrict__ upT_slot,

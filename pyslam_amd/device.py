@@ -155,6 +155,13 @@ class DeviceProblem:
         """Native RCCL: ps_gn_iteration then performs the sharded iteration incl. both all-reduces."""
         nat.check(self._lib.ps_set_collective(self._h, C.c_void_p(allreduce_fn_ptr), C.c_void_p(comm_ptr)))
 
+    def set_segment_exchange(self, allgather_fn_ptr, world, rank, maxlen, mine, dst, src_ptr, src_off):
+        """The core's own segment exchange (include/pyslam_hip.h: ps_set_segment_exchange; plan: distributed.segment_plan)."""
+        a = [np.ascontiguousarray(x, dtype=np.int64) for x in (mine, dst, src_ptr, src_off)]
+        p64 = lambda x: x.ctypes.data_as(C.POINTER(C.c_int64))
+        nat.check(self._lib.ps_set_segment_exchange(self._h, C.c_void_p(allgather_fn_ptr), int(world), int(rank), int(maxlen),
+                                                    int(a[0].size), p64(a[0]), int(a[1].size), p64(a[1]), p64(a[2]), p64(a[3])))
+
     def shard_buffer(self):
         ptr = C.c_void_p()
         nat.check(self._lib.ps_shard_buffer(self._h, C.byref(ptr)))

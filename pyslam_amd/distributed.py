@@ -140,6 +140,28 @@ def packed_layout(pattern_keys, nr, dof):
     return indices, tail
 
 
+def segment_plan(idx_lists, tail_len=3):
+    """The summation plan of the segment exchange as the core runs it (include/pyslam_hip.h: ps_set_segment_exchange).
+    idx_lists[r] = the element positions rank r sends (in the packed buffer [upper(S) | g | tail]); every rank's buffer in the
+    gathered array is [tail words | its elements | padding] of `maxlen` doubles.  -> (maxlen, dst, src_ptr, src_off): every
+    position some rank touches, and for each the offsets r * maxlen + tail_len + k of its contributions in ASCENDING RANK order --
+    the order every rank adds them up in, hence bit-identical sums everywhere.  Pure numpy: the CPU tests hold it against a
+    dense sum (tests/test_distributed_cpu.py)."""
+    lens = [int(i.size) for i in idx_lists]
+    maxlen = tail_len + (max(lens) if lens else 0)
+    if not lens or sum(lens) == 0:
+        return maxlen, np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int64)
+    pos = np.concatenate([np.asarray(i, dtype=np.int64) for i in idx_lists])
+    off = np.concatenate([r * maxlen + tail_len + np.arange(n, dtype=np.int64) for r, n in enumerate(lens)])
+    for r, i in enumerate(idx_lists):
+        if np.unique(i).size != i.size:
+            raise ValueError('segment_plan: rank {} lists an element twice'.format(r))
+    order = np.argsort(pos, kind='stable')               # stable: equal positions stay in rank order (the lists are concatenated by rank)
+    pos, off = pos[order], off[order]
+    first = np.flatnonzero(np.concatenate([[True], pos[1:] != pos[:-1]]))
+    return maxlen, pos[first], np.concatenate([first, [pos.size]]).astype(np.int64), off
+
+
 class SegmentExchange:
     """Round 5: the exchange of the partial reduced systems as an ALL-GATHER OF SEGMENTS instead of a sum all-reduce of
     the whole buffer.  With landmarks sharded by first observing pose (landmark_owner_lists) a rank's partial system is
@@ -236,6 +258,7 @@ class NativeRccl:
         if rc != 0:
             raise RuntimeError('ncclCommInitRank failed: {}'.format(rc))
         self.allreduce_ptr = C.cast(self.lib.ncclAllReduce, C.c_void_p).value
+        self.allgather_ptr = C.cast(self.lib.ncclAllGather, C.c_void_p).value
         try:
             self.self_check(dist)
         except Exception:
@@ -326,8 +349,6 @@ class ShardedDeviceProblem:
         self.exchange = exchange or os.environ.get('PYSLAM_AMD_EXCHANGE', 'allreduce')
         if self.exchange not in ('allreduce', 'segments'):
             raise ValueError("exchange must be 'allreduce' or 'segments'")
-        if self.exchange == 'segments':
-            native_rccl = False                              # (the core's own iteration knows the sum all-reduce only)
         mine = pose_pair_keys(lp_shard)
         gathered = [None] * self.world
         dist.all_gather_object(gathered, mine)
@@ -373,6 +394,7 @@ class ShardedDeviceProblem:
         self._scal = torch.zeros(2, dtype=torch.float64, device=self.dev.reduce_tensor.device)
         self._prof_level, self._pending_events, self._host_stage = 0, [], {}
         self.segments = None
+        self.core_segments = False
         if self.exchange == 'segments':
             touch = [None] * self.world
             dist.all_gather_object(touch, shard_touch(lp_shard))
@@ -380,7 +402,26 @@ class ShardedDeviceProblem:
                 indices, tail = self.dev.segment_layout()
             else:
                 indices, tail = packed_layout(union, lp_shard.num_reduced, lp_shard.dof)
-            self.segments = SegmentExchange(dist, torch, self.dev.reduce_tensor, [indices(b, p) for b, p in touch], tail)
+            idx_lists = [indices(b, p) for b, p in touch]
+            self._seg_idx_lists, self._seg_tail = idx_lists, tail
+            if self.native is not None and hasattr(self.dev, 'set_segment_exchange'):
+                self.enable_core_segments(self.native.allgather_ptr)
+            else:
+                self.segments = SegmentExchange(dist, torch, self.dev.reduce_tensor, idx_lists, tail)
+                self.segment_bytes = (self.segments.bytes_sent, self.segments.bytes_allreduce)
+
+    def enable_core_segments(self, allgather_fn_ptr):
+        """Round 6: the core's one-call iteration does the segment exchange itself (ncclAllGather -- or a stand-in with its
+        signature -- on the solver's stream + the fixed-order sum: include/pyslam_hip.h ps_set_segment_exchange); no torch launches
+        in the iteration.  Needs exchange='segments' and the core's collective path (ps_set_collective) set."""
+        idx_lists, tail = self._seg_idx_lists, self._seg_tail
+        if int(tail.max()) + 1 != int(self.dev.reduce_tensor.numel()):
+            raise ValueError('the packed layout ends at element {} but the core\'s exchange buffer holds {}'.format(
+                int(tail.max()) + 1, int(self.dev.reduce_tensor.numel())))
+        maxlen, dst, src_ptr, src_off = segment_plan(idx_lists, int(tail.size))
+        self.dev.set_segment_exchange(allgather_fn_ptr, self.world, self.rank, maxlen, idx_lists[self.rank], dst, src_ptr, src_off)
+        self.core_segments, self.segments = True, None
+        self.segment_bytes = (8 * (int(tail.size) + int(idx_lists[self.rank].size)), 8 * int(self.dev.reduce_tensor.numel()))
 
     # ---- iteration -----------------------------------------------------
     def eval_cost(self, include_all_constant=True):
@@ -437,6 +478,12 @@ class ShardedDeviceProblem:
     def set_solve_horizon(self, n):
         if hasattr(self.dev, 'set_solve_horizon'):
             self.dev.set_solve_horizon(n)
+
+    def set_expect_next(self, flag):
+        """What the caller's loop knows about its next call (pyslam_amd.problem.device_solve): the core's own sharded iteration
+        then runs the successor's landmark pass in its tail and sums the cost on its way, as on one GPU (round 6)."""
+        if self.native is not None and hasattr(self.dev, 'set_expect_next'):
+            self.dev.set_expect_next(flag)
 
     def get_params(self):
         return self.dev.get_params()
@@ -555,6 +602,9 @@ class ShardedProblemView:
 
     def set_solve_horizon(self, n):
         self.sharded.set_solve_horizon(n)
+
+    def set_expect_next(self, flag):
+        self.sharded.set_expect_next(flag)
 
     # ---- hot path ----------------------------------------------------------
     def eval_cost(self, include_all_constant=True):

@@ -301,3 +301,45 @@ def test_problem_solve_routes_to_the_sharded_driver():
     from pyslam_amd.lowering import pose_rows_to_matrices
     assert np.abs(poses - pose_rows_to_matrices(final.poses, 6)).max() < 1e-8
     assert np.abs(points - final.points).max() < 1e-8
+
+
+def test_segment_plan_sums_like_a_dense_all_reduce_in_rank_order():
+    """The plan the core's segment exchange runs (include/pyslam_hip.h: ps_set_segment_exchange; pyslam_amd.distributed.segment_plan),
+    emulated with numpy: k_seg_pack on every rank, the all-gather, k_seg_sum -- against the dense sum of the ranks' packed buffers,
+    with every destination's contributions taken in ascending rank order (what makes the sum the same number on every rank)."""
+    from pyslam_amd.distributed import segment_plan
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 3, 8):
+        n, T = 5000, 3                                        # packed buffer: n body elements + 3 tail words
+        idx = []
+        for r in range(world):                                # overlapping windows, as landmark shards of a trajectory give
+            lo = int(n * r / world * 0.9); hi = min(n, lo + int(n / world * 1.6) + 1)
+            idx.append(np.sort(rng.choice(np.arange(lo, hi), size=(hi - lo) * 3 // 4, replace=False)).astype(np.int64))
+        maxlen, dst, src_ptr, src_off = segment_plan(idx, T)
+        assert maxlen == T + max(i.size for i in idx) and src_ptr[0] == 0 and src_ptr[-1] == src_off.size == sum(i.size for i in idx)
+        assert np.array_equal(dst, np.unique(np.concatenate(idx)))
+        packs = []
+        for r in range(world):
+            p = np.zeros(n + T); p[idx[r]] = rng.standard_normal(idx[r].size) * 10.0 ** rng.integers(-6, 6, idx[r].size)
+            p[n:] = rng.standard_normal(T); packs.append(p)
+        seg_all = np.zeros(world * maxlen)
+        for r in range(world):                                # k_seg_pack + all-gather
+            seg_all[r * maxlen:r * maxlen + T] = packs[r][n:]
+            seg_all[r * maxlen + T:r * maxlen + T + idx[r].size] = packs[r][idx[r]]
+        for me in range(world):                               # k_seg_sum on rank `me`: into ITS packed buffer
+            out = packs[me].copy()
+            for k in range(dst.size):
+                v = 0.0
+                ranks = []
+                for q in range(src_ptr[k], src_ptr[k + 1]):
+                    v += seg_all[src_off[q]]; ranks.append(src_off[q] // maxlen)
+                assert ranks == sorted(ranks) and len(set(ranks)) == len(ranks)
+                out[dst[k]] = v
+            for w in range(T):
+                out[n + w] = sum(seg_all[r * maxlen + w] for r in range(world))
+            ref = np.zeros(n + T)
+            for r in range(world):                            # the dense sum, in rank order
+                ref += packs[r]
+            assert np.array_equal(out, ref), (world, me)
+    with pytest.raises(ValueError):
+        segment_plan([np.array([1, 1, 2], dtype=np.int64)], 3)

@@ -72,7 +72,7 @@ def test_one_rank_segment_exchange_is_the_identity(dist1):
     ref = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
     ref.set_option('lagged_inverse', 0)
     ref.set_option('cg_persist', 0); ref.set_option('xcg_persist', 0)      # (as the torch-driven sharded iteration: see above)
-    sh = ShardedDeviceProblem(lp, dist1, exchange='segments')
+    sh = ShardedDeviceProblem(lp, dist1, exchange='segments', native_rccl=False)       # (the torch-driven exchange)
     assert sh.native is None and sh.segments is not None
     for _ in range(3):
         a = ref.gn_iteration(0., 1e-12, 1000, True)
@@ -83,6 +83,34 @@ def test_one_rank_segment_exchange_is_the_identity(dist1):
     assert np.array_equal(pa, pb) and np.array_equal(la, lb)
     sh.close()
     ref.close()
+
+
+def test_one_rank_core_segment_exchange_is_the_identity(dist1):
+    """Round 6: exchange='segments' inside the core's own sharded iteration (ps_set_segment_exchange: k_seg_pack, ncclAllGather over
+    the native communicator, k_seg_sum in rank order) with one rank: the iterations are the unsharded ones bit for bit, and the
+    cost rides on the successor's landmark pass as on one GPU (option expect_next)."""
+    import torch
+    from pyslam_amd.device import DeviceProblem
+    from pyslam_amd.distributed import ShardedDeviceProblem
+    lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=4000, obs_per_lm=6, half_window=8, seed=3)
+    for expect in (False, True):
+        ref = DeviceProblem(lp, stream=torch.cuda.current_stream().cuda_stream)
+        ref.set_option('lagged_inverse', 0)
+        sh = ShardedDeviceProblem(lp, dist1, exchange='segments')
+        assert sh.native is not None and sh.core_segments and sh.segments is None
+        for d in (ref, sh):
+            d.set_expect_next(expect)
+        for _ in range(3):
+            a = ref.gn_iteration(0., 1e-12, 1000, True)
+            b = sh.gn_iteration(0., 1e-12, 1000, True)
+            assert a[0] == b[0] and a[2] == b[2]
+        pa, la = ref.get_params()
+        pb, lb = sh.get_params()
+        assert np.array_equal(pa, pb) and np.array_equal(la, lb)
+        if expect:
+            assert sh.dev.get_info()['landmark_passes_taken_over'] >= 2          # the cost rode on the next landmark pass on the shard too
+        sh.close()
+        ref.close()
 
 
 def _two_rank_worker(rank, world, port, out, native, exchange='allreduce'):
@@ -98,7 +126,7 @@ def _two_rank_worker(rank, world, port, out, native, exchange='allreduce'):
     lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=4000, obs_per_lm=6, half_window=8, seed=3)                 #  collective, not the suite)
     sp = ShardedDeviceProblem(shard_landmarks(lp, rank, world), dist, native_rccl=False, exchange=exchange)
     if exchange == 'segments':
-        assert sp.segments.bytes_sent < 0.8 * sp.segments.bytes_allreduce      # a band segment, not the whole system
+        assert sp.segment_bytes[0] < 0.8 * sp.segment_bytes[1]                  # a band segment, not the whole system
     if native:
         # drive the core's OWN collective path (ps_set_collective: ps_gn_iteration issues both all-reduces
         # itself) with a stand-in for ncclAllReduce that sums over gloo -- same signature, in place
@@ -111,6 +139,17 @@ def _two_rank_worker(rank, world, port, out, native, exchange='allreduce'):
         cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)(all_reduce)
         sp.dev.set_collective(C.cast(cb, C.c_void_p).value, 1)
         sp.native = type('Standin', (), {'close': lambda self: None, 'keep': cb})()
+        if exchange == 'segments':
+            # ... and the core's own SEGMENT exchange (round 6, ps_set_segment_exchange) with a stand-in for ncclAllGather
+            def all_gather(send, recv, count, dtype, comm, stream):
+                src = torch.as_tensor(_RawDeviceArray(send, count), device='cuda')
+                dst = torch.as_tensor(_RawDeviceArray(recv, count * world), device='cuda')
+                dist.all_gather(list(dst.view(world, count).unbind(0)), src)
+                return 0
+            cg = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)(all_gather)
+            sp.native.keep2 = cg
+            sp.enable_core_segments(C.cast(cg, C.c_void_p).value)
+            assert sp.core_segments and sp.segments is None
     trace = [sp.eval_cost(True)]
     for _ in range(3):
         trace.append(sp.gn_iteration(0., 1e-12, 1000, True))
@@ -122,7 +161,7 @@ def _two_rank_worker(rank, world, port, out, native, exchange='allreduce'):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('native,exchange', [(False, 'allreduce'), (True, 'allreduce'), (False, 'segments')])
+@pytest.mark.parametrize('native,exchange', [(False, 'allreduce'), (True, 'allreduce'), (False, 'segments'), (True, 'segments')])
 def test_two_ranks_on_one_gpu_reproduce_the_unsharded_iterations(native, exchange):
     """world_size 2 with the real HIP core in both ranks (one GPU, gloo collectives): sharded linearisation,
     all-reduce of [S | g | cost], replicated reduced solve, shard-local tail, all-reduce of the shard scalars."""
