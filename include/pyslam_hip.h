@@ -432,6 +432,17 @@ int ps_sparse_normal_direct(int32_t m, int32_t n, const int32_t* j_row_ptr, cons
  * Stands in for the coarse-level part of scipy.sparse.linalg.spsolve (reference pyslam/problem.py:186); test and measurement entry. */
 int ps_debug_band_inverse(const double* a, int32_t ncb, int32_t dof, int32_t bw, int32_t chunk_nodes, float* ainv_out,
                           double* elapsed_us);
+/* Stress entry behind DESIGN.md section 3 "side stream" (round 6; test and measurement infrastructure): the coarse level's
+ * factorisation kernels run `launches` times on a stream of their own -- lowest priority if `lowprio` -- while, if `aggressor`,
+ * streaming copy kernels keep an ordinary stream busy; every output is compared bit for bit with one produced on an idle device.
+ * mode 0: serial band walk (k_band_chol + k_band_inverse_rl); 1: partitioned band factorisation (BandPart); 2: dense LDS-resident
+ * k_coarse_chol + k_xcg_ainv (ncb dof <= 90); 3: the same with its matrices in global scratch; + 8: the input is produced on the
+ * same stream by a copy kernel in front of every factorisation (the buffer holds 2 A before); + 16: with an event recorded in
+ * between.  `a` as ps_debug_band_inverse.
+ * -> n_diff: launches whose fp32 inverse differs from the reference in any bit; n_pivot: launches that reported a non-positive
+ * pivot on this positive definite input.  A kernel that is a function of its input gives 0 / 0 whatever runs beside it. */
+int ps_debug_factor_stress(const double* a, int32_t ncb, int32_t dof, int32_t bw, int32_t mode, int32_t launches, int32_t lowprio,
+                           int32_t aggressor, int32_t* n_diff, int32_t* n_pivot);
 
 /* Frame-to-frame RANSAC, the step before the motion-only solve in the reference's sparse VO pipeline
    (pyslam/pipelines/sparse.py:148-150).  Stateless; host pointers in, host pointers out.

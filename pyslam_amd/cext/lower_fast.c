@@ -13,10 +13,36 @@
 #include <Python.h>
 #include <stdint.h>
 #include <string.h>
+/* Round 6: block.obs through the numpy C API (PyArray_DATA after a type / shape / layout check) instead of the buffer protocol,
+ * whose numpy implementation builds and caches a format string per array -- one allocation per block on the first lowering
+ * (500 000 blocks: ~35 of the walk's 80 ms); -DPS_LOWER_NO_NUMPY falls back to the buffer protocol (no numpy headers). */
+#ifndef PS_LOWER_NO_NUMPY
+#define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
+#include <numpy/arrayobject.h>
+#endif
 
 static PyObject *s_KIND, *s_camera, *s_stiffness, *s_obs, *s_CAMERA_ID;
 
 typedef struct { PyObject *cam, *stiff, *loss; long g; } GroupSlot;
+
+/* An instance attribute by its interned name: straight from the instance dictionary when the TYPE says that is what getattr
+ * would return (generic getattr, no descriptor of that name anywhere in the MRO -- checked once per type by plain_attrs()), the
+ * general protocol otherwise.  -> NEW reference or NULL (error cleared by the caller). */
+static PyObject* inst_attr(PyObject* o, PyObject* name, int plain) {
+    if (plain) {
+        PyObject** dp = _PyObject_GetDictPtr(o);
+        if (dp && *dp) {
+            PyObject* v = PyDict_GetItemWithError(*dp, name);      /* borrowed */
+            if (v) { Py_INCREF(v); return v; }
+            if (PyErr_Occurred()) return NULL;
+        }
+    }
+    return PyObject_GetAttr(o, name);
+}
+static int plain_attrs(PyTypeObject* tp) {
+    return tp->tp_getattro == PyObject_GenericGetAttr && !_PyType_Lookup(tp, s_camera) && !_PyType_Lookup(tp, s_stiffness) &&
+           !_PyType_Lookup(tp, s_obs);
+}
 
 /* walk(blocks, keys, losses, i0, param_dict, pose_ix, point_ix, group_of, o_pose, o_pt, o_uvd, o_g, count)
  * -> (i, count): blocks i0 .. i-1 were taken; block i (if i < len) is for the caller */
@@ -43,12 +69,27 @@ static PyObject* walk(PyObject* self, PyObject* args) {
     if (b_pt.len / 4 < cap || b_g.len / 4 < cap || b_uvd.len / 24 < cap) { PyErr_SetString(PyExc_ValueError, "lower_fast.walk: column arrays of different capacity"); failed = 1; }
 
     PyTypeObject *reproj_tp = NULL, *other_tp = NULL;
+    int plain = 0;
     PyObject* cam_ok = NULL;                 /* the camera whose CAMERA_ID was last found to be 0 or 1 (borrowed; compared by address only) */
     GroupSlot slots[4];
     int nslots = 0;
     Py_ssize_t i = i0;
     for (; i < n && !failed; ++i) {
         if (count >= cap) break;
+        /* the walk is bound by the latency of the interpreter's object graph (block -> its dictionary -> the values -> obs -> data):
+         * ask for the next blocks' first levels while this one is taken */
+        if (i + 12 < n) { __builtin_prefetch(PyList_GET_ITEM(blocks, i + 12)); __builtin_prefetch(PyList_GET_ITEM(keys, i + 12)); }
+        if (plain && i + 6 < n) {
+            PyObject* b6 = PyList_GET_ITEM(blocks, i + 6);
+            if (Py_TYPE(b6) == reproj_tp) { PyObject** dp6 = _PyObject_GetDictPtr(b6); if (dp6 && *dp6) __builtin_prefetch(*dp6); }
+        }
+        if (plain && i + 3 < n) {
+            PyObject* b3 = PyList_GET_ITEM(blocks, i + 3);
+            if (Py_TYPE(b3) == reproj_tp) {
+                PyObject** dp3 = _PyObject_GetDictPtr(b3);
+                if (dp3 && *dp3 && ((PyDictObject*)*dp3)->ma_values) __builtin_prefetch(((PyDictObject*)*dp3)->ma_values);
+            }
+        }
         PyObject* block = PyList_GET_ITEM(blocks, i);
         PyTypeObject* tp = Py_TYPE(block);
         if (tp != reproj_tp) {
@@ -59,18 +100,19 @@ static PyObject* walk(PyObject* self, PyObject* args) {
             Py_DECREF(kind);
             if (!is_reproj) { other_tp = tp; break; }
             reproj_tp = tp;
+            plain = plain_attrs(tp);
         }
         PyObject* ks = PyList_GET_ITEM(keys, i);
         PyObject *k0, *k1;
         if (PyList_Check(ks) && PyList_GET_SIZE(ks) == 2) { k0 = PyList_GET_ITEM(ks, 0); k1 = PyList_GET_ITEM(ks, 1); }
         else if (PyTuple_Check(ks) && PyTuple_GET_SIZE(ks) == 2) { k0 = PyTuple_GET_ITEM(ks, 0); k1 = PyTuple_GET_ITEM(ks, 1); }
         else break;
-        int c0 = PyDict_Contains(param_dict, k0), c1 = c0 == 1 ? PyDict_Contains(param_dict, k1) : 0;
-        if (c0 != 1 || c1 != 1) { PyErr_Clear(); break; }
+        /* (pose_ix / point_ix hold exactly the keys of param_dict, split by kind -- lowering.py: classify -- so a key found there IS
+         *  a parameter: no second look into param_dict itself; a key found in neither ends the run and the Python loop says why) */
         PyObject* pi = PyDict_GetItemWithError(pose_ix, k0);       /* borrowed */
         PyObject* qi = pi ? PyDict_GetItemWithError(point_ix, k1) : NULL;
         if (!pi || !qi) { PyErr_Clear(); break; }
-        PyObject* cam = PyObject_GetAttr(block, s_camera);
+        PyObject* cam = inst_attr(block, s_camera, plain);
         if (!cam) { PyErr_Clear(); break; }
         if (cam != cam_ok) {
             PyObject* cid = PyObject_GetAttr(cam, s_CAMERA_ID);
@@ -80,7 +122,7 @@ static PyObject* walk(PyObject* self, PyObject* args) {
             if (v != 0 && v != 1) { Py_DECREF(cam); break; }
             cam_ok = cam;
         }
-        PyObject* stiff = PyObject_GetAttr(block, s_stiffness);
+        PyObject* stiff = inst_attr(block, s_stiffness, plain);
         if (!stiff) { PyErr_Clear(); Py_DECREF(cam); break; }
         PyObject* loss = PyList_GET_ITEM(losses, i);
         long g = -1;
@@ -97,13 +139,24 @@ static PyObject* walk(PyObject* self, PyObject* args) {
             sl->cam = cam; sl->stiff = stiff; sl->loss = loss; sl->g = g;
         }
         Py_DECREF(cam); Py_DECREF(stiff);          /* (still referenced by the block; the slots compare addresses only) */
-        PyObject* obs = PyObject_GetAttr(block, s_obs);
+        PyObject* obs = inst_attr(block, s_obs, plain);
         if (!obs) { PyErr_Clear(); break; }
-        Py_buffer ov;
-        if (PyObject_GetBuffer(obs, &ov, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS)) { PyErr_Clear(); Py_DECREF(obs); break; }
-        const int good = ov.itemsize == 8 && ov.len == 24 && ov.format && (strcmp(ov.format, "d") == 0 || strcmp(ov.format, "=d") == 0 || strcmp(ov.format, "<d") == 0);
-        if (good) memcpy(o_uvd + 3 * count, ov.buf, 24);
-        PyBuffer_Release(&ov);
+        int good = 0;
+#ifndef PS_LOWER_NO_NUMPY
+        if (PyArray_CheckExact(obs)) {           /* three native doubles in a row: straight from the array's data */
+            PyArrayObject* a = (PyArrayObject*)obs;
+            good = PyArray_TYPE(a) == NPY_DOUBLE && PyArray_ISNOTSWAPPED(a) && PyArray_ISALIGNED(a) && PyArray_SIZE(a) == 3 &&
+                   PyArray_IS_C_CONTIGUOUS(a);
+            if (good) memcpy(o_uvd + 3 * count, PyArray_DATA(a), 24);
+        } else
+#endif
+        {
+            Py_buffer ov;
+            if (PyObject_GetBuffer(obs, &ov, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS)) { PyErr_Clear(); Py_DECREF(obs); break; }
+            good = ov.itemsize == 8 && ov.len == 24 && ov.format && (strcmp(ov.format, "d") == 0 || strcmp(ov.format, "=d") == 0 || strcmp(ov.format, "<d") == 0);
+            if (good) memcpy(o_uvd + 3 * count, ov.buf, 24);
+            PyBuffer_Release(&ov);
+        }
         Py_DECREF(obs);
         if (!good) break;
         const long pv = PyLong_AsLong(pi), qv = PyLong_AsLong(qi);
@@ -139,9 +192,15 @@ static PyObject* classify(PyObject* self, PyObject* args) {
         const int is_nd = (PyObject*)Py_TYPE(val) == nd_type ? 1 : PyObject_IsInstance(val, nd_type);
         if (is_nd < 0) { Py_DECREF(poses); Py_DECREF(points); return NULL; }
         if (is_nd) {
-            Py_buffer v;
-            if (PyObject_GetBuffer(val, &v, PyBUF_STRIDES) == 0) { ok = v.ndim == 1 && v.shape[0] == 3; PyBuffer_Release(&v); }
-            else PyErr_Clear();
+#ifndef PS_LOWER_NO_NUMPY
+            if (PyArray_Check(val)) ok = PyArray_NDIM((PyArrayObject*)val) == 1 && PyArray_DIM((PyArrayObject*)val, 0) == 3;
+            else
+#endif
+            {
+                Py_buffer v;
+                if (PyObject_GetBuffer(val, &v, PyBUF_STRIDES) == 0) { ok = v.ndim == 1 && v.shape[0] == 3; PyBuffer_Release(&v); }
+                else PyErr_Clear();
+            }
         }
         if (!ok) { badkey = key; break; }
         if (PyList_Append(points, key)) { Py_DECREF(poses); Py_DECREF(points); return NULL; }
@@ -167,6 +226,15 @@ static PyObject* gather3(PyObject* self, PyObject* args) {
         PyObject* val = PyDict_GetItemWithError(param_dict, PyList_GET_ITEM(keys, i));
         int done = 0;
         Py_buffer v;
+#ifndef PS_LOWER_NO_NUMPY
+        if (val && PyArray_CheckExact(val)) {
+            PyArrayObject* a = (PyArrayObject*)val;
+            if (PyArray_TYPE(a) == NPY_DOUBLE && PyArray_ISNOTSWAPPED(a) && PyArray_ISALIGNED(a) && PyArray_SIZE(a) == 3 && PyArray_IS_C_CONTIGUOUS(a)) {
+                memcpy(out + 3 * i, PyArray_DATA(a), 24); done = 1;
+            }
+        }
+        if (!done)
+#endif
         if (val && PyObject_GetBuffer(val, &v, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) == 0) {
             if (is_f64x3(&v)) { memcpy(out + 3 * i, v.buf, 24); done = 1; }
             PyBuffer_Release(&v);
@@ -193,6 +261,16 @@ static PyObject* scatter3(PyObject* self, PyObject* args) {
         PyObject* val = PyDict_GetItemWithError(param_dict, PyList_GET_ITEM(keys, i));
         int done = 0;
         Py_buffer v;
+#ifndef PS_LOWER_NO_NUMPY
+        if (val && PyArray_CheckExact(val)) {
+            PyArrayObject* a = (PyArrayObject*)val;
+            if (PyArray_TYPE(a) == NPY_DOUBLE && PyArray_ISNOTSWAPPED(a) && PyArray_ISALIGNED(a) && PyArray_SIZE(a) == 3 && PyArray_IS_C_CONTIGUOUS(a) &&
+                PyArray_ISWRITEABLE(a)) {
+                memcpy(PyArray_DATA(a), in + 3 * i, 24); done = 1;
+            }
+        }
+        if (!done)
+#endif
         if (val && PyObject_GetBuffer(val, &v, PyBUF_WRITABLE | PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) == 0) {
             if (is_f64x3(&v)) { memcpy(v.buf, in + 3 * i, 24); done = 1; }
             PyBuffer_Release(&v);
@@ -216,5 +294,8 @@ PyMODINIT_FUNC PyInit__lower_fast(void) {
     s_KIND = PyUnicode_InternFromString("KIND"); s_camera = PyUnicode_InternFromString("camera");
     s_stiffness = PyUnicode_InternFromString("stiffness"); s_obs = PyUnicode_InternFromString("obs");
     s_CAMERA_ID = PyUnicode_InternFromString("CAMERA_ID");
+#ifndef PS_LOWER_NO_NUMPY
+    import_array();
+#endif
     return PyModule_Create(&moddef);
 }

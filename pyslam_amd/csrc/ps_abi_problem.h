@@ -73,6 +73,18 @@ int ps_problem_destroy(ps_problem* h) {
                 c[5] * 1e3 / khz / h->cp_launches);
         hipFree(h->cp_dbg);
     }
+    if (h->chk_sums) {
+        hipDeviceSynchronize();
+        fprintf(stderr, "PS_XCG_INV_SUM %p:", (void*)h);
+        for (int k = 0; k < std::min(h->chk_nsum, 64); ++k) fprintf(stderr, " [%d use %016llx | side A_c %016llx -> inv %016llx]", k, h->chk_sums[3 * k], h->chk_sums[3 * k + 1], h->chk_sums[3 * k + 2]);
+        fprintf(stderr, "\n");
+        hipHostFree(h->chk_sums);
+    }
+    if (h->chk_cnt) {
+        int32_t c[4] = {}; hipDeviceSynchronize(); hipMemcpy(c, h->chk_cnt, 16, hipMemcpyDeviceToHost);
+        fprintf(stderr, "PS_XCG_AC_CHECK: %d comparisons, entries that differ between the side stream's assembly and the solver stream's: A_c %d, BSZ %d; A_c behind the assembly vs at the end of the side job: %d\n", c[2], c[0], c[1], c[3]);
+        hipFree(h->chk_Ac_side); hipFree(h->chk_Ac); hipFree(h->chk_BSZ); hipFree(h->chk_cnt);
+    }
     if (ps_env("PS_HOST_TIMING") && h->host_calls)
         fprintf(stderr, "ps_gn_iteration: %ld calls, %.1f us per call on the host, of which %.1f us waiting for the GPU (%ld waits)\n",
                 h->host_calls, h->host_call_ns * 1e-3 / h->host_calls, h->host_wait_ns * 1e-3 / h->host_calls, h->host_waits);

@@ -336,6 +336,107 @@ int ps_sparse_normal_direct(int32_t m, int32_t n, const int32_t* j_row_ptr, cons
 // read).  chunk_nodes < 0: the one-workgroup column walk (k_band_chol + k_band_inverse_rl); 0: the partitioned form with its
 // automatic chunk size; > 0: that many interior nodes per chunk.  ainv_out: nc x nc fp32 (what the explicit two-level PCG
 // keeps).  elapsed_us (may be NULL): GPU time of the factorisation + inverse launches, measured with events.
+int ps_debug_factor_stress(const double* a, int32_t ncb, int32_t dof, int32_t bw, int32_t mode, int32_t launches, int32_t lowprio,
+                           int32_t aggressor, int32_t* n_diff, int32_t* n_pivot) {
+    // mode bits: 8 = the input is PRODUCED on the victim stream in front of every factorisation (the buffer first holds 2 A, then a
+    // many-workgroup copy kernel writes A: a factorisation that starts before its producer has finished reads a mix of both);
+    // 16 = an event is recorded between producer and factorisation (as xcg_side_enqueue does with ev_acdone)
+    const bool produce = (mode & 8) != 0, with_event = (mode & 16) != 0;
+    mode &= 7;
+    if (!a || !n_diff || !n_pivot || ncb <= 0 || (dof != 3 && dof != 6) || mode < 0 || mode > 3 || launches < 1) return fail("bad argument");
+    if (mode <= 1 && (bw < 1 || bw > PS_BAND_MAXB)) return fail("bad band width");
+    if (need_device()) return -1;
+    const int nc = ncb * dof;
+    if (mode == 2 && nc > 90) return fail("mode 2 (LDS-resident k_coarse_chol) needs ncb dof <= 90");
+    DevBuf bA, bInv, bLr, bLc, brd, bXs, bst, bLi, bLiT, bsc, ga, gb;
+    const size_t gn = (size_t)16 << 20;
+    if (bA.get((size_t)nc * nc * 8) || bInv.get((size_t)nc * nc * 4) || bst.get(ST_NWORDS * 4) || bLr.get((size_t)nc * PS_BAND_W * 8) ||
+        bLc.get((size_t)nc * PS_BAND_W * 8) || brd.get((size_t)nc * 8) || bXs.get((size_t)nc * nc * 8) || bLi.get((size_t)nc * nc * 8) ||
+        bLiT.get((size_t)nc * nc * 8) || bsc.get((size_t)2 * nc * nc * 8) || ga.get(gn * 8) || gb.get(gn * 8)) return -1;
+    HIP_OK(hipMemcpy(bA.p, a, (size_t)nc * nc * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(ga.p, 0, gn * 8));
+    DevBuf bA1, bA2;
+    hipEvent_t evp = nullptr;
+    if (produce) {
+        std::vector<double> a2((size_t)nc * nc);
+        for (size_t k = 0; k < a2.size(); ++k) a2[k] = 2.0 * a[k];
+        if (bA1.get((size_t)nc * nc * 8) || bA2.get((size_t)nc * nc * 8)) return -1;
+        HIP_OK(hipMemcpy(bA1.p, a, (size_t)nc * nc * 8, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(bA2.p, a2.data(), (size_t)nc * nc * 8, hipMemcpyHostToDevice));
+        HIP_OK(hipEventCreateWithFlags(&evp, hipEventDisableTiming));
+    }
+    struct EvGuard { hipEvent_t e; ~EvGuard() { if (e) hipEventDestroy(e); } } evg{evp};
+    hipStream_t vs = nullptr, as = nullptr;
+    int lo = 0, hi = 0;
+    HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (lowprio) HIP_OK(hipStreamCreateWithPriority(&vs, hipStreamNonBlocking, lo)); else HIP_OK(hipStreamCreateWithFlags(&vs, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&as, hipStreamNonBlocking));
+    struct Streams { hipStream_t a, b; ~Streams() { hipStreamDestroy(a); hipStreamDestroy(b); } } streams{vs, as};
+    std::unique_ptr<BandPart> bp;
+    if (mode == 1) {
+        const int m = BandPart::auto_m(ncb, bw);
+        if (!BandPart::eligible(ncb, bw, m)) return fail("mode 1: the partitioned factorisation does not apply to this shape");
+        bp.reset(new BandPart());
+        if (bp->build(ncb, dof, bw, m, vs)) return -1;
+    }
+    const size_t chol_lds = 2 * (size_t)nc * nc * sizeof(double);
+    if (mode == 2 && (dof == 6 ? ensure_dynamic_lds((const void*)k_coarse_chol<6, true>, chol_lds) : ensure_dynamic_lds((const void*)k_coarse_chol<3, true>, chol_lds))) return -1;
+    auto run = [&](hipStream_t st) -> int {
+        if (produce) {
+            copy_doubles(st, bA.as<double>(), bA2.as<double>(), (size_t)nc * nc);       // 2 A ...
+            copy_doubles(st, bA.as<double>(), bA1.as<double>(), (size_t)nc * nc);       // ... then A, by a kernel of many workgroups
+            if (with_event) HIP_OK(hipEventRecord(evp, st));
+        }
+        HIP_OK(hipMemsetAsync(bst.p, 0, ST_NWORDS * 4, st));
+        HIP_OK(hipMemsetAsync(bInv.p, 0, (size_t)nc * nc * 4, st));
+        if (mode == 0) {
+            HIP_OK(hipMemsetAsync(bLr.p, 0, (size_t)nc * PS_BAND_W * 8, st));
+            HIP_OK(hipMemsetAsync(bLc.p, 0, (size_t)nc * PS_BAND_W * 8, st));
+            if (dof == 6) hipLaunchKernelGGL(k_band_chol<6>, dim3(1), dim3(256), 0, st, ncb, bw, bA.as<double>(), bLr.as<double>(), bLc.as<double>(), brd.as<double>(), bst.as<int32_t>(), nc, (const int2*)nullptr);
+            else hipLaunchKernelGGL(k_band_chol<3>, dim3(1), dim3(256), 0, st, ncb, bw, bA.as<double>(), bLr.as<double>(), bLc.as<double>(), brd.as<double>(), bst.as<int32_t>(), nc, (const int2*)nullptr);
+            hipLaunchKernelGGL(k_band_inverse_rl<false>, dim3(cdiv(nc, 4)), dim3(256), 0, st, nc, (const double*)bLr.as<double>(), (const double*)bLc.as<double>(),
+                               (const double*)brd.as<double>(), bXs.as<double>(), bInv.as<float>(), (const BandInvItem*)nullptr, (double*)nullptr, nc);
+        } else if (mode == 1) {
+            if (dof == 6 ? bp->run<6>(st, bA.as<double>(), nc, bInv.as<float>(), nc, bst.as<int32_t>()) : bp->run<3>(st, bA.as<double>(), nc, bInv.as<float>(), nc, bst.as<int32_t>())) return -1;
+        } else {
+            if (mode == 2) {
+                if (dof == 6) hipLaunchKernelGGL((k_coarse_chol<6, true>), dim3(1), dim3(1024), chol_lds, st, ncb, bA.as<double>(), bLi.as<double>(), bLiT.as<double>(), bst.as<int32_t>(), nullptr);
+                else hipLaunchKernelGGL((k_coarse_chol<3, true>), dim3(1), dim3(1024), chol_lds, st, ncb, bA.as<double>(), bLi.as<double>(), bLiT.as<double>(), bst.as<int32_t>(), nullptr);
+            } else {
+                if (dof == 6) hipLaunchKernelGGL((k_coarse_chol<6, false>), dim3(1), dim3(1024), 0, st, ncb, bA.as<double>(), bLi.as<double>(), bLiT.as<double>(), bst.as<int32_t>(), bsc.as<double>());
+                else hipLaunchKernelGGL((k_coarse_chol<3, false>), dim3(1), dim3(1024), 0, st, ncb, bA.as<double>(), bLi.as<double>(), bLiT.as<double>(), bst.as<int32_t>(), bsc.as<double>());
+            }
+            hipLaunchKernelGGL(k_xcg_ainv, dim3(cdiv(nc, PS_AI_T) * (cdiv(nc, PS_AI_T) + 1) / 2), dim3(256), 0, st, nc, bLi.as<double>(), bInv.as<float>(), nc);
+        }
+        return 0;
+    };
+    std::vector<float> ref((size_t)nc * nc), out((size_t)nc * nc);
+    int32_t stw[ST_NWORDS];
+    if (run(vs)) return -1;
+    HIP_OK(hipStreamSynchronize(vs));
+    HIP_OK(hipMemcpy(ref.data(), bInv.p, ref.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(stw, bst.p, sizeof(stw), hipMemcpyDeviceToHost));
+    if (stw[ST_DIAG_FAIL]) return fail("ps_debug_factor_stress: the input is not positive definite (idle reference run)");
+    *n_diff = *n_pivot = 0;
+    for (int k = 0; k < launches; ++k) {
+        if (aggressor == 1) for (int q = 0; q < 3; ++q) copy_doubles(as, gb.as<double>(), ga.as<double>(), gn);
+        if (aggressor == 2) {                                 // workgroups with 96 KB of LDS each, scribbling over all of it
+            const size_t lds = 96 * 1024;
+            if (ensure_dynamic_lds((const void*)k_lds_scribble, lds)) return -1;
+            for (int q = 0; q < 2; ++q) hipLaunchKernelGGL(k_lds_scribble, dim3(1024), dim3(512), lds, as, (int)(lds / 8), 6, gb.as<double>());
+        }
+        if (run(vs)) return -1;
+        HIP_OK(hipStreamSynchronize(vs));
+        HIP_OK(hipMemcpy(out.data(), bInv.p, out.size() * 4, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(stw, bst.p, sizeof(stw), hipMemcpyDeviceToHost));
+        if (std::memcmp(out.data(), ref.data(), out.size() * 4)) ++*n_diff;
+        if (stw[ST_DIAG_FAIL]) ++*n_pivot;
+    }
+    HIP_OK(hipDeviceSynchronize());
+    if (bp) bp.reset();
+    return 0;
+}
+
 int ps_debug_band_inverse(const double* a, int32_t ncb, int32_t dof, int32_t bw, int32_t chunk_nodes, float* ainv_out, double* elapsed_us) {
     if (!a || !ainv_out || ncb <= 0 || (dof != 3 && dof != 6) || bw < 1 || bw > PS_BAND_MAXB) return fail("bad argument");
     if (need_device()) return -1;

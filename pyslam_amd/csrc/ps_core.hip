@@ -290,6 +290,10 @@ struct ps_problem {
     hipStream_t side = nullptr;
     int side_cus = 0;               // > 0: the side stream is confined to this many compute units (CU mask)
     hipEvent_t ev_ac = nullptr, ev_chol = nullptr, ev_acdone = nullptr;
+    // PS_XCG_AC_CHECK (measurement build, tools/probes/lowprio_hunt.sh): A_c / BSZ assembled a second time on the solver stream and
+    // compared bit for bit with what the side stream assembled: [entries of A_c that differ, of BSZ, comparisons]
+    unsigned long long* chk_sums = nullptr; int chk_nsum = 0;      // PS_XCG_INV_SUM: bit checksums (pinned) of [inverse consumed | A_c the side job factored | inverse it produced] per set-up
+    double *chk_Ac = nullptr, *chk_BSZ = nullptr, *chk_Ac_side = nullptr; int32_t* chk_cnt = nullptr; size_t chk_bsz_n = 0;
     bool acdone_pending = false;    // explicit PCG: the side stream may still be assembling A_c from SB / the basis (wait before they are overwritten)
     int32_t* lag_status = nullptr;  // ST_DIAG_FAIL of the side-stream factorisation
     double* Mc = nullptr;           // split mode: dense coarse-coarse block M of the lagged system

@@ -118,6 +118,15 @@ int xcg_setup(ps_problem* h, int max_iters, bool allow_lag) {
         h->xcg_lag_count = 0;
         h->xcg_ref_pending = true;
     }
+    {   // PS_XCG_INV_SUM (measurement build): checksum of the coarse inverse this solve consumes
+        static const bool inv_sum = ps_env("PS_XCG_INV_SUM") != nullptr;
+        if (inv_sum) {
+            if (!h->chk_sums) { HIP_OK(hipHostMalloc(&h->chk_sums, 3 * 64 * 8, hipHostMallocMapped)); std::memset(h->chk_sums, 0, 3 * 64 * 8); }
+            ++h->chk_nsum;                                   // (this set-up's slot: chk_nsum - 1, also for its side job)
+            if (h->chk_nsum <= 64)
+                hipLaunchKernelGGL(k_bit_sum, dim3(64), dim3(256), 0, h->stream, (size_t)nc * nc, (const unsigned*)h->LciT2[h->lci_cur], h->chk_sums + 3 * (h->chk_nsum - 1));
+        }
+    }
     h->xf_active = h->xcg_fused && h->xf_ok && h->xf_skip == 0;
     h->xp_defer = false;
     {   // xstate, the second p buffer and (one- / two-launch form) ts_0 and the records of buffer 0: one launch
@@ -167,11 +176,55 @@ int xcg_side_enqueue(ps_problem* h) {
     h->xcg_side_todo = false;
     const int nc = h->nc, nb = h->lci_cur ^ 1;
     HIP_OK(hipStreamWaitEvent(h->side, h->ev_ac, 0));
+    {   // PS_SIDE_DELAY=<rounds> (measurement build, tools/probes/lowprio_hunt.sh): a slow one-workgroup kernel in front of the side job
+        // of an ORDINARY side stream -- the job then overlaps the solver stream's later work the way a low-priority one does.
+        // Differences with it = a race of this protocol that timing exposes; none = the lowest-priority queue itself
+        static const int side_delay = ps_env("PS_SIDE_DELAY") ? atoi(ps_env("PS_SIDE_DELAY")) : 0;
+        if (side_delay > 0) {
+            if (!h->xy) return fail("PS_SIDE_DELAY: no scratch");
+            if (ensure_dynamic_lds((const void*)k_lds_scribble, 96 * 1024)) return -1;
+            hipLaunchKernelGGL(k_lds_scribble, dim3(1), dim3(512), 96 * 1024, h->side, 96 * 1024 / 8, side_delay, h->chol_scratch);
+        }
+    }
     if (!xcg_ac_on_main()) xcg_assemble_ac<D>(h, h->side);
     HIP_OK(hipEventRecord(h->ev_acdone, h->side));
     h->acdone_pending = true;
+    // (measurement switches of the low-priority hunt, tools/probes/lowprio_hunt.sh: PS_XCG_AC_WAIT=1 the solver stream waits for the
+    //  side stream's assembly at once; =2 it waits for the whole side job)
+    static const int ac_wait = ps_env("PS_XCG_AC_WAIT") ? atoi(ps_env("PS_XCG_AC_WAIT")) : 0;
+    if (ac_wait == 1) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_acdone, 0));
+    static const bool ac_check = ps_env("PS_XCG_AC_CHECK") != nullptr;
+    if (ac_check && !xcg_ac_on_main()) {
+        // the same assembly once more on the SOLVER stream (after the side stream's), into buffers of its own, and a bitwise comparison
+        const size_t nA = (size_t)h->nc * h->nc;
+        if (!h->chk_cnt) {
+            int32_t n_ent = 0;
+            HIP_OK(hipMemcpy(&n_ent, h->ent_ptr + h->nr, sizeof(n_ent), hipMemcpyDeviceToHost));
+            h->chk_bsz_n = (size_t)n_ent * D * D;
+            HIP_OK(hipMalloc(&h->chk_Ac, nA * 8)); HIP_OK(hipMalloc(&h->chk_BSZ, std::max<size_t>(h->chk_bsz_n, 1) * 8)); HIP_OK(hipMalloc(&h->chk_cnt, 16));
+            HIP_OK(hipMalloc(&h->chk_Ac_side, nA * 8));
+            HIP_OK(hipMemset(h->chk_cnt, 0, 16));
+        }
+        // ... and what the SIDE stream itself sees of A_c right behind its assembly (a copy kernel in front of the factorisation),
+        // compared at the end of the side job with A_c as it is then: slot 3
+        copy_doubles(h->side, h->chk_Ac_side, h->Ac, nA);
+        HIP_OK(hipStreamWaitEvent(h->stream, h->ev_acdone, 0));
+        hipLaunchKernelGGL(k_xcoarse_rowsums<D>, dim3(h->nr), dim3(256), (size_t)(h->max_row_ents + 1) * D * D * sizeof(double), h->stream,
+                           h->nr, h->ent_ptr, h->ent_q, h->ent_lo, h->ent_hi, h->acol_idx, h->pnode, h->pw0, h->pw1, h->SB, h->Bmat, h->chk_BSZ);
+        hipLaunchKernelGGL(k_xcoarse_matrix<D>, dim3(cdiv((long)h->ncb * h->ncb * D * D, 256)), dim3(256), 0, h->stream,
+                           h->ncb, h->seg_ptr, h->seg_ent, h->seg_row, h->pnode, h->pw0, h->pw1, h->chk_BSZ, h->chk_Ac);
+        hipLaunchKernelGGL(k_cmp_bits, dim3(64), dim3(256), 0, h->stream, nA, (const double*)h->Ac, (const double*)h->chk_Ac, h->chk_cnt, 0);
+        hipLaunchKernelGGL(k_cmp_bits, dim3(64), dim3(256), 0, h->stream, h->chk_bsz_n, (const double*)h->BSZ, (const double*)h->chk_BSZ, h->chk_cnt, 1);
+    }
     if (xcg_coarse_inverse<D>(h, h->side, nb, h->lag_status)) return -1;
+    if (h->chk_sums && h->chk_nsum >= 1 && h->chk_nsum <= 64) {      // PS_XCG_INV_SUM: what the side job factored (A_c as it is at its end) and what it produced
+        hipLaunchKernelGGL(k_bit_sum, dim3(64), dim3(256), 0, h->side, (size_t)2 * h->nc * h->nc, (const unsigned*)h->Ac, h->chk_sums + 3 * (h->chk_nsum - 1) + 1);
+        hipLaunchKernelGGL(k_bit_sum, dim3(64), dim3(256), 0, h->side, (size_t)h->nc * h->nc, (const unsigned*)h->LciT2[nb], h->chk_sums + 3 * (h->chk_nsum - 1) + 2);
+    }
+    if (ac_check && h->chk_Ac_side)
+        hipLaunchKernelGGL(k_cmp_bits, dim3(64), dim3(256), 0, h->side, (size_t)h->nc * h->nc, (const double*)h->Ac, (const double*)h->chk_Ac_side, h->chk_cnt, 3);
     HIP_OK(hipEventRecord(h->ev_chol, h->side));
+    if (ac_wait == 2) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0));
     h->lci_next = nb; h->side_pending = true; h->xcg_tag[nb] = h->xcg_setup_cost; h->xcg_tag_lambda[nb] = h->xcg_setup_lambda;
     return 0;
 }

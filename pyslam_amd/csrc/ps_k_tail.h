@@ -748,6 +748,38 @@ __global__ __launch_bounds__(256) void k_shard_pack(
     }
 }
 
+// aggressor of ps_debug_factor_stress (aggressor = 2): workgroups that own a large dynamic LDS allocation and keep writing all of it
+__global__ __launch_bounds__(512) void k_lds_scribble(int words, int rounds, double* __restrict__ sink)
+{
+    extern __shared__ double scr[];
+    double acc = 0.0;
+    for (int r = 0; r < rounds; ++r) {
+        for (int i = threadIdx.x; i < words; i += blockDim.x) scr[i] = (double)(i ^ r) * 1.0e300;
+        __syncthreads();
+        for (int i = threadIdx.x; i < words; i += blockDim.x) acc += scr[words - 1 - i];
+        __syncthreads();
+    }
+    if (acc == 12345.678) sink[blockIdx.x] = acc;
+}
+
+// order-independent bit checksum of n 4-byte words (measurement build: PS_XCG_INV_SUM): *out = sum of (word * (index + 1)) mod 2^64
+__global__ __launch_bounds__(256) void k_bit_sum(size_t nwords, const unsigned* __restrict__ a, unsigned long long* __restrict__ out)
+{
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) s += (unsigned long long)a[i] * (i + 1);
+    if (s) atomicAdd(out, s);
+}
+
+// bitwise comparison of two arrays (measurement build: PS_XCG_AC_CHECK): cnt[slot] += entries that differ, cnt[2] += 1 per launch
+__global__ __launch_bounds__(256) void k_cmp_bits(size_t n, const double* __restrict__ a, const double* __restrict__ b, int32_t* __restrict__ cnt, int slot)
+{
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        bad += __double_as_longlong(a[i]) != __double_as_longlong(b[i]);
+    if (bad) atomicAdd(&cnt[slot], bad);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && slot == 0) atomicAdd(&cnt[2], 1);
+}
+
 // ---- segment exchange (ps_set_segment_exchange): [tail words | this rank's elements of the packed system], read straight from
 // S / g / cost / status at the packed positions (k_shard_pack's layout: the upper blocks in up_slot order, then g, cost (2), the flag)
 // -- no pass over the whole 23.5 MB buffer when a rank owns an eighth of it ...

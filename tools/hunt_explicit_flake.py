@@ -15,7 +15,7 @@ dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 KEYS = ('cg_restarts', 'cg_kernel_launches', 'xcg_fused_solves', 'xcg_fused_fallbacks', 'ldi_solves', 'ldi_fallbacks', 'ldi_seeds')
-bad = 0
+bad = errors = 0
 for rnd in range(rounds):
     rng = np.random.default_rng(seed0 + rnd)
     kf = int(rng.choice([40, 90, 90, 150]))
@@ -34,9 +34,14 @@ for rnd in range(rounds):
                 d.set_option(kv.split('=')[0], float(kv.split('=')[1]))
     sync = (lambda: torch.cuda.synchronize()) if os.environ.get('HUNT_SYNC') else (lambda: None)
     for it in range(4):
-        ra = a.gn_iteration(0., 1e-12, 2000, True); sync()
-        rb = b.gn_iteration(0., 1e-12, 2000, True); sync()
-        rs = sh.gn_iteration(0., 1e-12, 2000, True); sync()
+        try:
+            ra = a.gn_iteration(0., 1e-12, 2000, True); sync()
+            rb = b.gn_iteration(0., 1e-12, 2000, True); sync()
+            rs = sh.gn_iteration(0., 1e-12, 2000, True); sync()
+        except Exception as e:          # noqa: BLE001  (a spurious failure of a side-stream factorisation: counted, the hunt goes on)
+            errors += 1
+            print('ERROR round %d iteration %d: %s' % (rnd, it, str(e)[:90]), flush=True)
+            break
         if not (ra == rb and ra[0] == rs[0] and ra[2] == rs[2]):
             bad += 1
             print('DIFF round %d kf %d obs %d edges %d iteration %d' % (rnd, kf, lp.num_obs, lp.num_edges, it))
@@ -46,4 +51,4 @@ for rnd in range(rounds):
     sh.close(); a.close(); b.close()
     if rnd % 50 == 0:
         print('round', rnd, 'differences so far', bad, flush=True)
-print('rounds', rounds, 'differences', bad)
+print('rounds', rounds, 'differences', bad, 'errors', errors)
