@@ -561,9 +561,9 @@ def main():
         torch.cuda.synchronize()
 
     core = dev.dev if hasattr(dev, 'dev') else dev
-    # timed region: cold solves (module docstring); ONE hipEvent pair around the dominant (Schur) kernel on every 4th
-    # linearisation (an event pair costs ~8 us of pipeline bubbles)
-    core.set_option('profile_every', 4)
+    # timed region: cold solves (module docstring); ONE hipEvent pair per four linearisations (a pair costs ~8 us of pipeline
+    # bubbles): around the Schur pair kernel on every 8th, around the CG launch on the 8th's in between
+    core.set_option('profile_every', 8)
     dev.set_profiling(1)
     dev.stage_times(reset=True)
     warm_solves = max(1, (args.warmup + 3) // 4)
@@ -649,7 +649,7 @@ def main():
                                             'solves); the solve time also holds the start-cost pass, the best-parameter snapshots and '
                                             'the final restore'},
             'stage_ms': {k: round(v, 4) for k, v in name_stage_totals(stage_ms).items()},
-            'stage_ms_note': 'schur_pairs, cg_kernel (the CG launch alone): hipEvent pairs inside the timed region, on every 4th linearisation; the other stages from one '
+            'stage_ms_note': 'schur_pairs, cg_kernel (the CG launch alone): hipEvent pairs inside the timed region, each on every 8th linearisation (alternating: one pair per four iterations); the other stages from one '
                              'more untimed cold solve with an event pair around every stage, per iteration of that solve. landmark_pass: '
                              'since round 5 the pass of the NEXT iteration runs in the tail and sums the cost after the step on its way '
                              '(one evaluation of every observation per iteration); cost = what is left of the cost-only pass (the last '

@@ -11,7 +11,10 @@ struct StageTimer {
     int slot = -1;
     StageTimer(ps_problem* h_, int st, int level = 2) : h(h_), stage(st) {
         if (h->profiling < level) return;
-        if (h->profiling == 1 && h->prof_every > 1 && h->prof_tick % h->prof_every != 0) return;   // sampled launches only
+        // sampled launches only; the two level-1 pairs on DIFFERENT linearisations (the Schur kernel on multiples of
+        // "profile_every", the CG launch half a period later): never two pairs -- ~8 us of pipeline bubbles each -- in one iteration
+        if (h->profiling == 1 && h->prof_every > 1 &&
+            h->prof_tick % h->prof_every != (st == PS_ST_CG_KERNEL ? h->prof_every / 2 : 0)) return;
         if (h->ev_used + 2 > h->ev_pool.size()) {
             for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); h->ev_pool.push_back(e); }
         }
