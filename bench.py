@@ -36,9 +36,10 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of
 the fixed C4 problem (2 000 keyframes, 500 000 landmarks, 5 M blocks; BASELINE.json
 configs[3]), the same cold solves: every rank generates the same problem and keeps landmark
 shard ``rank`` of N (``shard_landmarks``); the reduced pose system [upper(S) | g | cost | flag]
-is summed with one RCCL all-reduce per iteration (issued by the HIP core itself on
-the solver's stream) and then solved redundantly on every rank; a second small
-all-reduce sums the shards' cost and landmark step norm.  Rank 0 also times the
+is exchanged once per iteration by the HIP core itself on the solver's stream -- N > 1: an RCCL
+all-gather of the ranks' band segments, summed by every rank in rank order (``--exchange allreduce``:
+one sum all-reduce of the whole packed system) -- and then solved redundantly on every rank; a
+second small all-reduce sums the shards' cost and landmark step norm.  Rank 0 also times the
 unsharded C4 problem on its own GPU after the timed region (``c4_single_gpu_ms``).
 
 Prints ONE JSON line (rank 0).
@@ -546,7 +547,9 @@ def main():
     if dist is not None:
         from pyslam_amd.distributed import ShardedDeviceProblem, shard_landmarks
         lp = shard_landmarks(lp_full, rank, world, order=args.shard_order)       # the FIXED problem, split N ways (strong scaling)
-        dev = ShardedDeviceProblem(lp, dist, exchange=args.exchange)
+        # (N > 1: the segment exchange inside the core -- a rank sends the 3.2 MB band segment its shard touches instead of joining a
+        #  23.5 MB all-reduce; --exchange allreduce / PYSLAM_AMD_EXCHANGE choose otherwise)
+        dev = ShardedDeviceProblem(lp, dist, exchange=args.exchange or os.environ.get('PYSLAM_AMD_EXCHANGE') or ('segments' if world > 1 else None))
     else:
         from pyslam_amd.device import DeviceProblem
         lp = lp_full

@@ -261,7 +261,8 @@ int ps_set_segment_exchange(ps_problem* h, void* nccl_all_gather_fn, int32_t wor
         }
     }
     if (n_dst && src_ptr[0] != 0) return fail("ps_set_segment_exchange: src_ptr must start at 0");
-    const std::vector<int64_t> vm(mine, mine + n_mine), vd(dst, dst + n_dst), vp(src_ptr, src_ptr + (n_dst ? n_dst + 1 : 0)),
+    if ((int64_t)world * maxlen > INT32_MAX || body > INT32_MAX) return fail("ps_set_segment_exchange: the exchange does not fit 32-bit plan entries");
+    const std::vector<int32_t> vm(mine, mine + n_mine), vd(dst, dst + n_dst), vp(src_ptr, src_ptr + (n_dst ? n_dst + 1 : 0)),
                                vo(src_off, src_off + (n_dst ? src_ptr[n_dst] : 0));
     if (h->upload(&h->seg_mine, vm) || h->upload(&h->seg_dst, vd) || h->upload(&h->seg_src_ptr, vp) || h->upload(&h->seg_src_off, vo) ||
         h->alloc(&h->seg_in, (size_t)maxlen) || h->alloc(&h->seg_all, (size_t)maxlen * world)) return -1;

@@ -436,7 +436,7 @@ struct ps_problem {
     allgather_fn seg_allgather = nullptr;
     int seg_world = 0, seg_rank = 0;
     long seg_maxlen = 0, seg_nmine = 0, seg_ndst = 0;
-    int64_t *seg_mine = nullptr, *seg_dst = nullptr, *seg_src_off = nullptr, *seg_src_ptr = nullptr;
+    int32_t *seg_mine = nullptr, *seg_dst = nullptr, *seg_src_off = nullptr, *seg_src_ptr = nullptr;   // (the plan in 32 bits on the device: 12 B per element less to read)
     double *seg_in = nullptr, *seg_all = nullptr;
     // sharded exchange buffer [upper(S) | g | cost | flag] (k_shard_pack / k_shard_unpack), built on first use
     double* shard_pack = nullptr;

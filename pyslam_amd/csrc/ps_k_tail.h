@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void k_cmp_bits(size_t n, const double* __rest
 template <int D>
 __global__ __launch_bounds__(256) void k_seg_pack(long nup, const int32_t* __restrict__ up_slot, const double* __restrict__ S,
                                                   long ntail, const double* __restrict__ tail /* g | cost */, const int32_t* __restrict__ status,
-                                                  long T, long nmine, const int64_t* __restrict__ mine, double* __restrict__ seg_in, long maxlen)
+                                                  long T, long nmine, const int32_t* __restrict__ mine, double* __restrict__ seg_in, long maxlen)
 {
     constexpr int DD = D * D;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < maxlen; t += (long)gridDim.x * blockDim.x) {
@@ -803,8 +803,8 @@ __global__ __launch_bounds__(256) void k_seg_pack(long nup, const int32_t* __res
 // destination element over its contributors in rank order (no atomics: one thread per destination, a fixed order -- the same number
 // on every rank), the tail words over all ranks
 template <int D>
-__global__ __launch_bounds__(256) void k_seg_sum(long ndst, const int64_t* __restrict__ dst, const int64_t* __restrict__ src_ptr,
-                                                 const int64_t* __restrict__ src_off, const double* __restrict__ seg_all,
+__global__ __launch_bounds__(256) void k_seg_sum(long ndst, const int32_t* __restrict__ dst, const int32_t* __restrict__ src_ptr,
+                                                 const int32_t* __restrict__ src_off, const double* __restrict__ seg_all,
                                                  long T, int world, long maxlen, long nup, const int32_t* __restrict__ up_slot,
                                                  const int32_t* __restrict__ upT_slot, double* __restrict__ S, long ntail,
                                                  double* __restrict__ tail, int32_t* __restrict__ status)
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256) void k_seg_sum(long ndst, const int64_t* __res
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < ndst + T; t += (long)gridDim.x * blockDim.x) {
         double v = 0.0;
         if (t < ndst) {
-            for (int64_t k = src_ptr[t]; k < src_ptr[t + 1]; ++k) v += seg_all[src_off[k]];
+            for (int k = src_ptr[t]; k < src_ptr[t + 1]; ++k) v += seg_all[src_off[k]];
             const long p = dst[t];
             if (p < nup * DD) {
                 const long b = p / DD;

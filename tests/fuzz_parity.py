@@ -53,8 +53,10 @@ def run(n_cases, seed0=0, verbose=True):
                 dev.set_option('coarse_groups', int(rng.integers(30, min(340, (lp.num_reduced - 1) // 2) + 1)))   # (beyond 256 nodes: the big coarse kernel)
         elif mode == 'nocoarse':
             dev.set_option('coarse_groups', 0)
-        elif mode == 'G':
-            dev.set_option('coarse_groups', int(rng.integers(1, 20)))
+        g_forced = 0
+        if mode == 'G':
+            g_forced = int(rng.integers(1, 20))
+            dev.set_option('coarse_groups', g_forced)
         if rng.integers(4) == 0:
             dev.set_option('direct_max_unknowns', 0)
         # round 5: the kernels that replaced others keep their predecessors as variants -- both sides of each switch are swept
@@ -117,8 +119,9 @@ def run(n_cases, seed0=0, verbose=True):
                 if not (e2 < (1e-5 if its2 < 300 else 1e-3)) and not (its2 >= 4000 and mode == 'nocoarse'):
                     ok = False
                     print('   (case %d second iteration: cost/pose error %.1e, cg %d)' % (case, e2, its2), flush=True)
-            if not ok and its >= 4000 and mode == 'nocoarse':
-                ok = True          # a long chain with the coarse level switched off does not converge in 4 000 iterations: expected
+            if not ok and its >= 4000 and (mode == 'nocoarse' or (mode == 'G' and lp.num_reduced >= 100 * g_forced)):
+                ok = True          # a long chain with the coarse level switched off -- or forced down to one interval per 100+ poses
+                                   # (round 6, case 1021025: 700 poses, ONE interval) -- does not converge in 4 000 iterations: expected
             if not ok and its > 0 and its < 4000:
                 # ill-conditioned system or a wrong solve?  the device step must satisfy the ORACLE's normal equations
                 Pm, bv, _ = orc.normal_equations(lp, points_first=False, lm_lambda=lam)
