@@ -13,6 +13,8 @@
 #include <Python.h>
 #include <stdint.h>
 #include <string.h>
+#include <pthread.h>
+#include <stdlib.h>
 /* Round 6: block.obs through the numpy C API (PyArray_DATA after a type / shape / layout check) instead of the buffer protocol,
  * whose numpy implementation builds and caches a format string per array -- one allocation per block on the first lowering
  * (500 000 blocks: ~35 of the walk's 80 ms); -DPS_LOWER_NO_NUMPY falls back to the buffer protocol (no numpy headers). */
@@ -44,13 +46,85 @@ static int plain_attrs(PyTypeObject* tp) {
            !_PyType_Lookup(tp, s_obs);
 }
 
+/* ---- the walk on several threads (round 6) ----------------------------------------------------------------------------------
+ * The walk is bound by the latency of the interpreter's object graph (~75 ns per block over five levels of pointers), not by work:
+ * it scales with threads.  The calling thread HOLDS THE GIL and waits in pthread_join, so no Python code runs and nothing is mutated
+ * while the workers run; the workers only READ -- borrowed references, no reference count is touched, no Python API that can
+ * allocate, raise or run user code is called (exact str keys with cached hashes through _PyDict_GetItem_KnownHash, exact ndarrays
+ * through the array struct, exact small ints) -- and write rows of the caller's column arrays at positions fixed by the block index.
+ * Anything irregular (another type, a key without a cached hash, a group not yet known, an observation that is not three doubles)
+ * ends a worker's chunk; the first such block over all chunks is where the caller continues serially, exactly as before.
+ * PYSLAM_AMD_LOWER_THREADS=1 switches it off (lowering.py passes the thread count). */
+typedef struct {
+    PyObject **blocks, **keys, **losses;
+    Py_ssize_t lo, hi, stop;                 /* chunk [lo, hi); stop = first block NOT taken */
+    Py_ssize_t row0, i_base;                 /* block i goes to row row0 + (i - i_base) */
+    PyTypeObject* reproj_tp;
+    PyObject *pose_ix, *point_ix;
+    const GroupSlot* slots; int nslots;
+    int32_t *o_pose, *o_pt, *o_g; double* o_uvd;
+    Py_hash_t h_camera, h_stiffness, h_obs;
+} WalkChunk;
+
+static inline Py_hash_t cached_str_hash(PyObject* k) {
+    return PyUnicode_CheckExact(k) ? ((PyASCIIObject*)k)->hash : -1;
+}
+
+static void* walk_chunk(void* arg) {
+    WalkChunk* c = (WalkChunk*)arg;
+    Py_ssize_t i = c->lo;
+    for (; i < c->hi; ++i) {
+        PyObject* block = c->blocks[i];
+        if (Py_TYPE(block) != c->reproj_tp) break;
+        PyObject* ks = c->keys[i];
+        PyObject *k0, *k1;
+        if (PyList_CheckExact(ks) && PyList_GET_SIZE(ks) == 2) { k0 = PyList_GET_ITEM(ks, 0); k1 = PyList_GET_ITEM(ks, 1); }
+        else if (PyTuple_CheckExact(ks) && PyTuple_GET_SIZE(ks) == 2) { k0 = PyTuple_GET_ITEM(ks, 0); k1 = PyTuple_GET_ITEM(ks, 1); }
+        else break;
+        const Py_hash_t h0 = cached_str_hash(k0), h1 = cached_str_hash(k1);
+        if (h0 == -1 || h1 == -1) break;
+        PyObject* pi = _PyDict_GetItem_KnownHash(c->pose_ix, k0, h0);
+        PyObject* qi = pi ? _PyDict_GetItem_KnownHash(c->point_ix, k1, h1) : NULL;
+        if (!pi || !qi || !PyLong_CheckExact(pi) || !PyLong_CheckExact(qi)) break;
+        PyObject** dp = _PyObject_GetDictPtr(block);
+        if (!dp || !*dp) break;
+        PyObject* cam = _PyDict_GetItem_KnownHash(*dp, s_camera, c->h_camera);
+        PyObject* stiff = cam ? _PyDict_GetItem_KnownHash(*dp, s_stiffness, c->h_stiffness) : NULL;
+        PyObject* obs = stiff ? _PyDict_GetItem_KnownHash(*dp, s_obs, c->h_obs) : NULL;
+        if (!obs) break;
+        PyObject* loss = c->losses[i];
+        long g = -1;
+        for (int q = 0; q < c->nslots; ++q)
+            if (c->slots[q].cam == cam && c->slots[q].stiff == stiff && c->slots[q].loss == loss) { g = c->slots[q].g; break; }
+        if (g < 0) break;
+        const Py_ssize_t row = c->row0 + (i - c->i_base);
+#ifndef PS_LOWER_NO_NUMPY
+        if (!PyArray_CheckExact(obs)) break;
+        PyArrayObject* a = (PyArrayObject*)obs;
+        if (!(PyArray_TYPE(a) == NPY_DOUBLE && PyArray_ISNOTSWAPPED(a) && PyArray_ISALIGNED(a) && PyArray_SIZE(a) == 3 && PyArray_IS_C_CONTIGUOUS(a))) break;
+        memcpy(c->o_uvd + 3 * row, PyArray_DATA(a), 24);
+#else
+        break;
+#endif
+        /* exact ints of at most one 30-bit digit (indices into tables of < 2^30 rows): read from the object, no API call */
+        const Py_ssize_t sp = Py_SIZE(pi), sq = Py_SIZE(qi);
+        if (sp < 0 || sp > 1 || sq < 0 || sq > 1) break;
+        c->o_pose[row] = sp ? (int32_t)((PyLongObject*)pi)->ob_digit[0] : 0;
+        c->o_pt[row] = sq ? (int32_t)((PyLongObject*)qi)->ob_digit[0] : 0;
+        c->o_g[row] = (int32_t)g;
+    }
+    c->stop = i;
+    return NULL;
+}
+
 /* walk(blocks, keys, losses, i0, param_dict, pose_ix, point_ix, group_of, o_pose, o_pt, o_uvd, o_g, count)
  * -> (i, count): blocks i0 .. i-1 were taken; block i (if i < len) is for the caller */
 static PyObject* walk(PyObject* self, PyObject* args) {
     PyObject *blocks, *keys, *losses, *param_dict, *pose_ix, *point_ix, *group_of, *a_pose, *a_pt, *a_uvd, *a_g;
     Py_ssize_t i0, count;
-    if (!PyArg_ParseTuple(args, "OOOnOOOOOOOOn", &blocks, &keys, &losses, &i0, &param_dict, &pose_ix, &point_ix, &group_of,
-                          &a_pose, &a_pt, &a_uvd, &a_g, &count)) return NULL;
+    int nthreads = 1;
+    if (!PyArg_ParseTuple(args, "OOOnOOOOOOOOn|i", &blocks, &keys, &losses, &i0, &param_dict, &pose_ix, &point_ix, &group_of,
+                          &a_pose, &a_pt, &a_uvd, &a_g, &count, &nthreads)) return NULL;
     if (!PyList_Check(blocks) || !PyList_Check(keys) || !PyList_Check(losses) || !PyDict_Check(param_dict) ||
         !PyDict_Check(pose_ix) || !PyDict_Check(point_ix))
         return Py_BuildValue("nn", i0, count);
@@ -76,6 +150,36 @@ static PyObject* walk(PyObject* self, PyObject* args) {
     Py_ssize_t i = i0;
     for (; i < n && !failed; ++i) {
         if (count >= cap) break;
+        /* (round 6) a long run, the type known to have plain attributes, the group table warm: the rest on several threads */
+        if (nthreads > 1 && plain && reproj_tp && nslots > 0 && i - i0 >= 256 && n - i >= 65536 && cap - count >= n - i) {
+            enum { MAXT = 16 };
+            const int T = nthreads > MAXT ? MAXT : nthreads;
+            WalkChunk ch[MAXT];
+            pthread_t th[MAXT];
+            const Py_ssize_t span = n - i;
+            const Py_hash_t hc = cached_str_hash(s_camera), hs = cached_str_hash(s_stiffness), ho = cached_str_hash(s_obs);
+            int started = 0;
+            if (hc != -1 && hs != -1 && ho != -1) {
+                for (int t = 0; t < T; ++t) {
+                    WalkChunk* c = &ch[t];
+                    c->blocks = ((PyListObject*)blocks)->ob_item; c->keys = ((PyListObject*)keys)->ob_item; c->losses = ((PyListObject*)losses)->ob_item;
+                    c->lo = i + span * t / T; c->hi = i + span * (t + 1) / T; c->stop = c->lo;
+                    c->row0 = count; c->i_base = i; c->reproj_tp = reproj_tp; c->pose_ix = pose_ix; c->point_ix = point_ix;
+                    c->slots = slots; c->nslots = nslots; c->o_pose = o_pose; c->o_pt = o_pt; c->o_g = o_g; c->o_uvd = o_uvd;
+                    c->h_camera = hc; c->h_stiffness = hs; c->h_obs = ho;
+                }
+                for (int t = 1; t < T; ++t) { if (pthread_create(&th[t], NULL, walk_chunk, &ch[t])) break; started = t; }
+                walk_chunk(&ch[0]);
+                for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+                /* blocks are taken up to the first one some chunk did not take (a chunk whose thread could not be started took none) */
+                Py_ssize_t stop = ch[0].stop;
+                if (stop == ch[0].hi) for (int t = 1; t < T; ++t) { if (t > started) break; stop = ch[t].stop; if (stop != ch[t].hi) break; }
+                count += stop - i;
+                i = stop;
+                nthreads = 1;                    /* (whatever is left: serially, from the block that ended the run) */
+                if (i >= n) break;
+            } else nthreads = 1;
+        }
         /* the walk is bound by the latency of the interpreter's object graph (block -> its dictionary -> the values -> obs -> data):
          * ask for the next blocks' first levels while this one is taken */
         if (i + 12 < n) { __builtin_prefetch(PyList_GET_ITEM(blocks, i + 12)); __builtin_prefetch(PyList_GET_ITEM(keys, i + 12)); }
@@ -176,7 +280,10 @@ static PyObject* classify(PyObject* self, PyObject* args) {
     PyObject *param_dict, *pose_types, *nd_type;
     if (!PyArg_ParseTuple(args, "O!OO", &PyDict_Type, &param_dict, &pose_types, &nd_type)) return NULL;
     PyObject *poses = PyList_New(0), *points = PyList_New(0), *badkey = Py_None;
-    if (!poses || !points) { Py_XDECREF(poses); Py_XDECREF(points); return NULL; }
+    /* (round 6) the index dictionaries key -> position of the two lists, filled in the same pass (they were two dictionary
+     * comprehensions over 50 000 keys on the Python side: 4 ms of a C3 lowering) */
+    PyObject *pose_ix = PyDict_New(), *point_ix = PyDict_New();
+    if (!poses || !points || !pose_ix || !point_ix) { Py_XDECREF(poses); Py_XDECREF(points); Py_XDECREF(pose_ix); Py_XDECREF(point_ix); return NULL; }
     Py_ssize_t pos = 0;
     PyObject *key, *val;
     PyTypeObject* last_pose_tp = NULL;
@@ -184,13 +291,18 @@ static PyObject* classify(PyObject* self, PyObject* args) {
         int is_pose = Py_TYPE(val) == last_pose_tp;
         if (!is_pose && (PyObject*)Py_TYPE(val) != nd_type) {
             is_pose = PyObject_IsInstance(val, pose_types);
-            if (is_pose < 0) { Py_DECREF(poses); Py_DECREF(points); return NULL; }
+            if (is_pose < 0) { Py_DECREF(poses); Py_DECREF(points); Py_DECREF(pose_ix); Py_DECREF(point_ix); return NULL; }
             if (is_pose) last_pose_tp = Py_TYPE(val);
         }
-        if (is_pose) { if (PyList_Append(poses, key)) { Py_DECREF(poses); Py_DECREF(points); return NULL; } continue; }
+        if (is_pose) {
+            PyObject* ix = PyLong_FromSsize_t(PyList_GET_SIZE(poses));
+            if (!ix || PyDict_SetItem(pose_ix, key, ix) || PyList_Append(poses, key)) { Py_XDECREF(ix); Py_DECREF(poses); Py_DECREF(points); Py_DECREF(pose_ix); Py_DECREF(point_ix); return NULL; }
+            Py_DECREF(ix);
+            continue;
+        }
         int ok = 0;
         const int is_nd = (PyObject*)Py_TYPE(val) == nd_type ? 1 : PyObject_IsInstance(val, nd_type);
-        if (is_nd < 0) { Py_DECREF(poses); Py_DECREF(points); return NULL; }
+        if (is_nd < 0) { Py_DECREF(poses); Py_DECREF(points); Py_DECREF(pose_ix); Py_DECREF(point_ix); return NULL; }
         if (is_nd) {
 #ifndef PS_LOWER_NO_NUMPY
             if (PyArray_Check(val)) ok = PyArray_NDIM((PyArrayObject*)val) == 1 && PyArray_DIM((PyArrayObject*)val, 0) == 3;
@@ -203,9 +315,13 @@ static PyObject* classify(PyObject* self, PyObject* args) {
             }
         }
         if (!ok) { badkey = key; break; }
-        if (PyList_Append(points, key)) { Py_DECREF(poses); Py_DECREF(points); return NULL; }
+        {
+            PyObject* ix = PyLong_FromSsize_t(PyList_GET_SIZE(points));
+            if (!ix || PyDict_SetItem(point_ix, key, ix) || PyList_Append(points, key)) { Py_XDECREF(ix); Py_DECREF(poses); Py_DECREF(points); Py_DECREF(pose_ix); Py_DECREF(point_ix); return NULL; }
+            Py_DECREF(ix);
+        }
     }
-    return Py_BuildValue("NNO", poses, points, badkey);
+    return Py_BuildValue("NNONN", poses, points, badkey, pose_ix, point_ix);
 }
 
 static int is_f64x3(const Py_buffer* v) {

@@ -187,7 +187,12 @@ int xcg_side_enqueue(ps_problem* h) {
         }
     }
     if (!xcg_ac_on_main()) xcg_assemble_ac<D>(h, h->side);
-    HIP_OK(hipEventRecord(h->ev_acdone, h->side));
+    // (measurement switches of the low-priority hunt: PS_XCG_ACDONE_LATE=1 records ev_acdone at the END of the side job instead of
+    //  between assembly and factorisation -- the solver stream then waits for the whole job before it rewrites SB / the basis, which is
+    //  safe; PS_XCG_SIDE_PAD=1 puts a one-workgroup dummy kernel between the event and the factorisation)
+    static const bool acdone_late = ps_env("PS_XCG_ACDONE_LATE") != nullptr, side_pad = ps_env("PS_XCG_SIDE_PAD") != nullptr;
+    if (!acdone_late) HIP_OK(hipEventRecord(h->ev_acdone, h->side));
+    if (side_pad) copy_doubles(h->side, h->xy, h->xy, 1);
     h->acdone_pending = true;
     // (measurement switches of the low-priority hunt, tools/probes/lowprio_hunt.sh: PS_XCG_AC_WAIT=1 the solver stream waits for the
     //  side stream's assembly at once; =2 it waits for the whole side job)
@@ -223,6 +228,7 @@ int xcg_side_enqueue(ps_problem* h) {
     }
     if (ac_check && h->chk_Ac_side)
         hipLaunchKernelGGL(k_cmp_bits, dim3(64), dim3(256), 0, h->side, (size_t)h->nc * h->nc, (const double*)h->Ac, (const double*)h->chk_Ac_side, h->chk_cnt, 3);
+    if (acdone_late) HIP_OK(hipEventRecord(h->ev_acdone, h->side));
     HIP_OK(hipEventRecord(h->ev_chol, h->side));
     if (ac_wait == 2) HIP_OK(hipStreamWaitEvent(h->stream, h->ev_chol, 0));
     h->lci_next = nb; h->side_pending = true; h->xcg_tag[nb] = h->xcg_setup_cost; h->xcg_tag_lambda[nb] = h->xcg_setup_lambda;

@@ -261,6 +261,17 @@ def _loss_id_k(loss):
 _FAST = [False, None]        # [looked for, the C walk or None]
 
 
+def _walk_threads():
+    """Threads of the C walk over long runs of reprojection blocks (cext/lower_fast.c: read-only workers under the caller's GIL):
+    PYSLAM_AMD_LOWER_THREADS, default min(16, cores); 1 = the serial walk."""
+    import os
+    try:
+        n = int(os.environ.get('PYSLAM_AMD_LOWER_THREADS', '0'))
+    except ValueError:
+        n = 0
+    return n if n > 0 else max(1, min(16, os.cpu_count() or 1))
+
+
 def _fast_walk():
     """pyslam_amd/cext/lower_fast.c (built by __graft_entry__.build() into pyslam_amd/lib/_lower_fast<EXT_SUFFIX>, or here on
     first use when a C compiler is at hand): the walk over runs of reprojection blocks.  None -- every block through the
@@ -311,7 +322,7 @@ def _load_fast_walk(rebuild=False):
                 np_inc = ['-I' + np.get_include()] if os.path.exists(os.path.join(np.get_include(), 'numpy', 'arrayobject.h')) else ['-DPS_LOWER_NO_NUMPY']
             except Exception:       # noqa: BLE001
                 np_inc = ['-DPS_LOWER_NO_NUMPY']
-            subprocess.run(['gcc', '-O2', '-shared', '-fPIC', '-I' + sysconfig.get_paths()['include']] + np_inc + [src, '-o', tmp], check=True,
+            subprocess.run(['gcc', '-O2', '-shared', '-fPIC', '-pthread', '-I' + sysconfig.get_paths()['include']] + np_inc + [src, '-o', tmp], check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             os.replace(tmp, out)
         finally:
@@ -336,11 +347,9 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
     fast = _fast_walk()
     if fast is not None and type(param_dict) is dict:
         # the same split in C (pyslam_amd/cext/lower_fast.c: classify): the keys in the dictionary's order
-        pose_keys, point_keys, bad = fast.classify(param_dict, (SE3, SE2), np.ndarray)
+        pose_keys, point_keys, bad, pose_ix, point_ix = fast.classify(param_dict, (SE3, SE2), np.ndarray)
         if bad is not None:
             raise NotLowerable("parameter {!r} is neither an SE2/SE3 pose nor a 3-vector".format(bad))
-        pose_ix = {k: i for i, k in enumerate(pose_keys)}
-        point_ix = {k: i for i, k in enumerate(point_keys)}
         for key in pose_keys:
             d = param_dict[key].dof
             if dof is None:
@@ -424,7 +433,7 @@ def lower(param_dict, residual_blocks, block_param_keys, block_loss_functions,
             # a run of consecutive reprojection blocks in C (pyslam_amd/cext/lower_fast.c); it stops at the first block it
             # does not take, which then goes through the general path below
             nxt, cnt = walk(residual_blocks, block_param_keys, block_loss_functions, i, param_dict, pose_ix, point_ix, obs_group,
-                            o_pose, o_pt, o_uvd, o_g, cnt)
+                            o_pose, o_pt, o_uvd, o_g, cnt, _walk_threads())
             if nxt > i:
                 i = nxt - 1
                 continue

@@ -183,3 +183,36 @@ def test_parameter_split_gather_and_write_back_with_unusual_landmark_arrays():
                 problem._lower()
         finally:
             lowering._FAST[:] = [False, None]
+
+
+def test_the_walk_on_several_threads_gives_the_serial_walks_tables(monkeypatch):
+    """Round 6: long runs of reprojection blocks are walked by read-only worker threads under the caller's GIL
+    (cext/lower_fast.c: walk_chunk; PYSLAM_AMD_LOWER_THREADS).  Same tables as the serial walk and as the Python loop -- also when
+    irregular blocks sit inside the workers' chunks: an observation that is a list, a float32 one, a key that is not an exact str
+    (handed back to the Python loop one by one, the run starts again behind each), a second loss and a block of another kind."""
+    assert _walk_available()
+    lp, _ = synthetic.stereo_ba(num_kf=40, num_lm=18000, obs_per_lm=5, half_window=8, seed=6)      # 90 000 blocks: beyond the 65 536 a run needs
+    problem = synthetic.to_objects(lp, NS)
+    n = len(problem.residual_blocks)
+    assert n >= 70000
+
+    class KeyStr(str):
+        pass
+    blocks, keys, losses = problem.residual_blocks, problem.block_param_keys, problem.block_loss_functions
+    blocks[30000].obs = [float(v) for v in blocks[30000].obs]                     # a list
+    blocks[61234].obs = np.asarray(blocks[61234].obs, dtype=np.float32)           # not float64
+    keys[45000] = [KeyStr(keys[45000][0]), keys[45000][1]]                        # equal to the key, not an exact str
+    losses[52000] = Ls.HuberLoss(2.0)                                             # a group the warm-up has not seen
+    losses[52001] = losses[52000]
+    out = {}
+    for threads in ('1', '3', '8'):
+        monkeypatch.setenv('PYSLAM_AMD_LOWER_THREADS', threads)
+        out[threads] = problem._lower()
+    lowering._FAST[:] = [True, None]
+    try:
+        slow = problem._lower()
+    finally:
+        lowering._FAST[:] = [False, None]
+    for threads in out:
+        _same(out[threads], slow)
+    assert out['8'].num_obs == n and len(out['8'].obs_groups) == 2
