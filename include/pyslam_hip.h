@@ -385,6 +385,9 @@ int ps_debug_table_checksums(ps_problem* h, uint64_t* out, int capacity, int* co
                               compute units the handle's stream may use (device count, stream CU mask, occupancy of the kernel:
                               ps_problem_info.persist_cus / persist_cus_needed) and while one-launch solves of other handles of the
                               process leave them free (cg_persist_refused)
+     "cg_pipelined"       [0] the one-launch folded CG with pipelined recurrences (the dot products formed while the exchange is in
+                              flight): 2 = always (-2.8 % at C3; costs CG iterations and digits on ill-conditioned systems), 1 = only
+                              when the previous reduced solve of the handle took at most 32 iterations, 0 = Chronopoulos-Gear
      "xcg_persist"        [1] the explicit two-level PCG of bundle adjustments (long rows, one workgroup per compute unit of the stream: up to 2 048 poses on a whole MI355X) in ONE
                               launch per solve (csrc/ps_k_xcg_persist.h): matrix in registers / LDS, w, partials and records exchanged
                               in-launch; 0: one launch per iteration (k_xcg_fused1).  Time-outs as "cg_persist"

@@ -353,6 +353,12 @@ struct ps_problem {
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     // the folded CG in ONE launch (ps_k_cg_persist.h): option "cg_persist"; task table built with the coarse level
     int cg_persist = 1;
+    // option "cg_pipelined": the one-launch folded CG with the PIPELINED recurrences (ps_k_cg_persist.h, round 6; measured, OFF by
+    // default).  Always on (2) they take 2.8 % off a C3 iteration (0.4 us per CG iteration) and cost iterations and digits on
+    // ill-conditioned systems (pose graphs: 74 CG iterations where Chronopoulos-Gear takes 60, the step 4e-9 off); restricted to
+    // solves whose predecessor on the handle took at most 32 iterations (1) the gain is gone (the first call of every solve is
+    // excluded and two instantiations alternate): 0.3074 against 0.3038 ms.  0 (default) = Chronopoulos-Gear everywhere
+    int cg_pipelined = 0;
     bool cp_ok = false;             // the augmented system fits the kernel's layout
     bool cp_recovered = false;      // the launch just enqueued recovers x itself when it converges
     int cp_ntasks = 0, cg_max_launches = 0;

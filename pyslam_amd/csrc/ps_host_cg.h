@@ -437,8 +437,9 @@ int build_coarse(ps_problem* h) {
         const bool cp_ne6 = (long)tasks.size() * D <= 6L * PS_CP_NT;
         int cp_per_cu = 0;
         {
-            const void* kfn = D == 6 ? (cp_ne6 ? (const void*)k_cg_persist<6, 6> : (const void*)k_cg_persist<6, 12>)
-                                     : (cp_ne6 ? (const void*)k_cg_persist<3, 6> : (const void*)k_cg_persist<3, 12>);
+            // (the Chronopoulos-Gear instantiation: it holds more registers than the pipelined one, so its answer covers both)
+            const void* kfn = D == 6 ? (cp_ne6 ? (const void*)k_cg_persist<6, 6, false> : (const void*)k_cg_persist<6, 12, false>)
+                                     : (cp_ne6 ? (const void*)k_cg_persist<3, 6, false> : (const void*)k_cg_persist<3, 12, false>);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&cp_per_cu, kfn, PS_CP_NT, 0) != hipSuccess) { (void)hipGetLastError(); cp_per_cu = 0; }
         }
         h->cp_cus_needed = cp_per_cu > 0 ? cdiv(cp_nwg, cp_per_cu) : 0;
@@ -870,13 +871,17 @@ void cg_fused_launch(ps_problem* h, double tol, int count) {
             hipMemsetAsync(h->cp_exch, 0, (size_t)4 * h->cp_ntasks * D * sizeof(unsigned long long), h->stream);
             h->cp_salt = 1;
         }
-#define PS_CP_LAUNCH(NE) hipLaunchKernelGGL((k_cg_persist<D, NE>), dim3(cdiv(h->cp_ntasks, PS_CP_NT / 64)), dim3(PS_CP_NT), 0, h->stream, h->nr_aug * D, \
+#define PS_CP_LAUNCH_(NE, PIPE) hipLaunchKernelGGL((k_cg_persist<D, NE, PIPE>), dim3(cdiv(h->cp_ntasks, PS_CP_NT / 64)), dim3(PS_CP_NT), 0, h->stream, h->nr_aug * D, \
                            h->cp_ntasks, (const CpTask*)h->cp_tasks, h->cp_row_task0, h->acol_idx, h->Saug, h->cg_r[0], h->cg_w[0], h->cg_s[0], h->cg_p, \
                            h->cg_xh, h->hist, cap, nl, tol2, h->status, h->scalars, h->cp_exch, h->cp_salt, h->cp_spin, h->cp_dbg,                  \
                            CpRecover{h->nr, h->ncb, h->pnode, h->pw0, h->pw1, h->Linv, h->Lci2[h->lci_cur], h->Bmat, h->x})
         // (two instantiations by the number of exchanged sums per thread: the small one keeps 40 registers and 24 KB of LDS free)
+        // pipelined recurrences only where the last solve was an easy one (ps_core.hip: cg_pipelined)
+        const bool pipe = h->cg_pipelined == 2 || (h->cg_pipelined == 1 && h->last_pcg_iters > 0 && h->last_pcg_iters <= 32);
+#define PS_CP_LAUNCH(NE) do { if (pipe) PS_CP_LAUNCH_(NE, true); else PS_CP_LAUNCH_(NE, false); } while (0)
         if ((long)h->cp_ntasks * D <= 6L * PS_CP_NT) PS_CP_LAUNCH(6); else PS_CP_LAUNCH(12);
 #undef PS_CP_LAUNCH
+#undef PS_CP_LAUNCH_
         h->cg_launched = nl; h->cg_kernel_launches += 1; ++h->cp_launches;
         h->cp_recovered = true;                               // (a converged solve leaves x behind: the gated k_coarse_recover is not needed)
         return;

@@ -55,7 +55,7 @@ PS_DEV void cp_put(ps_u64* g, unsigned tag, double v) {
     __hip_atomic_store((ps_gu64*)(g + 1), ((ps_u64)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int D, int NE>
+template <int D, int NE, bool PIPE = false>
 __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
     int n /* augmented unknowns */, int ntasks, const CpTask* __restrict__ tasks,
     const int32_t* __restrict__ row_task0 /* first task of every block row; [rows] = ntasks */,
@@ -115,6 +115,133 @@ __global__ __launch_bounds__(PS_CP_NT) void k_cg_persist(
     long long ck[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PS_CP_CLK(i) do { if (dbg) { const long long now_ = wall_clock64(); ck[i] += now_ - last_; last_ = now_; } } while (0)
     long long last_ = dbg ? wall_clock64() : 0;
+    if constexpr (PIPE) {
+        // ---- round 6: the PIPELINED recurrences (Ghysels & Vanroose), option "cg_pipelined".  The Chronopoulos-Gear loop below cannot
+        // start an iteration's products before its own dot products are summed (r_{k+1} needs alpha_k, alpha_k needs w_k . r_k, w_k is
+        // what the exchange delivers): per iteration  gather -> barrier -> dots -> barrier -> recurrences -> barrier -> products, all on
+        // the critical path.  Here the product is applied to w_k = S^ r_k, which the END of the previous iteration already knows
+        // (w_k = w_{k-1} - alpha z_{k-1}, z = S^ s): the products are published FIRST and gamma = r.r, delta = w.r, alpha, beta are
+        // formed while the exchange is in flight;  then  z = q + beta z,  s = w + beta s,  p = r + beta p,  x += alpha p,
+        // r -= alpha s,  w -= alpha z  with q = S^ w_k.  Two barriers per iteration instead of three, the dots off the critical path.
+        // Same alpha, beta, gamma sequence in exact arithmetic (history, stopping rule, status words as below); one more replicated
+        // vector (z).  The operator is the scaled two-level one (eigenvalues 0.74 .. 2.05): the drift of the recurred w, z against the
+        // true products is ~ iterations x eps, far below the 1e-12 the solve stops at.
+        double vz[PS_CP_NV];
+#pragma unroll
+        for (int v = 0; v < PS_CP_NV; ++v) vz[v] = 0.0;
+        for (int k = -1; k < nlaunch - 1; ++k) {
+            double (*rd)[PS_CP_NT / 64] = red[k & 1];
+            // ---- the vector to multiply into LDS (pass -1: r_0, whose product is w_0; then w_k), the two dots' partials beside it
+            double gs = 0.0, ds = 0.0;
+#pragma unroll
+            for (int v = 0; v < PS_CP_NV; ++v) {
+                const int i = t + v * PS_CP_NT;
+                if (i < n) { rn[i] = (k < 0) ? vr[v] : vw[v]; gs += vr[v] * vr[v]; ds += vw[v] * vr[v]; }
+            }
+            gs = wave_sum(gs); ds = wave_sum(ds);
+            if (lane == 0) { rd[0][wv] = gs; rd[1][wv] = ds; }
+            PS_CP_CLK(0);
+            __syncthreads();
+            PS_CP_CLK(1);
+            // ---- this wave's task: six sums of S^(row, its blocks) x that vector, published as tagged granules
+            const unsigned tag = salt * 4096u + (unsigned)(k + 2);
+            ps_u64* buf = exch + (size_t)(k & 1) * nex * 2;
+            {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < PS_CP_NQ; ++q) {
+                    const double* vv = rn + cj[q];
+#pragma unroll
+                    for (int c = 0; c < D; ++c) acc += sv[q][c] * vv[c];
+                }
+                acc += __shfl_xor(acc, 8, 64);
+                acc += __shfl_xor(acc, 16, 64);
+                acc += __shfl_xor(acc, 32, 64);
+                if (task < ntasks && lane < D) cp_put(buf + 2 * ((size_t)task * D + lane), tag, acc);
+            }
+            PS_CP_CLK(2);
+            // ---- while the exchange is in flight: gamma_k = r_k . r_k, delta_k = w_k . r_k, the stopping rule, alpha_k, beta_k
+            double alpha = 0.0, beta = 0.0;
+            bool stop_now = false;
+            if (k >= 0) {
+                gamma = 0.0; delta = 0.0;
+#pragma unroll
+                for (int w2 = 0; w2 < PS_CP_NT / 64; ++w2) { gamma += rd[0][w2]; delta += rd[1][w2]; }
+                if (k == 0) thresh = tol2 * gamma;
+                if (!(gamma > thresh)) {                     // converged (gamma == 0 too); NaN = breakdown
+                    if (chief) { status[ST_PCG_DONE] = (gamma != gamma) ? 2 : 1; scalars[SC_RRFINAL] = gamma; if (k == 0) scalars[SC_RR0] = gamma; }
+                    converged = !(gamma != gamma);
+                    stop_now = true;
+                } else {
+                    beta = (k == 0) ? 0.0 : gamma * inv_gprev;
+                    const double denom = (k == 0) ? delta : delta - beta * gamma * inv_aprev;
+                    alpha = gamma / denom;
+                    if (!(denom > 0.0)) {                    // breakdown: stop, the host reports it
+                        if (chief) { status[ST_PCG_DONE] = 2; scalars[SC_RRFINAL] = gamma; }
+                        stop_now = true;
+                    } else {
+                        if (chief) {
+                            hist[k] = gamma; hist[cap + k] = alpha; status[ST_PCG_ITERS] = k + 1; scalars[SC_RRFINAL] = gamma;
+                            if (k == 0) { scalars[SC_THRESH] = thresh; scalars[SC_RR0] = gamma; }
+                        }
+                        inv_gprev = 1.0 / gamma; inv_aprev = 1.0 / alpha;
+                    }
+                }
+            }
+            if (stop_now) break;                             // (uniform: every workgroup sums the same numbers in the same order)
+            // ---- gather every published sum, then q of every entry = the sum of its row's tasks, in task order, from LDS
+            {
+                double gv[NE];
+                bool ok = false;
+                const long long t_enter = (long long)wall_clock64();
+                for (unsigned spins = 0; !ok; ++spins) {
+                    ok = true;
+#pragma unroll
+                    for (int v = 0; v < NE; ++v) {
+                        const int j = t + v * PS_CP_NT;
+                        gv[v] = 0.0;
+                        if (j < (int)nex) {
+                            const ps_u64* g = buf + 2 * (size_t)j;
+                            const ps_u64 a = __hip_atomic_load((const ps_gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const ps_u64 b = __hip_atomic_load((const ps_gu64*)(g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+                            gv[v] = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+                        }
+                    }
+                    ok = __all(ok);
+                    if (!ok) {
+                        if (spins > spin_limit || (long long)wall_clock64() - t_enter > PS_PERSIST_TIMEOUT_TICKS) { bad = 1; break; }
+                        if (PS_CP_SLEEP) __builtin_amdgcn_s_sleep(PS_CP_SLEEP);
+                        ck[7] += 1;
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < NE; ++v) { const int j = t + v * PS_CP_NT; if (j < (int)nex) wex[j] = gv[v]; }
+            }
+            PS_CP_CLK(3);
+            __syncthreads();
+            PS_CP_CLK(4);
+            if (bad) {                                       // an exchange timed out: a breakdown the host answers with the other kernels
+                if (t == 0) { status[ST_PCG_DONE] = 2; status[ST_PERSIST_FAIL] = 1; }
+                break;
+            }
+#pragma unroll
+            for (int v = 0; v < PS_CP_NV; ++v) {
+                double q = 0.0;
+                for (int m = 0; m < en[v]; ++m) q += wex[e0[v] + m * D];
+                if (k < 0) vw[v] = q;                        // w_0 = S^ r_0
+                else {
+                    vz[v] = q + beta * vz[v];
+                    vs[v] = vw[v] + beta * vs[v];
+                    vp[v] = vr[v] + beta * vp[v];
+                    vx[v] += alpha * vp[v];
+                    vr[v] -= alpha * vs[v];
+                    vw[v] -= alpha * vz[v];
+                }
+            }
+            PS_CP_CLK(5);
+        }
+    } else
     for (int k = -1; k < nlaunch - 1; ++k) {
         double alpha = 0.0, beta = 0.0;
         if (k >= 0) {

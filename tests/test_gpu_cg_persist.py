@@ -154,3 +154,29 @@ def test_one_launch_explicit_pcg_equals_the_launch_per_iteration_form(name, make
         assert abs(tc[0] - tb[0]) <= 1e-10 * abs(tb[0])
     for other in (b, c):
         assert np.abs(a[1][0] - other[1][0]).max() <= 1e-9 and np.abs(a[1][1] - other[1][1]).max() <= 1e-8
+
+
+def test_pipelined_recurrences_give_the_same_solve_on_a_well_conditioned_system():
+    """Round 6, option cg_pipelined (off by default: DESIGN.md section 5): the one-launch CG with the pipelined recurrences -- products of
+    w_k published first, the dot products formed while the exchange is in flight -- is the same Krylov iteration: on a bundle
+    adjustment (preconditioned condition number ~3) the same iteration counts, the step to 1e-9, the trajectory to 1e-10."""
+    from pyslam_amd.device import DeviceProblem
+    lp, _ = synthetic.stereo_ba(num_kf=200, num_lm=12000, obs_per_lm=10, half_window=20, seed=0)
+    out = {}
+    for pipe in (2, 0):
+        dev = DeviceProblem(lp)
+        dev.set_option('cg_pipelined', pipe)
+        dev.set_option('lagged_inverse', 0)
+        dev.linearize(0.0)
+        its, relres = dev.solve_reduced(1e-13, 4000)
+        dev.backsub()
+        xp, xl = dev.get_dx()
+        trace = [dev.gn_iteration(0.0, 1e-12, 4000, True) for _ in range(3)]
+        out[pipe] = (its, relres, xp, xl, trace, dev.cg_persist_counts())
+        dev.close()
+    a, b = out[2], out[0]
+    assert a[5][0] >= 4 and a[5][1] == 0
+    assert abs(a[0] - b[0]) <= 1 and a[1] <= 1e-13 * 1.001
+    assert rel(a[2], b[2]) <= 1e-9 and rel(a[3], b[3]) <= 1e-9
+    for ta, tb in zip(a[4], b[4]):
+        assert abs(ta[0] - tb[0]) <= 1e-10 * abs(tb[0]) and abs(ta[2] - tb[2]) <= 1
