@@ -122,7 +122,8 @@ def run(n_cases, seed0=0, verbose=True):
             if not ok and its >= 4000 and (mode == 'nocoarse' or (mode == 'G' and lp.num_reduced >= 100 * g_forced)):
                 ok = True          # a long chain with the coarse level switched off -- or forced down to one interval per 100+ poses
                                    # (round 6, case 1021025: 700 poses, ONE interval) -- does not converge in 4 000 iterations: expected
-            if not ok and its > 0 and its < 4000:
+            if not ok and its < 4000:          # (its == 0: the direct solve of a small reduced system -- round 6, case 1125238: an SE(2) chain of
+                                               #  condition 1e12 whose cost misses 1e-7 by 2e-8: the residual decides there too)
                 # ill-conditioned system or a wrong solve?  the device step must satisfy the ORACLE's normal equations
                 Pm, bv, _ = orc.normal_equations(lp, points_first=False, lm_lambda=lam)
                 xp, xl = dev.get_dx()

@@ -161,10 +161,12 @@ def _two_rank_worker(rank, world, port, out, native, exchange='allreduce'):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('native,exchange', [(False, 'allreduce'), (True, 'allreduce'), (False, 'segments'), (True, 'segments')])
-def test_two_ranks_on_one_gpu_reproduce_the_unsharded_iterations(native, exchange):
-    """world_size 2 with the real HIP core in both ranks (one GPU, gloo collectives): sharded linearisation,
-    all-reduce of [S | g | cost], replicated reduced solve, shard-local tail, all-reduce of the shard scalars."""
+@pytest.mark.parametrize('native,exchange,world', [(False, 'allreduce', 2), (True, 'allreduce', 2), (False, 'segments', 2), (True, 'segments', 2),
+                                                   (True, 'segments', 3)])
+def test_two_ranks_on_one_gpu_reproduce_the_unsharded_iterations(native, exchange, world):
+    """world_size 2 (3: the core's segment sum with three contributors to a block) with the real HIP core in every rank (one GPU,
+    gloo collectives): sharded linearisation, exchange of [S | g | cost], replicated reduced solve, shard-local tail, all-reduce of
+    the shard scalars."""
     import socket
     import torch
     import torch.multiprocessing as mp
@@ -172,7 +174,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_unsharded_iterations(native, exchang
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, native, exchange)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, q, native, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     trace, poses = q.get(timeout=300)
