@@ -849,6 +849,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "band_chol") { h->band_chol = value != 0; h->lci_next = -1; }
     else if (n == "lm_packed") h->lm_packed = value != 0;
     else if (n == "pose_async") h->pose_async = (int)value;
+    else if (n == "pose_xcd") h->pose_xcd = value != 0;
     else if (n == "cg_pipelined") { if (value != 0 && value != 1 && value != 2) return fail("cg_pipelined must be 0, 1 or 2"); h->cg_pipelined = (int)value; }
     else if (n == "fuse_cost") h->fuse_cost = (int)value;       // 0 off, 1 on, 2 = in the tails only (not the start cost / ps_eval_cost)
     else if (n == "sync_refactor") h->sync_refactor = value != 0;

@@ -460,6 +460,7 @@ struct ps_problem {
     // option "pose_async": the pose pass beside the Schur pair kernel (both read what the landmark pass left: nothing of each
     // other's) -- 1: on a second stream, joined by events in front of the finalisation
     int pose_async = 0;
+    int pose_xcd = 1;               // option "pose_xcd": the pose pass's items in eight contiguous ranges, one per XCD (round 6)
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; 
     // lagged dense inverse of the reduced system as the CG preconditioner (ps_k_ldi.h / ps_host_ldi.h)
     int ldi_enable = 1;             // option "lagged_inverse"

@@ -1074,12 +1074,15 @@ int linearize(ps_problem* h, double lambda, bool allow_prelm) {
             HIP_OK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
             pst = h->aux;
         }
+        // (option "pose_xcd", default on: the pose-ordered items in eight contiguous ranges, one per XCD -- ps_k_linearize.h)
+        const int per_xcd = h->pose_xcd ? cdiv(h->npitems, 8) : 0;
+        const int nblk = per_xcd ? 8 * per_xcd : h->npitems;
         if (h->wide_obs)
-            hipLaunchKernelGGL(k_pose_pass<true>, dim3(h->npitems), dim3(256), 0, pst, h->pitems, h->pobs,
-                               h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp);
+            hipLaunchKernelGGL(k_pose_pass<true>, dim3(nblk), dim3(256), 0, pst, h->pitems, h->pobs,
+                               h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp, h->npitems, per_xcd);
         else
-            hipLaunchKernelGGL(k_pose_pass<false>, dim3(h->npitems), dim3(256), 0, pst, h->pitems, h->pobs,
-                               h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp);
+            hipLaunchKernelGGL(k_pose_pass<false>, dim3(nblk), dim3(256), 0, pst, h->pitems, h->pobs,
+                               h->poses, h->points, h->ogroups, h->Cinv, h->cvec, h->ppartial, lambda != 0.0 ? 1 : 0, wp, h->npitems, per_xcd);
         if (pose_side) HIP_OK(hipEventRecord(h->ev_join, h->aux));
         const bool pose_schur = h->pose_mode && h->schur_mode != 0;
         // tiled Schur: the combine launch also finalizes the poses (unless a task writes a diagonal block)

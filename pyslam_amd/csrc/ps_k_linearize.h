@@ -237,13 +237,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_POSE_WAV
     const double* __restrict__ poses, const double* __restrict__ points,
     const ObsGroup* __restrict__ groups, const double* __restrict__ Cinv,
     const double* __restrict__ cvec, double* __restrict__ partial, int want_diag /* lambda != 0: the six damping sums too */,
-    ObsWide wide)
+    ObsWide wide, int nitems, int per_xcd /* > 0: XCD-major order of the items (round 6), 0: item = workgroup */)
 {
     __shared__ double red[4][PS_NPOSE_ACC];
 #if PS_POSE_TRANSPOSE
     __shared__ double tr[4][64 * 17];
 #endif
-    const PItem it = items[blockIdx.x];
+    // Round 6: workgroup b runs on XCD b % 8 (observed dispatch rule; affects speed only).  The items are in pose order and a pose's
+    // observations gather points / C^-1 / c of the landmarks it sees -- with item = workgroup every XCD walked ALL poses and pulled
+    // the whole landmark table through its own L2 (C3: 60 MB of fabric traffic for 16 MB of records, round-5 verdict weak #4).  With
+    // the item list cut into eight contiguous ranges, one per XCD, an XCD sees one stretch of the trajectory and its landmarks once.
+    const int item = per_xcd > 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (item >= nitems) return;
+    const PItem it = items[item];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const Se3 T = se3_load(poses + 12 * (size_t)it.pad);          // pad = pose table index of this chunk
     double acc[PS_NPOSE_ACC];
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PS_POSE_WAV
 #endif
     __syncthreads();
     if (threadIdx.x < PS_NPOSE_ACC)
-        partial[(size_t)blockIdx.x * PS_NPOSE_ACC + threadIdx.x] =
+        partial[(size_t)item * PS_NPOSE_ACC + threadIdx.x] =
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
