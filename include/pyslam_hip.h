@@ -116,6 +116,8 @@ typedef struct ps_problem_info {
     int32_t persist_cus_needed;  /* units the one-launch form of this handle needs resident (0: the system does not fit the form) */
     int64_t landmark_passes_taken_over; /* linearisations that found their landmark pass done: it ran in the previous call's tail
                                     (or in ps_eval_cost) and summed that cost on its way -- options "expect_next", "fuse_cost"   */
+    int64_t xcg_persist4_solves; /* of cg_persist_solves: those the four-wave form of the explicit PCG ran (k_xcg_persist4: one wave
+                                    per SIMD, its rows of the coarse inverse in registers; option "xcg_persist4")              */
 } ps_problem_info;
 
 enum { PS_NUM_STAGES = 12 };
@@ -391,6 +393,10 @@ int ps_debug_table_checksums(ps_problem* h, uint64_t* out, int capacity, int* co
      "xcg_persist"        [1] the explicit two-level PCG of bundle adjustments (long rows, one workgroup per compute unit of the stream: up to 2 048 poses on a whole MI355X) in ONE
                               launch per solve (csrc/ps_k_xcg_persist.h): matrix in registers / LDS, w, partials and records exchanged
                               in-launch; 0: one launch per iteration (k_xcg_fused1).  Time-outs as "cg_persist"
+     "xcg_persist4"       [1] that launch as FOUR waves per workgroup (one per SIMD: 512 registers per lane) with the workgroup's rows of
+                              the coarse inverse kept in registers (csrc/ps_k_xcg_persist4.h), where the coarse level fits (at most
+                              640 coarse unknowns, 44 rows of y per workgroup); 0: always the eight-wave kernel.  Same bits either way
+     "pose_xcd"           [1] the pose pass's work items in eight contiguous ranges, one per XCD (0: item = workgroup); speed only
      "lm_packed" [1], "band_part" [1], "band_part_chunk" [0 auto], "sync_refactor" [1], "hold_across_steps" [1]: round-5 kernels and
                               schedules against their predecessors (DESIGN.md sections 0 and 3)
      "cg_force_restart"   [0] tests: end the first pass of a synchronous reduced solve at 1e-4 and restart from the true residual

@@ -56,7 +56,7 @@ class ProblemInfo(C.Structure):
         ('ldi_solves', C.c_int64), ('ldi_fallbacks', C.c_int64), ('ldi_seeds', C.c_int64),
         ('xcg_fused_solves', C.c_int64), ('xcg_fused_fallbacks', C.c_int64),
         ('cg_persist_solves', C.c_int64), ('cg_persist_failures', C.c_int64), ('cg_persist_refused', C.c_int64),
-        ('persist_cus', C.c_int32), ('persist_cus_needed', C.c_int32), ('landmark_passes_taken_over', C.c_int64),
+        ('persist_cus', C.c_int32), ('persist_cus_needed', C.c_int32), ('landmark_passes_taken_over', C.c_int64), ('xcg_persist4_solves', C.c_int64),
     ]
 
 
@@ -174,7 +174,7 @@ _CREATE_ENV = {'PS_CREATE_DEVICE', 'PS_CREATE_KEYS64', 'PS_PAIRS_BY_LANDMARK', '
 _MEASURE_ENV = {'PS_ALLOC_GUARD', 'PS_ARENA_POISON', 'PS_BAND_INV_DOT', 'PS_CP_CLOCKS', 'PS_CREATE_TIMING', 'PS_DIRECT_3LAUNCH',
                 'PS_DIRECT_THREADS', 'PS_EVENT_FLAGS', 'PS_F2_ABLATE', 'PS_F2_ROWS', 'PS_HOST_TIMING', 'PS_LAZY_COARSE', 'PS_LDI_SEED_LAG',
                 'PS_POSE_CHUNK', 'PS_RS_ABLATE', 'PS_SCALE_NO_PIPE', 'PS_SCHUR_KEEP_TILES', 'PS_SCHUR_LDS_PAD', 'PS_SCHUR_NO_LPT',
-                'PS_SCHUR_SPLIT', 'PS_SIDE_CUS', 'PS_SIDE_DELAY', 'PS_SIDE_KICK', 'PS_SIDE_LOWPRIO', 'PS_XCG_ACDONE_LATE', 'PS_XCG_AC_CHECK', 'PS_XCG_AC_MAIN', 'PS_XCG_AC_WAIT', 'PS_XCG_INV_SUM', 'PS_XCG_SIDE_PAD', 'PS_XCG_ROWS_RT', 'PS_XF2_PF'}
+                'PS_SCHUR_SPLIT', 'PS_SIDE_CUS', 'PS_SIDE_DELAY', 'PS_SIDE_KICK', 'PS_SIDE_LOWPRIO', 'PS_XCG_ACDONE_LATE', 'PS_XCG_AC_CHECK', 'PS_XCG_AC_MAIN', 'PS_XCG_AC_WAIT', 'PS_XCG_INV_SUM', 'PS_XCG_SIDE_PAD', 'PS_XCG_ROWS_RT', 'PS_XF2_PF', 'PS_XP_CLOCKS'}
 
 
 def load():

@@ -73,6 +73,23 @@ int ps_problem_destroy(ps_problem* h) {
                 c[5] * 1e3 / khz / h->cp_launches);
         hipFree(h->cp_dbg);
     }
+    if (h->xp_dbg) {                                      // (PS_XP_CLOCKS: the LAST launch's time stamps, averaged over its passes)
+        std::vector<long long> c(3 * 64 * 8); hipMemcpy(c.data(), h->xp_dbg, c.size() * 8, hipMemcpyDeviceToHost);
+        int khz = 100000; hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0);
+        for (int w = 0; w < 3; ++w) {
+            double ph[6] = {0, 0, 0, 0, 0, 0}; int np = 0;
+            for (int p = 1; p < 64; ++p) {                   // (pass 0 = launch -1: no scalars yet; skipped)
+                const long long* t = &c[((size_t)w * 64 + p) * 8];
+                if (!t[6] || !t[4]) break;
+                ph[0] += t[0] - t[6]; ph[1] += t[1] - t[0]; ph[2] += t[2] - t[1]; ph[3] += t[5] - t[2]; ph[4] += t[3] - t[5]; ph[5] += t[4] - t[3]; ++np;
+            }
+            const double u = 1e3 / khz / std::max(np, 1);
+            fprintf(stderr, "k_xcg_persist, workgroup %s, last launch, %d passes, us per pass: t + coarse y %.2f | columns %.2f | products + publish %.2f | "
+                    "first gather pass %.2f | rest of the gather %.2f | record sums + dots %.2f | sum %.2f\n", w == 0 ? "0" : (w == 1 ? "nwg/2" : "nwg-1"), np,
+                    ph[0] * u, ph[1] * u, ph[2] * u, ph[3] * u, ph[4] * u, ph[5] * u, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) * u);
+        }
+        hipFree(h->xp_dbg);
+    }
     if (h->chk_sums) {
         hipDeviceSynchronize();
         fprintf(stderr, "PS_XCG_INV_SUM %p:", (void*)h);

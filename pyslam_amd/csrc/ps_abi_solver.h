@@ -16,6 +16,7 @@ int ps_get_info(ps_problem* h, ps_problem_info* info) {
     info->cg_persist_refused = h->cp_refused; info->persist_cus = h->persist_cus;
     info->persist_cus_needed = h->cp_ok ? h->cp_cus_needed : (h->xp_ok ? h->xp_cus_needed : 0);
     info->landmark_passes_taken_over = h->prelm_used;
+    info->xcg_persist4_solves = h->xp4_launches;
     return 0;
 }
 
@@ -850,6 +851,7 @@ int ps_set_option(ps_problem* h, const char* name, double value) {
     else if (n == "lm_packed") h->lm_packed = value != 0;
     else if (n == "pose_async") h->pose_async = (int)value;
     else if (n == "pose_xcd") h->pose_xcd = value != 0;
+    else if (n == "xcg_persist4") h->xcg_persist4 = value != 0;
     else if (n == "cg_pipelined") { if (value != 0 && value != 1 && value != 2) return fail("cg_pipelined must be 0, 1 or 2"); h->cg_pipelined = (int)value; }
     else if (n == "fuse_cost") h->fuse_cost = (int)value;       // 0 off, 1 on, 2 = in the tails only (not the start cost / ps_eval_cost)
     else if (n == "sync_refactor") h->sync_refactor = value != 0;

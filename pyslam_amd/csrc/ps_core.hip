@@ -349,6 +349,9 @@ struct ps_problem {
     double *xf_tq[2] = {}, *xf_ts[2] = {}, *xf_t[2] = {};
     int xf_rmax = 1, xf_nwg = 0, xf_pf = 2;
     size_t xf_nrec = 0;
+    int xf_ymax = 0;
+    int xcg_persist4 = 0;           // option "xcg_persist4": the one-launch explicit PCG as four waves per workgroup where its conditions hold (ps_k_xcg_persist4.h; measured slower: off)
+    long xp4_launches = 0;
     long xf_solves = 0, xf_fallbacks = 0;
     int cg_lds = 1;                 // small systems: k_cg_fused_lds (whole vector through LDS)
     // the folded CG in ONE launch (ps_k_cg_persist.h): option "cg_persist"; task table built with the coarse level
@@ -399,6 +402,8 @@ struct ps_problem {
     long xp_launches = 0;
     bool xp_defer = false;          // xcg_setup left launch -1 to the one launch that runs them all
     long long* cp_dbg = nullptr;    // measurement build, PS_CP_CLOCKS: phase clocks of the kernel's first workgroup
+    long long* xp_dbg = nullptr;    // measurement build, PS_XP_CLOCKS: phase clocks of three workgroups of k_xcg_persist
+    long xp_dbg_launches = 0;
     int prof_every = 1;             // profiling level 1: time the Schur kernel of every n-th linearisation only
     long prof_tick = 0;
     int prev_pcg_iters = -1;        // iteration count of the solve before the last one (launch-count prediction)

@@ -553,6 +553,8 @@ int build_coarse(ps_problem* h) {
             HIP_OK(hipMemsetAsync(h->xf_tq[0], 0, nrec * sizeof(double), h->stream));
             HIP_OK(hipMemsetAsync(h->xf_tq[1], 0, nrec * sizeof(double), h->stream));
             h->xf_rmax = rmax; h->xf_nwg = nwg; h->xf_nrec = nrec;
+            h->xf_ymax = 0;                                 // most rows of y = A_c^-1 t any workgroup needs (k_xcg_persist4 keeps them in registers)
+            for (int g = 0; g < nwg; ++g) h->xf_ymax = std::max(h->xf_ymax, (nhi[g] - nlo[g] + 1) * D);
             h->xf_pf = maxlen <= 16 ? 2 : (maxlen <= 48 ? 6 : 8);
             h->xf_ok = true;
             // one launch per SOLVE (ps_k_xcg_persist.h): all workgroups at once (one per compute unit), the records of a node

@@ -257,27 +257,51 @@ void xcg_launch(ps_problem* h, double tol, int count) {
             h->xp_salt = 1;
         }
         const int nl = h->cg_max_launches + 1;               // passes: k = -1 .. max_iters - 1
+        if (ps_env("PS_XP_CLOCKS") && !h->xp_dbg) {                                                                     // (measurement build only)
+            hipMalloc(&h->xp_dbg, 3 * 64 * 8 * 8); hipMemset(h->xp_dbg, 0, 3 * 64 * 8 * 8);
+            fprintf(stderr, "k_xcg_persist: nr %d, nc %d, ncb %d, ell width %d, records %zu, workgroups %d, pf %d\n", nr, nc, h->ncb, h->ell_wf, (size_t)h->xf_nrec, h->xf_nwg, h->xf_pf);
+        }
         // (the matrix: PF blocks per lane in registers, PL in LDS behind t and the records; a row wider than 8 (PF + PL) blocks reads
         //  the rest from L2 in every iteration)
         const bool ne2 = nc <= 2 * 64 * PS_XF_ROWS;
-        const size_t ysum_doubles = (size_t)PS_XF_NODES * D * (((ne2 ? 2 : 4) * 64 * PS_XF_ROWS + 63) / 64);      // (phase 2's segment sums share the records' place)
-        const size_t lds0 = ((size_t)((nc + 1) & ~1) + ((std::max(h->xf_nrec, ysum_doubles) + 1) & ~(size_t)1)) * sizeof(double);
+        const size_t lds0 = ((size_t)((nc + 1) & ~1) + (((size_t)h->xf_nrec + 1) & ~(size_t)1)) * sizeof(double);
 #define PS_XP_LAUNCH(PF, PL, NE) do {                                                                                                         \
-            const size_t lds = lds0 + (size_t)(PL) * 64 * PS_XF_ROWS * (D * sizeof(double) + sizeof(int32_t));                                 \
+            const size_t lds = lds0 + (size_t)(PL) * 64 * PS_XF_ROWS * (D * sizeof(double) + sizeof(int32_t)) + ovf_bytes;                     \
             if (ensure_dynamic_lds((const void*)k_xcg_persist<D, PF, PL, NE>, lds)) { launched = false; break; }                              \
             int per_cu_ = 0;                                                                                                                   \
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, (const void*)k_xcg_persist<D, PF, PL, NE>, 64 * PS_XF_ROWS, lds) != hipSuccess || \
                 per_cu_ < 1 || cdiv(h->xf_nwg, per_cu_) > h->persist_capacity()) { launched = false; break; }                                 \
             hipLaunchKernelGGL((k_xcg_persist<D, PF, PL, NE>), dim3(h->xf_nwg), dim3(64 * PS_XF_ROWS), lds, h->stream, nr, h->arow_ptr,        \
                                h->ell_wf, h->Saug, a, h->xf_cnt, nl, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate,        \
-                               h->xp_exch, h->xp_salt, h->cp_spin); } while (0)
+                               h->xp_exch, h->xp_salt, h->cp_spin, h->xp_dbg); ++h->xp_dbg_launches; } while (0)
         // (LDS: the static arrays + t + the records + PL blocks per lane of the matrix: as many as fit 160 KB)
         const size_t per_pl = (size_t)64 * PS_XF_ROWS * (D * sizeof(double) + sizeof(int32_t));
         const size_t fixed = 11700 + 1024;                   // (the kernel's static arrays, -Rpass-analysis=kernel-resource-usage)
-        const size_t room = 160 * 1024 - fixed - std::min<size_t>(lds0, 120 * 1024);
+        const size_t ovf_bytes = (size_t)PS_XF_ROWS * 8 * (D * sizeof(double) + sizeof(int32_t));      // (the kk = 0 lanes' one block more)
+        const size_t room = 160 * 1024 - fixed - ovf_bytes - std::min<size_t>(lds0, 120 * 1024);
         const int pl = h->xf_pf == 8 ? (room >= 4 * per_pl ? 4 : (room >= 2 * per_pl ? 2 : 0)) : 0;
-        bool launched = true;
-        if (h->xf_pf == 2) { if (ne2) PS_XP_LAUNCH(2, 0, 2); else PS_XP_LAUNCH(2, 0, 4); }
+        bool launched = true, four_done = false;
+        // four waves per workgroup, the rows of A_c^-1 and seven blocks per lane and row in registers (ps_k_xcg_persist4.h): BA-like
+        // rows (pf 8) whose coarse level fits its register arrays
+        if constexpr (D == 6) {
+            constexpr int X4_NYW = 11, X4_NQ = 5, PF4 = 6, PL4 = 4;
+            const size_t lds4 = lds0 + (size_t)PL4 * PS_X4_RPW * PS_X4_NT * (D * sizeof(double) + sizeof(int32_t));
+            if (h->xcg_persist4 && h->xf_pf == 8 && (nc & 1) == 0 && nc <= 128 * X4_NQ && nc <= 3 * PS_X4_NT && h->xf_ymax <= PS_X4_NW * X4_NYW &&
+                h->xf_nrec <= (size_t)PS_X4_NR * PS_X4_NT && lds4 + fixed <= 160 * 1024) {
+                auto k4 = k_xcg_persist4<6, PF4, PL4, 3, X4_NYW, X4_NQ>;
+                int per_cu_ = 0;
+                if (!ensure_dynamic_lds((const void*)k4, lds4) &&
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, (const void*)k4, PS_X4_NT, lds4) == hipSuccess && per_cu_ >= 1 &&
+                    cdiv(h->xf_nwg, per_cu_) <= h->persist_capacity()) {
+                    hipLaunchKernelGGL(k4, dim3(h->xf_nwg), dim3(PS_X4_NT), lds4, h->stream, nr, h->arow_ptr, h->ell_wf, h->Saug, a, h->xf_cnt,
+                                       nl, tol * tol, h->hist, h->hist_cap, h->status, h->scalars, h->xstate, h->xp_exch, h->xp_salt, h->cp_spin, h->xp_dbg);
+                    ++h->xp_dbg_launches; ++h->xp4_launches;
+                    four_done = true;
+                } else (void)hipGetLastError();
+            }
+        }
+        if (four_done) { }
+        else if (h->xf_pf == 2) { if (ne2) PS_XP_LAUNCH(2, 0, 2); else PS_XP_LAUNCH(2, 0, 4); }
         else if (pl == 4) { if (ne2) PS_XP_LAUNCH(6, 4, 2); else PS_XP_LAUNCH(6, 4, 4); }
         else if (pl == 2) { if (ne2) PS_XP_LAUNCH(6, 2, 2); else PS_XP_LAUNCH(6, 2, 4); }
         else { if (ne2) PS_XP_LAUNCH(6, 0, 2); else PS_XP_LAUNCH(6, 0, 4); }

@@ -49,10 +49,17 @@ struct CpRecover { int nr, ncb; const int32_t* pnode; const double *pw0, *pw1, *
 typedef unsigned long long ps_u64;
 typedef __attribute__((address_space(1))) ps_u64 ps_gu64;
 
+// Round 6: both granules of a double PUBLISHED by one 16-byte store -- `global_store_dwordx4 ... sc1`, the same bits and cache policy
+// as the two relaxed agent-scope 8-byte stores (`global_store_dwordx2 ... sc1`) it replaces, half the write requests.  A granule still
+// carries its own tag and lands by an aligned 8-byte half of the access, so a reader that sees one new half and one old one retries
+// as before.  (k_xcg_persist at C4: first pass over the exchange 4.7 -> 4.0 us; k_cg_persist at C3: gather 50.4 -> 48.7 us per
+// launch.  Readers keep two 8-byte loads per double: 16-byte loads through inline assembly need 128-bit landing tuples --
+// k_xcg_persist: scratch 32 -> 190-260 B per lane -- and where there is room for them, k_cg_persist at C3, they measured nothing.)
+typedef unsigned ps_u32x4 __attribute__((ext_vector_type(4)));
 PS_DEV void cp_put(ps_u64* g, unsigned tag, double v) {
     const ps_u64 b = (ps_u64)__double_as_longlong(v);
-    __hip_atomic_store((ps_gu64*)g, ((ps_u64)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store((ps_gu64*)(g + 1), ((ps_u64)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const ps_u32x4 q = {(unsigned)(b & 0xffffffffull), tag, (unsigned)(b >> 32), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(g), "v"(q) : "memory");
 }
 
 template <int D, int NE, bool PIPE = false>

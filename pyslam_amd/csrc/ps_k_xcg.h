@@ -559,6 +559,49 @@ __global__ void k_lag_status_check(const int32_t* __restrict__ lag_status, int32
 #define PS_XF_NEMAX 4                         // coarse entries per thread: nc <= 4 * 512
 #define PS_XF_RB 4                            // records of a node requested together
 
+// y = A_c^-1 t for `nrows_y` consecutive rows of the fp32 inverse (phase 2 of k_xcg_fused1 / k_xcg_persist), t in LDS.
+// Round 6: a WAVE per row, the lanes along the row -- lane l takes the columns 2 l + 128 q: every load instruction of the wave reads
+// 512 contiguous bytes; no segment sums in LDS, one barrier less.  (Rounds 4-5 gave a THREAD 64 consecutive entries of a row.)  The
+// phase is a chain of L2 round trips either way -- C4: 42 rows of 600 entries per interior workgroup, 5.2 us of k_xcg_persist's
+// 17.6 us per iteration in both forms; three rows of a wave requested together cost 200 B per lane of scratch in kernels that have
+// no register to spare -- which is why k_xcg_persist4 keeps its rows of the inverse in registers (ps_k_xcg_persist4.h).
+// A lane sums its columns in ascending order, the lanes by the wave's fixed tree: the same sums in all three kernels, run to run.
+template <int RB = 1 /* rows of a wave requested together: the phase is a chain of L2 round trips, RB of them in flight */>
+PS_DEV void xcg_coarse_rows(const float* __restrict__ Ainv, int nc, int row_first, int nrows_y, const double* __restrict__ tl /* LDS */,
+                            double* __restrict__ yl /* LDS */, int wv, int lane, int nwaves)
+{
+    if ((nc & 1) == 0) {                                     // (rows of an even nc start 8-byte aligned)
+        for (int rr0 = wv; rr0 < nrows_y; rr0 += nwaves * RB) {
+            const float* ar[RB];
+            double v[RB];
+#pragma unroll
+            for (int b = 0; b < RB; ++b) { ar[b] = Ainv + (size_t)(row_first + min(rr0 + b * nwaves, nrows_y - 1)) * nc; v[b] = 0.0; }
+#pragma unroll (RB >= 4 ? 1 : 2)
+            for (int j = 2 * lane; j < nc; j += 128) {
+                float2 f[RB];
+#pragma unroll
+                for (int b = 0; b < RB; ++b) f[b] = *reinterpret_cast<const float2*>(ar[b] + j);
+                const double t0 = tl[j], t1 = tl[j + 1];
+#pragma unroll
+                for (int b = 0; b < RB; ++b) v[b] += (double)f[b].x * t0 + (double)f[b].y * t1;
+            }
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const double y = wave_sum(v[b]);
+                if (lane == 0 && rr0 + b * nwaves < nrows_y) yl[rr0 + b * nwaves] = y;
+            }
+        }
+        return;
+    }
+    for (int rr = wv; rr < nrows_y; rr += nwaves) {
+        const float* ar = Ainv + (size_t)(row_first + rr) * nc;
+        double v = 0.0;
+        for (int j = lane; j < nc; j += 64) v += (double)ar[j] * tl[j];
+        v = wave_sum(v);
+        if (lane == 0) yl[rr] = v;
+    }
+}
+
 struct XcgFusedArgs {
     const int32_t* cptr; const int32_t* cols;   // per workgroup: its distinct columns (ascending)
     const uint16_t* lidx;                       // per matrix block: slot of its column in the workgroup's list
@@ -587,7 +630,6 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
     __shared__ double su[PS_XF_CAP * D];                          // u_{k+1} of the workgroup's columns
     __shared__ double sr[PS_XF_ROWS * D], suo[PS_XF_ROWS * D];    // r_{k+1}, u_{k+1} of its own rows
     __shared__ double yl[PS_XF_NODES * D];
-    __shared__ double ysum[PS_XF_NODES * D * ((PS_XF_NEMAX * 64 * PS_XF_ROWS + 63) / 64)];   // segment sums of phase 2
     __shared__ double lds[32];
     __shared__ double wred[PS_XF_ROWS][2];
     __shared__ double cw[PS_XF_ROWS][PS_XCG_NSLOT][D];
@@ -713,40 +755,8 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_fused1(
         }
     }
     __syncthreads();
-    // ---- 2. y = A_c^-1 t_{k+1} for the nodes n_lo .. n_hi: the rows are cut into segments of 64 entries, one per thread (all
-    // of a thread's loads independent: ONE round trip for the phase), segment sums added up in LDS in a fixed order
-    {
-        const int nseg = (nc + 63) >> 6, nitems = nrows_y * nseg;
-        for (int it0 = 0; it0 < nitems; it0 += NT) {
-            const int it = it0 + tid;
-            double v = 0.0;
-            if (it < nitems) {
-                const int rr = it / nseg, sg = it - rr * nseg, j0 = sg << 6, j1 = min(nc, j0 + 64);
-                const float* ar = a.Ainv + (size_t)(n_lo * D + rr) * nc;
-                if ((nc & 1) == 0 && j1 - j0 == 64) {            // (rows of an even nc start 8-byte aligned)
-#pragma unroll 8
-                    for (int q = 0; q < 32; ++q) {
-                        const float2 f = *reinterpret_cast<const float2*>(ar + j0 + 2 * q);
-                        v += (double)f.x * tl[j0 + 2 * q] + (double)f.y * tl[j0 + 2 * q + 1];
-                    }
-                } else if ((nc & 1) == 0) {
-                    for (int j = j0; j < j1; j += 2) {
-                        const float2 f = *reinterpret_cast<const float2*>(ar + j);
-                        v += (double)f.x * tl[j] + (double)f.y * tl[j + 1];
-                    }
-                } else {
-                    for (int j = j0; j < j1; ++j) v += (double)ar[j] * tl[j];
-                }
-            }
-            if (it < nitems) ysum[it] = v;
-        }
-        __syncthreads();
-        if (tid < nrows_y) {
-            double v = 0.0;
-            for (int sg = 0; sg < nseg; ++sg) v += ysum[tid * nseg + sg];
-            yl[tid] = v;
-        }
-    }
+    // ---- 2. y = A_c^-1 t_{k+1} for the nodes n_lo .. n_hi (a wave per row: xcg_coarse_rows)
+    xcg_coarse_rows(a.Ainv, nc, n_lo * D, nrows_y, tl, yl, wv, lane, PS_XF_ROWS);
     }
     __syncthreads();
     // ---- 3. the workgroup's columns: s, r, u (+ the owner's stores and p, x)

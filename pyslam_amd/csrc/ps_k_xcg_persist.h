@@ -35,7 +35,8 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
     int nr, const int32_t* __restrict__ row_ptr, int wf, const double* __restrict__ S, XcgFusedArgs a,
     const int32_t* __restrict__ rec_cnt /* live records per coarse node */, int nlaunch, double tol2,
     double* __restrict__ hist, int cap, int32_t* __restrict__ status, double* __restrict__ scalars, double* __restrict__ xstate,
-    ps_u64* __restrict__ exch /* 2 x E doubles as two granules each; E = nr D + 2 nwg + ncb rmax D */, unsigned salt, unsigned spin_limit)
+    ps_u64* __restrict__ exch /* 2 x E doubles as two granules each; E = nr D + 2 nwg + ncb rmax D */, unsigned salt, unsigned spin_limit,
+    long long* __restrict__ dbg /* measurement build (PS_XP_CLOCKS): time stamps of workgroups 0, nwg / 2, nwg - 1 ([3][64 passes][8 phases]), else NULL */)
 {
     constexpr int NT = 64 * PS_XF_ROWS, DD = D * D;
     constexpr int NCOL = (PS_XF_CAP * D + NT - 1) / NT;
@@ -53,11 +54,12 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
     const bool chief = wg == 0 && tid == 0;
     const int nrec = a.ncb * a.rmax * D;
     double* trec = tl + ((nc + 1) & ~1);
-    // (the segment sums of phase 2 live where the records of phase 5 do: never at the same time, and 12 KB more for the matrix)
-    double* ysum = trec;
-    constexpr int YS = PS_XF_NODES * D * ((NE * 64 * PS_XF_ROWS + 63) / 64);
-    double* sml = trec + ((max(nrec, YS) + 1) & ~1);         // PL blocks per lane of the matrix: [(i D + c) NT + tid]
+    double* sml = trec + ((nrec + 1) & ~1);                  // PL blocks per lane of the matrix: [(i D + c) NT + tid]
     int32_t* sll = reinterpret_cast<int32_t*>(sml + (size_t)PL * D * NT);     // their LDS slots: [i NT + tid]
+    // one block more for the eight lanes kk = 0 of a row (a row of 8 (PF + PL) + 1 blocks -- C4: 81 -- used to fetch it from L2 in
+    // every iteration: a round trip in the middle of the products): [(wave 8 + r) D + c], its slot (-1: none) behind
+    double* ovf = reinterpret_cast<double*>(sll + (size_t)PL * NT);
+    int32_t* ovs = reinterpret_cast<int32_t*>(ovf + (size_t)PS_XF_ROWS * 8 * D);
     if (tid == 0) bad = 0;
     if (status[ST_PCG_DONE]) return;
     // ---- once: the workgroup's state
@@ -131,6 +133,22 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
 #pragma unroll
         for (int c = 0; c < D; ++c) sml[(size_t)(i * D + c) * NT + tid] = v6[c];
     }
+    if (kk == 0) {
+        const int b = rbeg + 8 * (PF + PL);
+        int slot = -1;
+        double v6[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) v6[c] = 0.0;
+        if (r < D && b < rend) {
+            slot = (int)a.lidx[b] * D;
+            const double* sp = S + (size_t)b * DD + r * D;
+#pragma unroll
+            for (int c = 0; c < D; ++c) v6[c] = sp[c];
+        }
+        ovs[wv * 8 + r] = slot;
+#pragma unroll
+        for (int c = 0; c < D; ++c) ovf[(size_t)(wv * 8 + r) * D + c] = v6[c];
+    }
     // (constants of phase 4)
     double bl = 0.0, rw0 = 0.0, rw1 = 0.0;
     int prow = 0, pfirst = 0, rout = -1;
@@ -141,8 +159,18 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
         prow = a.pnode[urow]; pfirst = a.pnode[row0]; rw0 = a.pw0[urow]; rw1 = a.pw1[urow];
     }
     double gamma = 0.0, delta = 0.0, g_prev = 0.0, a_prev = 0.0, thresh = 0.0;
+#ifdef PS_MEASURE
+    // phase clocks (PS_XP_CLOCKS): time stamps straight to memory, [workgroup slot][pass][phase] -- no loop-carried registers in a
+    // kernel that has none to spare
+    const int dslot = wg == 0 ? 0 : (wg == nwg / 2 ? 1 : (wg == nwg - 1 ? 2 : -1));
+    int dpass = 0;
+#define PS_XP_CLK(i) do { if (dbg && dslot >= 0 && tid == 0 && dpass < 64) dbg[((size_t)dslot * 64 + dpass) * 8 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define PS_XP_CLK(i) do { } while (0)
+#endif
     for (int k = -1; k < nlaunch - 1; ++k) {
         double alpha = 0.0, beta = 0.0;
+        PS_XP_CLK(6);                                        // (pass start)
         if (k >= 0) {
             if (k == 0) thresh = tol2 * gamma;
             if (!(gamma > thresh)) {
@@ -170,42 +198,19 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
             }
         }
         __syncthreads();
-        // ---- 2. y = A_c^-1 t_{k+1} for the nodes n_lo .. n_hi (as k_xcg_fused1)
+        // ---- 2. y = A_c^-1 t_{k+1} for the nodes n_lo .. n_hi (as k_xcg_fused1: a wave per row)
         {
-            const int nseg = (nc + 63) >> 6, nitems = nrows_y * nseg;
-            for (int it0 = 0; it0 < nitems; it0 += NT) {
-                const int it = it0 + tid;
-                double v = 0.0;
-                if (it < nitems) {
-                    const int rr = it / nseg, sg = it - rr * nseg, j0 = sg << 6, j1 = min(nc, j0 + 64);
-                    const float* ar = a.Ainv + (size_t)(n_lo * D + rr) * nc;
-                    if (j1 - j0 == 64) {
-#pragma unroll 8
-                        for (int q = 0; q < 32; ++q) {
-                            const float2 f = *reinterpret_cast<const float2*>(ar + j0 + 2 * q);
-                            v += (double)f.x * tl[j0 + 2 * q] + (double)f.y * tl[j0 + 2 * q + 1];
-                        }
-                    } else {
-                        for (int j = j0; j < j1; j += 2) {
-                            const float2 f = *reinterpret_cast<const float2*>(ar + j);
-                            v += (double)f.x * tl[j] + (double)f.y * tl[j + 1];
-                        }
-                    }
-                    ysum[it] = v;
-                }
-            }
-            __syncthreads();
-            if (tid < nrows_y) {
-                double v = 0.0;
-                for (int sg = 0; sg < nseg; ++sg) v += ysum[tid * nseg + sg];
-                yl[tid] = v;
-            }
+            int first = n_lo * D;
+            asm volatile("" : "+s"(first));                  // (the rows' addresses formed in the loop, not carried through it)
+            xcg_coarse_rows<2>(a.Ainv, nc, first, nrows_y, tl, yl, wv, lane, PS_XF_ROWS);
         }
         __syncthreads();
+        PS_XP_CLK(0);
         // ---- 3. the workgroup's columns: s, r, u; the owner's p, x
 #pragma unroll
         for (int q = 0; q < NCOL; ++q) {
-            const int j = jj[q];
+            int j = jj[q];
+            asm volatile("" : "+v"(j));                      // (keeps the loads of the column's constants IN the loop: hoisted, 17 registers per item)
             if (j >= 0) {
                 const int e = tid + q * NT, c = e / D, m = e - c * D;
                 const double sn = wj[q] + beta * sj[q];
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
             po = pn; xo += alpha * pn;
         }
         __syncthreads();
+        PS_XP_CLK(1);
         if (own_item) uo = suo[tid];                         // u_{k+1} of the own rows, for the next iteration's p
         // ---- 4. w_{k+1} = S^ u_{k+1} for the own rows, partials, records of P^T w: published
         const unsigned tag = salt * 4096u + (unsigned)(k + 2);
@@ -251,7 +257,15 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
 #pragma unroll
                     for (int c = 0; c < D; ++c) acc += sml[(size_t)(i * D + c) * NT + tid] * uc[c];
                 }
-                for (int b = rbeg + kk + 8 * (PF + PL); b < rend; b += 8) {
+                if (kk == 0) {
+                    const int os = ovs[wv * 8 + r];
+                    if (os >= 0) {
+                        const double* uc = su + os;
+#pragma unroll
+                        for (int c = 0; c < D; ++c) acc += ovf[(size_t)(wv * 8 + r) * D + c] * uc[c];
+                    }
+                }
+                for (int b = rbeg + kk + 8 * (PF + PL) + (kk == 0 ? 8 : 0); b < rend; b += 8) {
                     const double* uc = su + (int)a.lidx[b] * D;
                     const double* sp = S + (size_t)b * DD + r * D;
 #pragma unroll
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
             for (int ww = 0; ww < PS_XF_ROWS; ++ww) v += (&cw[ww][0][0])[tid];
             cp_put(buf + 2 * (offT + (size_t)rout * D + tid % D), tag, v);
         }
+        PS_XP_CLK(2);
         // ---- 5. gather what the next iteration needs: w of the columns, every workgroup's partials, every live record
         double gs = 0.0, ds = 0.0;
         {
@@ -301,18 +316,22 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
             bool ok = false;
             for (unsigned spins = 0; !ok; ++spins) {
                 ok = true;
+                int tg = tid;
+                asm volatile("" : "+v"(tg));                 // (the addresses of the pass formed here, not carried through the solve: two registers each)
 #pragma unroll
                 for (int q = 0; q < NCOL; ++q) {
                     if (jj[q] >= 0) {
-                        const int e = tid + q * NT, c = e / D, m = e - c * D;
+                        const int e = tg + q * NT, c = e / D, m = e - c * D;
                         (void)c;
-                        ok = xp_get(buf + 2 * ((size_t)jj[q] * D + m), tag, wj[q]) && ok;
+                        int jq = jj[q];
+                        asm volatile("" : "+v"(jq));
+                        ok = xp_get(buf + 2 * ((size_t)jq * D + m), tag, wj[q]) && ok;
                     }
                 }
                 gs = 0.0; ds = 0.0;
                 if (tid < nwg) {                             // (nwg <= 256 < NT: one partial pair per thread)
-                    ok = xp_get(buf + 2 * (offG + tid), tag, gs) && ok;
-                    ok = xp_get(buf + 2 * (offG + nwg + tid), tag, ds) && ok;
+                    ok = xp_get(buf + 2 * (offG + tg), tag, gs) && ok;
+                    ok = xp_get(buf + 2 * (offG + nwg + tg), tag, ds) && ok;
                 }
                 // the live records, flat, four slots at a time (eight at once cost 30 more registers than the matrix can spare)
 #pragma unroll
@@ -321,11 +340,14 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
 #pragma unroll
                     for (int u = u0; u < u0 + 4; ++u) {
                         rv[u] = 0.0;
-                        if (live & (1u << u)) ok = xp_get(buf + 2 * (offT + (size_t)(tid + u * NT)), tag, rv[u]) && ok;
+                        if (live & (1u << u)) ok = xp_get(buf + 2 * (offT + (size_t)(tg + u * NT)), tag, rv[u]) && ok;
                     }
                     if ((live >> (u0 + 4)) == 0) break;
                 }
                 ok = __all(ok);
+#ifdef PS_MEASURE
+                if (spins == 0) PS_XP_CLK(5);
+#endif
                 if (!ok) {
                     // (bounded by TIME as well: with 250 workgroups polling, a pass that fails can take far longer than one that succeeds)
                     if (spins > spin_limit || (long long)wall_clock64() - t_enter > PS_PERSIST_TIMEOUT_TICKS) { bad = 1; break; }
@@ -336,6 +358,7 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
             for (int u = 0; u < PS_XP_NR; ++u) { const int f = tid + u * NT; if (f < nrec) trec[f] = rv[u]; }
         }
         __syncthreads();
+        PS_XP_CLK(3);
         // the records of every coarse entry summed in record order (as k_xcg_fused1 sums them)
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
@@ -348,12 +371,17 @@ __global__ __launch_bounds__(64 * PS_XF_ROWS) void k_xcg_persist(
             }
         }
         block_sum2(gs, ds, lds);
+        PS_XP_CLK(4);
+#ifdef PS_MEASURE
+        ++dpass;
+#endif
         if (bad) {
             if (tid == 0) { status[ST_PCG_DONE] = 2; status[ST_PERSIST_FAIL] = 1; }
             break;
         }
         gamma = gs; delta = ds;
     }
+#undef PS_XP_CLK
     // ---- what the caller reads: x^ (and p) of the own rows
     if (own_item) { const size_t o = (size_t)row0 * D + tid; a.p[o] = po; a.x[o] = xo; }
 }

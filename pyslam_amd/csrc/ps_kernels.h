@@ -103,6 +103,7 @@ PS_DEV void block_sum2(double& a, double& b, double* lds /* >= 32 doubles */) {
 #include "ps_k_cg_persist.h"
 #include "ps_k_xcg.h"
 #include "ps_k_xcg_persist.h"
+#include "ps_k_xcg_persist4.h"
 #include "ps_k_coarse.h"
 #include "ps_k_band.h"
 #include "ps_k_bandpart.h"

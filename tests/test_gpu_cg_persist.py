@@ -156,6 +156,28 @@ def test_one_launch_explicit_pcg_equals_the_launch_per_iteration_form(name, make
         assert np.abs(a[1][0] - other[1][0]).max() <= 1e-9 and np.abs(a[1][1] - other[1][1]).max() <= 1e-8
 
 
+def test_four_wave_form_of_the_one_launch_explicit_pcg_gives_the_same_bits():
+    """Round 6, option xcg_persist4 (off by default: measured slower, HISTORY round 6): k_xcg_persist as four waves per workgroup --
+    one wave per SIMD, 512 registers per lane, the workgroup's rows of the fp32 coarse inverse resident in registers
+    (csrc/ps_k_xcg_persist4.h).  Same recurrences, same order of every sum: costs, iteration counts and parameters are those of
+    the eight-wave kernel bit for bit."""
+    from pyslam_amd.device import DeviceProblem
+    lp = synthetic.stereo_ba(num_kf=1000, num_lm=30000, obs_per_lm=10, half_window=20, seed=3)[0]
+    out = {}
+    for four in (1, 0):
+        dev = DeviceProblem(lp)
+        dev.set_option('xcg_persist4', four)
+        trace = [dev.gn_iteration(0.0, 1e-12, 2000, True) for _ in range(3)]
+        out[four] = (trace, dev.get_params(), dev.get_info())
+        dev.close()
+    a, b = out[1], out[0]
+    assert a[2]['xcg_persist4_solves'] == 3 and a[2]['cg_persist_failures'] == 0
+    assert b[2]['xcg_persist4_solves'] == 0 and b[2]['cg_persist_solves'] == 3
+    for ta, tb in zip(a[0], b[0]):
+        assert ta[0] == tb[0] and ta[2] == tb[2]
+    assert np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+
+
 def test_pipelined_recurrences_give_the_same_solve_on_a_well_conditioned_system():
     """Round 6, option cg_pipelined (off by default: DESIGN.md section 5): the one-launch CG with the pipelined recurrences -- products of
     w_k published first, the dot products formed while the exchange is in flight -- is the same Krylov iteration: on a bundle

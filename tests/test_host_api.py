@@ -267,7 +267,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert ctypes.sizeof(_native.ProblemDesc) == 272 and ctypes.sizeof(_native.ProblemInfo) == 176  # gcc sizeof
+    assert ctypes.sizeof(_native.ProblemDesc) == 272 and ctypes.sizeof(_native.ProblemInfo) == 184  # gcc sizeof
 
 
 def test_the_list_of_measurement_switches_is_the_sources_list():
