@@ -59,7 +59,9 @@ typedef unsigned ps_u32x4 __attribute__((ext_vector_type(4)));
 PS_DEV void cp_put(ps_u64* g, unsigned tag, double v) {
     const ps_u64 b = (ps_u64)__double_as_longlong(v);
     const ps_u32x4 q = {(unsigned)(b & 0xffffffffull), tag, (unsigned)(b >> 32), tag};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(g), "v"(q) : "memory");
+    // (`s_nop 1`: on gfx940+ a VALU write to the data registers of a store wider than 64 bits needs two wait states behind it; the
+    //  compiler inserts them for its own stores and cannot see into this one -- the next cp_put reuses these very registers)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(g), "v"(q) : "memory");
 }
 
 template <int D, int NE, bool PIPE = false>
